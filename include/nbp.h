@@ -1,0 +1,188 @@
+/*
+ * nbp.h -- C ABI of libnbp: the MI355X-native replacement for the per-clique
+ * nonparametric Chapman-Kolmogorov hot path of IncrementalInference.jl (IIF).
+ *
+ * The reference has NO FFI for this path: it is extended by Julia multiple
+ * dispatch.  This header therefore *defines* the boundary a Julia `ccall` shim binds to
+ * (INTEGRATION.md shows the shim).  Every entry point cites the reference function it replaces
+ * (paths relative to the IncrementalInference.jl source tree, v0.35.6).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / C++ types.
+ *  - all floating point is IEEE double (reference: Float64 everywhere).
+ *  - the caller owns every host buffer; the library never keeps a host pointer past return.
+ *  - return value: 0 = NBP_OK, <0 = hard error (the Julia shim turns it into `error()` so the
+ *    clique Task fails and `monitorCSMs` propagates ERROR_STATUS, CliqStateMachineUtils.jl:184-246).
+ *  - soft conditions are counted, not raised: non-converged per-particle solves are used anyway
+ *    (NumericalCalculations.jl:128-131), NaN solves leave the particle unchanged (:348-351).
+ *
+ * Host point layout ("P doubles per point", packed AoS, exactly what Julia holds):
+ *    NBP_EUCLID1/2/3 : P = D, SVector{D,Float64}                (Variables/DefaultVariables.jl:9-19)
+ *    NBP_CIRCULAR    : P = 1, angle in [-pi,pi) (shim packs Vector{Vector{Float64}}, :52)
+ *    NBP_SE2         : P = 6, ArrayPartition(t[2], R[2x2] column-major) = x,y,R11,R21,R12,R22
+ *                      (test/testSpecialEuclidean2Mani.jl:14)
+ * Device layout ("slot"): tangent coordinates at the identity, SoA: coord d of particle n at
+ *    slot_base + d*N + n, d < D (SE2 is stored as x,y,theta), then bw[3], see DESIGN.md.
+ */
+#ifndef NBP_H
+#define NBP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBP_MAXV 6   /* variables attached to one factor (multihypo door sighting uses 5) */
+#define NBP_MAXF 8   /* densities multiplied in one manifoldProduct                        */
+#define NBP_MAXD 3   /* tangent dimension                                                   */
+#define NBP_MAXC 4   /* Mixture components                                                  */
+#define NBP_MAXN 512 /* particles per belief                                                */
+#define NBP_COMP_STRIDE 13 /* per component: weight, mean[3], sqrt-cov L[3][3] row-major    */
+
+typedef int32_t nbp_status;
+#define NBP_OK 0
+#define NBP_ERR_ARG (-1)
+#define NBP_ERR_HIP (-2)
+#define NBP_ERR_NOGPU (-3)
+#define NBP_ERR_RANGE (-4)
+
+/* getManifold(variableType): Position{N} -> TranslationGroup(N), Circular -> RealCircleGroup,
+ * SE(2) -> SpecialEuclidean(2; vectors=HybridTangentRepresentation()) */
+enum nbp_manifold {
+  NBP_EUCLID1 = 1,
+  NBP_EUCLID2 = 2,
+  NBP_EUCLID3 = 3,
+  NBP_CIRCULAR = 4,
+  NBP_SE2 = 5
+};
+
+/* the closed set of residual functors */
+enum nbp_factor {
+  NBP_F_PRIOR = 1,      /* Prior / PriorCircular / ManifoldPrior: point = wrap(mean + L n)
+                           Factors/DefaultPrior.jl:17, Circular.jl:56-60, GenericFunctions.jl:181-214 */
+  NBP_F_MSGPRIOR = 2,   /* MsgPrior{ManifoldKernelDensity}: draw from the KDE held in var_slot[1]
+                           Factors/MsgPrior.jl:27-30, services/TreeMessageUtils.jl:86-89 */
+  NBP_F_LINREL = 3,     /* LinearRelative{D}: r = z - (x2 - x1)       Factors/LinearRelative.jl:42-49 */
+  NBP_F_CIRCULAR = 4,   /* CircularCircular                            Factors/Circular.jl:24-28       */
+  NBP_F_SE2 = 5,        /* ManifoldFactor(SpecialEuclidean(2))         Factors/GenericFunctions.jl:39-44,98-100 */
+  NBP_F_EUCLIDDIST = 6  /* EuclidDistance: r = z - ||x2 - x1||         Factors/EuclidDistance.jl:20    */
+};
+
+/*
+ * One proposal = one `approxConvBelief(dfg, fct, target)` (services/ApproxConv.jl:4-45):
+ * evalFactor -> evalPotentialSpecific (services/EvalFactor.jl:321-395 relative, :400-542 prior)
+ * followed by manikde! (bandwidth fit).  Carries exactly the knobs the reference reads from
+ * SolverParams / the factor (entities/SolverParams.jl:12-75, services/FactorGraph.jl:824-839).
+ */
+typedef struct nbp_proposal_desc {
+  int32_t factor_kind;        /* enum nbp_factor                                              */
+  int32_t manifold;           /* enum nbp_manifold of the solve-for variable                  */
+  int32_t nvars;              /* variables attached to the factor (1 for priors)              */
+  int32_t sfidx;              /* 0-based index of the solve-for variable in var_slot          */
+  int32_t var_slot[NBP_MAXV]; /* belief slot of every attached variable (getVariableOrder);
+                                 NBP_F_MSGPRIOR: var_slot[1] = slot holding the message KDE   */
+  int32_t out_slot;           /* scratch slot that receives the proposal (never the belief itself:
+                                 services/CalcFactor.jl:543-548)                              */
+  int32_t ncomp;              /* 1, or the number of Mixture components (Factors/Mixture.jl)  */
+  int32_t has_multihypo;      /* 0: hypotheses === nothing                                    */
+  int32_t inflate_cycles;     /* SolverParams.inflateCycles (default 3)                       */
+  int32_t mhidx_in;           /* >=0: offset into the ctx int32 side buffer holding an injected
+                                 mhidx[N] (exact-match tests); -1: sample internally           */
+  int32_t mhidx_out;          /* >=0: offset in the side buffer where the used mhidx[N] is stored */
+  int32_t skip_bandwidth;     /* 1: do not fit the bandwidth (caller discards it)              */
+  double multihypo[NBP_MAXV]; /* parsed Categorical p: certain variables carry 0.0
+                                 (services/FactorGraph.jl:639-651)                            */
+  double nullhypo;            /* max(ccw.nullhypo, nullSurplus)   EvalFactor.jl:352            */
+  double inflation;           /* ccw.inflation (default SolverParams.inflation = 5.0)          */
+  double spread_nh;           /* SolverParams.spreadNH (3.0)                                   */
+  double comp[NBP_MAXC][NBP_COMP_STRIDE]; /* measurement model, see NBP_COMP_STRIDE            */
+  uint64_t seed;              /* Philox key of this op (counter-based RNG)          */
+} nbp_proposal_desc;
+
+/*
+ * One product = the `AMP.manifoldProduct(dens, M; Niter=1, N)` call of propagateBelief
+ * (services/GraphProductOperations.jl:53-60) plus the bandwidth fit of the result and the
+ * `setBelief!` write-back (services/SolveTree.jl:74, services/FactorGraph.jl:250-263).
+ */
+typedef struct nbp_product_desc {
+  int32_t manifold;
+  int32_t nfactors;            /* 1 = pass-through (AMP returns the single density)            */
+  int32_t niter;               /* Gibbs sweeps per tree level (reference passes Niter=1)       */
+  int32_t out_slot;            /* belief slot that receives points + bandwidth                 */
+  int32_t in_slot[NBP_MAXF];   /* proposal slots                                               */
+  int32_t labels_out;          /* >=0: offset in the int32 side buffer for labels[N][nfactors] */
+  int32_t pad_;
+  uint64_t seed;
+} nbp_product_desc;
+
+/* belief copy: tree message traffic (TreeBelief val+bw, entities/BeliefTypes.jl:47-57) */
+typedef struct nbp_copy_desc {
+  int32_t src_slot;
+  int32_t dst_slot;
+} nbp_copy_desc;
+
+typedef struct nbp_diag {
+  int64_t solves;        /* per-particle optimiser runs                        */
+  int64_t nonconverged;  /* NumericalCalculations.jl:128-131                   */
+  int64_t nan_results;   /* NumericalCalculations.jl:348-351                   */
+  int64_t residual_evals;
+} nbp_diag;
+
+typedef struct nbp_ctx nbp_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* `arena` may be NULL (library allocates with hipMalloc) or a device pointer owned by the caller
+ * (e.g. a torch tensor, so torch.distributed/RCCL can exchange slots); arena_bytes must be at
+ * least nbp_arena_bytes(N, n_slots).  `side_ints` = size of the int32 side buffer (mhidx, labels). */
+int64_t nbp_arena_bytes(int32_t N, int32_t n_slots);
+int64_t nbp_slot_stride_doubles(int32_t N);
+nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *arena,
+                          int64_t arena_bytes, int32_t side_ints, nbp_ctx **out);
+nbp_status nbp_ctx_destroy(nbp_ctx *ctx);
+const char *nbp_last_error(void);
+nbp_status nbp_synchronize(nbp_ctx *ctx);
+void *nbp_arena_ptr(nbp_ctx *ctx);
+void *nbp_stream_ptr(nbp_ctx *ctx); /* hipStream_t the library launches on */
+
+/* ---- belief I/O: setValKDE!/getVal at the boundary (FactorGraph.jl:250-297) --------------- */
+nbp_status nbp_slot_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP,
+                          const double *bw_D /* nullable */);
+nbp_status nbp_slot_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP,
+                         double *bw_D /* nullable */);
+nbp_status nbp_side_write(nbp_ctx *ctx, int32_t offset, const int32_t *src, int32_t n);
+nbp_status nbp_side_read(nbp_ctx *ctx, int32_t offset, int32_t *dst, int32_t n);
+
+/* ---- factor seam: approxConvOnElements!/evalFactor + manikde! (EvalFactor.jl:14-27,571-603) */
+nbp_status nbp_run_proposals(nbp_ctx *ctx, const nbp_proposal_desc *descs, int32_t n);
+/* ---- AMP.manikde!(M, pts) bandwidth selection for slots already resident ------------------ */
+nbp_status nbp_run_bandwidth(nbp_ctx *ctx, const int32_t *slots, const int32_t *manifolds, int32_t n);
+/* ---- variable seam: AMP.manifoldProduct + rebandwidth (GraphProductOperations.jl:53-60) --- */
+nbp_status nbp_run_products(nbp_ctx *ctx, const nbp_product_desc *descs, int32_t n);
+nbp_status nbp_run_copies(nbp_ctx *ctx, const nbp_copy_desc *descs, int32_t n);
+
+/* ---- clique seam: a whole up/down schedule resident on the device --------------------------
+ * Replaces upGibbsCliqueDensity (SolveTree.jl:164-239) and solveCliqDownFrontalProducts!
+ * (CliqStateMachineUtils.jl:479-571) for *all cliques of a tree level at once*: a program is an
+ * ordered list of stages; a stage is a batch of independent proposals, products or copies.
+ * Upload once, replay per solve.                                                              */
+typedef struct nbp_program nbp_program;
+enum nbp_stage_kind { NBP_STAGE_PROPOSALS = 1, NBP_STAGE_PRODUCTS = 2, NBP_STAGE_COPIES = 3 };
+nbp_status nbp_program_create(nbp_ctx *ctx, nbp_program **out);
+nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *descs, int32_t n);
+nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
+nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);
+nbp_status nbp_program_reseed(nbp_program *prog, uint64_t salt); /* xor-mix all op seeds on device */
+nbp_status nbp_program_num_stages(nbp_program *prog, int32_t *out);
+nbp_status nbp_program_destroy(nbp_program *prog);
+
+/* per-kernel timing with HIP events on the library stream (bench.py roofline leg) */
+nbp_status nbp_timing_enable(nbp_ctx *ctx, int32_t on);
+nbp_status nbp_timing_read(nbp_ctx *ctx, double *ms_proposals, int64_t *launches_proposals,
+                           double *ms_products, int64_t *launches_products);
+nbp_status nbp_diag_read(nbp_ctx *ctx, nbp_diag *out, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBP_H */

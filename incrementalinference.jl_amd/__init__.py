@@ -1,0 +1,18 @@
+"""MI355X-native drop-in for IncrementalInference.jl's per-clique nonparametric
+Chapman-Kolmogorov hot path (approxConv -> per-particle solve -> manifold KDE product ->
+clique Gibbs schedule).  Compute lives in csrc/libnbp.so (hand-written HIP, gfx950) behind the
+C ABI of include/nbp.h; this package is the host-side mirror of the reference's API for that
+path.  There is no CPU fallback: the compute entry points raise when libnbp.so or a GPU is
+missing."""
+from . import abi, bayestree, canonical, seeds  # noqa: F401
+from .backend import HipBackend, NbpError  # noqa: F401
+from .bayestree import (buildTreeFromOrdering, buildTreeReset, getEliminationOrder,  # noqa: F401
+                        nestedDissectionOrder)
+from .canonical import (generateChainEuclid, generateCircularDoors, generateGraph_Kaess,  # noqa: F401
+                        generateGraph_LineStep, generateMixtureChain, generateSE2Lattice)
+from .factorgraph import (Circular, CircularCircular, ContinuousEuclid, ContinuousScalar,  # noqa: F401
+                          EuclidDistance, LinearRelative, ManifoldFactor, ManifoldPrior, Mixture,
+                          MsgPrior, MvNormal, Normal, Prior, PriorCircular, SolverParams,
+                          SpecialEuclidean2, addFactor, addVariable, getSolverParams, initfg)
+from .solver import (TreeProgram, approxConv, approxConvBelief, initAll, localProduct,  # noqa: F401
+                     localProductAndUpdate, propagateBelief, setValKDE, solveTree)

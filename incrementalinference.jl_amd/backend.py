@@ -1,0 +1,161 @@
+"""Device backend: thin object wrapper over the libnbp C ABI (include/nbp.h).
+
+The host-side mirror of the reference API (factorgraph.py / solver.py) talks to a *backend*
+through this narrow interface: belief slots in, descriptor batches run, belief slots out.
+The product backend is :class:`HipBackend`.  (The CPU oracle implements the same interface in
+``oracle/oracle_backend.py`` -- test infrastructure, never imported from this package.)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class NbpError(RuntimeError):
+    """Hard error from libnbp (status < 0).  The Julia shim maps this to `error()`, which fails
+    the clique Task and makes `monitorCSMs` tear the solve down with a CompositeException
+    (reference: CliqStateMachineUtils.jl:184-246, test/testCSMMonitor.jl:51)."""
+
+
+def _as_array(descs, ctype):
+    if isinstance(descs, C.Array):
+        return descs, len(descs)
+    arr = (ctype * len(descs))(*descs)
+    return arr, len(descs)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, N, n_slots, side_ints=0, device=0, arena_ptr=None, arena_bytes=0):
+        self.lib = abi.load_library()
+        self.N, self.n_slots = int(N), int(n_slots)
+        self._ctx = C.c_void_p()
+        self._check(self.lib.nbp_ctx_create(device, self.N, self.n_slots, arena_ptr, arena_bytes,
+                                            max(int(side_ints), 1), C.byref(self._ctx)))
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.nbp_last_error()
+            raise NbpError(f"libnbp status {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self._ctx:
+            self.lib.nbp_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- belief I/O -----------------------------------------------------------------------
+    def slot_write(self, slot, manifold, pts, bw=None):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(self.N, abi.MANIFOLD_P[manifold])
+        bwp = None
+        if bw is not None:
+            bw = np.ascontiguousarray(bw, dtype=np.float64)
+            bwp = bw.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self.lib.nbp_slot_write(self._ctx, slot, manifold,
+                                            pts.ctypes.data_as(C.POINTER(C.c_double)), bwp))
+
+    def slot_read(self, slot, manifold):
+        pts = np.empty((self.N, abi.MANIFOLD_P[manifold]))
+        bw = np.empty(abi.MANIFOLD_DIM[manifold])
+        self._check(self.lib.nbp_slot_read(self._ctx, slot, manifold,
+                                           pts.ctypes.data_as(C.POINTER(C.c_double)),
+                                           bw.ctypes.data_as(C.POINTER(C.c_double))))
+        return pts, bw
+
+    def side_write(self, offset, ints):
+        a = np.ascontiguousarray(ints, dtype=np.int32)
+        self._check(self.lib.nbp_side_write(self._ctx, offset, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
+
+    def side_read(self, offset, n):
+        a = np.empty(n, dtype=np.int32)
+        self._check(self.lib.nbp_side_read(self._ctx, offset, a.ctypes.data_as(C.POINTER(C.c_int32)), n))
+        return a
+
+    # ---- op batches -----------------------------------------------------------------------
+    def run_proposals(self, descs):
+        arr, n = _as_array(descs, abi.ProposalDesc)
+        self._check(self.lib.nbp_run_proposals(self._ctx, arr, n))
+
+    def run_products(self, descs):
+        arr, n = _as_array(descs, abi.ProductDesc)
+        self._check(self.lib.nbp_run_products(self._ctx, arr, n))
+
+    def run_copies(self, descs):
+        arr, n = _as_array(descs, abi.CopyDesc)
+        self._check(self.lib.nbp_run_copies(self._ctx, arr, n))
+
+    def run_bandwidth(self, slots, manifolds):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        m = np.ascontiguousarray(manifolds, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._check(self.lib.nbp_run_bandwidth(self._ctx, s.ctypes.data_as(ip), m.ctypes.data_as(ip), s.size))
+
+    def synchronize(self):
+        self._check(self.lib.nbp_synchronize(self._ctx))
+
+    # ---- resident programs (clique seam) -----------------------------------------------------
+    def program(self, stages):
+        return HipProgram(self, stages)
+
+    def timing_enable(self, on=True):
+        self._check(self.lib.nbp_timing_enable(self._ctx, int(on)))
+
+    def timing_read(self):
+        ms_p, ms_q = C.c_double(), C.c_double()
+        n_p, n_q = C.c_int64(), C.c_int64()
+        self._check(self.lib.nbp_timing_read(self._ctx, C.byref(ms_p), C.byref(n_p), C.byref(ms_q), C.byref(n_q)))
+        return {"proposals_ms": ms_p.value, "proposals_launches": n_p.value,
+                "products_ms": ms_q.value, "products_launches": n_q.value}
+
+    def diag(self, reset=False):
+        d = abi.Diag()
+        self._check(self.lib.nbp_diag_read(self._ctx, C.byref(d), int(reset)))
+        return {k: getattr(d, k) for k, _ in abi.Diag._fields_}
+
+    def arena_ptr(self):
+        return self.lib.nbp_arena_ptr(self._ctx)
+
+    def stream_ptr(self):
+        return self.lib.nbp_stream_ptr(self._ctx)
+
+
+_STAGE_CTYPE = {abi.STAGE_PROPOSALS: abi.ProposalDesc, abi.STAGE_PRODUCTS: abi.ProductDesc,
+                abi.STAGE_COPIES: abi.CopyDesc}
+
+
+class HipProgram:
+    """A device-resident schedule: list of (kind, descriptor-array) stages uploaded once."""
+
+    def __init__(self, backend, stages):
+        self.backend, lib = backend, backend.lib
+        self._p = C.c_void_p()
+        backend._check(lib.nbp_program_create(backend._ctx, C.byref(self._p)))
+        for kind, descs in stages:
+            arr, n = _as_array(descs, _STAGE_CTYPE[kind])
+            backend._check(lib.nbp_program_add_stage(self._p, kind, C.cast(arr, C.c_void_p), n))
+        backend._check(lib.nbp_program_finalize(self._p))
+        self.n_stages = len(stages)
+
+    def run(self, first=0, last=-1):
+        self.backend._check(self.backend.lib.nbp_program_run(self._p, first, last))
+
+    def reseed(self, salt):
+        self.backend._check(self.backend.lib.nbp_program_reseed(self._p, C.c_uint64(salt)))
+
+    def close(self):
+        if self._p:
+            self.backend.lib.nbp_program_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

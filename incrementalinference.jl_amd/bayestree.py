@@ -1,0 +1,405 @@
+"""Bayes (junction) tree construction and the per-clique Gibbs id lists.
+
+Host-side integer work that defines WHAT the device runs (the schedule), reproduced from the
+reference so that the same variable-update sequence is executed:
+  getEliminationOrder          src/services/BayesNet.jl:19-60
+  buildBayesNet!               src/services/BayesNet.jl:139-189
+  newPotential / buildTree!    src/services/JunctionTreeUtils.jl:435-495
+  setCliqPotentials!           src/services/JunctionTreeUtils.jl:1045-1083
+  compCliqAssocMatrices!       src/services/JunctionTreeUtils.jl:1294-1340
+  setCliqMCIDs! and friends    src/services/JunctionTreeUtils.jl:1352-1523
+  determineCliqVariableDownSequence  src/CliqueStateMachine/services/CliqStateMachineUtils.jl:424-462
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class TreeClique:
+    id: int
+    frontalIDs: list = field(default_factory=list)
+    separatorIDs: list = field(default_factory=list)
+    parent: int = -1
+    children: list = field(default_factory=list)
+    potentials: list = field(default_factory=list)      # factor labels used in the up solve
+    dwnPotentials: list = field(default_factory=list)   # all factors touching the frontals
+    inmsgIDs: list = field(default_factory=list)
+    cliqAssocMat: np.ndarray = None
+    cliqMsgMat: np.ndarray = None
+    directPriorMsgIDs: list = field(default_factory=list)
+    directvarIDs: list = field(default_factory=list)
+    itervarIDs: list = field(default_factory=list)
+    msgskipIDs: list = field(default_factory=list)
+    directFrtlMsgIDs: list = field(default_factory=list)
+
+    @property
+    def allIDs(self):
+        return self.frontalIDs + self.separatorIDs
+
+
+@dataclass
+class BayesTree:
+    cliques: dict = field(default_factory=dict)
+    frontals: dict = field(default_factory=dict)  # variable -> clique id
+    roots: list = field(default_factory=list)
+    eliminationOrder: list = field(default_factory=list)
+
+    def getClique(self, cid):
+        return self.cliques[cid]
+
+    def postorder(self):
+        out = []
+
+        def rec(c):
+            for ch in self.cliques[c].children:
+                rec(ch)
+            out.append(c)
+
+        import sys
+        sys.setrecursionlimit(max(10000, 4 * len(self.cliques) + 100))
+        for r in self.roots:
+            rec(r)
+        return out
+
+    def depths(self):
+        d = {}
+        stack = [(r, 0) for r in self.roots]
+        while stack:
+            c, k = stack.pop()
+            d[c] = k
+            for ch in self.cliques[c].children:
+                stack.append((ch, k + 1))
+        return d
+
+    def heights(self):
+        h = {}
+        for c in self.postorder():
+            ch = self.cliques[c].children
+            h[c] = 0 if not ch else 1 + max(h[x] for x in ch)
+        return h
+
+
+# ------------------------------------------------------------------------------------------------
+# elimination order
+# ------------------------------------------------------------------------------------------------
+def getEliminationOrder(fg, ordering="qr"):
+    """:qr = column-pivoted dense QR of the factor x variable biadjacency (LAPACK geqp3, the same
+    routine Julia's `qr(A, ColumnNorm())` calls), reversed -- BayesNet.jl:40-44.
+    :nested_dissection = recursive graph bisection (balanced tree; the ordering the benchmark
+    harness passes explicitly through `eliminationOrder`, as solveTree! allows, SolverAPI.jl:338)."""
+    labels = fg.ls()
+    if ordering == "qr":
+        from scipy.linalg import qr
+        fl = fg.lsf()
+        A = np.zeros((len(fl), len(labels)))
+        col = {v: i for i, v in enumerate(labels)}
+        for r, f in enumerate(fl):
+            for v in fg.getFactor(f).variables:
+                A[r, col[v]] = 1.0
+        _, _, p = qr(A, pivoting=True)
+        return [labels[i] for i in p[::-1]]
+    if ordering == "nested_dissection":
+        return nestedDissectionOrder(fg)
+    raise ValueError(f"getEliminationOrder -- cannot do the requested ordering {ordering}")
+
+
+def nestedDissectionOrder(fg):
+    """Recursive bisection with BFS level-structure separators.  Returns an elimination order in
+    which separators are eliminated after both halves, giving a balanced Bayes tree on chains and
+    lattices (depth O(log n) instead of O(n))."""
+    adj = {v: set() for v in fg.ls()}
+    for f in fg.lsf():
+        vs = fg.getFactor(f).variables
+        for a in vs:
+            for b in vs:
+                if a != b:
+                    adj[a].add(b)
+    index = {v: i for i, v in enumerate(fg.ls())}
+
+    def components(nodes):
+        nodes = set(nodes)
+        comps = []
+        while nodes:
+            s = min(nodes, key=index.get)
+            comp, stack = {s}, [s]
+            while stack:
+                u = stack.pop()
+                for w in adj[u]:
+                    if w in nodes and w not in comp:
+                        comp.add(w)
+                        stack.append(w)
+            nodes -= comp
+            comps.append(sorted(comp, key=index.get))
+        return comps
+
+    def bfs_levels(nodes, start):
+        nodes = set(nodes)
+        seen, frontier, levels = {start}, [start], []
+        while frontier:
+            levels.append(frontier)
+            nxt = []
+            for u in frontier:
+                for w in sorted(adj[u], key=index.get):
+                    if w in nodes and w not in seen:
+                        seen.add(w)
+                        nxt.append(w)
+            frontier = nxt
+        return levels
+
+    order = []
+    work = [list(c) for c in components(adj.keys())][::-1]
+    # iterative post-order: each item is ("split", nodes) or ("emit", separator)
+    stack = [("split", c) for c in work]
+    while stack:
+        kind, nodes = stack.pop()
+        if kind == "emit":
+            order.extend(nodes)
+            continue
+        if len(nodes) <= 2:
+            order.extend(nodes)
+            continue
+        # pseudo-peripheral start: BFS twice
+        lv = bfs_levels(nodes, nodes[0])
+        lv = bfs_levels(nodes, lv[-1][0])
+        if len(lv) < 3:
+            order.extend(nodes)
+            continue
+        # pick the level that best balances the two sides
+        sizes = np.cumsum([len(x) for x in lv])
+        total = sizes[-1]
+        best, bestk = None, None
+        for k in range(1, len(lv) - 1):
+            left, right = sizes[k - 1], total - sizes[k]
+            score = (abs(left - right), len(lv[k]))
+            if best is None or score < best:
+                best, bestk = score, k
+        sep = lv[bestk]
+        rest = [v for v in nodes if v not in set(sep)]
+        stack.append(("emit", sep))
+        for comp in components(rest)[::-1]:
+            stack.append(("split", comp))
+    return order
+
+
+# ------------------------------------------------------------------------------------------------
+# Bayes net + tree
+# ------------------------------------------------------------------------------------------------
+def buildBayesNet(fg, elimorder):
+    """Variable elimination, returns {variable: separator list Si}.  BayesNet.jl:139-189: Si is
+    collected in neighbour order over the not-yet-eliminated factors of v, then a chain-rule
+    marginal over Si is added to the graph."""
+    fvars = {f: list(fg.getFactor(f).variables) for f in fg.lsf()}
+    vfacs = {v: list(fg.ls(v)) for v in fg.ls()}
+    eliminated = set()
+    sep = {}
+    nmarg = 0
+    for v in elimorder:
+        Si = []
+        for f in vfacs[v]:
+            if f in eliminated or f not in fvars:
+                continue
+            for s in fvars[f]:
+                if s != v and s not in Si:
+                    Si.append(s)
+            eliminated.add(f)
+        sep[v] = Si if v != elimorder[-1] else []
+        if v == elimorder[-1] and Si:
+            sep[v] = Si  # disjoint handling: last variable normally has an empty Si anyway
+        # rmVarFromMarg: marginal factors that touch v lose v (they were just eliminated above)
+        if Si:
+            nmarg += 1
+            name = f"__marg{nmarg}"
+            fvars[name] = list(Si)
+            for s in Si:
+                vfacs[s].append(name)
+    return sep
+
+
+def buildTree(fg, elimorder):
+    """buildTree!/newPotential, JunctionTreeUtils.jl:435-495 (Kaess et al., Bayes tree Alg. 2)."""
+    sep = buildBayesNet(fg, elimorder)
+    pos = {v: i for i, v in enumerate(elimorder)}
+    tree = BayesTree(eliminationOrder=list(elimorder))
+    nid = 0
+    for var in reversed(elimorder):
+        Sj = sep[var]
+        if len(Sj) == 0:
+            nid += 1
+            tree.cliques[nid] = TreeClique(nid, [var], [])
+            tree.frontals[var] = nid
+            tree.roots.append(nid)
+            continue
+        felbl = min(Sj, key=lambda s: pos[s])  # identifyFirstEliminatedSeparator
+        CpID = tree.frontals[felbl]
+        cp = tree.cliques[CpID]
+        if sorted(cp.frontalIDs + cp.separatorIDs) == sorted(Sj):
+            cp.frontalIDs.append(var)  # appendClique!
+            tree.frontals[var] = CpID
+        else:
+            nid += 1
+            tree.cliques[nid] = TreeClique(nid, [var], list(Sj), parent=CpID)  # newChildClique!
+            tree.frontals[var] = nid
+            cp.children.append(nid)
+    return tree
+
+
+# ------------------------------------------------------------------------------------------------
+# clique potentials and Gibbs id lists
+# ------------------------------------------------------------------------------------------------
+def _setCliqPotentials(fg, cliq, used):
+    allv = set(cliq.allIDs)
+    frtfcts = []
+    for fr in cliq.frontalIDs:
+        for f in fg.ls(fr):
+            if f not in frtfcts:
+                frtfcts.append(f)
+    pots = []
+    for f in frtfcts:
+        if f in used:
+            continue
+        if set(fg.getFactor(f).variables) <= allv:
+            pots.append(f)
+    for f in pots:
+        used.add(f)
+    cliq.potentials = pots
+    cliq.dwnPotentials = list(frtfcts)  # getCliqFactorsFromFrontals(inseparator=false, unused=false)
+
+
+def _compCliqAssocMatrices(fg, tree, cliq):
+    cols = cliq.allIDs
+    inmsg = []
+    for ch in cliq.children:
+        inmsg += tree.cliques[ch].separatorIDs  # collectSeparators
+    cliq.inmsgIDs = inmsg
+    A = np.zeros((len(cliq.potentials), len(cols)), dtype=bool)
+    Mm = np.zeros((len(inmsg), len(cols)), dtype=bool)
+    for j, c in enumerate(cols):
+        for i, m in enumerate(inmsg):
+            if m == c:
+                Mm[i, j] = True
+        for i, f in enumerate(cliq.potentials):
+            if c in fg.getFactor(f).variables:
+                A[i, j] = True
+    cliq.cliqAssocMat, cliq.cliqMsgMat = A, Mm
+
+
+def _cols_where(cols, mask):
+    return [c for c, m in zip(cols, mask) if m]
+
+
+def setCliqMCIDs(cliq):
+    """JunctionTreeUtils.jl:1352-1523"""
+    nf = len(cliq.frontalIDs)
+    cols = cliq.allIDs
+    A, Mm = cliq.cliqAssocMat.astype(int), cliq.cliqMsgMat.astype(int)
+    mat = np.vstack([A, Mm]) if (A.size or Mm.size) else np.zeros((0, len(cols)), dtype=int)
+
+    # directPriorMsgIDs :1366-1378
+    singr = mat.sum(axis=1) == 1
+    sumsrAc = mat[singr, :].sum(axis=0) if mat.shape[0] else np.zeros(len(cols), dtype=int)
+    sumc = mat.sum(axis=0) if mat.shape[0] else np.zeros(len(cols), dtype=int)
+    cliq.directPriorMsgIDs = _cols_where(cols, (sumsrAc - sumc) == 0)
+
+    # directAssignmentIDs :1391-1405
+    mab = (mat.sum(axis=0) == 1) & (A.sum(axis=0) == 1) if mat.shape[0] else np.zeros(len(cols), dtype=bool)
+    cliq.directvarIDs = _cols_where(cols, mab)
+
+    # mcmcIterationIDs :1407-1431
+    if mat.sum() == 0:
+        raise RuntimeError("mcmcIterationIDs -- unaccounted variables")
+    multi = mat.sum(axis=0) > 1
+    usset = list(cliq.directvarIDs)
+    for c in _cols_where(cols, multi):
+        if c not in usset:
+            usset.append(c)
+    alliter = [c for c in usset if c not in cliq.directPriorMsgIDs]
+
+    # getCliqVarSingletons :1273-1287 (partials=true default => prior rows AND partial => none here)
+    upmsgids = _cols_where(cols, Mm.sum(axis=0) >= 1)
+    allsings = list(upmsgids)
+    # mcmcIterationIdsOrdered :1447-1484
+    singletonvars = [c for c in alliter if c in allsings]
+    nonsingl = [c for c in alliter if c not in singletonvars]
+    lenf = mat.sum(axis=0)
+    colidx = {c: i for i, c in enumerate(cols)}
+    nonsingl = [nonsingl[i] for i in np.argsort([lenf[colidx[c]] for c in nonsingl], kind="stable")]
+    singletonvars = [singletonvars[i] for i in np.argsort([lenf[colidx[c]] for c in singletonvars], kind="stable")]
+    cliq.itervarIDs = nonsingl + singletonvars
+
+    # skipThroughMsgsIDs :1342-1353
+    condA, condM = A[:, nf:], Mm[:, nf:]
+    cm = np.vstack([condA, condM])
+    mskip = (cm.sum(axis=0) == 1) & (condM.sum(axis=0) == 1)
+    cliq.msgskipIDs = _cols_where(cliq.separatorIDs, mskip)
+
+    # directFrtlMsgIDs :1380-1389
+    fa, fm = A[:, :nf], Mm[:, :nf]
+    fmat = np.vstack([fa, fm])
+    mfr = (fmat.sum(axis=0) == 1) & (fm.sum(axis=0) == 1)
+    cliq.directFrtlMsgIDs = _cols_where(cliq.frontalIDs, mfr)
+
+
+def buildCliquePotentials(fg, tree):
+    """post-order traversal, JunctionTreeUtils.jl:1524-1541"""
+    used = set()
+    for cid in tree.postorder():
+        cliq = tree.cliques[cid]
+        _setCliqPotentials(fg, cliq, used)
+        _compCliqAssocMatrices(fg, tree, cliq)
+        setCliqMCIDs(cliq)
+
+
+def buildTreeFromOrdering(fg, elimorder):
+    tree = buildTree(fg, elimorder)
+    buildCliquePotentials(fg, tree)
+    return tree
+
+
+def buildTreeReset(fg, eliminationOrder=None, ordering="qr"):
+    """buildTreeReset!(dfg, eliminationOrder)   (JunctionTreeUtils.jl:823-860)"""
+    order = list(eliminationOrder) if eliminationOrder is not None else getEliminationOrder(fg, ordering)
+    return buildTreeFromOrdering(fg, order)
+
+
+def upGibbsSchedule(cliq, gibbsIters=3):
+    """The ordered list of variable updates of upGibbsCliqueDensity (SolveTree.jl:164-239):
+    fmcmc!(directFrtlMsgIDs,1); fmcmc!(msgskipIDs,1); fmcmc!(itervarIDs,iters);
+    fmcmc!(directPriorMsgIDs \\ msgskipIDs, 1).  fmcmc! forces MCMCIter=1 for a single label (:106-108)."""
+    sched = []
+
+    def fmcmc(lbls, iters):
+        if len(lbls) == 1:
+            iters = 1
+        for _ in range(iters):
+            sched.extend(lbls)
+
+    fmcmc(cliq.directFrtlMsgIDs, 1)
+    if cliq.msgskipIDs:
+        fmcmc(cliq.msgskipIDs, 1)
+    if cliq.itervarIDs:
+        fmcmc(cliq.itervarIDs, gibbsIters)
+    if cliq.directPriorMsgIDs:
+        fmcmc([v for v in cliq.directPriorMsgIDs if v not in cliq.msgskipIDs], 1)
+    return sched
+
+
+def determineCliqVariableDownSequence(fg, cliq):
+    """frontals that share a factor with another frontal iterate; the others are direct
+    (CliqStateMachineUtils.jl:424-462, evaluated on the sub graph after addDownVariableFactors!)."""
+    frs = set(cliq.frontalIDs)
+    iterv = []
+    for f in cliq.dwnPotentials:
+        hit = [v for v in fg.getFactor(f).variables if v in frs]
+        if len(hit) > 1:
+            for v in hit:
+                if v not in iterv:
+                    iterv.append(v)
+    return [v for v in cliq.frontalIDs if v in iterv]
+
+
+def downSchedule(fg, cliq, MCIters=3):
+    """solveCliqDownFrontalProducts!, CliqStateMachineUtils.jl:479-571"""
+    iterFrtls = determineCliqVariableDownSequence(fg, cliq)
+    directs = [v for v in cliq.frontalIDs if v not in iterFrtls]
+    return directs + iterFrtls * MCIters

@@ -1,0 +1,585 @@
+// nbp_api.hip -- host side of libnbp: the C ABI declared in include/nbp.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC nbp_api.hip -o libnbp.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nbp_kernels.h"
+
+static thread_local std::string g_err;
+static nbp_status fail(nbp_status code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(NBP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+struct nbp_ctx {
+  int device = 0, N = 0, n_slots = 0, side_ints = 0, threads = 0;
+  int64_t S = 0;
+  double *arena = nullptr;
+  bool own_arena = false;
+  int32_t *side = nullptr;
+  nbp_counters *counters = nullptr;
+  hipStream_t stream = nullptr;
+  nbp_levels T{};
+  int32_t *lv_ints = nullptr;
+  double *lv_dbls = nullptr;
+  // staging for immediate-mode calls
+  void *stage = nullptr;
+  size_t stage_bytes = 0;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_prop, ev_prod;
+  double ms_prop = 0, ms_prod = 0;
+  int64_t n_prop = 0, n_prod = 0;
+};
+
+static int manifold_dim_h(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
+static int manifold_P_h(int m) { return m == NBP_SE2 ? 6 : manifold_dim_h(m); }
+static bool manifold_ok(int m) { return m >= NBP_EUCLID1 && m <= NBP_SE2; }
+static double wrap_h(double a) {
+  const double PI = 3.14159265358979323846, TP = 6.28318530717958647692;
+  if (a >= -PI && a < PI) return a;
+  double r = fmod(a + PI, TP);
+  if (r < 0) r += TP;
+  return r - PI;
+}
+
+extern "C" {
+
+int64_t nbp_slot_stride_doubles(int32_t N) { return 3 * (int64_t)N + 8; }
+int64_t nbp_arena_bytes(int32_t N, int32_t n_slots) { return nbp_slot_stride_doubles(N) * 8 * (int64_t)n_slots; }
+const char *nbp_last_error(void) { return g_err.c_str(); }
+
+// data-independent level tables of the balanced KD-tree over N leaves
+static nbp_status build_levels(nbp_ctx *c) {
+  const int N = c->N;
+  std::vector<std::vector<int>> lo(1), hi(1), child;
+  lo[0] = {0};
+  hi[0] = {N};
+  int l = 0;
+  for (;;) {
+    bool all_leaf = true;
+    for (size_t k = 0; k < lo[l].size(); k++)
+      if (hi[l][k] - lo[l][k] > 1) all_leaf = false;
+    if (all_leaf) break;
+    lo.emplace_back();
+    hi.emplace_back();
+    child.emplace_back();
+    for (size_t k = 0; k < lo[l].size(); k++) {
+      int a = lo[l][k], b = hi[l][k];
+      if (b - a == 1) {
+        lo[l + 1].push_back(a);
+        hi[l + 1].push_back(b);
+      } else {
+        int mid = a + (b - a + 1) / 2;
+        lo[l + 1].push_back(a); hi[l + 1].push_back(mid);
+        lo[l + 1].push_back(mid); hi[l + 1].push_back(b);
+      }
+      child[l].push_back((int)lo[l + 1].size() - 1);
+    }
+    l++;
+    if (l >= NBP_MAXLEVELS - 1) return fail(NBP_ERR_RANGE, "tree too deep");
+  }
+  const int L = l;
+  std::vector<int32_t> ints;
+  std::vector<double> dbls;
+  int total = 0;
+  for (int i = 0; i <= L; i++) { c->T.cnt[i] = (int)lo[i].size(); c->T.off[i] = total; total += c->T.cnt[i]; }
+  std::vector<int32_t> nlo(total), nhi(total), nch(total, 0), pos((size_t)(L + 1) * N);
+  dbls.resize(total);
+  for (int i = 0; i <= L; i++)
+    for (int k = 0; k < c->T.cnt[i]; k++) {
+      nlo[c->T.off[i] + k] = lo[i][k];
+      nhi[c->T.off[i] + k] = hi[i][k];
+      if (i < L) nch[c->T.off[i] + k] = child[i][k];
+      dbls[c->T.off[i] + k] = std::log((double)(hi[i][k] - lo[i][k]) / (double)N);
+      for (int p = lo[i][k]; p < hi[i][k]; p++) pos[(size_t)i * N + p] = k;
+    }
+  ints.insert(ints.end(), nlo.begin(), nlo.end());
+  ints.insert(ints.end(), nhi.begin(), nhi.end());
+  ints.insert(ints.end(), nch.begin(), nch.end());
+  ints.insert(ints.end(), pos.begin(), pos.end());
+  HIPCHK(hipMalloc(&c->lv_ints, ints.size() * 4));
+  HIPCHK(hipMalloc(&c->lv_dbls, dbls.size() * 8));
+  HIPCHK(hipMemcpy(c->lv_ints, ints.data(), ints.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->lv_dbls, dbls.data(), dbls.size() * 8, hipMemcpyHostToDevice));
+  c->T.N = N;
+  c->T.L = L;
+  c->T.node_lo = c->lv_ints;
+  c->T.node_hi = c->lv_ints + total;
+  c->T.node_child = c->lv_ints + 2 * total;
+  c->T.pos_node = c->lv_ints + 3 * total;
+  c->T.node_logw = c->lv_dbls;
+  return NBP_OK;
+}
+
+nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *arena, int64_t arena_bytes,
+                          int32_t side_ints, nbp_ctx **out) {
+  if (!out) return fail(NBP_ERR_ARG, "out is null");
+  if (N < 8 || N > NBP_MAXN) return fail(NBP_ERR_RANGE, "N must be in [8, 512]");
+  if (n_slots < 1) return fail(NBP_ERR_ARG, "n_slots < 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(NBP_ERR_NOGPU, "no HIP device visible: libnbp has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(NBP_ERR_ARG, "bad device index");
+  HIPCHK(hipSetDevice(device));
+  nbp_ctx *c = new nbp_ctx();
+  c->device = device;
+  c->N = N;
+  c->n_slots = n_slots;
+  c->S = nbp_slot_stride_doubles(N);
+  c->threads = ((N + 63) / 64) * 64;
+  c->side_ints = side_ints > 0 ? side_ints : 1;
+  if (arena) {
+    if (arena_bytes < nbp_arena_bytes(N, n_slots)) { delete c; return fail(NBP_ERR_ARG, "arena too small"); }
+    c->arena = (double *)arena;
+  } else {
+    HIPCHK(hipMalloc(&c->arena, nbp_arena_bytes(N, n_slots)));
+    HIPCHK(hipMemset(c->arena, 0, nbp_arena_bytes(N, n_slots)));
+    c->own_arena = true;
+  }
+  HIPCHK(hipMalloc(&c->side, (size_t)c->side_ints * 4));
+  HIPCHK(hipMemset(c->side, 0, (size_t)c->side_ints * 4));
+  HIPCHK(hipMalloc(&c->counters, sizeof(nbp_counters)));
+  HIPCHK(hipMemset(c->counters, 0, sizeof(nbp_counters)));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  nbp_status rc = build_levels(c);
+  if (rc != NBP_OK) return rc;
+  // allow the full 160 KiB LDS for the product kernel
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  *out = c;
+  return NBP_OK;
+}
+
+nbp_status nbp_ctx_destroy(nbp_ctx *c) {
+  if (!c) return NBP_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto &p : c->ev_prop) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  for (auto &p : c->ev_prod) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  if (c->own_arena) hipFree(c->arena);
+  hipFree(c->side);
+  hipFree(c->counters);
+  hipFree(c->lv_ints);
+  hipFree(c->lv_dbls);
+  if (c->stage) hipFree(c->stage);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return NBP_OK;
+}
+
+nbp_status nbp_synchronize(nbp_ctx *c) {
+  if (!c) return fail(NBP_ERR_ARG, "ctx is null");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+void *nbp_arena_ptr(nbp_ctx *c) { return c ? c->arena : nullptr; }
+void *nbp_stream_ptr(nbp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---- belief I/O --------------------------------------------------------------------------------
+nbp_status nbp_slot_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, const double *bw) {
+  if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
+  if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
+  const int N = c->N, D = manifold_dim_h(manifold), P = manifold_P_h(manifold);
+  std::vector<double> s(c->S, 0.0);
+  for (int n = 0; n < N; n++) {
+    const double *p = pts + (size_t)n * P;
+    if (manifold == NBP_SE2) {
+      s[n] = p[0];
+      s[N + n] = p[1];
+      s[2 * N + n] = std::atan2(p[3], p[2]);
+    } else if (manifold == NBP_CIRCULAR) {
+      s[n] = wrap_h(p[0]);
+    } else {
+      for (int d = 0; d < D; d++) s[d * N + n] = p[d];
+    }
+  }
+  for (int d = 0; d < D; d++) s[3 * N + d] = bw ? bw[d] : 0.0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->arena + c->S * slot, s.data(), c->S * 8, hipMemcpyHostToDevice));
+  return NBP_OK;
+}
+
+nbp_status nbp_slot_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts, double *bw) {
+  if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
+  if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
+  const int N = c->N, D = manifold_dim_h(manifold), P = manifold_P_h(manifold);
+  std::vector<double> s(c->S);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(s.data(), c->arena + c->S * slot, c->S * 8, hipMemcpyDeviceToHost));
+  for (int n = 0; n < N; n++) {
+    double *p = pts + (size_t)n * P;
+    if (manifold == NBP_SE2) {
+      double th = s[2 * N + n];
+      p[0] = s[n]; p[1] = s[N + n];
+      p[2] = std::cos(th); p[3] = std::sin(th); p[4] = -std::sin(th); p[5] = std::cos(th);
+    } else {
+      for (int d = 0; d < D; d++) p[d] = s[d * N + n];
+    }
+  }
+  if (bw)
+    for (int d = 0; d < D; d++) bw[d] = s[3 * N + d];
+  return NBP_OK;
+}
+
+nbp_status nbp_side_write(nbp_ctx *c, int32_t offset, const int32_t *src, int32_t n) {
+  if (!c || !src) return fail(NBP_ERR_ARG, "null argument");
+  if (offset < 0 || n < 0 || offset + n > c->side_ints) return fail(NBP_ERR_RANGE, "side buffer range");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->side + offset, src, (size_t)n * 4, hipMemcpyHostToDevice));
+  return NBP_OK;
+}
+nbp_status nbp_side_read(nbp_ctx *c, int32_t offset, int32_t *dst, int32_t n) {
+  if (!c || !dst) return fail(NBP_ERR_ARG, "null argument");
+  if (offset < 0 || n < 0 || offset + n > c->side_ints) return fail(NBP_ERR_RANGE, "side buffer range");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(dst, c->side + offset, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return NBP_OK;
+}
+
+// ---- validation ----------------------------------------------------------------------------------
+static nbp_status check_proposals(nbp_ctx *c, const nbp_proposal_desc *d, int n) {
+  for (int i = 0; i < n; i++) {
+    const nbp_proposal_desc &p = d[i];
+    if (!manifold_ok(p.manifold)) return fail(NBP_ERR_ARG, "proposal: unknown manifold");
+    if (p.factor_kind < NBP_F_PRIOR || p.factor_kind > NBP_F_EUCLIDDIST) return fail(NBP_ERR_ARG, "proposal: unknown factor kind");
+    if (p.nvars < 1 || p.nvars > NBP_MAXV) return fail(NBP_ERR_RANGE, "proposal: nvars");
+    if (p.sfidx < 0 || p.sfidx >= p.nvars) return fail(NBP_ERR_RANGE, "proposal: sfidx");
+    if (p.ncomp < 1 || p.ncomp > NBP_MAXC) return fail(NBP_ERR_RANGE, "proposal: ncomp");
+    if (p.inflate_cycles < 0 || p.inflate_cycles > 8) return fail(NBP_ERR_RANGE, "proposal: inflate_cycles");
+    if (p.out_slot < 0 || p.out_slot >= c->n_slots) return fail(NBP_ERR_RANGE, "proposal: out_slot");
+    int nv = (p.factor_kind == NBP_F_MSGPRIOR) ? 2 : p.nvars;
+    for (int k = 0; k < nv; k++)
+      if (p.var_slot[k] < 0 || p.var_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "proposal: var_slot");
+    if ((p.factor_kind == NBP_F_PRIOR || p.factor_kind == NBP_F_MSGPRIOR) && p.nvars != 1)
+      return fail(NBP_ERR_ARG, "proposal: priors are unary");
+    if (p.factor_kind >= NBP_F_LINREL && p.nvars < 2) return fail(NBP_ERR_ARG, "proposal: relative factor needs >= 2 variables");
+    if (p.factor_kind >= NBP_F_LINREL && !p.has_multihypo && p.nvars != 2)
+      return fail(NBP_ERR_ARG, "proposal: binary mechanics without multihypo needs nvars == 2");
+    if (p.factor_kind == NBP_F_CIRCULAR && p.manifold != NBP_CIRCULAR) return fail(NBP_ERR_ARG, "CircularCircular needs Circular variables");
+    if (p.factor_kind == NBP_F_SE2 && p.manifold != NBP_SE2) return fail(NBP_ERR_ARG, "SE2 factor needs SE2 variables");
+    if (p.factor_kind == NBP_F_LINREL && p.manifold > NBP_EUCLID3) return fail(NBP_ERR_ARG, "LinearRelative needs Euclid variables");
+    if (p.mhidx_in >= 0 && p.mhidx_in + c->N > c->side_ints) return fail(NBP_ERR_RANGE, "proposal: mhidx_in");
+    if (p.mhidx_out >= 0 && p.mhidx_out + c->N > c->side_ints) return fail(NBP_ERR_RANGE, "proposal: mhidx_out");
+    if (p.has_multihypo) {
+      int ncert = 0;
+      for (int k = 0; k < p.nvars; k++) ncert += (p.multihypo[k] == 0.0);
+      if (ncert != 1) return fail(NBP_ERR_ARG, "proposal: multihypo needs exactly one certain variable (binary mechanics)");
+    }
+  }
+  return NBP_OK;
+}
+static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
+  for (int i = 0; i < n; i++) {
+    const nbp_product_desc &p = d[i];
+    if (!manifold_ok(p.manifold)) return fail(NBP_ERR_ARG, "product: unknown manifold");
+    if (p.nfactors < 1 || p.nfactors > NBP_MAXF) return fail(NBP_ERR_RANGE, "product: nfactors");
+    if (p.niter < 1 || p.niter > 8) return fail(NBP_ERR_RANGE, "product: niter");
+    if (p.out_slot < 0 || p.out_slot >= c->n_slots) return fail(NBP_ERR_RANGE, "product: out_slot");
+    for (int k = 0; k < p.nfactors; k++)
+      if (p.in_slot[k] < 0 || p.in_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "product: in_slot");
+    if (p.labels_out >= 0 && p.labels_out + c->N * p.nfactors > c->side_ints) return fail(NBP_ERR_RANGE, "product: labels_out");
+    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->threads);
+    if (p.nfactors > 1 && lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: F*D*N exceeds the 160 KiB LDS");
+  }
+  return NBP_OK;
+}
+static nbp_status check_copies(nbp_ctx *c, const nbp_copy_desc *d, int n) {
+  for (int i = 0; i < n; i++)
+    if (d[i].src_slot < 0 || d[i].src_slot >= c->n_slots || d[i].dst_slot < 0 || d[i].dst_slot >= c->n_slots)
+      return fail(NBP_ERR_RANGE, "copy: slot out of range");
+  return NBP_OK;
+}
+
+// ---- launches --------------------------------------------------------------------------------------
+static nbp_status tic(nbp_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+  if (!c->timing) return NBP_OK;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  HIPCHK(hipEventRecord(a, c->stream));
+  v.emplace_back(a, b);
+  return NBP_OK;
+}
+static nbp_status toc(nbp_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+  if (!c->timing) return NBP_OK;
+  HIPCHK(hipEventRecord(v.back().second, c->stream));
+  return NBP_OK;
+}
+
+static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int n) {
+  if (n <= 0) return NBP_OK;
+  nbp_status rc = tic(c, c->ev_prop);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nbp_proposal_kernel, dim3(n), dim3(c->threads), nbp_proposal_lds_bytes(c->N), c->stream, dev,
+                     c->arena, c->N, c->S, c->side, c->counters);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev_prop);
+}
+static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, size_t lds) {
+  if (n <= 0) return NBP_OK;
+  nbp_status rc = tic(c, c->ev_prod);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nbp_product_kernel, dim3(n), dim3(c->threads), lds, c->stream, dev, c->arena, c->N, c->S,
+                     c->side, c->T);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev_prod);
+}
+static size_t products_lds(nbp_ctx *c, const nbp_product_desc *d, int n) {
+  size_t lds = 1024;
+  for (int i = 0; i < n; i++)
+    if (d[i].nfactors > 1) {
+      size_t b = nbp_product_lds_bytes(d[i].nfactors, manifold_dim_h(d[i].manifold), c->N, c->threads);
+      if (b > lds) lds = b;
+    }
+  return lds;
+}
+static nbp_status launch_copies(nbp_ctx *c, const nbp_copy_desc *dev, int n) {
+  if (n <= 0) return NBP_OK;
+  hipLaunchKernelGGL(nbp_copy_kernel, dim3(n), dim3(256), 0, c->stream, dev, c->arena, c->S);
+  HIPCHK(hipGetLastError());
+  return NBP_OK;
+}
+
+static nbp_status stage_upload(nbp_ctx *c, const void *src, size_t bytes) {
+  if (bytes > c->stage_bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stage) HIPCHK(hipFree(c->stage));
+    c->stage_bytes = bytes * 2;
+    HIPCHK(hipMalloc(&c->stage, c->stage_bytes));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));  // the previous batch may still read the staging buffer
+  HIPCHK(hipMemcpy(c->stage, src, bytes, hipMemcpyHostToDevice));
+  return NBP_OK;
+}
+
+nbp_status nbp_run_proposals(nbp_ctx *c, const nbp_proposal_desc *descs, int32_t n) {
+  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  nbp_status rc = check_proposals(c, descs, n);
+  if (rc) return rc;
+  rc = stage_upload(c, descs, sizeof(nbp_proposal_desc) * (size_t)n);
+  if (rc) return rc;
+  rc = launch_proposals(c, (const nbp_proposal_desc *)c->stage, n);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+
+nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n) {
+  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  nbp_status rc = check_products(c, descs, n);
+  if (rc) return rc;
+  rc = stage_upload(c, descs, sizeof(nbp_product_desc) * (size_t)n);
+  if (rc) return rc;
+  rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_lds(c, descs, n));
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+
+nbp_status nbp_run_copies(nbp_ctx *c, const nbp_copy_desc *descs, int32_t n) {
+  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  nbp_status rc = check_copies(c, descs, n);
+  if (rc) return rc;
+  rc = stage_upload(c, descs, sizeof(nbp_copy_desc) * (size_t)n);
+  if (rc) return rc;
+  rc = launch_copies(c, (const nbp_copy_desc *)c->stage, n);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+
+nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *manifolds, int32_t n) {
+  if (!c || ((!slots || !manifolds) && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; i++) {
+    if (slots[i] < 0 || slots[i] >= c->n_slots) return fail(NBP_ERR_RANGE, "bandwidth: slot out of range");
+    if (!manifold_ok(manifolds[i])) return fail(NBP_ERR_ARG, "bandwidth: unknown manifold");
+  }
+  std::vector<int32_t> both(slots, slots + n);
+  both.insert(both.end(), manifolds, manifolds + n);
+  nbp_status rc = stage_upload(c, both.data(), both.size() * 4);
+  if (rc) return rc;
+  const int32_t *ds = (const int32_t *)c->stage;
+  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n), dim3(c->threads), ((size_t)3 * c->N + 16) * 8, c->stream, ds, ds + n,
+                     c->arena, c->N, c->S);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+
+// ---- resident programs ---------------------------------------------------------------------------------
+struct nbp_stage {
+  int kind, n;
+  size_t offset, lds;  // byte offset of the descriptors in the program blob
+};
+struct nbp_program {
+  nbp_ctx *ctx = nullptr;
+  std::vector<nbp_stage> stages;
+  std::vector<char> blob;
+  char *dev = nullptr;
+  bool finalized = false;
+};
+
+nbp_status nbp_program_create(nbp_ctx *c, nbp_program **out) {
+  if (!c || !out) return fail(NBP_ERR_ARG, "null argument");
+  nbp_program *p = new nbp_program();
+  p->ctx = c;
+  *out = p;
+  return NBP_OK;
+}
+
+nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs, int32_t n) {
+  if (!p || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
+  if (n < 0) return fail(NBP_ERR_ARG, "n < 0");
+  size_t esz;
+  nbp_status rc = NBP_OK;
+  size_t lds = 0;
+  switch (kind) {
+  case NBP_STAGE_PROPOSALS: esz = sizeof(nbp_proposal_desc); rc = check_proposals(p->ctx, (const nbp_proposal_desc *)descs, n); break;
+  case NBP_STAGE_PRODUCTS:
+    esz = sizeof(nbp_product_desc);
+    rc = check_products(p->ctx, (const nbp_product_desc *)descs, n);
+    lds = products_lds(p->ctx, (const nbp_product_desc *)descs, n);
+    break;
+  case NBP_STAGE_COPIES: esz = sizeof(nbp_copy_desc); rc = check_copies(p->ctx, (const nbp_copy_desc *)descs, n); break;
+  default: return fail(NBP_ERR_ARG, "unknown stage kind");
+  }
+  if (rc) return rc;
+  size_t off = (p->blob.size() + 63) & ~(size_t)63;
+  p->blob.resize(off + esz * (size_t)n);
+  if (n) memcpy(p->blob.data() + off, descs, esz * (size_t)n);
+  p->stages.push_back({kind, n, off, lds});
+  return NBP_OK;
+}
+
+nbp_status nbp_program_finalize(nbp_program *p) {
+  if (!p) return fail(NBP_ERR_ARG, "null argument");
+  if (p->finalized) return NBP_OK;
+  HIPCHK(hipSetDevice(p->ctx->device));
+  size_t bytes = p->blob.size() ? p->blob.size() : 64;
+  HIPCHK(hipMalloc(&p->dev, bytes));
+  if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+  p->finalized = true;
+  return NBP_OK;
+}
+
+nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
+  if (!p) return fail(NBP_ERR_ARG, "null argument");
+  if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+  nbp_ctx *c = p->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int ns = (int)p->stages.size();
+  if (last < 0 || last > ns) last = ns;
+  if (first < 0) first = 0;
+  for (int s = first; s < last; s++) {
+    const nbp_stage &st = p->stages[s];
+    nbp_status rc = NBP_OK;
+    if (st.kind == NBP_STAGE_PROPOSALS) rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
+    else if (st.kind == NBP_STAGE_PRODUCTS) rc = launch_products(c, (const nbp_product_desc *)(p->dev + st.offset), st.n, st.lds);
+    else rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
+    if (rc) return rc;
+  }
+  return NBP_OK;  // asynchronous: nbp_synchronize / nbp_slot_read wait for completion
+}
+
+nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
+  if (!p || !p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+  nbp_ctx *c = p->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  for (const nbp_stage &st : p->stages) {
+    if (st.n == 0) continue;
+    int blocks = (st.n + 255) / 256;
+    if (st.kind == NBP_STAGE_PROPOSALS)
+      hipLaunchKernelGGL(nbp_reseed_proposals, dim3(blocks), dim3(256), 0, c->stream, (nbp_proposal_desc *)(p->dev + st.offset), st.n, salt);
+    else if (st.kind == NBP_STAGE_PRODUCTS)
+      hipLaunchKernelGGL(nbp_reseed_products, dim3(blocks), dim3(256), 0, c->stream, (nbp_product_desc *)(p->dev + st.offset), st.n, salt);
+  }
+  HIPCHK(hipGetLastError());
+  return NBP_OK;
+}
+
+nbp_status nbp_program_num_stages(nbp_program *p, int32_t *out) {
+  if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
+  *out = (int32_t)p->stages.size();
+  return NBP_OK;
+}
+
+nbp_status nbp_program_destroy(nbp_program *p) {
+  if (!p) return NBP_OK;
+  if (p->dev) {
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->dev);
+  }
+  delete p;
+  return NBP_OK;
+}
+
+// ---- timing / diagnostics -------------------------------------------------------------------------------
+nbp_status nbp_timing_enable(nbp_ctx *c, int32_t on) {
+  if (!c) return fail(NBP_ERR_ARG, "null argument");
+  c->timing = on != 0;
+  return NBP_OK;
+}
+static nbp_status drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms, int64_t &cnt) {
+  for (auto &p : v) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, p.first, p.second));
+    ms += t;
+    cnt++;
+    hipEventDestroy(p.first);
+    hipEventDestroy(p.second);
+  }
+  v.clear();
+  return NBP_OK;
+}
+nbp_status nbp_timing_read(nbp_ctx *c, double *ms_prop, int64_t *n_prop, double *ms_prod, int64_t *n_prod) {
+  if (!c) return fail(NBP_ERR_ARG, "null argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  nbp_status rc = drain(c->ev_prop, c->ms_prop, c->n_prop);
+  if (rc) return rc;
+  rc = drain(c->ev_prod, c->ms_prod, c->n_prod);
+  if (rc) return rc;
+  if (ms_prop) *ms_prop = c->ms_prop;
+  if (n_prop) *n_prop = c->n_prop;
+  if (ms_prod) *ms_prod = c->ms_prod;
+  if (n_prod) *n_prod = c->n_prod;
+  c->ms_prop = c->ms_prod = 0;
+  c->n_prop = c->n_prod = 0;
+  return NBP_OK;
+}
+nbp_status nbp_diag_read(nbp_ctx *c, nbp_diag *out, int32_t reset) {
+  if (!c || !out) return fail(NBP_ERR_ARG, "null argument");
+  nbp_counters h;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(&h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+  out->solves = (int64_t)h.solves;
+  out->nonconverged = (int64_t)h.nonconverged;
+  out->nan_results = (int64_t)h.nan_results;
+  out->residual_evals = (int64_t)h.residual_evals;
+  if (reset) HIPCHK(hipMemset(c->counters, 0, sizeof(h)));
+  return NBP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,640 @@
+// nbp_device.h -- CDNA4 (gfx950) device code for libnbp.
+//
+// Hand-written HIP for the per-clique nonparametric Chapman-Kolmogorov hot path of
+// IncrementalInference.jl (IIF).  Two kernels do all the arithmetic:
+//
+//   nbp_proposal_kernel : one workgroup per `approxConvBelief` (ApproxConv.jl:4-45)
+//                         = measurement sampling + hypothesis recipe + entropy injection +
+//                           per-particle numerical solve + LCV bandwidth fit.
+//   nbp_product_kernel  : one workgroup per `AMP.manifoldProduct` (GraphProductOperations.jl:53-60)
+//                         = KD-tree build + multiscale Gibbs label sampling + product draw +
+//                           LCV bandwidth fit + belief write-back.
+//
+// Mapping: one lane per particle (wave64; workgroup = roundup(N,64) lanes), particle coordinates
+// SoA in HBM (coalesced 8 B/lane loads), every operand staged once into LDS, cross-lane
+// reductions with DPP/shuffle inside a wave and a fixed-order LDS tree across waves (bitwise
+// reproducible run to run).  No MFMA: this is particle-wise nonlinear residual evaluation and
+// O(N^2) kernel sums in FP64, not a dense contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nbp.h"
+
+#define NBP_PI 3.14159265358979323846
+#define NBP_TWO_PI 6.28318530717958647692
+
+// RNG purposes -- shared contract with the CPU oracle (DESIGN.md "RNG")
+#define PURP_MEAS 1
+#define PURP_MIXLBL 2
+#define PURP_HYPO 3
+#define PURP_ENTROPY 4
+#define PURP_KDESEL 5
+#define PURP_KDENOISE 6
+#define PURP_PGIBBS 9
+#define PURP_PFINAL 10
+#define NBP_TAG 0x4E4250u
+
+#define NBP_MAXLEVELS 12
+
+// Level tables of the balanced KD-tree over N leaves: data-independent, built once per context.
+struct nbp_levels {
+  int32_t N, L;                       // L = depth (levels 0..L)
+  int32_t cnt[NBP_MAXLEVELS];         // nodes per level
+  int32_t off[NBP_MAXLEVELS];         // offset of the level in the node arrays
+  const int32_t *node_lo;             // [total] first leaf position of the node
+  const int32_t *node_hi;             // [total] one past the last
+  const int32_t *node_child;          // [total] index (within the next level) of the LAST child
+  const int32_t *pos_node;            // [(L+1)*N] node (within its level) owning position i
+  const double *node_logw;            // [total] log((hi-lo)/N)
+};
+
+struct nbp_counters {
+  unsigned long long solves, nonconverged, nan_results, residual_evals;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u01_from(uint32_t lo, uint32_t hi) {
+  unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  return ((double)(v >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void uniform_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k,
+                                             double &ua, double &ub) {
+  uint32_t o[4];
+  philox4x32_10(n, purpose, k, NBP_TAG, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  ua = u01_from(o[0], o[1]);
+  ub = u01_from(o[2], o[3]);
+}
+
+__device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k,
+                                            double &na, double &nb) {
+  double ua, ub;
+  uniform_pair(seed, n, purpose, k, ua, ub);
+  double r = sqrt(-2.0 * log(ua));
+  double th = NBP_TWO_PI * ub;
+  double s, c;
+  sincos(th, &s, &c);
+  na = r * c;
+  nb = r * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// manifolds in tangent coordinates at the identity
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mani_dim(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
+__device__ __forceinline__ bool is_circ(int m, int d) {
+  return (m == NBP_CIRCULAR && d == 0) || (m == NBP_SE2 && d == 2);
+}
+// Manifolds.sym_rem -> [-pi, pi); exact identity on the principal interval
+__device__ __forceinline__ double wrap_pi(double a) {
+  if (a >= -NBP_PI && a < NBP_PI) return a;
+  double r = fmod(a + NBP_PI, NBP_TWO_PI);
+  if (r < 0) r += NBP_TWO_PI;
+  return r - NBP_PI;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workgroup reductions: wave64 butterfly + fixed-order combine across waves (deterministic)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// `red` = LDS scratch of >= 16 doubles.  All threads of the block must call.
+__device__ __forceinline__ double block_sum(double v, double *red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double t = red[0];
+  for (int i = 1; i < nw; i++) t += red[i];
+  return t;
+}
+__device__ __forceinline__ double block_min(double v, double *red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_min(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double t = red[0];
+  for (int i = 1; i < nw; i++) t = fmin(t, red[i]);
+  return t;
+}
+__device__ __forceinline__ double block_max(double v, double *red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double t = red[0];
+  for (int i = 1; i < nw; i++) t = fmax(t, red[i]);
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics: mean(M, pts, GeodesicInterpolation()) and calcStdBasicSpread
+// (services/VariableStatistics.jl:22-36).  x = LDS or global SoA [d*stride + n].
+// Euclidean coordinates: arithmetic mean by tree reduction (equal to the running mean up to
+// rounding).  Circular coordinates: the running geodesic interpolation is order dependent, so lane
+// 0 walks it sequentially exactly like Manifolds.jl does.
+// ------------------------------------------------------------------------------------------------
+__device__ double mean_geodesic_coord(const double *x, int N, int manifold, int d, double *red) {
+  double mu;
+  if (is_circ(manifold, d)) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double m = x[0];
+      for (int i = 1; i < N; i++) {
+        double dl = wrap_pi(x[i] - m);
+        m = wrap_pi(m + dl / (double)(i + 1));
+      }
+      red[15] = m;
+    }
+    __syncthreads();
+    mu = red[15];
+  } else {
+    double v = (threadIdx.x < N) ? x[threadIdx.x] : 0.0;
+    mu = block_sum(v, red) / (double)N;
+  }
+  return mu;
+}
+
+// default mean(M, pts): arithmetic / extrinsic circular mean
+__device__ double mean_default_coord(const double *x, int N, int manifold, int d, double *red) {
+  if (is_circ(manifold, d)) {
+    double s = 0, c = 0;
+    if (threadIdx.x < N) sincos(x[threadIdx.x], &s, &c);
+    double ss = block_sum(s, red), sc = block_sum(c, red);
+    return atan2(ss, sc);
+  }
+  double v = (threadIdx.x < N) ? x[threadIdx.x] : 0.0;
+  return block_sum(v, red) / (double)N;
+}
+
+__device__ double std_basic_spread(const double *x, int stride, int N, int manifold, double *red) {
+  const int D = mani_dim(manifold);
+  double acc = 0;
+  for (int d = 0; d < D; d++) {
+    double mu = mean_geodesic_coord(x + d * stride, N, manifold, d, red);
+    if (threadIdx.x < N) {
+      double dl = x[d * stride + threadIdx.x] - mu;
+      if (is_circ(manifold, d)) {
+        dl = wrap_pi(dl);
+        acc += (manifold == NBP_SE2 ? 2.0 : 1.0) * dl * dl;
+      } else
+        acc += dl * dl;
+    }
+  }
+  double sg = sqrt(block_sum(acc, red) / (double)(N - 1));
+  return (1e-10 < sg) ? sg : 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual functors -> sum(r.^2)   (CalcFactorNormSq, NumericalCalculations.jl:386-396)
+// ------------------------------------------------------------------------------------------------
+struct objective_t {
+  int kind, manifold, D, solve_b;
+  double z[3], other[3];
+  unsigned int evals;
+};
+
+__device__ __forceinline__ double residual_normsq(int kind, int D, const double *z, const double *a, const double *b) {
+  double acc = 0;
+  switch (kind) {
+  case NBP_F_LINREL:  // Factors/LinearRelative.jl:42-49
+    for (int d = 0; d < D; d++) {
+      double r = z[d] - (b[d] - a[d]);
+      acc += r * r;
+    }
+    break;
+  case NBP_F_CIRCULAR: {  // Factors/Circular.jl:24-28
+    double r = wrap_pi((a[0] + z[0]) - b[0]);
+    acc = r * r;
+    break;
+  }
+  case NBP_F_SE2: {  // Factors/GenericFunctions.jl:39-44
+    double s, c;
+    sincos(a[2], &s, &c);
+    double r0 = (a[0] + c * z[0] - s * z[1]) - b[0];
+    double r1 = (a[1] + s * z[0] + c * z[1]) - b[1];
+    double r2 = wrap_pi((a[2] + z[2]) - b[2]);
+    acc = r0 * r0 + r1 * r1 + r2 * r2;
+    break;
+  }
+  case NBP_F_EUCLIDDIST: {  // Factors/EuclidDistance.jl:20
+    double q = 0;
+    for (int d = 0; d < D; d++) q += (b[d] - a[d]) * (b[d] - a[d]);
+    double r = z[0] - sqrt(q);
+    acc = r * r;
+    break;
+  }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ double objective(objective_t &o, const double *x) {
+  o.evals++;
+  return o.solve_b ? residual_normsq(o.kind, o.D, o.z, o.other, x) : residual_normsq(o.kind, o.D, o.z, x, o.other);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Optim.NelderMead restated (Gao-Han adaptive parameters, AffineSimplexer a=0.025 b=0.5,
+// g_tol 1e-8 on nmobjective, 1000 iterations) -- NumericalCalculations.jl:108,122-126.
+// One lane = one particle; the simplex lives in registers (DN is a compile-time constant).
+// ------------------------------------------------------------------------------------------------
+template <int DN>
+__device__ __forceinline__ void nm_sort(const double (&f)[DN + 1], int (&ord)[DN + 1]) {
+#pragma unroll
+  for (int i = 0; i <= DN; i++) ord[i] = i;
+#pragma unroll
+  for (int i = 1; i <= DN; i++) {  // stable insertion sort, fully unrolled
+#pragma unroll
+    for (int j = i; j >= 1; j--) {
+      bool sw = f[ord[j - 1]] > f[ord[j]];
+      int a = ord[j - 1], b = ord[j];
+      ord[j - 1] = sw ? b : a;
+      ord[j] = sw ? a : b;
+    }
+  }
+}
+
+template <int DN>
+__device__ __forceinline__ double nm_objective(const double (&f)[DN + 1]) {
+  double a = 0;
+#pragma unroll
+  for (int i = 0; i <= DN; i++) a += f[i];
+  a /= (double)(DN + 1);
+  double v = 0;
+#pragma unroll
+  for (int i = 0; i <= DN; i++) v += (f[i] - a) * (f[i] - a);
+  return sqrt(v / (double)DN);
+}
+
+// small helpers to read/write simplex rows by a runtime index without spilling to scratch
+template <int DN>
+__device__ __forceinline__ void sx_get(const double (&sx)[DN + 1][DN], int i, double (&v)[DN]) {
+#pragma unroll
+  for (int d = 0; d < DN; d++) {
+    double t = sx[0][d];
+#pragma unroll
+    for (int q = 1; q <= DN; q++) t = (i == q) ? sx[q][d] : t;
+    v[d] = t;
+  }
+}
+template <int DN>
+__device__ __forceinline__ void sx_set(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int i, const double (&v)[DN], double fv) {
+#pragma unroll
+  for (int q = 0; q <= DN; q++) {
+    if (i == q) {
+#pragma unroll
+      for (int d = 0; d < DN; d++) sx[q][d] = v[d];
+      f[q] = fv;
+    }
+  }
+}
+template <int DN>
+__device__ __forceinline__ double f_get(const double (&f)[DN + 1], int i) {
+  double t = f[0];
+#pragma unroll
+  for (int q = 1; q <= DN; q++) t = (i == q) ? f[q] : t;
+  return t;
+}
+
+template <int DN>
+__device__ bool nelder_mead(objective_t &o, double *x) {
+  constexpr int M = DN + 1;
+  const double alpha = 1.0, beta = 1.0 + 2.0 / DN, gamma = 0.75 - 1.0 / (2.0 * DN), delta = 1.0 - 1.0 / DN;
+  double sx[M][DN], f[M];
+  int ord[M];
+#pragma unroll
+  for (int i = 0; i < M; i++)
+#pragma unroll
+    for (int d = 0; d < DN; d++) sx[i][d] = x[d];
+#pragma unroll
+  for (int j = 0; j < DN; j++) sx[j + 1][j] = (1.0 + 0.5) * sx[j + 1][j] + 0.025;
+#pragma unroll
+  for (int i = 0; i < M; i++) f[i] = objective(o, sx[i]);
+  nm_sort<DN>(f, ord);
+  bool converged = nm_objective<DN>(f) <= 1e-8;
+  int it = 0;
+  while (!converged && it < 1000) {
+    it++;
+    bool shrink = false;
+    const int ih = ord[M - 1];
+    double xc[DN], xl[DN], xh[DN], xr[DN], xcache[DN];
+    sx_get<DN>(sx, ih, xh);
+    sx_get<DN>(sx, ord[0], xl);
+#pragma unroll
+    for (int d = 0; d < DN; d++) {
+      double s = 0;
+#pragma unroll
+      for (int i = 0; i < M; i++) s += (i != ih) ? sx[i][d] : 0.0;
+      xc[d] = s / (double)DN;
+    }
+    const double f_lowest = f_get<DN>(f, ord[0]), f_second = f_get<DN>(f, ord[DN - 1]), f_highest = f_get<DN>(f, ih);
+#pragma unroll
+    for (int d = 0; d < DN; d++) xr[d] = xc[d] + alpha * (xc[d] - xh[d]);
+    const double f_reflect = objective(o, xr);
+    if (f_reflect < f_lowest) {
+#pragma unroll
+      for (int d = 0; d < DN; d++) xcache[d] = xc[d] + beta * (xr[d] - xc[d]);
+      const double f_expand = objective(o, xcache);
+      if (f_expand < f_reflect) sx_set<DN>(sx, f, ih, xcache, f_expand);
+      else sx_set<DN>(sx, f, ih, xr, f_reflect);
+#pragma unroll
+      for (int i = M - 1; i >= 1; i--) ord[i] = ord[i - 1];
+      ord[0] = ih;
+    } else if (f_reflect < f_second) {
+      sx_set<DN>(sx, f, ih, xr, f_reflect);
+      nm_sort<DN>(f, ord);
+    } else {
+      const bool outside = f_reflect < f_highest;
+      const double sgn = outside ? gamma : -gamma;
+#pragma unroll
+      for (int d = 0; d < DN; d++) xcache[d] = xc[d] + sgn * (xr[d] - xc[d]);
+      const double fc = objective(o, xcache);
+      if (fc < (outside ? f_reflect : f_highest)) {
+        sx_set<DN>(sx, f, ih, xcache, fc);
+        nm_sort<DN>(f, ord);
+      } else
+        shrink = true;
+    }
+    if (shrink) {
+#pragma unroll
+      for (int q = 0; q < M; q++) {
+        if (q != ord[0]) {
+          double v[DN];
+#pragma unroll
+          for (int d = 0; d < DN; d++) v[d] = xl[d] + delta * (sx[q][d] - xl[d]);
+          double fv = objective(o, v);
+#pragma unroll
+          for (int d = 0; d < DN; d++) sx[q][d] = v[d];
+          f[q] = fv;
+        }
+      }
+      nm_sort<DN>(f, ord);
+    }
+    converged = nm_objective<DN>(f) <= 1e-8;
+  }
+  // after_while!: the better of the best vertex and the centroid of the DN best
+  nm_sort<DN>(f, ord);
+  const int ih = ord[M - 1];
+  double xc[DN], xb[DN];
+#pragma unroll
+  for (int d = 0; d < DN; d++) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++) s += (i != ih) ? sx[i][d] : 0.0;
+    xc[d] = s / (double)DN;
+  }
+  const double fcen = objective(o, xc);
+  sx_get<DN>(sx, ord[0], xb);
+  const bool usec = fcen < f_get<DN>(f, ord[0]);
+#pragma unroll
+  for (int d = 0; d < DN; d++) x[d] = usec ? xc[d] : xb[d];
+  return converged;
+}
+
+// Optim.BFGS for a 1-D decision variable (islen1 branch), central finite differences,
+// Armijo / quadratic-interpolation line search (documented deviation from HagerZhang).
+__device__ __forceinline__ double fd_grad1(objective_t &o, double x) {
+  double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x));
+  double xp = x + h, xm = x - h;
+  return (objective(o, &xp) - objective(o, &xm)) / (2.0 * h);
+}
+
+__device__ bool bfgs_1d(objective_t &o, double *x) {
+  double xc = *x, fx = objective(o, &xc), g = fd_grad1(o, xc), H = 1.0;
+  bool converged = false;
+  for (int it = 0; it < 1000; it++) {
+    if (fabs(g) <= 1e-8) { converged = true; break; }
+    double s = -H * g;
+    if (s * g >= 0) { H = 1.0; s = -g; }
+    double al = 1.0, dphi0 = g * s, xn = xc, fn = fx;
+    bool ok = false;
+    for (int ls = 0; ls < 50; ls++) {
+      xn = xc + al * s;
+      fn = objective(o, &xn);
+      if (fn <= fx + 1e-4 * al * dphi0) { ok = true; break; }
+      double aq = -dphi0 * al * al / (2.0 * (fn - fx - dphi0 * al));
+      if (!(aq >= 0.1 * al)) aq = 0.1 * al;
+      if (aq > 0.5 * al) aq = 0.5 * al;
+      al = aq;
+    }
+    if (!ok) break;
+    double gn = fd_grad1(o, xn), dx = xn - xc, dg = gn - g;
+    if (dx == 0.0) { converged = fabs(gn) <= 1e-8; break; }
+    if (dx * dg > 0) H = dx / dg;
+    xc = xn; fx = fn; g = gn;
+  }
+  *x = xc;
+  return converged;
+}
+
+// _solveCCWNumeric! for one particle (NumericalCalculations.jl:413-452, :90-133)
+__device__ void solve_particle(int kind, int manifold, const double *z, const double *other, int solve_b,
+                               double *x, unsigned int &n_solves, unsigned int &n_nonconv,
+                               unsigned int &n_nan, unsigned int &n_evals) {
+  objective_t o;
+  o.kind = kind; o.manifold = manifold; o.D = mani_dim(manifold); o.solve_b = solve_b; o.evals = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
+  double xc[3] = {x[0], x[1], x[2]};
+  bool conv;
+  if (o.D == 1) conv = bfgs_1d(o, xc);
+  else if (o.D == 2) conv = nelder_mead<2>(o, xc);
+  else conv = nelder_mead<3>(o, xc);
+  n_solves++;
+  n_evals += o.evals;
+  if (!conv) n_nonconv++;
+  bool bad = false;
+  for (int d = 0; d < o.D; d++) bad |= isnan(xc[d]);
+  if (bad) { n_nan++; return; }
+  for (int d = 0; d < o.D; d++) x[d] = is_circ(manifold, d) ? wrap_pi(xc[d]) : xc[d];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bandwidth: leave-one-out likelihood cross validation, golden-section search (KDE.jl `:lcv`).
+// x = LDS array of N coordinates.  Lane i owns point i and walks all j (LDS broadcast reads);
+// the N terms are tree-reduced.  O(N^2) exp per evaluation, ~16-21 evaluations per coordinate.
+// ------------------------------------------------------------------------------------------------
+__device__ double neg_loo_ll(const double *x, int N, bool circ, double h, double *red) {
+  const double inv2h2 = 1.0 / (2.0 * h * h);
+  const double lognorm = log(h) + 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
+  double term = 0;
+  const int i = threadIdx.x;
+  if (i < N) {
+    const double xi = x[i];
+    double s = 0;
+    if (circ) {
+      for (int j = 0; j < N; j++) {
+        double d = wrap_pi(xi - x[j]);
+        double e = exp(-d * d * inv2h2);
+        s += (j == i) ? 0.0 : e;
+      }
+    } else {
+      for (int j = 0; j < N; j++) {
+        double d = xi - x[j];
+        double e = exp(-d * d * inv2h2);
+        s += (j == i) ? 0.0 : e;
+      }
+    }
+    if (s < 1e-300) s = 1e-300;
+    term = log(s) - lognorm;
+  }
+  return -block_sum(term, red) / (double)N;
+}
+
+__device__ double lcv_bandwidth_1d(const double *x, int N, bool circ, double *red) {
+  const int i = threadIdx.x;
+  double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
+  if (i < N) {
+    lo = hi = x[i];
+    if (i + 1 < N) {
+      double d = x[i] - x[i + 1];
+      if (circ) d = wrap_pi(d);
+      mn = fabs(d);
+    }
+  }
+  double minm = block_min(mn, red);
+  lo = block_min(lo, red);
+  hi = block_max(hi, red);
+  double maxm = circ ? NBP_TWO_PI : (hi - lo);
+  if (!(maxm > 0)) return 1.0;
+  if (minm < 1e-6 * maxm) minm = 1e-6 * maxm;
+  const double sc = 0.5 * (minm + maxm);
+  const double ax = minm / sc, bx = 1.0, cx = maxm / sc;
+  const double R = 0.61803399, C = 1.0 - R, tol = 1e-2;
+  double x0 = ax, x3 = cx, x1, x2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
+  else { x2 = bx; x1 = bx - C * (bx - ax); }
+  double f1 = neg_loo_ll(x, N, circ, x1 * sc, red), f2 = neg_loo_ll(x, N, circ, x2 * sc, red);
+  while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, circ, x2 * sc, red); }
+    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, circ, x1 * sc, red); }
+  }
+  return (f1 < f2 ? x1 : x2) * sc;
+}
+
+// rand(Categorical(p)) by inverse CDF on one uniform
+__device__ __forceinline__ int categorical(const double *p, int n, double u) {
+  double c = 0;
+  int last = 0;
+  for (int i = 0; i < n; i++) {
+    if (p[i] > 0) last = i;
+    c += p[i];
+    if (u < c) return i;
+  }
+  return last;
+}
+
+// ------------------------------------------------------------------------------------------------
+// _prepareHypoRecipe! (ExplicitDiscreteMarginalizations.jl:142-289), integer part.  1-based
+// variable indices like the reference; hypothesis 0 = null hypothesis.
+// ------------------------------------------------------------------------------------------------
+struct recipe_t {
+  int ngroups;
+  int hypo[NBP_MAXV + 1];
+  int nact[NBP_MAXV + 1];
+  int act[NBP_MAXV + 1][NBP_MAXV];
+  int empty[NBP_MAXV + 1];
+  int ncertain;
+  int certain[NBP_MAXV];
+  double cat_p[NBP_MAXV + 1];
+  int cat_first, ncat;
+};
+
+__device__ inline bool in_list(const int *l, int n, int v) {
+  for (int i = 0; i < n; i++)
+    if (l[i] == v) return true;
+  return false;
+}
+__device__ inline void sorted_union(const int *a, int na, int v, int *out, int *nout) {
+  int n = 0;
+  bool placed = in_list(a, na, v);
+  for (int i = 0; i < na; i++) {  // `a` (certainidx) is ascending
+    if (!placed && v < a[i]) { out[n++] = v; placed = true; }
+    out[n++] = a[i];
+  }
+  if (!placed) out[n++] = v;
+  *nout = n;
+}
+
+__device__ void build_recipe(const nbp_proposal_desc *d, recipe_t *R) {
+  const int nvars = d->nvars, sf1 = d->sfidx + 1;
+  R->ncertain = 0;
+  for (int g = 0; g <= NBP_MAXV; g++) { R->nact[g] = 0; R->empty[g] = 0; R->hypo[g] = 0; }
+  if (!d->has_multihypo) {
+    R->ncertain = nvars;
+    for (int i = 0; i < nvars; i++) R->certain[i] = i + 1;
+    R->ngroups = nvars + 1;
+    for (int g = 0; g <= nvars; g++) {
+      R->hypo[g] = g;
+      if (g == 0) { R->nact[g] = 1; R->act[g][0] = sf1; }
+      else if (g == 1) { R->nact[g] = nvars; for (int i = 0; i < nvars; i++) R->act[g][i] = i + 1; }
+      else R->empty[g] = 1;
+    }
+    R->ncat = 2; R->cat_first = 0;
+    R->cat_p[0] = d->nullhypo; R->cat_p[1] = 1.0 - d->nullhypo;
+    return;
+  }
+  int unc[NBP_MAXV], nunc = 0;
+  for (int i = 0; i < nvars; i++) {
+    if (d->multihypo[i] == 0.0) R->certain[R->ncertain++] = i + 1;
+    else if (0.0 < d->multihypo[i]) unc[nunc++] = i + 1;
+  }
+  const bool sfunc = in_list(unc, nunc, sf1), sfincer = in_list(R->certain, R->ncertain, sf1);
+  int np = 0, pidx0;
+  if (sfunc) {
+    double nhw = (double)(nunc + 1), tot = 0;
+    R->cat_p[np++] = 1.0 / nhw;
+    for (int i = 0; i < nvars; i++) R->cat_p[np++] = (double)nunc / nhw * d->multihypo[i];
+    for (int i = 0; i < np; i++) tot += R->cat_p[i];
+    for (int i = 0; i < np; i++) R->cat_p[i] /= tot;
+    pidx0 = 0;
+  } else {
+    for (int i = 0; i < nvars; i++) R->cat_p[np++] = d->multihypo[i];
+    pidx0 = 1;
+  }
+  R->ncat = np; R->cat_first = pidx0; R->ngroups = np;
+  for (int g = 0; g < np; g++) {
+    const int pidx = pidx0 + g;
+    const bool pidxincer = in_list(R->certain, R->ncertain, pidx);
+    R->hypo[g] = pidx;
+    if (!pidxincer && sfincer && pidx != 0) sorted_union(R->certain, R->ncertain, pidx, R->act[g], &R->nact[g]);
+    else if (((pidxincer && !sfincer) || sf1 == pidx) && pidx != 0) sorted_union(R->certain, R->ncertain, sf1, R->act[g], &R->nact[g]);
+    else if (pidxincer && sfincer && pidx != 0) { R->nact[g] = 0; R->empty[g] = 1; }
+    else if (!pidxincer && !sfincer && pidx != 0) { R->nact[g] = nunc; for (int i = 0; i < nunc; i++) R->act[g][i] = unc[i]; }
+    else { R->nact[g] = 1; R->act[g][0] = sf1; }
+  }
+}

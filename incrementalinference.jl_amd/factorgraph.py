@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's graph API for the hot path.
+
+Names follow IncrementalInference.jl / DistributedFactorGraphs.jl (Julia `foo!` -> Python `foo`):
+variables  ContinuousScalar, ContinuousEuclid(N), Circular, SpecialEuclidean2
+           (src/Variables/DefaultVariables.jl:9-19,37-38,52; test/testSpecialEuclidean2Mani.jl:14)
+factors    Prior, PriorCircular, ManifoldPrior, LinearRelative, CircularCircular, ManifoldFactor,
+           EuclidDistance, Mixture, MsgPrior   (src/Factors/*.jl)
+graph      initfg, addVariable, addFactor(multihypo=, nullhypo=, inflation=), getVariable, ls, lsf
+           (src/services/FactorGraph.jl:587-632, 824-875)
+params     SolverParams with the reference defaults (src/entities/SolverParams.jl:12-75)
+
+Only bookkeeping lives here; all particle arithmetic happens in libnbp behind include/nbp.h.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+
+# ------------------------------------------------------------------------------------------------
+# distributions (only what the factor set samples from)
+# ------------------------------------------------------------------------------------------------
+class Normal:
+    def __init__(self, mu=0.0, sigma=1.0):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def mean_sqrtcov(self):
+        return np.array([self.mu]), np.array([[self.sigma]])
+
+
+class MvNormal:
+    """MvNormal(mu, Sigma).  Like Distributions.jl, a vector second argument is a vector of
+    standard deviations (`MvNormal(mu, sigma::Vector)`), a matrix is the covariance."""
+
+    def __init__(self, mu, cov):
+        self.mu = np.atleast_1d(np.asarray(mu, dtype=float))
+        cov = np.asarray(cov, dtype=float)
+        if cov.ndim == 0:
+            cov = np.eye(self.mu.size) * float(cov) ** 2
+        elif cov.ndim == 1:
+            cov = np.diag(cov ** 2)
+        self.cov = cov
+
+    def mean_sqrtcov(self):
+        return self.mu, np.linalg.cholesky(self.cov)
+
+
+# ------------------------------------------------------------------------------------------------
+# variable types
+# ------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class VariableType:
+    name: str
+    manifold: int
+
+    @property
+    def dim(self):
+        return abi.MANIFOLD_DIM[self.manifold]
+
+    @property
+    def P(self):
+        return abi.MANIFOLD_P[self.manifold]
+
+    def identity(self):
+        """getPointIdentity(varType) -- ManifoldsExtentions.jl:102-155"""
+        if self.manifold == abi.SE2:
+            return np.array([0.0, 0.0, 1.0, 0.0, 0.0, 1.0])
+        return np.zeros(self.P)
+
+
+ContinuousScalar = VariableType("ContinuousScalar", abi.EUCLID1)
+Circular = VariableType("Circular", abi.CIRCULAR)
+SpecialEuclidean2 = VariableType("SpecialEuclidean2", abi.SE2)
+
+
+def ContinuousEuclid(n):
+    return VariableType(f"ContinuousEuclid{{{n}}}", {1: abi.EUCLID1, 2: abi.EUCLID2, 3: abi.EUCLID3}[n])
+
+
+# ------------------------------------------------------------------------------------------------
+# factors
+# ------------------------------------------------------------------------------------------------
+class _Factor:
+    kind = 0
+    is_prior = False
+    zdim = None  # None = dimension of the variable
+
+    def components(self):
+        """list of (weight, mean, sqrtcov) measurement components"""
+        mu, L = self.Z.mean_sqrtcov()
+        return [(1.0, mu, L)]
+
+
+class Prior(_Factor):
+    """Prior(Z): r = z - x   (Factors/DefaultPrior.jl:17)"""
+    kind, is_prior = abi.F_PRIOR, True
+
+    def __init__(self, Z):
+        self.Z = Z
+
+
+class PriorCircular(Prior):
+    """PriorCircular(Z)   (Factors/Circular.jl:56-74)"""
+
+
+class ManifoldPrior(_Factor):
+    """ManifoldPrior(M, p, Z): point = retract(p, hat(rand(Z)))   (Factors/GenericFunctions.jl:181-214).
+    `p` is given in tangent coordinates at the identity ((x, y, theta) for SE(2))."""
+    kind, is_prior = abi.F_PRIOR, True
+
+    def __init__(self, p, Z):
+        self.p, self.Z = np.atleast_1d(np.asarray(p, dtype=float)), Z
+
+    def components(self):
+        mu, L = self.Z.mean_sqrtcov()
+        return [(1.0, self.p + mu, L)]
+
+
+class LinearRelative(_Factor):
+    """LinearRelative(Z): r = z - (x2 - x1)   (Factors/LinearRelative.jl:42-49)"""
+    kind = abi.F_LINREL
+
+    def __init__(self, Z):
+        self.Z = Z
+
+
+class CircularCircular(_Factor):
+    """CircularCircular(Z)   (Factors/Circular.jl:24-28)"""
+    kind, zdim = abi.F_CIRCULAR, 1
+
+    def __init__(self, Z):
+        self.Z = Z
+
+
+class ManifoldFactor(_Factor):
+    """ManifoldFactor(SpecialEuclidean(2), Z), Z on the Lie algebra (dx, dy, dtheta)
+    (Factors/GenericFunctions.jl:39-44, 98-100)"""
+    kind, zdim = abi.F_SE2, 3
+
+    def __init__(self, Z):
+        self.Z = Z
+
+
+class EuclidDistance(_Factor):
+    """EuclidDistance(Z): r = z - ||x2 - x1||   (Factors/EuclidDistance.jl:20)"""
+    kind, zdim = abi.F_EUCLIDDIST, 1
+
+    def __init__(self, Z):
+        self.Z = Z
+
+
+class Mixture(_Factor):
+    """Mixture(mechanics, components, diversity): per-particle component label ~ Categorical
+    (Factors/Mixture.jl:38-155).  `mechanics` is a factor class or instance."""
+
+    def __init__(self, mechanics, components, diversity):
+        self.mechanics = mechanics(components[0]) if isinstance(mechanics, type) else mechanics
+        self.comps = list(components)
+        self.diversity = np.asarray(diversity, dtype=float)
+        if len(self.comps) != self.diversity.size or len(self.comps) > abi.MAXC:
+            raise ValueError("Mixture: components/diversity mismatch or too many components")
+        self.kind, self.is_prior, self.zdim = self.mechanics.kind, self.mechanics.is_prior, self.mechanics.zdim
+
+    def components(self):
+        out = []
+        for w, z in zip(self.diversity / self.diversity.sum(), self.comps):
+            mu, L = z.mean_sqrtcov()
+            if isinstance(self.mechanics, ManifoldPrior):
+                mu = self.mechanics.p + mu
+            out.append((float(w), mu, L))
+        return out
+
+
+class MsgPrior(_Factor):
+    """MsgPrior(belief): tree message as a prior (Factors/MsgPrior.jl:10-36,
+    services/TreeMessageUtils.jl:86-89).  `slot` holds the TreeBelief (val + bw) on the device."""
+    kind, is_prior = abi.F_MSGPRIOR, True
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def components(self):
+        return [(1.0, np.zeros(1), np.zeros((1, 1)))]
+
+
+# ------------------------------------------------------------------------------------------------
+# SolverParams (entities/SolverParams.jl:12-75) -- hot-path knobs only
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class SolverParams:
+    N: int = 100
+    spreadNH: float = 3.0
+    inflation: float = 5.0
+    nullSurplusAdd: float = 0.3
+    inflateCycles: int = 3
+    gibbsIters: int = 3
+    alwaysFreshMeasurements: bool = True
+    graphinit: bool = True
+    upsolve: bool = True
+    downsolve: bool = True
+    productNiter: int = 1  # AMP.manifoldProduct(...; Niter=1), GraphProductOperations.jl:56
+
+
+@dataclass
+class DFGVariable:
+    label: str
+    varType: VariableType
+    initialized: bool = False
+    val: np.ndarray = None  # N x P points (host copy of the posterior)
+    bw: np.ndarray = None
+    solvedCount: int = 0
+    ismargin: bool = False
+
+
+@dataclass
+class DFGFactor:
+    label: str
+    variables: list
+    fnc: _Factor
+    multihypo: np.ndarray = None  # parsed Categorical p (certain -> 0.0) or None
+    nullhypo: float = 0.0
+    inflation: float = 5.0
+    tags: set = field(default_factory=set)
+
+    @property
+    def isMultihypo(self):
+        return self.multihypo is not None
+
+
+def parseusermultihypo(multihypo, nullhypo):
+    """services/FactorGraph.jl:634-655"""
+    if multihypo is None or len(multihypo) == 0:
+        return None, float(nullhypo)
+    mh = np.asarray(multihypo, dtype=float).copy()
+    mh[mh > 1 - 1e-10] = 0.0
+    frac = mh.sum() % 1
+    if not (abs(frac) < 1e-10 or 1 - 1e-10 < frac):
+        raise ValueError("ensure multihypo sums to a (or nearly, 1e-10) integer, see #1086")
+    if not np.isclose(mh[mh > 1e-10].sum(), 1.0):
+        raise ValueError("fractional multihypo entries must sum to 1")
+    mh /= mh.sum()
+    return mh, float(nullhypo)
+
+
+class FactorGraph:
+    """In-memory graph (the LocalDFG role)."""
+
+    def __init__(self, solverParams=None):
+        self.solverParams = solverParams or SolverParams()
+        self.variables = {}
+        self.factors = {}
+        self._adj = {}  # variable label -> [factor labels] in insertion order
+
+    # -- DFG-style accessors -------------------------------------------------------------------
+    def ls(self, var=None):
+        return list(self.variables) if var is None else list(self._adj[var])
+
+    def lsf(self):
+        return list(self.factors)
+
+    def listNeighbors(self, label):
+        return list(self._adj[label]) if label in self.variables else list(self.factors[label].variables)
+
+    def getVariable(self, label):
+        return self.variables[label]
+
+    def getFactor(self, label):
+        return self.factors[label]
+
+    def getVal(self, label):
+        return self.variables[label].val
+
+    def isInitialized(self, label):
+        return self.variables[label].initialized
+
+
+def initfg(solverParams=None):
+    return FactorGraph(solverParams)
+
+
+def getSolverParams(fg):
+    return fg.solverParams
+
+
+def addVariable(fg, label, varType, N=None):
+    """addVariable!(dfg, label, varType)   (services/FactorGraph.jl:587-632)"""
+    if label in fg.variables:
+        raise KeyError(f"variable {label} already exists")
+    N = N or fg.solverParams.N
+    v = DFGVariable(label, varType, False, np.tile(varType.identity(), (N, 1)), np.zeros(varType.dim))
+    fg.variables[label] = v
+    fg._adj[label] = []
+    return v
+
+
+def addFactor(fg, variables, fnc, multihypo=None, nullhypo=0.0, inflation=None, label=None, tags=()):
+    """addFactor!(dfg, Xi, usrfnc; multihypo, nullhypo, inflation)   (services/FactorGraph.jl:824-875)"""
+    variables = list(variables)
+    for v in variables:
+        if v not in fg.variables:
+            raise KeyError(f"variable {v} not in graph")
+    if multihypo is not None and len(multihypo) and len(multihypo) != len(variables):
+        raise ValueError("When using multihypo=[...], the number of variables and multihypo probabilities must match.")
+    if fnc.is_prior and len(variables) != 1:
+        raise ValueError("priors are unary factors")
+    if len(variables) > abi.MAXV:
+        raise ValueError(f"at most {abi.MAXV} variables per factor")
+    mh, nh = parseusermultihypo(multihypo, nullhypo)
+    if label is None:
+        base = "".join(variables) + "f"
+        k = 1
+        while f"{base}{k}" in fg.factors:
+            k += 1
+        label = f"{base}{k}"
+    f = DFGFactor(label, variables, fnc, mh, nh,
+                  fg.solverParams.inflation if inflation is None else float(inflation), set(tags))
+    fg.factors[label] = f
+    for v in variables:
+        fg._adj[v].append(label)
+    return f

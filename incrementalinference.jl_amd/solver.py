@@ -1,0 +1,493 @@
+"""Host-side mirror of the reference's hot-path entry points, compiled to libnbp descriptor
+batches.  Julia `foo!` -> Python `foo`:
+
+  approxConvBelief / approxConv     src/services/ApproxConv.jl:4-47
+  proposalbeliefs (descriptor form) src/services/ApproxConv.jl:238-304
+  propagateBelief                   src/services/GraphProductOperations.jl:16-64
+  localProduct / localProductAndUpdate   :93-155
+  initAll / doautoinit              src/services/GraphInit.jl:132-199, 495-555
+  solveTree                         src/services/SolverAPI.jl:326-493, with the clique work of
+      upGibbsCliqueDensity (src/services/SolveTree.jl:164-239) and solveCliqDownFrontalProducts!
+      (src/CliqueStateMachine/services/CliqStateMachineUtils.jl:479-571) batched per tree level
+      into one device-resident program (the CliqueStateMachine's rendezvous order,
+      CliqueStateMachine.jl:221-234 / 617-629, becomes the stage order).
+
+Every function takes a `backend` class/instance implementing backend.HipBackend's interface; the
+default is the HIP library and there is no CPU fallback in this package.
+"""
+import time
+
+import numpy as np
+
+from . import abi, bayestree
+from .backend import HipBackend
+from .factorgraph import MsgPrior
+from .seeds import op_seed
+
+PASS_INIT, PASS_UP, PASS_DOWN, PASS_UNIT = 0, 1, 2, 3
+PRODUCT_ID = 0xFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# descriptor builders
+# ------------------------------------------------------------------------------------------------
+def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhidx_in=-1, mhidx_out=-1,
+                  skip_bandwidth=False, inflateCycles=None):
+    """One approxConvBelief(dfg, fct, target) as a libnbp descriptor (ApproxConv.jl:4-45 +
+    evalFactor kwargs, EvalFactor.jl:571-603)."""
+    sp = fg.solverParams
+    d = abi.ProposalDesc()
+    fnc = fct.fnc
+    vt = fg.getVariable(target).varType
+    d.factor_kind = fnc.kind
+    d.manifold = vt.manifold
+    d.out_slot = out_slot
+    d.inflate_cycles = sp.inflateCycles if inflateCycles is None else inflateCycles
+    d.mhidx_in, d.mhidx_out = mhidx_in, mhidx_out
+    d.skip_bandwidth = int(skip_bandwidth)
+    d.inflation = fct.inflation
+    d.spread_nh = sp.spreadNH
+    d.nullhypo = max(fct.nullhypo, nullSurplus)  # EvalFactor.jl:352
+    d.seed = seed
+    if isinstance(fnc, MsgPrior):
+        d.nvars, d.sfidx = 1, 0
+        d.var_slot[0] = slot_of(target)
+        d.var_slot[1] = fnc.slot
+        d.ncomp = 1
+        d.comp[0][0] = 1.0
+        return d
+    d.nvars = len(fct.variables)
+    d.sfidx = fct.variables.index(target)
+    for i, v in enumerate(fct.variables):
+        d.var_slot[i] = slot_of(v)
+    comps = fnc.components()
+    d.ncomp = len(comps)
+    for c, (w, mu, L) in enumerate(comps):
+        d.comp[c][0] = w
+        for i in range(min(3, len(mu))):
+            d.comp[c][1 + i] = mu[i]
+        for i in range(min(3, L.shape[0])):
+            for j in range(i + 1):
+                d.comp[c][4 + 3 * i + j] = L[i, j]
+    if fct.multihypo is not None:
+        d.has_multihypo = 1
+        for i, p in enumerate(fct.multihypo):
+            d.multihypo[i] = p
+    return d
+
+
+def product_desc(manifold, in_slots, out_slot, seed, niter=1, labels_out=-1):
+    d = abi.ProductDesc()
+    d.manifold, d.nfactors, d.niter, d.out_slot = manifold, len(in_slots), niter, out_slot
+    for i, s in enumerate(in_slots):
+        d.in_slot[i] = s
+    d.labels_out, d.seed = labels_out, seed
+    return d
+
+
+def _null_surplus(fg, factors):
+    """proposalbeliefs!, ApproxConv.jl:255-265: relative non-multihypo siblings of a multihypo
+    factor get nullSurplusAdd."""
+    ns = [0.0] * len(factors)
+    if any(f.isMultihypo for f in factors):
+        for i, f in enumerate(factors):
+            if not f.fnc.is_prior and not f.isMultihypo:
+                ns[i] = fg.solverParams.nullSurplusAdd
+    return ns
+
+
+def _make_backend(backend, N, n_slots, side_ints=0):
+    if backend is None:
+        backend = HipBackend
+    if isinstance(backend, type) or callable(backend) and not hasattr(backend, "slot_write"):
+        return backend(N, n_slots, side_ints=side_ints), True
+    return backend, False
+
+
+# ------------------------------------------------------------------------------------------------
+# unit level: factor seam and variable seam
+# ------------------------------------------------------------------------------------------------
+def approxConvBelief(fg, fctlabel, target, backend=None, seed=0, nullSurplus=0.0, mhidx=None, return_mhidx=False):
+    """approxConvBelief(dfg, fct, target) -> (points N x P, bandwidth D)   ApproxConv.jl:4-45.
+    The stored belief of `target` is never modified (CalcFactor.jl:543-548)."""
+    fct = fg.getFactor(fctlabel)
+    N = fg.solverParams.N
+    labels = list(fct.variables)
+    slot = {v: i for i, v in enumerate(labels)}
+    out = len(labels)
+    be, own = _make_backend(backend, N, out + 1, side_ints=2 * N)
+    try:
+        for v in labels:
+            var = fg.getVariable(v)
+            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+        mh_in = -1
+        if mhidx is not None:
+            be.side_write(0, np.asarray(mhidx, dtype=np.int32))
+            mh_in = 0
+        d = proposal_desc(fg, fct, target, slot.__getitem__, out, op_seed(seed, PASS_UNIT, 0, 0, 0),
+                          nullSurplus=nullSurplus, mhidx_in=mh_in, mhidx_out=N)
+        be.run_proposals([d])
+        pts, bw = be.slot_read(out, fg.getVariable(target).varType.manifold)
+        used = be.side_read(N, N)
+    finally:
+        if own:
+            be.close()
+    return (pts, bw, used) if return_mhidx else (pts, bw)
+
+
+def approxConv(fg, fctlabel, target, **kw):
+    """approxConv(dfg, fct, target) = getPoints(approxConvBelief(...))   ApproxConv.jl:47"""
+    return approxConvBelief(fg, fctlabel, target, **kw)[0]
+
+
+def propagateBelief(fg, destlbl, factors=None, backend=None, seed=0, return_proposals=False):
+    """propagateBelief(dfg, destvar, factors) -> ((pts, bw), ipc)   GraphProductOperations.jl:16-64:
+    one proposal per factor (proposalbeliefs!) then AMP.manifoldProduct(dens; Niter=1, N)."""
+    sp = fg.solverParams
+    N = sp.N
+    flabels = list(fg.ls(destlbl)) if factors is None else list(factors)
+    fcts = [fg.getFactor(f) for f in flabels]
+    if not fcts:
+        raise ValueError(f"propagateBelief: no factors for {destlbl}")
+    labels = []
+    for f in fcts:
+        for v in f.variables:
+            if v not in labels:
+                labels.append(v)
+    if destlbl not in labels:
+        labels.append(destlbl)
+    slot = {v: i for i, v in enumerate(labels)}
+    nv = len(labels)
+    be, own = _make_backend(backend, N, nv + len(fcts) + 1)
+    man = fg.getVariable(destlbl).varType.manifold
+    try:
+        for v in labels:
+            var = fg.getVariable(v)
+            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+        ns = _null_surplus(fg, fcts)
+        descs = [proposal_desc(fg, f, destlbl, slot.__getitem__, nv + i, op_seed(seed, PASS_UNIT, 0, 0, i + 1),
+                               nullSurplus=ns[i]) for i, f in enumerate(fcts)]
+        be.run_proposals(descs)
+        out = nv + len(fcts)
+        be.run_products([product_desc(man, [nv + i for i in range(len(fcts))], out,
+                                      op_seed(seed, PASS_UNIT, 0, 0, PRODUCT_ID), sp.productNiter)])
+        pts, bw = be.slot_read(out, man)
+        props = [be.slot_read(nv + i, man) for i in range(len(fcts))] if return_proposals else None
+    finally:
+        if own:
+            be.close()
+    ipc = np.full(fg.getVariable(destlbl).varType.dim, float(len(fcts)))  # ApproxConv.jl:298-303
+    if return_proposals:
+        return (pts, bw), ipc, props
+    return (pts, bw), ipc
+
+
+def localProduct(fg, sym, **kw):
+    """localProduct(dfg, sym) -> (product, proposals, factor labels, ipc)   GraphProductOperations.jl:93-120"""
+    lb = list(fg.ls(sym))
+    (pts, bw), ipc, props = propagateBelief(fg, sym, lb, return_proposals=True, **kw)
+    return (pts, bw), props, lb, ipc
+
+
+def setValKDE(fg, sym, pts, bw, setinit=True):
+    """setValKDE!(vari, mkd, setinit, ipc)   FactorGraph.jl:250-263"""
+    v = fg.getVariable(sym)
+    v.val, v.bw = np.array(pts, dtype=float), np.array(bw, dtype=float)
+    if setinit:
+        v.initialized = True
+
+
+def localProductAndUpdate(fg, sym, setkde=True, **kw):
+    """localProductAndUpdate!(dfg, sym, setkde)   GraphProductOperations.jl:136-155"""
+    (pts, bw), _, lbl, ipc = localProduct(fg, sym, **kw)
+    if setkde and len(pts):
+        setValKDE(fg, sym, pts, bw, False)
+    return (pts, bw), ipc, lbl
+
+
+# ------------------------------------------------------------------------------------------------
+# graph initialisation (GraphInit.jl:132-199, 495-555)
+# ------------------------------------------------------------------------------------------------
+def _init_plan(fg):
+    """Simulate initAll!'s sweep on the host: ordered list of (variable, usable factor labels)."""
+    init = {v: fg.getVariable(v).initialized for v in fg.ls()}
+    plan = []
+    for _ in range(10):
+        repeat = False
+        for sym in fg.ls():
+            if init[sym]:
+                continue
+            use = []
+            for fl in fg.ls(sym):
+                f = fg.getFactor(fl)
+                others = [v for v in f.variables if v != sym]
+                if f.isMultihypo:
+                    # factorCanInitFromOtherVars + isLeastOneHypoAvailable (#427): we require all
+                    # hypotheses initialised (documented restriction)
+                    ok = all(init[v] for v in others)
+                else:
+                    ok = all(init[v] for v in others)
+                if ok:
+                    use.append(fl)
+            if use:
+                plan.append((sym, use))
+                init[sym] = True
+            else:
+                repeat = True
+        if not repeat:
+            break
+    return plan, init
+
+
+def initAll(fg, backend=None, seed=0):
+    """initAll!(dfg): initialise every variable from already-initialised neighbours in add-history
+    order; each init is a propagateBelief over the usable factors.  Independent inits are batched
+    into one launch."""
+    sp = fg.solverParams
+    N = sp.N
+    plan, _ = _init_plan(fg)
+    if not plan:
+        return 0
+    labels = fg.ls()
+    slot = {v: i for i, v in enumerate(labels)}
+    V = len(labels)
+    maxF = max(len(u) for _, u in plan)
+    # group consecutive independent inits into stages
+    groups, cur, produced = [], [], set()
+    for sym, use in plan:
+        deps = set()
+        for fl in use:
+            deps.update(v for v in fg.getFactor(fl).variables if v != sym)
+        if deps & produced:
+            groups.append(cur)
+            cur, produced = [], set()
+        cur.append((sym, use))
+        produced.add(sym)
+    if cur:
+        groups.append(cur)
+    width = max(len(g) for g in groups)
+    be, own = _make_backend(backend, N, V + width * maxF)
+    try:
+        for v in labels:
+            var = fg.getVariable(v)
+            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+        stages = []
+        for gi, g in enumerate(groups):
+            props, prods = [], []
+            for ci, (sym, use) in enumerate(g):
+                fcts = [fg.getFactor(f) for f in use]
+                ns = _null_surplus(fg, fcts)
+                base = V + ci * maxF
+                for i, f in enumerate(fcts):
+                    props.append(proposal_desc(fg, f, sym, slot.__getitem__, base + i,
+                                               op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i]))
+                prods.append(product_desc(fg.getVariable(sym).varType.manifold, [base + i for i in range(len(fcts))],
+                                          slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter))
+            stages.append((abi.STAGE_PROPOSALS, props))
+            stages.append((abi.STAGE_PRODUCTS, prods))
+        prog = be.program(stages)
+        prog.run()
+        be.synchronize()
+        for sym, _ in plan:
+            pts, bw = be.slot_read(slot[sym], fg.getVariable(sym).varType.manifold)
+            setValKDE(fg, sym, pts, bw, True)
+        prog.close()
+    finally:
+        if own:
+            be.close()
+    return len(plan)
+
+
+# ------------------------------------------------------------------------------------------------
+# tree solve
+# ------------------------------------------------------------------------------------------------
+class TreeProgram:
+    """The whole up+down solve of a Bayes tree compiled into libnbp stages.
+
+    Slot plan (DESIGN.md "HBM layout"):  main[v] | clique-local beliefs B[c,v] | per-clique proposal
+    scratch.  The clique-local copies are the reference's deep-copied `cliqSubFg`
+    (SubGraphFunctions.jl:48); an up message is the child's separator slot read in place by the
+    parent's MsgPrior proposal; a down message is a slot copy parent -> child
+    (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84)."""
+
+    def __init__(self, fg, tree, seed=0, cliques=None):
+        self.fg, self.tree, self.seed = fg, tree, seed
+        sp = fg.solverParams
+        labels = fg.ls()
+        self.main = {v: i for i, v in enumerate(labels)}
+        nxt = len(labels)
+        self.B = {}
+        self.scratch = {}
+        self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
+        heights, depths = tree.heights(), tree.depths()
+        self.heights, self.depths = heights, depths
+        only = set(cliques) if cliques is not None else None
+        for cid, cl in tree.cliques.items():
+            if only is not None and cid not in only:
+                continue
+            for v in cl.allIDs:
+                self.B[(cid, v)] = nxt
+                nxt += 1
+            # up-solve factor lists per variable: clique potentials touching v + child messages on v
+            upf = {}
+            for v in cl.allIDs:
+                lst = [("f", f) for f in cl.potentials if v in fg.getFactor(f).variables]
+                for ch in cl.children:
+                    if v in tree.cliques[ch].separatorIDs:
+                        lst.append(("m", ch))
+                upf[v] = lst
+            sched = [v for v in bayestree.upGibbsSchedule(cl, sp.gibbsIters) if upf[v]]
+            self.upsched[cid], self.upfacs[cid] = sched, upf
+            dnf = {v: [f for f in fg.ls(v)] for v in cl.frontalIDs}
+            self.dnfacs[cid] = dnf
+            self.dnsched[cid] = bayestree.downSchedule(fg, cl, sp.gibbsIters) if cl.parent >= 0 else []
+            maxf = max([len(upf[v]) for v in sched] + [len(dnf[v]) for v in self.dnsched[cid]] + [1])
+            if maxf > abi.MAXF:
+                raise ValueError(f"clique {cid}: {maxf} densities in one product exceeds NBP_MAXF")
+            self.scratch[cid] = (nxt, maxf)
+            nxt += maxf
+        self.n_slots = nxt
+        self.cliques = [c for c in tree.cliques if only is None or c in only]
+        self.stages = []
+        self.stage_pass = []
+        self.n_updates_up = 0
+        self.n_updates_down = 0
+        self.alg_bytes = 0
+        self._compile()
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _account(self, man, F_in):
+        N = self.fg.solverParams.N
+        P, D = abi.MANIFOLD_P[man], abi.MANIFOLD_DIM[man]
+        self.alg_bytes += (F_in + 2) * N * P * 8 + (F_in + 1) * D * 8  # B_upd, SURVEY 8(d)
+
+    def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step):
+        fg, sp = self.fg, self.fg.solverParams
+        base, _ = self.scratch[cid]
+        fcts = []
+        for kind, ref in entries:
+            if kind == "f":
+                fcts.append(fg.getFactor(ref))
+            else:  # child message -> MsgPrior (generateMsgPrior, TreeMessageUtils.jl:86-89)
+                from .factorgraph import DFGFactor
+                fcts.append(DFGFactor(f"msg{ref}_{v}", [v], MsgPrior(self.B[(ref, v)]), None, 0.0, sp.inflation))
+        ns = _null_surplus(fg, fcts)
+        props = [proposal_desc(fg, f, v, slot_of, base + i, op_seed(self.seed, passid, cid, step, i + 1), nullSurplus=ns[i])
+                 for i, f in enumerate(fcts)]
+        man = fg.getVariable(v).varType.manifold
+        prod = product_desc(man, [base + i for i in range(len(fcts))], out_slot,
+                            op_seed(self.seed, passid, cid, step, PRODUCT_ID), sp.productNiter)
+        self._account(man, sum(0 if f.fnc.is_prior and not isinstance(f.fnc, MsgPrior) else 1 for f in fcts))
+        return props, prod
+
+    def _compile(self):
+        tree, fg = self.tree, self.fg
+        add = self.stages.append
+        # deep copy of the clique sub graphs (SubGraphFunctions.jl:48)
+        copies = [abi.CopyDesc(self.main[v], self.B[(c, v)]) for c in self.cliques for v in tree.cliques[c].allIDs]
+        add((abi.STAGE_COPIES, copies)); self.stage_pass.append("copy")
+        # ---- up pass: leaves first ------------------------------------------------------------
+        maxh = max(self.heights[c] for c in self.cliques)
+        for h in range(maxh + 1):
+            level = [c for c in self.cliques if self.heights[c] == h]
+            nsteps = max(len(self.upsched[c]) for c in level)
+            for k in range(nsteps):
+                props, prods = [], []
+                for c in level:
+                    sched = self.upsched[c]
+                    if k >= len(sched):
+                        continue
+                    v = sched[k]
+                    p, q = self._update_ops(c, v, self.upfacs[c][v], lambda u, c=c: self.B[(c, u)], self.B[(c, v)], PASS_UP, k)
+                    props += p
+                    prods.append(q)
+                    self.n_updates_up += 1
+                add((abi.STAGE_PROPOSALS, props)); self.stage_pass.append("up")
+                add((abi.STAGE_PRODUCTS, prods)); self.stage_pass.append("up")
+        # roots: posterior = up-solve result (CliqueStateMachine.jl preDownSolve root branch)
+        rootcopies = [abi.CopyDesc(self.B[(r, v)], self.main[v]) for r in tree.roots if r in self.B_cliques() for v in tree.cliques[r].frontalIDs]
+        add((abi.STAGE_COPIES, rootcopies)); self.stage_pass.append("down")
+        # ---- down pass: root first --------------------------------------------------------------
+        maxd = max(self.depths[c] for c in self.cliques)
+        for dpt in range(1, maxd + 1):
+            level = [c for c in self.cliques if self.depths[c] == dpt]
+            # down message: separators := parent's values (updateSubFgFromDownMsgs!)
+            msg = [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)]) for c in level for s in tree.cliques[c].separatorIDs]
+            add((abi.STAGE_COPIES, msg)); self.stage_pass.append("down")
+            nsteps = max(len(self.dnsched[c]) for c in level)
+            for k in range(nsteps):
+                props, prods = [], []
+                for c in level:
+                    sched = self.dnsched[c]
+                    if k >= len(sched):
+                        continue
+                    v = sched[k]
+                    inclq = set(tree.cliques[c].allIDs)
+
+                    def slot_of(u, c=c, inclq=inclq):
+                        return self.B[(c, u)] if u in inclq else self.main[u]
+
+                    p, q = self._update_ops(c, v, [("f", f) for f in self.dnfacs[c][v]], slot_of, self.B[(c, v)], PASS_DOWN, k)
+                    props += p
+                    prods.append(q)
+                    self.n_updates_down += 1
+                add((abi.STAGE_PROPOSALS, props)); self.stage_pass.append("down")
+                add((abi.STAGE_PRODUCTS, prods)); self.stage_pass.append("down")
+            # transferUpdateSubGraph!: frontals -> main graph (CliqueStateMachine.jl:928-966)
+            fin = [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in level for v in tree.cliques[c].frontalIDs]
+            add((abi.STAGE_COPIES, fin)); self.stage_pass.append("down")
+
+    def B_cliques(self):
+        return set(self.cliques)
+
+    @property
+    def n_messages(self):
+        """one LikelihoodMessage per tree edge and direction (CliqueStateMachine.jl:590-593, 900-903)"""
+        return 2 * sum(1 for c in self.cliques if self.tree.cliques[c].parent >= 0)
+
+    def stats(self):
+        np_, nq = 0, 0
+        for kind, d in self.stages:
+            if kind == abi.STAGE_PROPOSALS:
+                np_ += len(d)
+            elif kind == abi.STAGE_PRODUCTS:
+                nq += len(d)
+        return {"stages": len(self.stages), "proposals": np_, "products": nq, "updates_up": self.n_updates_up,
+                "updates_down": self.n_updates_down, "messages": self.n_messages, "slots": self.n_slots,
+                "alg_bytes": self.alg_bytes, "cliques": len(self.cliques)}
+
+
+def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, ordering="qr", return_timing=False):
+    """solveTree!(dfg; eliminationOrder) -> tree   (SolverAPI.jl:326-493).
+    graphinit -> buildTreeReset! -> up pass -> down pass -> posteriors written back to `fg`."""
+    sp = fg.solverParams
+    t0 = time.perf_counter()
+    if sp.graphinit:
+        initAll(fg, backend=backend if (backend is None or not hasattr(backend, 'slot_write')) else None, seed=seed)
+    t1 = time.perf_counter()
+    if tree is None:
+        tree = bayestree.buildTreeReset(fg, eliminationOrder, ordering)
+    t2 = time.perf_counter()
+    tp = TreeProgram(fg, tree, seed=seed)
+    be, own = _make_backend(backend, sp.N, tp.n_slots)
+    try:
+        for v in fg.ls():
+            var = fg.getVariable(v)
+            be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+        prog = be.program(tp.stages)
+        t3 = time.perf_counter()
+        prog.run()
+        be.synchronize()
+        t4 = time.perf_counter()
+        for v in fg.ls():
+            var = fg.getVariable(v)
+            pts, bw = be.slot_read(tp.main[v], var.varType.manifold)
+            setValKDE(fg, v, pts, bw, True)
+            var.solvedCount += 1
+        prog.close()
+    finally:
+        if own:
+            be.close()
+    if return_timing:
+        return tree, {"init_s": t1 - t0, "tree_s": t2 - t1, "compile_s": t3 - t2, "solve_s": t4 - t3, **tp.stats()}
+    return tree

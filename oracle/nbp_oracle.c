@@ -1,0 +1,1029 @@
+/*
+ * nbp_oracle.c -- CPU restatement (plain C, serial) of the IncrementalInference.jl per-clique
+ * nonparametric Chapman-Kolmogorov hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT THE PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product path is libnbp (HIP) and never links,
+ * loads or calls anything in this directory.
+ *
+ * PARITY STATUS: "parity unpinned" at sample level.  Julia is not installed here and the
+ * reference ships no golden vectors; half of the arithmetic lives in
+ * un-vendored third-party packages, whose *published algorithms* are restated below:
+ *    KernelDensityEstimate.jl 0.5.6 -- leave-one-out likelihood CV bandwidth, golden section
+ *                                      (Ihler's KDE toolbox `ksize(.,'lcv')`), and the multiscale
+ *                                      sequential Gibbs product sampler (Ihler, Sudderth, Freeman,
+ *                                      Willsky, "Efficient Multiscale Sampling from Products of
+ *                                      Gaussian Mixtures", NIPS 2003) = `prodAppxMSGibbsS`
+ *    ApproxManifoldProducts 0.9     -- manikde!/manifoldProduct: the same on tangent coordinates
+ *                                      at the identity, circular coordinates wrapped
+ *    Optim 1                        -- NelderMead (Gao-Han adaptive parameters, AffineSimplexer),
+ *                                      BFGS for 1-D decision variables
+ *    Manifolds 0.10 / ManifoldsBase -- exp/log/compose/vee/hat for TranslationGroup(D),
+ *                                      RealCircleGroup, SpecialEuclidean(2; Hybrid tangent repr.)
+ * The oracle is pinned *in distribution* by the acceptance bands of the reference's own tests
+ * (tests/test_oracle_reference_bands.py cites each test file:line).
+ *
+ * All file:line citations are relative to the IncrementalInference.jl v0.35.6 source tree.
+ *
+ * Data layout (shared with libnbp): an arena of "slots"; slot s starts at
+ * arena + s*(3N+8) doubles: coordinate d of particle n at [d*N+n], bandwidth at [3N+d].
+ */
+#define _GNU_SOURCE
+#include "../include/nbp.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PI 3.14159265358979323846
+#define TWO_PI 6.28318530717958647692
+
+/* RNG purposes (counter word 1).  Shared contract with the HIP kernels. */
+#define PURP_MEAS 1
+#define PURP_MIXLBL 2
+#define PURP_HYPO 3
+#define PURP_ENTROPY 4
+#define PURP_KDESEL 5
+#define PURP_KDENOISE 6
+#define PURP_PGIBBS 9
+#define PURP_PFINAL 10
+#define NBP_TAG 0x4E4250u
+
+typedef struct {
+  int64_t solves, nonconverged, nan_results, residual_evals, lcv_evals;
+} orc_diag;
+
+static orc_diag g_diag;
+
+void orc_diag_read(orc_diag *out, int reset) {
+  *out = g_diag;
+  if (reset) memset(&g_diag, 0, sizeof(g_diag));
+}
+
+int64_t orc_slot_stride(int32_t N) { return 3 * (int64_t)N + 8; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11) -- counter-based so that CPU and GPU draw identical     */
+/* streams irrespective of the execution order.                                                */
+/* ------------------------------------------------------------------------------------------ */
+void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                uint32_t out[4]) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static double u01_from(uint32_t lo, uint32_t hi) {
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  return ((double)(v >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+/* two uniforms in (0,1) for (seed, n, purpose, k) */
+void orc_uniform_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k, double *ua, double *ub) {
+  uint32_t o[4];
+  orc_philox(n, purpose, k, NBP_TAG, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  *ua = u01_from(o[0], o[1]);
+  *ub = u01_from(o[2], o[3]);
+}
+
+/* two standard normals (Box-Muller) */
+void orc_normal_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k, double *na, double *nb) {
+  double ua, ub;
+  orc_uniform_pair(seed, n, purpose, k, &ua, &ub);
+  double r = sqrt(-2.0 * log(ua));
+  double th = TWO_PI * ub;
+  *na = r * cos(th);
+  *nb = r * sin(th);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Manifolds in tangent coordinates at the identity                                            */
+/* ------------------------------------------------------------------------------------------ */
+static int mani_dim(int m) {
+  switch (m) {
+  case NBP_EUCLID1: return 1;
+  case NBP_EUCLID2: return 2;
+  case NBP_EUCLID3: return 3;
+  case NBP_CIRCULAR: return 1;
+  case NBP_SE2: return 3;
+  }
+  return 0;
+}
+static int mani_P(int m) { return m == NBP_SE2 ? 6 : mani_dim(m); }
+static int is_circ(int m, int d) { return (m == NBP_CIRCULAR && d == 0) || (m == NBP_SE2 && d == 2); }
+
+/* Manifolds.sym_rem: wrap to [-pi, pi) */
+double orc_wrap(double a) {
+  double r = fmod(a + PI, TWO_PI);
+  if (r < 0) r += TWO_PI;
+  return r - PI;
+}
+
+int32_t orc_manifold_dim(int32_t m) { return mani_dim(m); }
+int32_t orc_manifold_P(int32_t m) { return mani_P(m); }
+
+/* host AoS points (N x P) -> slot coordinates (vee(M, e, log(M, e, p)), what AMP.manikde! stores) */
+void orc_slot_write(double *arena, int32_t N, int32_t slot, int32_t manifold, const double *pts, const double *bw) {
+  double *s = arena + orc_slot_stride(N) * slot;
+  int D = mani_dim(manifold), P = mani_P(manifold);
+  for (int n = 0; n < N; n++) {
+    const double *p = pts + (size_t)n * P;
+    if (manifold == NBP_SE2) {
+      s[0 * N + n] = p[0];
+      s[1 * N + n] = p[1];
+      s[2 * N + n] = atan2(p[3], p[2]); /* R = [c -s; s c] column-major: R11,R21,R12,R22 */
+    } else if (manifold == NBP_CIRCULAR) {
+      s[n] = orc_wrap(p[0]);
+    } else {
+      for (int d = 0; d < D; d++) s[d * N + n] = p[d];
+    }
+  }
+  for (int d = 0; d < 3; d++) s[3 * N + d] = (bw && d < D) ? bw[d] : 0.0;
+}
+
+void orc_slot_read(const double *arena, int32_t N, int32_t slot, int32_t manifold, double *pts, double *bw) {
+  const double *s = arena + orc_slot_stride(N) * slot;
+  int D = mani_dim(manifold), P = mani_P(manifold);
+  for (int n = 0; n < N; n++) {
+    double *p = pts + (size_t)n * P;
+    if (manifold == NBP_SE2) {
+      double th = s[2 * N + n];
+      p[0] = s[n]; p[1] = s[N + n];
+      p[2] = cos(th); p[3] = sin(th); p[4] = -sin(th); p[5] = cos(th);
+    } else {
+      for (int d = 0; d < D; d++) p[d] = s[d * N + n];
+    }
+  }
+  if (bw) for (int d = 0; d < D; d++) bw[d] = s[3 * N + d];
+}
+
+/* mean(M, pts, GeodesicInterpolation()) : running geodesic interpolation, Manifolds.jl.
+ * services/VariableStatistics.jl:30 */
+static void mean_geodesic(int manifold, const double *x, int N, double *mu) {
+  int D = mani_dim(manifold);
+  for (int d = 0; d < D; d++) {
+    double m = x[d * N];
+    for (int i = 1; i < N; i++) {
+      double dl = x[d * N + i] - m;
+      if (is_circ(manifold, d)) dl = orc_wrap(dl);
+      m = m + dl / (double)(i + 1);
+      if (is_circ(manifold, d)) m = orc_wrap(m);
+    }
+    mu[d] = m;
+  }
+}
+
+/* default mean(M, pts): arithmetic on Euclidean coordinates, extrinsic on the circle */
+static void mean_default(int manifold, const double *x, int N, double *mu) {
+  int D = mani_dim(manifold);
+  for (int d = 0; d < D; d++) {
+    if (is_circ(manifold, d)) {
+      double sc = 0, ss = 0;
+      for (int i = 0; i < N; i++) { sc += cos(x[d * N + i]); ss += sin(x[d * N + i]); }
+      mu[d] = atan2(ss, sc);
+    } else {
+      double s = 0;
+      for (int i = 0; i < N; i++) s += x[d * N + i];
+      mu[d] = s / N;
+    }
+  }
+}
+
+/* calcStdBasicSpread, services/VariableStatistics.jl:22-36: sigma = sqrt(sum d(mu,x_i)^2/(N-1)),
+ * 1.0 if sigma < 1e-10.  Rotation part of SE(2) carries the Frobenius metric (||skew(w)||^2 = 2w^2). */
+double orc_std_basic_spread(int manifold, const double *x, int N) {
+  double mu[3];
+  int D = mani_dim(manifold);
+  mean_geodesic(manifold, x, N, mu);
+  double acc = 0;
+  for (int i = 0; i < N; i++) {
+    for (int d = 0; d < D; d++) {
+      double dl = x[d * N + i] - mu[d];
+      if (is_circ(manifold, d)) {
+        dl = orc_wrap(dl);
+        acc += (manifold == NBP_SE2 ? 2.0 : 1.0) * dl * dl;
+      } else
+        acc += dl * dl;
+    }
+  }
+  double sg = sqrt(acc / (double)(N - 1));
+  return (1e-10 < sg) ? sg : 1.0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Residual functors.  a = first active variable, b = second, z = measurement      */
+/* tangent coordinates.  Returns sum(r.^2) (CalcFactorNormSq, NumericalCalculations.jl:386-396) */
+/* ------------------------------------------------------------------------------------------ */
+static int factor_zdim(int kind, int manifold) {
+  switch (kind) {
+  case NBP_F_LINREL: return mani_dim(manifold);
+  case NBP_F_CIRCULAR: return 1;
+  case NBP_F_SE2: return 3;
+  case NBP_F_EUCLIDDIST: return 1;
+  default: return mani_dim(manifold); /* priors sample points */
+  }
+}
+
+int32_t orc_residual(int32_t kind, int32_t manifold, const double *z, const double *a, const double *b, double *r) {
+  int D = mani_dim(manifold);
+  #pragma omp atomic
+  g_diag.residual_evals++;
+  switch (kind) {
+  case NBP_F_LINREL: /* Factors/LinearRelative.jl:42-49 */
+    for (int d = 0; d < D; d++) r[d] = z[d] - (b[d] - a[d]);
+    return D;
+  case NBP_F_CIRCULAR: { /* Factors/Circular.jl:24-28 -> GenericFunctions.jl:47-52 */
+    double qhat = a[0] + z[0]; /* exp(M, p, X) */
+    r[0] = orc_wrap(qhat - b[0]); /* vee(log(M, q, qhat)) */
+    return 1;
+  }
+  case NBP_F_SE2: { /* Factors/GenericFunctions.jl:39-44 */
+    double c = cos(a[2]), s = sin(a[2]);
+    double qx = a[0] + c * z[0] - s * z[1]; /* compose(p, exp(e, X)) */
+    double qy = a[1] + s * z[0] + c * z[1];
+    double qt = a[2] + z[2];
+    r[0] = qx - b[0];
+    r[1] = qy - b[1];
+    r[2] = orc_wrap(qt - b[2]);
+    return 3;
+  }
+  case NBP_F_EUCLIDDIST: { /* Factors/EuclidDistance.jl:20 */
+    double acc = 0;
+    for (int d = 0; d < D; d++) acc += (b[d] - a[d]) * (b[d] - a[d]);
+    r[0] = z[0] - sqrt(acc);
+    return 1;
+  }
+  }
+  return 0;
+}
+
+typedef struct {
+  int kind, manifold, D, solve_b;
+  double z[3], other[3];
+} objective_t;
+
+static double objective(const objective_t *o, const double *x) {
+  double r[3];
+  int nr = o->solve_b ? orc_residual(o->kind, o->manifold, o->z, o->other, x, r)
+                      : orc_residual(o->kind, o->manifold, o->z, x, o->other, r);
+  double acc = 0;
+  for (int i = 0; i < nr; i++) acc += r[i] * r[i];
+  return acc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Optim.NelderMead restated: AdaptiveParameters (Gao & Han 2012), AffineSimplexer(a=0.025,     */
+/* b=0.5), g_tol = 1e-8 on sqrt(var(f_simplex)*(n+1)/n... ) [nmobjective], iterations = 1000.   */
+/* Call site: NumericalCalculations.jl:108,122-126.                                            */
+/* ------------------------------------------------------------------------------------------ */
+static void nm_sort(int m, const double *f, int *ord) {
+  for (int i = 0; i < m; i++) ord[i] = i;
+  for (int i = 1; i < m; i++) { /* stable insertion sort */
+    int k = ord[i], j = i - 1;
+    while (j >= 0 && f[ord[j]] > f[k]) { ord[j + 1] = ord[j]; j--; }
+    ord[j + 1] = k;
+  }
+}
+static double nm_objective(int m, int n, const double *f) {
+  double a = 0;
+  for (int i = 0; i < m; i++) a += f[i];
+  a /= m;
+  double v = 0;
+  for (int i = 0; i < m; i++) v += (f[i] - a) * (f[i] - a);
+  return sqrt(v / n);
+}
+
+int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: minimizer */, int *iters) {
+  const int m = n + 1;
+  const double alpha = 1.0, beta = 1.0 + 2.0 / n, gamma = 0.75 - 1.0 / (2.0 * n), delta = 1.0 - 1.0 / n;
+  double sx[4][3], f[4], xc[3], xr[3], xcache[3], xl[3];
+  int ord[4];
+  for (int i = 0; i < m; i++)
+    for (int d = 0; d < n; d++) sx[i][d] = x[d];
+  for (int j = 0; j < n; j++) sx[j + 1][j] = (1.0 + 0.5) * sx[j + 1][j] + 0.025;
+  for (int i = 0; i < m; i++) f[i] = objective(o, sx[i]);
+  nm_sort(m, f, ord);
+  int converged = nm_objective(m, n, f) <= 1e-8;
+  int it = 0;
+  while (!converged && it < 1000) {
+    it++;
+    int shrink = 0;
+    int ih = ord[m - 1];
+    for (int d = 0; d < n; d++) {
+      double s = 0;
+      for (int i = 0; i < m; i++) if (i != ih) s += sx[i][d];
+      xc[d] = s / n;
+      xl[d] = sx[ord[0]][d];
+    }
+    double f_lowest = f[ord[0]], f_second = f[ord[n - 1]], f_highest = f[ih];
+    for (int d = 0; d < n; d++) xr[d] = xc[d] + alpha * (xc[d] - sx[ih][d]);
+    double f_reflect = objective(o, xr);
+    if (f_reflect < f_lowest) {
+      for (int d = 0; d < n; d++) xcache[d] = xc[d] + beta * (xr[d] - xc[d]);
+      double f_expand = objective(o, xcache);
+      if (f_expand < f_reflect) {
+        for (int d = 0; d < n; d++) sx[ih][d] = xcache[d];
+        f[ih] = f_expand;
+      } else {
+        for (int d = 0; d < n; d++) sx[ih][d] = xr[d];
+        f[ih] = f_reflect;
+      }
+      for (int i = m - 1; i >= 1; i--) ord[i] = ord[i - 1];
+      ord[0] = ih;
+    } else if (f_reflect < f_second) {
+      for (int d = 0; d < n; d++) sx[ih][d] = xr[d];
+      f[ih] = f_reflect;
+      nm_sort(m, f, ord);
+    } else {
+      if (f_reflect < f_highest) { /* outside contraction */
+        for (int d = 0; d < n; d++) xcache[d] = xc[d] + gamma * (xr[d] - xc[d]);
+        double fc = objective(o, xcache);
+        if (fc < f_reflect) {
+          for (int d = 0; d < n; d++) sx[ih][d] = xcache[d];
+          f[ih] = fc;
+          nm_sort(m, f, ord);
+        } else
+          shrink = 1;
+      } else { /* inside contraction */
+        for (int d = 0; d < n; d++) xcache[d] = xc[d] - gamma * (xr[d] - xc[d]);
+        double fc = objective(o, xcache);
+        if (fc < f_highest) {
+          for (int d = 0; d < n; d++) sx[ih][d] = xcache[d];
+          f[ih] = fc;
+          nm_sort(m, f, ord);
+        } else
+          shrink = 1;
+      }
+    }
+    if (shrink) {
+      for (int i = 1; i < m; i++) {
+        int oi = ord[i];
+        for (int d = 0; d < n; d++) sx[oi][d] = xl[d] + delta * (sx[oi][d] - xl[d]);
+        f[oi] = objective(o, sx[oi]);
+      }
+      nm_sort(m, f, ord);
+    }
+    converged = nm_objective(m, n, f) <= 1e-8;
+  }
+  /* after_while!: better of best vertex and centroid of the n best */
+  nm_sort(m, f, ord);
+  int ih = ord[m - 1];
+  for (int d = 0; d < n; d++) {
+    double s = 0;
+    for (int i = 0; i < m; i++) if (i != ih) s += sx[i][d];
+    xc[d] = s / n;
+  }
+  double fcen = objective(o, xc);
+  if (fcen < f[ord[0]])
+    for (int d = 0; d < n; d++) x[d] = xc[d];
+  else
+    for (int d = 0; d < n; d++) x[d] = sx[ord[0]][d];
+  if (iters) *iters = it;
+  return converged;
+}
+
+/* 1-D decision variable: Optim.BFGS with central finite differences (islen1 branch,
+ * NumericalCalculations.jl:108).  Restated with an Armijo/quadratic-interpolation line search in
+ * place of HagerZhang (documented deviation; identical fixed point for the residual set). */
+static double fd_grad1(const objective_t *o, double x) {
+  double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x)); /* cbrt(eps(Float64)) */
+  double xp = x + h, xm = x - h;
+  return (objective(o, &xp) - objective(o, &xm)) / (2.0 * h);
+}
+
+int orc_bfgs_1d(const objective_t *o, double *x, int *iters) {
+  double xc = *x, fx = objective(o, &xc), g = fd_grad1(o, xc), H = 1.0;
+  int converged = 0, it = 0;
+  for (it = 0; it < 1000; it++) {
+    if (fabs(g) <= 1e-8) { converged = 1; break; }
+    double s = -H * g;
+    if (s * g >= 0) { H = 1.0; s = -g; }
+    double al = 1.0, dphi0 = g * s, xn = xc, fn = fx;
+    int ok = 0;
+    for (int ls = 0; ls < 50; ls++) {
+      xn = xc + al * s;
+      fn = objective(o, &xn);
+      if (fn <= fx + 1e-4 * al * dphi0) { ok = 1; break; }
+      double aq = -dphi0 * al * al / (2.0 * (fn - fx - dphi0 * al));
+      if (!(aq >= 0.1 * al)) aq = 0.1 * al;
+      if (aq > 0.5 * al) aq = 0.5 * al;
+      al = aq;
+    }
+    if (!ok) break;
+    double gn = fd_grad1(o, xn), dx = xn - xc, dg = gn - g;
+    if (dx == 0.0) { converged = fabs(gn) <= 1e-8; break; }
+    if (dx * dg > 0) H = dx / dg;
+    xc = xn; fx = fn; g = gn;
+  }
+  *x = xc;
+  if (iters) *iters = it;
+  return converged;
+}
+
+/* _solveCCWNumeric! for one particle, NumericalCalculations.jl:413-452 + :90-133 */
+static void solve_particle(int kind, int manifold, const double *z, const double *other, int solve_b, double *x) {
+  objective_t o;
+  o.kind = kind; o.manifold = manifold; o.D = mani_dim(manifold); o.solve_b = solve_b;
+  for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
+  double xc[3];
+  int D = o.D;
+  for (int d = 0; d < D; d++) xc[d] = x[d]; /* X0c = vee(M, e, log(M, e, u0)) */
+  int conv;
+#pragma omp atomic
+  g_diag.solves++;
+  if (D == 1) conv = orc_bfgs_1d(&o, xc, 0); /* islen1 -> BFGS */
+  else conv = orc_nelder_mead(&o, D, xc, 0);
+  if (!conv) {
+#pragma omp atomic
+    g_diag.nonconverged++;
+  } /* @warn only; the result is still used (:128-131) */
+  for (int d = 0; d < D; d++)
+    if (isnan(xc[d])) {
+#pragma omp atomic
+      g_diag.nan_results++;
+      return;
+    }
+  for (int d = 0; d < D; d++) x[d] = is_circ(manifold, d) ? orc_wrap(xc[d]) : xc[d]; /* exp(M, e, hat(..)) */
+}
+
+/* exposed for unit tests */
+int32_t orc_solve_particle(int32_t kind, int32_t manifold, const double *z, const double *other, int32_t solve_b, double *x) {
+  solve_particle(kind, manifold, z, other, solve_b, x);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* _prepareHypoRecipe!, services/ExplicitDiscreteMarginalizations.jl:142-232 (multihypo) and   */
+/* :234-289 (none / nullhypo).  INTEGER, exact-match item.  Indices are 1-based like the        */
+/* reference; hypothesis 0 is the null hypothesis.                                              */
+/* Output, for group g = 0..ngroups-1:  hypo[g] = pidx, nact[g], act[g][..] = iterah,           */
+/* and `empty[g]` = 1 when the reference forces allelements[g] = Int[].                          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int ngroups;
+  int hypo[NBP_MAXV + 1];
+  int nact[NBP_MAXV + 1];
+  int act[NBP_MAXV + 1][NBP_MAXV];
+  int empty[NBP_MAXV + 1];
+  int ncertain;
+  int certain[NBP_MAXV];
+  int sf_uncertain;
+  double cat_p[NBP_MAXV + 1]; /* categorical over groups used to draw mhidx */
+  int cat_first;              /* hypothesis index of cat_p[0] */
+  int ncat;
+} recipe_t;
+
+static int in_list(const int *l, int n, int v) {
+  for (int i = 0; i < n; i++) if (l[i] == v) return 1;
+  return 0;
+}
+static void sorted_union(const int *a, int na, int v, int *out, int *nout) {
+  int tmp[NBP_MAXV + 1], n = 0;
+  for (int i = 0; i < na; i++) tmp[n++] = a[i];
+  if (!in_list(a, na, v)) tmp[n++] = v;
+  for (int i = 1; i < n; i++) { int k = tmp[i], j = i - 1; while (j >= 0 && tmp[j] > k) { tmp[j + 1] = tmp[j]; j--; } tmp[j + 1] = k; }
+  for (int i = 0; i < n; i++) out[i] = tmp[i];
+  *nout = n;
+}
+
+void orc_build_recipe(int has_multihypo, const double *mhp, int nvars, int sfidx1, double nullhypo, recipe_t *R) {
+  memset(R, 0, sizeof(*R));
+  if (!has_multihypo) {
+    /* :234-289 */
+    R->ncertain = nvars;
+    for (int i = 0; i < nvars; i++) R->certain[i] = i + 1;
+    R->ngroups = nvars + 1;
+    for (int g = 0; g <= nvars; g++) {
+      R->hypo[g] = g;
+      if (g == 0) { R->nact[g] = 1; R->act[g][0] = sfidx1; }
+      else if (g == 1) { R->nact[g] = nvars; for (int i = 0; i < nvars; i++) R->act[g][i] = i + 1; }
+      else { R->nact[g] = 0; R->empty[g] = 1; }
+    }
+    R->ncat = 2; R->cat_first = 0;
+    R->cat_p[0] = nullhypo; R->cat_p[1] = 1.0 - nullhypo;
+    return;
+  }
+  /* getHypothesesVectors :17-24 */
+  int unc[NBP_MAXV], nunc = 0;
+  for (int i = 0; i < nvars; i++) {
+    if (mhp[i] == 0.0) R->certain[R->ncertain++] = i + 1;
+    else if (0.0 < mhp[i]) unc[nunc++] = i + 1;
+  }
+  int sfunc = in_list(unc, nunc, sfidx1), sfincer = in_list(R->certain, R->ncertain, sfidx1);
+  R->sf_uncertain = sfunc;
+  double p[NBP_MAXV + 1];
+  int np = 0, pidx0;
+  if (sfunc) { /* :176-183 prepend the bad-init null hypothesis */
+    double nhw = (double)(nunc + 1), tot = 0;
+    p[np++] = 1.0 / nhw;
+    for (int i = 0; i < nvars; i++) p[np++] = (double)nunc / nhw * mhp[i];
+    for (int i = 0; i < np; i++) tot += p[i];
+    for (int i = 0; i < np; i++) p[i] /= tot;
+    pidx0 = 0;
+  } else {
+    for (int i = 0; i < nvars; i++) p[np++] = mhp[i];
+    pidx0 = 1;
+  }
+  R->ncat = np; R->cat_first = pidx0;
+  for (int i = 0; i < np; i++) R->cat_p[i] = p[i];
+  R->ngroups = np;
+  for (int g = 0; g < np; g++) { /* :195-222 */
+    int pidx = pidx0 + g;
+    int pidxincer = in_list(R->certain, R->ncertain, pidx);
+    R->hypo[g] = pidx;
+    if (!pidxincer && sfincer && pidx != 0) {
+      sorted_union(R->certain, R->ncertain, pidx, R->act[g], &R->nact[g]);
+    } else if (((pidxincer && !sfincer) || sfidx1 == pidx) && pidx != 0) {
+      sorted_union(R->certain, R->ncertain, sfidx1, R->act[g], &R->nact[g]);
+    } else if (pidxincer && sfincer && pidx != 0) {
+      R->nact[g] = 0; R->empty[g] = 1;
+    } else if (!pidxincer && !sfincer && pidx != 0) {
+      R->nact[g] = nunc; for (int i = 0; i < nunc; i++) R->act[g][i] = unc[i];
+    } else { /* pidx == 0 */
+      R->nact[g] = 1; R->act[g][0] = sfidx1;
+    }
+  }
+}
+
+/* flat export for the exact-match tests (test/testExplicitMultihypo.jl:8-240) */
+int32_t orc_hypo_recipe(int32_t has_multihypo, const double *mhp, int32_t nvars, int32_t sfidx1, double nullhypo,
+                        const int32_t *mhidx, int32_t N, int32_t *certain_out, int32_t *ncertain_out,
+                        int32_t *hypo_out, int32_t *nact_out, int32_t *act_out /* [(MAXV+1)*MAXV] */,
+                        int32_t *nelem_out, int32_t *elem_out /* [(MAXV+1)*N], 1-based */) {
+  recipe_t R;
+  orc_build_recipe(has_multihypo, mhp, nvars, sfidx1, nullhypo, &R);
+  *ncertain_out = R.ncertain;
+  for (int i = 0; i < R.ncertain; i++) certain_out[i] = R.certain[i];
+  for (int g = 0; g < R.ngroups; g++) {
+    hypo_out[g] = R.hypo[g];
+    nact_out[g] = R.nact[g];
+    for (int i = 0; i < R.nact[g]; i++) act_out[g * NBP_MAXV + i] = R.act[g][i];
+    int c = 0;
+    if (!R.empty[g])
+      for (int n = 0; n < N; n++) if (mhidx[n] == R.hypo[g]) elem_out[(size_t)g * N + c++] = n + 1;
+    nelem_out[g] = c;
+  }
+  return R.ngroups;
+}
+
+/* rand(Categorical(p)) by inverse CDF on one uniform */
+static int categorical(const double *p, int n, double u) {
+  double c = 0;
+  int last = 0;
+  for (int i = 0; i < n; i++) {
+    if (p[i] > 0) last = i;
+    c += p[i];
+    if (u < c) return i;
+  }
+  return last;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Bandwidth: KernelDensityEstimate `kde!(pts, :lcv)` per coordinate -- golden-section search   */
+/* of the leave-one-out negative log likelihood (Ihler ksize 'lcv'); call sites                 */
+/* services/ApproxConv.jl:38,41 and AMP.manifoldProduct's rebandwidth.                          */
+/* ------------------------------------------------------------------------------------------ */
+static double neg_loo_ll(const double *x, int N, int circ, double h) {
+  double inv2h2 = 1.0 / (2.0 * h * h), acc = 0;
+  double lognorm = log(h) + 0.5 * log(TWO_PI) + log((double)(N - 1));
+  #pragma omp atomic
+  g_diag.lcv_evals++;
+  for (int i = 0; i < N; i++) {
+    double s = 0;
+    for (int j = 0; j < N; j++) {
+      if (j == i) continue;
+      double d = x[i] - x[j];
+      if (circ) d = orc_wrap(d);
+      s += exp(-d * d * inv2h2);
+    }
+    if (s < 1e-300) s = 1e-300;
+    acc += log(s) - lognorm;
+  }
+  return -acc / N;
+}
+
+double orc_lcv_bandwidth_1d(const double *x, int32_t N, int32_t circ) {
+  double minm = INFINITY, lo = INFINITY, hi = -INFINITY;
+  for (int i = 0; i < N; i++) {
+    if (x[i] < lo) lo = x[i];
+    if (x[i] > hi) hi = x[i];
+    if (i + 1 < N) {
+      double d = fabs(circ ? orc_wrap(x[i] - x[i + 1]) : x[i] - x[i + 1]);
+      if (d < minm) minm = d;
+    }
+  }
+  double maxm = circ ? TWO_PI : (hi - lo);
+  if (!(maxm > 0)) return 1.0;
+  if (minm < 1e-6 * maxm) minm = 1e-6 * maxm;
+  double sc = 0.5 * (minm + maxm);
+  double ax = minm / sc, bx = 1.0, cx = maxm / sc; /* = 2minm/(minm+maxm), 1, 2maxm/(minm+maxm) */
+  const double R = 0.61803399, C = 1.0 - R, tol = 1e-2;
+  double x0 = ax, x3 = cx, x1, x2;
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
+  else { x2 = bx; x1 = bx - C * (bx - ax); }
+  double f1 = neg_loo_ll(x, N, circ, x1 * sc), f2 = neg_loo_ll(x, N, circ, x2 * sc);
+  while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, circ, x2 * sc); }
+    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, circ, x1 * sc); }
+  }
+  return (f1 < f2 ? x1 : x2) * sc;
+}
+
+static void fit_bandwidth(double *slot, int N, int manifold) {
+  int D = mani_dim(manifold);
+  for (int d = 0; d < D; d++) slot[3 * N + d] = orc_lcv_bandwidth_1d(slot + d * N, N, is_circ(manifold, d));
+  for (int d = D; d < 3; d++) slot[3 * N + d] = 0.0;
+}
+
+void orc_run_bandwidth(double *arena, int32_t N, int32_t slot, int32_t manifold) {
+  fit_bandwidth(arena + orc_slot_stride(N) * slot, N, manifold);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Proposal = approxConvBelief (ApproxConv.jl:4-45)                                            */
+/* ------------------------------------------------------------------------------------------ */
+static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, int *label) {
+  /* Mixture.sampleFactor (Factors/Mixture.jl:114-155): label ~ Categorical(diversity) */
+  int c = 0;
+  if (d->ncomp > 1) {
+    double w[NBP_MAXC], ua, ub;
+    for (int i = 0; i < d->ncomp; i++) w[i] = d->comp[i][0];
+    orc_uniform_pair(d->seed, n, PURP_MIXLBL, 0, &ua, &ub);
+    c = categorical(w, d->ncomp, ua);
+  }
+  if (label) *label = c;
+  const double *cp = d->comp[c];
+  double nn[4];
+  orc_normal_pair(d->seed, n, PURP_MEAS, 0, &nn[0], &nn[1]);
+  if (zdim > 2) orc_normal_pair(d->seed, n, PURP_MEAS, 1, &nn[2], &nn[3]);
+  for (int i = 0; i < zdim; i++) { /* rand(MvNormal(mu, L L')) */
+    double acc = cp[1 + i];
+    for (int j = 0; j <= i; j++) acc += cp[4 + i * 3 + j] * nn[j];
+    z[i] = acc;
+  }
+  for (int i = zdim; i < 3; i++) z[i] = 0;
+}
+
+/* addEntropyOnManifold!, EvalFactor.jl:95-132 */
+static void add_entropy(int manifold, double *X, int N, int n, double spread, uint64_t seed, int kbase) {
+  int D = mani_dim(manifold);
+  double u[4];
+  orc_uniform_pair(seed, n, PURP_ENTROPY, kbase, &u[0], &u[1]);
+  if (D > 2) orc_uniform_pair(seed, n, PURP_ENTROPY, kbase + 1, &u[2], &u[3]);
+  for (int d = 0; d < D; d++) {
+    double v = X[d * N + n] + spread * (u[d] - 0.5);
+    X[d * N + n] = is_circ(manifold, d) ? orc_wrap(v) : v;
+  }
+}
+
+/* calcVariableDistanceExpectedFractional, EvalFactor.jl:40-92 */
+static double var_distance_expected_fractional(const nbp_proposal_desc *d, const recipe_t *R, const double *arena,
+                                               int N, const double *X, double kappa) {
+  int sf1 = d->sfidx + 1;
+  if (in_list(R->certain, R->ncertain, sf1)) return kappa * orc_std_basic_spread(d->manifold, X, N);
+  int D = mani_dim(d->manifold);
+  double ref[3], mu[3], best = 1e-2;
+  mean_default(d->manifold, X, N, ref);
+  for (int i = 1; i <= d->nvars; i++) {
+    const double *pts = (i == sf1) ? X : arena + orc_slot_stride(N) * d->var_slot[i - 1];
+    if (in_list(R->certain, R->ncertain, i)) mean_geodesic(d->manifold, pts, N, mu);
+    else mean_default(d->manifold, pts, N, mu);
+    double acc = 0;
+    for (int k = 0; k < D; k++) acc += (ref[k] - mu[k]) * (ref[k] - mu[k]);
+    double dist = sqrt(acc);
+    if (dist > best) best = dist;
+  }
+  return kappa * best;
+}
+
+int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_proposal_desc *d) {
+  const int64_t S = orc_slot_stride(N);
+  const int D = mani_dim(d->manifold);
+  double *out = arena + S * d->out_slot;
+  const int sf1 = d->sfidx + 1;
+  int *mhidx = (int *)malloc(sizeof(int) * N);
+  recipe_t R;
+  orc_build_recipe(d->has_multihypo, d->multihypo, d->nvars, sf1, d->nullhypo, &R);
+
+  /* mhidx: injected, or rand(Categorical) -- ExplicitDiscreteMarginalizations.jl:186,261 */
+  for (int n = 0; n < N; n++) {
+    if (d->mhidx_in >= 0) mhidx[n] = side[d->mhidx_in + n];
+    else if (!d->has_multihypo && d->nullhypo == 0.0) mhidx[n] = 1;
+    else {
+      double ua, ub;
+      orc_uniform_pair(d->seed, n, PURP_HYPO, 0, &ua, &ub);
+      mhidx[n] = R.cat_first + categorical(R.cat_p, R.ncat, ua);
+    }
+    if (d->mhidx_out >= 0) side[d->mhidx_out + n] = mhidx[n];
+  }
+
+  if (d->factor_kind == NBP_F_PRIOR || d->factor_kind == NBP_F_MSGPRIOR) {
+    /* evalPotentialSpecific(prior), EvalFactor.jl:400-542 */
+    const double *cur = arena + S * d->var_slot[0];
+    double *X = (double *)malloc(sizeof(double) * 3 * N);
+    memcpy(X, cur, sizeof(double) * 3 * N); /* addEntr = deepcopy(solveForPts) */
+    double spread = d->spread_nh * orc_std_basic_spread(d->manifold, X, N); /* :464 */
+    for (int n = 0; n < N; n++) {
+      if (mhidx[n] == 1) {
+        if (d->factor_kind == NBP_F_PRIOR) {
+          double z[3];
+          sample_measurement(d, n, D, z, 0);
+          for (int k = 0; k < D; k++) X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[k]) : z[k];
+        } else { /* MsgPrior{MKD}: sample(belief,1): random kernel + bw*randn, Factors/MsgPrior.jl:27-30 */
+          const double *msg = arena + S * d->var_slot[1];
+          double ua, ub, nn[4];
+          orc_uniform_pair(d->seed, n, PURP_KDESEL, 0, &ua, &ub);
+          int i = (int)(ua * N);
+          if (i >= N) i = N - 1;
+          orc_normal_pair(d->seed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
+          if (D > 2) orc_normal_pair(d->seed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
+          for (int k = 0; k < D; k++) {
+            double v = msg[k * N + i] + msg[3 * N + k] * nn[k];
+            X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(v) : v;
+          }
+        }
+      } else { /* nullhypo particles keep their value + entropy, :476 */
+        add_entropy(d->manifold, X, N, n, spread, d->seed, 0);
+      }
+    }
+    memcpy(out, X, sizeof(double) * 3 * N);
+    free(X);
+  } else {
+    /* evalPotentialSpecific(relative), EvalFactor.jl:321-395 */
+    const int zdim = factor_zdim(d->factor_kind, d->manifold);
+    double *X = out; /* ccwl.varValsAll[sfidx] = deepcopy(target), CalcFactor.jl:543-548 */
+    memmove(X, arena + S * d->var_slot[d->sfidx], sizeof(double) * 3 * N);
+    double *Z = (double *)malloc(sizeof(double) * 3 * N);
+    for (int n = 0; n < N; n++) sample_measurement(d, n, zdim, Z + 3 * n, 0); /* sampleFactor!, :578 */
+
+    /* computeAcrossHypothesis!, EvalFactor.jl:145-237 */
+    for (int g = 0; g < R.ngroups; g++) {
+      int hyp = R.hypo[g];
+      int solve_case = (in_list(R.certain, R.ncertain, sf1) && hyp != 0) || in_list(R.certain, R.ncertain, hyp) || hyp == sf1;
+      if (R.empty[g]) continue;
+      if (solve_case) {
+        if (R.nact[g] != 2) { free(Z); free(mhidx); return NBP_ERR_ARG; } /* binary mechanics only */
+        int va = R.act[g][0], vb = R.act[g][1];
+        int solve_b = (vb == sf1);
+        int vother = solve_b ? va : vb;
+        const double *O = arena + S * d->var_slot[vother - 1];
+        for (int c = 0; c < d->inflate_cycles; c++) { /* :184-207 */
+          double spread = var_distance_expected_fractional(d, &R, arena, N, X, d->inflation);
+          for (int n = 0; n < N; n++)
+            if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8 + c) * 2);
+          for (int n = 0; n < N; n++) { /* approxConvOnElements!, :14-27 */
+            if (mhidx[n] != hyp) continue;
+            double x[3], oth[3];
+            for (int k = 0; k < D; k++) { x[k] = X[k * N + n]; oth[k] = O[k * N + n]; }
+            solve_particle(d->factor_kind, d->manifold, Z + 3 * n, oth, solve_b, x);
+            for (int k = 0; k < D; k++) X[k * N + n] = x[k];
+          }
+        }
+      } else { /* other-hypothesis (:208-220) and nullhypo (:222-231): entropy only */
+        double spread = var_distance_expected_fractional(d, &R, arena, N, X, d->spread_nh);
+        for (int n = 0; n < N; n++)
+          if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8) * 2);
+      }
+    }
+    free(Z);
+  }
+  free(mhidx);
+  if (!d->skip_bandwidth) fit_bandwidth(out, N, d->manifold); /* manikde!, ApproxConv.jl:36-42 */
+  return NBP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* AMP.manifoldProduct (GraphProductOperations.jl:53-60): multiscale sequential Gibbs sampler.  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int N, L;
+  int cnt[12];
+  int *lo[12], *hi[12], *child[12]; /* child[l][k] = index at level l+1 of the LAST child of node k */
+} levels_t;
+
+static void levels_build(levels_t *T, int N) {
+  T->N = N;
+  int l = 0;
+  T->cnt[0] = 1;
+  T->lo[0] = (int *)malloc(sizeof(int)); T->hi[0] = (int *)malloc(sizeof(int));
+  T->lo[0][0] = 0; T->hi[0][0] = N;
+  for (;;) {
+    int all_leaf = 1;
+    for (int k = 0; k < T->cnt[l]; k++) if (T->hi[l][k] - T->lo[l][k] > 1) all_leaf = 0;
+    if (all_leaf) break;
+    int c = 0;
+    T->lo[l + 1] = (int *)malloc(sizeof(int) * N); T->hi[l + 1] = (int *)malloc(sizeof(int) * N);
+    T->child[l] = (int *)malloc(sizeof(int) * T->cnt[l]);
+    for (int k = 0; k < T->cnt[l]; k++) {
+      int lo = T->lo[l][k], hi = T->hi[l][k];
+      if (hi - lo == 1) { T->lo[l + 1][c] = lo; T->hi[l + 1][c] = hi; c++; } /* leaf: left child = itself */
+      else {
+        int mid = lo + (hi - lo + 1) / 2;
+        T->lo[l + 1][c] = lo; T->hi[l + 1][c] = mid; c++;
+        T->lo[l + 1][c] = mid; T->hi[l + 1][c] = hi; c++;
+      }
+      T->child[l][k] = c - 1;
+    }
+    T->cnt[l + 1] = c;
+    l++;
+  }
+  T->L = l;
+}
+static void levels_free(levels_t *T) {
+  for (int l = 0; l <= T->L; l++) { free(T->lo[l]); free(T->hi[l]); if (l < T->L) free(T->child[l]); }
+}
+
+typedef struct { const double *x; int N, dim; } sortctx_t;
+static int cmp_idx(const void *a, const void *b, void *ctx) {
+  const sortctx_t *g = (const sortctx_t *)ctx;
+  int ia = *(const int *)a, ib = *(const int *)b;
+  double xa = g->x[g->dim * g->N + ia], xb = g->x[g->dim * g->N + ib];
+  if (xa < xb) return -1;
+  if (xa > xb) return 1;
+  return ia - ib;
+}
+/* KD-tree permutation: split the widest coordinate at the median (BallTree build) */
+static void kd_build(const double *x, int N, int D, int *idx, int lo, int hi) {
+  if (hi - lo <= 1) return;
+  int best = 0;
+  double bext = -1;
+  for (int d = 0; d < D; d++) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = lo; i < hi; i++) { double v = x[d * N + idx[i]]; if (v < mn) mn = v; if (v > mx) mx = v; }
+    if (mx - mn > bext) { bext = mx - mn; best = d; }
+  }
+  sortctx_t g;
+  g.x = x; g.N = N; g.dim = best;
+  qsort_r(idx + lo, hi - lo, sizeof(int), cmp_idx, &g);
+  int mid = lo + (hi - lo + 1) / 2;
+  kd_build(x, N, D, idx, lo, mid);
+  kd_build(x, N, D, idx, mid, hi);
+}
+
+int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d) {
+  const int64_t S = orc_slot_stride(N);
+  const int D = mani_dim(d->manifold), F = d->nfactors, M = d->manifold;
+  double *out = arena + S * d->out_slot;
+  if (F == 1) { /* single density: AMP returns it as is */
+    memmove(out, arena + S * d->in_slot[0], sizeof(double) * (3 * N + 3));
+    if (d->labels_out >= 0) for (int n = 0; n < N; n++) side[d->labels_out + n] = n;
+    return NBP_OK;
+  }
+  levels_t T;
+  levels_build(&T, N);
+  /* per density: sorted, centred coordinates and per-level node statistics */
+  int *idx[NBP_MAXF];
+  double *xs[NBP_MAXF], ctr[NBP_MAXF][3], h2[NBP_MAXF][3];
+  double *nmean[NBP_MAXF][12], *nvar[NBP_MAXF][12];
+  for (int j = 0; j < F; j++) {
+    const double *x = arena + S * d->in_slot[j];
+    idx[j] = (int *)malloc(sizeof(int) * N);
+    for (int i = 0; i < N; i++) idx[j][i] = i;
+    kd_build(x, N, D, idx[j], 0, N);
+    xs[j] = (double *)malloc(sizeof(double) * 3 * N);
+    for (int k = 0; k < D; k++) {
+      double c = 0;
+      for (int i = 0; i < N; i++) c += x[k * N + i];
+      c /= N;
+      ctr[j][k] = c;
+      h2[j][k] = x[3 * N + k] * x[3 * N + k];
+      for (int i = 0; i < N; i++) xs[j][k * N + i] = x[k * N + idx[j][i]] - c;
+    }
+    for (int l = 0; l <= T.L; l++) {
+      nmean[j][l] = (double *)malloc(sizeof(double) * 3 * T.cnt[l]);
+      nvar[j][l] = (double *)malloc(sizeof(double) * 3 * T.cnt[l]);
+      for (int z = 0; z < T.cnt[l]; z++) {
+        int lo = T.lo[l][z], hi = T.hi[l][z], n = hi - lo;
+        for (int k = 0; k < D; k++) {
+          double s1 = 0, s2 = 0;
+          for (int i = lo; i < hi; i++) { double v = xs[j][k * N + i]; s1 += v; s2 += v * v; }
+          double mu = s1 / n, var = s2 / n - mu * mu;
+          if (var < 0) var = 0;
+          nmean[j][l][k * T.cnt[l] + z] = ctr[j][k] + mu;
+          nvar[j][l][k * T.cnt[l] + z] = var + h2[j][k]; /* moment-matched Gaussian of the sub-mixture */
+        }
+      }
+    }
+  }
+  double *res = (double *)malloc(sizeof(double) * 3 * N);
+  for (int s = 0; s < N; s++) {
+    int ind[NBP_MAXF];
+    for (int j = 0; j < F; j++) ind[j] = 0; /* levelInit!: root */
+    for (int l = 1; l <= T.L; l++) {
+      for (int j = 0; j < F; j++) ind[j] = T.child[l - 1][ind[j]]; /* levelDown! */
+      const int cnt = T.cnt[l];
+      for (int it = 0; it < d->niter; it++) {
+        for (int j = 0; j < F; j++) { /* sequential Gibbs sweep: sampleIndex(j) */
+          double mn[3], vn[3];
+          for (int k = 0; k < D; k++) { /* product of all but the jth selected Gaussians */
+            double prec = 0, acc = 0, ss = 0, sc = 0;
+            for (int q = 0; q < F; q++) {
+              if (q == j) continue;
+              double mq = nmean[q][l][k * cnt + ind[q]], vq = nvar[q][l][k * cnt + ind[q]];
+              prec += 1.0 / vq;
+              if (is_circ(M, k)) { ss += sin(mq) / vq; sc += cos(mq) / vq; }
+              else acc += mq / vq;
+            }
+            vn[k] = 1.0 / prec;
+            mn[k] = is_circ(M, k) ? atan2(ss, sc) : acc * vn[k]; /* getMu: Euclid / getCircMu */
+          }
+          double ua, ub;
+          orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), &ua, &ub);
+          double u = ua, m = -INFINITY, sum = 0;
+          int choice = -1;
+          for (int z = 0; z < cnt; z++) {
+            double e = 0;
+            for (int k = 0; k < D; k++) {
+              double tmp = nmean[j][l][k * cnt + z] - mn[k];
+              if (is_circ(M, k)) tmp = orc_wrap(tmp);
+              double v = nvar[j][l][k * cnt + z] + vn[k];
+              e += tmp * tmp / v + log(v);
+            }
+            e = -0.5 * e + log((double)(T.hi[l][z] - T.lo[l][z]) / N);
+            if (!(e > -INFINITY)) continue;
+            if (e > m) { sum = (sum > 0) ? sum * exp(m - e) : 0.0; m = e; }
+            double w = exp(e - m), sold = sum;
+            sum += w;
+            double t = u * sum;
+            if (t < w) { choice = z; u = t / w; }
+            else u = (t - w) / sold;
+            if (u > 0.99999999999999989) u = 0.99999999999999989;
+          }
+          if (choice >= 0) ind[j] = choice;
+        }
+      }
+    }
+    /* samplePoint!: draw from the product of the F selected leaf kernels */
+    double nn[4];
+    orc_normal_pair(d->seed, s, PURP_PFINAL, 0, &nn[0], &nn[1]);
+    if (D > 2) orc_normal_pair(d->seed, s, PURP_PFINAL, 1, &nn[2], &nn[3]);
+    const int cnt = T.cnt[T.L];
+    for (int k = 0; k < D; k++) {
+      double prec = 0, acc = 0, ss = 0, sc = 0;
+      for (int q = 0; q < F; q++) {
+        double mq = nmean[q][T.L][k * cnt + ind[q]], vq = nvar[q][T.L][k * cnt + ind[q]];
+        prec += 1.0 / vq;
+        if (is_circ(M, k)) { ss += sin(mq) / vq; sc += cos(mq) / vq; }
+        else acc += mq / vq;
+      }
+      double mu = is_circ(M, k) ? atan2(ss, sc) : acc / prec;
+      double v = mu + sqrt(1.0 / prec) * nn[k];
+      res[k * N + s] = is_circ(M, k) ? orc_wrap(v) : v;
+    }
+    if (d->labels_out >= 0)
+      for (int j = 0; j < F; j++) side[d->labels_out + s * F + j] = idx[j][T.lo[T.L][ind[j]]];
+  }
+  for (int k = 0; k < D; k++) memcpy(out + k * N, res + k * N, sizeof(double) * N);
+  for (int k = D; k < 3; k++) memset(out + k * N, 0, sizeof(double) * N);
+  free(res);
+  for (int j = 0; j < F; j++) {
+    free(idx[j]); free(xs[j]);
+    for (int l = 0; l <= T.L; l++) { free(nmean[j][l]); free(nvar[j][l]); }
+  }
+  levels_free(&T);
+  fit_bandwidth(out, N, M); /* rebandwidth of the product */
+  return NBP_OK;
+}
+
+void orc_run_copy(double *arena, int32_t N, const nbp_copy_desc *c) {
+  const int64_t S = orc_slot_stride(N);
+  memmove(arena + S * c->dst_slot, arena + S * c->src_slot, sizeof(double) * S);
+}
+
+/* batch drivers, used by the CPU baseline: the same stage semantics as nbp_program_run */
+/* ops of one stage are independent by construction (distinct out slots), so the multi-core
+ * baseline runs them with OpenMP -- the analogue of the reference's task-per-clique concurrency
+ * (services/SolverAPI.jl:59-97). */
+int32_t orc_run_proposals(double *arena, int32_t N, int32_t *side, const nbp_proposal_desc *d, int32_t n) {
+  int rc = NBP_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; i++) { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; }
+  return rc;
+}
+int32_t orc_run_products(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d, int32_t n) {
+  int rc = NBP_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; }
+  return rc;
+}
+void orc_set_threads(int32_t n);
+void orc_run_copies(double *arena, int32_t N, const nbp_copy_desc *c, int32_t n) {
+  for (int i = 0; i < n; i++) orc_run_copy(arena, N, c + i);
+}
+
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int32_t n) { omp_set_num_threads(n); }
+int32_t orc_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int32_t n) { (void)n; }
+int32_t orc_get_max_threads(void) { return 1; }
+#endif

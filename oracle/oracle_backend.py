@@ -1,0 +1,171 @@
+"""CPU oracle backend -- TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's
+cpu_baseline leg).  Implements the same backend interface as iif_amd.backend.HipBackend on top of
+oracle/liboracle.so (plain C restatement, oracle/nbp_oracle.c).  Never imported by the package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import iif_amd_loader
+
+abi = iif_amd_loader.load().abi
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _DIR, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_DIR, "nbp_oracle.c")):
+            build()
+        L = C.CDLL(_SO)
+        dp, ip, i32 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32
+        L.orc_slot_stride.restype = C.c_int64
+        L.orc_slot_write.argtypes = [dp, i32, i32, i32, dp, dp]
+        L.orc_slot_write.restype = None
+        L.orc_slot_read.argtypes = [dp, i32, i32, i32, dp, dp]
+        L.orc_slot_read.restype = None
+        L.orc_run_proposals.argtypes = [dp, i32, ip, C.POINTER(abi.ProposalDesc), i32]
+        L.orc_run_products.argtypes = [dp, i32, ip, C.POINTER(abi.ProductDesc), i32]
+        L.orc_run_copies.argtypes = [dp, i32, C.POINTER(abi.CopyDesc), i32]
+        L.orc_run_copies.restype = None
+        L.orc_run_bandwidth.argtypes = [dp, i32, i32, i32]
+        L.orc_run_bandwidth.restype = None
+        L.orc_lcv_bandwidth_1d.argtypes = [dp, i32, i32]
+        L.orc_lcv_bandwidth_1d.restype = C.c_double
+        L.orc_wrap.argtypes = [C.c_double]
+        L.orc_wrap.restype = C.c_double
+        L.orc_std_basic_spread.argtypes = [i32, dp, i32]
+        L.orc_std_basic_spread.restype = C.c_double
+        L.orc_residual.argtypes = [i32, i32, dp, dp, dp, dp]
+        L.orc_solve_particle.argtypes = [i32, i32, dp, dp, i32, dp]
+        L.orc_hypo_recipe.argtypes = [i32, dp, i32, i32, C.c_double, ip, i32, ip, ip, ip, ip, ip, ip, ip]
+        L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        L.orc_philox.restype = None
+        L.orc_uniform_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp, dp]
+        L.orc_uniform_pair.restype = None
+        L.orc_normal_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp, dp]
+        L.orc_normal_pair.restype = None
+        L.orc_set_threads.argtypes = [i32]
+        L.orc_set_threads.restype = None
+        L.orc_get_max_threads.restype = i32
+        L.orc_diag_read.argtypes = [C.POINTER(C.c_int64 * 5), i32]
+        L.orc_diag_read.restype = None
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, N, n_slots, side_ints=0, threads=1, **_):
+        self.lib = lib()
+        self.N, self.n_slots = int(N), int(n_slots)
+        self.arena = np.zeros(self.n_slots * abi.slot_stride(self.N))
+        self.side = np.zeros(max(int(side_ints), 1), dtype=np.int32)
+        self.threads = threads
+
+    def close(self):
+        pass
+
+    def _sidep(self):
+        return self.side.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def slot_write(self, slot, manifold, pts, bw=None):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(self.N, abi.MANIFOLD_P[manifold])
+        bwp = None
+        if bw is not None:
+            bw = np.ascontiguousarray(bw, dtype=np.float64)
+            bwp = _dp(bw)
+        self.lib.orc_slot_write(_dp(self.arena), self.N, slot, manifold, _dp(pts), bwp)
+
+    def slot_read(self, slot, manifold):
+        pts = np.empty((self.N, abi.MANIFOLD_P[manifold]))
+        bw = np.empty(abi.MANIFOLD_DIM[manifold])
+        self.lib.orc_slot_read(_dp(self.arena), self.N, slot, manifold, _dp(pts), _dp(bw))
+        return pts, bw
+
+    def side_write(self, offset, ints):
+        a = np.asarray(ints, dtype=np.int32)
+        self.side[offset:offset + a.size] = a
+
+    def side_read(self, offset, n):
+        return self.side[offset:offset + n].copy()
+
+    def _arr(self, descs, ctype):
+        if isinstance(descs, C.Array):
+            return descs, len(descs)
+        return (ctype * len(descs))(*descs), len(descs)
+
+    def run_proposals(self, descs):
+        self.lib.orc_set_threads(self.threads)
+        arr, n = self._arr(descs, abi.ProposalDesc)
+        rc = self.lib.orc_run_proposals(_dp(self.arena), self.N, self._sidep(), arr, n)
+        if rc:
+            raise RuntimeError(f"oracle status {rc}")
+
+    def run_products(self, descs):
+        self.lib.orc_set_threads(self.threads)
+        arr, n = self._arr(descs, abi.ProductDesc)
+        rc = self.lib.orc_run_products(_dp(self.arena), self.N, self._sidep(), arr, n)
+        if rc:
+            raise RuntimeError(f"oracle status {rc}")
+
+    def run_copies(self, descs):
+        arr, n = self._arr(descs, abi.CopyDesc)
+        self.lib.orc_run_copies(_dp(self.arena), self.N, arr, n)
+
+    def run_bandwidth(self, slots, manifolds):
+        for s, m in zip(slots, manifolds):
+            self.lib.orc_run_bandwidth(_dp(self.arena), self.N, int(s), int(m))
+
+    def synchronize(self):
+        pass
+
+    def program(self, stages):
+        return OracleProgram(self, stages)
+
+    def diag(self, reset=False):
+        d = (C.c_int64 * 5)()
+        self.lib.orc_diag_read(C.byref(d), int(reset))
+        return dict(zip(["solves", "nonconverged", "nan_results", "residual_evals", "lcv_evals"], list(d)))
+
+
+class OracleProgram:
+    def __init__(self, backend, stages):
+        self.backend = backend
+        self.stages = [(k, backend._arr(d, {abi.STAGE_PROPOSALS: abi.ProposalDesc,
+                                            abi.STAGE_PRODUCTS: abi.ProductDesc,
+                                            abi.STAGE_COPIES: abi.CopyDesc}[k])[0]) for k, d in stages]
+        self.n_stages = len(stages)
+
+    def run(self, first=0, last=-1):
+        last = self.n_stages if last < 0 else last
+        for kind, arr in self.stages[first:last]:
+            if kind == abi.STAGE_PROPOSALS:
+                self.backend.run_proposals(arr)
+            elif kind == abi.STAGE_PRODUCTS:
+                self.backend.run_products(arr)
+            else:
+                self.backend.run_copies(arr)
+
+    def reseed(self, salt):
+        from iif_amd.seeds import mix_seed
+        for kind, arr in self.stages:
+            if kind != abi.STAGE_COPIES:
+                for d in arr:
+                    d.seed = mix_seed(d.seed, salt)
+
+    def close(self):
+        pass
