@@ -3,7 +3,7 @@
 The host-side mirror of the reference API (factorgraph.py / solver.py) talks to a *backend*
 through this narrow interface: belief slots in, descriptor batches run, belief slots out.
 The product backend is :class:`HipBackend`.  (The CPU oracle implements the same interface in
-``oracle/oracle_backend.py`` -- test infrastructure, never imported from this package.)
+``oracle/`` -- test infrastructure, never imported from this package.)
 """
 import ctypes as C
 

@@ -122,6 +122,7 @@ static int is_circ(int m, int d) { return (m == NBP_CIRCULAR && d == 0) || (m ==
 
 /* Manifolds.sym_rem: wrap to [-pi, pi) */
 double orc_wrap(double a) {
+  if (a >= -PI && a < PI) return a; /* exact identity on the principal interval */
   double r = fmod(a + PI, TWO_PI);
   if (r < 0) r += TWO_PI;
   return r - PI;

@@ -1,0 +1,224 @@
+"""-m gpu: the HIP kernels against the CPU oracle on identical seeded inputs, through the C ABI.
+Floating point: <= 1e-9 relative per particle; integers (mhidx, product labels) identical."""
+import numpy as np
+import pytest
+
+from parity_utils import (abi, assert_points_close, both, iif, product_desc, rand_points,
+                          relative_factor_desc)
+
+pytestmark = pytest.mark.gpu
+
+MANIS = [abi.EUCLID1, abi.EUCLID2, abi.EUCLID3, abi.CIRCULAR, abi.SE2]
+
+
+@pytest.mark.parametrize("manifold", MANIS)
+@pytest.mark.parametrize("N", [100, 200])
+def test_bandwidth_lcv(oracle_backend, hip_backend, manifold, N):
+    rng = np.random.default_rng(manifold * 1000 + N)
+    pts = rand_points(rng, manifold, N, center=0.5, spread=0.7)
+
+    def setup(be):
+        be.slot_write(0, manifold, pts)
+
+    o, h = both(oracle_backend, hip_backend, N, 2, 0, setup, lambda be: be.run_bandwidth([0], [manifold]),
+                lambda be: be.slot_read(0, manifold))
+    assert_points_close(manifold, o[0], h[0], what="slot roundtrip")
+    np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
+    assert (o[1] > 0).all()
+
+
+@pytest.mark.parametrize("manifold,kind", [(abi.EUCLID1, abi.F_PRIOR), (abi.EUCLID2, abi.F_PRIOR),
+                                           (abi.EUCLID3, abi.F_PRIOR), (abi.CIRCULAR, abi.F_PRIOR),
+                                           (abi.SE2, abi.F_PRIOR)])
+@pytest.mark.parametrize("nullhypo", [0.0, 0.3])
+def test_prior_proposal(oracle_backend, hip_backend, manifold, kind, nullhypo):
+    N = 200
+    rng = np.random.default_rng(7 + manifold)
+    cur = rand_points(rng, manifold, N, center=1.0, spread=0.5)
+    D = abi.MANIFOLD_DIM[manifold]
+    d = relative_factor_desc(kind, manifold, 1, 0, [0], 1, 4242 + manifold, [0.3, -0.2, 0.5][:D], [0.1, 0.2, 0.05][:D],
+                             nullhypo=nullhypo, mhidx_out=0)
+
+    def setup(be):
+        be.slot_write(0, manifold, cur)
+
+    o, h = both(oracle_backend, hip_backend, N, 2, N, setup, lambda be: be.run_proposals([d]),
+                lambda be: (be.slot_read(1, manifold), be.side_read(0, N)))
+    np.testing.assert_array_equal(o[1], h[1])
+    assert_points_close(manifold, o[0][0], h[0][0], what="prior proposal")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    if nullhypo > 0:
+        assert 0 < (o[1] == 0).sum() < N
+
+
+CASES = [
+    (abi.F_LINREL, abi.EUCLID1, [1.0], [0.1]),
+    (abi.F_LINREL, abi.EUCLID2, [1.0, 1.0], [0.1, 0.1]),
+    (abi.F_LINREL, abi.EUCLID3, [1.0, 0.0, -0.5], [0.1, 0.2, 0.1]),
+    (abi.F_CIRCULAR, abi.CIRCULAR, [0.4], [0.05]),
+    (abi.F_SE2, abi.SE2, [1.0, 0.2, 0.3], [0.1, 0.1, 0.01]),
+    (abi.F_EUCLIDDIST, abi.EUCLID2, [3.0], [0.1]),
+]
+
+
+@pytest.mark.parametrize("kind,manifold,mean,sig", CASES)
+@pytest.mark.parametrize("sfidx", [0, 1])
+def test_relative_conv(oracle_backend, hip_backend, kind, manifold, mean, sig, sfidx):
+    N = 200
+    rng = np.random.default_rng(100 * kind + manifold + sfidx)
+    a = rand_points(rng, manifold, N, center=0.0, spread=0.3)
+    b = rand_points(rng, manifold, N, center=1.0, spread=0.3)
+    d = relative_factor_desc(kind, manifold, 2, sfidx, [0, 1], 2, 999 + kind * 7 + sfidx, mean, sig)
+
+    def setup(be):
+        be.slot_write(0, manifold, a)
+        be.slot_write(1, manifold, b)
+
+    def read(be):
+        return be.slot_read(2, manifold), be.slot_read(sfidx, manifold), be.diag(reset=True)
+
+    o, h = both(oracle_backend, hip_backend, N, 3, 0, setup, lambda be: be.run_proposals([d]), read)
+    # EuclidDistance has a ring of solutions: Nelder-Mead walks to it from the inflated start, a
+    # rare branch flip may move a particle along the ring by more than the tolerance
+    max_bad = 2 if kind == abi.F_EUCLIDDIST else 0
+    assert_points_close(manifold, o[0][0], h[0][0], rtol=1e-7 if kind == abi.F_EUCLIDDIST else 1e-9, max_bad=max_bad,
+                        what="relative conv")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-6 if kind == abi.F_EUCLIDDIST else 1e-9)
+    # mutation contract: the stored belief of the target is untouched (testMultiHypo3Door.jl:74-90)
+    assert_points_close(manifold, h[1][0], b if sfidx == 1 else a, what="target belief untouched")
+    assert h[2]["solves"] == 3 * N == o[2]["solves"]
+    assert h[2]["nan_results"] == 0
+
+
+def test_mixture_and_nullhypo_conv(oracle_backend, hip_backend):
+    N, manifold = 300, abi.EUCLID3
+    rng = np.random.default_rng(5)
+    a = rand_points(rng, manifold, N)
+    b = rand_points(rng, manifold, N, center=1.0)
+    comps = [(0.8, [1, 0, 0], [0.1, 0.1, 0.1]), (0.2, [1, 0, 0], [1.0, 1.0, 1.0])]
+    d = relative_factor_desc(abi.F_LINREL, manifold, 2, 1, [0, 1], 2, 31337, None, None, ncomp=2, comps=comps,
+                             nullhypo=0.25, mhidx_out=0)
+
+    def setup(be):
+        be.slot_write(0, manifold, a)
+        be.slot_write(1, manifold, b)
+
+    o, h = both(oracle_backend, hip_backend, N, 3, N, setup, lambda be: be.run_proposals([d]),
+                lambda be: (be.slot_read(2, manifold), be.side_read(0, N)))
+    np.testing.assert_array_equal(o[1], h[1])
+    assert_points_close(manifold, o[0][0], h[0][0], what="mixture conv")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("sfidx", [0, 1, 3])
+def test_multihypo_conv_injected_mhidx(oracle_backend, hip_backend, sfidx):
+    """door-sighting pattern (testMultiHypo3Door.jl:57): [x, l0..l3], multihypo=[1,.25,.25,.25,.25]."""
+    N, manifold = 200, abi.CIRCULAR
+    rng = np.random.default_rng(11 + sfidx)
+    doors = [-2.4, -0.8, 0.8, 2.4]
+    pts = [rand_points(rng, manifold, N, center=0.7, spread=0.2)] + [rand_points(rng, manifold, N, center=t, spread=0.01) for t in doors]
+    mh = [0.0, 0.25, 0.25, 0.25, 0.25]
+    if sfidx == 0:
+        mhidx = rng.integers(2, 6, size=N).astype(np.int32)
+    else:
+        mhidx = rng.choice([0, 2, 3, 4, 5], size=N).astype(np.int32)
+    d = relative_factor_desc(abi.F_CIRCULAR, manifold, 5, sfidx, [0, 1, 2, 3, 4], 5, 77 + sfidx, [0.0], [0.1],
+                             multihypo=mh, mhidx_in=0, mhidx_out=N)
+
+    def setup(be):
+        for i, p in enumerate(pts):
+            be.slot_write(i, manifold, p)
+        be.side_write(0, mhidx)
+
+    o, h = both(oracle_backend, hip_backend, N, 6, 2 * N, setup, lambda be: be.run_proposals([d]),
+                lambda be: (be.slot_read(5, manifold), be.side_read(N, N)))
+    np.testing.assert_array_equal(h[1], mhidx)
+    np.testing.assert_array_equal(o[1], mhidx)
+    assert_points_close(manifold, o[0][0], h[0][0], what="multihypo conv")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+
+
+def test_multihypo_sampled_mhidx_identical(oracle_backend, hip_backend):
+    N, manifold = 200, abi.CIRCULAR
+    rng = np.random.default_rng(3)
+    pts = [rand_points(rng, manifold, N, spread=0.3) for _ in range(5)]
+    d = relative_factor_desc(abi.F_CIRCULAR, manifold, 5, 2, [0, 1, 2, 3, 4], 5, 555, [0.0], [0.1],
+                             multihypo=[0.0, 0.25, 0.25, 0.25, 0.25], mhidx_out=0)
+
+    def setup(be):
+        for i, p in enumerate(pts):
+            be.slot_write(i, manifold, p)
+
+    o, h = both(oracle_backend, hip_backend, N, 6, N, setup, lambda be: be.run_proposals([d]),
+                lambda be: (be.slot_read(5, manifold), be.side_read(0, N)))
+    np.testing.assert_array_equal(o[1], h[1])
+    assert set(np.unique(o[1])) <= {0, 2, 3, 4, 5} and (o[1] == 0).any()
+    assert_points_close(manifold, o[0][0], h[0][0])
+
+
+def test_msgprior_proposal(oracle_backend, hip_backend):
+    N, manifold = 200, abi.SE2
+    rng = np.random.default_rng(21)
+    cur = rand_points(rng, manifold, N)
+    msg = rand_points(rng, manifold, N, center=2.0, spread=0.2)
+    d = relative_factor_desc(abi.F_MSGPRIOR, manifold, 1, 0, [0, 1], 2, 8080, [0], [0])
+
+    def setup(be):
+        be.slot_write(0, manifold, cur)
+        be.slot_write(1, manifold, msg, bw=np.array([0.05, 0.07, 0.02]))
+
+    o, h = both(oracle_backend, hip_backend, N, 3, 0, setup, lambda be: be.run_proposals([d]),
+                lambda be: be.slot_read(2, manifold))
+    assert_points_close(manifold, o[0], h[0], what="MsgPrior proposal")
+    np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("manifold", MANIS)
+@pytest.mark.parametrize("F", [2, 3])
+def test_manifold_product(oracle_backend, hip_backend, manifold, F):
+    N = 200
+    rng = np.random.default_rng(manifold * 10 + F)
+    D = abi.MANIFOLD_DIM[manifold]
+    dens = [rand_points(rng, manifold, N, center=0.2 * j, spread=0.5) for j in range(F)]
+    bws = [np.full(D, 0.15 + 0.03 * j) for j in range(F)]
+    d = product_desc(manifold, list(range(F)), F, 2024 + manifold + F, labels_out=0)
+
+    def setup(be):
+        for j in range(F):
+            be.slot_write(j, manifold, dens[j], bws[j])
+
+    o, h = both(oracle_backend, hip_backend, N, F + 1, N * F, setup, lambda be: be.run_products([d]),
+                lambda be: (be.slot_read(F, manifold), be.side_read(0, N * F)))
+    lab_o, lab_h = o[1].reshape(N, F), h[1].reshape(N, F)
+    same = (lab_o == lab_h).all(axis=1)
+    assert same.sum() >= N - 1, f"{N - same.sum()} samples picked different labels"
+    assert_points_close(manifold, o[0][0][same], h[0][0][same], what="product samples")
+    if same.all():
+        np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+
+
+def test_product_passthrough_single_density(oracle_backend, hip_backend):
+    N, manifold = 100, abi.EUCLID2
+    rng = np.random.default_rng(1)
+    p = rand_points(rng, manifold, N)
+    d = product_desc(manifold, [0], 1, 5)
+
+    def setup(be):
+        be.slot_write(0, manifold, p, np.array([0.3, 0.4]))
+
+    o, h = both(oracle_backend, hip_backend, N, 2, 0, setup, lambda be: be.run_products([d]),
+                lambda be: be.slot_read(1, manifold))
+    np.testing.assert_array_equal(h[0], p)
+    np.testing.assert_array_equal(h[1], [0.3, 0.4])
+    np.testing.assert_array_equal(o[0], p)
+
+
+def test_error_codes(hip_backend):
+    be = hip_backend(100, 2, 0)
+    d = relative_factor_desc(abi.F_LINREL, abi.EUCLID1, 2, 1, [0, 7], 1, 1, [1.0], [0.1])  # slot 7 out of range
+    with pytest.raises(iif.NbpError):
+        be.run_proposals([d])
+    d2 = relative_factor_desc(99, abi.EUCLID1, 2, 1, [0, 1], 1, 1, [1.0], [0.1])
+    with pytest.raises(iif.NbpError):
+        be.run_proposals([d2])
+    be.close()
