@@ -142,6 +142,7 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
     for (int g = 0; g < R.ngroups; g++) {
       if (R.empty[g]) continue;
       const int hyp = R.hypo[g];
+      if (!__syncthreads_or(myh == hyp)) continue;  // empty allelements[g]: nothing to do
       const bool solve_case = (in_list(R.certain, R.ncertain, sf1) && hyp != 0) || in_list(R.certain, R.ncertain, hyp) || hyp == sf1;
       if (solve_case) {
         const int va = R.act[g][0], vb = R.act[g][1];
@@ -376,10 +377,11 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
           }
           double ua, ub;
           uniform_pair(d->seed, tid, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
-          double u = ua, m = -INFINITY, sum = 0;
-          int choice = -1;
+          // rand(Categorical(p)) by inverse CDF over the nodes of this level.  Pass 1: running
+          // max + rescaled total; pass 2: cumulative sum until u*total (weights are recomputed,
+          // not stored: N doubles per lane would not fit in registers or LDS).
           const double *mj = lm + j * D * N, *vj = lv + j * D * N;
-          for (int z = 0; z < cnt; z++) {
+          auto node_e = [&](int z) -> double {
             double e = 0;
 #pragma unroll
             for (int k = 0; k < D; k++) {
@@ -388,16 +390,22 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
               const double v = vj[k * N + z] + vn[k];
               e += tmp * tmp / v + log(v);
             }
-            e = -0.5 * e + T.node_logw[off + z];
-            if (!(e > -INFINITY)) continue;
-            if (e > m) { sum = (sum > 0) ? sum * exp(m - e) : 0.0; m = e; }
-            const double w = exp(e - m), sold = sum;
-            sum += w;
-            const double t = u * sum;
-            if (t < w) { choice = z; u = t / w; }
-            else u = (t - w) / sold;
-            if (u > 0.99999999999999989) u = 0.99999999999999989;
+            return -0.5 * e + T.node_logw[off + z];
+          };
+          double m = -INFINITY, tot = 0;
+          for (int z = 0; z < cnt; z++) {
+            const double e = node_e(z);
+            if (e > m) { tot = (tot > 0) ? tot * exp(m - e) : 0.0; m = e; }
+            tot += exp(e - m);
           }
+          const double target = ua * tot;
+          double c = 0;
+          int choice = -1;
+          for (int z = 0; z < cnt; z++) {
+            c += exp(node_e(z) - m);
+            if (target < c) { choice = z; break; }
+          }
+          if (choice < 0) choice = cnt - 1;
           if (choice >= 0) ind[j * TB + tid] = choice;
         }
       }

@@ -770,6 +770,9 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
       int hyp = R.hypo[g];
       int solve_case = (in_list(R.certain, R.ncertain, sf1) && hyp != 0) || in_list(R.certain, R.ncertain, hyp) || hyp == sf1;
       if (R.empty[g]) continue;
+      int nelem = 0;
+      for (int n = 0; n < N; n++) nelem += (mhidx[n] == hyp);
+      if (nelem == 0) continue; /* empty allelements[g]: every loop of the reference is a no-op */
       if (solve_case) {
         if (R.nact[g] != 2) { free(Z); free(mhidx); return NBP_ERR_ARG; } /* binary mechanics only */
         int va = R.act[g][0], vb = R.act[g][1];
@@ -938,25 +941,25 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
           }
           double ua, ub;
           orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), &ua, &ub);
-          double u = ua, m = -INFINITY, sum = 0;
-          int choice = -1;
-          for (int z = 0; z < cnt; z++) {
-            double e = 0;
-            for (int k = 0; k < D; k++) {
-              double tmp = nmean[j][l][k * cnt + z] - mn[k];
-              if (is_circ(M, k)) tmp = orc_wrap(tmp);
-              double v = nvar[j][l][k * cnt + z] + vn[k];
-              e += tmp * tmp / v + log(v);
+          /* rand(Categorical(p)) by inverse CDF (max-stabilised weights) */
+          double u = ua; int choice = -1;
+          {
+            double ev[NBP_MAXN]; double m = -INFINITY;
+            for (int z = 0; z < cnt; z++) {
+              double e = 0;
+              for (int k = 0; k < D; k++) {
+                double tmp = nmean[j][l][k * cnt + z] - mn[k];
+                if (is_circ(M, k)) tmp = orc_wrap(tmp);
+                double v = nvar[j][l][k * cnt + z] + vn[k];
+                e += tmp * tmp / v + log(v);
+              }
+              e = -0.5 * e + log((double)(T.hi[l][z] - T.lo[l][z]) / N);
+              ev[z] = e; if (e > m) m = e;
             }
-            e = -0.5 * e + log((double)(T.hi[l][z] - T.lo[l][z]) / N);
-            if (!(e > -INFINITY)) continue;
-            if (e > m) { sum = (sum > 0) ? sum * exp(m - e) : 0.0; m = e; }
-            double w = exp(e - m), sold = sum;
-            sum += w;
-            double t = u * sum;
-            if (t < w) { choice = z; u = t / w; }
-            else u = (t - w) / sold;
-            if (u > 0.99999999999999989) u = 0.99999999999999989;
+            double tot = 0; for (int z = 0; z < cnt; z++) { ev[z] = exp(ev[z] - m); tot += ev[z]; }
+            double target = u * tot, c = 0;
+            for (int z = 0; z < cnt; z++) { c += ev[z]; if (target < c) { choice = z; break; } }
+            if (choice < 0) choice = cnt - 1;
           }
           if (choice >= 0) ind[j] = choice;
         }
