@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""bench.py -- clique-messages/s of the MI355X-native nonparametric belief-propagation solve.
+
+A "step" is one full up+down solveTree pass (every clique up-solved and down-solved once) over the
+BASELINE.json config-2 graph: ContinuousEuclid(2) odometry chain with periodic priors, N=200
+particles, nested-dissection elimination order; beliefs are resident in HBM when the timed region
+starts (the init beliefs are restored from a device-side snapshot at the start of every step).
+
+Prints ONE JSON line (see the driver contract).  value = clique messages (one per tree edge and
+direction, CliqueStateMachine.jl:590-593/900-903) per second over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nvars", type=int, default=1000, help="variables per GPU (config 2: 1000; north-star 2': 10000)")
+    ap.add_argument("--particles", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-vars", type=int, default=96)
+    return ap.parse_args()
+
+
+def build_workload(iif, nvars, N, seed):
+    fg = iif.generateChainEuclid(nvars, vardims=2, priorEvery=100, N=N)
+    order = iif.nestedDissectionOrder(fg)
+    tree = iif.buildTreeReset(fg, order)
+    return fg, order, tree
+
+
+def cpu_baseline(iif, nvars, N, threads):
+    """the CPU restatement (oracle/, kind="port") on a bounded sample: the same chain shape with
+    fewer variables, one full up+down solve, OpenMP over the independent ops of a stage."""
+    from oracle.oracle_backend import OracleBackend
+    fg, order, tree = build_workload(iif, nvars, N, 0)
+    mk = lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=threads)
+    iif.initAll(fg, backend=mk, seed=0)
+    tp = iif.TreeProgram(fg, tree, seed=1)
+    be = mk(N, tp.n_slots)
+    for v in fg.ls():
+        var = fg.getVariable(v)
+        be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+    prog = be.program(tp.stages)
+    t0 = time.perf_counter()
+    prog.run()
+    dt = time.perf_counter() - t0
+    return tp.n_messages / dt, dt, tp.n_messages
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import iif_amd_loader
+    iif = iif_amd_loader.load()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    N = a.particles
+    from bench_support import RankSolve
+    rs = RankSolve(iif, a.nvars, N, rank, world, local, dist)
+    rs.prepare()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        rs.be.synchronize()
+
+    for w in range(a.warmup):
+        rs.step(1000 + w)
+    rs.be.timing_enable(True)
+    rs.be.timing_read()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        rs.step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tim = rs.be.timing_read()
+    rs.be.timing_enable(False)
+    rs.check_posteriors()
+
+    msgs_total = rs.global_messages
+    value = msgs_total * a.steps / dt
+    st = rs.stats
+    # roofline of the dominant kernel (HIP events on the library stream)
+    prop_avg = tim["proposals_ms"] / max(tim["proposals_launches"], 1)
+    prod_avg = tim["products_ms"] / max(tim["products_launches"], 1)
+    dominant = "nbp_product_kernel" if tim["products_ms"] >= tim["proposals_ms"] else "nbp_proposal_kernel"
+    share = st["alg_bytes_product"] if dominant == "nbp_product_kernel" else st["alg_bytes_proposal"]
+    launches = (tim["products_launches"] if dominant == "nbp_product_kernel" else tim["proposals_launches"]) / a.steps
+    avg_ms = prod_avg if dominant == "nbp_product_kernel" else prop_avg
+    bytes_per_launch = share / max(launches, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "clique-messages/sec", "value": value, "unit": "messages/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"ContinuousEuclid(2) {a.nvars * world}-variable odometry chain + priors every 100, "
+                               f"N={N} particles, nested-dissection order, full up+down solveTree",
+                   "variables_per_gpu": a.nvars, "particles": N, "cliques": st["cliques_global"],
+                   "messages_per_step": msgs_total, "variable_updates_per_step": st["updates_global"],
+                   "parallelism": f"cliques sharded over {world} GPU(s)" if world > 1 else "single GPU"},
+        "solve_wall_s": dt / a.steps, "posterior_max_mean_err": getattr(rs, "posterior_max_mean_err", None),
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": achieved / 8000.0, "traffic": None,
+                     "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
+                     "launches_per_step": launches,
+                     "kernel_ms_per_step": {"nbp_proposal_kernel": tim["proposals_ms"] / a.steps,
+                                            "nbp_product_kernel": tim["products_ms"] / a.steps},
+                     "note": "latency/FP64-VALU bound by construction: ~13 KB algorithmic bytes per variable "
+                             "update against ~1e7 FP64 exp/log/div; see DESIGN.md"},
+    }
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        threads = os.cpu_count() or 1
+        v, secs, m = cpu_baseline(iif, a.cpu_sample_vars, N, threads)
+        out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port",
+                               "sample": f"{a.cpu_sample_vars}-variable chain of the same shape, N={N}, one full "
+                                         f"up+down solve ({m} messages) in {secs:.1f} s, OpenMP over stage ops"}
+        out["vs_cpu_baseline"] = value / v
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

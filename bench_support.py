@@ -1,0 +1,57 @@
+"""Per-rank solve object used by bench.py (single GPU now; sharded multi-GPU in dist_solver)."""
+import numpy as np
+
+
+class RankSolve:
+    def __init__(self, iif, nvars, N, rank, world, local, dist):
+        self.iif, self.nvars, self.N = iif, nvars, N
+        self.rank, self.world, self.local, self.dist = rank, world, local, dist
+
+    def prepare(self):
+        iif = self.iif
+        if self.world > 1:
+            from iif_amd.dist_solver import ShardedTreeSolve
+            self.impl = ShardedTreeSolve(iif, self.nvars * self.world, self.N, self.rank, self.world, self.local, self.dist)
+            self.impl.prepare()
+            self.be = self.impl.be
+            self.global_messages = self.impl.global_messages
+            self.stats = self.impl.stats
+            return
+        fg = iif.generateChainEuclid(self.nvars, vardims=2, priorEvery=100, N=self.N)
+        order = iif.nestedDissectionOrder(fg)
+        tree = iif.buildTreeReset(fg, order)
+        mk = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints, device=self.local)
+        iif.initAll(fg, backend=mk, seed=0)
+        self.fg, self.tree = fg, tree
+        tp = iif.TreeProgram(fg, tree, seed=1, snapshot=True)
+        self.tp = tp
+        self.be = mk(self.N, tp.n_slots)
+        for v in fg.ls():
+            var = fg.getVariable(v)
+            self.be.slot_write(tp.snap[v], var.varType.manifold, var.val, var.bw)
+        self.prog = self.be.program(tp.stages)
+        st = tp.stats()
+        self.global_messages = tp.n_messages
+        self.stats = {"cliques_global": st["cliques"], "updates_global": st["updates_up"] + st["updates_down"],
+                      "alg_bytes_product": tp.alg_bytes_product, "alg_bytes_proposal": tp.alg_bytes_proposal}
+
+    def step(self, k):
+        if self.world > 1:
+            return self.impl.step(k)
+        self.prog.reseed(0x9E37 + k)
+        self.prog.run()
+
+    def check_posteriors(self):
+        """posteriors within the BASELINE.md tolerance of the ground truth x_i = (i, i)"""
+        if self.world > 1:
+            return self.impl.check_posteriors()
+        tp, fg = self.tp, self.fg
+        worst = 0.0
+        for i in range(0, self.nvars, max(1, self.nvars // 64)):
+            pts, _ = self.be.slot_read(tp.main[f"x{i}"], fg.getVariable(f"x{i}").varType.manifold)
+            worst = max(worst, float(np.abs(pts.mean(axis=0) - i).max()))
+        self.posterior_max_mean_err = worst
+        # NBP posteriors carry Monte-Carlo error of the order of the posterior sigma (~0.5 midway
+        # between priors); the CPU oracle shows the same level (tests/test_gpu_tree_parity.py)
+        if not worst < 1.5:
+            raise RuntimeError(f"posterior means off by {worst}: result invalid")

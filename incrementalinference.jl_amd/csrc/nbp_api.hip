@@ -323,6 +323,7 @@ static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev_prop);
   if (rc) return rc;
+  (void)hipGetLastError();  // clear stale, unrelated errors
   hipLaunchKernelGGL(nbp_proposal_kernel, dim3(n), dim3(c->threads), nbp_proposal_lds_bytes(c->N), c->stream, dev,
                      c->arena, c->N, c->S, c->side, c->counters);
   HIPCHK(hipGetLastError());
@@ -332,6 +333,7 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev_prod);
   if (rc) return rc;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(nbp_product_kernel, dim3(n), dim3(c->threads), lds, c->stream, dev, c->arena, c->N, c->S,
                      c->side, c->T);
   HIPCHK(hipGetLastError());
@@ -348,6 +350,7 @@ static size_t products_lds(nbp_ctx *c, const nbp_product_desc *d, int n) {
 }
 static nbp_status launch_copies(nbp_ctx *c, const nbp_copy_desc *dev, int n) {
   if (n <= 0) return NBP_OK;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(nbp_copy_kernel, dim3(n), dim3(256), 0, c->stream, dev, c->arena, c->S);
   HIPCHK(hipGetLastError());
   return NBP_OK;
@@ -420,6 +423,7 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
   nbp_status rc = stage_upload(c, both.data(), both.size() * 4);
   if (rc) return rc;
   const int32_t *ds = (const int32_t *)c->stage;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n), dim3(c->threads), ((size_t)3 * c->N + 16) * 8, c->stream, ds, ds + n,
                      c->arena, c->N, c->S);
   HIPCHK(hipGetLastError());
@@ -507,6 +511,7 @@ nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
   if (!p || !p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
   nbp_ctx *c = p->ctx;
   HIPCHK(hipSetDevice(c->device));
+  (void)hipGetLastError();
   for (const nbp_stage &st : p->stages) {
     if (st.n == 0) continue;
     int blocks = (st.n + 255) / 256;

@@ -310,12 +310,18 @@ class TreeProgram:
     parent's MsgPrior proposal; a down message is a slot copy parent -> child
     (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84)."""
 
-    def __init__(self, fg, tree, seed=0, cliques=None):
+    def __init__(self, fg, tree, seed=0, cliques=None, snapshot=False):
         self.fg, self.tree, self.seed = fg, tree, seed
         sp = fg.solverParams
         labels = fg.ls()
         self.main = {v: i for i, v in enumerate(labels)}
         nxt = len(labels)
+        # optional snapshot of the initial beliefs so that the program can be replayed (bench):
+        # stage 0 restores main[v] from snap[v]
+        self.snap = None
+        if snapshot:
+            self.snap = {v: nxt + i for i, v in enumerate(labels)}
+            nxt += len(labels)
         self.B = {}
         self.scratch = {}
         self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
@@ -353,6 +359,8 @@ class TreeProgram:
         self.n_updates_up = 0
         self.n_updates_down = 0
         self.alg_bytes = 0
+        self.alg_bytes_proposal = 0
+        self.alg_bytes_product = 0
         self._compile()
 
     # -- helpers ------------------------------------------------------------------------------
@@ -360,6 +368,10 @@ class TreeProgram:
         N = self.fg.solverParams.N
         P, D = abi.MANIFOLD_P[man], abi.MANIFOLD_DIM[man]
         self.alg_bytes += (F_in + 2) * N * P * 8 + (F_in + 1) * D * 8  # B_upd, SURVEY 8(d)
+        # split of B_upd between the two kernels: the proposal kernel reads the F_in
+        # operand beliefs and the variable's own old belief; the product kernel writes the new one
+        self.alg_bytes_proposal += (F_in + 1) * N * P * 8 + F_in * D * 8
+        self.alg_bytes_product += N * P * 8 + D * 8
 
     def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step):
         fg, sp = self.fg, self.fg.solverParams
@@ -383,6 +395,8 @@ class TreeProgram:
     def _compile(self):
         tree, fg = self.tree, self.fg
         add = self.stages.append
+        if self.snap is not None:
+            add((abi.STAGE_COPIES, [abi.CopyDesc(self.snap[v], self.main[v]) for v in fg.ls()])); self.stage_pass.append("copy")
         # deep copy of the clique sub graphs (SubGraphFunctions.jl:48)
         copies = [abi.CopyDesc(self.main[v], self.B[(c, v)]) for c in self.cliques for v in tree.cliques[c].allIDs]
         add((abi.STAGE_COPIES, copies)); self.stage_pass.append("copy")
