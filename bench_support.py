@@ -33,7 +33,7 @@ class RankSolve:
         st = tp.stats()
         self.global_messages = tp.n_messages
         self.stats = {"cliques_global": st["cliques"], "updates_global": st["updates_up"] + st["updates_down"],
-                      "alg_bytes_product": tp.alg_bytes_product, "alg_bytes_proposal": tp.alg_bytes_proposal}
+                      "alg_bytes": tp.alg_bytes_by_kernel()}
 
     def step(self, k):
         if self.world > 1:

@@ -131,7 +131,7 @@ def load_library(path=None):
     lib.nbp_program_num_stages.argtypes = [vp, ip]
     lib.nbp_program_destroy.argtypes = [vp]
     lib.nbp_timing_enable.argtypes = [vp, i32]
-    lib.nbp_timing_read.argtypes = [vp, dp, C.POINTER(i64), dp, C.POINTER(i64)]
+    lib.nbp_timing_read.argtypes = [vp, dp, C.POINTER(i64)]
     lib.nbp_diag_read.argtypes = [vp, C.POINTER(Diag), i32]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -107,12 +107,15 @@ class HipBackend:
     def timing_enable(self, on=True):
         self._check(self.lib.nbp_timing_enable(self._ctx, int(on)))
 
+    KERNELS = ("nbp_proposal_kernel", "nbp_proposal_bandwidth_kernel", "nbp_product_kernel",
+               "nbp_product_bandwidth_kernel")
+
     def timing_read(self):
-        ms_p, ms_q = C.c_double(), C.c_double()
-        n_p, n_q = C.c_int64(), C.c_int64()
-        self._check(self.lib.nbp_timing_read(self._ctx, C.byref(ms_p), C.byref(n_p), C.byref(ms_q), C.byref(n_q)))
-        return {"proposals_ms": ms_p.value, "proposals_launches": n_p.value,
-                "products_ms": ms_q.value, "products_launches": n_q.value}
+        """{kernel: (total ms, launches)} measured with HIP events on the library stream"""
+        ms = (C.c_double * 4)()
+        nl = (C.c_int64 * 4)()
+        self._check(self.lib.nbp_timing_read(self._ctx, ms, nl))
+        return {k: (ms[i], nl[i]) for i, k in enumerate(self.KERNELS)}
 
     def diag(self, reset=False):
         d = abi.Diag()

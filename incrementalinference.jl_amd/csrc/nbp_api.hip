@@ -23,7 +23,7 @@ static nbp_status fail(nbp_status code, const std::string &msg) {
   } while (0)
 
 struct nbp_ctx {
-  int device = 0, N = 0, n_slots = 0, side_ints = 0, threads = 0;
+  int device = 0, N = 0, n_slots = 0, side_ints = 0, threads = 0, Npad = 0, P = 1;
   int64_t S = 0;
   double *arena = nullptr;
   bool own_arena = false;
@@ -38,9 +38,9 @@ struct nbp_ctx {
   size_t stage_bytes = 0;
   // timing
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_prop, ev_prod;
-  double ms_prop = 0, ms_prod = 0;
-  int64_t n_prop = 0, n_prod = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
+  double ms[4] = {0, 0, 0, 0};
+  int64_t nl[4] = {0, 0, 0, 0};
 };
 
 static int manifold_dim_h(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
@@ -138,7 +138,11 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   c->N = N;
   c->n_slots = n_slots;
   c->S = nbp_slot_stride_doubles(N);
-  c->threads = ((N + 63) / 64) * 64;
+  c->Npad = ((N + 63) / 64) * 64;
+  c->P = 1024 / c->Npad;
+  if (c->P > 4) c->P = 4;
+  if (c->P < 1) c->P = 1;
+  c->threads = c->P * c->Npad;
   c->side_ints = side_ints > 0 ? side_ints : 1;
   if (arena) {
     if (arena_bytes < nbp_arena_bytes(N, n_slots)) { delete c; return fail(NBP_ERR_ARG, "arena too small"); }
@@ -157,6 +161,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
   *out = c;
   return NBP_OK;
 }
@@ -165,8 +170,8 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (!c) return NBP_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  for (auto &p : c->ev_prop) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  for (auto &p : c->ev_prod) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  for (auto &v : c->ev)
+    for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   if (c->own_arena) hipFree(c->arena);
   hipFree(c->side);
   hipFree(c->counters);
@@ -291,7 +296,7 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
     for (int k = 0; k < p.nfactors; k++)
       if (p.in_slot[k] < 0 || p.in_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "product: in_slot");
     if (p.labels_out >= 0 && p.labels_out + c->N * p.nfactors > c->side_ints) return fail(NBP_ERR_RANGE, "product: labels_out");
-    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->threads);
+    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->Npad, c->P);
     if (p.nfactors > 1 && lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: F*D*N exceeds the 160 KiB LDS");
   }
   return NBP_OK;
@@ -321,29 +326,43 @@ static nbp_status toc(nbp_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>>
 
 static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int n) {
   if (n <= 0) return NBP_OK;
-  nbp_status rc = tic(c, c->ev_prop);
+  nbp_status rc = tic(c, c->ev[0]);
   if (rc) return rc;
   (void)hipGetLastError();  // clear stale, unrelated errors
-  hipLaunchKernelGGL(nbp_proposal_kernel, dim3(n), dim3(c->threads), nbp_proposal_lds_bytes(c->N), c->stream, dev,
-                     c->arena, c->N, c->S, c->side, c->counters);
+  hipLaunchKernelGGL(nbp_proposal_kernel, dim3(n), dim3(c->Npad), nbp_proposal_lds_bytes(c->N), c->stream, dev, c->arena,
+                     c->N, c->Npad, c->S, c->side, c->counters);
   HIPCHK(hipGetLastError());
-  return toc(c, c->ev_prop);
+  rc = toc(c, c->ev[0]);
+  if (rc) return rc;
+  rc = tic(c, c->ev[1]);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nbp_proposal_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P),
+                     c->stream, dev, c->arena, c->N, c->Npad, c->S);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev[1]);
 }
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, size_t lds) {
   if (n <= 0) return NBP_OK;
-  nbp_status rc = tic(c, c->ev_prod);
+  nbp_status rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_product_kernel, dim3(n), dim3(c->threads), lds, c->stream, dev, c->arena, c->N, c->S,
-                     c->side, c->T);
+  hipLaunchKernelGGL(nbp_product_kernel, dim3(n), dim3(c->threads), lds, c->stream, dev, c->arena, c->N, c->Npad,
+                     c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
-  return toc(c, c->ev_prod);
+  rc = toc(c, c->ev[2]);
+  if (rc) return rc;
+  rc = tic(c, c->ev[3]);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nbp_product_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P),
+                     c->stream, dev, c->arena, c->N, c->Npad, c->S);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev[3]);
 }
 static size_t products_lds(nbp_ctx *c, const nbp_product_desc *d, int n) {
   size_t lds = 1024;
   for (int i = 0; i < n; i++)
     if (d[i].nfactors > 1) {
-      size_t b = nbp_product_lds_bytes(d[i].nfactors, manifold_dim_h(d[i].manifold), c->N, c->threads);
+      size_t b = nbp_product_lds_bytes(d[i].nfactors, manifold_dim_h(d[i].manifold), c->N, c->Npad, c->P);
       if (b > lds) lds = b;
     }
   return lds;
@@ -424,8 +443,8 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
   if (rc) return rc;
   const int32_t *ds = (const int32_t *)c->stage;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n), dim3(c->threads), ((size_t)3 * c->N + 16) * 8, c->stream, ds, ds + n,
-                     c->arena, c->N, c->S);
+  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n), dim3(c->threads),
+                     nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P), c->stream, ds, ds + n, c->arena, c->N, c->Npad, c->S);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
@@ -559,19 +578,17 @@ static nbp_status drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, doubl
   v.clear();
   return NBP_OK;
 }
-nbp_status nbp_timing_read(nbp_ctx *c, double *ms_prop, int64_t *n_prop, double *ms_prod, int64_t *n_prod) {
+nbp_status nbp_timing_read(nbp_ctx *c, double *ms, int64_t *launches) {
   if (!c) return fail(NBP_ERR_ARG, "null argument");
   HIPCHK(hipStreamSynchronize(c->stream));
-  nbp_status rc = drain(c->ev_prop, c->ms_prop, c->n_prop);
-  if (rc) return rc;
-  rc = drain(c->ev_prod, c->ms_prod, c->n_prod);
-  if (rc) return rc;
-  if (ms_prop) *ms_prop = c->ms_prop;
-  if (n_prop) *n_prop = c->n_prop;
-  if (ms_prod) *ms_prod = c->ms_prod;
-  if (n_prod) *n_prod = c->n_prod;
-  c->ms_prop = c->ms_prod = 0;
-  c->n_prop = c->n_prod = 0;
+  for (int k = 0; k < 4; k++) {
+    nbp_status rc = drain(c->ev[k], c->ms[k], c->nl[k]);
+    if (rc) return rc;
+    if (ms) ms[k] = c->ms[k];
+    if (launches) launches[k] = c->nl[k];
+    c->ms[k] = 0;
+    c->nl[k] = 0;
+  }
   return NBP_OK;
 }
 nbp_status nbp_diag_read(nbp_ctx *c, nbp_diag *out, int32_t reset) {

@@ -36,6 +36,7 @@
 #define NBP_TAG 0x4E4250u
 
 #define NBP_MAXLEVELS 12
+#define NBP_RED 48
 
 // Level tables of the balanced KD-tree over N leaves: data-independent, built once per context.
 struct nbp_levels {
@@ -110,6 +111,29 @@ __device__ __forceinline__ double wrap_pi(double a) {
   return r - NBP_PI;
 }
 
+// exp(x) for x <= ~0 in the O(N^2) kernel sums: Cody-Waite reduction + degree-12 polynomial,
+// <= 2 ulp, no special-case handling (arguments are -d^2/(2h^2) or log-weights minus their max).
+__device__ __forceinline__ double exp_nonpos(double x) {
+  if (x < -708.0) return 0.0;
+  const double k = rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 2.08767569878680989792e-09;  // 1/12!
+  p = fma(p, r, 2.50521083854417187751e-08);
+  p = fma(p, r, 2.75573192239858906526e-07);
+  p = fma(p, r, 2.75573192239858906526e-06);
+  p = fma(p, r, 2.48015873015873015873e-05);
+  p = fma(p, r, 1.98412698412698412698e-04);
+  p = fma(p, r, 1.38888888888888888889e-03);
+  p = fma(p, r, 8.33333333333333333333e-03);
+  p = fma(p, r, 4.16666666666666666667e-02);
+  p = fma(p, r, 1.66666666666666666667e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+
 // ------------------------------------------------------------------------------------------------
 // workgroup reductions: wave64 butterfly + fixed-order combine across waves (deterministic)
 // ------------------------------------------------------------------------------------------------
@@ -129,7 +153,8 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// `red` = LDS scratch of >= 16 doubles.  All threads of the block must call.
+// `red` = LDS scratch of NBP_RED doubles: [0,32) wave partials, [32,48) broadcast slots.
+// All threads of the block must call.
 __device__ __forceinline__ double block_sum(double v, double *red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   v = wave_sum(v);
@@ -178,10 +203,10 @@ __device__ double mean_geodesic_coord(const double *x, int N, int manifold, int 
         double dl = wrap_pi(x[i] - m);
         m = wrap_pi(m + dl / (double)(i + 1));
       }
-      red[15] = m;
+      red[32] = m;
     }
     __syncthreads();
-    mu = red[15];
+    mu = red[32];
   } else {
     double v = (threadIdx.x < N) ? x[threadIdx.x] : 0.0;
     mu = block_sum(v, red) / (double)N;
@@ -221,71 +246,81 @@ __device__ double std_basic_spread(const double *x, int stride, int N, int manif
 
 // ------------------------------------------------------------------------------------------------
 // residual functors -> sum(r.^2)   (CalcFactorNormSq, NumericalCalculations.jl:386-396)
+// KIND and DN are compile-time so that every array lives in registers (no scratch).
 // ------------------------------------------------------------------------------------------------
+template <int KIND, int DN>
 struct objective_t {
-  int kind, manifold, D, solve_b;
   double z[3], other[3];
+  int solve_b;
   unsigned int evals;
-};
-
-__device__ __forceinline__ double residual_normsq(int kind, int D, const double *z, const double *a, const double *b) {
-  double acc = 0;
-  switch (kind) {
-  case NBP_F_LINREL:  // Factors/LinearRelative.jl:42-49
-    for (int d = 0; d < D; d++) {
-      double r = z[d] - (b[d] - a[d]);
-      acc += r * r;
+  __device__ __forceinline__ double normsq(const double *a, const double *b) const {
+    double acc = 0;
+    if (KIND == NBP_F_LINREL) {  // Factors/LinearRelative.jl:42-49
+#pragma unroll
+      for (int d = 0; d < DN; d++) {
+        double r = z[d] - (b[d] - a[d]);
+        acc += r * r;
+      }
+    } else if (KIND == NBP_F_CIRCULAR) {  // Factors/Circular.jl:24-28
+      double r = wrap_pi((a[0] + z[0]) - b[0]);
+      acc = r * r;
+    } else if (KIND == NBP_F_SE2) {  // Factors/GenericFunctions.jl:39-44
+      double s, c;
+      sincos(a[2], &s, &c);
+      double r0 = (a[0] + c * z[0] - s * z[1]) - b[0];
+      double r1 = (a[1] + s * z[0] + c * z[1]) - b[1];
+      double r2 = wrap_pi((a[2] + z[2]) - b[2]);
+      acc = r0 * r0 + r1 * r1 + r2 * r2;
+    } else {  // NBP_F_EUCLIDDIST, Factors/EuclidDistance.jl:20
+      double q = 0;
+#pragma unroll
+      for (int d = 0; d < DN; d++) q += (b[d] - a[d]) * (b[d] - a[d]);
+      double r = z[0] - sqrt(q);
+      acc = r * r;
     }
-    break;
-  case NBP_F_CIRCULAR: {  // Factors/Circular.jl:24-28
-    double r = wrap_pi((a[0] + z[0]) - b[0]);
-    acc = r * r;
-    break;
+    return acc;
   }
-  case NBP_F_SE2: {  // Factors/GenericFunctions.jl:39-44
-    double s, c;
-    sincos(a[2], &s, &c);
-    double r0 = (a[0] + c * z[0] - s * z[1]) - b[0];
-    double r1 = (a[1] + s * z[0] + c * z[1]) - b[1];
-    double r2 = wrap_pi((a[2] + z[2]) - b[2]);
-    acc = r0 * r0 + r1 * r1 + r2 * r2;
-    break;
+  __device__ __forceinline__ double operator()(const double (&x)[DN]) {
+    evals++;
+    double xo[DN];
+#pragma unroll
+    for (int d = 0; d < DN; d++) xo[d] = other[d];
+    return solve_b ? normsq(xo, x) : normsq(x, xo);
   }
-  case NBP_F_EUCLIDDIST: {  // Factors/EuclidDistance.jl:20
-    double q = 0;
-    for (int d = 0; d < D; d++) q += (b[d] - a[d]) * (b[d] - a[d]);
-    double r = z[0] - sqrt(q);
-    acc = r * r;
-    break;
-  }
-  }
-  return acc;
-}
-
-__device__ __forceinline__ double objective(objective_t &o, const double *x) {
-  o.evals++;
-  return o.solve_b ? residual_normsq(o.kind, o.D, o.z, o.other, x) : residual_normsq(o.kind, o.D, o.z, x, o.other);
-}
+};
 
 // ------------------------------------------------------------------------------------------------
 // Optim.NelderMead restated (Gao-Han adaptive parameters, AffineSimplexer a=0.025 b=0.5,
 // g_tol 1e-8 on nmobjective, 1000 iterations) -- NumericalCalculations.jl:108,122-126.
-// One lane = one particle; the simplex lives in registers (DN is a compile-time constant).
+// One lane = one particle; the simplex lives in registers.
 // ------------------------------------------------------------------------------------------------
+// The simplex is kept PHYSICALLY sorted by f (vertex 0 = best, vertex DN = worst) with
+// compare-exchange steps on compile-time indices, so every access is a register access (an index
+// permutation `ord[]` makes LLVM spill the simplex to scratch for the runtime-indexed reads).
 template <int DN>
-__device__ __forceinline__ void nm_sort(const double (&f)[DN + 1], int (&ord)[DN + 1]) {
+__device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int i) {
+  const bool sw = f[i] < f[i - 1];
+  const double fa = f[i - 1], fb = f[i];
+  f[i - 1] = sw ? fb : fa;
+  f[i] = sw ? fa : fb;
 #pragma unroll
-  for (int i = 0; i <= DN; i++) ord[i] = i;
-#pragma unroll
-  for (int i = 1; i <= DN; i++) {  // stable insertion sort, fully unrolled
-#pragma unroll
-    for (int j = i; j >= 1; j--) {
-      bool sw = f[ord[j - 1]] > f[ord[j]];
-      int a = ord[j - 1], b = ord[j];
-      ord[j - 1] = sw ? b : a;
-      ord[j] = sw ? a : b;
-    }
+  for (int d = 0; d < DN; d++) {
+    const double a = sx[i - 1][d], b = sx[i][d];
+    sx[i - 1][d] = sw ? b : a;
+    sx[i][d] = sw ? a : b;
   }
+}
+template <int DN>
+__device__ __forceinline__ void nm_sort_all(double (&sx)[DN + 1][DN], double (&f)[DN + 1]) {
+#pragma unroll
+  for (int pass = 0; pass < DN; pass++)
+#pragma unroll
+    for (int i = DN; i >= 1 + pass; i--) nm_cswap<DN>(sx, f, i);
+}
+template <int DN>
+__device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&f)[DN + 1]) {
+#pragma unroll
+  for (int i = DN; i >= 1; i--) nm_cswap<DN>(sx, f, i);
 }
 
 template <int DN>
@@ -300,42 +335,11 @@ __device__ __forceinline__ double nm_objective(const double (&f)[DN + 1]) {
   return sqrt(v / (double)DN);
 }
 
-// small helpers to read/write simplex rows by a runtime index without spilling to scratch
-template <int DN>
-__device__ __forceinline__ void sx_get(const double (&sx)[DN + 1][DN], int i, double (&v)[DN]) {
-#pragma unroll
-  for (int d = 0; d < DN; d++) {
-    double t = sx[0][d];
-#pragma unroll
-    for (int q = 1; q <= DN; q++) t = (i == q) ? sx[q][d] : t;
-    v[d] = t;
-  }
-}
-template <int DN>
-__device__ __forceinline__ void sx_set(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int i, const double (&v)[DN], double fv) {
-#pragma unroll
-  for (int q = 0; q <= DN; q++) {
-    if (i == q) {
-#pragma unroll
-      for (int d = 0; d < DN; d++) sx[q][d] = v[d];
-      f[q] = fv;
-    }
-  }
-}
-template <int DN>
-__device__ __forceinline__ double f_get(const double (&f)[DN + 1], int i) {
-  double t = f[0];
-#pragma unroll
-  for (int q = 1; q <= DN; q++) t = (i == q) ? f[q] : t;
-  return t;
-}
-
-template <int DN>
-__device__ bool nelder_mead(objective_t &o, double *x) {
+template <int KIND, int DN>
+__device__ __forceinline__ bool nelder_mead(objective_t<KIND, DN> &o, double (&x)[DN]) {
   constexpr int M = DN + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / DN, gamma = 0.75 - 1.0 / (2.0 * DN), delta = 1.0 - 1.0 / DN;
   double sx[M][DN], f[M];
-  int ord[M];
 #pragma unroll
   for (int i = 0; i < M; i++)
 #pragma unroll
@@ -343,108 +347,101 @@ __device__ bool nelder_mead(objective_t &o, double *x) {
 #pragma unroll
   for (int j = 0; j < DN; j++) sx[j + 1][j] = (1.0 + 0.5) * sx[j + 1][j] + 0.025;
 #pragma unroll
-  for (int i = 0; i < M; i++) f[i] = objective(o, sx[i]);
-  nm_sort<DN>(f, ord);
+  for (int i = 0; i < M; i++) f[i] = o(sx[i]);
+  nm_sort_all<DN>(sx, f);
   bool converged = nm_objective<DN>(f) <= 1e-8;
   int it = 0;
   while (!converged && it < 1000) {
     it++;
-    bool shrink = false;
-    const int ih = ord[M - 1];
-    double xc[DN], xl[DN], xh[DN], xr[DN], xcache[DN];
-    sx_get<DN>(sx, ih, xh);
-    sx_get<DN>(sx, ord[0], xl);
+    double xc[DN], xr[DN], xcache[DN];
 #pragma unroll
     for (int d = 0; d < DN; d++) {
       double s = 0;
 #pragma unroll
-      for (int i = 0; i < M; i++) s += (i != ih) ? sx[i][d] : 0.0;
+      for (int i = 0; i < DN; i++) s += sx[i][d];
       xc[d] = s / (double)DN;
     }
-    const double f_lowest = f_get<DN>(f, ord[0]), f_second = f_get<DN>(f, ord[DN - 1]), f_highest = f_get<DN>(f, ih);
+    const double f_lowest = f[0], f_second = f[DN - 1], f_highest = f[DN];
 #pragma unroll
-    for (int d = 0; d < DN; d++) xr[d] = xc[d] + alpha * (xc[d] - xh[d]);
-    const double f_reflect = objective(o, xr);
-    if (f_reflect < f_lowest) {
-#pragma unroll
-      for (int d = 0; d < DN; d++) xcache[d] = xc[d] + beta * (xr[d] - xc[d]);
-      const double f_expand = objective(o, xcache);
-      if (f_expand < f_reflect) sx_set<DN>(sx, f, ih, xcache, f_expand);
-      else sx_set<DN>(sx, f, ih, xr, f_reflect);
-#pragma unroll
-      for (int i = M - 1; i >= 1; i--) ord[i] = ord[i - 1];
-      ord[0] = ih;
-    } else if (f_reflect < f_second) {
-      sx_set<DN>(sx, f, ih, xr, f_reflect);
-      nm_sort<DN>(f, ord);
-    } else {
+    for (int d = 0; d < DN; d++) xr[d] = xc[d] + alpha * (xc[d] - sx[DN][d]);
+    const double f_reflect = o(xr);
+    const bool do_expand = f_reflect < f_lowest;
+    const bool accept_reflect = !do_expand && f_reflect < f_second;
+    bool shrink = false;
+    if (!accept_reflect) {
       const bool outside = f_reflect < f_highest;
-      const double sgn = outside ? gamma : -gamma;
+      const double coef = do_expand ? beta : (outside ? gamma : -gamma);
 #pragma unroll
-      for (int d = 0; d < DN; d++) xcache[d] = xc[d] + sgn * (xr[d] - xc[d]);
-      const double fc = objective(o, xcache);
-      if (fc < (outside ? f_reflect : f_highest)) {
-        sx_set<DN>(sx, f, ih, xcache, fc);
-        nm_sort<DN>(f, ord);
-      } else
-        shrink = true;
+      for (int d = 0; d < DN; d++) xcache[d] = xc[d] + coef * (xr[d] - xc[d]);
+      const double f2 = o(xcache);
+      // expansion: the better of (expand, reflect) replaces the worst; contraction: accepted only
+      // if it improves on min(reflect, highest)
+      const bool take2 = do_expand ? (f2 < f_reflect) : (f2 < (outside ? f_reflect : f_highest));
+      const bool taker = do_expand && !take2;
+      shrink = !do_expand && !take2;
+      if (take2 || taker) {
+#pragma unroll
+        for (int d = 0; d < DN; d++) sx[DN][d] = take2 ? xcache[d] : xr[d];
+        f[DN] = take2 ? f2 : f_reflect;
+        nm_sift_last<DN>(sx, f);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DN; d++) sx[DN][d] = xr[d];
+      f[DN] = f_reflect;
+      nm_sift_last<DN>(sx, f);
     }
     if (shrink) {
 #pragma unroll
-      for (int q = 0; q < M; q++) {
-        if (q != ord[0]) {
-          double v[DN];
+      for (int q = 1; q < M; q++) {
 #pragma unroll
-          for (int d = 0; d < DN; d++) v[d] = xl[d] + delta * (sx[q][d] - xl[d]);
-          double fv = objective(o, v);
-#pragma unroll
-          for (int d = 0; d < DN; d++) sx[q][d] = v[d];
-          f[q] = fv;
-        }
+        for (int d = 0; d < DN; d++) sx[q][d] = sx[0][d] + delta * (sx[q][d] - sx[0][d]);
+        f[q] = o(sx[q]);
       }
-      nm_sort<DN>(f, ord);
+      nm_sort_all<DN>(sx, f);
     }
     converged = nm_objective<DN>(f) <= 1e-8;
   }
   // after_while!: the better of the best vertex and the centroid of the DN best
-  nm_sort<DN>(f, ord);
-  const int ih = ord[M - 1];
-  double xc[DN], xb[DN];
+  double xc[DN];
 #pragma unroll
   for (int d = 0; d < DN; d++) {
     double s = 0;
 #pragma unroll
-    for (int i = 0; i < M; i++) s += (i != ih) ? sx[i][d] : 0.0;
+    for (int i = 0; i < DN; i++) s += sx[i][d];
     xc[d] = s / (double)DN;
   }
-  const double fcen = objective(o, xc);
-  sx_get<DN>(sx, ord[0], xb);
-  const bool usec = fcen < f_get<DN>(f, ord[0]);
+  const double fcen = o(xc);
+  const bool usec = fcen < f[0];
 #pragma unroll
-  for (int d = 0; d < DN; d++) x[d] = usec ? xc[d] : xb[d];
+  for (int d = 0; d < DN; d++) x[d] = usec ? xc[d] : sx[0][d];
   return converged;
 }
 
 // Optim.BFGS for a 1-D decision variable (islen1 branch), central finite differences,
 // Armijo / quadratic-interpolation line search (documented deviation from HagerZhang).
-__device__ __forceinline__ double fd_grad1(objective_t &o, double x) {
+template <int KIND>
+__device__ __forceinline__ double fd_grad1(objective_t<KIND, 1> &o, double x) {
   double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x));
-  double xp = x + h, xm = x - h;
-  return (objective(o, &xp) - objective(o, &xm)) / (2.0 * h);
+  double xp[1] = {x + h}, xm[1] = {x - h};
+  return (o(xp) - o(xm)) / (2.0 * h);
 }
 
-__device__ bool bfgs_1d(objective_t &o, double *x) {
-  double xc = *x, fx = objective(o, &xc), g = fd_grad1(o, xc), H = 1.0;
+template <int KIND>
+__device__ __forceinline__ bool bfgs_1d(objective_t<KIND, 1> &o, double (&x)[1]) {
+  double xc[1] = {x[0]};
+  double fx = o(xc), g = fd_grad1<KIND>(o, xc[0]), H = 1.0;
   bool converged = false;
   for (int it = 0; it < 1000; it++) {
     if (fabs(g) <= 1e-8) { converged = true; break; }
     double s = -H * g;
     if (s * g >= 0) { H = 1.0; s = -g; }
-    double al = 1.0, dphi0 = g * s, xn = xc, fn = fx;
+    double al = 1.0, dphi0 = g * s, fn = fx;
+    double xn[1] = {xc[0]};
     bool ok = false;
     for (int ls = 0; ls < 50; ls++) {
-      xn = xc + al * s;
-      fn = objective(o, &xn);
+      xn[0] = xc[0] + al * s;
+      fn = o(xn);
       if (fn <= fx + 1e-4 * al * dphi0) { ok = true; break; }
       double aq = -dphi0 * al * al / (2.0 * (fn - fx - dphi0 * al));
       if (!(aq >= 0.1 * al)) aq = 0.1 * al;
@@ -452,70 +449,112 @@ __device__ bool bfgs_1d(objective_t &o, double *x) {
       al = aq;
     }
     if (!ok) break;
-    double gn = fd_grad1(o, xn), dx = xn - xc, dg = gn - g;
+    double gn = fd_grad1<KIND>(o, xn[0]), dx = xn[0] - xc[0], dg = gn - g;
     if (dx == 0.0) { converged = fabs(gn) <= 1e-8; break; }
     if (dx * dg > 0) H = dx / dg;
-    xc = xn; fx = fn; g = gn;
+    xc[0] = xn[0]; fx = fn; g = gn;
   }
-  *x = xc;
+  x[0] = xc[0];
   return converged;
 }
 
 // _solveCCWNumeric! for one particle (NumericalCalculations.jl:413-452, :90-133)
-__device__ void solve_particle(int kind, int manifold, const double *z, const double *other, int solve_b,
-                               double *x, unsigned int &n_solves, unsigned int &n_nonconv,
-                               unsigned int &n_nan, unsigned int &n_evals) {
-  objective_t o;
-  o.kind = kind; o.manifold = manifold; o.D = mani_dim(manifold); o.solve_b = solve_b; o.evals = 0;
+template <int KIND, int DN>
+__device__ __forceinline__ void solve_particle_t(int manifold, const double *z, const double *other, int solve_b, double *x,
+                                                 unsigned int &n_solves, unsigned int &n_nonconv, unsigned int &n_nan,
+                                                 unsigned int &n_evals) {
+  objective_t<KIND, DN> o;
+  o.solve_b = solve_b;
+  o.evals = 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
-  double xc[3] = {x[0], x[1], x[2]};
+  double xc[DN];
+#pragma unroll
+  for (int d = 0; d < DN; d++) xc[d] = x[d];
   bool conv;
-  if (o.D == 1) conv = bfgs_1d(o, xc);
-  else if (o.D == 2) conv = nelder_mead<2>(o, xc);
-  else conv = nelder_mead<3>(o, xc);
+  if constexpr (DN == 1) conv = bfgs_1d<KIND>(o, xc);
+  else conv = nelder_mead<KIND, DN>(o, xc);
   n_solves++;
   n_evals += o.evals;
   if (!conv) n_nonconv++;
   bool bad = false;
-  for (int d = 0; d < o.D; d++) bad |= isnan(xc[d]);
+#pragma unroll
+  for (int d = 0; d < DN; d++) bad |= isnan(xc[d]);
   if (bad) { n_nan++; return; }
-  for (int d = 0; d < o.D; d++) x[d] = is_circ(manifold, d) ? wrap_pi(xc[d]) : xc[d];
+#pragma unroll
+  for (int d = 0; d < DN; d++) x[d] = is_circ(manifold, d) ? wrap_pi(xc[d]) : xc[d];
+}
+
+// wave-uniform dispatch on (factor kind, tangent dimension)
+__device__ __forceinline__ void solve_particle(int kind, int manifold, const double *z, const double *other, int solve_b,
+                                               double *x, unsigned int &a, unsigned int &b, unsigned int &c, unsigned int &e) {
+  const int D = mani_dim(manifold);
+  switch (kind) {
+  case NBP_F_LINREL:
+    if (D == 1) solve_particle_t<NBP_F_LINREL, 1>(manifold, z, other, solve_b, x, a, b, c, e);
+    else if (D == 2) solve_particle_t<NBP_F_LINREL, 2>(manifold, z, other, solve_b, x, a, b, c, e);
+    else solve_particle_t<NBP_F_LINREL, 3>(manifold, z, other, solve_b, x, a, b, c, e);
+    break;
+  case NBP_F_CIRCULAR: solve_particle_t<NBP_F_CIRCULAR, 1>(manifold, z, other, solve_b, x, a, b, c, e); break;
+  case NBP_F_SE2: solve_particle_t<NBP_F_SE2, 3>(manifold, z, other, solve_b, x, a, b, c, e); break;
+  default:
+    if (D == 1) solve_particle_t<NBP_F_EUCLIDDIST, 1>(manifold, z, other, solve_b, x, a, b, c, e);
+    else if (D == 2) solve_particle_t<NBP_F_EUCLIDDIST, 2>(manifold, z, other, solve_b, x, a, b, c, e);
+    else solve_particle_t<NBP_F_EUCLIDDIST, 3>(manifold, z, other, solve_b, x, a, b, c, e);
+    break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Bandwidth: leave-one-out likelihood cross validation, golden-section search (KDE.jl `:lcv`).
-// x = LDS array of N coordinates.  Lane i owns point i and walks all j (LDS broadcast reads);
-// the N terms are tree-reduced.  O(N^2) exp per evaluation, ~16-21 evaluations per coordinate.
+// x = LDS array of N coordinates.  The workgroup is P x Npad lanes: lane (i, p) owns point i and
+// walks the points j = p, p+P, ... (wave-uniform j -> LDS broadcast reads, 4 independent exp chains
+// in flight); the P partial row sums are combined in a fixed order through LDS (`part`), the N row
+// terms are tree-reduced.  O(N^2) exp per evaluation, ~16-21 evaluations per coordinate.
 // ------------------------------------------------------------------------------------------------
-__device__ double neg_loo_ll(const double *x, int N, bool circ, double h, double *red) {
+template <bool CIRC>
+__device__ __forceinline__ double loo_partial(const double *x, int N, int i, int p, int P, double xi, double c) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int j = p;
+  for (; j + 3 * P < N; j += 4 * P) {
+    double d0 = xi - x[j], d1 = xi - x[j + P], d2 = xi - x[j + 2 * P], d3 = xi - x[j + 3 * P];
+    if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); d2 = wrap_pi(d2); d3 = wrap_pi(d3); }
+    double e0 = exp_nonpos(-d0 * d0 * c), e1 = exp_nonpos(-d1 * d1 * c);
+    double e2 = exp_nonpos(-d2 * d2 * c), e3 = exp_nonpos(-d3 * d3 * c);
+    s0 += (j == i) ? 0.0 : e0;
+    s1 += (j + P == i) ? 0.0 : e1;
+    s2 += (j + 2 * P == i) ? 0.0 : e2;
+    s3 += (j + 3 * P == i) ? 0.0 : e3;
+  }
+  for (; j < N; j += P) {
+    double d = xi - x[j];
+    if (CIRC) d = wrap_pi(d);
+    double e = exp_nonpos(-d * d * c);
+    s0 += (j == i) ? 0.0 : e;
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
+__device__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red) {
   const double inv2h2 = 1.0 / (2.0 * h * h);
   const double lognorm = log(h) + 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
-  double term = 0;
-  const int i = threadIdx.x;
+  const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
   if (i < N) {
     const double xi = x[i];
-    double s = 0;
-    if (circ) {
-      for (int j = 0; j < N; j++) {
-        double d = wrap_pi(xi - x[j]);
-        double e = exp(-d * d * inv2h2);
-        s += (j == i) ? 0.0 : e;
-      }
-    } else {
-      for (int j = 0; j < N; j++) {
-        double d = xi - x[j];
-        double e = exp(-d * d * inv2h2);
-        s += (j == i) ? 0.0 : e;
-      }
-    }
+    part[p * Npad + i] = circ ? loo_partial<true>(x, N, i, p, P, xi, inv2h2) : loo_partial<false>(x, N, i, p, P, xi, inv2h2);
+  }
+  __syncthreads();
+  double term = 0;
+  if (p == 0 && i < N) {
+    double s = part[i];
+    for (int q = 1; q < P; q++) s += part[q * Npad + i];
     if (s < 1e-300) s = 1e-300;
     term = log(s) - lognorm;
   }
   return -block_sum(term, red) / (double)N;
 }
 
-__device__ double lcv_bandwidth_1d(const double *x, int N, bool circ, double *red) {
+__device__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red) {
   const int i = threadIdx.x;
   double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
   if (i < N) {
@@ -538,10 +577,10 @@ __device__ double lcv_bandwidth_1d(const double *x, int N, bool circ, double *re
   double x0 = ax, x3 = cx, x1, x2;
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
   else { x2 = bx; x1 = bx - C * (bx - ax); }
-  double f1 = neg_loo_ll(x, N, circ, x1 * sc, red), f2 = neg_loo_ll(x, N, circ, x2 * sc, red);
+  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red);
   while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
-    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, circ, x2 * sc, red); }
-    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, circ, x1 * sc, red); }
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red); }
+    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red); }
   }
   return (f1 < f2 ? x1 : x2) * sc;
 }

@@ -1,4 +1,9 @@
 // nbp_kernels.h -- the gfx950 kernels of libnbp (see nbp_device.h for the shared device code).
+//
+// Workgroup geometry: P x Npad lanes, Npad = roundup(N, 64), P = min(4, 1024 / Npad).
+// lane (i, p): i = tid % Npad is the particle / output sample, p = tid / Npad is its helper index.
+// All lanes of a wave share p, so the O(N) inner loops read LDS with wave-uniform addresses
+// (broadcast) and the P helpers of a particle split those loops P ways.
 #pragma once
 #include "nbp_device.h"
 
@@ -6,40 +11,44 @@
 // Proposal kernel: one workgroup = one approxConvBelief (ApproxConv.jl:4-45)
 //   evalFactor -> evalPotentialSpecific (EvalFactor.jl:321-395 relative, :400-542 prior)
 //   -> manikde! bandwidth.
-// LDS: X[3][N] target scratch (the deepcopy of CalcFactor.jl:543-548), Z[3][N] measurements,
-//      mhidx[N], reduction scratch.  HBM traffic: reads the operand beliefs once (coalesced,
-//      8 B/lane), writes the proposal once.
+// LDS: X[3][N] target scratch (the deepcopy of CalcFactor.jl:543-548), mhidx[N], LCV partial sums.
+// HBM traffic: reads the operand beliefs once (coalesced, 8 B/lane), writes the proposal once.
 // ================================================================================================
 __device__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z) {
   int c = 0;
   if (d->ncomp > 1) {  // Mixture.sampleFactor, Factors/Mixture.jl:114-155
-    double w[NBP_MAXC], ua, ub;
-    for (int i = 0; i < NBP_MAXC; i++) w[i] = (i < d->ncomp) ? d->comp[i][0] : 0.0;
+    double ua, ub, cum = 0;
     uniform_pair(d->seed, n, PURP_MIXLBL, 0, ua, ub);
-    c = categorical(w, d->ncomp, ua);
+    int last = 0;
+    c = -1;
+    for (int i = 0; i < d->ncomp; i++) {
+      const double w = d->comp[i][0];
+      if (w > 0) last = i;
+      cum += w;
+      if (c < 0 && ua < cum) c = i;
+    }
+    if (c < 0) c = last;
   }
   const double *cp = d->comp[c];
-  double nn[4] = {0, 0, 0, 0};
-  normal_pair(d->seed, n, PURP_MEAS, 0, nn[0], nn[1]);
-  if (zdim > 2) normal_pair(d->seed, n, PURP_MEAS, 1, nn[2], nn[3]);
-  for (int i = 0; i < 3; i++) {
-    double acc = 0;
-    if (i < zdim) {
-      acc = cp[1 + i];
-      for (int j = 0; j <= i; j++) acc += cp[4 + i * 3 + j] * nn[j];
-    }
-    z[i] = acc;
-  }
+  double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+  normal_pair(d->seed, n, PURP_MEAS, 0, n0, n1);
+  if (zdim > 2) normal_pair(d->seed, n, PURP_MEAS, 1, n2, n3);
+  z[0] = cp[1] + cp[4] * n0;
+  z[1] = (zdim > 1) ? cp[2] + cp[7] * n0 + cp[8] * n1 : 0.0;
+  z[2] = (zdim > 2) ? cp[3] + cp[10] * n0 + cp[11] * n1 + cp[12] * n2 : 0.0;
 }
 
 // addEntropyOnManifold!, EvalFactor.jl:95-132
 __device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int n, double spread, uint64_t seed, int kbase) {
-  double u[4] = {0, 0, 0, 0};
-  uniform_pair(seed, n, PURP_ENTROPY, kbase, u[0], u[1]);
-  if (D > 2) uniform_pair(seed, n, PURP_ENTROPY, kbase + 1, u[2], u[3]);
-  for (int k = 0; k < D; k++) {
-    double v = x[k] + spread * (u[k] - 0.5);
-    x[k] = is_circ(manifold, k) ? wrap_pi(v) : v;
+  double u0, u1, u2 = 0, u3 = 0;
+  uniform_pair(seed, n, PURP_ENTROPY, kbase, u0, u1);
+  if (D > 2) uniform_pair(seed, n, PURP_ENTROPY, kbase + 1, u2, u3);
+  double v0 = x[0] + spread * (u0 - 0.5);
+  x[0] = is_circ(manifold, 0) ? wrap_pi(v0) : v0;
+  if (D > 1) x[1] = x[1] + spread * (u1 - 0.5);
+  if (D > 2) {
+    double v2 = x[2] + spread * (u2 - 0.5);
+    x[2] = is_circ(manifold, 2) ? wrap_pi(v2) : v2;
   }
 }
 
@@ -64,17 +73,17 @@ __device__ double var_distance_expected_fractional(const nbp_proposal_desc *d, c
   return kappa * best;
 }
 
-__global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int64_t S, int32_t *side,
-                                    nbp_counters *ctr) {
+__global__ void __launch_bounds__(512)
+nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side,
+                    nbp_counters *ctr) {
   extern __shared__ double smem[];
-  double *X = smem;          // [3][N]
-  double *Z = X + 3 * N;     // [3][N]
-  double *red = Z + 3 * N;   // [16]
-  int *mh = (int *)(red + 16);
+  double *X = smem;                 // [3][N]
+  double *red = X + 3 * N;          // [NBP_RED]
+  int *mh = (int *)(red + NBP_RED); // [N]
   __shared__ recipe_t R;
   const nbp_proposal_desc *d = descs + blockIdx.x;
   const int n = threadIdx.x, M = d->manifold, D = mani_dim(M), kind = d->factor_kind;
-  const bool live = n < N;
+  const bool live = n < N;  // lanes (i < N, p == 0) own a particle
   double *out = arena + S * d->out_slot;
   unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
 
@@ -110,18 +119,23 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
         if (kind == NBP_F_PRIOR) {
           double z[3];
           sample_measurement(d, n, D, z);
-          for (int k = 0; k < D; k++) x[k] = is_circ(M, k) ? wrap_pi(z[k]) : z[k];
+          x[0] = is_circ(M, 0) ? wrap_pi(z[0]) : z[0];
+          x[1] = z[1];
+          x[2] = is_circ(M, 2) ? wrap_pi(z[2]) : z[2];
         } else {  // MsgPrior{MKD}: sample(belief): random kernel + bw*randn (Factors/MsgPrior.jl:27-30)
           const double *msg = arena + S * d->var_slot[1];
-          double ua, ub, nn[4] = {0, 0, 0, 0};
+          double ua, ub, n0, n1, n2 = 0, n3 = 0;
           uniform_pair(d->seed, n, PURP_KDESEL, 0, ua, ub);
           int i = (int)(ua * N);
           if (i >= N) i = N - 1;
-          normal_pair(d->seed, n, PURP_KDENOISE, 0, nn[0], nn[1]);
-          if (D > 2) normal_pair(d->seed, n, PURP_KDENOISE, 1, nn[2], nn[3]);
-          for (int k = 0; k < D; k++) {
-            double v = msg[k * N + i] + msg[3 * N + k] * nn[k];
-            x[k] = is_circ(M, k) ? wrap_pi(v) : v;
+          normal_pair(d->seed, n, PURP_KDENOISE, 0, n0, n1);
+          if (D > 2) normal_pair(d->seed, n, PURP_KDENOISE, 1, n2, n3);
+          double v0 = msg[i] + msg[3 * N] * n0;
+          x[0] = is_circ(M, 0) ? wrap_pi(v0) : v0;
+          if (D > 1) x[1] = msg[N + i] + msg[3 * N + 1] * n1;
+          if (D > 2) {
+            double v2 = msg[2 * N + i] + msg[3 * N + 2] * n2;
+            x[2] = is_circ(M, 2) ? wrap_pi(v2) : v2;
           }
         }
       } else {
@@ -135,7 +149,6 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
     const int zdim = (kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1);
     double z[3] = {0, 0, 0};
     if (live) sample_measurement(d, n, zdim, z);  // sampleFactor!, CalcFactor.jl:578
-    (void)Z;
     const int sf1 = d->sfidx + 1;
     const int myh = live ? mh[n] : -1000;
     // computeAcrossHypothesis!, EvalFactor.jl:145-237
@@ -150,8 +163,11 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
         const int vother = solve_b ? va : vb;
         const double *O = arena + S * d->var_slot[vother - 1];
         double oth[3] = {0, 0, 0};
-        if (myh == hyp)
-          for (int k = 0; k < D; k++) oth[k] = O[k * N + n];
+        if (myh == hyp) {
+          oth[0] = O[n];
+          if (D > 1) oth[1] = O[N + n];
+          if (D > 2) oth[2] = O[2 * N + n];
+        }
         for (int c = 0; c < d->inflate_cycles; c++) {  // :184-207
           const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->inflation, red);
           __syncthreads();
@@ -159,7 +175,9 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
             double x[3] = {X[n], X[N + n], X[2 * N + n]};
             add_entropy(M, D, x, n, spread, d->seed, (g * 8 + c) * 2);
             solve_particle(kind, M, z, oth, solve_b, x, n_solves, n_nonconv, n_nan, n_evals);  // approxConvOnElements!
-            for (int k = 0; k < D; k++) X[k * N + n] = x[k];
+            X[n] = x[0];
+            if (D > 1) X[N + n] = x[1];
+            if (D > 2) X[2 * N + n] = x[2];
           }
           __syncthreads();
         }
@@ -169,26 +187,23 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
         if (myh == hyp) {
           double x[3] = {X[n], X[N + n], X[2 * N + n]};
           add_entropy(M, D, x, n, spread, d->seed, (g * 8) * 2);
-          for (int k = 0; k < D; k++) X[k * N + n] = x[k];
+          X[n] = x[0];
+          if (D > 1) X[N + n] = x[1];
+          if (D > 2) X[2 * N + n] = x[2];
         }
         __syncthreads();
       }
     }
   }
-  // manikde!(M, pts): bandwidth per coordinate (ApproxConv.jl:36-42)
-  if (!d->skip_bandwidth) {
-    for (int k = 0; k < D; k++) {
-      double h = lcv_bandwidth_1d(X + k * N, N, is_circ(M, k), red);
-      if (n == 0) out[3 * N + k] = h;
-    }
-    if (n == 0)
-      for (int k = D; k < 3; k++) out[3 * N + k] = 0.0;
-  }
+  // manikde!(M, pts) (ApproxConv.jl:36-42): the bandwidth fit runs as nbp_proposal_bandwidth_kernel
+  // right behind this kernel on the same stream (P x Npad lanes; this kernel keeps one lane per
+  // particle so that the Nelder-Mead simplex stays in registers).
   if (live)
     for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
   // diagnostics: one atomic per wave
   {
     unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
+#pragma unroll
     for (int q = 0; q < 4; q++) {
       unsigned int t = v[q];
       for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
@@ -203,19 +218,58 @@ __global__ void nbp_proposal_kernel(const nbp_proposal_desc *descs, double *aren
   }
 }
 
+static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
+
+// fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)
+__device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int N, int Npad, double *smem) {
+  const int D = mani_dim(M), n = threadIdx.x;
+  if (k >= D) {
+    if (n == 0) s[3 * N + k] = 0.0;
+    return;
+  }
+  const int P = blockDim.x / Npad;
+  double *X = smem, *part = smem + N, *red = part + P * Npad;
+  if (n < N) X[n] = s[k * N + n];
+  __syncthreads();
+  double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red);
+  if (n == 0) s[3 * N + k] = h;
+}
+
+// manikde! bandwidth of the proposals just written by nbp_proposal_kernel
+__global__ void __launch_bounds__(1024)
+nbp_proposal_bandwidth_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S) {
+  extern __shared__ double smem[];
+  // grid (n, 3): one workgroup per (proposal, coordinate) -- the D fits are independent
+  const nbp_proposal_desc *d = descs + blockIdx.x;
+  if (d->skip_bandwidth) return;
+  lcv_slot_coordinate(arena + S * d->out_slot, d->manifold, blockIdx.y, N, Npad, smem);
+}
+
+// manikde! rebandwidth of the products just written by nbp_product_kernel
+__global__ void __launch_bounds__(1024)
+nbp_product_bandwidth_kernel(const nbp_product_desc *descs, double *arena, int N, int Npad, int64_t S) {
+  extern __shared__ double smem[];
+  const nbp_product_desc *d = descs + blockIdx.x;
+  if (d->nfactors == 1) return;  // pass-through keeps the proposal's bandwidth
+  lcv_slot_coordinate(arena + S * d->out_slot, d->manifold, blockIdx.y, N, Npad, smem);
+}
+static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) { return ((size_t)3 * N + (size_t)P * Npad + NBP_RED) * 8; }
+
 // ================================================================================================
 // Bandwidth kernel: AMP.manikde!(M, pts) for a resident slot
 // ================================================================================================
-__global__ void nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int64_t S) {
+__global__ void __launch_bounds__(1024)
+nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S) {
   extern __shared__ double smem[];
-  double *X = smem, *red = smem + 3 * N;
+  const int P = blockDim.x / Npad;
+  double *X = smem, *part = smem + 3 * N, *red = part + P * Npad;
   double *s = arena + S * slots[blockIdx.x];
   const int M = manifolds[blockIdx.x], D = mani_dim(M), n = threadIdx.x;
   if (n < N)
     for (int k = 0; k < 3; k++) X[k * N + n] = s[k * N + n];
   __syncthreads();
   for (int k = 0; k < D; k++) {
-    double h = lcv_bandwidth_1d(X + k * N, N, is_circ(M, k), red);
+    double h = lcv_bandwidth_1d(X + k * N, N, Npad, is_circ(M, k), part, red);
     if (n == 0) s[3 * N + k] = h;
   }
 }
@@ -249,75 +303,116 @@ __global__ void nbp_reseed_products(nbp_product_desc *d, int n, uint64_t salt) {
 // Algorithm (Ihler et al. NIPS 2003, `prodAppxMSGibbsS`): every input KDE gets a balanced KD-tree
 // whose nodes carry the moment-matched Gaussian of their leaves; all N output samples walk the
 // trees root->leaves in lock step; at every level each sample runs `niter` sequential Gibbs sweeps
-// re-drawing its label in density j from p(l_j | others) over ALL nodes of that level; at the
-// leaves the sample is drawn from the product of the F selected kernels.
+// re-drawing its label in density j from p(l_j | others) over ALL nodes of that level (inverse
+// CDF); at the leaves the sample is drawn from the product of the F selected kernels.
 //
-// Mapping: lane s = output sample s.  The KD permutation is built by rank counting inside each
-// segment (no barriers inside a level); node statistics of the *current* level for all densities
-// live in LDS (lm/lv) and are read with wave-uniform addresses (LDS broadcast) in the O(N) label
-// loop; per-sample labels live in LDS (ind).
+// Mapping: lanes (s, 0..P-1) = output sample s.  The node loop of a draw is split into P contiguous
+// node ranges: pass 1 gives every helper its (max, total) -> combined through LDS; only the helper
+// whose range contains u*total walks its range again (pass 2).  Node statistics of the *current*
+// level for all densities live in LDS and are read with wave-uniform addresses (broadcast).
+// The KD permutation is built by rank counting inside each segment, also split P ways.
 // ================================================================================================
-template <int D>
-__device__ void product_body(const nbp_product_desc *d, double *arena, int N, int64_t S, int32_t *side,
-                             const nbp_levels &T, double *smem) {
-  const int F = d->nfactors, M = d->manifold, tid = threadIdx.x, TB = blockDim.x;
-  double *xs = smem;                 // [F][D][N] sorted, centred
-  double *lm = xs + F * D * N;       // [F][D][N] node mean of the current level
-  double *lv = lm + F * D * N;       // [F][D][N] node variance (+ bandwidth^2)
-  double *cen = lv + F * D * N;      // [F][3]
-  double *h2 = cen + F * 3;          // [F][3]
-  double *red = h2 + F * 3;          // [16]
-  int *idx = (int *)(red + 16);      // [F][N]
-  int *ind = idx + F * N;            // [F][TB]
-  int *tmpA = ind + F * TB;          // [N]
-  int *tmpB = tmpA + N;              // [N]
-  double *out = arena + S * d->out_slot;
-  bool circ[D];
-#pragma unroll
-  for (int k = 0; k < D; k++) circ[k] = is_circ(M, k);
+struct product_lds {
+  double *xs, *lm, *lv, *cen, *h2, *red, *gm, *gt, *ext;
+  int *idx, *ind, *tmpA, *tmpB, *prk, *bdim;
+};
 
-  // ---- KD-tree permutation per density ----------------------------------------------------
+__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Npad, int P, double *base, product_lds *L) {
+  size_t o = 0;
+  auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
+  size_t xs = dbl((size_t)F * D * N), lm = dbl((size_t)F * D * N), lv = dbl((size_t)F * D * N);
+  size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3), red = dbl(NBP_RED);
+  size_t gm = dbl((size_t)P * Npad), gt = dbl((size_t)P * Npad);  // gt doubles as LCV `part`
+  size_t ext = dbl((size_t)3 * Npad);
+  size_t ints0 = o;  // int region starts here (8-byte aligned)
+  size_t io = 0;
+  auto i32 = [&](size_t n) { size_t r = io; io += n; return r; };
+  size_t idx = i32((size_t)F * N), ind = i32((size_t)F * Npad), tA = i32(N), tB = i32(N), prk = i32((size_t)P * Npad), bd = i32(Npad);
+  if (L) {
+    L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2; L->red = base + red;
+    L->gm = base + gm; L->gt = base + gt; L->ext = base + ext;
+    int *ib = (int *)(base + ints0);
+    L->idx = ib + idx; L->ind = ib + ind; L->tmpA = ib + tA; L->tmpB = ib + tB; L->prk = ib + prk; L->bdim = ib + bd;
+  }
+  return ints0 * 8 + io * 4;
+}
+
+template <int MANI>
+__device__ void product_body(const nbp_product_desc *d, double *arena, int N, int Npad, int64_t S, int32_t *side,
+                             const nbp_levels &T, double *smem) {
+  constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
+  constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
+  const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
+  const int P = TB / Npad, s = tid % Npad, sub = tid / Npad;
+  product_lds L;
+  product_lds_layout(F, D, N, Npad, P, smem, &L);
+  double *xs = L.xs, *lm = L.lm, *lv = L.lv, *cen = L.cen, *h2 = L.h2, *red = L.red;
+  int *idx = L.idx, *ind = L.ind;
+  double *out = arena + S * d->out_slot;
+
+  // ---- KD-tree permutation per density (median split of the widest coordinate) ----------------
   for (int j = 0; j < F; j++) {
     const double *x = arena + S * d->in_slot[j];
     double *raw = lm + j * D * N;  // temporary home of the unsorted coordinates
     if (tid < N) {
 #pragma unroll
       for (int k = 0; k < D; k++) raw[k * N + tid] = x[k * N + tid];
-      tmpA[tid] = tid;
+      L.tmpA[tid] = tid;
     }
     if (tid < 3) h2[j * 3 + tid] = (tid < D) ? x[3 * N + tid] * x[3 * N + tid] : 0.0;
     __syncthreads();
-    int *pa = tmpA, *pb = tmpB;
+    int *pa = L.tmpA, *pb = L.tmpB;
     for (int l = 0; l < T.L; l++) {
-      if (tid < N) {
-        const int node = T.pos_node[l * N + tid];
-        const int lo = T.node_lo[T.off[l] + node], hi = T.node_hi[T.off[l] + node];
-        const int me = pa[tid];
-        if (hi - lo > 1) {
-          int best = 0;
-          if (D > 1) {  // widest coordinate of the segment
-            double bext = -1.0;
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-              double mn = INFINITY, mx = -INFINITY;
-              for (int p = lo; p < hi; p++) {
-                double v = raw[k * N + pa[p]];
-                mn = fmin(mn, v);
-                mx = fmax(mx, v);
-              }
-              if (mx - mn > bext) { bext = mx - mn; best = k; }
-            }
-          }
-          const double v = raw[best * N + me];
-          int rank = 0;
+      const int cnt = T.cnt[l], off = T.off[l];
+      if (D > 1) {
+        // extent of every segment in every coordinate: item = (node, coordinate), then argmax
+        for (int item = tid; item < cnt * D; item += TB) {
+          const int z = item / D, k = item % D;
+          const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
+          double mn = INFINITY, mx = -INFINITY;
           for (int p = lo; p < hi; p++) {
+            const double v = raw[k * N + pa[p]];
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+          }
+          L.ext[item] = mx - mn;
+        }
+        __syncthreads();
+        for (int z = tid; z < cnt; z += TB) {
+          int best = 0;
+          double bext = -1.0;
+#pragma unroll
+          for (int k = 0; k < D; k++)
+            if (L.ext[z * D + k] > bext) { bext = L.ext[z * D + k]; best = k; }
+          L.bdim[z] = best;
+        }
+        __syncthreads();
+      }
+      // rank of every element inside its segment, counted P ways
+      int lo = 0, hi = 0, me = 0;
+      if (s < N) {
+        const int node = T.pos_node[l * N + s];
+        lo = T.node_lo[off + node];
+        hi = T.node_hi[off + node];
+        me = pa[s];
+        int rank = 0;
+        if (hi - lo > 1) {
+          const int best = (D > 1) ? L.bdim[node] : 0;
+          const double v = raw[best * N + me];
+          const int len = hi - lo, a = lo + (sub * len) / P, b = lo + ((sub + 1) * len) / P;
+          for (int p = a; p < b; p++) {
             const int ip = pa[p];
             const double vp = raw[best * N + ip];
             rank += (vp < v || (vp == v && ip < me)) ? 1 : 0;
           }
-          pb[lo + rank] = me;
-        } else
-          pb[tid] = me;
+        }
+        L.prk[sub * Npad + s] = rank;
+      }
+      __syncthreads();
+      if (sub == 0 && s < N) {
+        int rank = 0;
+        for (int q = 0; q < P; q++) rank += L.prk[q * Npad + s];
+        pb[(hi - lo > 1) ? lo + rank : s] = me;
       }
       __syncthreads();
       int *t = pa; pa = pb; pb = t;
@@ -333,7 +428,8 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
   }
 
   // ---- multiscale Gibbs ---------------------------------------------------------------------
-  for (int j = 0; j < F; j++) ind[j * TB + tid] = 0;  // levelInit!: root
+  if (sub == 0)
+    for (int j = 0; j < F; j++) ind[j * Npad + s] = 0;  // levelInit!: root
   for (int l = 1; l <= T.L; l++) {
     const int cnt = T.cnt[l], off = T.off[l];
     __syncthreads();
@@ -350,18 +446,32 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
       lm[jk * N + z] = cen[j * 3 + k] + mu;
       lv[jk * N + z] = var + h2[j * 3 + k];
     }
+    if (sub == 0 && s < N)
+      for (int j = 0; j < F; j++) ind[j * Npad + s] = T.node_child[T.off[l - 1] + ind[j * Npad + s]];  // levelDown!
     __syncthreads();
-    if (tid < N) {
-      for (int j = 0; j < F; j++) ind[j * TB + tid] = T.node_child[T.off[l - 1] + ind[j * TB + tid]];  // levelDown!
-      for (int it = 0; it < d->niter; it++) {
-        for (int j = 0; j < F; j++) {  // sampleIndex(j)
-          double mn[D], vn[D];
+    const int z0 = (sub * cnt) / P, z1 = ((sub + 1) * cnt) / P;  // this helper's node range
+    for (int it = 0; it < d->niter; it++) {
+      for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
+        double mn[D], vn[D], ua = 0, m = -INFINITY, tot = 0;
+        const double *mj = lm + j * D * N, *vj = lv + j * D * N;
+        auto node_e = [&](int z) -> double {
+          double e = 0;
 #pragma unroll
           for (int k = 0; k < D; k++) {
+            double tmp = mj[k * N + z] - mn[k];
+            if (circ[k]) tmp = wrap_pi(tmp);
+            const double v = vj[k * N + z] + vn[k];
+            e += tmp * tmp / v + log(v);
+          }
+          return -0.5 * e + T.node_logw[off + z];
+        };
+        if (s < N) {
+#pragma unroll
+          for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
             double prec = 0, acc = 0, ss = 0, sc = 0;
             for (int q = 0; q < F; q++) {
               if (q == j) continue;
-              const int iq = ind[q * TB + tid];
+              const int iq = ind[q * Npad + s];
               const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
               prec += 1.0 / vq;
               if (circ[k]) {
@@ -375,53 +485,67 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
             vn[k] = 1.0 / prec;
             mn[k] = circ[k] ? atan2(ss, sc) : acc * vn[k];
           }
-          double ua, ub;
-          uniform_pair(d->seed, tid, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
-          // rand(Categorical(p)) by inverse CDF over the nodes of this level.  Pass 1: running
-          // max + rescaled total; pass 2: cumulative sum until u*total (weights are recomputed,
-          // not stored: N doubles per lane would not fit in registers or LDS).
-          const double *mj = lm + j * D * N, *vj = lv + j * D * N;
-          auto node_e = [&](int z) -> double {
-            double e = 0;
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-              double tmp = mj[k * N + z] - mn[k];
-              if (circ[k]) tmp = wrap_pi(tmp);
-              const double v = vj[k * N + z] + vn[k];
-              e += tmp * tmp / v + log(v);
-            }
-            return -0.5 * e + T.node_logw[off + z];
-          };
-          double m = -INFINITY, tot = 0;
-          for (int z = 0; z < cnt; z++) {
+          double ub;
+          uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
+          // pass 1 over this helper's range: running max + rescaled total
+          for (int z = z0; z < z1; z++) {
             const double e = node_e(z);
-            if (e > m) { tot = (tot > 0) ? tot * exp(m - e) : 0.0; m = e; }
-            tot += exp(e - m);
+            if (e > m) { tot = (tot > 0) ? tot * exp_nonpos(m - e) : 0.0; m = e; }
+            tot += exp_nonpos(e - m);
           }
-          const double target = ua * tot;
-          double c = 0;
-          int choice = -1;
-          for (int z = 0; z < cnt; z++) {
-            c += exp(node_e(z) - m);
-            if (target < c) { choice = z; break; }
-          }
-          if (choice < 0) choice = cnt - 1;
-          if (choice >= 0) ind[j * TB + tid] = choice;
+          L.gm[sub * Npad + s] = m;
+          L.gt[sub * Npad + s] = tot;
         }
+        __syncthreads();
+        if (s < N) {
+          double Mx = -INFINITY;
+          for (int q = 0; q < P; q++) Mx = fmax(Mx, L.gm[q * Npad + s]);
+          // every helper computes the same cumulative shares -> the same owner
+          double total = 0, before = 0;
+          int owner = -1, lastne = 0;
+          double cum[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (q < P) {
+              const double tq = L.gt[q * Npad + s];
+              const double sc = (tq > 0) ? tq * exp_nonpos(L.gm[q * Npad + s] - Mx) : 0.0;
+              if (q == sub) before = total;
+              total += sc;
+              if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
+            }
+            cum[q] = total;
+          }
+          const double target = ua * total;
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (q < P && owner < 0 && target < cum[q]) owner = q;
+          if (owner < 0) owner = lastne;
+          if (owner == sub) {  // pass 2: inverse CDF inside the owning range
+            double c = before;
+            int choice = z1 - 1;
+            for (int z = z0; z < z1; z++) {
+              c += exp_nonpos(node_e(z) - Mx);
+              if (target < c) { choice = z; break; }
+            }
+            ind[j * Npad + s] = choice;
+          }
+        }
+        __syncthreads();
       }
     }
   }
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
   double res[D];
   if (tid < N) {
-    double nn[4] = {0, 0, 0, 0};
-    normal_pair(d->seed, tid, PURP_PFINAL, 0, nn[0], nn[1]);
-    if (D > 2) normal_pair(d->seed, tid, PURP_PFINAL, 1, nn[2], nn[3]);
+    double n0, n1, n2 = 0, n3 = 0;
+    normal_pair(d->seed, tid, PURP_PFINAL, 0, n0, n1);
+    if (D > 2) normal_pair(d->seed, tid, PURP_PFINAL, 1, n2, n3);
+    const double nn[3] = {n0, n1, n2};
 #pragma unroll
     for (int k = 0; k < D; k++) {
       double prec = 0, acc = 0, ss = 0, sc = 0;
       for (int q = 0; q < F; q++) {
-        const int iq = ind[q * TB + tid];
+        const int iq = ind[q * Npad + tid];
         const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
         prec += 1.0 / vq;
         if (circ[k]) {
@@ -438,29 +562,17 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
     }
     if (d->labels_out >= 0)
       for (int j = 0; j < F; j++)
-        side[d->labels_out + tid * F + j] = idx[j * N + T.node_lo[T.off[T.L] + ind[j * TB + tid]]];
+        side[d->labels_out + tid * F + j] = idx[j * N + T.node_lo[T.off[T.L] + ind[j * Npad + tid]]];
   }
-  __syncthreads();
-  double *R = xs;  // reuse: [D][N] result
+  // setBelief!: the rebandwidth runs as nbp_product_bandwidth_kernel right behind this kernel
   if (tid < N) {
 #pragma unroll
-    for (int k = 0; k < D; k++) R[k * N + tid] = res[k];
+    for (int k = 0; k < 3; k++) out[k * N + tid] = (k < D) ? res[k < D ? k : 0] : 0.0;
   }
-  __syncthreads();
-  // rebandwidth + setBelief!
-#pragma unroll
-  for (int k = 0; k < D; k++) {
-    double h = lcv_bandwidth_1d(R + k * N, N, circ[k], red);
-    if (tid == 0) out[3 * N + k] = h;
-  }
-  if (tid == 0)
-    for (int k = D; k < 3; k++) out[3 * N + k] = 0.0;
-  if (tid < N)
-    for (int k = 0; k < 3; k++) out[k * N + tid] = (k < D) ? R[k * N + tid] : 0.0;
 }
 
-__global__ void nbp_product_kernel(const nbp_product_desc *descs, double *arena, int N, int64_t S, int32_t *side,
-                                   nbp_levels T) {
+__global__ void __launch_bounds__(1024)
+nbp_product_kernel(const nbp_product_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side, nbp_levels T) {
   extern __shared__ double smem[];
   const nbp_product_desc *d = descs + blockIdx.x;
   if (d->nfactors == 1) {  // single density: AMP returns it unchanged
@@ -470,17 +582,15 @@ __global__ void nbp_product_kernel(const nbp_product_desc *descs, double *arena,
     if (d->labels_out >= 0 && threadIdx.x < N) side[d->labels_out + threadIdx.x] = threadIdx.x;
     return;
   }
-  switch (mani_dim(d->manifold)) {
-  case 1: product_body<1>(d, arena, N, S, side, T, smem); break;
-  case 2: product_body<2>(d, arena, N, S, side, T, smem); break;
-  default: product_body<3>(d, arena, N, S, side, T, smem); break;
+  switch (d->manifold) {
+  case NBP_EUCLID1: product_body<NBP_EUCLID1>(d, arena, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID2: product_body<NBP_EUCLID2>(d, arena, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID3: product_body<NBP_EUCLID3>(d, arena, N, Npad, S, side, T, smem); break;
+  case NBP_CIRCULAR: product_body<NBP_CIRCULAR>(d, arena, N, Npad, S, side, T, smem); break;
+  default: product_body<NBP_SE2>(d, arena, N, Npad, S, side, T, smem); break;
   }
 }
 
-// LDS bytes of the product kernel for (F, D, N, threads)
-static inline size_t nbp_product_lds_bytes(int F, int D, int N, int TB) {
-  size_t dbl = (size_t)3 * F * D * N + 6 * F + 16;
-  size_t ints = (size_t)F * N + (size_t)F * TB + 2 * N;
-  return dbl * 8 + ints * 4;
+static inline size_t nbp_product_lds_bytes(int F, int D, int N, int Npad, int P) {
+  return product_lds_layout(F, D, N, Npad, P, nullptr, nullptr);
 }
-static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)6 * N + 16) * 8 + (size_t)N * 4; }

@@ -359,8 +359,8 @@ class TreeProgram:
         self.n_updates_up = 0
         self.n_updates_down = 0
         self.alg_bytes = 0
-        self.alg_bytes_proposal = 0
-        self.alg_bytes_product = 0
+        self.alg = {"nbp_proposal_kernel": 0, "nbp_proposal_bandwidth_kernel": 0, "nbp_product_kernel": 0,
+                    "nbp_product_bandwidth_kernel": 0}
         self._compile()
 
     # -- helpers ------------------------------------------------------------------------------
@@ -368,10 +368,13 @@ class TreeProgram:
         N = self.fg.solverParams.N
         P, D = abi.MANIFOLD_P[man], abi.MANIFOLD_DIM[man]
         self.alg_bytes += (F_in + 2) * N * P * 8 + (F_in + 1) * D * 8  # B_upd, SURVEY 8(d)
-        # split of B_upd between the two kernels: the proposal kernel reads the F_in
-        # operand beliefs and the variable's own old belief; the product kernel writes the new one
-        self.alg_bytes_proposal += (F_in + 1) * N * P * 8 + F_in * D * 8
-        self.alg_bytes_product += N * P * 8 + D * 8
+        # split of B_upd over the kernels of one update (DESIGN.md "algorithmic bytes"): the proposal
+        # kernel reads the F_in operand beliefs + the variable's own old belief; the product kernel
+        # writes the new points; the bandwidth kernels write the (F_in + 1) bandwidth vectors.
+        self.alg["nbp_proposal_kernel"] += (F_in + 1) * N * P * 8
+        self.alg["nbp_proposal_bandwidth_kernel"] += F_in * D * 8
+        self.alg["nbp_product_kernel"] += N * P * 8
+        self.alg["nbp_product_bandwidth_kernel"] += D * 8
 
     def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step):
         fg, sp = self.fg, self.fg.solverParams
@@ -450,6 +453,9 @@ class TreeProgram:
             # transferUpdateSubGraph!: frontals -> main graph (CliqueStateMachine.jl:928-966)
             fin = [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in level for v in tree.cliques[c].frontalIDs]
             add((abi.STAGE_COPIES, fin)); self.stage_pass.append("down")
+
+    def alg_bytes_by_kernel(self):
+        return dict(self.alg)
 
     def B_cliques(self):
         return set(self.cliques)
