@@ -454,16 +454,36 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
         double mn[D], vn[D], ua = 0, m = -INFINITY, tot = 0;
         const double *mj = lm + j * D * N, *vj = lv + j * D * N;
+        // log-weight of node z given the product (mn, vn) of the other selected kernels:
+        //   -0.5 * sum_k [ (mean_zk - mn_k)^2 / (var_zk + vn_k) + log(var_zk + vn_k) ] + log w_z
+        // evaluated with ONE reciprocal and ONE log per node (product of the D variances); at the
+        // leaf level var_zk is the same for every node (bandwidth^2) so both are hoisted.
+        const bool leaf = (l == T.L);
+        double linv[D], llog = 0;
         auto node_e = [&](int z) -> double {
-          double e = 0;
+          double t[D], v[D];
 #pragma unroll
           for (int k = 0; k < D; k++) {
             double tmp = mj[k * N + z] - mn[k];
             if (circ[k]) tmp = wrap_pi(tmp);
-            const double v = vj[k * N + z] + vn[k];
-            e += tmp * tmp / v + log(v);
+            t[k] = tmp * tmp;
+            v[k] = vj[k * N + z] + vn[k];
           }
-          return -0.5 * e + T.node_logw[off + z];
+          double q;
+          if (leaf) {
+            q = llog;
+#pragma unroll
+            for (int k = 0; k < D; k++) q = fma(t[k], linv[k], q);
+          } else if (D == 1) {
+            q = t[0] / v[0] + log(v[0]);
+          } else if (D == 2) {
+            const double pv = v[0] * v[1];
+            q = (t[0] * v[1] + t[1] * v[0]) / pv + log(pv);
+          } else {
+            const double v01 = v[0] * v[1], pv = v01 * v[D - 1];
+            q = (t[0] * (v[1] * v[D - 1]) + t[1] * (v[0] * v[D - 1]) + t[D - 1] * v01) / pv + log(pv);
+          }
+          return fma(-0.5, q, T.node_logw[off + z]);
         };
         if (s < N) {
 #pragma unroll
@@ -484,6 +504,16 @@ __device__ void product_body(const nbp_product_desc *d, double *arena, int N, in
             }
             vn[k] = 1.0 / prec;
             mn[k] = circ[k] ? atan2(ss, sc) : acc * vn[k];
+          }
+          if (leaf) {
+            double pv = 1.0;
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+              const double v = h2[j * 3 + k] + vn[k];
+              linv[k] = 1.0 / v;
+              pv *= v;
+            }
+            llog = log(pv);
           }
           double ub;
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
