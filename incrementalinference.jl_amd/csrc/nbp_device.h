@@ -193,7 +193,7 @@ __device__ __forceinline__ double block_max(double v, double *red) {
 // rounding).  Circular coordinates: the running geodesic interpolation is order dependent, so lane
 // 0 walks it sequentially exactly like Manifolds.jl does.
 // ------------------------------------------------------------------------------------------------
-__device__ double mean_geodesic_coord(const double *x, int N, int manifold, int d, double *red) {
+__device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, int manifold, int d, double *red) {
   double mu;
   if (is_circ(manifold, d)) {
     __syncthreads();
@@ -215,7 +215,7 @@ __device__ double mean_geodesic_coord(const double *x, int N, int manifold, int 
 }
 
 // default mean(M, pts): arithmetic / extrinsic circular mean
-__device__ double mean_default_coord(const double *x, int N, int manifold, int d, double *red) {
+__device__ __forceinline__ double mean_default_coord(const double *x, int N, int manifold, int d, double *red) {
   if (is_circ(manifold, d)) {
     double s = 0, c = 0;
     if (threadIdx.x < N) sincos(x[threadIdx.x], &s, &c);
@@ -226,7 +226,7 @@ __device__ double mean_default_coord(const double *x, int N, int manifold, int d
   return block_sum(v, red) / (double)N;
 }
 
-__device__ double std_basic_spread(const double *x, int stride, int N, int manifold, double *red) {
+__device__ __forceinline__ double std_basic_spread(const double *x, int stride, int N, int manifold, double *red) {
   const int D = mani_dim(manifold);
   double acc = 0;
   for (int d = 0; d < D; d++) {
@@ -512,49 +512,77 @@ __device__ __forceinline__ void solve_particle(int kind, int manifold, const dou
 // in flight); the P partial row sums are combined in a fixed order through LDS (`part`), the N row
 // terms are tree-reduced.  O(N^2) exp per evaluation, ~16-21 evaluations per coordinate.
 // ------------------------------------------------------------------------------------------------
+// Pair-symmetric evaluation: K(x_i - x_j) = K(x_j - x_i), so lane i only visits the partners
+// j = i + t (mod N), t = 1 .. (N-1)/2 (plus t = N/2 for the lower half when N is even): every
+// unordered pair is computed once, added to lane i's own row sum (register) and to row j's
+// accumulator acc[wave][j] in LDS (one private accumulator row per wave: lanes of a wave hit
+// consecutive j -> conflict-free; a wave's LDS ops execute in order -> deterministic sums).
 template <bool CIRC>
-__device__ __forceinline__ double loo_partial(const double *x, int N, int i, int p, int P, double xi, double c) {
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int j = p;
-  for (; j + 3 * P < N; j += 4 * P) {
-    double d0 = xi - x[j], d1 = xi - x[j + P], d2 = xi - x[j + 2 * P], d3 = xi - x[j + 3 * P];
-    if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); d2 = wrap_pi(d2); d3 = wrap_pi(d3); }
-    double e0 = exp_nonpos(-d0 * d0 * c), e1 = exp_nonpos(-d1 * d1 * c);
-    double e2 = exp_nonpos(-d2 * d2 * c), e3 = exp_nonpos(-d3 * d3 * c);
-    s0 += (j == i) ? 0.0 : e0;
-    s1 += (j + P == i) ? 0.0 : e1;
-    s2 += (j + 2 * P == i) ? 0.0 : e2;
-    s3 += (j + 3 * P == i) ? 0.0 : e3;
+__device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, int t0, int t1, double xi, double c, double *accw) {
+  double s0 = 0, s1 = 0;
+  int t = t0;
+  for (; t + 1 < t1; t += 2) {
+    int j0 = i + t, j1 = i + t + 1;
+    j0 -= (j0 >= N) ? N : 0;
+    j1 -= (j1 >= N) ? N : 0;
+    double d0 = xi - x[j0], d1 = xi - x[j1];
+    if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); }
+    const double e0 = exp_nonpos(-d0 * d0 * c), e1 = exp_nonpos(-d1 * d1 * c);
+    s0 += e0;
+    s1 += e1;
+    accw[j0] += e0;
+    accw[j1] += e1;
   }
-  for (; j < N; j += P) {
-    double d = xi - x[j];
-    if (CIRC) d = wrap_pi(d);
-    double e = exp_nonpos(-d * d * c);
-    s0 += (j == i) ? 0.0 : e;
+  if (t < t1) {
+    int j0 = i + t;
+    j0 -= (j0 >= N) ? N : 0;
+    double d0 = xi - x[j0];
+    if (CIRC) d0 = wrap_pi(d0);
+    const double e0 = exp_nonpos(-d0 * d0 * c);
+    s0 += e0;
+    accw[j0] += e0;
   }
-  return (s0 + s1) + (s2 + s3);
+  return s0 + s1;
 }
 
-__device__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red) {
+// LDS: part[P][Npad] row-sum partials, acc[NW][N] per-wave partner accumulators
+__device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red) {
   const double inv2h2 = 1.0 / (2.0 * h * h);
   const double lognorm = log(h) + 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
+  const int w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  double *acc = part + P * Npad;
+  for (int q = threadIdx.x; q < NW * N; q += blockDim.x) acc[q] = 0.0;
+  __syncthreads();
   if (i < N) {
+    const int H = (N - 1) / 2;  // full partner steps
+    const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
     const double xi = x[i];
-    part[p * Npad + i] = circ ? loo_partial<true>(x, N, i, p, P, xi, inv2h2) : loo_partial<false>(x, N, i, p, P, xi, inv2h2);
+    double *accw = acc + w * N;
+    double s = circ ? loo_symmetric<true>(x, N, i, t0, t1, xi, inv2h2, accw) : loo_symmetric<false>(x, N, i, t0, t1, xi, inv2h2, accw);
+    if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair
+      const int j = i + N / 2;
+      double d = xi - x[j];
+      if (circ) d = wrap_pi(d);
+      const double e = exp_nonpos(-d * d * inv2h2);
+      s += e;
+      accw[j] += e;
+    }
+    part[p * Npad + i] = s;
   }
   __syncthreads();
   double term = 0;
   if (p == 0 && i < N) {
     double s = part[i];
     for (int q = 1; q < P; q++) s += part[q * Npad + i];
+    for (int q = 0; q < NW; q++) s += acc[q * N + i];
     if (s < 1e-300) s = 1e-300;
     term = log(s) - lognorm;
   }
   return -block_sum(term, red) / (double)N;
 }
 
-__device__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red) {
+__device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red) {
   const int i = threadIdx.x;
   double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
   if (i < N) {
@@ -613,12 +641,12 @@ struct recipe_t {
   int cat_first, ncat;
 };
 
-__device__ inline bool in_list(const int *l, int n, int v) {
+__device__ __forceinline__ bool in_list(const int *l, int n, int v) {
   for (int i = 0; i < n; i++)
     if (l[i] == v) return true;
   return false;
 }
-__device__ inline void sorted_union(const int *a, int na, int v, int *out, int *nout) {
+__device__ __forceinline__ void sorted_union(const int *a, int na, int v, int *out, int *nout) {
   int n = 0;
   bool placed = in_list(a, na, v);
   for (int i = 0; i < na; i++) {  // `a` (certainidx) is ascending
@@ -629,7 +657,7 @@ __device__ inline void sorted_union(const int *a, int na, int v, int *out, int *
   *nout = n;
 }
 
-__device__ void build_recipe(const nbp_proposal_desc *d, recipe_t *R) {
+__device__ __forceinline__ void build_recipe(const nbp_proposal_desc *d, recipe_t *R) {
   const int nvars = d->nvars, sf1 = d->sfidx + 1;
   R->ncertain = 0;
   for (int g = 0; g <= NBP_MAXV; g++) { R->nact[g] = 0; R->empty[g] = 0; R->hypo[g] = 0; }

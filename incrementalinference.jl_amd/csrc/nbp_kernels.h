@@ -14,7 +14,7 @@
 // LDS: X[3][N] target scratch (the deepcopy of CalcFactor.jl:543-548), mhidx[N], LCV partial sums.
 // HBM traffic: reads the operand beliefs once (coalesced, 8 B/lane), writes the proposal once.
 // ================================================================================================
-__device__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z) {
+__device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z) {
   int c = 0;
   if (d->ncomp > 1) {  // Mixture.sampleFactor, Factors/Mixture.jl:114-155
     double ua, ub, cum = 0;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int 
 }
 
 // calcVariableDistanceExpectedFractional, EvalFactor.jl:40-92 (block-uniform result)
-__device__ double var_distance_expected_fractional(const nbp_proposal_desc *d, const recipe_t *R, const double *arena,
+__device__ __forceinline__ double var_distance_expected_fractional(const nbp_proposal_desc *d, const recipe_t *R, const double *arena,
                                                    int64_t S, int N, const double *X, double kappa, double *red) {
   const int sf1 = d->sfidx + 1, M = d->manifold, D = mani_dim(M);
   if (in_list(R->certain, R->ncertain, sf1)) return kappa * std_basic_spread(X, N, N, M, red);
@@ -228,7 +228,7 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
     return;
   }
   const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + N, *red = part + P * Npad;
+  double *X = smem, *part = smem + N, *red = part + P * Npad + (blockDim.x >> 6) * N;
   if (n < N) X[n] = s[k * N + n];
   __syncthreads();
   double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red);
@@ -253,7 +253,10 @@ nbp_product_bandwidth_kernel(const nbp_product_desc *descs, double *arena, int N
   if (d->nfactors == 1) return;  // pass-through keeps the proposal's bandwidth
   lcv_slot_coordinate(arena + S * d->out_slot, d->manifold, blockIdx.y, N, Npad, smem);
 }
-static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) { return ((size_t)3 * N + (size_t)P * Npad + NBP_RED) * 8; }
+// X[3][N] | part[P][Npad] | acc[NW][N] | red     (NW = P*Npad/64 waves)
+static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
+  return ((size_t)3 * N + (size_t)P * Npad + (size_t)(P * Npad / 64) * N + NBP_RED) * 8;
+}
 
 // ================================================================================================
 // Bandwidth kernel: AMP.manikde!(M, pts) for a resident slot
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(1024)
 nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S) {
   extern __shared__ double smem[];
   const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + 3 * N, *red = part + P * Npad;
+  double *X = smem, *part = smem + 3 * N, *red = part + P * Npad + (blockDim.x >> 6) * N;
   double *s = arena + S * slots[blockIdx.x];
   const int M = manifolds[blockIdx.x], D = mani_dim(M), n = threadIdx.x;
   if (n < N)
@@ -338,7 +341,7 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Np
 }
 
 template <int MANI>
-__device__ void product_body(const nbp_product_desc *d, double *arena, int N, int Npad, int64_t S, int32_t *side,
+__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, int N, int Npad, int64_t S, int32_t *side,
                              const nbp_levels &T, double *smem) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
