@@ -96,13 +96,14 @@ static nbp_status build_levels(nbp_ctx *c) {
   int total = 0;
   for (int i = 0; i <= L; i++) { c->T.cnt[i] = (int)lo[i].size(); c->T.off[i] = total; total += c->T.cnt[i]; }
   std::vector<int32_t> nlo(total), nhi(total), nch(total, 0), pos((size_t)(L + 1) * N);
-  dbls.resize(total);
+  dbls.resize(2 * (size_t)total);
   for (int i = 0; i <= L; i++)
     for (int k = 0; k < c->T.cnt[i]; k++) {
       nlo[c->T.off[i] + k] = lo[i][k];
       nhi[c->T.off[i] + k] = hi[i][k];
       if (i < L) nch[c->T.off[i] + k] = child[i][k];
       dbls[c->T.off[i] + k] = std::log((double)(hi[i][k] - lo[i][k]) / (double)N);
+      dbls[total + c->T.off[i] + k] = (double)(hi[i][k] - lo[i][k]) / (double)N;
       for (int p = lo[i][k]; p < hi[i][k]; p++) pos[(size_t)i * N + p] = k;
     }
   ints.insert(ints.end(), nlo.begin(), nlo.end());
@@ -120,6 +121,7 @@ static nbp_status build_levels(nbp_ctx *c) {
   c->T.node_child = c->lv_ints + 2 * total;
   c->T.pos_node = c->lv_ints + 3 * total;
   c->T.node_logw = c->lv_dbls;
+  c->T.node_w = c->lv_dbls + total;
   return NBP_OK;
 }
 
@@ -606,5 +608,19 @@ nbp_status nbp_diag_read(nbp_ctx *c, nbp_diag *out, int32_t reset) {
   if (reset) HIPCHK(hipMemset(c->counters, 0, sizeof(h)));
   return NBP_OK;
 }
+
+#ifdef NBP_PHASE_TIMING
+nbp_status nbp_debug_phase_read(long long *out, int n, int reset) {
+  long long h[64];
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(nbp_phase_clk), sizeof(h)));
+  for (int i = 0; i < n && i < 64; i++) out[i] = h[i];
+  if (reset) {
+    memset(h, 0, sizeof(h));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nbp_phase_clk), h, sizeof(h)));
+  }
+  return NBP_OK;
+}
+#endif
 
 }  // extern "C"

@@ -48,6 +48,7 @@ struct nbp_levels {
   const int32_t *node_child;          // [total] index (within the next level) of the LAST child
   const int32_t *pos_node;            // [(L+1)*N] node (within its level) owning position i
   const double *node_logw;            // [total] log((hi-lo)/N)
+  const double *node_w;               // [total] (hi-lo)/N
 };
 
 struct nbp_counters {

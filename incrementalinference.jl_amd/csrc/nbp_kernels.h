@@ -315,8 +315,17 @@ __global__ void nbp_reseed_products(nbp_product_desc *d, int n, uint64_t salt) {
 // level for all densities live in LDS and are read with wave-uniform addresses (broadcast).
 // The KD permutation is built by rank counting inside each segment, also split P ways.
 // ================================================================================================
+#ifdef NBP_PHASE_TIMING
+__device__ long long nbp_phase_clk[64];
+#define NBP_TICK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)wall_clock64() - t_last_; t_last_ = wall_clock64(); } while (0)
+#define NBP_TICK_INIT() long long t_last_ = wall_clock64()
+#else
+#define NBP_TICK(k)
+#define NBP_TICK_INIT()
+#endif
+
 struct product_lds {
-  double *xs, *lm, *lv, *cen, *h2, *red, *gm, *gt, *ext;
+  double *xs, *lm, *lv, *cen, *h2, *red, *gm, *gt, *ext, *nw;
   int *idx, *ind, *tmpA, *tmpB, *prk, *bdim;
 };
 
@@ -327,13 +336,14 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Np
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3), red = dbl(NBP_RED);
   size_t gm = dbl((size_t)P * Npad), gt = dbl((size_t)P * Npad);  // gt doubles as LCV `part`
   size_t ext = dbl((size_t)3 * Npad);
+  size_t nw = dbl((size_t)Npad);  // node weights (hi-lo)/N of the current level
   size_t ints0 = o;  // int region starts here (8-byte aligned)
   size_t io = 0;
   auto i32 = [&](size_t n) { size_t r = io; io += n; return r; };
   size_t idx = i32((size_t)F * N), ind = i32((size_t)F * Npad), tA = i32(N), tB = i32(N), prk = i32((size_t)P * Npad), bd = i32(Npad);
   if (L) {
     L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2; L->red = base + red;
-    L->gm = base + gm; L->gt = base + gt; L->ext = base + ext;
+    L->gm = base + gm; L->gt = base + gt; L->ext = base + ext; L->nw = base + nw;
     int *ib = (int *)(base + ints0);
     L->idx = ib + idx; L->ind = ib + ind; L->tmpA = ib + tA; L->tmpB = ib + tB; L->prk = ib + prk; L->bdim = ib + bd;
   }
@@ -353,6 +363,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   int *idx = L.idx, *ind = L.ind;
   double *out = arena + S * d->out_slot;
 
+  NBP_TICK_INIT();
   // ---- KD-tree permutation per density (median split of the widest coordinate) ----------------
   for (int j = 0; j < F; j++) {
     const double *x = arena + S * d->in_slot[j];
@@ -381,6 +392,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           L.ext[item] = mx - mn;
         }
         __syncthreads();
+        NBP_TICK(0);  // KD extents
         for (int z = tid; z < cnt; z += TB) {
           int best = 0;
           double bext = -1.0;
@@ -418,6 +430,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         pb[(hi - lo > 1) ? lo + rank : s] = me;
       }
       __syncthreads();
+      NBP_TICK(1);  // KD rank + scatter
       int *t = pa; pa = pb; pb = t;
     }
 #pragma unroll
@@ -428,6 +441,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     }
     if (tid < N) idx[j * N + tid] = pa[tid];
     __syncthreads();
+    NBP_TICK(2);  // centre + sorted copy
   }
 
   // ---- multiscale Gibbs ---------------------------------------------------------------------
@@ -449,21 +463,29 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       lm[jk * N + z] = cen[j * 3 + k] + mu;
       lv[jk * N + z] = var + h2[j * 3 + k];
     }
+    for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
     if (sub == 0 && s < N)
       for (int j = 0; j < F; j++) ind[j * Npad + s] = T.node_child[T.off[l - 1] + ind[j * Npad + s]];  // levelDown!
     __syncthreads();
+    NBP_TICK(3);  // level statistics
     const int z0 = (sub * cnt) / P, z1 = ((sub + 1) * cnt) / P;  // this helper's node range
     for (int it = 0; it < d->niter; it++) {
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
+        // Draw l_j ~ p(l_j | others) by inverse CDF over the nodes of this level.
+        //   weight_z = w_z * N(mean_z; mn, var_z + vn)  =  exp(a_z) * g_z,
+        //   a_z = -0.5 * sum_k t_k^2 / v_k  (<= 0),   g_z = w_z / sqrt(prod_k v_k)
+        // evaluated in the linear domain with ONE rsqrt per node (its square is the reciprocal of the
+        // variance product) and the running max taken over a_z only; at the leaf level v_k and w_z
+        // are the same for every node, so g_z cancels and the reciprocals are hoisted.
+        // Pass 1 (all P helpers, contiguous node ranges, NCH chunks each): rescaled totals.
+        // Pass 2 (the owning helper only): locate the chunk, re-evaluate just that chunk.
+        constexpr int NCH = 4;
         double mn[D], vn[D], ua = 0, m = -INFINITY, tot = 0;
+        double cs[NCH], ms[NCH];
         const double *mj = lm + j * D * N, *vj = lv + j * D * N;
-        // log-weight of node z given the product (mn, vn) of the other selected kernels:
-        //   -0.5 * sum_k [ (mean_zk - mn_k)^2 / (var_zk + vn_k) + log(var_zk + vn_k) ] + log w_z
-        // evaluated with ONE reciprocal and ONE log per node (product of the D variances); at the
-        // leaf level var_zk is the same for every node (bandwidth^2) so both are hoisted.
         const bool leaf = (l == T.L);
-        double linv[D], llog = 0;
-        auto node_e = [&](int z) -> double {
+        double linv[D];
+        auto node_w = [&](int z, double &a, double &g) {
           double t[D], v[D];
 #pragma unroll
           for (int k = 0; k < D; k++) {
@@ -472,22 +494,23 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             t[k] = tmp * tmp;
             v[k] = vj[k * N + z] + vn[k];
           }
-          double q;
           if (leaf) {
-            q = llog;
+            double q = 0;
 #pragma unroll
             for (int k = 0; k < D; k++) q = fma(t[k], linv[k], q);
-          } else if (D == 1) {
-            q = t[0] / v[0] + log(v[0]);
-          } else if (D == 2) {
-            const double pv = v[0] * v[1];
-            q = (t[0] * v[1] + t[1] * v[0]) / pv + log(pv);
+            a = -0.5 * q;
+            g = 1.0;
           } else {
-            const double v01 = v[0] * v[1], pv = v01 * v[D - 1];
-            q = (t[0] * (v[1] * v[D - 1]) + t[1] * (v[0] * v[D - 1]) + t[D - 1] * v01) / pv + log(pv);
+            double pv, num;
+            if (D == 1) { pv = v[0]; num = t[0]; }
+            else if (D == 2) { pv = v[0] * v[1]; num = t[0] * v[1] + t[1] * v[0]; }
+            else { const double v01 = v[0] * v[1]; pv = v01 * v[D - 1]; num = t[0] * (v[1] * v[D - 1]) + t[1] * (v[0] * v[D - 1]) + t[D - 1] * v01; }
+            const double r = rsqrt(pv);
+            a = -0.5 * num * (r * r);
+            g = r * L.nw[z];
           }
-          return fma(-0.5, q, T.node_logw[off + z]);
         };
+        const int zr = z1 - z0, csz = (zr + NCH - 1) / NCH;  // chunk size of this helper's range
         if (s < N) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
@@ -498,10 +521,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
               prec += 1.0 / vq;
               if (circ[k]) {
-                double sn, cs;
-                sincos(mq, &sn, &cs);
+                double sn, cs_;
+                sincos(mq, &sn, &cs_);
                 ss += sn / vq;
-                sc += cs / vq;
+                sc += cs_ / vq;
               } else
                 acc += mq / vq;
             }
@@ -509,27 +532,38 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             mn[k] = circ[k] ? atan2(ss, sc) : acc * vn[k];
           }
           if (leaf) {
-            double pv = 1.0;
 #pragma unroll
-            for (int k = 0; k < D; k++) {
-              const double v = h2[j * 3 + k] + vn[k];
-              linv[k] = 1.0 / v;
-              pv *= v;
-            }
-            llog = log(pv);
+            for (int k = 0; k < D; k++) linv[k] = 1.0 / (h2[j * 3 + k] + vn[k]);
           }
           double ub;
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
-          // pass 1 over this helper's range: running max + rescaled total
-          for (int z = z0; z < z1; z++) {
-            const double e = node_e(z);
-            if (e > m) { tot = (tot > 0) ? tot * exp_nonpos(m - e) : 0.0; m = e; }
-            tot += exp_nonpos(e - m);
+          NBP_TICK(7);  // others-product + Philox (wave 0 only)
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            double cur = 0;
+            const int za = z0 + c * csz, zb = min(z1, za + csz);
+            for (int z = za; z < zb; z++) {
+              double a, g;
+              node_w(z, a, g);
+              if (a > m) {
+                const double f = exp_nonpos(m - a);  // m == -inf -> 0
+                tot *= f;
+                cur *= f;
+                m = a;
+              }
+              const double w = exp_nonpos(a - m) * g;
+              tot += w;
+              cur += w;
+            }
+            cs[c] = cur;
+            ms[c] = m;
           }
           L.gm[sub * Npad + s] = m;
           L.gt[sub * Npad + s] = tot;
+          NBP_TICK(8);  // pass-1 loop (wave 0 only)
         }
         __syncthreads();
+        NBP_TICK(4);  // others-product + pass 1
         if (s < N) {
           double Mx = -INFINITY;
           for (int q = 0; q < P; q++) Mx = fmax(Mx, L.gm[q * Npad + s]);
@@ -553,17 +587,35 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           for (int q = 0; q < 4; q++)
             if (q < P && owner < 0 && target < cum[q]) owner = q;
           if (owner < 0) owner = lastne;
-          if (owner == sub) {  // pass 2: inverse CDF inside the owning range
-            double c = before;
-            int choice = z1 - 1;
-            for (int z = z0; z < z1; z++) {
-              c += exp_nonpos(node_e(z) - Mx);
-              if (target < c) { choice = z; break; }
+          if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
+            double c0 = before;
+            int za = z0, zb = z1;
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+              const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx) : 0.0;
+              const int ca = z0 + c * csz, cb = min(z1, ca + csz);
+              if (!found && ca < cb) {
+                za = ca; zb = cb;  // remember the last non-empty chunk as the fallback
+                if (target < c0 + share) found = true;
+                else c0 += share;
+              }
+            }
+            double c = found ? c0 : -INFINITY;  // not found: take the last node of the last chunk
+            int choice = zb - 1;
+            if (found) {
+              for (int z = za; z < zb; z++) {
+                double a, g;
+                node_w(z, a, g);
+                c += exp_nonpos(a - Mx) * g;
+                if (target < c) { choice = z; break; }
+              }
             }
             ind[j * Npad + s] = choice;
           }
         }
         __syncthreads();
+        NBP_TICK(5);  // combine + pass 2
       }
     }
   }
@@ -597,6 +649,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       for (int j = 0; j < F; j++)
         side[d->labels_out + tid * F + j] = idx[j * N + T.node_lo[T.off[T.L] + ind[j * Npad + tid]]];
   }
+  NBP_TICK(6);  // final draw
   // setBelief!: the rebandwidth runs as nbp_product_bandwidth_kernel right behind this kernel
   if (tid < N) {
 #pragma unroll

@@ -1,0 +1,36 @@
+"""Summarise a rocprofv3 --kernel-trace CSV for the TIMED region of bench.py: the last
+`steps` x launches_per_step dispatches of each libnbp kernel (earlier dispatches belong to graph
+initialisation and warm-up).  Usage: summarize_trace.py <kernel_trace.csv> <steps> [launches_per_step]"""
+import csv
+import collections
+import sys
+
+
+def main(path, steps, lps=67):
+    rows = list(csv.DictReader(open(path)))
+    by = collections.defaultdict(list)
+    for r in rows:
+        name = r["Kernel_Name"].split("(")[0]
+        if name.startswith("nbp_"):
+            by[name].append(r)
+    print(f"{'kernel':34s} {'launches':>8s} {'avg_us':>10s} {'total_ms':>9s} | avg_us by grid size (blocks): <=8, <=64, <=300, >300")
+    out = {}
+    for name, rs in sorted(by.items()):
+        if name in ("nbp_reseed_proposals", "nbp_reseed_products", "nbp_copy_kernel"):
+            tail = rs
+        else:
+            tail = rs[-steps * lps:]
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tail]
+        g = [int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) for r in tail]
+        buckets = collections.defaultdict(list)
+        for dur, grid in zip(d, g):
+            b = 0 if grid <= 8 else 1 if grid <= 64 else 2 if grid <= 300 else 3
+            buckets[b].append(dur)
+        bs = " ".join(f"{(sum(buckets[b]) / len(buckets[b])) if buckets[b] else 0:9.1f}(n={len(buckets[b])}, {sum(buckets[b]) / 1e3 / steps:6.1f}ms/step)" for b in range(4))
+        print(f"{name:34s} {len(tail):8d} {sum(d) / len(d):10.1f} {sum(d) / 1e3:9.2f} | {bs}")
+        out[name] = (len(tail), sum(d) / len(d))
+    return out
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 67)
