@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--nvars", type=int, default=1000, help="variables per GPU (config 2: 1000; north-star 2': 10000)")
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-vars", type=int, default=96)
+    ap.add_argument("--cpu-sample-vars", type=int, default=300)
     return ap.parse_args()
 
 
@@ -131,11 +131,20 @@ def main():
                              "update against ~1e7 FP64 exp/log/div; see DESIGN.md"},
     }
     if rank == 0 and not a.no_cpu_baseline and world == 1:
-        threads = os.cpu_count() or 1
-        v, secs, m = cpu_baseline(iif, a.cpu_sample_vars, N, threads)
+        # the OpenMP port parallelises over the independent ops of a stage; with hundreds of threads
+        # it is oversubscribed (measured on the MI355X host: 32 threads is the sweet spot), so the
+        # baseline is the best of a few thread counts and `cores` is the count actually used
+        ncpu = os.cpu_count() or 1
+        best = None
+        for threads in sorted({min(ncpu, t) for t in (16, 32, 64)}):
+            v, secs, m = cpu_baseline(iif, a.cpu_sample_vars, N, threads)
+            if best is None or v > best[0]:
+                best = (v, secs, m, threads)
+        v, secs, m, threads = best
         out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port",
                                "sample": f"{a.cpu_sample_vars}-variable chain of the same shape, N={N}, one full "
-                                         f"up+down solve ({m} messages) in {secs:.1f} s, OpenMP over stage ops"}
+                                         f"up+down solve ({m} messages) in {secs:.1f} s, OpenMP over stage ops, "
+                                         f"best of 16/32/64 threads on a {ncpu}-thread host"}
         out["vs_cpu_baseline"] = value / v
     if rank == 0:
         print(json.dumps(out))

@@ -52,9 +52,23 @@ typedef struct {
   int64_t solves, nonconverged, nan_results, residual_evals, lcv_evals;
 } orc_diag;
 
-static orc_diag g_diag;
+static orc_diag g_diag;               /* merged totals */
+static __thread orc_diag t_diag;      /* per-thread counters, merged at the end of every op */
+
+static void diag_merge(void) {
+#pragma omp critical(orc_diag)
+  {
+    g_diag.solves += t_diag.solves;
+    g_diag.nonconverged += t_diag.nonconverged;
+    g_diag.nan_results += t_diag.nan_results;
+    g_diag.residual_evals += t_diag.residual_evals;
+    g_diag.lcv_evals += t_diag.lcv_evals;
+  }
+  memset(&t_diag, 0, sizeof(t_diag));
+}
 
 void orc_diag_read(orc_diag *out, int reset) {
+  diag_merge();
   *out = g_diag;
   if (reset) memset(&g_diag, 0, sizeof(g_diag));
 }
@@ -235,8 +249,7 @@ static int factor_zdim(int kind, int manifold) {
 
 int32_t orc_residual(int32_t kind, int32_t manifold, const double *z, const double *a, const double *b, double *r) {
   int D = mani_dim(manifold);
-  #pragma omp atomic
-  g_diag.residual_evals++;
+  t_diag.residual_evals++;
   switch (kind) {
   case NBP_F_LINREL: /* Factors/LinearRelative.jl:42-49 */
     for (int d = 0; d < D; d++) r[d] = z[d] - (b[d] - a[d]);
@@ -438,20 +451,12 @@ static void solve_particle(int kind, int manifold, const double *z, const double
   int D = o.D;
   for (int d = 0; d < D; d++) xc[d] = x[d]; /* X0c = vee(M, e, log(M, e, u0)) */
   int conv;
-#pragma omp atomic
-  g_diag.solves++;
+  t_diag.solves++;
   if (D == 1) conv = orc_bfgs_1d(&o, xc, 0); /* islen1 -> BFGS */
   else conv = orc_nelder_mead(&o, D, xc, 0);
-  if (!conv) {
-#pragma omp atomic
-    g_diag.nonconverged++;
-  } /* @warn only; the result is still used (:128-131) */
+  if (!conv) t_diag.nonconverged++; /* @warn only; the result is still used (:128-131) */
   for (int d = 0; d < D; d++)
-    if (isnan(xc[d])) {
-#pragma omp atomic
-      g_diag.nan_results++;
-      return;
-    }
+    if (isnan(xc[d])) { t_diag.nan_results++; return; }
   for (int d = 0; d < D; d++) x[d] = is_circ(manifold, d) ? orc_wrap(xc[d]) : xc[d]; /* exp(M, e, hat(..)) */
 }
 
@@ -595,8 +600,7 @@ static int categorical(const double *p, int n, double u) {
 static double neg_loo_ll(const double *x, int N, int circ, double h) {
   double inv2h2 = 1.0 / (2.0 * h * h), acc = 0;
   double lognorm = log(h) + 0.5 * log(TWO_PI) + log((double)(N - 1));
-  #pragma omp atomic
-  g_diag.lcv_evals++;
+  t_diag.lcv_evals++;
   for (int i = 0; i < N; i++) {
     double s = 0;
     for (int j = 0; j < N; j++) {
@@ -1009,13 +1013,13 @@ void orc_run_copy(double *arena, int32_t N, const nbp_copy_desc *c) {
 int32_t orc_run_proposals(double *arena, int32_t N, int32_t *side, const nbp_proposal_desc *d, int32_t n) {
   int rc = NBP_OK;
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int i = 0; i < n; i++) { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; }
+  for (int i = 0; i < n; i++) { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
   return rc;
 }
 int32_t orc_run_products(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d, int32_t n) {
   int rc = NBP_OK;
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; }
+  for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
   return rc;
 }
 void orc_set_threads(int32_t n);
