@@ -44,7 +44,9 @@ class RankSolve:
     def check_posteriors(self):
         """posteriors within the BASELINE.md tolerance of the ground truth x_i = (i, i)"""
         if self.world > 1:
-            return self.impl.check_posteriors()
+            self.impl.check_posteriors()
+            self.posterior_max_mean_err = self.impl.posterior_max_mean_err
+            return
         tp, fg = self.tp, self.fg
         worst = 0.0
         for i in range(0, self.nvars, max(1, self.nvars // 64)):

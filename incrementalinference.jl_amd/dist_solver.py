@@ -1,0 +1,143 @@
+"""Multi-GPU tree solve: independent cliques of a tree level shard across ranks (one process per
+GPU); only separator beliefs on tree edges that cross a rank boundary move, point to point.
+
+This is the MI355X-native stand-in for the reference's only distributed mechanisms -- the
+rendezvous `Channel{LikelihoodMessage}` per tree edge (JunctionTreeUtils.jl:943-956,
+CliqueStateMachine.jl:221-234/617-629) and the optional `remotecall_fetch` of a whole clique
+up-solve onto a `WorkerPool` (CliqStateMachineUtils.jl:369-385).  A message is the `TreeBelief`
+payload (val N x P, bw, entities/BeliefTypes.jl:47-57) = one slot (4.9 KB at N = 200): traffic is
+latency bound, so messages of one tree level are batched into a single group of point-to-point
+`isend/irecv` (RCCL over xGMI with backend "nccl", gloo in the CPU tests) -- no ring collective.
+"""
+import numpy as np
+
+from . import abi
+from .solver import TreeProgram
+
+
+def partition_cliques(tree, world, weight=None):
+    """Assign every clique to a rank: cut the tree into >= world subtrees by repeatedly splitting
+    the heaviest one, place subtrees largest-first on the least loaded rank, then give every
+    clique above the cut to the rank of its heaviest child (one of its edges stays local)."""
+    cl = tree.cliques
+    w = {c: (1.0 if weight is None else float(weight(c))) for c in cl}
+    sub = {}
+    for c in tree.postorder():
+        sub[c] = w[c] + sum(sub[ch] for ch in cl[c].children)
+    roots = list(tree.roots)
+    top = []
+    total = sum(w.values())
+    while len(roots) < 6 * world:
+        splittable = [r for r in roots if cl[r].children]
+        if not splittable:
+            break
+        r = max(splittable, key=lambda c: sub[c])
+        if len(roots) >= world and sub[r] <= 0.6 * total / world:
+            break  # fine enough for largest-first placement to balance the ranks
+        roots.remove(r)
+        top.append(r)
+        roots.extend(cl[r].children)
+    owner, load = {}, [0.0] * world
+    for r in sorted(roots, key=lambda c: -sub[c]):
+        k = int(np.argmin(load))
+        load[k] += sub[r]
+        stack = [r]
+        while stack:
+            c = stack.pop()
+            owner[c] = k
+            stack.extend(cl[c].children)
+    for c in reversed(top):  # children before parents
+        best = max(cl[c].children, key=lambda ch: sub[ch])
+        owner[c] = owner[best]
+        load[owner[c]] += w[c]
+    return owner
+
+
+class ShardedRunner:
+    """Runs one rank's share of a TreeProgram: stage segments interleaved with slot exchanges."""
+
+    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None):
+        self.tp, self.be, self.dist = tp, backend, dist
+        self.slot_tensor = slot_tensor
+        self.sync_device = sync_device or (lambda: None)
+        self.prog = backend.program(tp.stages)
+
+    def run(self, salt=None):
+        if salt is not None:
+            self.prog.reseed(salt)
+        for seg in self.tp.segments:
+            if seg[0] == "run":
+                if seg[2] > seg[1]:
+                    self.prog.run(seg[1], seg[2])
+            else:
+                self._exchange(seg[1], seg[2])
+
+    def _exchange(self, sends, recvs):
+        dist = self.dist
+        self.be.synchronize()  # the slots to send are complete
+        ops = []
+        for peer, slot in sends:
+            ops.append(dist.P2POp(dist.isend, self.slot_tensor(slot), peer))
+        for peer, slot in recvs:
+            ops.append(dist.P2POp(dist.irecv, self.slot_tensor(slot), peer))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        self.sync_device()
+
+    def close(self):
+        self.prog.close()
+
+
+class ShardedTreeSolve:
+    """bench.py's multi-GPU leg: the config-2 chain grown with the number of ranks (weak scaling),
+    one process per GPU, arena owned by torch so that RCCL can move slots."""
+
+    def __init__(self, iif, nvars_total, N, rank, world, local, dist):
+        self.iif, self.nvars, self.N = iif, nvars_total, N
+        self.rank, self.world, self.local, self.dist = rank, world, local, dist
+
+    def prepare(self):
+        import torch
+        iif = self.iif
+        fg = iif.generateChainEuclid(self.nvars, vardims=2, priorEvery=100, N=self.N)
+        order = iif.nestedDissectionOrder(fg)
+        tree = iif.buildTreeReset(fg, order)
+        mk = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints, device=self.local)
+        iif.initAll(fg, backend=mk, seed=0)  # replicated: every rank computes the same initial beliefs
+        self.fg, self.tree = fg, tree
+        owner = partition_cliques(tree, self.world)
+        tp = TreeProgram(fg, tree, seed=1, snapshot=True, owner=owner, rank=self.rank)
+        self.tp = tp
+        stride = abi.slot_stride(self.N)
+        self.arena = torch.zeros(tp.n_slots * stride, dtype=torch.float64, device=f"cuda:{self.local}")
+        self.be = iif.HipBackend(self.N, tp.n_slots, device=self.local, arena_ptr=self.arena.data_ptr(),
+                                 arena_bytes=self.arena.numel() * 8)
+        for v in fg.ls():
+            var = fg.getVariable(v)
+            self.be.slot_write(tp.snap[v], var.varType.manifold, var.val, var.bw)
+        self.runner = ShardedRunner(tp, self.be, self.dist, lambda s: self.arena[s * stride:(s + 1) * stride],
+                                    torch.cuda.synchronize)
+        st = tp.stats()
+        self.global_messages = tp.n_messages
+        # global totals over ranks
+        t = torch.tensor([float(st["updates_up"] + st["updates_down"])] + [float(tp.alg[k]) for k in sorted(tp.alg)],
+                         device=f"cuda:{self.local}", dtype=torch.float64)
+        if self.dist is not None:
+            self.dist.all_reduce(t)
+        self.stats = {"cliques_global": len(tree.cliques), "updates_global": int(t[0].item()),
+                      "alg_bytes": dict(tp.alg)}
+
+    def step(self, k):
+        self.runner.run(salt=0x9E37 + k)
+
+    def check_posteriors(self):
+        tp, fg = self.tp, self.fg
+        worst = 0.0
+        mine = [v for c in tp.cliques for v in self.tree.cliques[c].frontalIDs]
+        for v in mine[:: max(1, len(mine) // 32)]:
+            i = int(v[1:])
+            pts, _ = self.be.slot_read(tp.main[v], fg.getVariable(v).varType.manifold)
+            worst = max(worst, float(np.abs(pts.mean(axis=0) - i).max()))
+        if not worst < 1.5:
+            raise RuntimeError(f"rank {self.rank}: posterior means off by {worst}")
+        self.posterior_max_mean_err = worst

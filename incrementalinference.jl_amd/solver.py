@@ -304,14 +304,20 @@ def initAll(fg, backend=None, seed=0):
 class TreeProgram:
     """The whole up+down solve of a Bayes tree compiled into libnbp stages.
 
-    Slot plan (DESIGN.md "HBM layout"):  main[v] | clique-local beliefs B[c,v] | per-clique proposal
-    scratch.  The clique-local copies are the reference's deep-copied `cliqSubFg`
-    (SubGraphFunctions.jl:48); an up message is the child's separator slot read in place by the
-    parent's MsgPrior proposal; a down message is a slot copy parent -> child
-    (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84)."""
+    Slot plan (DESIGN.md "HBM layout"):  main[v] | snap[v] | clique-local beliefs B[c,v] | ghost
+    slots for messages arriving from other ranks | per-clique proposal scratch.  The clique-local
+    copies are the reference's deep-copied `cliqSubFg` (SubGraphFunctions.jl:48); an up message is
+    the child's separator slot read in place by the parent's MsgPrior proposal; a down message is a
+    slot copy parent -> child (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84).
 
-    def __init__(self, fg, tree, seed=0, cliques=None, snapshot=False):
+    Multi-GPU: `owner` maps every clique to a rank; a rank compiles only its own cliques.  Tree
+    edges whose two cliques live on different ranks become exchange items between the stage
+    segments (`self.segments`): the separator beliefs are sent slot-by-slot, point to point."""
+
+    def __init__(self, fg, tree, seed=0, snapshot=False, owner=None, rank=0):
         self.fg, self.tree, self.seed = fg, tree, seed
+        self.rank = rank
+        self.owner = owner or {c: 0 for c in tree.cliques}
         sp = fg.solverParams
         labels = fg.ls()
         self.main = {v: i for i, v in enumerate(labels)}
@@ -323,17 +329,22 @@ class TreeProgram:
             self.snap = {v: nxt + i for i, v in enumerate(labels)}
             nxt += len(labels)
         self.B = {}
+        self.ghost = {}
         self.scratch = {}
         self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
-        heights, depths = tree.heights(), tree.depths()
-        self.heights, self.depths = heights, depths
-        only = set(cliques) if cliques is not None else None
-        for cid, cl in tree.cliques.items():
-            if only is not None and cid not in only:
-                continue
+        self.heights, self.depths = tree.heights(), tree.depths()
+        mine = [c for c in tree.cliques if self.owner[c] == rank]
+        self.cliques = mine
+        for cid in mine:
+            cl = tree.cliques[cid]
             for v in cl.allIDs:
                 self.B[(cid, v)] = nxt
                 nxt += 1
+            for ch in cl.children:  # messages from children that live on another rank land in ghost slots
+                if self.owner[ch] != rank:
+                    for v in tree.cliques[ch].separatorIDs:
+                        self.ghost[(ch, v)] = nxt
+                        nxt += 1
             # up-solve factor lists per variable: clique potentials touching v + child messages on v
             upf = {}
             for v in cl.allIDs:
@@ -353,9 +364,10 @@ class TreeProgram:
             self.scratch[cid] = (nxt, maxf)
             nxt += maxf
         self.n_slots = nxt
-        self.cliques = [c for c in tree.cliques if only is None or c in only]
         self.stages = []
         self.stage_pass = []
+        self.segments = []  # ("run", first_stage, last_stage) | ("xchg", sends, recvs)
+        self._seg_start = 0
         self.n_updates_up = 0
         self.n_updates_down = 0
         self.alg_bytes = 0
@@ -376,6 +388,9 @@ class TreeProgram:
         self.alg["nbp_product_kernel"] += N * P * 8
         self.alg["nbp_product_bandwidth_kernel"] += D * 8
 
+    def _msg_slot(self, child, v):
+        return self.B[(child, v)] if self.owner[child] == self.rank else self.ghost[(child, v)]
+
     def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step):
         fg, sp = self.fg, self.fg.solverParams
         base, _ = self.scratch[cid]
@@ -385,7 +400,7 @@ class TreeProgram:
                 fcts.append(fg.getFactor(ref))
             else:  # child message -> MsgPrior (generateMsgPrior, TreeMessageUtils.jl:86-89)
                 from .factorgraph import DFGFactor
-                fcts.append(DFGFactor(f"msg{ref}_{v}", [v], MsgPrior(self.B[(ref, v)]), None, 0.0, sp.inflation))
+                fcts.append(DFGFactor(f"msg{ref}_{v}", [v], MsgPrior(self._msg_slot(ref, v)), None, 0.0, sp.inflation))
         ns = _null_surplus(fg, fcts)
         props = [proposal_desc(fg, f, v, slot_of, base + i, op_seed(self.seed, passid, cid, step, i + 1), nullSurplus=ns[i])
                  for i, f in enumerate(fcts)]
@@ -395,19 +410,32 @@ class TreeProgram:
         self._account(man, sum(0 if f.fnc.is_prior and not isinstance(f.fnc, MsgPrior) else 1 for f in fcts))
         return props, prod
 
+    def _add(self, kind, descs, tag):
+        self.stages.append((kind, descs))
+        self.stage_pass.append(tag)
+
+    def _exchange(self, edges):
+        """edges: [(src_rank, src_slot_key, dst_rank, dst_slot_key)] in a globally agreed order"""
+        sends = [(dr, sk()) for (sr, sk, dr, dk) in edges if sr == self.rank and dr != self.rank]
+        recvs = [(sr, dk()) for (sr, sk, dr, dk) in edges if dr == self.rank and sr != self.rank]
+        if sends or recvs:
+            self.segments.append(("run", self._seg_start, len(self.stages)))
+            self.segments.append(("xchg", sends, recvs))
+            self._seg_start = len(self.stages)
+
     def _compile(self):
-        tree, fg = self.tree, self.fg
-        add = self.stages.append
+        tree, fg, rank, owner = self.tree, self.fg, self.rank, self.owner
         if self.snap is not None:
-            add((abi.STAGE_COPIES, [abi.CopyDesc(self.snap[v], self.main[v]) for v in fg.ls()])); self.stage_pass.append("copy")
+            self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.snap[v], self.main[v]) for v in fg.ls()], "copy")
         # deep copy of the clique sub graphs (SubGraphFunctions.jl:48)
-        copies = [abi.CopyDesc(self.main[v], self.B[(c, v)]) for c in self.cliques for v in tree.cliques[c].allIDs]
-        add((abi.STAGE_COPIES, copies)); self.stage_pass.append("copy")
+        self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.main[v], self.B[(c, v)]) for c in self.cliques
+                                     for v in tree.cliques[c].allIDs], "copy")
+        allc = sorted(tree.cliques)
         # ---- up pass: leaves first ------------------------------------------------------------
-        maxh = max(self.heights[c] for c in self.cliques)
+        maxh = max(self.heights.values())
         for h in range(maxh + 1):
             level = [c for c in self.cliques if self.heights[c] == h]
-            nsteps = max(len(self.upsched[c]) for c in level)
+            nsteps = max([len(self.upsched[c]) for c in level] + [0])
             for k in range(nsteps):
                 props, prods = [], []
                 for c in level:
@@ -419,19 +447,38 @@ class TreeProgram:
                     props += p
                     prods.append(q)
                     self.n_updates_up += 1
-                add((abi.STAGE_PROPOSALS, props)); self.stage_pass.append("up")
-                add((abi.STAGE_PRODUCTS, prods)); self.stage_pass.append("up")
+                self._add(abi.STAGE_PROPOSALS, props, "up")
+                self._add(abi.STAGE_PRODUCTS, prods, "up")
+            # up messages that cross a rank boundary: child's separator beliefs -> parent's ghost slots
+            edges = []
+            for c in allc:
+                cl = tree.cliques[c]
+                if self.heights[c] == h and cl.parent >= 0 and owner[c] != owner[cl.parent]:
+                    for v in cl.separatorIDs:
+                        edges.append((owner[c], (lambda c=c, v=v: self.B[(c, v)]), owner[cl.parent],
+                                      (lambda c=c, v=v: self.ghost[(c, v)])))
+            self._exchange(edges)
         # roots: posterior = up-solve result (CliqueStateMachine.jl preDownSolve root branch)
-        rootcopies = [abi.CopyDesc(self.B[(r, v)], self.main[v]) for r in tree.roots if r in self.B_cliques() for v in tree.cliques[r].frontalIDs]
-        add((abi.STAGE_COPIES, rootcopies)); self.stage_pass.append("down")
+        self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.B[(r, v)], self.main[v]) for r in tree.roots if owner[r] == rank
+                                     for v in tree.cliques[r].frontalIDs], "down")
         # ---- down pass: root first --------------------------------------------------------------
-        maxd = max(self.depths[c] for c in self.cliques)
+        maxd = max(self.depths.values())
         for dpt in range(1, maxd + 1):
+            # down messages that cross a rank boundary: parent's values of the child's separators
+            edges = []
+            for c in allc:
+                cl = tree.cliques[c]
+                if self.depths[c] == dpt and owner[c] != owner[cl.parent]:
+                    for v in cl.separatorIDs:
+                        edges.append((owner[cl.parent], (lambda p=cl.parent, v=v: self.B[(p, v)]), owner[c],
+                                      (lambda c=c, v=v: self.B[(c, v)])))
+            self._exchange(edges)
             level = [c for c in self.cliques if self.depths[c] == dpt]
             # down message: separators := parent's values (updateSubFgFromDownMsgs!)
-            msg = [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)]) for c in level for s in tree.cliques[c].separatorIDs]
-            add((abi.STAGE_COPIES, msg)); self.stage_pass.append("down")
-            nsteps = max(len(self.dnsched[c]) for c in level)
+            msg = [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)]) for c in level
+                   if owner[tree.cliques[c].parent] == rank for s in tree.cliques[c].separatorIDs]
+            self._add(abi.STAGE_COPIES, msg, "down")
+            nsteps = max([len(self.dnsched[c]) for c in level] + [0])
             for k in range(nsteps):
                 props, prods = [], []
                 for c in level:
@@ -448,22 +495,21 @@ class TreeProgram:
                     props += p
                     prods.append(q)
                     self.n_updates_down += 1
-                add((abi.STAGE_PROPOSALS, props)); self.stage_pass.append("down")
-                add((abi.STAGE_PRODUCTS, prods)); self.stage_pass.append("down")
+                self._add(abi.STAGE_PROPOSALS, props, "down")
+                self._add(abi.STAGE_PRODUCTS, prods, "down")
             # transferUpdateSubGraph!: frontals -> main graph (CliqueStateMachine.jl:928-966)
-            fin = [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in level for v in tree.cliques[c].frontalIDs]
-            add((abi.STAGE_COPIES, fin)); self.stage_pass.append("down")
+            self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in level
+                                         for v in tree.cliques[c].frontalIDs], "down")
+        self.segments.append(("run", self._seg_start, len(self.stages)))
 
     def alg_bytes_by_kernel(self):
         return dict(self.alg)
 
-    def B_cliques(self):
-        return set(self.cliques)
-
     @property
     def n_messages(self):
-        """one LikelihoodMessage per tree edge and direction (CliqueStateMachine.jl:590-593, 900-903)"""
-        return 2 * sum(1 for c in self.cliques if self.tree.cliques[c].parent >= 0)
+        """one LikelihoodMessage per tree edge and direction (CliqueStateMachine.jl:590-593, 900-903);
+        counted over the WHOLE tree (all ranks)"""
+        return 2 * sum(1 for c in self.tree.cliques.values() if c.parent >= 0)
 
     def stats(self):
         np_, nq = 0, 0

@@ -1,0 +1,56 @@
+"""Worker for tests/test_dist_gloo.py: one rank of a 2-process sharded tree solve on the CPU
+(gloo backend, oracle backend).  Writes the posteriors of the variables this rank owns."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import iif_amd_loader  # noqa: E402
+
+iif = iif_amd_loader.load()
+from iif_amd.dist_solver import ShardedRunner, partition_cliques  # noqa: E402
+from oracle.oracle_backend import OracleBackend  # noqa: E402
+
+
+def build():
+    fg = iif.generateChainEuclid(24, vardims=2, priorEvery=8, N=100)
+    for v in fg.ls():  # deterministic synthetic "initialised" beliefs (no initAll needed here)
+        i = int(v[1:])
+        rng = np.random.default_rng(i)
+        iif.setValKDE(fg, v, rng.normal(size=(100, 2)) * 0.3 + i, np.array([0.1, 0.1]))
+    return fg, iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fg, tree = build()
+    owner = partition_cliques(tree, world)
+    tp = iif.TreeProgram(fg, tree, seed=7, owner=owner, rank=rank)
+    be = OracleBackend(100, tp.n_slots, 0, threads=2)
+    for v in fg.ls():
+        var = fg.getVariable(v)
+        be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+    stride = iif.abi.slot_stride(100)
+    arena_t = torch.from_numpy(be.arena)
+    runner = ShardedRunner(tp, be, dist, lambda s: arena_t[s * stride:(s + 1) * stride])
+    runner.run()
+    res = {}
+    for c in tp.cliques:
+        for v in tree.cliques[c].frontalIDs:
+            pts, bw = be.slot_read(tp.main[v], fg.getVariable(v).varType.manifold)
+            res[v] = pts
+            res[v + "_bw"] = bw
+    nx = sum(1 for s in tp.segments if s[0] == "xchg")
+    np.savez(out, n_exchanges=nx, n_messages=tp.n_messages, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,3 +50,20 @@ def test_euclid2_chain_posteriors(hip_backend):
         assert np.abs(m - i).max() < 0.35, (i, m)
         assert fg.getVal(f"x{i}").std(axis=0).max() < 1.0
     assert tm["messages"] == 2 * (len(tree.cliques) - len(tree.roots))
+
+
+def test_torch_owned_arena_sharded_path_single_rank(hip_backend):
+    """the multi-GPU leg with world = 1: arena allocated by torch and handed to libnbp by pointer
+    (what RCCL needs), TreeProgram with an owner map, ShardedRunner segments"""
+    import torch
+    from iif_amd.dist_solver import ShardedTreeSolve
+
+    s = ShardedTreeSolve(iif, 60, 100, rank=0, world=1, local=0, dist=None)
+    s.prepare()
+    s.step(0)
+    s.be.synchronize()
+    s.check_posteriors()
+    assert s.posterior_max_mean_err < 1.0
+    assert s.global_messages == 2 * (len(s.tree.cliques) - len(s.tree.roots))
+    assert s.arena.data_ptr() == s.be.arena_ptr()
+    torch.cuda.synchronize()
