@@ -112,27 +112,33 @@ __device__ __forceinline__ double wrap_pi(double a) {
   return r - NBP_PI;
 }
 
-// exp(x) for x <= ~0 in the O(N^2) kernel sums: Cody-Waite reduction + degree-12 polynomial,
-// <= 2 ulp, no special-case handling (arguments are -d^2/(2h^2) or log-weights minus their max).
-__device__ __forceinline__ double exp_nonpos(double x) {
-  if (x < -708.0) return 0.0;
-  const double k = rint(x * 1.4426950408889634074);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 2.08767569878680989792e-09;  // 1/12!
-  p = fma(p, r, 2.50521083854417187751e-08);
-  p = fma(p, r, 2.75573192239858906526e-07);
-  p = fma(p, r, 2.75573192239858906526e-06);
-  p = fma(p, r, 2.48015873015873015873e-05);
-  p = fma(p, r, 1.98412698412698412698e-04);
-  p = fma(p, r, 1.38888888888888888889e-03);
+// exp(x) for x <= ~0 in the O(N^2) kernel sums (arguments are -d^2/(2h^2) or weights relative to
+// their max).  Table-driven: x = (32k + j) ln2/32 + r, |r| <= ln2/64, exp(x) = 2^k * 2^(j/32) * p(r)
+// with a degree-6 polynomial; the integer n = 32k + j is taken from the low mantissa bits after
+// adding 1.5*2^52 and 2^k is applied by an integer add on the exponent field, so every operation is
+// a full-rate FP64/INT32 VALU op (no v_rndne/v_cvt/v_ldexp quarter-rate ops).  <= 2 ulp.
+// `tab` = the 32-entry 2^(j/32) table staged in LDS (nbp_exp_tab_init).
+__constant__ double NBP_EXP2_TAB[32] = {1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332, 1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
+#define NBP_EXPTAB 32
+__device__ __forceinline__ void nbp_exp_tab_init(double *tab) {
+  if (threadIdx.x < 32) tab[threadIdx.x] = NBP_EXP2_TAB[threadIdx.x];
+}
+__device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
+  if (x < -700.0) return 0.0;
+  const double t = fma(x, 46.16624130844683, 6755399441055744.0);
+  const int n = __double2loint(t);
+  const double tf = t - 6755399441055744.0;
+  double r = fma(tf, -2.16608493865351192653e-02, x);
+  r = fma(tf, -5.96317165397058656257e-12, r);
+  double p = 1.38888888888888888889e-03;
   p = fma(p, r, 8.33333333333333333333e-03);
   p = fma(p, r, 4.16666666666666666667e-02);
   p = fma(p, r, 1.66666666666666666667e-01);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
+  const double y = tab[n & 31] * p;
+  return __hiloint2double(__double2hiint(y) + ((n >> 5) << 20), __double2loint(y));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -519,7 +525,8 @@ __device__ __forceinline__ void solve_particle(int kind, int manifold, const dou
 // accumulator acc[wave][j] in LDS (one private accumulator row per wave: lanes of a wave hit
 // consecutive j -> conflict-free; a wave's LDS ops execute in order -> deterministic sums).
 template <bool CIRC>
-__device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, int t0, int t1, double xi, double c, double *accw) {
+__device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, int t0, int t1, double xi, double c, double *accw,
+                                                const double *tab) {
   double s0 = 0, s1 = 0;
   int t = t0;
   for (; t + 1 < t1; t += 2) {
@@ -528,7 +535,7 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, i
     j1 -= (j1 >= N) ? N : 0;
     double d0 = xi - x[j0], d1 = xi - x[j1];
     if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); }
-    const double e0 = exp_nonpos(-d0 * d0 * c), e1 = exp_nonpos(-d1 * d1 * c);
+    const double e0 = exp_nonpos(-d0 * d0 * c, tab), e1 = exp_nonpos(-d1 * d1 * c, tab);
     s0 += e0;
     s1 += e1;
     accw[j0] += e0;
@@ -539,7 +546,7 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, i
     j0 -= (j0 >= N) ? N : 0;
     double d0 = xi - x[j0];
     if (CIRC) d0 = wrap_pi(d0);
-    const double e0 = exp_nonpos(-d0 * d0 * c);
+    const double e0 = exp_nonpos(-d0 * d0 * c, tab);
     s0 += e0;
     accw[j0] += e0;
   }
@@ -547,7 +554,8 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, i
 }
 
 // LDS: part[P][Npad] row-sum partials, acc[NW][N] per-wave partner accumulators
-__device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red) {
+__device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red,
+                                             const double *tab) {
   const double inv2h2 = 1.0 / (2.0 * h * h);
   const double lognorm = log(h) + 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
@@ -560,12 +568,12 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
     const double xi = x[i];
     double *accw = acc + w * N;
-    double s = circ ? loo_symmetric<true>(x, N, i, t0, t1, xi, inv2h2, accw) : loo_symmetric<false>(x, N, i, t0, t1, xi, inv2h2, accw);
+    double s = circ ? loo_symmetric<true>(x, N, i, t0, t1, xi, inv2h2, accw, tab) : loo_symmetric<false>(x, N, i, t0, t1, xi, inv2h2, accw, tab);
     if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair
       const int j = i + N / 2;
       double d = xi - x[j];
       if (circ) d = wrap_pi(d);
-      const double e = exp_nonpos(-d * d * inv2h2);
+      const double e = exp_nonpos(-d * d * inv2h2, tab);
       s += e;
       accw[j] += e;
     }
@@ -583,7 +591,8 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   return -block_sum(term, red) / (double)N;
 }
 
-__device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red) {
+__device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red,
+                                                   const double *tab) {
   const int i = threadIdx.x;
   double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
   if (i < N) {
@@ -606,10 +615,10 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   double x0 = ax, x3 = cx, x1, x2;
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
   else { x2 = bx; x1 = bx - C * (bx - ax); }
-  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red);
+  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red, tab);
   while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
-    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red); }
-    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red); }
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red, tab); }
+    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red, tab); }
   }
   return (f1 < f2 ? x1 : x2) * sc;
 }

@@ -228,10 +228,11 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
     return;
   }
   const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + N, *red = part + P * Npad + (blockDim.x >> 6) * N;
+  double *X = smem, *part = smem + N, *red = part + P * Npad + (blockDim.x >> 6) * N, *tab = red + NBP_RED;
+  nbp_exp_tab_init(tab);
   if (n < N) X[n] = s[k * N + n];
   __syncthreads();
-  double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red);
+  double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red, tab);
   if (n == 0) s[3 * N + k] = h;
 }
 
@@ -255,7 +256,7 @@ nbp_product_bandwidth_kernel(const nbp_product_desc *descs, double *arena, int N
 }
 // X[3][N] | part[P][Npad] | acc[NW][N] | red     (NW = P*Npad/64 waves)
 static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
-  return ((size_t)3 * N + (size_t)P * Npad + (size_t)(P * Npad / 64) * N + NBP_RED) * 8;
+  return ((size_t)3 * N + (size_t)P * Npad + (size_t)(P * Npad / 64) * N + NBP_RED + NBP_EXPTAB) * 8;
 }
 
 // ================================================================================================
@@ -265,14 +266,15 @@ __global__ void __launch_bounds__(1024)
 nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S) {
   extern __shared__ double smem[];
   const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + 3 * N, *red = part + P * Npad + (blockDim.x >> 6) * N;
+  double *X = smem, *part = smem + 3 * N, *red = part + P * Npad + (blockDim.x >> 6) * N, *tab = red + NBP_RED;
   double *s = arena + S * slots[blockIdx.x];
   const int M = manifolds[blockIdx.x], D = mani_dim(M), n = threadIdx.x;
+  nbp_exp_tab_init(tab);
   if (n < N)
     for (int k = 0; k < 3; k++) X[k * N + n] = s[k * N + n];
   __syncthreads();
   for (int k = 0; k < D; k++) {
-    double h = lcv_bandwidth_1d(X + k * N, N, Npad, is_circ(M, k), part, red);
+    double h = lcv_bandwidth_1d(X + k * N, N, Npad, is_circ(M, k), part, red, tab);
     if (n == 0) s[3 * N + k] = h;
   }
 }
@@ -325,7 +327,7 @@ __device__ long long nbp_phase_clk[64];
 #endif
 
 struct product_lds {
-  double *xs, *lm, *lv, *cen, *h2, *red, *gm, *gt, *ext, *nw;
+  double *xs, *lm, *lv, *cen, *h2, *red, *gm, *gt, *ext, *nw, *tab;
   int *idx, *ind, *tmpA, *tmpB, *prk, *bdim;
 };
 
@@ -337,13 +339,14 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Np
   size_t gm = dbl((size_t)P * Npad), gt = dbl((size_t)P * Npad);  // gt doubles as LCV `part`
   size_t ext = dbl((size_t)3 * Npad);
   size_t nw = dbl((size_t)Npad);  // node weights (hi-lo)/N of the current level
+  size_t tab = dbl(NBP_EXPTAB);
   size_t ints0 = o;  // int region starts here (8-byte aligned)
   size_t io = 0;
   auto i32 = [&](size_t n) { size_t r = io; io += n; return r; };
   size_t idx = i32((size_t)F * N), ind = i32((size_t)F * Npad), tA = i32(N), tB = i32(N), prk = i32((size_t)P * Npad), bd = i32(Npad);
   if (L) {
     L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2; L->red = base + red;
-    L->gm = base + gm; L->gt = base + gt; L->ext = base + ext; L->nw = base + nw;
+    L->gm = base + gm; L->gt = base + gt; L->ext = base + ext; L->nw = base + nw; L->tab = base + tab;
     int *ib = (int *)(base + ints0);
     L->idx = ib + idx; L->ind = ib + ind; L->tmpA = ib + tA; L->tmpB = ib + tB; L->prk = ib + prk; L->bdim = ib + bd;
   }
@@ -363,6 +366,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   int *idx = L.idx, *ind = L.ind;
   double *out = arena + S * d->out_slot;
 
+  nbp_exp_tab_init(L.tab);
   NBP_TICK_INIT();
   // ---- KD-tree permutation per density (median split of the widest coordinate) ----------------
   for (int j = 0; j < F; j++) {
@@ -546,12 +550,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               double a, g;
               node_w(z, a, g);
               if (a > m) {
-                const double f = exp_nonpos(m - a);  // m == -inf -> 0
+                const double f = exp_nonpos(m - a, L.tab);  // m == -inf -> 0
                 tot *= f;
                 cur *= f;
                 m = a;
               }
-              const double w = exp_nonpos(a - m) * g;
+              const double w = exp_nonpos(a - m, L.tab) * g;
               tot += w;
               cur += w;
             }
@@ -575,7 +579,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           for (int q = 0; q < 4; q++) {
             if (q < P) {
               const double tq = L.gt[q * Npad + s];
-              const double sc = (tq > 0) ? tq * exp_nonpos(L.gm[q * Npad + s] - Mx) : 0.0;
+              const double sc = (tq > 0) ? tq * exp_nonpos(L.gm[q * Npad + s] - Mx, L.tab) : 0.0;
               if (q == sub) before = total;
               total += sc;
               if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
@@ -593,7 +597,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             bool found = false;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-              const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx) : 0.0;
+              const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
               const int ca = z0 + c * csz, cb = min(z1, ca + csz);
               if (!found && ca < cb) {
                 za = ca; zb = cb;  // remember the last non-empty chunk as the fallback
@@ -607,7 +611,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               for (int z = za; z < zb; z++) {
                 double a, g;
                 node_w(z, a, g);
-                c += exp_nonpos(a - Mx) * g;
+                c += exp_nonpos(a - Mx, L.tab) * g;
                 if (target < c) { choice = z; break; }
               }
             }
