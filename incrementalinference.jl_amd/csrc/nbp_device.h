@@ -553,7 +553,9 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, i
   return s0 + s1;
 }
 
-// LDS: part[P][Npad] row-sum partials, acc[NW][N] per-wave partner accumulators
+// LDS: part[P][Npad] row-sum partials, acc[NW][N] per-wave partner accumulators.
+// `acc` must be all-zero on entry and is all-zero again on exit (the combine step clears what it
+// reads), so one evaluation costs three barriers: compute | combine+log | cross-wave sum.
 __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red,
                                              const double *tab) {
   const double inv2h2 = 1.0 / (2.0 * h * h);
@@ -561,8 +563,6 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
   const int w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   double *acc = part + P * Npad;
-  for (int q = threadIdx.x; q < NW * N; q += blockDim.x) acc[q] = 0.0;
-  __syncthreads();
   if (i < N) {
     const int H = (N - 1) / 2;  // full partner steps
     const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
@@ -580,15 +580,30 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     part[p * Npad + i] = s;
   }
   __syncthreads();
+  // combine: helper p folds the accumulator rows p, p+P, ... of point i (and clears them)
+  if (i < N) {
+    double s = part[p * Npad + i];
+    for (int q = p; q < NW; q += P) {
+      s += acc[q * N + i];
+      acc[q * N + i] = 0.0;
+    }
+    part[p * Npad + i] = s;
+  }
+  __syncthreads();
   double term = 0;
   if (p == 0 && i < N) {
     double s = part[i];
     for (int q = 1; q < P; q++) s += part[q * Npad + i];
-    for (int q = 0; q < NW; q++) s += acc[q * N + i];
     if (s < 1e-300) s = 1e-300;
     term = log(s) - lognorm;
   }
-  return -block_sum(term, red) / (double)N;
+  // only the first Npad lanes hold terms: reduce their waves
+  term = wave_sum(term);
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < Npad) red[threadIdx.x >> 6] = term;
+  __syncthreads();
+  double tsum = red[0];
+  for (int q = 1; q < (Npad >> 6); q++) tsum += red[q];
+  return -tsum / (double)N;
 }
 
 __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red,
@@ -602,6 +617,10 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
       if (circ) d = wrap_pi(d);
       mn = fabs(d);
     }
+  }
+  {  // per-wave partner accumulators start at zero (neg_loo_ll keeps them zero between calls)
+    double *acc = part + (blockDim.x / Npad) * Npad;
+    for (int q = threadIdx.x; q < (int)(blockDim.x >> 6) * N; q += blockDim.x) acc[q] = 0.0;
   }
   double minm = block_min(mn, red);
   lo = block_min(lo, red);
