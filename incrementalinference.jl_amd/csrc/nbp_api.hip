@@ -163,8 +163,6 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)nbp_proposal_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   *out = c;
@@ -337,14 +335,7 @@ static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int
   hipLaunchKernelGGL(nbp_proposal_kernel, dim3(n), dim3(c->Npad), nbp_proposal_lds_bytes(c->N), c->stream, dev, c->arena,
                      c->N, c->Npad, c->S, c->side, c->counters);
   HIPCHK(hipGetLastError());
-  rc = toc(c, c->ev[0]);
-  if (rc) return rc;
-  rc = tic(c, c->ev[1]);
-  if (rc) return rc;
-  hipLaunchKernelGGL(nbp_proposal_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P),
-                     c->stream, dev, c->arena, c->N, c->Npad, c->S);
-  HIPCHK(hipGetLastError());
-  return toc(c, c->ev[1]);
+  return toc(c, c->ev[0]);
 }
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, size_t lds) {
   if (n <= 0) return NBP_OK;
@@ -354,15 +345,30 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   hipLaunchKernelGGL(nbp_product_kernel, dim3(n), dim3(c->threads), lds, c->stream, dev, c->arena, c->N, c->Npad,
                      c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
-  rc = toc(c, c->ev[2]);
-  if (rc) return rc;
-  rc = tic(c, c->ev[3]);
-  if (rc) return rc;
-  hipLaunchKernelGGL(nbp_product_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P),
-                     c->stream, dev, c->arena, c->N, c->Npad, c->S);
-  HIPCHK(hipGetLastError());
-  return toc(c, c->ev[3]);
+  return toc(c, c->ev[2]);
 }
+// manikde! bandwidth fits: grid (njobs, 3), one workgroup per (slot, coordinate)
+static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const int32_t *dev_manis, int n) {
+  if (n <= 0) return NBP_OK;
+  nbp_status rc = tic(c, c->ev[1]);
+  if (rc) return rc;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P), c->stream,
+                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev[1]);
+}
+
+// bandwidth jobs of a batch of proposals / products (host side)
+static void jobs_of_proposals(const nbp_proposal_desc *d, int n, std::vector<int32_t> &slots, std::vector<int32_t> &manis) {
+  for (int i = 0; i < n; i++)
+    if (!d[i].skip_bandwidth) { slots.push_back(d[i].out_slot); manis.push_back(d[i].manifold); }
+}
+static void jobs_of_products(const nbp_product_desc *d, int n, std::vector<int32_t> &slots, std::vector<int32_t> &manis) {
+  for (int i = 0; i < n; i++)
+    if (d[i].nfactors > 1) { slots.push_back(d[i].out_slot); manis.push_back(d[i].manifold); }  // pass-through keeps its bw
+}
+
 static size_t products_lds(nbp_ctx *c, const nbp_product_desc *d, int n) {
   size_t lds = 1024;
   for (int i = 0; i < n; i++)
@@ -392,15 +398,37 @@ static nbp_status stage_upload(nbp_ctx *c, const void *src, size_t bytes) {
   return NBP_OK;
 }
 
+// upload [descriptors | job slots | job manifolds] in one staging copy and return the device views
+static nbp_status stage_with_jobs(nbp_ctx *c, const void *descs, size_t desc_bytes, const std::vector<int32_t> &slots,
+                                  const std::vector<int32_t> &manis, const int32_t **dslots, const int32_t **dmanis) {
+  size_t off = (desc_bytes + 63) & ~(size_t)63;
+  std::vector<char> buf(off + (slots.size() + manis.size()) * 4 + 8);
+  memcpy(buf.data(), descs, desc_bytes);
+  if (!slots.empty()) {
+    memcpy(buf.data() + off, slots.data(), slots.size() * 4);
+    memcpy(buf.data() + off + slots.size() * 4, manis.data(), manis.size() * 4);
+  }
+  nbp_status rc = stage_upload(c, buf.data(), buf.size());
+  if (rc) return rc;
+  *dslots = (const int32_t *)((char *)c->stage + off);
+  *dmanis = *dslots + slots.size();
+  return NBP_OK;
+}
+
 nbp_status nbp_run_proposals(nbp_ctx *c, const nbp_proposal_desc *descs, int32_t n) {
   if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
   if (n <= 0) return NBP_OK;
   HIPCHK(hipSetDevice(c->device));
   nbp_status rc = check_proposals(c, descs, n);
   if (rc) return rc;
-  rc = stage_upload(c, descs, sizeof(nbp_proposal_desc) * (size_t)n);
+  std::vector<int32_t> js, jm;
+  jobs_of_proposals(descs, n, js, jm);
+  const int32_t *ds, *dm;
+  rc = stage_with_jobs(c, descs, sizeof(nbp_proposal_desc) * (size_t)n, js, jm, &ds, &dm);
   if (rc) return rc;
   rc = launch_proposals(c, (const nbp_proposal_desc *)c->stage, n);
+  if (rc) return rc;
+  rc = launch_bandwidth(c, ds, dm, (int)js.size());  // manikde!(M, pts), ApproxConv.jl:36-42
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
@@ -412,9 +440,14 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   HIPCHK(hipSetDevice(c->device));
   nbp_status rc = check_products(c, descs, n);
   if (rc) return rc;
-  rc = stage_upload(c, descs, sizeof(nbp_product_desc) * (size_t)n);
+  std::vector<int32_t> js, jm;
+  jobs_of_products(descs, n, js, jm);
+  const int32_t *ds, *dm;
+  rc = stage_with_jobs(c, descs, sizeof(nbp_product_desc) * (size_t)n, js, jm, &ds, &dm);
   if (rc) return rc;
   rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_lds(c, descs, n));
+  if (rc) return rc;
+  rc = launch_bandwidth(c, ds, dm, (int)js.size());  // rebandwidth of the product
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
@@ -447,18 +480,22 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
   nbp_status rc = stage_upload(c, both.data(), both.size() * 4);
   if (rc) return rc;
   const int32_t *ds = (const int32_t *)c->stage;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n), dim3(c->threads),
-                     nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P), c->stream, ds, ds + n, c->arena, c->N, c->Npad, c->S);
-  HIPCHK(hipGetLastError());
+  rc = launch_bandwidth(c, ds, ds + n, n);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
 }
 
 // ---- resident programs ---------------------------------------------------------------------------------
 struct nbp_stage {
-  int kind, n;
-  size_t offset, lds;  // byte offset of the descriptors in the program blob
+  int kind = 0, n = 0;
+  size_t offset = 0, lds = 0;  // byte offset of the descriptors in the program blob
+  // bandwidth fits (slot, manifold) to run BEFORE / AFTER this stage's kernel.  The rebandwidth of a
+  // product stage is deferred and merged into the bandwidth launch of the NEXT proposal stage (the
+  // next proposals read points, not bandwidths), unless that stage holds a MsgPrior (reads bw) or a
+  // copy stage intervenes: one LCV launch per variable update instead of two on the critical path.
+  std::vector<int32_t> pre_slots, pre_manis, post_slots, post_manis;
+  size_t pre_off = 0, post_off = 0;
 };
 struct nbp_program {
   nbp_ctx *ctx = nullptr;
@@ -466,6 +503,7 @@ struct nbp_program {
   std::vector<char> blob;
   char *dev = nullptr;
   bool finalized = false;
+  int n_user_stages = 0;
 };
 
 nbp_status nbp_program_create(nbp_ctx *c, nbp_program **out) {
@@ -497,7 +535,9 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
   size_t off = (p->blob.size() + 63) & ~(size_t)63;
   p->blob.resize(off + esz * (size_t)n);
   if (n) memcpy(p->blob.data() + off, descs, esz * (size_t)n);
-  p->stages.push_back({kind, n, off, lds});
+  nbp_stage st;
+  st.kind = kind; st.n = n; st.offset = off; st.lds = lds;
+  p->stages.push_back(st);
   return NBP_OK;
 }
 
@@ -505,6 +545,53 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
   if (p->finalized) return NBP_OK;
   HIPCHK(hipSetDevice(p->ctx->device));
+  p->n_user_stages = (int)p->stages.size();
+  {  // schedule the bandwidth fits
+    std::vector<int32_t> pend_s, pend_m;
+    for (nbp_stage &st : p->stages) {
+      const char *d = p->blob.data() + st.offset;
+      if (st.kind == NBP_STAGE_PROPOSALS) {
+        // a MsgPrior samples from the KDE in var_slot[1] (points AND bandwidth): if that slot's
+        // rebandwidth is still pending it has to run before this stage
+        bool needs_bw = false;
+        for (int i = 0; i < st.n; i++) {
+          const nbp_proposal_desc &pd = ((const nbp_proposal_desc *)d)[i];
+          if (pd.factor_kind != NBP_F_MSGPRIOR) continue;
+          for (int32_t ps : pend_s) needs_bw |= (ps == pd.var_slot[1]);
+        }
+        if (needs_bw) { st.pre_slots.swap(pend_s); st.pre_manis.swap(pend_m); }
+        else { st.post_slots.swap(pend_s); st.post_manis.swap(pend_m); }
+        pend_s.clear(); pend_m.clear();
+        jobs_of_proposals((const nbp_proposal_desc *)d, st.n, st.post_slots, st.post_manis);
+      } else if (st.kind == NBP_STAGE_PRODUCTS) {
+        st.pre_slots.swap(pend_s); st.pre_manis.swap(pend_m);  // two product stages in a row: flush
+        pend_s.clear(); pend_m.clear();
+        jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
+      } else {
+        st.pre_slots.swap(pend_s); st.pre_manis.swap(pend_m);  // copies move bandwidths too
+        pend_s.clear(); pend_m.clear();
+      }
+    }
+    if (!pend_s.empty()) {  // trailing flush stage
+      nbp_stage fin;
+      fin.kind = NBP_STAGE_COPIES; fin.n = 0; fin.offset = 0;
+      fin.pre_slots.swap(pend_s); fin.pre_manis.swap(pend_m);
+      p->stages.push_back(fin);
+    }
+    for (nbp_stage &st : p->stages) {
+      auto put = [&](const std::vector<int32_t> &a, const std::vector<int32_t> &b) {
+        size_t off = (p->blob.size() + 63) & ~(size_t)63;
+        p->blob.resize(off + (a.size() + b.size()) * 4);
+        if (!a.empty()) {
+          memcpy(p->blob.data() + off, a.data(), a.size() * 4);
+          memcpy(p->blob.data() + off + a.size() * 4, b.data(), b.size() * 4);
+        }
+        return off;
+      };
+      st.pre_off = put(st.pre_slots, st.pre_manis);
+      st.post_off = put(st.post_slots, st.post_manis);
+    }
+  }
   size_t bytes = p->blob.size() ? p->blob.size() : 64;
   HIPCHK(hipMalloc(&p->dev, bytes));
   if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
@@ -517,15 +604,23 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
   nbp_ctx *c = p->ctx;
   HIPCHK(hipSetDevice(c->device));
-  const int ns = (int)p->stages.size();
-  if (last < 0 || last > ns) last = ns;
+  const int ns = (int)p->stages.size(), nuser = p->n_user_stages;
+  // a partial run [first, last) must still flush the bandwidth fits deferred by its last product
+  // stage: they live in the `pre` list of stage `last` (or of the trailing flush stage)
+  if (last < 0 || last >= nuser) last = ns;
   if (first < 0) first = 0;
-  for (int s = first; s < last; s++) {
+  for (int s = first; s <= last && s < ns; s++) {
     const nbp_stage &st = p->stages[s];
-    nbp_status rc = NBP_OK;
+    nbp_status rc = launch_bandwidth(c, (const int32_t *)(p->dev + st.pre_off), (const int32_t *)(p->dev + st.pre_off) + st.pre_slots.size(),
+                                     (int)st.pre_slots.size());
+    if (rc) return rc;
+    if (s == last) break;  // only the flush part of the stage after the range
     if (st.kind == NBP_STAGE_PROPOSALS) rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
     else if (st.kind == NBP_STAGE_PRODUCTS) rc = launch_products(c, (const nbp_product_desc *)(p->dev + st.offset), st.n, st.lds);
     else rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
+    if (rc) return rc;
+    rc = launch_bandwidth(c, (const int32_t *)(p->dev + st.post_off), (const int32_t *)(p->dev + st.post_off) + st.post_slots.size(),
+                          (int)st.post_slots.size());
     if (rc) return rc;
   }
   return NBP_OK;  // asynchronous: nbp_synchronize / nbp_slot_read wait for completion
@@ -550,7 +645,7 @@ nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
 
 nbp_status nbp_program_num_stages(nbp_program *p, int32_t *out) {
   if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
-  *out = (int32_t)p->stages.size();
+  *out = p->finalized ? p->n_user_stages : (int32_t)p->stages.size();
   return NBP_OK;
 }
 

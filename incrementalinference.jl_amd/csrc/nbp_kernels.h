@@ -236,47 +236,20 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   if (n == 0) s[3 * N + k] = h;
 }
 
-// manikde! bandwidth of the proposals just written by nbp_proposal_kernel
-__global__ void __launch_bounds__(1024)
-nbp_proposal_bandwidth_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S) {
-  extern __shared__ double smem[];
-  // grid (n, 3): one workgroup per (proposal, coordinate) -- the D fits are independent
-  const nbp_proposal_desc *d = descs + blockIdx.x;
-  if (d->skip_bandwidth) return;
-  lcv_slot_coordinate(arena + S * d->out_slot, d->manifold, blockIdx.y, N, Npad, smem);
-}
-
-// manikde! rebandwidth of the products just written by nbp_product_kernel
-__global__ void __launch_bounds__(1024)
-nbp_product_bandwidth_kernel(const nbp_product_desc *descs, double *arena, int N, int Npad, int64_t S) {
-  extern __shared__ double smem[];
-  const nbp_product_desc *d = descs + blockIdx.x;
-  if (d->nfactors == 1) return;  // pass-through keeps the proposal's bandwidth
-  lcv_slot_coordinate(arena + S * d->out_slot, d->manifold, blockIdx.y, N, Npad, smem);
-}
-// X[3][N] | part[P][Npad] | acc[NW][N] | red     (NW = P*Npad/64 waves)
-static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
-  return ((size_t)3 * N + (size_t)P * Npad + (size_t)(P * Npad / 64) * N + NBP_RED + NBP_EXPTAB) * 8;
-}
-
 // ================================================================================================
-// Bandwidth kernel: AMP.manikde!(M, pts) for a resident slot
+// Bandwidth kernel: AMP.manikde!(M, pts) -- grid (njobs, 3): one workgroup per (slot, coordinate);
+// the D per-coordinate fits of a KDE are independent.  Used for proposals (ApproxConv.jl:36-42),
+// for the rebandwidth of products and for nbp_run_bandwidth.
 // ================================================================================================
 __global__ void __launch_bounds__(1024)
 nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S) {
   extern __shared__ double smem[];
-  const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + 3 * N, *red = part + P * Npad + (blockDim.x >> 6) * N, *tab = red + NBP_RED;
-  double *s = arena + S * slots[blockIdx.x];
-  const int M = manifolds[blockIdx.x], D = mani_dim(M), n = threadIdx.x;
-  nbp_exp_tab_init(tab);
-  if (n < N)
-    for (int k = 0; k < 3; k++) X[k * N + n] = s[k * N + n];
-  __syncthreads();
-  for (int k = 0; k < D; k++) {
-    double h = lcv_bandwidth_1d(X + k * N, N, Npad, is_circ(M, k), part, red, tab);
-    if (n == 0) s[3 * N + k] = h;
-  }
+  lcv_slot_coordinate(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem);
+}
+
+// X[N] | part[P][Npad] | acc[NW][N] | red | exp table     (NW = P*Npad/64 waves)
+static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
+  return ((size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * N + NBP_RED + NBP_EXPTAB) * 8;
 }
 
 __global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S) {
@@ -506,9 +479,9 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             g = 1.0;
           } else {
             double pv, num;
-            if (D == 1) { pv = v[0]; num = t[0]; }
-            else if (D == 2) { pv = v[0] * v[1]; num = t[0] * v[1] + t[1] * v[0]; }
-            else { const double v01 = v[0] * v[1]; pv = v01 * v[D - 1]; num = t[0] * (v[1] * v[D - 1]) + t[1] * (v[0] * v[D - 1]) + t[D - 1] * v01; }
+            if constexpr (D == 1) { pv = v[0]; num = t[0]; }
+            else if constexpr (D == 2) { pv = v[0] * v[1]; num = t[0] * v[1] + t[1] * v[0]; }
+            else { const double v01 = v[0] * v[1]; pv = v01 * v[2]; num = t[0] * (v[1] * v[2]) + t[1] * (v[0] * v[2]) + t[2] * v01; }
             const double r = rsqrt(pv);
             a = -0.5 * num * (r * r);
             g = r * L.nw[z];

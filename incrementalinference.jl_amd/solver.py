@@ -371,8 +371,7 @@ class TreeProgram:
         self.n_updates_up = 0
         self.n_updates_down = 0
         self.alg_bytes = 0
-        self.alg = {"nbp_proposal_kernel": 0, "nbp_proposal_bandwidth_kernel": 0, "nbp_product_kernel": 0,
-                    "nbp_product_bandwidth_kernel": 0}
+        self.alg = {"nbp_proposal_kernel": 0, "nbp_bandwidth_kernel": 0, "nbp_product_kernel": 0}
         self._compile()
 
     # -- helpers ------------------------------------------------------------------------------
@@ -384,9 +383,8 @@ class TreeProgram:
         # kernel reads the F_in operand beliefs + the variable's own old belief; the product kernel
         # writes the new points; the bandwidth kernels write the (F_in + 1) bandwidth vectors.
         self.alg["nbp_proposal_kernel"] += (F_in + 1) * N * P * 8
-        self.alg["nbp_proposal_bandwidth_kernel"] += F_in * D * 8
+        self.alg["nbp_bandwidth_kernel"] += (F_in + 1) * D * 8
         self.alg["nbp_product_kernel"] += N * P * 8
-        self.alg["nbp_product_bandwidth_kernel"] += D * 8
 
     def _msg_slot(self, child, v):
         return self.B[(child, v)] if self.owner[child] == self.rank else self.ghost[(child, v)]
@@ -419,6 +417,8 @@ class TreeProgram:
         sends = [(dr, sk()) for (sr, sk, dr, dk) in edges if sr == self.rank and dr != self.rank]
         recvs = [(sr, dk()) for (sr, sk, dr, dk) in edges if dr == self.rank and sr != self.rank]
         if sends or recvs:
+            # an empty copy stage forces libnbp to flush the deferred bandwidth fits before slots travel
+            self._add(abi.STAGE_COPIES, [], "flush")
             self.segments.append(("run", self._seg_start, len(self.stages)))
             self.segments.append(("xchg", sends, recvs))
             self._seg_start = len(self.stages)
