@@ -178,8 +178,8 @@ nbp_status nbp_program_destroy(nbp_program *prog);
 
 /* per-kernel timing with HIP events on the library stream (bench.py roofline leg) */
 nbp_status nbp_timing_enable(nbp_ctx *ctx, int32_t on);
-/* ms[4] / launches[4]: 0 = nbp_proposal_kernel, 1 = nbp_bandwidth_kernel, 2 = nbp_product_kernel,
- *                      3 = reserved (0); accumulators are reset by the call */
+/* ms[4] / launches[4] per kernel: 0 = proposal kernel, 1 = prep kernel = bandwidth fits + KD-tree builds,
+ *                      2 = product kernel, 3 = plain bandwidth kernel = early flushes; reset by the call */
 nbp_status nbp_timing_read(nbp_ctx *ctx, double *ms, int64_t *launches);
 nbp_status nbp_diag_read(nbp_ctx *ctx, nbp_diag *out, int32_t reset);
 

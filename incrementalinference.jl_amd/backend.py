@@ -107,7 +107,7 @@ class HipBackend:
     def timing_enable(self, on=True):
         self._check(self.lib.nbp_timing_enable(self._ctx, int(on)))
 
-    KERNELS = ("nbp_proposal_kernel", "nbp_bandwidth_kernel", "nbp_product_kernel")
+    KERNELS = ("nbp_proposal_kernel", "nbp_prep_kernel", "nbp_product_kernel", "nbp_bandwidth_kernel")
 
     def timing_read(self):
         """{kernel: (total ms, launches)} measured with HIP events on the library stream"""

@@ -33,6 +33,8 @@ struct nbp_ctx {
   nbp_levels T{};
   int32_t *lv_ints = nullptr;
   double *lv_dbls = nullptr;
+  double *ws = nullptr;  // KD workspace: [products][NBP_MAXF] x nbp_kd_ws_doubles(N)
+  int ws_products = 0;
   // staging for immediate-mode calls
   void *stage = nullptr;
   size_t stage_bytes = 0;
@@ -164,6 +166,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   // allow the full 160 KiB LDS for the product kernel
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   *out = c;
   return NBP_OK;
@@ -181,6 +184,7 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   hipFree(c->lv_ints);
   hipFree(c->lv_dbls);
   if (c->stage) hipFree(c->stage);
+  if (c->ws) hipFree(c->ws);
   hipStreamDestroy(c->stream);
   delete c;
   return NBP_OK;
@@ -299,7 +303,7 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
     for (int k = 0; k < p.nfactors; k++)
       if (p.in_slot[k] < 0 || p.in_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "product: in_slot");
     if (p.labels_out >= 0 && p.labels_out + c->N * p.nfactors > c->side_ints) return fail(NBP_ERR_RANGE, "product: labels_out");
-    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->Npad, c->P);
+    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->Npad, c->threads, c->Npad);
     if (p.nfactors > 1 && lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: F*D*N exceeds the 160 KiB LDS");
   }
   return NBP_OK;
@@ -337,26 +341,62 @@ static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[0]);
 }
-static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, size_t lds) {
+static nbp_status ensure_ws(nbp_ctx *c, int nprod) {
+  if (nprod <= c->ws_products) return NBP_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->ws) HIPCHK(hipFree(c->ws));
+  c->ws_products = nprod + nprod / 4 + 16;
+  HIPCHK(hipMalloc(&c->ws, (size_t)c->ws_products * NBP_MAXF * nbp_kd_ws_doubles(c->N) * 8));
+  return NBP_OK;
+}
+
+// sample groups per product: spread a product over G workgroups when the launch cannot fill the chip
+static int product_groups(nbp_ctx *c, int n) {
+  int G = n >= 128 ? 1 : (n >= 48 ? 2 : 4);
+  while (G > 1 && ((c->Npad / 64) % G != 0)) G >>= 1;
+  return G;
+}
+
+// nbp_prep_kernel: pending bandwidth fits + KD builds of this product batch, one launch
+static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
+                              const nbp_product_desc *dev, int n) {
+  nbp_status rc = ensure_ws(c, n);
+  if (rc) return rc;
+  rc = tic(c, c->ev[1]);
+  if (rc) return rc;
+  size_t lds = nbp_kd_lds_bytes(3, c->N, c->Npad, c->P);
+  if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * NBP_MAXF), dim3(c->threads), lds, c->stream, bw_slots, bw_manis, nbw, dev,
+                     n, c->arena, c->ws, c->N, c->Npad, c->S, c->T);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev[1]);
+}
+
+static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD) {
   if (n <= 0) return NBP_OK;
+  const int G = product_groups(c, n), SPB = c->Npad / G;
+  // maxFD encodes the largest (F, D) of the batch as F*4 + D
+  const size_t lds = nbp_product_lds_bytes(maxFD / 4, maxFD % 4, c->N, c->Npad, c->threads, SPB);
   nbp_status rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_product_kernel, dim3(n), dim3(c->threads), lds, c->stream, dev, c->arena, c->N, c->Npad,
+  hipLaunchKernelGGL(nbp_product_kernel, dim3(n, G), dim3(c->threads), lds, c->stream, dev, c->arena, c->ws, c->N, c->Npad,
                      c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }
+
 // manikde! bandwidth fits: grid (njobs, 3), one workgroup per (slot, coordinate)
 static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const int32_t *dev_manis, int n) {
   if (n <= 0) return NBP_OK;
-  nbp_status rc = tic(c, c->ev[1]);
+  nbp_status rc = tic(c, c->ev[3]);
   if (rc) return rc;
   (void)hipGetLastError();
   hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P), c->stream,
                      dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S);
   HIPCHK(hipGetLastError());
-  return toc(c, c->ev[1]);
+  return toc(c, c->ev[3]);
 }
 
 // bandwidth jobs of a batch of proposals / products (host side)
@@ -369,14 +409,15 @@ static void jobs_of_products(const nbp_product_desc *d, int n, std::vector<int32
     if (d[i].nfactors > 1) { slots.push_back(d[i].out_slot); manis.push_back(d[i].manifold); }  // pass-through keeps its bw
 }
 
-static size_t products_lds(nbp_ctx *c, const nbp_product_desc *d, int n) {
-  size_t lds = 1024;
+// largest (F, D) of a product batch, encoded F*4 + D (sizes the LDS of the launch)
+static int products_maxfd(const nbp_product_desc *d, int n) {
+  int F = 2, D = 1;
   for (int i = 0; i < n; i++)
     if (d[i].nfactors > 1) {
-      size_t b = nbp_product_lds_bytes(d[i].nfactors, manifold_dim_h(d[i].manifold), c->N, c->Npad, c->P);
-      if (b > lds) lds = b;
+      if (d[i].nfactors > F) F = d[i].nfactors;
+      if (manifold_dim_h(d[i].manifold) > D) D = manifold_dim_h(d[i].manifold);
     }
-  return lds;
+  return F * 4 + D;
 }
 static nbp_status launch_copies(nbp_ctx *c, const nbp_copy_desc *dev, int n) {
   if (n <= 0) return NBP_OK;
@@ -445,7 +486,9 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   const int32_t *ds, *dm;
   rc = stage_with_jobs(c, descs, sizeof(nbp_product_desc) * (size_t)n, js, jm, &ds, &dm);
   if (rc) return rc;
-  rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_lds(c, descs, n));
+  rc = launch_prep(c, nullptr, nullptr, 0, (const nbp_product_desc *)c->stage, n);  // KD trees
+  if (rc) return rc;
+  rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n));
   if (rc) return rc;
   rc = launch_bandwidth(c, ds, dm, (int)js.size());  // rebandwidth of the product
   if (rc) return rc;
@@ -487,19 +530,23 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
 }
 
 // ---- resident programs ---------------------------------------------------------------------------------
+// Scheduling of the bandwidth fits (manikde!).  Fits are *deferred*: a proposal stage only queues
+// its fits; the next product stage runs them inside its nbp_prep_kernel launch, next to the KD-tree
+// builds (which need points, not bandwidths); the product's own rebandwidth is queued in turn and
+// rides with the prep launch of the NEXT update.  A queued fit is flushed early (plain
+// nbp_bandwidth_kernel launch) when a later stage reads the bandwidth of that slot: a MsgPrior
+// proposal sampling from it, or a copy stage moving whole slots.  Per update the critical path is
+// proposal -> prep (LCV || KD) -> product.
 struct nbp_stage {
-  int kind = 0, n = 0;
-  size_t offset = 0, lds = 0;  // byte offset of the descriptors in the program blob
-  // bandwidth fits (slot, manifold) to run BEFORE / AFTER this stage's kernel.  The rebandwidth of a
-  // product stage is deferred and merged into the bandwidth launch of the NEXT proposal stage (the
-  // next proposals read points, not bandwidths), unless that stage holds a MsgPrior (reads bw) or a
-  // copy stage intervenes: one LCV launch per variable update instead of two on the critical path.
-  std::vector<int32_t> pre_slots, pre_manis, post_slots, post_manis;
-  size_t pre_off = 0, post_off = 0;
+  int kind = 0, n = 0, maxfd = 0;
+  size_t offset = 0;            // byte offset of the descriptors in the program blob
+  std::vector<int32_t> ent_s, ent_m;  // fits pending at ENTRY of the stage
+  size_t ent_off = 0;
+  bool flush_before = false;    // run the pending fits in a plain bandwidth launch before the stage
 };
 struct nbp_program {
   nbp_ctx *ctx = nullptr;
-  std::vector<nbp_stage> stages;
+  std::vector<nbp_stage> stages;  // + one trailing pseudo stage holding the fits pending at exit
   std::vector<char> blob;
   char *dev = nullptr;
   bool finalized = false;
@@ -520,13 +567,13 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
   if (n < 0) return fail(NBP_ERR_ARG, "n < 0");
   size_t esz;
   nbp_status rc = NBP_OK;
-  size_t lds = 0;
+  nbp_stage st;
   switch (kind) {
   case NBP_STAGE_PROPOSALS: esz = sizeof(nbp_proposal_desc); rc = check_proposals(p->ctx, (const nbp_proposal_desc *)descs, n); break;
   case NBP_STAGE_PRODUCTS:
     esz = sizeof(nbp_product_desc);
     rc = check_products(p->ctx, (const nbp_product_desc *)descs, n);
-    lds = products_lds(p->ctx, (const nbp_product_desc *)descs, n);
+    st.maxfd = products_maxfd((const nbp_product_desc *)descs, n);
     break;
   case NBP_STAGE_COPIES: esz = sizeof(nbp_copy_desc); rc = check_copies(p->ctx, (const nbp_copy_desc *)descs, n); break;
   default: return fail(NBP_ERR_ARG, "unknown stage kind");
@@ -535,8 +582,7 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
   size_t off = (p->blob.size() + 63) & ~(size_t)63;
   p->blob.resize(off + esz * (size_t)n);
   if (n) memcpy(p->blob.data() + off, descs, esz * (size_t)n);
-  nbp_stage st;
-  st.kind = kind; st.n = n; st.offset = off; st.lds = lds;
+  st.kind = kind; st.n = n; st.offset = off;
   p->stages.push_back(st);
   return NBP_OK;
 }
@@ -546,52 +592,43 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   if (p->finalized) return NBP_OK;
   HIPCHK(hipSetDevice(p->ctx->device));
   p->n_user_stages = (int)p->stages.size();
-  {  // schedule the bandwidth fits
-    std::vector<int32_t> pend_s, pend_m;
-    for (nbp_stage &st : p->stages) {
-      const char *d = p->blob.data() + st.offset;
-      if (st.kind == NBP_STAGE_PROPOSALS) {
-        // a MsgPrior samples from the KDE in var_slot[1] (points AND bandwidth): if that slot's
-        // rebandwidth is still pending it has to run before this stage
-        bool needs_bw = false;
-        for (int i = 0; i < st.n; i++) {
-          const nbp_proposal_desc &pd = ((const nbp_proposal_desc *)d)[i];
-          if (pd.factor_kind != NBP_F_MSGPRIOR) continue;
-          for (int32_t ps : pend_s) needs_bw |= (ps == pd.var_slot[1]);
-        }
-        if (needs_bw) { st.pre_slots.swap(pend_s); st.pre_manis.swap(pend_m); }
-        else { st.post_slots.swap(pend_s); st.post_manis.swap(pend_m); }
-        pend_s.clear(); pend_m.clear();
-        jobs_of_proposals((const nbp_proposal_desc *)d, st.n, st.post_slots, st.post_manis);
-      } else if (st.kind == NBP_STAGE_PRODUCTS) {
-        st.pre_slots.swap(pend_s); st.pre_manis.swap(pend_m);  // two product stages in a row: flush
-        pend_s.clear(); pend_m.clear();
-        jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
-      } else {
-        st.pre_slots.swap(pend_s); st.pre_manis.swap(pend_m);  // copies move bandwidths too
-        pend_s.clear(); pend_m.clear();
+  p->stages.emplace_back();  // trailing pseudo stage: fits pending at exit
+  p->stages.back().kind = 0;
+  std::vector<int32_t> pend_s, pend_m;
+  int maxprod = 0;
+  for (nbp_stage &st : p->stages) {
+    const char *d = p->blob.data() + st.offset;
+    st.ent_s = pend_s;
+    st.ent_m = pend_m;
+    if (st.kind == NBP_STAGE_PROPOSALS) {
+      // a MsgPrior samples from the KDE in var_slot[1] (points AND bandwidth)
+      for (int i = 0; i < st.n && !st.flush_before; i++) {
+        const nbp_proposal_desc &pd = ((const nbp_proposal_desc *)d)[i];
+        if (pd.factor_kind != NBP_F_MSGPRIOR) continue;
+        for (int32_t ps : pend_s) st.flush_before |= (ps == pd.var_slot[1]);
       }
-    }
-    if (!pend_s.empty()) {  // trailing flush stage
-      nbp_stage fin;
-      fin.kind = NBP_STAGE_COPIES; fin.n = 0; fin.offset = 0;
-      fin.pre_slots.swap(pend_s); fin.pre_manis.swap(pend_m);
-      p->stages.push_back(fin);
-    }
-    for (nbp_stage &st : p->stages) {
-      auto put = [&](const std::vector<int32_t> &a, const std::vector<int32_t> &b) {
-        size_t off = (p->blob.size() + 63) & ~(size_t)63;
-        p->blob.resize(off + (a.size() + b.size()) * 4);
-        if (!a.empty()) {
-          memcpy(p->blob.data() + off, a.data(), a.size() * 4);
-          memcpy(p->blob.data() + off + a.size() * 4, b.data(), b.size() * 4);
-        }
-        return off;
-      };
-      st.pre_off = put(st.pre_slots, st.pre_manis);
-      st.post_off = put(st.post_slots, st.post_manis);
+      if (st.flush_before) { pend_s.clear(); pend_m.clear(); }
+      jobs_of_proposals((const nbp_proposal_desc *)d, st.n, pend_s, pend_m);
+    } else if (st.kind == NBP_STAGE_PRODUCTS) {
+      pend_s.clear(); pend_m.clear();  // the entry fits run inside this stage's prep launch
+      jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
+      if (st.n > maxprod) maxprod = st.n;
+    } else {  // copies (move bandwidths too) and the trailing pseudo stage
+      st.flush_before = true;
+      pend_s.clear(); pend_m.clear();
     }
   }
+  for (nbp_stage &st : p->stages) {
+    size_t off = (p->blob.size() + 63) & ~(size_t)63;
+    p->blob.resize(off + (st.ent_s.size() + st.ent_m.size()) * 4);
+    if (!st.ent_s.empty()) {
+      memcpy(p->blob.data() + off, st.ent_s.data(), st.ent_s.size() * 4);
+      memcpy(p->blob.data() + off + st.ent_s.size() * 4, st.ent_m.data(), st.ent_m.size() * 4);
+    }
+    st.ent_off = off;
+  }
+  nbp_status rc = ensure_ws(p->ctx, maxprod);
+  if (rc) return rc;
   size_t bytes = p->blob.size() ? p->blob.size() : 64;
   HIPCHK(hipMalloc(&p->dev, bytes));
   if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
@@ -604,26 +641,31 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
   nbp_ctx *c = p->ctx;
   HIPCHK(hipSetDevice(c->device));
-  const int ns = (int)p->stages.size(), nuser = p->n_user_stages;
-  // a partial run [first, last) must still flush the bandwidth fits deferred by its last product
-  // stage: they live in the `pre` list of stage `last` (or of the trailing flush stage)
-  if (last < 0 || last >= nuser) last = ns;
+  const int nuser = p->n_user_stages;
+  if (last < 0 || last > nuser) last = nuser;
   if (first < 0) first = 0;
-  for (int s = first; s <= last && s < ns; s++) {
+  auto ent_s = [&](const nbp_stage &st) { return (const int32_t *)(p->dev + st.ent_off); };
+  for (int s = first; s < last; s++) {
     const nbp_stage &st = p->stages[s];
-    nbp_status rc = launch_bandwidth(c, (const int32_t *)(p->dev + st.pre_off), (const int32_t *)(p->dev + st.pre_off) + st.pre_slots.size(),
-                                     (int)st.pre_slots.size());
+    const int nent = (int)st.ent_s.size();
+    nbp_status rc = NBP_OK;
+    if (st.flush_before) rc = launch_bandwidth(c, ent_s(st), ent_s(st) + nent, nent);
     if (rc) return rc;
-    if (s == last) break;  // only the flush part of the stage after the range
-    if (st.kind == NBP_STAGE_PROPOSALS) rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
-    else if (st.kind == NBP_STAGE_PRODUCTS) rc = launch_products(c, (const nbp_product_desc *)(p->dev + st.offset), st.n, st.lds);
-    else rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
-    if (rc) return rc;
-    rc = launch_bandwidth(c, (const int32_t *)(p->dev + st.post_off), (const int32_t *)(p->dev + st.post_off) + st.post_slots.size(),
-                          (int)st.post_slots.size());
+    if (st.kind == NBP_STAGE_PROPOSALS) {
+      rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
+    } else if (st.kind == NBP_STAGE_PRODUCTS) {
+      const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
+      rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n);
+      if (!rc) rc = launch_products(c, dd, st.n, st.maxfd);
+    } else {
+      rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
+    }
     if (rc) return rc;
   }
-  return NBP_OK;  // asynchronous: nbp_synchronize / nbp_slot_read wait for completion
+  // leave every slot consistent: run whatever is still pending at the end of the range
+  const nbp_stage &nx = p->stages[last];
+  return launch_bandwidth(c, ent_s(nx), ent_s(nx) + nx.ent_s.size(), (int)nx.ent_s.size());
+  // asynchronous: nbp_synchronize / nbp_slot_read wait for completion
 }
 
 nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {

@@ -275,8 +275,8 @@ __global__ void nbp_reseed_products(nbp_product_desc *d, int n, uint64_t salt) {
 }
 
 // ================================================================================================
-// Product kernel: one workgroup = one AMP.manifoldProduct(dens, M; Niter, N) + rebandwidth +
-// setBelief!  (GraphProductOperations.jl:53-60, SolveTree.jl:74).
+// AMP.manifoldProduct(dens, M; Niter, N) + setBelief!  (GraphProductOperations.jl:53-60,
+// SolveTree.jl:74), split over two kernels.
 //
 // Algorithm (Ihler et al. NIPS 2003, `prodAppxMSGibbsS`): every input KDE gets a balanced KD-tree
 // whose nodes carry the moment-matched Gaussian of their leaves; all N output samples walk the
@@ -284,146 +284,190 @@ __global__ void nbp_reseed_products(nbp_product_desc *d, int n, uint64_t salt) {
 // re-drawing its label in density j from p(l_j | others) over ALL nodes of that level (inverse
 // CDF); at the leaves the sample is drawn from the product of the F selected kernels.
 //
-// Mapping: lanes (s, 0..P-1) = output sample s.  The node loop of a draw is split into P contiguous
-// node ranges: pass 1 gives every helper its (max, total) -> combined through LDS; only the helper
-// whose range contains u*total walks its range again (pass 2).  Node statistics of the *current*
-// level for all densities live in LDS and are read with wave-uniform addresses (broadcast).
-// The KD permutation is built by rank counting inside each segment, also split P ways.
+// nbp_prep_kernel   (heterogeneous grid): workgroup b < 3*nbw fits the bandwidth of one (slot,
+//                   coordinate); the others build the KD permutation of one (product, density) and
+//                   leave the sorted, centred coordinates in an HBM workspace.  The tree build does
+//                   not need bandwidths, so it runs beside the LCV fits of the same update instead
+//                   of behind them.
+// nbp_product_kernel: grid (nprod, G): workgroup (p, g) draws the output samples [g*SPB, (g+1)*SPB)
+//                   of product p, SPB = Npad/G, with P' = 1024/SPB helper lanes per sample.  G > 1 is
+//                   chosen by the host when a launch has fewer products than CUs (latency-bound
+//                   tree tops); results do not depend on G (RNG is keyed by the sample index).
 // ================================================================================================
 #ifdef NBP_PHASE_TIMING
 __device__ long long nbp_phase_clk[64];
-#define NBP_TICK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)wall_clock64() - t_last_; t_last_ = wall_clock64(); } while (0)
+#define NBP_TICK(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)wall_clock64() - t_last_; t_last_ = wall_clock64(); } while (0)
 #define NBP_TICK_INIT() long long t_last_ = wall_clock64()
 #else
 #define NBP_TICK(k)
 #define NBP_TICK_INIT()
 #endif
 
+// HBM workspace of one (product, density): xs[3][N] | cen[4] | idx[N] (int32)
+__host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return (size_t)3 * N + 4 + (size_t)(N + 1) / 2; }
+
+// KD-tree permutation of one density: median split of the widest coordinate, by rank counting
+// inside each segment (P helper lanes per position, no sort network).
+template <int D>
+__device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, int Npad, const nbp_levels &T, double *smem) {
+  const int tid = threadIdx.x, TB = blockDim.x, P = TB / Npad, s = tid % Npad, sub = tid / Npad;
+  double *raw = smem;                   // [D][N]
+  double *ext = raw + (size_t)D * N;    // [3*Npad]
+  double *red = ext + 3 * Npad;         // [NBP_RED]
+  int *tmpA = (int *)(red + NBP_RED);   // [N]
+  int *tmpB = tmpA + N;                 // [N]
+  int *prk = tmpB + N;                  // [P*Npad]
+  int *bdim = prk + P * Npad;           // [Npad]
+  if (tid < N) {
+#pragma unroll
+    for (int k = 0; k < D; k++) raw[k * N + tid] = x[k * N + tid];
+    tmpA[tid] = tid;
+  }
+  __syncthreads();
+  int *pa = tmpA, *pb = tmpB;
+  for (int l = 0; l < T.L; l++) {
+    const int cnt = T.cnt[l], off = T.off[l];
+    if (D > 1) {
+      // extent of every segment in every coordinate: item = (node, coordinate, quarter), then argmax
+      for (int item = tid; item < cnt * D; item += TB) {
+        const int z = item / D, k = item % D;
+        const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
+        double mn = INFINITY, mx = -INFINITY;
+        for (int p = lo; p < hi; p++) {
+          const double v = raw[k * N + pa[p]];
+          mn = fmin(mn, v);
+          mx = fmax(mx, v);
+        }
+        ext[item] = mx - mn;
+      }
+      __syncthreads();
+      for (int z = tid; z < cnt; z += TB) {
+        int best = 0;
+        double bext = -1.0;
+#pragma unroll
+        for (int k = 0; k < D; k++)
+          if (ext[z * D + k] > bext) { bext = ext[z * D + k]; best = k; }
+        bdim[z] = best;
+      }
+      __syncthreads();
+    }
+    int lo = 0, hi = 0, me = 0;
+    if (s < N) {
+      const int node = T.pos_node[l * N + s];
+      lo = T.node_lo[off + node];
+      hi = T.node_hi[off + node];
+      me = pa[s];
+      int rank = 0;
+      if (hi - lo > 1) {
+        const int best = (D > 1) ? bdim[node] : 0;
+        const double v = raw[best * N + me];
+        const int len = hi - lo, a = lo + (sub * len) / P, b = lo + ((sub + 1) * len) / P;
+        for (int p = a; p < b; p++) {
+          const int ip = pa[p];
+          const double vp = raw[best * N + ip];
+          rank += (vp < v || (vp == v && ip < me)) ? 1 : 0;
+        }
+      }
+      prk[sub * Npad + s] = rank;
+    }
+    __syncthreads();
+    if (sub == 0 && s < N) {
+      int rank = 0;
+      for (int q = 0; q < P; q++) rank += prk[q * Npad + s];
+      pb[(hi - lo > 1) ? lo + rank : s] = me;
+    }
+    __syncthreads();
+    int *t = pa; pa = pb; pb = t;
+  }
+  int *widx = (int *)(wsj + 3 * N + 4);
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    double c = block_sum(tid < N ? raw[k * N + tid] : 0.0, red) / (double)N;
+    if (tid == 0) wsj[3 * N + k] = c;
+    if (tid < N) wsj[k * N + tid] = raw[k * N + pa[tid]] - c;
+  }
+  if (tid < N) widx[tid] = pa[tid];
+}
+
+static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
+  return ((size_t)D * N + 3 * Npad + NBP_RED) * 8 + ((size_t)2 * N + (size_t)P * Npad + Npad) * 4;
+}
+
+__global__ void __launch_bounds__(1024)
+nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod,
+                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T) {
+  extern __shared__ double smem[];
+  const int b = blockIdx.x;
+  if (b < 3 * nbw) {  // manikde! bandwidth of (slot, coordinate)
+    lcv_slot_coordinate(arena + S * bw_slots[b / 3], bw_manis[b / 3], b % 3, N, Npad, smem);
+    return;
+  }
+  const int q = b - 3 * nbw, p = q / NBP_MAXF, j = q % NBP_MAXF;
+  if (p >= nprod) return;
+  const nbp_product_desc *d = descs + p;
+  if (d->nfactors == 1 || j >= d->nfactors) return;
+  const double *x = arena + S * d->in_slot[j];
+  double *wsj = ws + (size_t)(p * NBP_MAXF + j) * nbp_kd_ws_doubles(N);
+  switch (mani_dim(d->manifold)) {
+  case 1: kd_build<1>(x, wsj, N, Npad, T, smem); break;
+  case 2: kd_build<2>(x, wsj, N, Npad, T, smem); break;
+  default: kd_build<3>(x, wsj, N, Npad, T, smem); break;
+  }
+}
+
 struct product_lds {
-  double *xs, *lm, *lv, *cen, *h2, *red, *gm, *gt, *ext, *nw, *tab;
-  int *idx, *ind, *tmpA, *tmpB, *prk, *bdim;
+  double *xs, *lm, *lv, *cen, *h2, *gm, *gt, *nw, *tab;
+  int *ind;
 };
 
-__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Npad, int P, double *base, product_lds *L) {
+__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Npad, int TB, int SPB, double *base, product_lds *L) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
   size_t xs = dbl((size_t)F * D * N), lm = dbl((size_t)F * D * N), lv = dbl((size_t)F * D * N);
-  size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3), red = dbl(NBP_RED);
-  size_t gm = dbl((size_t)P * Npad), gt = dbl((size_t)P * Npad);  // gt doubles as LCV `part`
-  size_t ext = dbl((size_t)3 * Npad);
-  size_t nw = dbl((size_t)Npad);  // node weights (hi-lo)/N of the current level
-  size_t tab = dbl(NBP_EXPTAB);
-  size_t ints0 = o;  // int region starts here (8-byte aligned)
-  size_t io = 0;
-  auto i32 = [&](size_t n) { size_t r = io; io += n; return r; };
-  size_t idx = i32((size_t)F * N), ind = i32((size_t)F * Npad), tA = i32(N), tB = i32(N), prk = i32((size_t)P * Npad), bd = i32(Npad);
+  size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
+  size_t gm = dbl((size_t)TB), gt = dbl((size_t)TB);
+  size_t nw = dbl((size_t)Npad), tab = dbl(NBP_EXPTAB);
+  size_t ints0 = o;
   if (L) {
-    L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2; L->red = base + red;
-    L->gm = base + gm; L->gt = base + gt; L->ext = base + ext; L->nw = base + nw; L->tab = base + tab;
-    int *ib = (int *)(base + ints0);
-    L->idx = ib + idx; L->ind = ib + ind; L->tmpA = ib + tA; L->tmpB = ib + tB; L->prk = ib + prk; L->bdim = ib + bd;
+    L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2;
+    L->gm = base + gm; L->gt = base + gt; L->nw = base + nw; L->tab = base + tab;
+    L->ind = (int *)(base + ints0);
   }
-  return ints0 * 8 + io * 4;
+  return ints0 * 8 + (size_t)F * SPB * 4;
 }
 
 template <int MANI>
-__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, int N, int Npad, int64_t S, int32_t *side,
-                             const nbp_levels &T, double *smem) {
+__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int N, int Npad,
+                                             int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
   const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
-  const int P = TB / Npad, s = tid % Npad, sub = tid / Npad;
+  const int G = gridDim.y, SPB = Npad / G, P = TB / SPB;  // samples per workgroup, helpers per sample
+  const int sl = tid % SPB, sub = tid / SPB, s = blockIdx.y * SPB + sl;
+  const bool live = s < N;
   product_lds L;
-  product_lds_layout(F, D, N, Npad, P, smem, &L);
-  double *xs = L.xs, *lm = L.lm, *lv = L.lv, *cen = L.cen, *h2 = L.h2, *red = L.red;
-  int *idx = L.idx, *ind = L.ind;
+  product_lds_layout(F, D, N, Npad, TB, SPB, smem, &L);
+  double *xs = L.xs, *lm = L.lm, *lv = L.lv, *cen = L.cen, *h2 = L.h2;
+  int *ind = L.ind;
   double *out = arena + S * d->out_slot;
-
+  const double *wsp = ws + (size_t)blockIdx.x * NBP_MAXF * nbp_kd_ws_doubles(N);
   nbp_exp_tab_init(L.tab);
   NBP_TICK_INIT();
-  // ---- KD-tree permutation per density (median split of the widest coordinate) ----------------
-  for (int j = 0; j < F; j++) {
-    const double *x = arena + S * d->in_slot[j];
-    double *raw = lm + j * D * N;  // temporary home of the unsorted coordinates
-    if (tid < N) {
-#pragma unroll
-      for (int k = 0; k < D; k++) raw[k * N + tid] = x[k * N + tid];
-      L.tmpA[tid] = tid;
-    }
-    if (tid < 3) h2[j * 3 + tid] = (tid < D) ? x[3 * N + tid] * x[3 * N + tid] : 0.0;
-    __syncthreads();
-    int *pa = L.tmpA, *pb = L.tmpB;
-    for (int l = 0; l < T.L; l++) {
-      const int cnt = T.cnt[l], off = T.off[l];
-      if (D > 1) {
-        // extent of every segment in every coordinate: item = (node, coordinate), then argmax
-        for (int item = tid; item < cnt * D; item += TB) {
-          const int z = item / D, k = item % D;
-          const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
-          double mn = INFINITY, mx = -INFINITY;
-          for (int p = lo; p < hi; p++) {
-            const double v = raw[k * N + pa[p]];
-            mn = fmin(mn, v);
-            mx = fmax(mx, v);
-          }
-          L.ext[item] = mx - mn;
-        }
-        __syncthreads();
-        NBP_TICK(0);  // KD extents
-        for (int z = tid; z < cnt; z += TB) {
-          int best = 0;
-          double bext = -1.0;
-#pragma unroll
-          for (int k = 0; k < D; k++)
-            if (L.ext[z * D + k] > bext) { bext = L.ext[z * D + k]; best = k; }
-          L.bdim[z] = best;
-        }
-        __syncthreads();
-      }
-      // rank of every element inside its segment, counted P ways
-      int lo = 0, hi = 0, me = 0;
-      if (s < N) {
-        const int node = T.pos_node[l * N + s];
-        lo = T.node_lo[off + node];
-        hi = T.node_hi[off + node];
-        me = pa[s];
-        int rank = 0;
-        if (hi - lo > 1) {
-          const int best = (D > 1) ? L.bdim[node] : 0;
-          const double v = raw[best * N + me];
-          const int len = hi - lo, a = lo + (sub * len) / P, b = lo + ((sub + 1) * len) / P;
-          for (int p = a; p < b; p++) {
-            const int ip = pa[p];
-            const double vp = raw[best * N + ip];
-            rank += (vp < v || (vp == v && ip < me)) ? 1 : 0;
-          }
-        }
-        L.prk[sub * Npad + s] = rank;
-      }
-      __syncthreads();
-      if (sub == 0 && s < N) {
-        int rank = 0;
-        for (int q = 0; q < P; q++) rank += L.prk[q * Npad + s];
-        pb[(hi - lo > 1) ? lo + rank : s] = me;
-      }
-      __syncthreads();
-      NBP_TICK(1);  // KD rank + scatter
-      int *t = pa; pa = pb; pb = t;
-    }
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-      double c = block_sum(tid < N ? raw[k * N + tid] : 0.0, red) / (double)N;
-      if (tid == 0) cen[j * 3 + k] = c;
-      if (tid < N) xs[(j * D + k) * N + tid] = raw[k * N + pa[tid]] - c;
-    }
-    if (tid < N) idx[j * N + tid] = pa[tid];
-    __syncthreads();
-    NBP_TICK(2);  // centre + sorted copy
+  // ---- stage the KD-sorted, centred coordinates of every density + bandwidths ------------------
+  for (int item = tid; item < F * D * N; item += TB) {
+    const int j = item / (D * N), r = item % (D * N);
+    xs[item] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + r];
   }
-
-  // ---- multiscale Gibbs ---------------------------------------------------------------------
+  if (tid < F * 3) {
+    const int j = tid / 3, k = tid % 3;
+    const double bw = arena[S * d->in_slot[j] + 3 * N + k];
+    h2[tid] = (k < D) ? bw * bw : 0.0;
+    cen[tid] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
+  }
   if (sub == 0)
-    for (int j = 0; j < F; j++) ind[j * Npad + s] = 0;  // levelInit!: root
+    for (int j = 0; j < F; j++) ind[j * SPB + sl] = 0;  // levelInit!: root
+  NBP_TICK(2);
+  // ---- multiscale Gibbs ---------------------------------------------------------------------
   for (int l = 1; l <= T.L; l++) {
     const int cnt = T.cnt[l], off = T.off[l];
     __syncthreads();
@@ -441,8 +485,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       lv[jk * N + z] = var + h2[j * 3 + k];
     }
     for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
-    if (sub == 0 && s < N)
-      for (int j = 0; j < F; j++) ind[j * Npad + s] = T.node_child[T.off[l - 1] + ind[j * Npad + s]];  // levelDown!
+    if (sub == 0 && live)
+      for (int j = 0; j < F; j++) ind[j * SPB + sl] = T.node_child[T.off[l - 1] + ind[j * SPB + sl]];  // levelDown!
     __syncthreads();
     NBP_TICK(3);  // level statistics
     const int z0 = (sub * cnt) / P, z1 = ((sub + 1) * cnt) / P;  // this helper's node range
@@ -488,13 +532,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           }
         };
         const int zr = z1 - z0, csz = (zr + NCH - 1) / NCH;  // chunk size of this helper's range
-        if (s < N) {
+        if (live) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
             double prec = 0, acc = 0, ss = 0, sc = 0;
             for (int q = 0; q < F; q++) {
               if (q == j) continue;
-              const int iq = ind[q * Npad + s];
+              const int iq = ind[q * SPB + sl];
               const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
               prec += 1.0 / vq;
               if (circ[k]) {
@@ -514,7 +558,6 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           }
           double ub;
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
-          NBP_TICK(7);  // others-product + Philox (wave 0 only)
 #pragma unroll
           for (int c = 0; c < NCH; c++) {
             double cur = 0;
@@ -535,37 +578,36 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             cs[c] = cur;
             ms[c] = m;
           }
-          L.gm[sub * Npad + s] = m;
-          L.gt[sub * Npad + s] = tot;
-          NBP_TICK(8);  // pass-1 loop (wave 0 only)
+          L.gm[sub * SPB + sl] = m;
+          L.gt[sub * SPB + sl] = tot;
         }
         __syncthreads();
         NBP_TICK(4);  // others-product + pass 1
-        if (s < N) {
-          double Mx = -INFINITY;
-          for (int q = 0; q < P; q++) Mx = fmax(Mx, L.gm[q * Npad + s]);
-          // every helper computes the same cumulative shares -> the same owner
-          double total = 0, before = 0;
-          int owner = -1, lastne = 0;
-          double cum[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            if (q < P) {
-              const double tq = L.gt[q * Npad + s];
-              const double sc = (tq > 0) ? tq * exp_nonpos(L.gm[q * Npad + s] - Mx, L.tab) : 0.0;
-              if (q == sub) before = total;
-              total += sc;
-              if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
-            }
-            cum[q] = total;
-          }
+        double Mx = -INFINITY;
+        if (live) {  // common scale, then this helper's share on that scale
+          for (int q = 0; q < P; q++) Mx = fmax(Mx, L.gm[q * SPB + sl]);
+        }
+        __syncthreads();
+        if (live) L.gt[sub * SPB + sl] = (tot > 0) ? tot * exp_nonpos(m - Mx, L.tab) : 0.0;
+        __syncthreads();
+        if (live) {
+          // every helper walks the same shares -> the same owner (first helper whose cumulative
+          // share exceeds u * total; the last non-empty helper if rounding leaves none)
+          double total = 0;
+          for (int q = 0; q < P; q++) total += L.gt[q * SPB + sl];
           const double target = ua * total;
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (q < P && owner < 0 && target < cum[q]) owner = q;
-          if (owner < 0) owner = lastne;
-          if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
-            double c0 = before;
+          double c0 = 0, before = 0;
+          int owner = -1, lastne = 0;
+          for (int q = 0; q < P; q++) {
+            if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
+            const double nc = c0 + L.gt[q * SPB + sl];
+            if (owner < 0 && target < nc) { owner = q; before = c0; }
+            c0 = nc;
+          }
+          if (owner < 0) {  // rounding left u*total beyond the last share: last node of the level
+            if (sub == lastne) ind[j * SPB + sl] = z1 - 1;
+          } else if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
+            double cacc = before;
             int za = z0, zb = z1;
             bool found = false;
 #pragma unroll
@@ -573,14 +615,14 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
               const int ca = z0 + c * csz, cb = min(z1, ca + csz);
               if (!found && ca < cb) {
-                za = ca; zb = cb;  // remember the last non-empty chunk as the fallback
-                if (target < c0 + share) found = true;
-                else c0 += share;
+                za = ca; zb = cb;  // the last non-empty chunk is the fallback
+                if (target < cacc + share) found = true;
+                else cacc += share;
               }
             }
-            double c = found ? c0 : -INFINITY;  // not found: take the last node of the last chunk
             int choice = zb - 1;
             if (found) {
+              double c = cacc;
               for (int z = za; z < zb; z++) {
                 double a, g;
                 node_w(z, a, g);
@@ -588,7 +630,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
                 if (target < c) { choice = z; break; }
               }
             }
-            ind[j * Npad + s] = choice;
+            ind[j * SPB + sl] = choice;
           }
         }
         __syncthreads();
@@ -597,24 +639,24 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     }
   }
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
-  double res[D];
-  if (tid < N) {
+  if (sub == 0 && live) {
+    double res[D];
     double n0, n1, n2 = 0, n3 = 0;
-    normal_pair(d->seed, tid, PURP_PFINAL, 0, n0, n1);
-    if (D > 2) normal_pair(d->seed, tid, PURP_PFINAL, 1, n2, n3);
+    normal_pair(d->seed, s, PURP_PFINAL, 0, n0, n1);
+    if (D > 2) normal_pair(d->seed, s, PURP_PFINAL, 1, n2, n3);
     const double nn[3] = {n0, n1, n2};
 #pragma unroll
     for (int k = 0; k < D; k++) {
       double prec = 0, acc = 0, ss = 0, sc = 0;
       for (int q = 0; q < F; q++) {
-        const int iq = ind[q * Npad + tid];
+        const int iq = ind[q * SPB + sl];
         const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
         prec += 1.0 / vq;
         if (circ[k]) {
-          double sn, cs;
-          sincos(mq, &sn, &cs);
+          double sn, cs_;
+          sincos(mq, &sn, &cs_);
           ss += sn / vq;
-          sc += cs / vq;
+          sc += cs_ / vq;
         } else
           acc += mq / vq;
       }
@@ -623,22 +665,24 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       res[k] = circ[k] ? wrap_pi(v) : v;
     }
     if (d->labels_out >= 0)
-      for (int j = 0; j < F; j++)
-        side[d->labels_out + tid * F + j] = idx[j * N + T.node_lo[T.off[T.L] + ind[j * Npad + tid]]];
+      for (int j = 0; j < F; j++) {
+        const int *widx = (const int *)(wsp + (size_t)j * nbp_kd_ws_doubles(N) + 3 * N + 4);
+        side[d->labels_out + s * F + j] = widx[T.node_lo[T.off[T.L] + ind[j * SPB + sl]]];
+      }
+    // setBelief!: the rebandwidth rides with the next nbp_prep_kernel / nbp_bandwidth_kernel launch
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k * N + s] = (k < D) ? res[k < D ? k : 0] : 0.0;
   }
   NBP_TICK(6);  // final draw
-  // setBelief!: the rebandwidth runs as nbp_product_bandwidth_kernel right behind this kernel
-  if (tid < N) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) out[k * N + tid] = (k < D) ? res[k < D ? k : 0] : 0.0;
-  }
 }
 
 __global__ void __launch_bounds__(1024)
-nbp_product_kernel(const nbp_product_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side, nbp_levels T) {
+nbp_product_kernel(const nbp_product_desc *descs, double *arena, const double *ws, int N, int Npad, int64_t S, int32_t *side,
+                   nbp_levels T) {
   extern __shared__ double smem[];
   const nbp_product_desc *d = descs + blockIdx.x;
   if (d->nfactors == 1) {  // single density: AMP returns it unchanged
+    if (blockIdx.y != 0) return;
     const double *src = arena + S * d->in_slot[0];
     double *out = arena + S * d->out_slot;
     for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
@@ -646,14 +690,14 @@ nbp_product_kernel(const nbp_product_desc *descs, double *arena, int N, int Npad
     return;
   }
   switch (d->manifold) {
-  case NBP_EUCLID1: product_body<NBP_EUCLID1>(d, arena, N, Npad, S, side, T, smem); break;
-  case NBP_EUCLID2: product_body<NBP_EUCLID2>(d, arena, N, Npad, S, side, T, smem); break;
-  case NBP_EUCLID3: product_body<NBP_EUCLID3>(d, arena, N, Npad, S, side, T, smem); break;
-  case NBP_CIRCULAR: product_body<NBP_CIRCULAR>(d, arena, N, Npad, S, side, T, smem); break;
-  default: product_body<NBP_SE2>(d, arena, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID1: product_body<NBP_EUCLID1>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID2: product_body<NBP_EUCLID2>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID3: product_body<NBP_EUCLID3>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_CIRCULAR: product_body<NBP_CIRCULAR>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  default: product_body<NBP_SE2>(d, arena, ws, N, Npad, S, side, T, smem); break;
   }
 }
 
-static inline size_t nbp_product_lds_bytes(int F, int D, int N, int Npad, int P) {
-  return product_lds_layout(F, D, N, Npad, P, nullptr, nullptr);
+static inline size_t nbp_product_lds_bytes(int F, int D, int N, int Npad, int TB, int SPB) {
+  return product_lds_layout(F, D, N, Npad, TB, SPB, nullptr, nullptr);
 }

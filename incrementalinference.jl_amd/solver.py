@@ -371,7 +371,7 @@ class TreeProgram:
         self.n_updates_up = 0
         self.n_updates_down = 0
         self.alg_bytes = 0
-        self.alg = {"nbp_proposal_kernel": 0, "nbp_bandwidth_kernel": 0, "nbp_product_kernel": 0}
+        self.alg = {"nbp_proposal_kernel": 0, "nbp_prep_kernel": 0, "nbp_product_kernel": 0, "nbp_bandwidth_kernel": 0}
         self._compile()
 
     # -- helpers ------------------------------------------------------------------------------
@@ -383,7 +383,7 @@ class TreeProgram:
         # kernel reads the F_in operand beliefs + the variable's own old belief; the product kernel
         # writes the new points; the bandwidth kernels write the (F_in + 1) bandwidth vectors.
         self.alg["nbp_proposal_kernel"] += (F_in + 1) * N * P * 8
-        self.alg["nbp_bandwidth_kernel"] += (F_in + 1) * D * 8
+        self.alg["nbp_prep_kernel"] += (F_in + 1) * D * 8
         self.alg["nbp_product_kernel"] += N * P * 8
 
     def _msg_slot(self, child, v):
