@@ -83,7 +83,11 @@ def generateCircularDoors(nposes=2000, N=200, sightEvery=25):
         else:
             addFactor(fg, [f"x{i - 1}", f"x{i}"], CircularCircular(Normal(step, 0.05)))
         if i % sightEvery == 0:
-            addFactor(fg, [f"x{i}", "l0", "l1", "l2", "l3"], CircularCircular(Normal(0.0, 0.1)),
+            # door sighting with unknown association: the measurement is the bearing difference to the
+            # nearest door (so exactly one of the four hypotheses is consistent with the truth)
+            xi = (i * step + np.pi) % (2 * np.pi) - np.pi
+            dz = min(((d - xi + np.pi) % (2 * np.pi) - np.pi for d in doors), key=abs)
+            addFactor(fg, [f"x{i}", "l0", "l1", "l2", "l3"], CircularCircular(Normal(dz, 0.1)),
                       multihypo=[1.0, 0.25, 0.25, 0.25, 0.25])
     return fg
 
