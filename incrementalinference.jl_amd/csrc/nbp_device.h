@@ -124,7 +124,8 @@ __device__ __forceinline__ void nbp_exp_tab_init(double *tab) {
   if (threadIdx.x < 32) tab[threadIdx.x] = NBP_EXP2_TAB[threadIdx.x];
 }
 __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
-  if (x < -700.0) return 0.0;
+  // clamp instead of branching: exp(-700) = 1e-304 is as good as 0 for every sum it enters
+  x = fmax(x, -700.0);
   const double t = fma(x, 46.16624130844683, 6755399441055744.0);
   const int n = __double2loint(t);
   const double tf = t - 6755399441055744.0;
