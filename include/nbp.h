@@ -127,6 +127,7 @@ typedef struct nbp_diag {
   int64_t nonconverged;  /* NumericalCalculations.jl:128-131                   */
   int64_t nan_results;   /* NumericalCalculations.jl:348-351                   */
   int64_t residual_evals;
+  int64_t lcv_evals;     /* leave-one-out likelihood evaluations (each = N(N-1)/2 kernel pairs) */
 } nbp_diag;
 
 typedef struct nbp_ctx nbp_ctx;

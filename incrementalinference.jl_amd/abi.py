@@ -64,6 +64,7 @@ class Diag(C.Structure):
         ("nonconverged", C.c_int64),
         ("nan_results", C.c_int64),
         ("residual_evals", C.c_int64),
+        ("lcv_evals", C.c_int64),
     ]
 
 

@@ -357,6 +357,17 @@ static int product_groups(nbp_ctx *c, int n) {
   return G;
 }
 
+// Helper lanes per particle for the LCV / KD launches: P = 4 (1024-lane workgroups) minimises the
+// latency of a single fit when the launch cannot fill the chip; P = 2 (512 lanes) lets four
+// workgroups share a CU so that the barrier/combine phases of one overlap the pair loop of the
+// others when there are many fits (throughput mode).
+static int lcv_helpers(nbp_ctx *c, int nblocks) {
+  int P = c->P;
+  if (nblocks > 256 && P > 2) P = 2;
+  if (nblocks > 4 * 256) P = 1;
+  return P;
+}
+
 // nbp_prep_kernel: pending bandwidth fits + KD builds of this product batch, one launch
 static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
                               const nbp_product_desc *dev, int n) {
@@ -364,11 +375,12 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   if (rc) return rc;
   rc = tic(c, c->ev[1]);
   if (rc) return rc;
-  size_t lds = nbp_kd_lds_bytes(3, c->N, c->Npad, c->P);
-  if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P);
+  const int P = lcv_helpers(c, 2 * nbw + 2 * n);
+  size_t lds = nbp_kd_lds_bytes(3, c->N, c->Npad, P);
+  if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, P);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * NBP_MAXF), dim3(c->threads), lds, c->stream, bw_slots, bw_manis, nbw, dev,
-                     n, c->arena, c->ws, c->N, c->Npad, c->S, c->T);
+  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * NBP_MAXF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw, dev,
+                     n, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
 }
@@ -393,8 +405,9 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
   nbp_status rc = tic(c, c->ev[3]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(c->threads), nbp_bandwidth_lds_bytes(c->N, c->Npad, c->P), c->stream,
-                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S);
+  const int P = lcv_helpers(c, 2 * n);
+  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[3]);
 }
@@ -742,6 +755,7 @@ nbp_status nbp_diag_read(nbp_ctx *c, nbp_diag *out, int32_t reset) {
   out->nonconverged = (int64_t)h.nonconverged;
   out->nan_results = (int64_t)h.nan_results;
   out->residual_evals = (int64_t)h.residual_evals;
+  out->lcv_evals = (int64_t)h.lcv_evals;
   if (reset) HIPCHK(hipMemset(c->counters, 0, sizeof(h)));
   return NBP_OK;
 }

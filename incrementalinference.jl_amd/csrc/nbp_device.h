@@ -52,7 +52,7 @@ struct nbp_levels {
 };
 
 struct nbp_counters {
-  unsigned long long solves, nonconverged, nan_results, residual_evals;
+  unsigned long long solves, nonconverged, nan_results, residual_evals, lcv_evals;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -608,7 +608,7 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
 }
 
 __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red,
-                                                   const double *tab) {
+                                                   const double *tab, nbp_counters *ctr) {
   const int i = threadIdx.x;
   double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
   if (i < N) {
@@ -636,10 +636,13 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
   else { x2 = bx; x1 = bx - C * (bx - ax); }
   double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red, tab);
+  unsigned int nev = 2;
   while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
+    nev++;
     if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red, tab); }
     else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red, tab); }
   }
+  if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
   return (f1 < f2 ? x1 : x2) * sc;
 }
 

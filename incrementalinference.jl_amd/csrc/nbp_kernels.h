@@ -221,7 +221,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
 static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
 
 // fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)
-__device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int N, int Npad, double *smem) {
+__device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int N, int Npad, double *smem, nbp_counters *ctr) {
   const int D = mani_dim(M), n = threadIdx.x;
   if (k >= D) {
     if (n == 0) s[3 * N + k] = 0.0;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   nbp_exp_tab_init(tab);
   if (n < N) X[n] = s[k * N + n];
   __syncthreads();
-  double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red, tab);
+  double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red, tab, ctr);
   if (n == 0) s[3 * N + k] = h;
 }
 
@@ -242,9 +242,10 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
 // for the rebandwidth of products and for nbp_run_bandwidth.
 // ================================================================================================
 __global__ void __launch_bounds__(1024)
-nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S) {
+nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S,
+                     nbp_counters *ctr) {
   extern __shared__ double smem[];
-  lcv_slot_coordinate(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem);
+  lcv_slot_coordinate(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
 }
 
 // X[N] | part[P][Npad] | acc[NW][N] | red | exp table     (NW = P*Npad/64 waves)
@@ -395,11 +396,11 @@ static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
 
 __global__ void __launch_bounds__(1024)
 nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod,
-                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T) {
+                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr) {
   extern __shared__ double smem[];
   const int b = blockIdx.x;
   if (b < 3 * nbw) {  // manikde! bandwidth of (slot, coordinate)
-    lcv_slot_coordinate(arena + S * bw_slots[b / 3], bw_manis[b / 3], b % 3, N, Npad, smem);
+    lcv_slot_coordinate(arena + S * bw_slots[b / 3], bw_manis[b / 3], b % 3, N, Npad, smem, ctr);
     return;
   }
   const int q = b - 3 * nbw, p = q / NBP_MAXF, j = q % NBP_MAXF;
