@@ -388,12 +388,14 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD) {
   if (n <= 0) return NBP_OK;
   const int G = product_groups(c, n), SPB = c->Npad / G;
+  // throughput mode: 512-lane workgroups (four per CU) once the launch fills the chip
+  const int TB = (n >= 256 && c->P > 2) ? 2 * c->Npad : c->threads;
   // maxFD encodes the largest (F, D) of the batch as F*4 + D
-  const size_t lds = nbp_product_lds_bytes(maxFD / 4, maxFD % 4, c->N, c->Npad, c->threads, SPB);
+  const size_t lds = nbp_product_lds_bytes(maxFD / 4, maxFD % 4, c->N, c->Npad, TB, SPB);
   nbp_status rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_product_kernel, dim3(n, G), dim3(c->threads), lds, c->stream, dev, c->arena, c->ws, c->N, c->Npad,
+  hipLaunchKernelGGL(nbp_product_kernel, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->Npad,
                      c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
