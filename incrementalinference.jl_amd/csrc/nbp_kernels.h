@@ -417,8 +417,8 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
 }
 
 struct product_lds {
-  double *xs, *lm, *lv, *cen, *h2, *gm, *gt, *nw, *tab;
-  int *ind;
+  double *xs, *lm, *lv, *cen, *h2, *gm, *gt, *nw, *tab, *cMx, *cbefore, *ctarget;
+  int *ind, *cowner;
 };
 
 __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Npad, int TB, int SPB, double *base, product_lds *L) {
@@ -428,13 +428,16 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Np
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
   size_t gm = dbl((size_t)TB), gt = dbl((size_t)TB);
   size_t nw = dbl((size_t)Npad), tab = dbl(NBP_EXPTAB);
+  size_t cMx = dbl((size_t)SPB), cbefore = dbl((size_t)SPB), ctarget = dbl((size_t)SPB);
   size_t ints0 = o;
   if (L) {
     L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2;
     L->gm = base + gm; L->gt = base + gt; L->nw = base + nw; L->tab = base + tab;
+    L->cMx = base + cMx; L->cbefore = base + cbefore; L->ctarget = base + ctarget;
     L->ind = (int *)(base + ints0);
+    L->cowner = L->ind + (size_t)F * SPB;
   }
-  return ints0 * 8 + (size_t)F * SPB * 4;
+  return ints0 * 8 + ((size_t)F * SPB + SPB) * 4;
 }
 
 template <int MANI>
@@ -584,46 +587,39 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         }
         __syncthreads();
         NBP_TICK(4);  // others-product + pass 1
-        double Mx = -INFINITY;
-        if (live) {  // common scale, then this helper's share on that scale
+        // combine: every helper rescales its own total to the common max (one exp each, in parallel),
+        // then ONE lane per sample walks the P shares to find the helper range that holds u * total.
+        if (live) {
+          double Mx = -INFINITY;
           for (int q = 0; q < P; q++) Mx = fmax(Mx, L.gm[q * SPB + sl]);
+          const double sh = (tot > 0) ? tot * exp_nonpos(m - Mx, L.tab) : 0.0;
+          __builtin_amdgcn_s_waitcnt(0);  // all gm reads of this lane are done before gt is rewritten
+          L.gt[sub * SPB + sl] = sh;
+          if (sub == 0) L.cMx[sl] = Mx;
         }
         __syncthreads();
-        if (live) L.gt[sub * SPB + sl] = (tot > 0) ? tot * exp_nonpos(m - Mx, L.tab) : 0.0;
-        __syncthreads();
-        if (live) {
-          // every helper walks the same shares -> the same owner (first helper whose cumulative
-          // share exceeds u * total; the last non-empty helper if rounding leaves none)
+        if (sub == 0 && live) {
           double total = 0;
           for (int q = 0; q < P; q++) total += L.gt[q * SPB + sl];
           const double target = ua * total;
           double c0 = 0, before = 0;
-          int owner = -1, lastne = 0;
+          int owner = -1;
           for (int q = 0; q < P; q++) {
-            if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
             const double nc = c0 + L.gt[q * SPB + sl];
             if (owner < 0 && target < nc) { owner = q; before = c0; }
             c0 = nc;
           }
-          if (owner < 0) {  // rounding left u*total beyond the last share: last node of the level
-            if (sub == lastne) ind[j * SPB + sl] = z1 - 1;
-          } else if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
-            double cacc = before;
-            int za = z0, zb = z1;
-            bool found = false;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-              const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
-              const int ca = z0 + c * csz, cb = min(z1, ca + csz);
-              if (!found && ca < cb) {
-                za = ca; zb = cb;  // the last non-empty chunk is the fallback
-                if (target < cacc + share) found = true;
-                else cacc += share;
-              }
-            }
-            int choice = zb - 1;
-            if (found) {
-              double c = cacc;
+          if (P >= 8) {
+            // many short helper ranges (sample-split launch): this lane finishes the draw itself --
+            // one fully occupied wave instead of 1/P-occupied passes in every wave
+            int choice;
+            if (owner < 0) {
+              choice = cnt - 1;
+            } else {
+              const int za = (owner * cnt) / P, zb = ((owner + 1) * cnt) / P;
+              const double Mx = L.cMx[sl];
+              double c = before;
+              choice = zb - 1;
               for (int z = za; z < zb; z++) {
                 double a, g;
                 node_w(z, a, g);
@@ -632,10 +628,55 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               }
             }
             ind[j * SPB + sl] = choice;
+          } else {
+            L.cbefore[sl] = before;
+            L.ctarget[sl] = target;
+            L.cowner[sl] = owner;
           }
         }
+        NBP_TICK(7);
         __syncthreads();
-        NBP_TICK(5);  // combine + pass 2
+        NBP_TICK(8);
+        if (P < 8) {
+          if (live) {
+            const double Mx = L.cMx[sl], before = L.cbefore[sl], target = L.ctarget[sl];
+            const int owner = L.cowner[sl];
+            int lastne = 0;
+            for (int q = 0; q < P; q++)
+              if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
+            if (owner < 0) {  // rounding left u*total beyond the last share: last node of the level
+              if (sub == lastne) ind[j * SPB + sl] = z1 - 1;
+            } else if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
+              double cacc = before;
+              int za = z0, zb = z1;
+              bool found = false;
+#pragma unroll
+              for (int c = 0; c < NCH; c++) {
+                const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
+                const int ca = z0 + c * csz, cb = min(z1, ca + csz);
+                if (!found && ca < cb) {
+                  za = ca; zb = cb;  // the last non-empty chunk is the fallback
+                  if (target < cacc + share) found = true;
+                  else cacc += share;
+                }
+              }
+              int choice = zb - 1;
+              if (found) {
+                double c = cacc;
+                for (int z = za; z < zb; z++) {
+                  double a, g;
+                  node_w(z, a, g);
+                  c += exp_nonpos(a - Mx, L.tab) * g;
+                  if (target < c) { choice = z; break; }
+                }
+              }
+              ind[j * SPB + sl] = choice;
+            }
+          }
+          NBP_TICK(9);
+          __syncthreads();
+        }
+        NBP_TICK(5);  // barrier after pass 2
       }
     }
   }

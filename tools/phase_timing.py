@@ -6,7 +6,7 @@ import numpy as np
 from parity_utils import abi, iif, rand_points, product_desc
 lib = abi.load_library(os.path.join(R, "tools", "libnbp_dbg.so"))
 abi._lib = lib
-names = ["KD extents", "KD rank", "centre/copy", "level stats", "wait@pass1 barrier", "combine+pass2", "final draw", "others+philox(w0)", "pass1 loop(w0)"]
+names = ["-", "-", "stage ws->LDS", "level stats", "pass1 (to barrier)", "barrier after pass2", "final draw", "combine(w0)", "barrier after combine", "pass2(w0)"]
 for (N, man, F) in [(200, abi.EUCLID2, 2), (200, abi.EUCLID2, 3), (200, abi.SE2, 3), (300, abi.EUCLID3, 2)]:
     be = iif.HipBackend(N, F + 2, 0)
     rng = np.random.default_rng(0); D = abi.MANIFOLD_DIM[man]
@@ -19,6 +19,6 @@ for (N, man, F) in [(200, abi.EUCLID2, 2), (200, abi.EUCLID2, 3), (200, abi.SE2,
     for _ in range(5):
         be.run_products([d])
     lib.nbp_debug_phase_read(out, 64, 1)
-    tot = sum(out[:9])
+    tot = sum(out[:10])
     print(f"N={N} man={man} F={F}: total {tot / 5 / 100:.1f} us | " + ", ".join(f"{n} {out[i] / 5 / 100:.1f}" for i, n in enumerate(names)))
     be.close()
