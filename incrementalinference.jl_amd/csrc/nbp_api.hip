@@ -370,7 +370,7 @@ static int lcv_helpers(nbp_ctx *c, int nblocks) {
 
 // nbp_prep_kernel: pending bandwidth fits + KD builds of this product batch, one launch
 static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
-                              const nbp_product_desc *dev, int n) {
+                              const nbp_product_desc *dev, int n, int maxFD) {
   nbp_status rc = ensure_ws(c, n);
   if (rc) return rc;
   rc = tic(c, c->ev[1]);
@@ -379,8 +379,9 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   size_t lds = nbp_kd_lds_bytes(3, c->N, c->Npad, P);
   if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, P);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * NBP_MAXF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw, dev,
-                     n, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
+  const int kdF = maxFD / 4;
+  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw, dev,
+                     n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
 }
@@ -501,7 +502,7 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   const int32_t *ds, *dm;
   rc = stage_with_jobs(c, descs, sizeof(nbp_product_desc) * (size_t)n, js, jm, &ds, &dm);
   if (rc) return rc;
-  rc = launch_prep(c, nullptr, nullptr, 0, (const nbp_product_desc *)c->stage, n);  // KD trees
+  rc = launch_prep(c, nullptr, nullptr, 0, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n));  // KD trees
   if (rc) return rc;
   rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n));
   if (rc) return rc;
@@ -670,7 +671,7 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
-      rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n);
+      rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd);
     } else {
       rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);

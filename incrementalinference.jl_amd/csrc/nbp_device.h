@@ -131,13 +131,22 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
   const double tf = t - 6755399441055744.0;
   double r = fma(tf, -2.16608493865351192653e-02, x);
   r = fma(tf, -5.96317165397058656257e-12, r);
-  double p = 1.38888888888888888889e-03;
-  p = fma(p, r, 8.33333333333333333333e-03);
-  p = fma(p, r, 4.16666666666666666667e-02);
-  p = fma(p, r, 1.66666666666666666667e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
+  // Horner with the coefficients pinned in SGPRs: one v_fma_f64 per step (hipcc otherwise keeps them
+  // in VGPRs and pays a v_mov_b64 + v_fmac_f64 per step)
+  double p;
+#define NBP_FMA_S(dst, a, b, cst) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "s"(cst))
+  {
+    const double c6 = 1.38888888888888888889e-03, c5 = 8.33333333333333333333e-03, c4 = 4.16666666666666666667e-02,
+                 c3 = 1.66666666666666666667e-01;
+    double q;
+    NBP_FMA_S(q, c6, r, c5);
+    NBP_FMA_S(q, q, r, c4);
+    NBP_FMA_S(q, q, r, c3);
+    p = fma(q, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+  }
+#undef NBP_FMA_S
   const double y = tab[n & 31] * p;
   return __hiloint2double(__double2hiint(y) + ((n >> 5) << 20), __double2loint(y));
 }

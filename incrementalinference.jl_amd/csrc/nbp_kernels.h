@@ -395,7 +395,7 @@ static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
 }
 
 __global__ void __launch_bounds__(1024)
-nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod,
+nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
                 double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr) {
   extern __shared__ double smem[];
   const int b = blockIdx.x;
@@ -403,7 +403,7 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
     lcv_slot_coordinate(arena + S * bw_slots[b / 3], bw_manis[b / 3], b % 3, N, Npad, smem, ctr);
     return;
   }
-  const int q = b - 3 * nbw, p = q / NBP_MAXF, j = q % NBP_MAXF;
+  const int q = b - 3 * nbw, p = q / kdF, j = q % kdF;  // kdF = largest nfactors of the batch
   if (p >= nprod) return;
   const nbp_product_desc *d = descs + p;
   if (d->nfactors == 1 || j >= d->nfactors) return;
