@@ -1,0 +1,97 @@
+"""-m gpu: size-independent properties at BASELINE sizes and edge sizes (no oracle needed):
+determinism, launch-geometry independence, manifold validity, extreme particle counts."""
+import numpy as np
+import pytest
+
+from parity_utils import (abi, assert_points_close, both, iif, product_desc, rand_points,
+                          relative_factor_desc)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_same_seed_same_result_different_seed_differs(hip_backend):
+    def run(seed):
+        fg = iif.generateChainEuclid(30, vardims=2, priorEvery=10, N=200)
+        iif.solveTree(fg, eliminationOrder=iif.nestedDissectionOrder(fg), backend=hip_backend, seed=seed)
+        return np.concatenate([fg.getVal(v).ravel() for v in fg.ls()])
+
+    a, b, c = run(11), run(11), run(12)
+    np.testing.assert_array_equal(a, b)  # counter-based RNG + fixed-order reductions: bitwise reproducible
+    assert np.abs(a - c).max() > 1e-3
+
+
+def test_batch_size_does_not_change_results(hip_backend):
+    """The host picks the workgroup geometry from the batch size (helper lanes P, sample groups G);
+    the same op must give the same answer alone and inside a chip-filling batch."""
+    N, man = 200, abi.EUCLID2
+    rng = np.random.default_rng(5)
+    a, b = rand_points(rng, man, N, 0.0, 0.4), rand_points(rng, man, N, 1.0, 0.4)
+    nbig = 1500
+
+    def run(nops):
+        be = hip_backend(N, 2 + 3 * nops, 0)
+        be.slot_write(0, man, a)
+        be.slot_write(1, man, b)
+        props, prods = [], []
+        for i in range(nops):
+            o = 2 + 3 * i
+            props.append(relative_factor_desc(abi.F_LINREL, man, 2, 1, [0, 1], o, 900, [1.0, 1.0], [0.1, 0.1]))
+            props.append(relative_factor_desc(abi.F_PRIOR, man, 1, 0, [1], o + 1, 901, [1.0, 1.0], [0.3, 0.3]))
+            prods.append(product_desc(man, [o, o + 1], o + 2, 902))
+        prog = be.program([(abi.STAGE_PROPOSALS, props), (abi.STAGE_PRODUCTS, prods)])
+        prog.run()
+        be.synchronize()
+        out = [be.slot_read(2 + 3 * i + 2, man) for i in (0, nops - 1)]
+        prop = be.slot_read(2, man)
+        be.close()
+        return out, prop
+
+    (s0, s1), sp = run(1)
+    (b0, b1), bp = run(nbig)
+    for (p, bw) in (b0, b1):
+        assert_points_close(man, s0[0], p, rtol=1e-9, what="product in big batch")
+        np.testing.assert_allclose(bw, s0[1], rtol=1e-9)
+    assert_points_close(man, sp[0], bp[0], rtol=1e-12, what="proposal in big batch")
+    np.testing.assert_allclose(bp[1], sp[1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("N", [8, 64, 65, 512])
+def test_extreme_particle_counts_match_oracle(oracle_backend, hip_backend, N):
+    man = abi.EUCLID2
+    rng = np.random.default_rng(N)
+    a, b = rand_points(rng, man, N, 0.0, 0.3), rand_points(rng, man, N, 1.0, 0.3)
+    d = relative_factor_desc(abi.F_LINREL, man, 2, 1, [0, 1], 2, 77, [1.0, 1.0], [0.1, 0.1])
+    d2 = relative_factor_desc(abi.F_PRIOR, man, 1, 0, [1], 3, 78, [1.0, 1.0], [0.3, 0.3])
+    pd = product_desc(man, [2, 3], 4, 79, labels_out=0)
+
+    def setup(be):
+        be.slot_write(0, man, a)
+        be.slot_write(1, man, b)
+
+    def run(be):
+        be.run_proposals([d, d2])
+        be.run_products([pd])
+
+    o, h = both(oracle_backend, hip_backend, N, 5, 2 * N, setup, run,
+                lambda be: (be.slot_read(2, man), be.slot_read(4, man), be.side_read(0, 2 * N)))
+    assert_points_close(man, o[0][0], h[0][0], what=f"conv N={N}")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_array_equal(o[2], h[2])
+    assert_points_close(man, o[1][0], h[1][0], what=f"product N={N}")
+    np.testing.assert_allclose(h[1][1], o[1][1], rtol=1e-9)
+
+
+def test_baseline_config2_full_size_properties(hip_backend):
+    """BASELINE config 2 at full size (1000 variables, N = 200): finite, on-manifold, bandwidths
+    positive, message count 2(C-1), every variable solved once, posterior means near x_i = (i, i)."""
+    fg = iif.generateChainEuclid(1000, vardims=2, priorEvery=100, N=200)
+    order = iif.nestedDissectionOrder(fg)
+    tree, tm = iif.solveTree(fg, eliminationOrder=order, backend=hip_backend, seed=1, return_timing=True)
+    assert tm["messages"] == 2 * (len(tree.cliques) - len(tree.roots))
+    assert sorted(v for c in tree.cliques.values() for v in c.frontalIDs) == sorted(fg.ls())
+    err = []
+    for i in range(1000):
+        var = fg.getVariable(f"x{i}")
+        assert var.solvedCount == 1 and np.isfinite(var.val).all() and (var.bw > 0).all()
+        err.append(np.abs(var.val.mean(axis=0) - i).max())
+    assert max(err) < 1.5 and np.mean(err) < 0.4
