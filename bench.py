@@ -114,6 +114,20 @@ def main():
     avg_ms = tim[dominant][0] / max(tim[dominant][1], 1)
     bytes_per_launch = st["alg_bytes"][dominant] / max(launches, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of
+    # this same command, calibrated on nbp_copy_kernel's known byte count: tools/pmc_traffic.py).  A PMC
+    # pass cannot run inside this process, so the committed summary is quoted for the workload it was
+    # collected on and the field stays null for any other.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if world == 1 and a.nvars == 1000 and N == 200 and os.path.exists(pmc):
+        try:
+            k = json.load(open(pmc))["kernels"][dominant]
+            traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        except Exception:
+            pass
+    alg_total = sum(st["alg_bytes"].values())
+    kern_s = sum(per_step.values()) * 1e-3
     out = {
         "metric": "clique-messages/sec", "value": value, "unit": "messages/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -125,7 +139,8 @@ def main():
                    "parallelism": f"cliques sharded over {world} GPU(s)" if world > 1 else "single GPU"},
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": getattr(rs, "posterior_max_mean_err", None),
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None,
+                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                     "whole_update_GBps": alg_total / kern_s / 1e9 if kern_s > 0 else 0.0,
                      "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
                      "launches_per_step": launches,
                      "kernel_ms_per_step": per_step,

@@ -1,0 +1,79 @@
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum,TCC_MISS_sum; one pass each,
+no tracing) of `bench.py --steps K`: per-kernel averages over the TIMED region (the last K x 67
+dispatches of each kernel), the nbp_copy_kernel calibration of the counters' units (a copy launch
+moves exactly blocks x slot_stride x 8 bytes each way in the same 8 B/lane access pattern the other
+kernels use), and the corrected HBM bytes per launch.
+Usage: pmc_traffic.py <dir with FETCH_SIZE/ WRITE_SIZE/ TCC/> <steps> <N> [out.json]"""
+import collections
+import csv
+import glob
+import gzip
+import json
+import sys
+
+
+def load(d):
+    fs = glob.glob(f"{d}/*counter_collection.csv*")
+    if not fs:
+        return []
+    f = fs[0]
+    fh = gzip.open(f, "rt") if f.endswith(".gz") else open(f)
+    return list(csv.DictReader(fh))
+
+
+def per_kernel(rows, counter, steps, lps=67):
+    by = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0]
+        if name.startswith("nbp_"):
+            by[name].append((float(r["Counter_Value"]), int(r["Grid_Size"]) // int(r["Workgroup_Size"])))
+    out = {}
+    for k, v in by.items():
+        tail = v if k in ("nbp_copy_kernel", "nbp_reseed_proposals", "nbp_reseed_products") else v[-steps * lps:]
+        out[k] = tail
+    return out
+
+
+def main(root, steps, N, outp=None):
+    S = 3 * N + 8
+    res = {"steps": steps, "N": N, "note": "values are per launch, timed region only"}
+    cal = {}
+    data = {}
+    for cname, sub in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("TCC_HIT_sum", "TCC"), ("TCC_MISS_sum", "TCC")):
+        data[cname] = per_kernel(load(f"{root}/{sub}"), cname, steps)
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        cp = data[cname].get("nbp_copy_kernel", [])
+        big = [(v, b) for v, b in cp if b >= 32]  # launches large enough that descriptors/instructions do not matter
+        if big:
+            known = sum(b * S * 8 for _, b in big)
+            raw = sum(v for v, _ in big)
+            cal[cname] = known / raw  # bytes per counter unit
+    res["calibration_bytes_per_unit"] = cal
+    kern = {}
+    for k in sorted(set(data["FETCH_SIZE"]) | set(data["WRITE_SIZE"])):
+        e = {}
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            v = data[cname].get(k, [])
+            if v:
+                e[cname + "_raw_avg"] = sum(x for x, _ in v) / len(v)
+                e[cname + "_bytes_avg"] = e[cname + "_raw_avg"] * cal.get(cname, 1024.0)
+                e["launches"] = len(v)
+        h = data["TCC_HIT_sum"].get(k, [])
+        m = data["TCC_MISS_sum"].get(k, [])
+        if h and m:
+            hs, ms = sum(x for x, _ in h), sum(x for x, _ in m)
+            e["l2_hit_rate"] = hs / max(hs + ms, 1.0)
+        if "FETCH_SIZE_bytes_avg" in e and "WRITE_SIZE_bytes_avg" in e:
+            e["hbm_bytes_per_launch"] = e["FETCH_SIZE_bytes_avg"] + e["WRITE_SIZE_bytes_avg"]
+        kern[k] = e
+    res["kernels"] = kern
+    s = json.dumps(res, indent=1)
+    print(s)
+    if outp:
+        open(outp, "w").write(s + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
