@@ -135,9 +135,74 @@ def approxConvBelief(fg, fctlabel, target, backend=None, seed=0, nullSurplus=0.0
     return (pts, bw, used) if return_mhidx else (pts, bw)
 
 
-def approxConv(fg, fctlabel, target, **kw):
-    """approxConv(dfg, fct, target) = getPoints(approxConvBelief(...))   ApproxConv.jl:47"""
-    return approxConvBelief(fg, fctlabel, target, **kw)[0]
+def findShortestPath(fg, frm, to):
+    """Shortest path over the bipartite variable/factor graph (unit edge weights), the role
+    `findShortestPathDijkstra` plays at ApproxConv.jl:100.  Returns [frm, ..., to]."""
+    import collections
+    isfct = lambda l: l in fg.factors
+    prev = {frm: None}
+    q = collections.deque([frm])
+    while q:
+        u = q.popleft()
+        if u == to:
+            break
+        nbrs = fg.getFactor(u).variables if isfct(u) else fg.ls(u)
+        for w in nbrs:
+            if w not in prev:
+                prev[w] = u
+                q.append(w)
+    if to not in prev:
+        raise ValueError(f"no path from {frm} to {to}")
+    path = [to]
+    while prev[path[-1]] is not None:
+        path.append(prev[path[-1]])
+    return path[::-1]
+
+
+def approxConvBeliefPath(fg, frm, target, backend=None, seed=0, path=None):
+    """approxConvBelief(dfg, from, target): the sequential chain of convolutions along the shortest
+    factor path, starting from the belief stored in `from` (a variable) or from a fresh prior
+    proposal (`from` a unary factor).  ApproxConv.jl:75-159.  Nothing in `fg` is modified: the chain
+    runs on device slots (the reference's temporary graph `tfg`); variables adjacent to the path
+    keep their `fg` beliefs (:114-115)."""
+    path = list(path) if path else findShortestPath(fg, frm, target)
+    if path[0] != frm:
+        raise ValueError("sanity check failing for shortest path function")
+    isfct = [l in fg.factors for l in path]
+    fcts = [l for l, f in zip(path, isfct) if f]
+    labels = []
+    for f in fcts:
+        for v in fg.getFactor(f).variables:
+            if v not in labels:
+                labels.append(v)
+    N = fg.solverParams.N
+    slot = {v: i for i, v in enumerate(labels)}
+    scratch = len(labels)
+    be, own = _make_backend(backend, N, scratch + 1)
+    try:
+        for v in labels:
+            var = fg.getVariable(v)
+            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+        for k, (l, f) in enumerate(zip(path, isfct)):
+            if not f:
+                continue
+            nxt = path[k + 1]
+            d = proposal_desc(fg, fg.getFactor(l), nxt, slot.__getitem__, scratch, op_seed(seed, PASS_UNIT, 0, k, 0))
+            be.run_proposals([d])
+            be.run_copies([abi.CopyDesc(scratch, slot[nxt])])
+        out = be.slot_read(slot[target], fg.getVariable(target).varType.manifold)
+    finally:
+        if own:
+            be.close()
+    return out
+
+
+def approxConv(fg, frm, target, **kw):
+    """approxConv(dfg, from, target) = getPoints(approxConvBelief(...))   ApproxConv.jl:47.  `from` is
+    a factor adjacent to `target` (direct request, :91-95) or any variable / prior factor (chain)."""
+    if frm in fg.factors and target in fg.getFactor(frm).variables:
+        return approxConvBelief(fg, frm, target, **kw)[0]
+    return approxConvBeliefPath(fg, frm, target, **kw)[0]
 
 
 def propagateBelief(fg, destlbl, factors=None, backend=None, seed=0, return_proposals=False):
@@ -195,6 +260,30 @@ def setValKDE(fg, sym, pts, bw, setinit=True):
     v.val, v.bw = np.array(pts, dtype=float), np.array(bw, dtype=float)
     if setinit:
         v.initialized = True
+
+
+def manikde(varType, pts, backend=None):
+    """manikde!(M, pts) -> (pts, bw): the automatic per-coordinate bandwidth of a point set
+    (call sites ApproxConv.jl:38,41, FGOSUtils.jl:118-128) through `nbp_run_bandwidth`."""
+    pts = np.asarray(pts, dtype=np.float64)
+    N = pts.shape[0]
+    be, own = _make_backend(backend, N, 1)
+    try:
+        be.slot_write(0, varType.manifold, pts, np.ones(varType.dim))
+        be.run_bandwidth([0], [varType.manifold])
+        out = be.slot_read(0, varType.manifold)
+    finally:
+        if own:
+            be.close()
+    return out
+
+
+def initVariable(fg, sym, pts, backend=None):
+    """initVariable!(dfg, sym, pts): fit the KDE bandwidth of `pts` and store the belief
+    (services/GraphInit.jl, setValKDE! at FactorGraph.jl:250-297).  N follows the point count."""
+    var = fg.getVariable(sym)
+    p, bw = manikde(var.varType, pts, backend=backend)
+    setValKDE(fg, sym, p, bw)
 
 
 def localProductAndUpdate(fg, sym, setkde=True, **kw):

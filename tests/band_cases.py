@@ -1,0 +1,236 @@
+"""Acceptance bands of the reference's own tests for the hot path, written once and
+run against both backends: the CPU oracle (`tests/test_oracle_reference_bands2.py`) and the HIP
+library on the GPU (`tests/test_gpu_reference_bands.py`).  Each case cites the reference test it
+restates.  The bands are the reference's; the graphs are rebuilt from the test descriptions."""
+import numpy as np
+
+from parity_utils import iif
+
+rng = np.random.default_rng
+
+
+def se2_near(pts, xy, theta, atol):
+    """count of SE(2) points (N x 6: t, R column-major) with ||p - q||_F-ish distance < atol, the role of
+    isapprox(M, p, q; atol) on SpecialEuclidean(2)"""
+    c, s = np.cos(theta), np.sin(theta)
+    q = np.array([xy[0], xy[1], c, s, -s, c])
+    return int((np.linalg.norm(pts - q, axis=1) < atol).sum())
+
+
+def se2_mean(pts):
+    th = np.arctan2(pts[:, 3].mean(), pts[:, 2].mean())
+    return pts[:, 0].mean(), pts[:, 1].mean(), th
+
+
+def case_forward_convolve(backend):
+    # test/testBasicForwardConvolve.jl:16-65 (IIF issue #477): conv, product with a measurement, conv
+    def forward(X0, Z, seed):
+        fg = iif.initfg(iif.SolverParams(N=100))
+        iif.addVariable(fg, "x0", iif.ContinuousScalar)
+        iif.initVariable(fg, "x0", X0, backend=backend)
+        iif.addVariable(fg, "x1", iif.ContinuousScalar)
+        iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(Z))
+        return iif.approxConv(fg, "x0x1f1", "x1", backend=backend, seed=seed)
+
+    r = rng(477)
+    X0 = r.normal(0, 0.1, (100, 1))
+    X1_ = forward(X0, iif.Normal(11, 1.0), 1)
+    # predX1 * measX1 : product of two KDEs through the variable seam
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    be = backend(100, 3)
+    try:
+        man = iif.ContinuousScalar.manifold
+        be.slot_write(0, man, X1_, np.ones(1))
+        be.slot_write(1, man, r.normal(9.5, 0.75, (100, 1)), np.ones(1))
+        be.run_bandwidth([0, 1], [man, man])
+        be.run_products([iif.product_desc(man, [0, 1], 2, 12345, 1)])
+        X1, _ = be.slot_read(2, man)
+    finally:
+        be.close()
+    assert 8.5 < X1.mean() < 11.5
+    X2 = forward(X1, iif.Normal(8, 2.0), 2)
+    assert X2.shape == (100, 1)
+    assert 15 < X2.mean() < 25
+
+
+def case_five_chain_spread(backend):
+    # test/testProductReproducable.jl:12-45
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for v in "abcde":
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+    iif.addFactor(fg, ["a"], iif.Prior(iif.Normal(0, 1)))
+    for u, v in zip("abcd", "bcde"):
+        iif.addFactor(fg, [u, v], iif.LinearRelative(iif.Normal(10, 1)))
+    iif.initAll(fg, backend=backend, seed=3)
+    iif.solveTree(fg, backend=backend, seed=4)
+    for k, (v, mt, lo, hi) in enumerate(zip("abcde", (3, 4, 4, 5, 5), (0.3, 0.5, 0.9, 1.2, 1.5), (2, 4, 6, 7, 8))):
+        p = fg.getVal(v)[:, 0]
+        assert abs(p.mean() - 10 * k) < mt, (v, p.mean())
+        assert lo < p.std(ddof=1) < hi, (v, p.std(ddof=1))
+
+
+def case_back_and_forth_spreads(backend):
+    # test/testProductReproducable.jl:52-99: 10 x (conv a->b, conv b->a): means stay, std grows above 3
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "a", iif.ContinuousScalar)
+    iif.addVariable(fg, "b", iif.ContinuousScalar)
+    iif.addFactor(fg, ["a", "b"], iif.LinearRelative(iif.Normal(10, 1)))
+    r = rng(52)
+    A = r.normal(0, 1, (100, 1))
+    B = 10 + r.normal(0, 1, (100, 1))
+    iif.initVariable(fg, "a", A, backend=backend)
+    iif.initVariable(fg, "b", B, backend=backend)
+    for i in range(10):
+        iif.initVariable(fg, "b", iif.approxConv(fg, "abf1", "b", backend=backend, seed=100 + 2 * i), backend=backend)
+        iif.initVariable(fg, "a", iif.approxConv(fg, "abf1", "a", backend=backend, seed=101 + 2 * i), backend=backend)
+    A_, B_ = fg.getVal("a")[:, 0], fg.getVal("b")[:, 0]
+    assert abs(A.mean()) < 1 and abs(A_.mean()) < 2
+    assert abs(B.mean() - 10) < 1 and abs(B_.mean() - 10) < 2
+    assert A.std(ddof=1) < 2 and 3 < A_.std(ddof=1)
+    assert B.std(ddof=1) < 2 and 3 < B_.std(ddof=1)
+
+
+def case_approxconv_kaess_chains(backend):
+    # test/testApproxConv.jl:40-81
+    fg = iif.generateGraph_Kaess(iif.SolverParams(N=100))
+    iif.initAll(fg, backend=backend, seed=5)  # the reference's graphinit on addFactor!
+    pts = iif.approxConv(fg, "x1f1", "x1", backend=backend, seed=6)
+    assert abs(pts.mean()) < 0.4 and 0.5 < pts.std(ddof=1) < 1.5
+    iif.initVariable(fg, "x1", pts, backend=backend)
+    pts = iif.approxConv(fg, "x1x2f1", "x2", backend=backend, seed=7)
+    assert abs(pts.mean()) < 0.7 and 0.7 < pts.std(ddof=1) < 2
+    pts = iif.approxConv(fg, "x1", "x3", backend=backend, seed=8)  # along a chain of variables
+    assert abs(pts.mean()) < 1.5 and 1.3 < pts.std(ddof=1) < 3.0
+    pts = iif.approxConv(fg, "x1f1", "l2", backend=backend, seed=9)  # from a prior down the chain
+    assert abs(pts.mean()) < 1.5 and 1.6 < pts.std(ddof=1) < 4.0
+
+
+def case_ccw_forward_reverse(backend):
+    # test/testCommonConvWrapper.jl:96-147: odo Normal(100, 1); forward lands in (90, 110), reverse in (-10, 10);
+    # the conv never modifies the stored beliefs
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.ContinuousEuclid(1))
+    iif.addVariable(fg, "x1", iif.ContinuousEuclid(1))
+    iif.initVariable(fg, "x0", np.zeros((100, 1)) + 1e-3 * rng(1).normal(size=(100, 1)), backend=backend)
+    iif.initVariable(fg, "x1", rng(2).uniform(size=(100, 1)), backend=backend)
+    iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(iif.Normal(100.0, 1.0)))
+    x0_before = fg.getVal("x0").copy()
+    pts = iif.approxConv(fg, "x0x1f1", "x1", backend=backend, seed=10)
+    assert 90.0 < pts.mean() < 110.0
+    assert -10.0 < fg.getVal("x0").mean() < 10.0
+    np.testing.assert_array_equal(fg.getVal("x0"), x0_before)
+    iif.initVariable(fg, "x1", 100 * np.ones((100, 1)) + 1e-3 * rng(3).normal(size=(100, 1)), backend=backend)
+    pts = iif.approxConv(fg, "x0x1f1", "x0", backend=backend, seed=11)
+    assert -10.0 < pts.mean() < 10.0
+    assert 90.0 < fg.getVal("x1").mean() < 110.0
+
+
+def case_conv_95_percent(backend):
+    # test/testMultithreaded.jl:14-37: 95 % of the convolved points within 5 of 10
+    N = 100
+    fg = iif.initfg(iif.SolverParams(N=N))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(0, 1)))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(iif.Normal(10.0, 1)))
+    iif.initAll(fg, backend=backend, seed=12)
+    pts = iif.approxConv(fg, "x0x1f1", "x1", backend=backend, seed=13)
+    assert 0.95 * N <= (np.abs(pts - 10.0) < 5.0).sum()
+
+
+def case_euclid_distance_1d(backend):
+    # test/testEuclidDistance.jl:9-41: bimodal at +-10, nothing in the middle
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(0, 1)))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0", "x1"], iif.EuclidDistance(iif.Normal(10, 1)))
+    iif.initAll(fg, backend=backend, seed=14)
+    iif.solveTree(fg, backend=backend, seed=15)
+    assert abs(fg.getVal("x0").mean()) < 1
+    pts = fg.getVal("x1")[:, 0]
+    N = pts.size
+    assert 0.3 * N < (pts > 5).sum()
+    assert 0.3 * N < (pts < -5).sum()
+    assert ((pts > -5) & (pts < 5)).sum() < 0.1 * N
+
+
+def case_euclid_distance_2d(backend):
+    # test/testEuclidDistance.jl:44-70: a ring of radius 10 around the origin
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.ContinuousEuclid(2))
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.MvNormal(np.zeros(2), np.diag([1.0, 1.0]))))
+    iif.addVariable(fg, "x1", iif.ContinuousEuclid(2))
+    iif.addFactor(fg, ["x0", "x1"], iif.EuclidDistance(iif.Normal(10, 1)))
+    iif.initAll(fg, backend=backend, seed=16)
+    iif.solveTree(fg, backend=backend, seed=17)
+    assert abs(fg.getVal("x0")[:, 0].mean()) < 1
+    r = np.linalg.norm(fg.getVal("x1"), axis=1)
+    assert 0.5 * r.size < ((r > 7) & (r < 13)).sum()
+
+
+def case_se2_hex(backend):
+    # test/testSpecialEuclidean2Mani.jl:164-204: hexagon of 6 odometry steps (10, 0, pi/3) from (10, 10, pi),
+    # a landmark seen from x0 and x6 closes the loop
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.SpecialEuclidean2)
+    iif.addFactor(fg, ["x0"], iif.ManifoldPrior(np.array([10.0, 10.0, np.pi]), iif.MvNormal(np.zeros(3), [0.1, 0.1, 0.01])))
+    for i in range(6):
+        iif.addVariable(fg, f"x{i+1}", iif.SpecialEuclidean2)
+        iif.addFactor(fg, [f"x{i}", f"x{i+1}"], iif.ManifoldFactor(iif.MvNormal([10.0, 0, np.pi / 3], [0.5, 0.5, 0.05])))
+    iif.addVariable(fg, "l1", iif.SpecialEuclidean2)
+    iif.addFactor(fg, ["x0", "l1"], iif.ManifoldFactor(iif.MvNormal([10.0, 0, 0], [0.1, 0.1, 0.01])))
+    iif.addFactor(fg, ["x6", "l1"], iif.ManifoldFactor(iif.MvNormal([10.0, 0, 0], [0.1, 0.1, 0.01])))
+    iif.initAll(fg, backend=backend, seed=18)
+    iif.solveTree(fg, backend=backend, seed=19)
+
+    def dist(v, xy, th):
+        x, y, t = se2_mean(fg.getVal(v))
+        dth = (t - th + np.pi) % (2 * np.pi) - np.pi
+        return np.sqrt((x - xy[0]) ** 2 + (y - xy[1]) ** 2 + 2 * dth * dth)  # Frobenius metric on R
+
+    assert dist("x0", (10.0, 10.0), np.pi) < 0.2
+    assert dist("x1", (0.0, 10.0), np.arctan2(-0.866, -0.5)) < 0.4
+    assert dist("x6", (10.0, 10.0), np.pi) < 0.5
+
+
+def case_se2_multihypo(backend):
+    # test/testSpecialEuclidean2Mani.jl:605-637: ManifoldFactor on [x0, x1a, x1b] multihypo [1, .5, .5]:
+    # x0 stays at the identity, more than 20 of 100 particles of each candidate land on (1, 2, pi/4)
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.SpecialEuclidean2)
+    iif.addFactor(fg, ["x0"], iif.ManifoldPrior(np.zeros(3), iif.MvNormal(np.zeros(3), [0.01, 0.01, 0.01])))
+    iif.addVariable(fg, "x1a", iif.SpecialEuclidean2)
+    iif.addVariable(fg, "x1b", iif.SpecialEuclidean2)
+    iif.addFactor(fg, ["x0", "x1a", "x1b"], iif.ManifoldFactor(iif.MvNormal([1, 2, np.pi / 4], [0.01, 0.01, 0.01])),
+                  multihypo=[1, 0.5, 0.5])
+    iif.initAll(fg, backend=backend, seed=20)
+    iif.solveTree(fg, backend=backend, seed=21)
+    x, y, t = se2_mean(fg.getVal("x0"))
+    assert np.sqrt(x * x + y * y + 2 * t * t) < 0.1
+    assert se2_near(fg.getVal("x1a"), (1.0, 2.0), np.pi / 4, 0.1) > 20
+    assert se2_near(fg.getVal("x1b"), (1.0, 2.0), np.pi / 4, 0.1) > 20
+
+
+def case_simple_mixture(backend):
+    # test/testMixtureLinearConditional.jl:135-200: Mixture(LinearRelative, [N(-1,.1), N(1,.1)], [.5,.5])
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(0.0, 0.1)))
+    iif.addFactor(fg, ["x0", "x1"], iif.Mixture(iif.LinearRelative, (iif.Normal(-1.0, 0.1), iif.Normal(1.0, 0.1)), [0.5, 0.5]))
+    iif.initAll(fg, backend=backend, seed=22)
+    iif.solveTree(fg, backend=backend, seed=23)
+    p0 = fg.getVal("x0")[:, 0]
+    assert abs(p0.mean()) < 0.1 and abs(p0.std() - 0.1) < 0.05
+    p1 = fg.getVal("x1")[:, 0]
+    pp, pn = p1[p1 >= 0], p1[p1 < 0]
+    assert pp.size > 10 and pn.size > 10
+    assert abs(pp.mean() - 1.0) < 0.1 and abs(pp.std() - 0.14) < 0.05
+    assert abs(pn.mean() + 1.0) < 0.1 and abs(pn.std() - 0.14) < 0.05
+
+
+CASES = [case_forward_convolve, case_five_chain_spread, case_back_and_forth_spreads, case_approxconv_kaess_chains,
+         case_ccw_forward_reverse, case_conv_95_percent, case_euclid_distance_1d, case_euclid_distance_2d,
+         case_se2_hex, case_se2_multihypo, case_simple_mixture]

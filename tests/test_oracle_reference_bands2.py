@@ -1,0 +1,42 @@
+"""CPU: the reference-test acceptance bands of tests/band_cases.py against the oracle."""
+import pytest
+
+import band_cases
+
+
+@pytest.mark.parametrize("case", band_cases.CASES, ids=lambda c: c.__name__)
+def test_band(case, oracle_backend):
+    case(oracle_backend)
+
+
+def test_residual_values():
+    """test/testApproxConv.jl:11-37: calcFactorResidualTemporary(LinearRelative{3}, z=[0,0,.5], (0, [0,0,1])) has
+    |sum| 0.5 (z dimension 3); plus the closed residual set of SURVEY a10 at hand-computed points."""
+    import ctypes as C
+    import os
+
+    import numpy as np
+
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so"))
+    dp = C.POINTER(C.c_double)
+    lib.orc_residual.restype = C.c_int32
+    lib.orc_residual.argtypes = [C.c_int32, C.c_int32, dp, dp, dp, dp]
+
+    def res(kind, man, z, a, b):
+        z, a, b = (np.ascontiguousarray(v, dtype=np.float64) for v in (z, a, b))
+        r = np.zeros(3)
+        n = lib.orc_residual(kind, man, z.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), r.ctypes.data_as(dp))
+        return r[:n]
+
+    F_LINREL, F_CIRC, F_SE2, F_DIST = 3, 4, 5, 6
+    E1, E2, E3, CIRC, SE2 = 1, 2, 3, 4, 5
+    r = res(F_LINREL, E3, [0, 0, 0.5], np.zeros(3), [0, 0, 1.0])
+    assert r.size == 3 and abs(np.abs(r).sum() - 0.5) < 1e-10
+    # CircularCircular: wraps through +-pi
+    assert abs(res(F_CIRC, CIRC, [0.2], [3.1], [-3.1])[0] - (3.3 - 2 * np.pi + 3.1)) < 1e-12
+    # SE(2): x1 = x0 * exp(z) exactly -> zero residual
+    a = np.array([1.0, 2.0, np.pi / 2])
+    z = np.array([1.0, 0.0, np.pi / 2])
+    b = np.array([1.0, 3.0, np.pi])
+    np.testing.assert_allclose(res(F_SE2, SE2, z, a, b), [0, 0, 0], atol=1e-12)
+    assert abs(res(F_DIST, E2, [5.0], [0, 0], [3, 4])[0]) < 1e-12
