@@ -534,36 +534,43 @@ __device__ __forceinline__ void solve_particle(int kind, int manifold, const dou
 // unordered pair is computed once, added to lane i's own row sum (register) and to row j's
 // accumulator acc[wave][j] in LDS (one private accumulator row per wave: lanes of a wave hit
 // consecutive j -> conflict-free; a wave's LDS ops execute in order -> deterministic sums).
+typedef __attribute__((address_space(3))) double nbp_lds_double;
+__device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
+
 template <bool CIRC>
-__device__ __forceinline__ double loo_symmetric(const double *x, int N, int i, int t0, int t1, double xi, double c, double *accw,
+__device__ __forceinline__ double loo_symmetric(const double *x, int i, int t0, int t1, double xi, double c, double *accw,
                                                 const double *tab) {
+  // x and the accumulator row are stored twice over ([0,2N)): partner i+t never wraps, so both
+  // addresses are one base register plus an immediate that advances with t
+  // The partner accumulation is an LDS atomic without return (ds_add_f64): lane i's slot at step t+1
+  // is lane i+1's slot at step t, so plain read-modify-writes of consecutive steps would have to stay
+  // strictly ordered (and exposed to the LDS latency); the atomic is applied by the LDS unit in the
+  // wave's program order, so sums stay deterministic (one private row per wave).
+  const double *xp = x + i;
+  nbp_lds_double *ap = (nbp_lds_double *)(accw + i);
   double s0 = 0, s1 = 0;
   int t = t0;
   for (; t + 1 < t1; t += 2) {
-    int j0 = i + t, j1 = i + t + 1;
-    j0 -= (j0 >= N) ? N : 0;
-    j1 -= (j1 >= N) ? N : 0;
-    double d0 = xi - x[j0], d1 = xi - x[j1];
+    double d0 = xi - xp[t], d1 = xi - xp[t + 1];
     if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); }
     const double e0 = exp_nonpos(-d0 * d0 * c, tab), e1 = exp_nonpos(-d1 * d1 * c, tab);
     s0 += e0;
     s1 += e1;
-    accw[j0] += e0;
-    accw[j1] += e1;
+    lds_add(ap + t, e0);
+    lds_add(ap + t + 1, e1);
   }
   if (t < t1) {
-    int j0 = i + t;
-    j0 -= (j0 >= N) ? N : 0;
-    double d0 = xi - x[j0];
+    double d0 = xi - xp[t];
     if (CIRC) d0 = wrap_pi(d0);
     const double e0 = exp_nonpos(-d0 * d0 * c, tab);
     s0 += e0;
-    accw[j0] += e0;
+    lds_add(ap + t, e0);
   }
   return s0 + s1;
 }
 
-// LDS: part[P][Npad] row-sum partials, acc[NW][N] per-wave partner accumulators.
+// LDS: x[2N] (the coordinate, twice), part[P][Npad] row-sum partials, acc[NW][2N] per-wave partner
+// accumulators (entry j and j+N both belong to point j).
 // `acc` must be all-zero on entry and is all-zero again on exit (the combine step clears what it
 // reads), so one evaluation costs three barriers: compute | combine+log | cross-wave sum.
 __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red,
@@ -577,15 +584,15 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     const int H = (N - 1) / 2;  // full partner steps
     const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
     const double xi = x[i];
-    double *accw = acc + w * N;
-    double s = circ ? loo_symmetric<true>(x, N, i, t0, t1, xi, inv2h2, accw, tab) : loo_symmetric<false>(x, N, i, t0, t1, xi, inv2h2, accw, tab);
+    double *accw = acc + w * 2 * N;
+    double s = circ ? loo_symmetric<true>(x, i, t0, t1, xi, inv2h2, accw, tab) : loo_symmetric<false>(x, i, t0, t1, xi, inv2h2, accw, tab);
     if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair
       const int j = i + N / 2;
       double d = xi - x[j];
       if (circ) d = wrap_pi(d);
       const double e = exp_nonpos(-d * d * inv2h2, tab);
       s += e;
-      accw[j] += e;
+      lds_add((nbp_lds_double *)(accw + j), e);
     }
     part[p * Npad + i] = s;
   }
@@ -594,8 +601,10 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   if (i < N) {
     double s = part[p * Npad + i];
     for (int q = p; q < NW; q += P) {
-      s += acc[q * N + i];
-      acc[q * N + i] = 0.0;
+      double *a = acc + q * 2 * N + i;
+      s += a[0] + a[N];
+      a[0] = 0.0;
+      a[N] = 0.0;
     }
     part[p * Npad + i] = s;
   }
@@ -630,7 +639,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   }
   {  // per-wave partner accumulators start at zero (neg_loo_ll keeps them zero between calls)
     double *acc = part + (blockDim.x / Npad) * Npad;
-    for (int q = threadIdx.x; q < (int)(blockDim.x >> 6) * N; q += blockDim.x) acc[q] = 0.0;
+    for (int q = threadIdx.x; q < (int)(blockDim.x >> 6) * 2 * N; q += blockDim.x) acc[q] = 0.0;
   }
   double minm = block_min(mn, red);
   lo = block_min(lo, red);

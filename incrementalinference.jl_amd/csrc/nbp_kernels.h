@@ -228,9 +228,9 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
     return;
   }
   const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + N, *red = part + P * Npad + (blockDim.x >> 6) * N, *tab = red + NBP_RED;
+  double *X = smem, *part = smem + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N, *tab = red + NBP_RED;
   nbp_exp_tab_init(tab);
-  if (n < N) X[n] = s[k * N + n];
+  if (n < N) X[n] = X[n + N] = s[k * N + n];
   __syncthreads();
   double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red, tab, ctr);
   if (n == 0) s[3 * N + k] = h;
@@ -248,9 +248,9 @@ nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *are
   lcv_slot_coordinate(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
 }
 
-// X[N] | part[P][Npad] | acc[NW][N] | red | exp table     (NW = P*Npad/64 waves)
+// X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
 static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
-  return ((size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * N + NBP_RED + NBP_EXPTAB) * 8;
+  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_EXPTAB) * 8;
 }
 
 __global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S) {
