@@ -91,6 +91,12 @@ typedef struct nbp_proposal_desc {
                                  mhidx[N] (exact-match tests); -1: sample internally           */
   int32_t mhidx_out;          /* >=0: offset in the side buffer where the used mhidx[N] is stored */
   int32_t skip_bandwidth;     /* 1: do not fit the bandwidth (caller discards it)              */
+  int32_t partial_mask;       /* 0: full factor.  Otherwise bit k set = tangent coordinate k is in the
+                                 factor's `.partial` tuple (ccw.partialDims, CalcFactor.jl:369-486):
+                                 the measurement has popcount(mask) dimensions; a partial prior sets
+                                 only those coordinates (setPointPartial!, EvalFactor.jl:457-538), a
+                                 partial relative factor solves and inflates only them (:184-198);
+                                 all other coordinates keep the target's current values          */
   double multihypo[NBP_MAXV]; /* parsed Categorical p: certain variables carry 0.0
                                  (services/FactorGraph.jl:639-651)                            */
   double nullhypo;            /* max(ccw.nullhypo, nullSurplus)   EvalFactor.jl:352            */
@@ -112,7 +118,11 @@ typedef struct nbp_product_desc {
   int32_t out_slot;            /* belief slot that receives points + bandwidth                 */
   int32_t in_slot[NBP_MAXF];   /* proposal slots                                               */
   int32_t labels_out;          /* >=0: offset in the int32 side buffer for labels[N][nfactors] */
-  int32_t pad_;
+  int32_t old_slot;            /* oldPoints (GraphProductOperations.jl:39-45): coordinates that no input
+                                  density informs are copied from this slot; -1 when every input is full */
+  uint8_t in_partial[NBP_MAXF]; /* per input density: 0 = full, else the coordinate bit mask of a partial
+                                  density (AMP.marginal(propBel, pardims), ApproxConv.jl:287-291): it
+                                  multiplies into the product on those coordinates only              */
   uint64_t seed;
 } nbp_product_desc;
 

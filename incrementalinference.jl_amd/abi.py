@@ -32,6 +32,7 @@ class ProposalDesc(C.Structure):
         ("mhidx_in", C.c_int32),
         ("mhidx_out", C.c_int32),
         ("skip_bandwidth", C.c_int32),
+        ("partial_mask", C.c_int32),
         ("multihypo", C.c_double * MAXV),
         ("nullhypo", C.c_double),
         ("inflation", C.c_double),
@@ -49,7 +50,8 @@ class ProductDesc(C.Structure):
         ("out_slot", C.c_int32),
         ("in_slot", C.c_int32 * MAXF),
         ("labels_out", C.c_int32),
-        ("pad_", C.c_int32),
+        ("old_slot", C.c_int32),
+        ("in_partial", C.c_uint8 * MAXF),
         ("seed", C.c_uint64),
     ]
 

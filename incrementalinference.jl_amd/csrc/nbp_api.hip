@@ -285,6 +285,14 @@ static nbp_status check_proposals(nbp_ctx *c, const nbp_proposal_desc *d, int n)
     if (p.factor_kind == NBP_F_LINREL && p.manifold > NBP_EUCLID3) return fail(NBP_ERR_ARG, "LinearRelative needs Euclid variables");
     if (p.mhidx_in >= 0 && p.mhidx_in + c->N > c->side_ints) return fail(NBP_ERR_RANGE, "proposal: mhidx_in");
     if (p.mhidx_out >= 0 && p.mhidx_out + c->N > c->side_ints) return fail(NBP_ERR_RANGE, "proposal: mhidx_out");
+    if (p.partial_mask) {
+      const int D = manifold_dim_h(p.manifold);
+      if (p.partial_mask < 0 || p.partial_mask >= (1 << D)) return fail(NBP_ERR_RANGE, "proposal: partial_mask");
+      if (p.factor_kind == NBP_F_LINREL) {
+        if (__builtin_popcount(p.partial_mask) != 1) return fail(NBP_ERR_ARG, "partial LinearRelative: one partial coordinate");
+      } else if (p.factor_kind != NBP_F_PRIOR)
+        return fail(NBP_ERR_ARG, "proposal: partial_mask is supported for Prior and LinearRelative factors");
+    }
     if (p.has_multihypo) {
       int ncert = 0;
       for (int k = 0; k < p.nvars; k++) ncert += (p.multihypo[k] == 0.0);
@@ -303,6 +311,16 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
     for (int k = 0; k < p.nfactors; k++)
       if (p.in_slot[k] < 0 || p.in_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "product: in_slot");
     if (p.labels_out >= 0 && p.labels_out + c->N * p.nfactors > c->side_ints) return fail(NBP_ERR_RANGE, "product: labels_out");
+    {
+      const int D = manifold_dim_h(p.manifold);
+      bool any = false;
+      for (int k = 0; k < p.nfactors; k++) {
+        if (p.in_partial[k] >= (1 << D)) return fail(NBP_ERR_RANGE, "product: in_partial");
+        any |= (p.in_partial[k] != 0);
+      }
+      if (any && D < 2) return fail(NBP_ERR_ARG, "product: partial densities need a variable of dimension >= 2");
+      if (any && (p.old_slot < 0 || p.old_slot >= c->n_slots)) return fail(NBP_ERR_RANGE, "product: old_slot");
+    }
     size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->Npad, c->threads, c->Npad);
     if (p.nfactors > 1 && lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: F*D*N exceeds the 160 KiB LDS");
   }

@@ -148,7 +148,8 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
   }
 #undef NBP_FMA_S
   const double y = tab[n & 31] * p;
-  return __hiloint2double(__double2hiint(y) + ((n >> 5) << 20), __double2loint(y));
+  // 2^(n>>5): add (n>>5)<<20 to the high word == ((n & ~31) << 15), one v_and + one v_lshl_add
+  return __hiloint2double(__double2hiint(y) + ((n & ~31) << 15), __double2loint(y));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,25 +549,30 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int i, int t0, 
   // wave's program order, so sums stay deterministic (one private row per wave).
   const double *xp = x + i;
   nbp_lds_double *ap = (nbp_lds_double *)(accw + i);
-  double s0 = 0, s1 = 0;
-  int t = t0;
-  for (; t + 1 < t1; t += 2) {
-    double d0 = xi - xp[t], d1 = xi - xp[t + 1];
-    if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); }
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int t = t0;  // t0, t1 are wave-uniform (scalar loop control)
+  for (; t + 3 < t1; t += 4) {
+    double d0 = xi - xp[t], d1 = xi - xp[t + 1], d2 = xi - xp[t + 2], d3 = xi - xp[t + 3];
+    if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); d2 = wrap_pi(d2); d3 = wrap_pi(d3); }
     const double e0 = exp_nonpos(-d0 * d0 * c, tab), e1 = exp_nonpos(-d1 * d1 * c, tab);
+    const double e2 = exp_nonpos(-d2 * d2 * c, tab), e3 = exp_nonpos(-d3 * d3 * c, tab);
     s0 += e0;
     s1 += e1;
+    s2 += e2;
+    s3 += e3;
     lds_add(ap + t, e0);
     lds_add(ap + t + 1, e1);
+    lds_add(ap + t + 2, e2);
+    lds_add(ap + t + 3, e3);
   }
-  if (t < t1) {
+  for (; t < t1; t++) {
     double d0 = xi - xp[t];
     if (CIRC) d0 = wrap_pi(d0);
     const double e0 = exp_nonpos(-d0 * d0 * c, tab);
     s0 += e0;
     lds_add(ap + t, e0);
   }
-  return s0 + s1;
+  return (s0 + s1) + (s2 + s3);
 }
 
 // LDS: x[2N] (the coordinate, twice), part[P][Npad] row-sum partials, acc[NW][2N] per-wave partner
@@ -582,7 +588,7 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   double *acc = part + P * Npad;
   if (i < N) {
     const int H = (N - 1) / 2;  // full partner steps
-    const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
+    const int t0 = __builtin_amdgcn_readfirstlane(1 + (p * H) / P), t1 = __builtin_amdgcn_readfirstlane(1 + ((p + 1) * H) / P);
     const double xi = x[i];
     double *accw = acc + w * 2 * N;
     double s = circ ? loo_symmetric<true>(x, i, t0, t1, xi, inv2h2, accw, tab) : loo_symmetric<false>(x, i, t0, t1, xi, inv2h2, accw, tab);

@@ -39,14 +39,17 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
 }
 
 // addEntropyOnManifold!, EvalFactor.jl:95-132
-__device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int n, double spread, uint64_t seed, int kbase) {
+// `mask`: the coordinates that receive entropy (the `p` argument, :99,114); 0 = all
+__device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int n, double spread, uint64_t seed, int kbase,
+                                            int mask = 0) {
   double u0, u1, u2 = 0, u3 = 0;
   uniform_pair(seed, n, PURP_ENTROPY, kbase, u0, u1);
   if (D > 2) uniform_pair(seed, n, PURP_ENTROPY, kbase + 1, u2, u3);
+  if (mask == 0) mask = 7;
   double v0 = x[0] + spread * (u0 - 0.5);
-  x[0] = is_circ(manifold, 0) ? wrap_pi(v0) : v0;
-  if (D > 1) x[1] = x[1] + spread * (u1 - 0.5);
-  if (D > 2) {
+  if (mask & 1) x[0] = is_circ(manifold, 0) ? wrap_pi(v0) : v0;
+  if (D > 1 && (mask & 2)) x[1] = x[1] + spread * (u1 - 0.5);
+  if (D > 2 && (mask & 4)) {
     double v2 = x[2] + spread * (u2 - 0.5);
     x[2] = is_circ(manifold, 2) ? wrap_pi(v2) : v2;
   }
@@ -116,7 +119,16 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     if (live) {
       double x[3] = {X[n], X[N + n], X[2 * N + n]};
       if (mh[n] == 1) {
-        if (kind == NBP_F_PRIOR) {
+        if (kind == NBP_F_PRIOR && d->partial_mask) {
+          // partial prior: setPointPartial! on the partial coordinates only (:457-538)
+          const int pmk = d->partial_mask;
+          double z[3];
+          sample_measurement(d, n, __popc(pmk & 7), z);
+          int pk = 0;
+          if (pmk & 1) { x[0] = is_circ(M, 0) ? wrap_pi(z[0]) : z[0]; pk = 1; }
+          if (pmk & 2) { x[1] = z[pk]; pk++; }
+          if (pmk & 4) { const double v = (pk == 0) ? z[0] : (pk == 1 ? z[1] : z[2]); x[2] = is_circ(M, 2) ? wrap_pi(v) : v; }
+        } else if (kind == NBP_F_PRIOR) {
           double z[3];
           sample_measurement(d, n, D, z);
           x[0] = is_circ(M, 0) ? wrap_pi(z[0]) : z[0];
@@ -139,14 +151,17 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           }
         }
       } else {
-        add_entropy(M, D, x, n, spread, d->seed, 0);  // :476
+        add_entropy(M, D, x, n, spread, d->seed, 0, d->partial_mask);  // :476, partialCoords :532
       }
       for (int k = 0; k < 3; k++) X[k * N + n] = x[k];
     }
     __syncthreads();
   } else {
     // evalPotentialSpecific(relative), EvalFactor.jl:321-395
-    const int zdim = (kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1);
+    // a partial relative factor (one partial coordinate, validated on the host) measures, inflates
+    // and solves that coordinate only (EvalFactor.jl:184-198, NumericalCalculations.jl:424)
+    const int pmask = d->partial_mask, pdim = pmask ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;
+    const int zdim = pmask ? 1 : ((kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1));
     double z[3] = {0, 0, 0};
     if (live) sample_measurement(d, n, zdim, z);  // sampleFactor!, CalcFactor.jl:578
     const int sf1 = d->sfidx + 1;
@@ -173,8 +188,16 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           __syncthreads();
           if (myh == hyp) {
             double x[3] = {X[n], X[N + n], X[2 * N + n]};
-            add_entropy(M, D, x, n, spread, d->seed, (g * 8 + c) * 2);
-            solve_particle(kind, M, z, oth, solve_b, x, n_solves, n_nonconv, n_nan, n_evals);  // approxConvOnElements!
+            add_entropy(M, D, x, n, spread, d->seed, (g * 8 + c) * 2, pmask);
+            if (pdim >= 0) {
+              double x1[3] = {pdim == 0 ? x[0] : (pdim == 1 ? x[1] : x[2]), 0, 0};
+              const double o1[3] = {pdim == 0 ? oth[0] : (pdim == 1 ? oth[1] : oth[2]), 0, 0};
+              solve_particle(NBP_F_LINREL, NBP_EUCLID1, z, o1, solve_b, x1, n_solves, n_nonconv, n_nan, n_evals);
+              if (pdim == 0) x[0] = x1[0];
+              else if (pdim == 1) x[1] = x1[0];
+              else x[2] = x1[0];
+            } else
+              solve_particle(kind, M, z, oth, solve_b, x, n_solves, n_nonconv, n_nan, n_evals);  // approxConvOnElements!
             X[n] = x[0];
             if (D > 1) X[N + n] = x[1];
             if (D > 2) X[2 * N + n] = x[2];
@@ -310,7 +333,8 @@ __host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return (size_t)3 * 
 // KD-tree permutation of one density: median split of the widest coordinate, by rank counting
 // inside each segment (P helper lanes per position, no sort network).
 template <int D>
-__device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, int Npad, const nbp_levels &T, double *smem) {
+__device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, int Npad, const nbp_levels &T, double *smem,
+                                         int mask /* coordinates the density informs */) {
   const int tid = threadIdx.x, TB = blockDim.x, P = TB / Npad, s = tid % Npad, sub = tid / Npad;
   double *raw = smem;                   // [D][N]
   double *ext = raw + (size_t)D * N;    // [3*Npad]
@@ -347,7 +371,7 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
         double bext = -1.0;
 #pragma unroll
         for (int k = 0; k < D; k++)
-          if (ext[z * D + k] > bext) { bext = ext[z * D + k]; best = k; }
+          if (((mask >> k) & 1) && ext[z * D + k] > bext) { bext = ext[z * D + k]; best = k; }
         bdim[z] = best;
       }
       __syncthreads();
@@ -409,10 +433,11 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
   if (d->nfactors == 1 || j >= d->nfactors) return;
   const double *x = arena + S * d->in_slot[j];
   double *wsj = ws + (size_t)(p * NBP_MAXF + j) * nbp_kd_ws_doubles(N);
+  const int mask = d->in_partial[j] ? d->in_partial[j] : 7;
   switch (mani_dim(d->manifold)) {
-  case 1: kd_build<1>(x, wsj, N, Npad, T, smem); break;
-  case 2: kd_build<2>(x, wsj, N, Npad, T, smem); break;
-  default: kd_build<3>(x, wsj, N, Npad, T, smem); break;
+  case 1: kd_build<1>(x, wsj, N, Npad, T, smem, 1); break;
+  case 2: kd_build<2>(x, wsj, N, Npad, T, smem, mask); break;
+  default: kd_build<3>(x, wsj, N, Npad, T, smem, mask); break;
   }
 }
 
@@ -440,7 +465,11 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Np
   return ints0 * 8 + ((size_t)F * SPB + SPB) * 4;
 }
 
-template <int MANI>
+// PARTIAL: some input density is partial (AMP.marginal(propBel, pardims), ApproxConv.jl:287-291): a
+// density enters the conditionals and the final draw on its own coordinates only; a coordinate that
+// no density informs keeps the old point (GraphProductOperations.jl:39-45).  Separate instantiation so
+// that the all-full path carries no masks.
+template <int MANI, bool PARTIAL>
 __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int N, int Npad,
                                              int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
@@ -510,6 +539,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         const double *mj = lm + j * D * N, *vj = lv + j * D * N;
         const bool leaf = (l == T.L);
         double linv[D];
+        bool use[D];  // PARTIAL: coordinates informed by density j and by at least one other
+#pragma unroll
+        for (int k = 0; k < D; k++) use[k] = true;
+        const int pmj = PARTIAL ? (d->in_partial[j] ? d->in_partial[j] : 7) : 7;
         auto node_w = [&](int z, double &a, double &g) {
           double t[D], v[D];
 #pragma unroll
@@ -518,6 +551,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             if (circ[k]) tmp = wrap_pi(tmp);
             t[k] = tmp * tmp;
             v[k] = vj[k * N + z] + vn[k];
+            if (PARTIAL && !use[k]) { t[k] = 0.0; v[k] = 1.0; }
           }
           if (leaf) {
             double q = 0;
@@ -542,6 +576,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             double prec = 0, acc = 0, ss = 0, sc = 0;
             for (int q = 0; q < F; q++) {
               if (q == j) continue;
+              if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
               const int iq = ind[q * SPB + sl];
               const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
               prec += 1.0 / vq;
@@ -553,12 +588,16 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               } else
                 acc += mq / vq;
             }
+            if (PARTIAL) {
+              use[k] = ((pmj >> k) & 1) && prec > 0;
+              if (!use[k]) prec = 1.0;
+            }
             vn[k] = 1.0 / prec;
             mn[k] = circ[k] ? atan2(ss, sc) : acc * vn[k];
           }
           if (leaf) {
 #pragma unroll
-            for (int k = 0; k < D; k++) linv[k] = 1.0 / (h2[j * 3 + k] + vn[k]);
+            for (int k = 0; k < D; k++) linv[k] = (PARTIAL && !use[k]) ? 0.0 : 1.0 / (h2[j * 3 + k] + vn[k]);
           }
           double ub;
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
@@ -691,6 +730,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     for (int k = 0; k < D; k++) {
       double prec = 0, acc = 0, ss = 0, sc = 0;
       for (int q = 0; q < F; q++) {
+        if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
         const int iq = ind[q * SPB + sl];
         const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
         prec += 1.0 / vq;
@@ -701,6 +741,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           sc += cs_ / vq;
         } else
           acc += mq / vq;
+      }
+      if (PARTIAL && !(prec > 0)) {  // uninformed coordinate: oldPoints
+        res[k] = (d->old_slot >= 0) ? arena[S * d->old_slot + k * N + s] : 0.0;
+        continue;
       }
       const double mu = circ[k] ? atan2(ss, sc) : acc / prec;
       const double v = mu + sqrt(1.0 / prec) * nn[k];
@@ -731,12 +775,22 @@ nbp_product_kernel(const nbp_product_desc *descs, double *arena, const double *w
     if (d->labels_out >= 0 && threadIdx.x < N) side[d->labels_out + threadIdx.x] = threadIdx.x;
     return;
   }
+  bool partial = false;
+  for (int j = 0; j < d->nfactors; j++) partial |= (d->in_partial[j] != 0);
+  if (partial) {  // validated on the host: D >= 2
+    switch (d->manifold) {
+    case NBP_EUCLID2: product_body<NBP_EUCLID2, true>(d, arena, ws, N, Npad, S, side, T, smem); break;
+    case NBP_EUCLID3: product_body<NBP_EUCLID3, true>(d, arena, ws, N, Npad, S, side, T, smem); break;
+    default: product_body<NBP_SE2, true>(d, arena, ws, N, Npad, S, side, T, smem); break;
+    }
+    return;
+  }
   switch (d->manifold) {
-  case NBP_EUCLID1: product_body<NBP_EUCLID1>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  case NBP_EUCLID2: product_body<NBP_EUCLID2>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  case NBP_EUCLID3: product_body<NBP_EUCLID3>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  case NBP_CIRCULAR: product_body<NBP_CIRCULAR>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  default: product_body<NBP_SE2>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID1: product_body<NBP_EUCLID1, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID2: product_body<NBP_EUCLID2, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID3: product_body<NBP_EUCLID3, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  default: product_body<NBP_SE2, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
   }
 }
 

@@ -125,6 +125,40 @@ class LinearRelative(_Factor):
         self.Z = Z
 
 
+def _partial_mask(partial, dim):
+    """`.partial` tuple of 1-based coordinate indices (the reference's convention) -> bit mask"""
+    partial = tuple(int(p) for p in partial)
+    if not partial or sorted(set(partial)) != list(partial) or partial[0] < 1 or partial[-1] > dim:
+        raise ValueError(f"partial must be increasing 1-based coordinate indices within 1..{dim}: {partial}")
+    m = 0
+    for p in partial:
+        m |= 1 << (p - 1)
+    return m
+
+
+class PartialPrior(Prior):
+    """PartialPrior(varType, Z, partial): a prior on the coordinates `partial` (1-based) only
+    (Factors/PartialPrior.jl; evaluation at EvalFactor.jl:457-538).  dim(Z) == len(partial)."""
+
+    def __init__(self, varType, Z, partial):
+        self.Z, self.partial = Z, tuple(partial)
+        self.partial_mask = _partial_mask(partial, varType.dim)
+        if len(Z.mean_sqrtcov()[0]) != len(self.partial):
+            raise ValueError("PartialPrior: dim(Z) must equal len(partial)")
+
+
+class PartialLinearRelative(LinearRelative):
+    """r = z - (x2[k] - x1[k]) on one coordinate k = partial[0]: the `DevelopPartialPairwise` factor of
+    test/testpartialconstraint.jl:31-45 (`.partial` relative factors solve, and inflate, only their
+    partial coordinates: EvalFactor.jl:184-198, NumericalCalculations.jl:424)."""
+
+    def __init__(self, varType, Z, partial=(2,)):
+        self.Z, self.partial = Z, tuple(partial)
+        if len(self.partial) != 1:
+            raise ValueError("PartialLinearRelative supports one partial coordinate")
+        self.partial_mask = _partial_mask(partial, varType.dim)
+
+
 class CircularCircular(_Factor):
     """CircularCircular(Z)   (Factors/Circular.jl:24-28)"""
     kind, zdim = abi.F_CIRCULAR, 1

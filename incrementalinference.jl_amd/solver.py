@@ -45,6 +45,7 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     d.inflate_cycles = sp.inflateCycles if inflateCycles is None else inflateCycles
     d.mhidx_in, d.mhidx_out = mhidx_in, mhidx_out
     d.skip_bandwidth = int(skip_bandwidth)
+    d.partial_mask = getattr(fnc, "partial_mask", 0)
     d.inflation = fct.inflation
     d.spread_nh = sp.spreadNH
     d.nullhypo = max(fct.nullhypo, nullSurplus)  # EvalFactor.jl:352
@@ -76,13 +77,24 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     return d
 
 
-def product_desc(manifold, in_slots, out_slot, seed, niter=1, labels_out=-1):
+def product_desc(manifold, in_slots, out_slot, seed, niter=1, labels_out=-1, partials=None, old_slot=-1):
+    """AMP.manifoldProduct(dens, M; Niter, oldPoints) descriptor.  `partials[i]` = coordinate bit mask of
+    a partial input density (0 = full); coordinates no density informs come from `old_slot`."""
     d = abi.ProductDesc()
     d.manifold, d.nfactors, d.niter, d.out_slot = manifold, len(in_slots), niter, out_slot
     for i, s in enumerate(in_slots):
         d.in_slot[i] = s
+    d.old_slot = -1
+    if partials is not None and any(partials):
+        for i, m in enumerate(partials):
+            d.in_partial[i] = m
+        d.old_slot = old_slot
     d.labels_out, d.seed = labels_out, seed
     return d
+
+
+def _partials(fcts):
+    return [getattr(f.fnc, "partial_mask", 0) for f in fcts]
 
 
 def _null_surplus(fg, factors):
@@ -235,7 +247,8 @@ def propagateBelief(fg, destlbl, factors=None, backend=None, seed=0, return_prop
         be.run_proposals(descs)
         out = nv + len(fcts)
         be.run_products([product_desc(man, [nv + i for i in range(len(fcts))], out,
-                                      op_seed(seed, PASS_UNIT, 0, 0, PRODUCT_ID), sp.productNiter)])
+                                      op_seed(seed, PASS_UNIT, 0, 0, PRODUCT_ID), sp.productNiter,
+                                      partials=_partials(fcts), old_slot=slot[destlbl])])
         pts, bw = be.slot_read(out, man)
         props = [be.slot_read(nv + i, man) for i in range(len(fcts))] if return_proposals else None
     finally:
@@ -371,7 +384,8 @@ def initAll(fg, backend=None, seed=0):
                     props.append(proposal_desc(fg, f, sym, slot.__getitem__, base + i,
                                                op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i]))
                 prods.append(product_desc(fg.getVariable(sym).varType.manifold, [base + i for i in range(len(fcts))],
-                                          slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter))
+                                          slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter,
+                                          partials=_partials(fcts), old_slot=slot[sym]))
             stages.append((abi.STAGE_PROPOSALS, props))
             stages.append((abi.STAGE_PRODUCTS, prods))
         prog = be.program(stages)
@@ -493,7 +507,8 @@ class TreeProgram:
                  for i, f in enumerate(fcts)]
         man = fg.getVariable(v).varType.manifold
         prod = product_desc(man, [base + i for i in range(len(fcts))], out_slot,
-                            op_seed(self.seed, passid, cid, step, PRODUCT_ID), sp.productNiter)
+                            op_seed(self.seed, passid, cid, step, PRODUCT_ID), sp.productNiter,
+                            partials=_partials(fcts), old_slot=slot_of(v))
         self._account(man, sum(0 if f.fnc.is_prior and not isinstance(f.fnc, MsgPrior) else 1 for f in fcts))
         return props, prod
 

@@ -678,12 +678,14 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
 }
 
 /* addEntropyOnManifold!, EvalFactor.jl:95-132 */
-static void add_entropy(int manifold, double *X, int N, int n, double spread, uint64_t seed, int kbase) {
+static void add_entropy(int manifold, double *X, int N, int n, double spread, uint64_t seed, int kbase, int mask) {
+  /* mask: coordinates that receive entropy (the `p` argument, :99,114); 0 = all */
   int D = mani_dim(manifold);
   double u[4];
   orc_uniform_pair(seed, n, PURP_ENTROPY, kbase, &u[0], &u[1]);
   if (D > 2) orc_uniform_pair(seed, n, PURP_ENTROPY, kbase + 1, &u[2], &u[3]);
   for (int d = 0; d < D; d++) {
+    if (mask && !((mask >> d) & 1)) continue;
     double v = X[d * N + n] + spread * (u[d] - 0.5);
     X[d * N + n] = is_circ(manifold, d) ? orc_wrap(v) : v;
   }
@@ -738,7 +740,15 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     double spread = d->spread_nh * orc_std_basic_spread(d->manifold, X, N); /* :464 */
     for (int n = 0; n < N; n++) {
       if (mhidx[n] == 1) {
-        if (d->factor_kind == NBP_F_PRIOR) {
+        if (d->factor_kind == NBP_F_PRIOR && d->partial_mask) {
+          /* partial prior: setPointPartial! on the partial coordinates only, :457-538 */
+          double z[3];
+          int zd = 0, pk = 0;
+          for (int k = 0; k < D; k++) zd += (d->partial_mask >> k) & 1;
+          sample_measurement(d, n, zd, z, 0);
+          for (int k = 0; k < D; k++)
+            if ((d->partial_mask >> k) & 1) { X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[pk]) : z[pk]; pk++; }
+        } else if (d->factor_kind == NBP_F_PRIOR) {
           double z[3];
           sample_measurement(d, n, D, z, 0);
           for (int k = 0; k < D; k++) X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[k]) : z[k];
@@ -756,14 +766,21 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
           }
         }
       } else { /* nullhypo particles keep their value + entropy, :476 */
-        add_entropy(d->manifold, X, N, n, spread, d->seed, 0);
+        add_entropy(d->manifold, X, N, n, spread, d->seed, 0, d->partial_mask); /* partialCoords, :532 */
       }
     }
     memcpy(out, X, sizeof(double) * 3 * N);
     free(X);
   } else {
     /* evalPotentialSpecific(relative), EvalFactor.jl:321-395 */
-    const int zdim = factor_zdim(d->factor_kind, d->manifold);
+    int zdim = factor_zdim(d->factor_kind, d->manifold);
+    int pdim = -1; /* the one partial coordinate of a partial relative factor */
+    if (d->partial_mask) {
+      int cnt = 0;
+      for (int k = 0; k < D; k++) if ((d->partial_mask >> k) & 1) { cnt++; pdim = k; }
+      if (d->factor_kind != NBP_F_LINREL || cnt != 1 || is_circ(d->manifold, pdim)) { free(mhidx); return NBP_ERR_ARG; }
+      zdim = 1;
+    }
     double *X = out; /* ccwl.varValsAll[sfidx] = deepcopy(target), CalcFactor.jl:543-548 */
     memmove(X, arena + S * d->var_slot[d->sfidx], sizeof(double) * 3 * N);
     double *Z = (double *)malloc(sizeof(double) * 3 * N);
@@ -786,19 +803,23 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
         for (int c = 0; c < d->inflate_cycles; c++) { /* :184-207 */
           double spread = var_distance_expected_fractional(d, &R, arena, N, X, d->inflation);
           for (int n = 0; n < N; n++)
-            if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8 + c) * 2);
+            if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8 + c) * 2, d->partial_mask);
           for (int n = 0; n < N; n++) { /* approxConvOnElements!, :14-27 */
             if (mhidx[n] != hyp) continue;
             double x[3], oth[3];
             for (int k = 0; k < D; k++) { x[k] = X[k * N + n]; oth[k] = O[k * N + n]; }
-            solve_particle(d->factor_kind, d->manifold, Z + 3 * n, oth, solve_b, x);
+            if (pdim >= 0) /* `.partial` -> islen1 -> BFGS (NumericalCalculations.jl:424); the gradient is
+                              zero off the partial coordinate, so the search runs on that coordinate alone */
+              solve_particle(NBP_F_LINREL, NBP_EUCLID1, Z + 3 * n, oth + pdim, solve_b, x + pdim);
+            else
+              solve_particle(d->factor_kind, d->manifold, Z + 3 * n, oth, solve_b, x);
             for (int k = 0; k < D; k++) X[k * N + n] = x[k];
           }
         }
       } else { /* other-hypothesis (:208-220) and nullhypo (:222-231): entropy only */
         double spread = var_distance_expected_fractional(d, &R, arena, N, X, d->spread_nh);
         for (int n = 0; n < N; n++)
-          if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8) * 2);
+          if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8) * 2, 0);
       }
     }
     free(Z);
@@ -859,11 +880,13 @@ static int cmp_idx(const void *a, const void *b, void *ctx) {
   return ia - ib;
 }
 /* KD-tree permutation: split the widest coordinate at the median (BallTree build) */
-static void kd_build(const double *x, int N, int D, int *idx, int lo, int hi) {
+static void kd_build(const double *x, int N, int D, int mask, int *idx, int lo, int hi) {
+  /* mask: the coordinates the density informs (all of them unless it is a partial density) */
   if (hi - lo <= 1) return;
   int best = 0;
   double bext = -1;
   for (int d = 0; d < D; d++) {
+    if (!((mask >> d) & 1)) continue;
     double mn = INFINITY, mx = -INFINITY;
     for (int i = lo; i < hi; i++) { double v = x[d * N + idx[i]]; if (v < mn) mn = v; if (v > mx) mx = v; }
     if (mx - mn > bext) { bext = mx - mn; best = d; }
@@ -872,8 +895,8 @@ static void kd_build(const double *x, int N, int D, int *idx, int lo, int hi) {
   g.x = x; g.N = N; g.dim = best;
   qsort_r(idx + lo, hi - lo, sizeof(int), cmp_idx, &g);
   int mid = lo + (hi - lo + 1) / 2;
-  kd_build(x, N, D, idx, lo, mid);
-  kd_build(x, N, D, idx, mid, hi);
+  kd_build(x, N, D, mask, idx, lo, mid);
+  kd_build(x, N, D, mask, idx, mid, hi);
 }
 
 int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d) {
@@ -885,6 +908,11 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     if (d->labels_out >= 0) for (int n = 0; n < N; n++) side[d->labels_out + n] = n;
     return NBP_OK;
   }
+  /* partial densities (AMP.marginal, ApproxConv.jl:287-291) multiply in on their coordinates only;
+     a coordinate no density informs keeps the old point (GraphProductOperations.jl:39-45) */
+  int pm[NBP_MAXF];
+  for (int j = 0; j < F; j++) pm[j] = d->in_partial[j] ? d->in_partial[j] : (1 << D) - 1;
+  const double *old = d->old_slot >= 0 ? arena + S * d->old_slot : 0;
   levels_t T;
   levels_build(&T, N);
   /* per density: sorted, centred coordinates and per-level node statistics */
@@ -895,7 +923,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     const double *x = arena + S * d->in_slot[j];
     idx[j] = (int *)malloc(sizeof(int) * N);
     for (int i = 0; i < N; i++) idx[j][i] = i;
-    kd_build(x, N, D, idx[j], 0, N);
+    kd_build(x, N, D, pm[j], idx[j], 0, N);
     xs[j] = (double *)malloc(sizeof(double) * 3 * N);
     for (int k = 0; k < D; k++) {
       double c = 0;
@@ -931,15 +959,17 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
       for (int it = 0; it < d->niter; it++) {
         for (int j = 0; j < F; j++) { /* sequential Gibbs sweep: sampleIndex(j) */
           double mn[3], vn[3];
+          int use[3]; /* coordinates that enter the weight: informed by j and by at least one other */
           for (int k = 0; k < D; k++) { /* product of all but the jth selected Gaussians */
             double prec = 0, acc = 0, ss = 0, sc = 0;
             for (int q = 0; q < F; q++) {
-              if (q == j) continue;
+              if (q == j || !((pm[q] >> k) & 1)) continue;
               double mq = nmean[q][l][k * cnt + ind[q]], vq = nvar[q][l][k * cnt + ind[q]];
               prec += 1.0 / vq;
               if (is_circ(M, k)) { ss += sin(mq) / vq; sc += cos(mq) / vq; }
               else acc += mq / vq;
             }
+            use[k] = ((pm[j] >> k) & 1) && prec > 0;
             vn[k] = 1.0 / prec;
             mn[k] = is_circ(M, k) ? atan2(ss, sc) : acc * vn[k]; /* getMu: Euclid / getCircMu */
           }
@@ -952,6 +982,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             for (int z = 0; z < cnt; z++) {
               double e = 0;
               for (int k = 0; k < D; k++) {
+                if (!use[k]) continue;
                 double tmp = nmean[j][l][k * cnt + z] - mn[k];
                 if (is_circ(M, k)) tmp = orc_wrap(tmp);
                 double v = nvar[j][l][k * cnt + z] + vn[k];
@@ -977,11 +1008,13 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     for (int k = 0; k < D; k++) {
       double prec = 0, acc = 0, ss = 0, sc = 0;
       for (int q = 0; q < F; q++) {
+        if (!((pm[q] >> k) & 1)) continue;
         double mq = nmean[q][T.L][k * cnt + ind[q]], vq = nvar[q][T.L][k * cnt + ind[q]];
         prec += 1.0 / vq;
         if (is_circ(M, k)) { ss += sin(mq) / vq; sc += cos(mq) / vq; }
         else acc += mq / vq;
       }
+      if (!(prec > 0)) { res[k * N + s] = old ? old[k * N + s] : 0.0; continue; } /* uninformed coordinate */
       double mu = is_circ(M, k) ? atan2(ss, sc) : acc / prec;
       double v = mu + sqrt(1.0 / prec) * nn[k];
       res[k * N + s] = is_circ(M, k) ? orc_wrap(v) : v;

@@ -231,6 +231,71 @@ def case_simple_mixture(backend):
     assert abs(pn.mean() + 1.0) < 0.1 and abs(pn.std() - 0.14) < 0.05
 
 
+def _partial_graph(backend, N=100):
+    # test/testpartialconstraint.jl:49-66: x1 in R^2 with a full prior N(0, 0.01 I) and a partial prior
+    # N(2, 1) on coordinate 1
+    fg = iif.initfg(iif.SolverParams(N=N))
+    E2 = iif.ContinuousEuclid(2)
+    iif.addVariable(fg, "x1", E2)
+    iif.addFactor(fg, ["x1"], iif.Prior(iif.MvNormal(np.zeros(2), np.diag([0.01, 0.01]))))
+    iif.addFactor(fg, ["x1"], iif.PartialPrior(E2, iif.Normal(2.0, 1.0), (1,)))
+    pts, bw = iif.approxConvBelief(fg, "x1f1", "x1", backend=backend, seed=30)  # doautoinit! from the full prior
+    iif.setValKDE(fg, "x1", pts, bw)
+    return fg, E2
+
+
+def case_partial_prior(backend):
+    # test/testpartialconstraint.jl:69-115 + :118-131
+    N = 100
+    fg, E2 = _partial_graph(backend, N)
+    pts = iif.approxConv(fg, "x1f1", "x1", backend=backend, seed=31)
+    assert pts.shape == (N, 2) and abs(pts[:, 0].mean()) < 0.3
+    X1 = fg.getVal("x1").copy()
+    pts = iif.approxConv(fg, "x1f2", "x1", backend=backend, seed=32)
+    assert pts.shape == (N, 2)
+    assert abs(pts[:, 0].mean() - 2.0) < 0.75
+    assert np.linalg.norm(X1[:, 0] - pts[:, 0]) > 2.0        # the partial coordinate moved
+    assert np.linalg.norm(X1[:, 1] - pts[:, 1]) < 1e-10       # the other one is untouched
+    np.testing.assert_array_equal(fg.getVal("x1"), X1)        # and the stored belief too
+    iif.solveTree(fg, backend=backend, seed=33)
+    p = fg.getVal("x1")
+    assert abs(p[:, 0].mean()) < 0.4 and abs(p[:, 1].mean()) < 0.4
+
+
+def case_partial_relative_and_products(backend):
+    # test/testpartialconstraint.jl:135-147,185-197,250-291: x2 with a partial pairwise factor on
+    # coordinate 2 (DevelopPartialPairwise) and a partial prior N(-20, 1) on coordinate 1
+    N = 100
+    fg, E2 = _partial_graph(backend, N)
+    iif.addVariable(fg, "x2", E2)
+    iif.addFactor(fg, ["x1", "x2"], iif.PartialLinearRelative(E2, iif.Normal(10.0, 1.0), (2,)))
+    iif.addFactor(fg, ["x2"], iif.PartialPrior(E2, iif.Normal(-20.0, 1.0), (1,)))
+    iif.initAll(fg, backend=backend, seed=34)
+    X2 = fg.getVal("x2").copy()
+    # the relative partial only touches coordinate 2 of its proposal
+    pts = iif.approxConv(fg, "x1x2f1", "x2", backend=backend, seed=35)
+    assert pts.shape == (N, 2)
+    assert np.linalg.norm(X2[:, 0] - pts[:, 0]) < 1e-10
+    assert abs((pts[:, 1] - fg.getVal("x1")[:, 1]).mean() - 10.0) < 0.75
+    pts = iif.approxConv(fg, "x2f1", "x2", backend=backend, seed=36)
+    assert abs(pts[:, 0].mean() + 20.0) < 0.75 and pts[:, 0].std() - 1.0 < 0.4
+    # propagateBelief returns full-dimension points even when only partials are sent in
+    (val, _), _ = iif.propagateBelief(fg, "x2", ["x2f1"], backend=backend, seed=37)
+    assert np.linalg.norm(X2[:, 1] - val[:, 1]) < 1e-10 and np.linalg.norm(X2[:, 0] - val[:, 0]) > 0
+    assert abs(val[:, 0].mean() + 20.0) < 0.75
+    (val, _), _ = iif.propagateBelief(fg, "x2", ["x1x2f1"], backend=backend, seed=38)
+    assert np.linalg.norm(X2[:, 0] - val[:, 0]) < 1e-10 and np.linalg.norm(X2[:, 1] - val[:, 1]) > 0
+    # combination of partials: every coordinate informed by exactly one density
+    (val, _), _ = iif.propagateBelief(fg, "x2", ["x1x2f1", "x2f1"], backend=backend, seed=39)
+    assert abs(val[:, 0].mean() + 20.0) < 1 and val[:, 0].std() - 1.0 < 3.0
+    assert abs(val[:, 1].mean() - 10.0) < 3.0
+    iif.solveTree(fg, backend=backend, seed=40)
+    p = fg.getVal("x1")
+    assert abs(p[:, 0].mean()) < 0.5 and abs(p[:, 1].mean()) < 0.5
+    q = fg.getVal("x2")
+    assert abs(q[:, 0].mean() + 20.0) < 1.0 and abs(q[:, 1].mean() - 10.0) < 3.0
+
+
 CASES = [case_forward_convolve, case_five_chain_spread, case_back_and_forth_spreads, case_approxconv_kaess_chains,
          case_ccw_forward_reverse, case_conv_95_percent, case_euclid_distance_1d, case_euclid_distance_2d,
-         case_se2_hex, case_se2_multihypo, case_simple_mixture]
+         case_se2_hex, case_se2_multihypo, case_simple_mixture, case_partial_prior, case_partial_relative_and_products]

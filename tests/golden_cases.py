@@ -20,6 +20,10 @@ CASES = {
     "product_euclid2_f3_n200": dict(op="prod", manifold=abi.EUCLID2, N=200, seed=121, F=3),
     "product_circular_f2_n200": dict(op="prod", manifold=abi.CIRCULAR, N=200, seed=122, F=2),
     "product_se2_f3_n100": dict(op="prod", manifold=abi.SE2, N=100, seed=123, F=3),
+    "partial_prior_euclid3_n200": dict(op="pprior", manifold=abi.EUCLID3, N=200, seed=131, mask=5, mean=[2.0, -1.0], sig=[1.0, 0.2], nullhypo=0.1),
+    "partial_linrel_euclid2_n100": dict(op="prel", manifold=abi.EUCLID2, N=100, seed=132, mask=2, sfidx=1),
+    "partial_product_se2_n200": dict(op="pprod", manifold=abi.SE2, N=200, seed=133, masks=[4, 3, 0]),
+    "partial_product_euclid3_uninformed_n100": dict(op="pprod", manifold=abi.EUCLID3, N=100, seed=134, masks=[1, 4]),
 }
 
 
@@ -35,6 +39,38 @@ def run_case(c, make_backend):
         be.run_proposals([d])
         pts, bw = be.slot_read(1, man)
         out = dict(in0=cur, pts=pts, bw=bw, mhidx=be.side_read(0, N))
+    elif c["op"] == "pprior":
+        be = make_backend(N, 2, N)
+        cur = rand_points(rng, man, N, 0.5, 0.4)
+        be.slot_write(0, man, cur)
+        d = relative_factor_desc(abi.F_PRIOR, man, 1, 0, [0], 1, c["seed"], c["mean"], c["sig"], nullhypo=c["nullhypo"], mhidx_out=0)
+        d.partial_mask = c["mask"]
+        be.run_proposals([d])
+        pts, bw = be.slot_read(1, man)
+        out = dict(in0=cur, pts=pts, bw=bw, mhidx=be.side_read(0, N))
+    elif c["op"] == "prel":
+        be = make_backend(N, 3, N)
+        a, b = rand_points(rng, man, N, 0.0, 0.3), rand_points(rng, man, N, 1.0, 0.3)
+        be.slot_write(0, man, a)
+        be.slot_write(1, man, b)
+        d = relative_factor_desc(abi.F_LINREL, man, 2, c["sfidx"], [0, 1], 2, c["seed"], [10.0], [1.0], mhidx_out=0)
+        d.partial_mask = c["mask"]
+        be.run_proposals([d])
+        pts, bw = be.slot_read(2, man)
+        out = dict(in0=a, in1=b, pts=pts, bw=bw, mhidx=be.side_read(0, N))
+    elif c["op"] == "pprod":
+        from parity_utils import iif
+        masks = c["masks"]
+        F = len(masks)
+        be = make_backend(N, F + 2, N * F)
+        ins = [rand_points(rng, man, N, 0.2 * j, 0.5) for j in range(F)]
+        old = rand_points(rng, man, N, 4.0, 0.2)
+        for j in range(F):
+            be.slot_write(j, man, ins[j], np.full(D, 0.15 + 0.03 * j))
+        be.slot_write(F, man, old)
+        be.run_products([iif.solver.product_desc(man, list(range(F)), F + 1, c["seed"], 1, 0, partials=masks, old_slot=F)])
+        pts, bw = be.slot_read(F + 1, man)
+        out = dict(pts=pts, bw=bw, labels=be.side_read(0, N * F), old=old, **{f"in{i}": p for i, p in enumerate(ins)})
     elif c["op"] in ("rel", "mix"):
         be = make_backend(N, 3, N)
         a, b = rand_points(rng, man, N, 0.0, 0.3), rand_points(rng, man, N, 1.0, 0.3)

@@ -222,3 +222,121 @@ def test_error_codes(hip_backend):
     with pytest.raises(iif.NbpError):
         be.run_proposals([d2])
     be.close()
+
+
+# ---- partial-dimension factors ----------------------------------------
+@pytest.mark.parametrize("manifold,mask", [(abi.EUCLID2, 1), (abi.EUCLID2, 2), (abi.EUCLID3, 5), (abi.EUCLID3, 2),
+                                           (abi.SE2, 3), (abi.SE2, 4)])
+@pytest.mark.parametrize("nullhypo", [0.0, 0.4])
+def test_partial_prior_proposal(oracle_backend, hip_backend, manifold, mask, nullhypo):
+    N = 200
+    rng = np.random.default_rng(70 + manifold + mask)
+    cur = rand_points(rng, manifold, N, center=1.0, spread=0.5)
+    Z = bin(mask).count("1")
+    d = relative_factor_desc(abi.F_PRIOR, manifold, 1, 0, [0], 1, 515 + manifold + mask, [0.3, -0.2, 0.5][:Z],
+                             [0.1, 0.2, 0.05][:Z], nullhypo=nullhypo, mhidx_out=0)
+    d.partial_mask = mask
+
+    def setup(be):
+        be.slot_write(0, manifold, cur)
+
+    o, h = both(oracle_backend, hip_backend, N, 2, N, setup, lambda be: be.run_proposals([d]),
+                lambda be: (be.slot_read(1, manifold), be.side_read(0, N)))
+    np.testing.assert_array_equal(o[1], h[1])
+    assert_points_close(manifold, o[0][0], h[0][0], what="partial prior proposal")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    # coordinates outside the mask keep the target's current values, exactly
+    from parity_utils import coords
+    D = abi.MANIFOLD_DIM[manifold]
+    c0, c1 = coords(manifold, cur), coords(manifold, h[0][0])
+    for k in range(D):
+        if not (mask >> k) & 1:
+            np.testing.assert_allclose(c1[:, k], c0[:, k], atol=1e-12)
+        else:
+            assert np.abs(c1[:, k] - c0[:, k]).max() > 1e-3
+
+
+@pytest.mark.parametrize("manifold,mask", [(abi.EUCLID2, 2), (abi.EUCLID2, 1), (abi.EUCLID3, 4)])
+@pytest.mark.parametrize("sfidx", [0, 1])
+def test_partial_relative_conv(oracle_backend, hip_backend, manifold, mask, sfidx):
+    N = 200
+    rng = np.random.default_rng(300 + manifold + mask + sfidx)
+    a = rand_points(rng, manifold, N, center=0.0, spread=0.3)
+    b = rand_points(rng, manifold, N, center=1.0, spread=0.3)
+    d = relative_factor_desc(abi.F_LINREL, manifold, 2, sfidx, [0, 1], 2, 888 + mask + sfidx, [10.0], [1.0])
+    d.partial_mask = mask
+
+    def setup(be):
+        be.slot_write(0, manifold, a)
+        be.slot_write(1, manifold, b)
+
+    o, h = both(oracle_backend, hip_backend, N, 3, 0, setup, lambda be: be.run_proposals([d]),
+                lambda be: be.slot_read(2, manifold))
+    assert_points_close(manifold, o[0], h[0], what="partial relative conv")
+    np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
+    k = {1: 0, 2: 1, 4: 2}[mask]
+    tgt, oth = (b, a) if sfidx == 1 else (a, b)
+    sign = 1.0 if sfidx == 1 else -1.0
+    assert abs((h[0][:, k] - oth[:, k]).mean() - sign * 10.0) < 0.5
+    for kk in range(abi.MANIFOLD_DIM[manifold]):
+        if kk != k:
+            np.testing.assert_allclose(h[0][:, kk], tgt[:, kk], atol=1e-12)
+
+
+PARTIAL_PRODUCTS = [
+    (abi.EUCLID2, [1, 0]),        # partial + full
+    (abi.EUCLID2, [1, 2]),        # two partials, disjoint coordinates
+    (abi.EUCLID2, [2, 2]),        # coordinate 0 uninformed -> old points
+    (abi.EUCLID3, [5, 0, 2]),
+    (abi.EUCLID3, [1, 1, 4]),     # coordinate 1 uninformed
+    (abi.SE2, [3, 0]),            # (x, y) partial + full
+    (abi.SE2, [4, 3, 0]),         # theta partial, xy partial, full
+]
+
+
+@pytest.mark.parametrize("manifold,masks", PARTIAL_PRODUCTS)
+@pytest.mark.parametrize("N", [100, 200])
+def test_partial_product(oracle_backend, hip_backend, manifold, masks, N):
+    F = len(masks)
+    rng = np.random.default_rng(900 + manifold + sum(masks) + N)
+    dens = [rand_points(rng, manifold, N, center=0.2 * j, spread=0.6) for j in range(F)]
+    old = rand_points(rng, manifold, N, center=5.0, spread=0.1)
+    out = F + 1
+    d = iif.solver.product_desc(manifold, list(range(F)), out, 31337 + N, 1, 0, partials=masks, old_slot=F)
+
+    def setup(be):
+        for j, p in enumerate(dens):
+            be.slot_write(j, manifold, p)
+        be.slot_write(F, manifold, old)
+        be.run_bandwidth(list(range(F)), [manifold] * F)
+
+    o, h = both(oracle_backend, hip_backend, N, F + 2, N * F, setup, lambda be: be.run_products([d]),
+                lambda be: (be.slot_read(out, manifold), be.side_read(0, N * F)))
+    np.testing.assert_array_equal(o[1], h[1])
+    assert_points_close(manifold, o[0][0], h[0][0], what="partial product")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    from parity_utils import coords
+    D = abi.MANIFOLD_DIM[manifold]
+    cov = 0
+    for m in masks:
+        cov |= m if m else (1 << D) - 1
+    co, cn = coords(manifold, old), coords(manifold, h[0][0])
+    for k in range(D):
+        if not (cov >> k) & 1:
+            np.testing.assert_allclose(cn[:, k], co[:, k], atol=1e-12)
+
+
+def test_partial_descriptors_are_validated(hip_backend):
+    be = hip_backend(64, 4, 0)
+    d = relative_factor_desc(abi.F_LINREL, abi.EUCLID2, 2, 1, [0, 1], 2, 1, [1.0], [1.0])
+    d.partial_mask = 3  # two partial coordinates on a relative factor: not supported
+    with pytest.raises(iif.NbpError):
+        be.run_proposals([d])
+    d = relative_factor_desc(abi.F_PRIOR, abi.EUCLID2, 1, 0, [0], 1, 1, [1.0], [1.0])
+    d.partial_mask = 4  # coordinate 2 of a 2-D variable
+    with pytest.raises(iif.NbpError):
+        be.run_proposals([d])
+    p = iif.solver.product_desc(abi.EUCLID2, [0, 1], 2, 1, 1, -1, partials=[1, 0], old_slot=99)
+    with pytest.raises(iif.NbpError):
+        be.run_products([p])
+    be.close()
