@@ -170,6 +170,12 @@ nbp_status nbp_run_proposals(nbp_ctx *ctx, const nbp_proposal_desc *descs, int32
 nbp_status nbp_run_bandwidth(nbp_ctx *ctx, const int32_t *slots, const int32_t *manifolds, int32_t n);
 /* ---- variable seam: AMP.manifoldProduct + rebandwidth (GraphProductOperations.jl:53-60) --- */
 nbp_status nbp_run_products(nbp_ctx *ctx, const nbp_product_desc *descs, int32_t n);
+/* approxDeconv(dfg, fct) (services/DeconvUtils.jl:32-160): per particle, sample a measurement and
+ * search from it for the measurement that zeroes the residual between the stored points of the two
+ * variables (var_slot[0], var_slot[1]).  out_slot receives the predicted measurement (tangent
+ * coordinates k < zDim, read it back with the Euclid manifold of that dimension), meas_slots[i] (may be
+ * NULL / -1) the sampled one.  Relative factors without multihypo only (reference #467/#927). */
+nbp_status nbp_run_deconv(nbp_ctx *ctx, const nbp_proposal_desc *descs, const int32_t *meas_slots, int32_t n);
 nbp_status nbp_run_copies(nbp_ctx *ctx, const nbp_copy_desc *descs, int32_t n);
 
 /* ---- clique seam: a whole up/down schedule resident on the device --------------------------

@@ -14,7 +14,7 @@ from .factorgraph import (Circular, CircularCircular, ContinuousEuclid, Continuo
                           EuclidDistance, LinearRelative, ManifoldFactor, ManifoldPrior, Mixture,
                           MsgPrior, MvNormal, Normal, PartialLinearRelative, PartialPrior, Prior, PriorCircular, SolverParams,
                           SpecialEuclidean2, addFactor, addVariable, getSolverParams, initfg)
-from .solver import (TreeProgram, approxConv, approxConvBelief, approxConvBeliefPath, findShortestPath,  # noqa: F401
+from .solver import (TreeProgram, approxConv, approxConvBelief, approxConvBeliefPath, approxDeconv, findShortestPath,  # noqa: F401
                      product_desc, proposal_desc,
                      initAll, initVariable, localProduct, localProductAndUpdate, manikde, propagateBelief,
                      setValKDE, solveTree)

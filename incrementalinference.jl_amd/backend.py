@@ -91,6 +91,11 @@ class HipBackend:
         arr, n = _as_array(descs, abi.CopyDesc)
         self._check(self.lib.nbp_run_copies(self._ctx, arr, n))
 
+    def run_deconv(self, descs, meas_slots=None):
+        arr, n = _as_array(descs, abi.ProposalDesc)
+        ms = np.ascontiguousarray(meas_slots if meas_slots is not None else [-1] * n, dtype=np.int32)
+        self._check(self.lib.nbp_run_deconv(self._ctx, arr, ms.ctypes.data_as(C.POINTER(C.c_int32)), n))
+
     def run_bandwidth(self, slots, manifolds):
         s = np.ascontiguousarray(slots, dtype=np.int32)
         m = np.ascontiguousarray(manifolds, dtype=np.int32)

@@ -530,6 +530,38 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   return NBP_OK;
 }
 
+nbp_status nbp_run_deconv(nbp_ctx *c, const nbp_proposal_desc *descs, const int32_t *meas_slots, int32_t n) {
+  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  nbp_status rc = check_proposals(c, descs, n);
+  if (rc) return rc;
+  std::vector<int32_t> ms((size_t)n, -1), none;
+  for (int i = 0; i < n; i++) {
+    const nbp_proposal_desc &p = descs[i];
+    if (p.factor_kind < NBP_F_LINREL) return fail(NBP_ERR_ARG, "deconv: relative factors only (a prior's predicted measurement is the point itself)");
+    if (p.has_multihypo || p.nvars != 2) return fail(NBP_ERR_ARG, "deconv: multihypo is not supported (reference issue #467/#927)");
+    if (p.partial_mask) return fail(NBP_ERR_ARG, "deconv: partial factors are not supported");
+    if (meas_slots) {
+      if (meas_slots[i] >= c->n_slots) return fail(NBP_ERR_RANGE, "deconv: meas_slot");
+      ms[i] = meas_slots[i];
+    }
+  }
+  const int32_t *ds, *dm;
+  rc = stage_with_jobs(c, descs, sizeof(nbp_proposal_desc) * (size_t)n, ms, none, &ds, &dm);
+  if (rc) return rc;
+  rc = tic(c, c->ev[0]);
+  if (rc) return rc;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_deconv_kernel, dim3(n), dim3(c->Npad), 0, c->stream, (const nbp_proposal_desc *)c->stage, ds, c->arena,
+                     c->N, c->S, c->counters);
+  HIPCHK(hipGetLastError());
+  rc = toc(c, c->ev[0]);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+
 nbp_status nbp_run_copies(nbp_ctx *c, const nbp_copy_desc *descs, int32_t n) {
   if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
   if (n <= 0) return NBP_OK;

@@ -353,8 +353,8 @@ __device__ __forceinline__ double nm_objective(const double (&f)[DN + 1]) {
   return sqrt(v / (double)DN);
 }
 
-template <int KIND, int DN>
-__device__ __forceinline__ bool nelder_mead(objective_t<KIND, DN> &o, double (&x)[DN]) {
+template <class OBJ, int DN>
+__device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   constexpr int M = DN + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / DN, gamma = 0.75 - 1.0 / (2.0 * DN), delta = 1.0 - 1.0 / DN;
   double sx[M][DN], f[M];
@@ -438,17 +438,17 @@ __device__ __forceinline__ bool nelder_mead(objective_t<KIND, DN> &o, double (&x
 
 // Optim.BFGS for a 1-D decision variable (islen1 branch), central finite differences,
 // Armijo / quadratic-interpolation line search (documented deviation from HagerZhang).
-template <int KIND>
-__device__ __forceinline__ double fd_grad1(objective_t<KIND, 1> &o, double x) {
+template <class OBJ>
+__device__ __forceinline__ double fd_grad1(OBJ &o, double x) {
   double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x));
   double xp[1] = {x + h}, xm[1] = {x - h};
   return (o(xp) - o(xm)) / (2.0 * h);
 }
 
-template <int KIND>
-__device__ __forceinline__ bool bfgs_1d(objective_t<KIND, 1> &o, double (&x)[1]) {
+template <class OBJ>
+__device__ __forceinline__ bool bfgs_1d(OBJ &o, double (&x)[1]) {
   double xc[1] = {x[0]};
-  double fx = o(xc), g = fd_grad1<KIND>(o, xc[0]), H = 1.0;
+  double fx = o(xc), g = fd_grad1(o, xc[0]), H = 1.0;
   bool converged = false;
   for (int it = 0; it < 1000; it++) {
     if (fabs(g) <= 1e-8) { converged = true; break; }
@@ -467,7 +467,7 @@ __device__ __forceinline__ bool bfgs_1d(objective_t<KIND, 1> &o, double (&x)[1])
       al = aq;
     }
     if (!ok) break;
-    double gn = fd_grad1<KIND>(o, xn[0]), dx = xn[0] - xc[0], dg = gn - g;
+    double gn = fd_grad1(o, xn[0]), dx = xn[0] - xc[0], dg = gn - g;
     if (dx == 0.0) { converged = fabs(gn) <= 1e-8; break; }
     if (dx * dg > 0) H = dx / dg;
     xc[0] = xn[0]; fx = fn; g = gn;
@@ -490,8 +490,8 @@ __device__ __forceinline__ void solve_particle_t(int manifold, const double *z, 
 #pragma unroll
   for (int d = 0; d < DN; d++) xc[d] = x[d];
   bool conv;
-  if constexpr (DN == 1) conv = bfgs_1d<KIND>(o, xc);
-  else conv = nelder_mead<KIND, DN>(o, xc);
+  if constexpr (DN == 1) conv = bfgs_1d(o, xc);
+  else conv = nelder_mead(o, xc);
   n_solves++;
   n_evals += o.evals;
   if (!conv) n_nonconv++;
@@ -519,6 +519,68 @@ __device__ __forceinline__ void solve_particle(int kind, int manifold, const dou
     if (D == 1) solve_particle_t<NBP_F_EUCLIDDIST, 1>(manifold, z, other, solve_b, x, a, b, c, e);
     else if (D == 2) solve_particle_t<NBP_F_EUCLIDDIST, 2>(manifold, z, other, solve_b, x, a, b, c, e);
     else solve_particle_t<NBP_F_EUCLIDDIST, 3>(manifold, z, other, solve_b, x, a, b, c, e);
+    break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// approxDeconv (DeconvUtils.jl:32-160): the measurement is the decision variable, both variable
+// points are fixed.  ZD = measurement dimension (NelderMead; BFGS when ZD == 1, :94,139).
+// ------------------------------------------------------------------------------------------------
+template <int KIND, int DN, int ZD>
+struct deconv_objective_t {
+  double a[3], b[3];
+  unsigned int evals;
+  __device__ __forceinline__ double operator()(const double (&zz)[ZD]) {
+    evals++;
+    objective_t<KIND, DN> o;
+#pragma unroll
+    for (int k = 0; k < 3; k++) o.z[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < ZD; k++) o.z[k] = zz[k];
+    return o.normsq(a, b);
+  }
+};
+
+template <int KIND, int DN, int ZD>
+__device__ __forceinline__ void deconv_particle_t(const double *a, const double *b, double *z, unsigned int &n_solves,
+                                                  unsigned int &n_nonconv, unsigned int &n_nan, unsigned int &n_evals) {
+  deconv_objective_t<KIND, DN, ZD> o;
+  o.evals = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { o.a[k] = a[k]; o.b[k] = b[k]; }
+  double zc[ZD];
+#pragma unroll
+  for (int k = 0; k < ZD; k++) zc[k] = z[k];
+  bool conv;
+  if constexpr (ZD == 1) conv = bfgs_1d(o, zc);
+  else conv = nelder_mead(o, zc);
+  n_solves++;
+  n_evals += o.evals;
+  if (!conv) n_nonconv++;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < ZD; k++) bad |= isnan(zc[k]);
+  if (bad) { n_nan++; return; }
+#pragma unroll
+  for (int k = 0; k < ZD; k++) z[k] = zc[k];
+}
+
+__device__ __forceinline__ void deconv_particle(int kind, int manifold, const double *a, const double *b, double *z,
+                                                unsigned int &s, unsigned int &nc, unsigned int &nn, unsigned int &e) {
+  const int D = mani_dim(manifold);
+  switch (kind) {
+  case NBP_F_LINREL:
+    if (D == 1) deconv_particle_t<NBP_F_LINREL, 1, 1>(a, b, z, s, nc, nn, e);
+    else if (D == 2) deconv_particle_t<NBP_F_LINREL, 2, 2>(a, b, z, s, nc, nn, e);
+    else deconv_particle_t<NBP_F_LINREL, 3, 3>(a, b, z, s, nc, nn, e);
+    break;
+  case NBP_F_CIRCULAR: deconv_particle_t<NBP_F_CIRCULAR, 1, 1>(a, b, z, s, nc, nn, e); break;
+  case NBP_F_SE2: deconv_particle_t<NBP_F_SE2, 3, 3>(a, b, z, s, nc, nn, e); break;
+  default:
+    if (D == 1) deconv_particle_t<NBP_F_EUCLIDDIST, 1, 1>(a, b, z, s, nc, nn, e);
+    else if (D == 2) deconv_particle_t<NBP_F_EUCLIDDIST, 2, 1>(a, b, z, s, nc, nn, e);
+    else deconv_particle_t<NBP_F_EUCLIDDIST, 3, 1>(a, b, z, s, nc, nn, e);
     break;
   }
 }

@@ -241,6 +241,50 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
   }
 }
 
+// ================================================================================================
+// Deconvolution kernel: one workgroup = one approxDeconv(dfg, fct) (DeconvUtils.jl:32-160), one lane
+// per particle: sample a measurement (the search start, returned as "measured"), then find the
+// measurement that zeroes the residual between the two stored variable points ("predicted").
+// ================================================================================================
+__global__ void __launch_bounds__(512)
+nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, double *arena, int N, int64_t S, nbp_counters *ctr) {
+  const nbp_proposal_desc *d = descs + blockIdx.x;
+  const int n = threadIdx.x, M = d->manifold, D = mani_dim(M), kind = d->factor_kind;
+  const int zdim = (kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1);
+  const double *A = arena + S * d->var_slot[0], *B = arena + S * d->var_slot[1];
+  double *out = arena + S * d->out_slot;
+  double *ms = (meas_slots && meas_slots[blockIdx.x] >= 0) ? arena + S * meas_slots[blockIdx.x] : nullptr;
+  unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
+  if (n < N) {
+    double z[3], a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+    sample_measurement(d, n, zdim, z);
+    if (ms)
+      for (int k = 0; k < 3; k++) ms[k * N + n] = (k < zdim) ? z[k] : 0.0;
+    a[0] = A[n]; b[0] = B[n];
+    if (D > 1) { a[1] = A[N + n]; b[1] = B[N + n]; }
+    if (D > 2) { a[2] = A[2 * N + n]; b[2] = B[2 * N + n]; }
+    deconv_particle(kind, M, a, b, z, n_solves, n_nonconv, n_nan, n_evals);
+    for (int k = 0; k < 3; k++) out[k * N + n] = (k < zdim) ? z[k] : 0.0;
+  }
+  if (n < 3) {
+    out[3 * N + n] = 0.0;
+    if (ms) ms[3 * N + n] = 0.0;
+  }
+  unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    unsigned int t = v[q];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    v[q] = t;
+  }
+  if ((threadIdx.x & 63) == 0 && (v[0] | v[3])) {
+    atomicAdd(&ctr->solves, (unsigned long long)v[0]);
+    atomicAdd(&ctr->nonconverged, (unsigned long long)v[1]);
+    atomicAdd(&ctr->nan_results, (unsigned long long)v[2]);
+    atomicAdd(&ctr->residual_evals, (unsigned long long)v[3]);
+  }
+}
+
 static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
 
 // fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)

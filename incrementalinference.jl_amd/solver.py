@@ -217,6 +217,61 @@ def approxConv(fg, frm, target, **kw):
     return approxConvBeliefPath(fg, frm, target, **kw)[0]
 
 
+def approxDeconv(fg, fctlabel, backend=None, seed=0):
+    """approxDeconv(dfg, fctsym) -> (predicted, measured)   services/DeconvUtils.jl:162-189, :32-160.
+    Inverse solve: per particle the measurement that makes the factor residual zero for the stored
+    points of its variables ("predicted", N x zDim tangent coordinates), next to N freshly sampled
+    measurements ("measured", also the starting points of the search).  Multihypo factors are not
+    supported (the reference's own limitation, issues #467/#927)."""
+    fct = fg.getFactor(fctlabel)
+    fnc = fct.fnc
+    N = fg.solverParams.N
+    if fnc.is_prior:
+        # r = z - x: the predicted measurement of particle n is the point itself (DefaultPrior.jl:17)
+        comps = fnc.components()
+        rng_pts = _sample_components(comps, N, seed)
+        var = fg.getVariable(fct.variables[0])
+        pred = var.val if var.varType.P == var.varType.dim else _coords(var.varType, var.val)
+        return np.array(pred, dtype=float), rng_pts
+    if fct.multihypo is not None:
+        raise NotImplementedError("approxDeconv on multihypo factors (reference issues #467, #927)")
+    labels = list(fct.variables)
+    be, own = _make_backend(backend, N, len(labels) + 2)
+    try:
+        for i, v in enumerate(labels):
+            var = fg.getVariable(v)
+            be.slot_write(i, var.varType.manifold, var.val, var.bw)
+        out, ms = len(labels), len(labels) + 1
+        d = proposal_desc(fg, fct, labels[-1], lambda v: labels.index(v), out, op_seed(seed, PASS_UNIT, 0, 0, 0))
+        be.run_deconv([d], [ms])
+        zdim = fnc.zdim or fg.getVariable(labels[-1]).varType.dim
+        zman = {1: abi.EUCLID1, 2: abi.EUCLID2, 3: abi.EUCLID3}[zdim]
+        pred, _ = be.slot_read(out, zman)
+        meas, _ = be.slot_read(ms, zman)
+    finally:
+        if own:
+            be.close()
+    return pred, meas
+
+
+def _coords(varType, pts):
+    if varType.manifold == abi.SE2:
+        return np.stack([pts[:, 0], pts[:, 1], np.arctan2(pts[:, 3], pts[:, 2])], axis=1)
+    return pts
+
+
+def _sample_components(comps, N, seed):
+    """host-side sampleFactor for the trivial prior case of approxDeconv"""
+    rng = np.random.default_rng(seed)
+    w = np.array([c[0] for c in comps])
+    lbl = rng.choice(len(comps), size=N, p=w / w.sum())
+    out = []
+    for n in range(N):
+        _, mu, L = comps[lbl[n]]
+        out.append(np.asarray(mu) + np.asarray(L) @ rng.normal(size=len(mu)))
+    return np.array(out)
+
+
 def propagateBelief(fg, destlbl, factors=None, backend=None, seed=0, return_proposals=False):
     """propagateBelief(dfg, destvar, factors) -> ((pts, bw), ipc)   GraphProductOperations.jl:16-64:
     one proposal per factor (proposalbeliefs!) then AMP.manifoldProduct(dens; Niter=1, N)."""

@@ -280,14 +280,15 @@ int32_t orc_residual(int32_t kind, int32_t manifold, const double *z, const doub
 }
 
 typedef struct {
-  int kind, manifold, D, solve_b;
-  double z[3], other[3];
+  int kind, manifold, D, solve_b; /* solve_b == 2: the measurement is the decision variable (deconv) */
+  double z[3], other[3];          /* deconv: z = first variable's point, other = second variable's point */
 } objective_t;
 
 static double objective(const objective_t *o, const double *x) {
   double r[3];
-  int nr = o->solve_b ? orc_residual(o->kind, o->manifold, o->z, o->other, x, r)
-                      : orc_residual(o->kind, o->manifold, o->z, x, o->other, r);
+  int nr = o->solve_b == 2 ? orc_residual(o->kind, o->manifold, x, o->z, o->other, r)
+           : o->solve_b    ? orc_residual(o->kind, o->manifold, o->z, o->other, x, r)
+                           : orc_residual(o->kind, o->manifold, o->z, x, o->other, r);
   double acc = 0;
   for (int i = 0; i < nr; i++) acc += r[i] * r[i];
   return acc;
@@ -1039,6 +1040,40 @@ void orc_run_copy(double *arena, int32_t N, const nbp_copy_desc *c) {
   memmove(arena + S * c->dst_slot, arena + S * c->src_slot, sizeof(double) * S);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* approxDeconv (services/DeconvUtils.jl:32-106 legacy, :108-160 AbstractManifoldMinimize):       */
+/* per particle, the measurement that zeroes the residual between the stored variable points,  */
+/* searched from a freshly sampled measurement (NelderMead, BFGS when zDim == 1, :94,139).      */
+/* out_slot <- predicted measurement coordinates, meas_slot <- the sampled ones.                */
+/* ------------------------------------------------------------------------------------------ */
+int32_t orc_run_deconv(double *arena, int32_t N, const nbp_proposal_desc *d, int32_t meas_slot) {
+  const int64_t S = orc_slot_stride(N);
+  if (d->factor_kind < NBP_F_LINREL || d->has_multihypo || d->nvars != 2 || d->partial_mask) return NBP_ERR_ARG;
+  const int D = mani_dim(d->manifold), zdim = factor_zdim(d->factor_kind, d->manifold);
+  const double *A = arena + S * d->var_slot[0], *B = arena + S * d->var_slot[1];
+  double *out = arena + S * d->out_slot, *ms = meas_slot >= 0 ? arena + S * meas_slot : 0;
+  for (int n = 0; n < N; n++) {
+    double z[3];
+    sample_measurement(d, n, zdim, z, 0);
+    if (ms) for (int k = 0; k < 3; k++) ms[k * N + n] = k < zdim ? z[k] : 0.0;
+    objective_t o;
+    o.kind = d->factor_kind; o.manifold = d->manifold; o.D = D; o.solve_b = 2;
+    for (int k = 0; k < 3; k++) { o.z[k] = k < D ? A[k * N + n] : 0.0; o.other[k] = k < D ? B[k * N + n] : 0.0; }
+    double zc[3] = {z[0], z[1], z[2]};
+    int conv;
+    t_diag.solves++;
+    if (zdim == 1) conv = orc_bfgs_1d(&o, zc, 0);
+    else conv = orc_nelder_mead(&o, zdim, zc, 0);
+    if (!conv) t_diag.nonconverged++;
+    int bad = 0;
+    for (int k = 0; k < zdim; k++) bad |= isnan(zc[k]);
+    if (bad) { t_diag.nan_results++; for (int k = 0; k < zdim; k++) zc[k] = z[k]; }
+    for (int k = 0; k < 3; k++) out[k * N + n] = k < zdim ? zc[k] : 0.0;
+  }
+  for (int k = 0; k < 3; k++) { out[3 * N + k] = 0.0; if (ms) ms[3 * N + k] = 0.0; }
+  return NBP_OK;
+}
+
 /* batch drivers, used by the CPU baseline: the same stage semantics as nbp_program_run */
 /* ops of one stage are independent by construction (distinct out slots), so the multi-core
  * baseline runs them with OpenMP -- the analogue of the reference's task-per-clique concurrency
@@ -1053,6 +1088,12 @@ int32_t orc_run_products(double *arena, int32_t N, int32_t *side, const nbp_prod
   int rc = NBP_OK;
 #pragma omp parallel for schedule(dynamic, 1)
   for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
+  return rc;
+}
+int32_t orc_run_deconvs(double *arena, int32_t N, const nbp_proposal_desc *d, const int32_t *meas_slots, int32_t n) {
+  int rc = NBP_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; i++) { int r = orc_run_deconv(arena, N, d + i, meas_slots ? meas_slots[i] : -1); if (r) rc = r; diag_merge(); }
   return rc;
 }
 void orc_set_threads(int32_t n);

@@ -34,6 +34,7 @@ def lib():
         L.orc_slot_read.restype = None
         L.orc_run_proposals.argtypes = [dp, i32, ip, C.POINTER(abi.ProposalDesc), i32]
         L.orc_run_products.argtypes = [dp, i32, ip, C.POINTER(abi.ProductDesc), i32]
+        L.orc_run_deconvs.argtypes = [dp, i32, C.POINTER(abi.ProposalDesc), ip, i32]
         L.orc_run_copies.argtypes = [dp, i32, C.POINTER(abi.CopyDesc), i32]
         L.orc_run_copies.restype = None
         L.orc_run_bandwidth.argtypes = [dp, i32, i32, i32]
@@ -119,6 +120,14 @@ class OracleBackend:
         self.lib.orc_set_threads(self.threads)
         arr, n = self._arr(descs, abi.ProductDesc)
         rc = self.lib.orc_run_products(_dp(self.arena), self.N, self._sidep(), arr, n)
+        if rc:
+            raise RuntimeError(f"oracle status {rc}")
+
+    def run_deconv(self, descs, meas_slots=None):
+        self.lib.orc_set_threads(self.threads)
+        arr, n = self._arr(descs, abi.ProposalDesc)
+        ms = np.ascontiguousarray(meas_slots if meas_slots is not None else [-1] * n, dtype=np.int32)
+        rc = self.lib.orc_run_deconvs(_dp(self.arena), self.N, arr, ms.ctypes.data_as(C.POINTER(C.c_int32)), n)
         if rc:
             raise RuntimeError(f"oracle status {rc}")
 

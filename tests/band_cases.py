@@ -299,3 +299,45 @@ def case_partial_relative_and_products(backend):
 CASES = [case_forward_convolve, case_five_chain_spread, case_back_and_forth_spreads, case_approxconv_kaess_chains,
          case_ccw_forward_reverse, case_conv_95_percent, case_euclid_distance_1d, case_euclid_distance_2d,
          case_se2_hex, case_se2_multihypo, case_simple_mixture, case_partial_prior, case_partial_relative_and_products]
+
+
+def case_deconv(backend):
+    # test/testDefaultDeconv.jl:14-32 (LinearRelative on a 1-D line), :140-163 (EuclidDistance) and
+    # test/testSpecialEuclidean2Mani.jl:225-258 (SE(2)): the predicted measurement distribution matches
+    # the measured one
+    fg = iif.generateGraph_LineStep(2, solverParams=iif.SolverParams(N=100))
+    iif.initAll(fg, backend=backend, seed=50)
+    f = [l for l in fg.lsf() if len(fg.getFactor(l).variables) == 2][0]
+    pred, meas = iif.approxDeconv(fg, f, backend=backend, seed=51)
+    assert pred.shape == meas.shape == (100, 1)
+    a, b = fg.getFactor(f).variables
+    np.testing.assert_allclose(pred[:, 0], fg.getVal(b)[:, 0] - fg.getVal(a)[:, 0], atol=1e-6)  # z* = x2 - x1
+    assert abs(pred.mean() - meas.mean()) < 0.2
+
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(0, 1)))
+    iif.addFactor(fg, ["x0", "x1"], iif.EuclidDistance(iif.Normal(10, 1)))
+    iif.initAll(fg, backend=backend, seed=52)
+    iif.solveTree(fg, backend=backend, seed=53)
+    pred, meas = iif.approxDeconv(fg, "x0x1f1", backend=backend, seed=54)
+    np.testing.assert_allclose(pred[:, 0], np.abs(fg.getVal("x1")[:, 0] - fg.getVal("x0")[:, 0]), atol=1e-5)
+    assert abs(pred.mean() - meas.mean()) < 1.0 and abs(pred.std() - meas.std()) < 1.0
+
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.SpecialEuclidean2)
+    iif.addVariable(fg, "x1", iif.SpecialEuclidean2)
+    iif.addFactor(fg, ["x0"], iif.ManifoldPrior(np.array([10.0, 10.0, np.pi]), iif.MvNormal(np.zeros(3), np.diag([0.1, 0.1, 0.01]) ** 2)))
+    iif.addFactor(fg, ["x0", "x1"], iif.ManifoldFactor(iif.MvNormal([10.0, 0, 0.1], np.diag([0.5, 0.5, 0.05]) ** 2)))
+    iif.initAll(fg, backend=backend, seed=55)
+    pred, meas = iif.approxDeconv(fg, "x0x1f1", backend=backend, seed=56)
+    assert pred.shape == (100, 3)
+    assert abs(pred[:, 2].mean() - 0.1) < 0.02 and abs(pred[:, 2].std() - 0.05) < 0.02
+    np.testing.assert_allclose(pred[:, :2].mean(axis=0), [10, 0], atol=0.3)
+    np.testing.assert_allclose(pred[:, :2].std(axis=0), [0.5, 0.5], atol=0.3)
+    assert abs(pred[:, 2].mean() - meas[:, 2].mean()) < 0.03 and abs(pred[:, 2].std() - meas[:, 2].std()) < 0.03
+    np.testing.assert_allclose(pred[:, :2].mean(axis=0), meas[:, :2].mean(axis=0), atol=0.3)
+
+
+CASES.append(case_deconv)

@@ -340,3 +340,39 @@ def test_partial_descriptors_are_validated(hip_backend):
     with pytest.raises(iif.NbpError):
         be.run_products([p])
     be.close()
+
+
+# ---- approxDeconv (DeconvUtils.jl) -------------------------------------------------------------
+@pytest.mark.parametrize("kind,manifold,mean,sig", CASES)
+def test_deconv(oracle_backend, hip_backend, kind, manifold, mean, sig):
+    N = 200
+    rng = np.random.default_rng(4000 + 10 * kind + manifold)
+    a = rand_points(rng, manifold, N, center=0.0, spread=0.3)
+    b = rand_points(rng, manifold, N, center=1.0, spread=0.3)
+    d = relative_factor_desc(kind, manifold, 2, 1, [0, 1], 2, 777 + kind, mean, sig)
+    Z = len(mean)
+    zman = {1: abi.EUCLID1, 2: abi.EUCLID2, 3: abi.EUCLID3}[Z]
+
+    def setup(be):
+        be.slot_write(0, manifold, a)
+        be.slot_write(1, manifold, b)
+
+    def read(be):
+        return be.slot_read(2, zman)[0], be.slot_read(3, zman)[0], be.diag(reset=True)
+
+    o, h = both(oracle_backend, hip_backend, N, 4, 0, setup, lambda be: be.run_deconv([d], [3]), read)
+    np.testing.assert_allclose(h[1], o[1], rtol=1e-12, atol=1e-14)  # sampled measurements: same stream
+    np.testing.assert_allclose(h[0], o[0], rtol=1e-9, atol=1e-9)    # predicted measurements
+    assert h[2]["solves"] == N
+    # the prediction zeroes the residual: check against the closed forms
+    from parity_utils import coords
+    ca, cb = coords(manifold, a), coords(manifold, b)
+    if kind == abi.F_LINREL:
+        np.testing.assert_allclose(h[0], cb - ca, atol=1e-5 if Z == 1 else 2e-3)  # NelderMead stops at g_tol 1e-8 on f
+    elif kind == abi.F_EUCLIDDIST:
+        np.testing.assert_allclose(h[0][:, 0], np.linalg.norm(cb - ca, axis=1), atol=1e-5)
+    elif kind == abi.F_SE2:
+        dx, dy = cb[:, 0] - ca[:, 0], cb[:, 1] - ca[:, 1]
+        c, s = np.cos(ca[:, 2]), np.sin(ca[:, 2])
+        np.testing.assert_allclose(h[0][:, 0], c * dx + s * dy, atol=2e-3)
+        np.testing.assert_allclose(h[0][:, 1], -s * dx + c * dy, atol=2e-3)
