@@ -30,6 +30,8 @@ def parse():
     ap.add_argument("--particles", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vars", type=int, default=300)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing: take the sharded multi-GPU code path (process group, torch-owned arena) even with one rank")
     return ap.parse_args()
 
 
@@ -68,7 +70,7 @@ def main():
     import iif_amd_loader
     iif = iif_amd_loader.load()
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)

@@ -9,7 +9,8 @@ class RankSolve:
 
     def prepare(self):
         iif = self.iif
-        if self.world > 1:
+        self.sharded = self.world > 1 or self.dist is not None
+        if self.sharded:
             from iif_amd.dist_solver import ShardedTreeSolve
             self.impl = ShardedTreeSolve(iif, self.nvars * self.world, self.N, self.rank, self.world, self.local, self.dist)
             self.impl.prepare()
@@ -36,14 +37,14 @@ class RankSolve:
                       "alg_bytes": tp.alg_bytes_by_kernel()}
 
     def step(self, k):
-        if self.world > 1:
+        if self.sharded:
             return self.impl.step(k)
         self.prog.reseed(0x9E37 + k)
         self.prog.run()
 
     def check_posteriors(self):
         """posteriors within the BASELINE.md tolerance of the ground truth x_i = (i, i)"""
-        if self.world > 1:
+        if self.sharded:
             self.impl.check_posteriors()
             self.posterior_max_mean_err = self.impl.posterior_max_mean_err
             return

@@ -1,0 +1,44 @@
+"""-m gpu: bench.py's contract (one JSON line, required fields) on a small chain, single process and
+through torch.distributed.run with the sharded code path (RCCL process group, torch-owned arena)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(line):
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "clique-messages/sec" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["config"]["messages_per_step"] == 2 * (d["config"]["cliques"] - 1)
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    return d
+
+
+def test_bench_single_process():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--nvars", "200", "--cpu-sample-vars", "40"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check(out.stdout.strip().splitlines()[-1])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+
+
+def test_bench_sharded_path_one_rank():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "1", "--steps", "2",
+                          "--warmup", "1", "--nvars", "200", "--force-dist", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check(out.stdout.strip().splitlines()[-1])
