@@ -617,6 +617,8 @@ struct nbp_program {
   char *dev = nullptr;
   bool finalized = false;
   int n_user_stages = 0;
+  size_t seed_off = 0;  // table of the blob offsets of every descriptor's seed field (one reseed launch)
+  int n_seeds = 0;
 };
 
 nbp_status nbp_program_create(nbp_ctx *c, nbp_program **out) {
@@ -693,6 +695,20 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     }
     st.ent_off = off;
   }
+  {
+    std::vector<int64_t> so;
+    for (int s = 0; s < p->n_user_stages; s++) {
+      const nbp_stage &st = p->stages[s];
+      if (st.kind == NBP_STAGE_PROPOSALS)
+        for (int i = 0; i < st.n; i++) so.push_back((int64_t)(st.offset + (size_t)i * sizeof(nbp_proposal_desc) + offsetof(nbp_proposal_desc, seed)));
+      else if (st.kind == NBP_STAGE_PRODUCTS)
+        for (int i = 0; i < st.n; i++) so.push_back((int64_t)(st.offset + (size_t)i * sizeof(nbp_product_desc) + offsetof(nbp_product_desc, seed)));
+    }
+    p->seed_off = (p->blob.size() + 63) & ~(size_t)63;
+    p->n_seeds = (int)so.size();
+    p->blob.resize(p->seed_off + so.size() * 8);
+    if (!so.empty()) memcpy(p->blob.data() + p->seed_off, so.data(), so.size() * 8);
+  }
   nbp_status rc = ensure_ws(p->ctx, maxprod);
   if (rc) return rc;
   size_t bytes = p->blob.size() ? p->blob.size() : 64;
@@ -739,14 +755,9 @@ nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
   nbp_ctx *c = p->ctx;
   HIPCHK(hipSetDevice(c->device));
   (void)hipGetLastError();
-  for (const nbp_stage &st : p->stages) {
-    if (st.n == 0) continue;
-    int blocks = (st.n + 255) / 256;
-    if (st.kind == NBP_STAGE_PROPOSALS)
-      hipLaunchKernelGGL(nbp_reseed_proposals, dim3(blocks), dim3(256), 0, c->stream, (nbp_proposal_desc *)(p->dev + st.offset), st.n, salt);
-    else if (st.kind == NBP_STAGE_PRODUCTS)
-      hipLaunchKernelGGL(nbp_reseed_products, dim3(blocks), dim3(256), 0, c->stream, (nbp_product_desc *)(p->dev + st.offset), st.n, salt);
-  }
+  if (p->n_seeds > 0)
+    hipLaunchKernelGGL(nbp_reseed_kernel, dim3((p->n_seeds + 255) / 256), dim3(256), 0, c->stream, p->dev,
+                       (const int64_t *)(p->dev + p->seed_off), p->n_seeds, salt);
   HIPCHK(hipGetLastError());
   return NBP_OK;
 }

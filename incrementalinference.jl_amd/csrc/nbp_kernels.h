@@ -333,13 +333,13 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__global__ void nbp_reseed_proposals(nbp_proposal_desc *d, int n, uint64_t salt) {
+// re-key every op of a resident program: seed <- splitmix64(seed ^ splitmix64(salt)) (seeds.py mix_seed)
+__global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, uint64_t salt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) d[i].seed = splitmix64(d[i].seed ^ splitmix64(salt));
-}
-__global__ void nbp_reseed_products(nbp_product_desc *d, int n, uint64_t salt) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) d[i].seed = splitmix64(d[i].seed ^ splitmix64(salt));
+  if (i < n) {
+    uint64_t *s = (uint64_t *)(blob + seed_off[i]);
+    *s = splitmix64(*s ^ splitmix64(salt));
+  }
 }
 
 // ================================================================================================

@@ -31,7 +31,7 @@ def per_kernel(rows, counter, steps, lps=67):
             by[name].append((float(r["Counter_Value"]), int(r["Grid_Size"]) // int(r["Workgroup_Size"])))
     out = {}
     for k, v in by.items():
-        tail = v if k in ("nbp_copy_kernel", "nbp_reseed_proposals", "nbp_reseed_products") else v[-steps * lps:]
+        tail = v if k in ("nbp_copy_kernel", "nbp_reseed_kernel") else v[-steps * lps:]
         out[k] = tail
     return out
 
