@@ -32,6 +32,8 @@ def test_bench_single_process():
     d = _check(out.stdout.strip().splitlines()[-1])
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    ns = d["north_star_10k"]  # BASELINE config 2': the graph the >= 20x target is stated on
+    assert ns["messages_per_step"] > 19000 and ns["vs_cpu_baseline"] > 20.0
 
 
 def test_bench_sharded_path_one_rank():
