@@ -97,7 +97,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("NBP_LIB_OVERRIDE") or LIB_PATH  # override: kernel experiments (tools/exp)
     if not os.path.exists(path):
         raise RuntimeError(
             f"libnbp.so not found at {path}: build it with `python __graft_entry__.py` "

@@ -129,8 +129,9 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
   const double t = fma(x, 46.16624130844683, 6755399441055744.0);
   const int n = __double2loint(t);
   const double tf = t - 6755399441055744.0;
-  double r = fma(tf, -2.16608493865351192653e-02, x);
-  r = fma(tf, -5.96317165397058656257e-12, r);
+  // one-constant reduction: |tf| <= 3.3e4, so the rounding of ln2/32 (<= 1.8e-18) moves r by <= 6e-14
+  // at the clamp and by < 1e-15 where the result still matters to a sum
+  const double r = fma(tf, -2.1660849392498290e-02, x);
   // Horner with the coefficients pinned in SGPRs: one v_fma_f64 per step (hipcc otherwise keeps them
   // in VGPRs and pays a v_mov_b64 + v_fmac_f64 per step)
   double p;
@@ -597,24 +598,44 @@ __device__ __forceinline__ void deconv_particle(int kind, int manifold, const do
 // unordered pair is computed once, added to lane i's own row sum (register) and to row j's
 // accumulator acc[wave][j] in LDS (one private accumulator row per wave: lanes of a wave hit
 // consecutive j -> conflict-free; a wave's LDS ops execute in order -> deterministic sums).
+// in-kernel phase timing (tools/phase_timing.py, tools/lcv_phase_timing.py): debug builds only
+#ifdef NBP_PHASE_TIMING
+__device__ long long nbp_phase_clk[64];
+#define NBP_TICK(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)wall_clock64() - t_last_; t_last_ = wall_clock64(); } while (0)
+#define NBP_TICK_INIT() long long t_last_ = wall_clock64()
+// shader-clock variant for the short phases of one LCV evaluation, measured in the LAST workgroup
+// of the launch (so that a chip-filling batch is in flight around it)
+#define NBP_CTICK(k) do { if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)__builtin_readcyclecounter() - c_last_; c_last_ = __builtin_readcyclecounter(); } while (0)
+#define NBP_CTICK_INIT() long long c_last_ = __builtin_readcyclecounter()
+#else
+#define NBP_TICK(k)
+#define NBP_TICK_INIT()
+#define NBP_CTICK(k)
+#define NBP_CTICK_INIT()
+#endif
+
 typedef __attribute__((address_space(3))) double nbp_lds_double;
+#ifdef NBP_EXPERIMENT_NO_PARTNER_ACC
+__device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { if (v < -1.0) (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
+#else
 __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
+#endif
 
 template <bool CIRC>
-__device__ __forceinline__ double loo_symmetric(const double *x, int i, int t0, int t1, double xi, double c, double *accw,
-                                                const double *tab) {
-  // x and the accumulator row are stored twice over ([0,2N)): partner i+t never wraps, so both
-  // addresses are one base register plus an immediate that advances with t
+__device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta, int n4, int nt, bool extra, double xi, double c,
+                                                double *accw, const double *tab) {
+  // x and the accumulator row are stored twice over ([0,2N)): partner pi+t never wraps, so both
+  // addresses are one base register plus an immediate that advances with t.
   // The partner accumulation is an LDS atomic without return (ds_add_f64): lane i's slot at step t+1
   // is lane i+1's slot at step t, so plain read-modify-writes of consecutive steps would have to stay
   // strictly ordered (and exposed to the LDS latency); the atomic is applied by the LDS unit in the
   // wave's program order, so sums stay deterministic (one private row per wave).
-  const double *xp = x + i;
-  nbp_lds_double *ap = (nbp_lds_double *)(accw + i);
+  // Steps [ta, ta + 4*n4 + nt) plus one more when `extra`; n4 and nt are wave-uniform (scalar loops).
+  const double *xp = x + pi + ta;
+  nbp_lds_double *ap = (nbp_lds_double *)(accw + pi + ta);
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int t = t0;  // t0, t1 are wave-uniform (scalar loop control)
-  for (; t + 3 < t1; t += 4) {
-    double d0 = xi - xp[t], d1 = xi - xp[t + 1], d2 = xi - xp[t + 2], d3 = xi - xp[t + 3];
+  for (int k = 0; k < n4; k++, xp += 4, ap += 4) {
+    double d0 = xi - xp[0], d1 = xi - xp[1], d2 = xi - xp[2], d3 = xi - xp[3];
     if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); d2 = wrap_pi(d2); d3 = wrap_pi(d3); }
     const double e0 = exp_nonpos(-d0 * d0 * c, tab), e1 = exp_nonpos(-d1 * d1 * c, tab);
     const double e2 = exp_nonpos(-d2 * d2 * c, tab), e3 = exp_nonpos(-d3 * d3 * c, tab);
@@ -622,49 +643,78 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int i, int t0, 
     s1 += e1;
     s2 += e2;
     s3 += e3;
-    lds_add(ap + t, e0);
-    lds_add(ap + t + 1, e1);
-    lds_add(ap + t + 2, e2);
-    lds_add(ap + t + 3, e3);
+    lds_add(ap, e0);
+    lds_add(ap + 1, e1);
+    lds_add(ap + 2, e2);
+    lds_add(ap + 3, e3);
   }
-  for (; t < t1; t++) {
-    double d0 = xi - xp[t];
+  for (int k = 0; k < nt; k++) {
+    double d0 = xi - xp[k];
     if (CIRC) d0 = wrap_pi(d0);
     const double e0 = exp_nonpos(-d0 * d0 * c, tab);
     s0 += e0;
-    lds_add(ap + t, e0);
+    lds_add(ap + k, e0);
+  }
+  if (extra) {
+    double d0 = xi - xp[nt];
+    if (CIRC) d0 = wrap_pi(d0);
+    const double e0 = exp_nonpos(-d0 * d0 * c, tab);
+    s1 += e0;
+    lds_add(ap + nt, e0);
   }
   return (s0 + s1) + (s2 + s3);
 }
 
 // LDS: x[2N] (the coordinate, twice), part[P][Npad] row-sum partials, acc[NW][2N] per-wave partner
 // accumulators (entry j and j+N both belong to point j).
-// `acc` must be all-zero on entry and is all-zero again on exit (the combine step clears what it
-// reads), so one evaluation costs three barriers: compute | combine+log | cross-wave sum.
-__device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double *part, double *red,
-                                             const double *tab) {
-  const double inv2h2 = 1.0 / (2.0 * h * h);
-  const double lognorm = log(h) + 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
+// `acc` and `part` must be all-zero on entry and are all-zero again on exit (the readers clear what
+// they read), so one evaluation costs three barriers: compute | combine+log | cross-wave sum.
+__device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double lognorm0, double *part,
+                                             double *red, const double *tab) {
+  // log(s_i) - log(h) - lognorm0 = log(s_i / h) - lognorm0: one log sequence per evaluation instead of
+  // three (every lane of a wave pays for a log whether one lane needs it or all of them do)
+  NBP_CTICK_INIT();
+  const double inv_h = 1.0 / h, inv2h2 = 0.5 * inv_h * inv_h;
   const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
   const int w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   double *acc = part + P * Npad;
-  if (i < N) {
+  {
+    // Lane roles of the pair loop.  Normally lane (i, p) owns point i and the p-th share of the partner
+    // steps.  The last wave of a row holds only A = N - 64*floor((N-1)/64) points; when it is at most
+    // half full its 64 lanes are re-dealt as A2 points x HH sub-helpers (A2 = A rounded up to a power
+    // of two, HH = 64/A2) that split the row's share HH ways, so that the wave leaves the SIMD after
+    // 1/HH of the steps instead of idling most of its lanes through all of them (N = 200: 8 points
+    // x 8 sub-helpers).  Row sums and partner sums are LDS atomics, so any dealing gives the same sets.
     const int H = (N - 1) / 2;  // full partner steps
-    const int t0 = __builtin_amdgcn_readfirstlane(1 + (p * H) / P), t1 = __builtin_amdgcn_readfirstlane(1 + ((p + 1) * H) / P);
-    const double xi = x[i];
-    double *accw = acc + w * 2 * N;
-    double s = circ ? loo_symmetric<true>(x, i, t0, t1, xi, inv2h2, accw, tab) : loo_symmetric<false>(x, i, t0, t1, xi, inv2h2, accw, tab);
+    const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
+    const int lastbase = (N - 1) & ~63, A = N - lastbase, l = threadIdx.x & 63;
+    int A2 = 1;
+    while (A2 < A) A2 <<= 1;
+    const bool redeal = (i >= lastbase) && A2 <= 32;  // wave-uniform
+    const int HH = redeal ? 64 / A2 : 1;
+    const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l / A2 : 0;
+    const int len = t1 - t0, lenmin = len / HH, rem = len - lenmin * HH;
+    const int ta = t0 + hh * lenmin + min(hh, rem);
+    const int n4 = __builtin_amdgcn_readfirstlane(lenmin >> 2), nt = __builtin_amdgcn_readfirstlane(lenmin & 3);
+    if (pi < N) {
+      const double xi = x[pi];
+      double *accw = acc + w * 2 * N;
+      const double s = circ ? loo_symmetric<true>(x, pi, ta, n4, nt, hh < rem, xi, inv2h2, accw, tab)
+                            : loo_symmetric<false>(x, pi, ta, n4, nt, hh < rem, xi, inv2h2, accw, tab);
+      lds_add((nbp_lds_double *)(part + p * Npad + pi), s);
+    }
     if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair
       const int j = i + N / 2;
-      double d = xi - x[j];
+      double d = x[i] - x[j];
       if (circ) d = wrap_pi(d);
       const double e = exp_nonpos(-d * d * inv2h2, tab);
-      s += e;
-      lds_add((nbp_lds_double *)(accw + j), e);
+      lds_add((nbp_lds_double *)(part + p * Npad + i), e);
+      lds_add((nbp_lds_double *)(acc + w * 2 * N + j), e);
     }
-    part[p * Npad + i] = s;
   }
+  NBP_CTICK(20);  // pair loop
   __syncthreads();
+  NBP_CTICK(21);  // barrier 1
   // combine: helper p folds the accumulator rows p, p+P, ... of point i (and clears them)
   if (i < N) {
     double s = part[p * Npad + i];
@@ -676,18 +726,25 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     }
     part[p * Npad + i] = s;
   }
+  NBP_CTICK(22);  // combine
   __syncthreads();
+  NBP_CTICK(23);  // barrier 2
   double term = 0;
   if (p == 0 && i < N) {
-    double s = part[i];
-    for (int q = 1; q < P; q++) s += part[q * Npad + i];
+    double s = 0;
+    for (int q = 0; q < P; q++) {  // read-and-clear: the next evaluation accumulates into zeros
+      s += part[q * Npad + i];
+      part[q * Npad + i] = 0.0;
+    }
     if (s < 1e-300) s = 1e-300;
-    term = log(s) - lognorm;
+    term = log(s * inv_h) - lognorm0;
   }
   // only the first Npad lanes hold terms: reduce their waves
   term = wave_sum(term);
   if ((threadIdx.x & 63) == 0 && threadIdx.x < Npad) red[threadIdx.x >> 6] = term;
+  NBP_CTICK(24);  // log + wave reduction
   __syncthreads();
+  NBP_CTICK(25);  // barrier 3
   double tsum = red[0];
   for (int q = 1; q < (Npad >> 6); q++) tsum += red[q];
   return -tsum / (double)N;
@@ -708,6 +765,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   {  // per-wave partner accumulators start at zero (neg_loo_ll keeps them zero between calls)
     double *acc = part + (blockDim.x / Npad) * Npad;
     for (int q = threadIdx.x; q < (int)(blockDim.x >> 6) * 2 * N; q += blockDim.x) acc[q] = 0.0;
+    for (int q = threadIdx.x; q < (int)blockDim.x; q += blockDim.x) part[q] = 0.0;  // row sums are atomics too
   }
   double minm = block_min(mn, red);
   lo = block_min(lo, red);
@@ -718,15 +776,16 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   const double sc = 0.5 * (minm + maxm);
   const double ax = minm / sc, bx = 1.0, cx = maxm / sc;
   const double R = 0.61803399, C = 1.0 - R, tol = 1e-2;
+  const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   double x0 = ax, x3 = cx, x1, x2;
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
   else { x2 = bx; x1 = bx - C * (bx - ax); }
-  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red, tab);
+  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab);
   unsigned int nev = 2;
   while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
     nev++;
-    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, part, red, tab); }
-    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, part, red, tab); }
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab); }
+    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab); }
   }
   if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
   return (f1 < f2 ? x1 : x2) * sc;

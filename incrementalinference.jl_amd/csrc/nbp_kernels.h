@@ -362,15 +362,6 @@ __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, ui
 //                   chosen by the host when a launch has fewer products than CUs (latency-bound
 //                   tree tops); results do not depend on G (RNG is keyed by the sample index).
 // ================================================================================================
-#ifdef NBP_PHASE_TIMING
-__device__ long long nbp_phase_clk[64];
-#define NBP_TICK(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)wall_clock64() - t_last_; t_last_ = wall_clock64(); } while (0)
-#define NBP_TICK_INIT() long long t_last_ = wall_clock64()
-#else
-#define NBP_TICK(k)
-#define NBP_TICK_INIT()
-#endif
-
 // HBM workspace of one (product, density): xs[3][N] | cen[4] | idx[N] (int32)
 __host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return (size_t)3 * N + 4 + (size_t)(N + 1) / 2; }
 
@@ -485,6 +476,7 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
   }
 }
 
+#define NBP_SMALL_LEVEL 16
 struct product_lds {
   double *xs, *lm, *lv, *cen, *h2, *gm, *gt, *nw, *tab, *cMx, *cbefore, *ctarget;
   int *ind, *cowner;
@@ -566,7 +558,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       for (int j = 0; j < F; j++) ind[j * SPB + sl] = T.node_child[T.off[l - 1] + ind[j * SPB + sl]];  // levelDown!
     __syncthreads();
     NBP_TICK(3);  // level statistics
-    const int z0 = (sub * cnt) / P, z1 = ((sub + 1) * cnt) / P;  // this helper's node range
+    // Small levels (the top of the trees): the sample's first lane draws alone over all nodes -- no
+    // helper shares to combine, so no barriers; `ind` of a sample is private to that lane until the
+    // barriers at the top of the next level.
+    const bool small = cnt <= NBP_SMALL_LEVEL;
+    const bool act = live && (!small || sub == 0);
+    const int z0 = small ? 0 : (sub * cnt) / P, z1 = small ? cnt : ((sub + 1) * cnt) / P;  // this lane's node range
     for (int it = 0; it < d->niter; it++) {
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
         // Draw l_j ~ p(l_j | others) by inverse CDF over the nodes of this level.
@@ -614,7 +611,34 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           }
         };
         const int zr = z1 - z0, csz = (zr + NCH - 1) / NCH;  // chunk size of this helper's range
-        if (live) {
+        // pass 2 inside this lane's own range: find the chunk that holds `target`, rescan only that chunk
+        auto scan_chunks = [&](double before, double target, double Mx) {
+          double cacc = before;
+          int za = z0, zb = z1;
+          bool found = false;
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
+            const int ca = z0 + c * csz, cb = min(z1, ca + csz);
+            if (!found && ca < cb) {
+              za = ca; zb = cb;  // the last non-empty chunk is the fallback
+              if (target < cacc + share) found = true;
+              else cacc += share;
+            }
+          }
+          int choice = zb - 1;
+          if (found) {
+            double c = cacc;
+            for (int z = za; z < zb; z++) {
+              double a, g;
+              node_w(z, a, g);
+              c += exp_nonpos(a - Mx, L.tab) * g;
+              if (target < c) { choice = z; break; }
+            }
+          }
+          return choice;
+        };
+        if (act) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
             double prec = 0, acc = 0, ss = 0, sc = 0;
@@ -665,9 +689,14 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             cs[c] = cur;
             ms[c] = m;
           }
-          L.gm[sub * SPB + sl] = m;
-          L.gt[sub * SPB + sl] = tot;
+          if (small) {
+            ind[j * SPB + sl] = scan_chunks(0.0, ua * tot, m);
+          } else {
+            L.gm[sub * SPB + sl] = m;
+            L.gt[sub * SPB + sl] = tot;
+          }
         }
+        if (small) continue;
         __syncthreads();
         NBP_TICK(4);  // others-product + pass 1
         // combine: every helper rescales its own total to the common max (one exp each, in parallel),
@@ -730,30 +759,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             if (owner < 0) {  // rounding left u*total beyond the last share: last node of the level
               if (sub == lastne) ind[j * SPB + sl] = z1 - 1;
             } else if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
-              double cacc = before;
-              int za = z0, zb = z1;
-              bool found = false;
-#pragma unroll
-              for (int c = 0; c < NCH; c++) {
-                const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
-                const int ca = z0 + c * csz, cb = min(z1, ca + csz);
-                if (!found && ca < cb) {
-                  za = ca; zb = cb;  // the last non-empty chunk is the fallback
-                  if (target < cacc + share) found = true;
-                  else cacc += share;
-                }
-              }
-              int choice = zb - 1;
-              if (found) {
-                double c = cacc;
-                for (int z = za; z < zb; z++) {
-                  double a, g;
-                  node_w(z, a, g);
-                  c += exp_nonpos(a - Mx, L.tab) * g;
-                  if (target < c) { choice = z; break; }
-                }
-              }
-              ind[j * SPB + sl] = choice;
+              ind[j * SPB + sl] = scan_chunks(before, target, Mx);
             }
           }
           NBP_TICK(9);
