@@ -164,7 +164,9 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
-  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_l8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_m4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_t2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
@@ -321,7 +323,7 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
       if (any && D < 2) return fail(NBP_ERR_ARG, "product: partial densities need a variable of dimension >= 2");
       if (any && (p.old_slot < 0 || p.old_slot >= c->n_slots)) return fail(NBP_ERR_RANGE, "product: old_slot");
     }
-    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, c->Npad, c->threads, c->Npad);
+    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, 256);  // largest SPB of any geometry: 8 waves x 32 samples
     if (p.nfactors > 1 && lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: F*D*N exceeds the 160 KiB LDS");
   }
   return NBP_OK;
@@ -369,11 +371,6 @@ static nbp_status ensure_ws(nbp_ctx *c, int nprod) {
 }
 
 // sample groups per product: spread a product over G workgroups when the launch cannot fill the chip
-static int product_groups(nbp_ctx *c, int n) {
-  int G = n >= 128 ? 1 : (n >= 48 ? 2 : 4);
-  while (G > 1 && ((c->Npad / 64) % G != 0)) G >>= 1;
-  return G;
-}
 
 // Helper lanes per particle for the LCV / KD launches: P = 4 (1024-lane workgroups) minimises the
 // latency of a single fit when the launch cannot fill the chip; P = 2 (512 lanes) lets four
@@ -404,23 +401,37 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   return toc(c, c->ev[1]);
 }
 
+// product launch geometry: HL helper lanes per sample (64/HL samples per wave), workgroups of `wpb` <= 8
+// waves, grid.y = G workgroups per product.  Latency mode (the launch cannot fill the chip): HL = 8 and
+// several small workgroups per product; throughput mode: HL = 2 so that one workgroup covers all
+// samples and the node statistics of a product are computed once.
+static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
+  *HL = n >= 192 ? 2 : (n >= 48 ? 4 : 8);
+  const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL == 8) ? 6 : 8;
+  int g = (waves + cap - 1) / cap;
+  *wpb = (waves + g - 1) / g;
+  *G = (waves + *wpb - 1) / *wpb;
+}
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD) {
   if (n <= 0) return NBP_OK;
-  const int G = product_groups(c, n), SPB = c->Npad / G;
-  // throughput mode: 512-lane workgroups (four per CU) once the launch fills the chip
-  const int TB = (n >= 256 && c->P > 2) ? 2 * c->Npad : c->threads;
+  int HL, wpb, G;
+  product_geometry(c, n, &HL, &wpb, &G);
+  const int TB = wpb * 64, SPB = TB / HL;
   // maxFD encodes the largest (F, D) of the batch as F*4 + D
-  const size_t lds = nbp_product_lds_bytes(maxFD / 4, maxFD % 4, c->N, c->Npad, TB, SPB);
+  const size_t lds = nbp_product_lds_bytes(maxFD / 4, maxFD % 4, c->N, SPB);
   nbp_status rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_product_kernel, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->Npad,
-                     c->S, c->side, c->T);
+  if (HL == 8)
+    hipLaunchKernelGGL(nbp_product_kernel_l8, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->S, c->side, c->T);
+  else if (HL == 4)
+    hipLaunchKernelGGL(nbp_product_kernel_m4, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->S, c->side, c->T);
+  else
+    hipLaunchKernelGGL(nbp_product_kernel_t2, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }
 
-// manikde! bandwidth fits: grid (njobs, 3), one workgroup per (slot, coordinate)
 static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const int32_t *dev_manis, int n) {
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev[3]);

@@ -476,52 +476,53 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
   }
 }
 
-#define NBP_SMALL_LEVEL 16
+// Gibbs geometry: HL adjacent lanes of ONE wave serve one output sample (a wave carries 64/HL samples).
+// The helpers of a sample split the nodes of a level into contiguous ranges and combine their shares
+// with wave shuffles, so a conditional draw needs no barrier and no LDS round trip; the only
+// workgroup barriers left are the two around the per-level node statistics.  The host picks HL per
+// launch: 8 when the launch cannot fill the chip (latency: short ranges, several small workgroups per
+// product), 4 or 2 when it can (throughput: one workgroup per product computes the node statistics once).
 struct product_lds {
-  double *xs, *lm, *lv, *cen, *h2, *gm, *gt, *nw, *tab, *cMx, *cbefore, *ctarget;
-  int *ind, *cowner;
+  double *xs, *lm, *lv, *cen, *h2, *nw, *tab;
+  int *ind;
 };
 
-__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int Npad, int TB, int SPB, double *base, product_lds *L) {
+__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, double *base, product_lds *L) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
   size_t xs = dbl((size_t)F * D * N), lm = dbl((size_t)F * D * N), lv = dbl((size_t)F * D * N);
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
-  size_t gm = dbl((size_t)TB), gt = dbl((size_t)TB);
-  size_t nw = dbl((size_t)Npad), tab = dbl(NBP_EXPTAB);
-  size_t cMx = dbl((size_t)SPB), cbefore = dbl((size_t)SPB), ctarget = dbl((size_t)SPB);
+  size_t nw = dbl((size_t)N), tab = dbl(NBP_EXPTAB);
   size_t ints0 = o;
   if (L) {
     L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2;
-    L->gm = base + gm; L->gt = base + gt; L->nw = base + nw; L->tab = base + tab;
-    L->cMx = base + cMx; L->cbefore = base + cbefore; L->ctarget = base + ctarget;
+    L->nw = base + nw; L->tab = base + tab;
     L->ind = (int *)(base + ints0);
-    L->cowner = L->ind + (size_t)F * SPB;
   }
-  return ints0 * 8 + ((size_t)F * SPB + SPB) * 4;
+  return ints0 * 8 + (size_t)F * SPB * 4;
 }
 
 // PARTIAL: some input density is partial (AMP.marginal(propBel, pardims), ApproxConv.jl:287-291): a
 // density enters the conditionals and the final draw on its own coordinates only; a coordinate that
 // no density informs keeps the old point (GraphProductOperations.jl:39-45).  Separate instantiation so
 // that the all-full path carries no masks.
-template <int MANI, bool PARTIAL>
-__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int N, int Npad,
-                                             int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
+template <int MANI, bool PARTIAL, int HL>
+__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int N, int64_t S,
+                                             int32_t *side, const nbp_levels &T, double *smem) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
   const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
-  const int G = gridDim.y, SPB = Npad / G, P = TB / SPB;  // samples per workgroup, helpers per sample
-  const int sl = tid % SPB, sub = tid / SPB, s = blockIdx.y * SPB + sl;
+  const int SPB = TB / HL;                 // output samples of this workgroup
+  const int sl = tid / HL, h = tid % HL;   // sample (local), helper index
+  const int s = blockIdx.y * SPB + sl;
   const bool live = s < N;
   product_lds L;
-  product_lds_layout(F, D, N, Npad, TB, SPB, smem, &L);
+  product_lds_layout(F, D, N, SPB, smem, &L);
   double *xs = L.xs, *lm = L.lm, *lv = L.lv, *cen = L.cen, *h2 = L.h2;
   int *ind = L.ind;
   double *out = arena + S * d->out_slot;
   const double *wsp = ws + (size_t)blockIdx.x * NBP_MAXF * nbp_kd_ws_doubles(N);
   nbp_exp_tab_init(L.tab);
-  NBP_TICK_INIT();
   // ---- stage the KD-sorted, centred coordinates of every density + bandwidths ------------------
   for (int item = tid; item < F * D * N; item += TB) {
     const int j = item / (D * N), r = item % (D * N);
@@ -533,9 +534,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     h2[tid] = (k < D) ? bw * bw : 0.0;
     cen[tid] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
   }
-  if (sub == 0)
+  if (h == 0)
     for (int j = 0; j < F; j++) ind[j * SPB + sl] = 0;  // levelInit!: root
-  NBP_TICK(2);
   // ---- multiscale Gibbs ---------------------------------------------------------------------
   for (int l = 1; l <= T.L; l++) {
     const int cnt = T.cnt[l], off = T.off[l];
@@ -554,16 +554,11 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       lv[jk * N + z] = var + h2[j * 3 + k];
     }
     for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
-    if (sub == 0 && live)
+    if (h == 0 && live)
       for (int j = 0; j < F; j++) ind[j * SPB + sl] = T.node_child[T.off[l - 1] + ind[j * SPB + sl]];  // levelDown!
     __syncthreads();
-    NBP_TICK(3);  // level statistics
-    // Small levels (the top of the trees): the sample's first lane draws alone over all nodes -- no
-    // helper shares to combine, so no barriers; `ind` of a sample is private to that lane until the
-    // barriers at the top of the next level.
-    const bool small = cnt <= NBP_SMALL_LEVEL;
-    const bool act = live && (!small || sub == 0);
-    const int z0 = small ? 0 : (sub * cnt) / P, z1 = small ? cnt : ((sub + 1) * cnt) / P;  // this lane's node range
+    const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range
+    const bool leaf = (l == T.L);
     for (int it = 0; it < d->niter; it++) {
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
         // Draw l_j ~ p(l_j | others) by inverse CDF over the nodes of this level.
@@ -572,13 +567,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         // evaluated in the linear domain with ONE rsqrt per node (its square is the reciprocal of the
         // variance product) and the running max taken over a_z only; at the leaf level v_k and w_z
         // are the same for every node, so g_z cancels and the reciprocals are hoisted.
-        // Pass 1 (all P helpers, contiguous node ranges, NCH chunks each): rescaled totals.
-        // Pass 2 (the owning helper only): locate the chunk, re-evaluate just that chunk.
+        // Pass 1 (all helpers, NCH chunks each): rescaled totals -> shuffle max / prefix sum.
+        // Pass 2 (the helper whose share holds u * total): locate the chunk, re-evaluate just that chunk.
         constexpr int NCH = 4;
         double mn[D], vn[D], ua = 0, m = -INFINITY, tot = 0;
         double cs[NCH], ms[NCH];
         const double *mj = lm + j * D * N, *vj = lv + j * D * N;
-        const bool leaf = (l == T.L);
         double linv[D];
         bool use[D];  // PARTIAL: coordinates informed by density j and by at least one other
 #pragma unroll
@@ -611,34 +605,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           }
         };
         const int zr = z1 - z0, csz = (zr + NCH - 1) / NCH;  // chunk size of this helper's range
-        // pass 2 inside this lane's own range: find the chunk that holds `target`, rescan only that chunk
-        auto scan_chunks = [&](double before, double target, double Mx) {
-          double cacc = before;
-          int za = z0, zb = z1;
-          bool found = false;
-#pragma unroll
-          for (int c = 0; c < NCH; c++) {
-            const double share = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
-            const int ca = z0 + c * csz, cb = min(z1, ca + csz);
-            if (!found && ca < cb) {
-              za = ca; zb = cb;  // the last non-empty chunk is the fallback
-              if (target < cacc + share) found = true;
-              else cacc += share;
-            }
-          }
-          int choice = zb - 1;
-          if (found) {
-            double c = cacc;
-            for (int z = za; z < zb; z++) {
-              double a, g;
-              node_w(z, a, g);
-              c += exp_nonpos(a - Mx, L.tab) * g;
-              if (target < c) { choice = z; break; }
-            }
-          }
-          return choice;
-        };
-        if (act) {
+        if (live) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
             double prec = 0, acc = 0, ss = 0, sc = 0;
@@ -689,88 +656,56 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             cs[c] = cur;
             ms[c] = m;
           }
-          if (small) {
-            ind[j * SPB + sl] = scan_chunks(0.0, ua * tot, m);
-          } else {
-            L.gm[sub * SPB + sl] = m;
-            L.gt[sub * SPB + sl] = tot;
-          }
         }
-        if (small) continue;
-        __syncthreads();
-        NBP_TICK(4);  // others-product + pass 1
-        // combine: every helper rescales its own total to the common max (one exp each, in parallel),
-        // then ONE lane per sample walks the P shares to find the helper range that holds u * total.
-        if (live) {
-          double Mx = -INFINITY;
-          for (int q = 0; q < P; q++) Mx = fmax(Mx, L.gm[q * SPB + sl]);
-          const double sh = (tot > 0) ? tot * exp_nonpos(m - Mx, L.tab) : 0.0;
-          __builtin_amdgcn_s_waitcnt(0);  // all gm reads of this lane are done before gt is rewritten
-          L.gt[sub * SPB + sl] = sh;
-          if (sub == 0) L.cMx[sl] = Mx;
+        // combine over the HL helper lanes of the sample (adjacent lanes of this wave): common max,
+        // shares rescaled to it, inclusive prefix sum -> the one helper whose interval holds u * total
+        double Mx = m;
+#pragma unroll
+        for (int o = 1; o < HL; o <<= 1) Mx = fmax(Mx, __shfl_xor(Mx, o, HL));
+        const double share = (tot > 0) ? tot * exp_nonpos(m - Mx, L.tab) : 0.0;
+        double incl = share;
+#pragma unroll
+        for (int o = 1; o < HL; o <<= 1) {
+          const double v = __shfl_up(incl, o, HL);
+          if (h >= o) incl += v;
         }
-        __syncthreads();
-        if (sub == 0 && live) {
-          double total = 0;
-          for (int q = 0; q < P; q++) total += L.gt[q * SPB + sl];
-          const double target = ua * total;
-          double c0 = 0, before = 0;
-          int owner = -1;
-          for (int q = 0; q < P; q++) {
-            const double nc = c0 + L.gt[q * SPB + sl];
-            if (owner < 0 && target < nc) { owner = q; before = c0; }
-            c0 = nc;
-          }
-          if (P >= 8) {
-            // many short helper ranges (sample-split launch): this lane finishes the draw itself --
-            // one fully occupied wave instead of 1/P-occupied passes in every wave
-            int choice;
-            if (owner < 0) {
-              choice = cnt - 1;
-            } else {
-              const int za = (owner * cnt) / P, zb = ((owner + 1) * cnt) / P;
-              const double Mx = L.cMx[sl];
-              double c = before;
-              choice = zb - 1;
-              for (int z = za; z < zb; z++) {
-                double a, g;
-                node_w(z, a, g);
-                c += exp_nonpos(a - Mx, L.tab) * g;
-                if (target < c) { choice = z; break; }
-              }
-            }
-            ind[j * SPB + sl] = choice;
-          } else {
-            L.cbefore[sl] = before;
-            L.ctarget[sl] = target;
-            L.cowner[sl] = owner;
-          }
-        }
-        NBP_TICK(7);
-        __syncthreads();
-        NBP_TICK(8);
-        if (P < 8) {
-          if (live) {
-            const double Mx = L.cMx[sl], before = L.cbefore[sl], target = L.ctarget[sl];
-            const int owner = L.cowner[sl];
-            int lastne = 0;
-            for (int q = 0; q < P; q++)
-              if ((q * cnt) / P < ((q + 1) * cnt) / P) lastne = q;
-            if (owner < 0) {  // rounding left u*total beyond the last share: last node of the level
-              if (sub == lastne) ind[j * SPB + sl] = z1 - 1;
-            } else if (owner == sub) {  // pass 2: find the chunk, then inverse CDF inside it
-              ind[j * SPB + sl] = scan_chunks(before, target, Mx);
+        const double total = __shfl(incl, HL - 1, HL), target = ua * total, before = incl - share;
+        int choice = -1;
+        if (live && share > 0 && target >= before && target < incl) {
+          // pass 2 inside this helper's own range: find the chunk that holds `target`, rescan only it
+          double cacc = before;
+          int za = z0, zb = z1;
+          bool found = false;
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            const double shc = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
+            const int ca = z0 + c * csz, cb = min(z1, ca + csz);
+            if (!found && ca < cb) {
+              za = ca; zb = cb;  // the last non-empty chunk is the fallback
+              if (target < cacc + shc) found = true;
+              else cacc += shc;
             }
           }
-          NBP_TICK(9);
-          __syncthreads();
+          choice = zb - 1;
+          if (found) {
+            double c = cacc;
+            for (int z = za; z < zb; z++) {
+              double a, g;
+              node_w(z, a, g);
+              c += exp_nonpos(a - Mx, L.tab) * g;
+              if (target < c) { choice = z; break; }
+            }
+          }
         }
-        NBP_TICK(5);  // barrier after pass 2
+#pragma unroll
+        for (int o = 1; o < HL; o <<= 1) choice = max(choice, __shfl_xor(choice, o, HL));
+        if (choice < 0) choice = cnt - 1;  // rounding left u * total beyond the last share
+        if (h == 0 && live) ind[j * SPB + sl] = choice;
       }
     }
   }
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
-  if (sub == 0 && live) {
+  if (h == 0 && live) {
     double res[D];
     double n0, n1, n2 = 0, n3 = 0;
     normal_pair(d->seed, s, PURP_PFINAL, 0, n0, n1);
@@ -809,41 +744,55 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k * N + s] = (k < D) ? res[k < D ? k : 0] : 0.0;
   }
-  NBP_TICK(6);  // final draw
 }
 
-__global__ void __launch_bounds__(1024)
-nbp_product_kernel(const nbp_product_desc *descs, double *arena, const double *ws, int N, int Npad, int64_t S, int32_t *side,
-                   nbp_levels T) {
-  extern __shared__ double smem[];
+template <int HL>
+__device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
   if (d->nfactors == 1) {  // single density: AMP returns it unchanged
     if (blockIdx.y != 0) return;
     const double *src = arena + S * d->in_slot[0];
     double *out = arena + S * d->out_slot;
     for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
-    if (d->labels_out >= 0 && threadIdx.x < N) side[d->labels_out + threadIdx.x] = threadIdx.x;
+    if (d->labels_out >= 0)
+      for (int i = threadIdx.x; i < N; i += blockDim.x) side[d->labels_out + i] = i;
     return;
   }
   bool partial = false;
   for (int j = 0; j < d->nfactors; j++) partial |= (d->in_partial[j] != 0);
   if (partial) {  // validated on the host: D >= 2
     switch (d->manifold) {
-    case NBP_EUCLID2: product_body<NBP_EUCLID2, true>(d, arena, ws, N, Npad, S, side, T, smem); break;
-    case NBP_EUCLID3: product_body<NBP_EUCLID3, true>(d, arena, ws, N, Npad, S, side, T, smem); break;
-    default: product_body<NBP_SE2, true>(d, arena, ws, N, Npad, S, side, T, smem); break;
+    case NBP_EUCLID2: product_body<NBP_EUCLID2, true, HL>(d, arena, ws, N, S, side, T, smem); break;
+    case NBP_EUCLID3: product_body<NBP_EUCLID3, true, HL>(d, arena, ws, N, S, side, T, smem); break;
+    default: product_body<NBP_SE2, true, HL>(d, arena, ws, N, S, side, T, smem); break;
     }
     return;
   }
   switch (d->manifold) {
-  case NBP_EUCLID1: product_body<NBP_EUCLID1, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  case NBP_EUCLID2: product_body<NBP_EUCLID2, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  case NBP_EUCLID3: product_body<NBP_EUCLID3, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
-  default: product_body<NBP_SE2, false>(d, arena, ws, N, Npad, S, side, T, smem); break;
+  case NBP_EUCLID1: product_body<NBP_EUCLID1, false, HL>(d, arena, ws, N, S, side, T, smem); break;
+  case NBP_EUCLID2: product_body<NBP_EUCLID2, false, HL>(d, arena, ws, N, S, side, T, smem); break;
+  case NBP_EUCLID3: product_body<NBP_EUCLID3, false, HL>(d, arena, ws, N, S, side, T, smem); break;
+  case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false, HL>(d, arena, ws, N, S, side, T, smem); break;
+  default: product_body<NBP_SE2, false, HL>(d, arena, ws, N, S, side, T, smem); break;
   }
 }
 
-static inline size_t nbp_product_lds_bytes(int F, int D, int N, int Npad, int TB, int SPB) {
-  return product_lds_layout(F, D, N, Npad, TB, SPB, nullptr, nullptr);
+// Three entry points = three register budgets: the latency variant (HL = 8, few workgroups in flight)
+// keeps everything in registers; the throughput variants trade a few spills for 4-5 waves per SIMD.
+#define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int N, int64_t S, int32_t *side, nbp_levels T
+__global__ void __launch_bounds__(512) nbp_product_kernel_l8(NBP_PRODUCT_ARGS) {
+  extern __shared__ double smem[];
+  product_kernel_body<8>(descs, arena, ws, N, S, side, T, smem);
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) nbp_product_kernel_m4(NBP_PRODUCT_ARGS) {
+  extern __shared__ double smem[];
+  product_kernel_body<4>(descs, arena, ws, N, S, side, T, smem);
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) nbp_product_kernel_t2(NBP_PRODUCT_ARGS) {
+  extern __shared__ double smem[];
+  product_kernel_body<2>(descs, arena, ws, N, S, side, T, smem);
+}
+
+static inline size_t nbp_product_lds_bytes(int F, int D, int N, int SPB) {
+  return product_lds_layout(F, D, N, SPB, nullptr, nullptr);
 }
