@@ -402,4 +402,8 @@ def downSchedule(fg, cliq, MCIters=3):
     """solveCliqDownFrontalProducts!, CliqStateMachineUtils.jl:479-571"""
     iterFrtls = determineCliqVariableDownSequence(fg, cliq)
     directs = [v for v in cliq.frontalIDs if v not in iterFrtls]
+    if getattr(fg.solverParams, "limitfixeddown", False):  # ignore limited fixed-lag variables, :498-502
+        skip = {v for v in cliq.frontalIDs if fg.getVariable(v).ismargin}
+        iterFrtls = [v for v in iterFrtls if v not in skip]
+        directs = [v for v in directs if v not in skip]
     return directs + iterFrtls * MCIters

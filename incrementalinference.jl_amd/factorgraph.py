@@ -233,6 +233,7 @@ class SolverParams:
     graphinit: bool = True
     upsolve: bool = True
     downsolve: bool = True
+    limitfixeddown: bool = False  # skip marginalized frontals in the down solve (CliqStateMachineUtils.jl:499)
     productNiter: int = 1  # AMP.manifoldProduct(...; Niter=1), GraphProductOperations.jl:56
 
 

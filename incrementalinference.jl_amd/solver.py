@@ -511,7 +511,8 @@ class TreeProgram:
                     if v in tree.cliques[ch].separatorIDs:
                         lst.append(("m", ch))
                 upf[v] = lst
-            sched = [v for v in bayestree.upGibbsSchedule(cl, sp.gibbsIters) if upf[v]]
+            # doFMCIteration skips marginalized variables (SolveTree.jl:61)
+            sched = [v for v in bayestree.upGibbsSchedule(cl, sp.gibbsIters) if upf[v] and not fg.getVariable(v).ismargin]
             self.upsched[cid], self.upfacs[cid] = sched, upf
             dnf = {v: [f for f in fg.ls(v)] for v in cl.frontalIDs}
             self.dnfacs[cid] = dnf

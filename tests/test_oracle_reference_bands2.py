@@ -40,3 +40,32 @@ def test_residual_values():
     b = np.array([1.0, 3.0, np.pi])
     np.testing.assert_allclose(res(F_SE2, SE2, z, a, b), [0, 0, 0], atol=1e-12)
     assert abs(res(F_DIST, E2, [5.0], [0, 0], [3, 4])[0]) < 1e-12
+
+
+def test_marginalized_variables_are_not_updated(oracle_backend):
+    """doFMCIteration skips `ismargin` variables in the up solve (SolveTree.jl:61);
+    `limitfixeddown` makes the down solve skip them too (CliqStateMachineUtils.jl:498-502)."""
+    import numpy as np
+
+    from parity_utils import iif
+
+    def build():
+        fg = iif.initfg(iif.SolverParams(N=100, limitfixeddown=True))
+        for i in range(4):
+            iif.addVariable(fg, f"x{i}", iif.ContinuousScalar)
+        iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(0.0, 0.1)))
+        for i in range(3):
+            iif.addFactor(fg, [f"x{i}", f"x{i+1}"], iif.LinearRelative(iif.Normal(1.0, 0.1)))
+        iif.initAll(fg, backend=oracle_backend, seed=60)
+        return fg
+
+    fg = build()
+    fg.getVariable("x0").ismargin = True
+    frozen = fg.getVal("x0").copy()
+    iif.solveTree(fg, backend=oracle_backend, seed=61)
+    np.testing.assert_array_equal(fg.getVal("x0"), frozen)
+    for i in range(1, 4):
+        assert abs(fg.getVal(f"x{i}").mean() - i) < 0.4
+    fg2 = build()
+    iif.solveTree(fg2, backend=oracle_backend, seed=61)
+    assert np.abs(fg2.getVal("x0") - frozen).max() > 0  # without the flag x0 is re-estimated
