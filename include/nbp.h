@@ -85,7 +85,9 @@ typedef struct nbp_proposal_desc {
   int32_t out_slot;           /* scratch slot that receives the proposal (never the belief itself:
                                  services/CalcFactor.jl:543-548)                              */
   int32_t ncomp;              /* 1, or the number of Mixture components (Factors/Mixture.jl)  */
-  int32_t has_multihypo;      /* 0: hypotheses === nothing                                    */
+  int32_t has_multihypo;      /* 0: hypotheses === nothing; else bit 0 set.  Optional isinit flags of the
+                                 attached variables (ExplicitDiscreteMarginalizations.jl:161-172): bit 7 =
+                                 flags present, bit 8+k = variable k is initialised                */
   int32_t inflate_cycles;     /* SolverParams.inflateCycles (default 3)                       */
   int32_t mhidx_in;           /* >=0: offset into the ctx int32 side buffer holding an injected
                                  mhidx[N] (exact-match tests); -1: sample internally           */

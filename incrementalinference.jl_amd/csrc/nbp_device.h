@@ -859,16 +859,32 @@ __device__ __forceinline__ void build_recipe(const nbp_proposal_desc *d, recipe_
     else if (0.0 < d->multihypo[i]) unc[nunc++] = i + 1;
   }
   const bool sfunc = in_list(unc, nunc, sf1), sfincer = in_list(R->certain, R->ncertain, sf1);
+  // :161-172 -- uninitialised hypotheses are suppressed in the draw of mhidx when fewer than nvars-1
+  // variables are initialised (isinit flags: has_multihypo bit 7 = present, bit 8+k = variable k)
+  double mhs[NBP_MAXV];
+  for (int i = 0; i < NBP_MAXV; i++) mhs[i] = (i < nvars) ? d->multihypo[i] : 0.0;
+  if (d->has_multihypo & 0x80) {
+    int ninit = 0;
+    for (int i = 0; i < nvars; i++) ninit += (d->has_multihypo >> (8 + i)) & 1;
+    if (ninit < nvars - 1) {
+      double tot = 0;
+      for (int i = 0; i < nvars; i++) {
+        if (!((d->has_multihypo >> (8 + i)) & 1) && i + 1 != sf1) mhs[i] = 0.0;
+        tot += mhs[i];
+      }
+      for (int i = 0; i < nvars; i++) mhs[i] /= tot;
+    }
+  }
   int np = 0, pidx0;
   if (sfunc) {
     double nhw = (double)(nunc + 1), tot = 0;
     R->cat_p[np++] = 1.0 / nhw;
-    for (int i = 0; i < nvars; i++) R->cat_p[np++] = (double)nunc / nhw * d->multihypo[i];
+    for (int i = 0; i < nvars; i++) R->cat_p[np++] = (double)nunc / nhw * mhs[i];
     for (int i = 0; i < np; i++) tot += R->cat_p[i];
     for (int i = 0; i < np; i++) R->cat_p[i] /= tot;
     pidx0 = 0;
   } else {
-    for (int i = 0; i < nvars; i++) R->cat_p[np++] = d->multihypo[i];
+    for (int i = 0; i < nvars; i++) R->cat_p[np++] = mhs[i];
     pidx0 = 1;
   }
   R->ncat = np; R->cat_first = pidx0; R->ngroups = np;

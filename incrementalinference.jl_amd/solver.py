@@ -32,7 +32,7 @@ PRODUCT_ID = 0xFFFF
 # descriptor builders
 # ------------------------------------------------------------------------------------------------
 def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhidx_in=-1, mhidx_out=-1,
-                  skip_bandwidth=False, inflateCycles=None):
+                  skip_bandwidth=False, inflateCycles=None, isinit=None):
     """One approxConvBelief(dfg, fct, target) as a libnbp descriptor (ApproxConv.jl:4-45 +
     evalFactor kwargs, EvalFactor.jl:571-603)."""
     sp = fg.solverParams
@@ -71,7 +71,12 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
             for j in range(i + 1):
                 d.comp[c][4 + 3 * i + j] = L[i, j]
     if fct.multihypo is not None:
-        d.has_multihypo = 1
+        # isinit flags: uninitialised hypotheses are suppressed (ExplicitDiscreteMarginalizations.jl:161-172)
+        flags = 1 | 0x80
+        for i, v in enumerate(fct.variables):
+            if (isinit[v] if isinit is not None else fg.getVariable(v).initialized):
+                flags |= 1 << (8 + i)
+        d.has_multihypo = flags
         for i, p in enumerate(fct.multihypo):
             d.multihypo[i] = p
     return d
@@ -378,16 +383,16 @@ def _init_plan(fg):
             for fl in fg.ls(sym):
                 f = fg.getFactor(fl)
                 others = [v for v in f.variables if v != sym]
-                if f.isMultihypo:
-                    # factorCanInitFromOtherVars + isLeastOneHypoAvailable (#427): we require all
-                    # hypotheses initialised (documented restriction)
-                    ok = all(init[v] for v in others)
-                else:
-                    ok = all(init[v] for v in others)
+                ok = all(init[v] for v in others)  # priors and general n-ary cases, GraphInit.jl:90
+                if not ok and f.isMultihypo:
+                    # at least one hypothesis available (GraphInit.jl:94-105, FactorGraph.jl:772-784)
+                    cer = [v for v, p in zip(f.variables, f.multihypo) if p == 0.0]
+                    unc = [v for v, p in zip(f.variables, f.multihypo) if p > 0.0]
+                    ok = (sym in cer and any(init[v] for v in unc)) or (sym in unc and all(init[v] for v in cer))
                 if ok:
                     use.append(fl)
             if use:
-                plan.append((sym, use))
+                plan.append((sym, use, dict(init)))  # + the initialisation state the proposals see
                 init[sym] = True
             else:
                 repeat = True
@@ -408,17 +413,17 @@ def initAll(fg, backend=None, seed=0):
     labels = fg.ls()
     slot = {v: i for i, v in enumerate(labels)}
     V = len(labels)
-    maxF = max(len(u) for _, u in plan)
+    maxF = max(len(u) for _, u, _ in plan)
     # group consecutive independent inits into stages
     groups, cur, produced = [], [], set()
-    for sym, use in plan:
+    for sym, use, st in plan:
         deps = set()
         for fl in use:
             deps.update(v for v in fg.getFactor(fl).variables if v != sym)
         if deps & produced:
             groups.append(cur)
             cur, produced = [], set()
-        cur.append((sym, use))
+        cur.append((sym, use, st))
         produced.add(sym)
     if cur:
         groups.append(cur)
@@ -431,13 +436,13 @@ def initAll(fg, backend=None, seed=0):
         stages = []
         for gi, g in enumerate(groups):
             props, prods = [], []
-            for ci, (sym, use) in enumerate(g):
+            for ci, (sym, use, st) in enumerate(g):
                 fcts = [fg.getFactor(f) for f in use]
                 ns = _null_surplus(fg, fcts)
                 base = V + ci * maxF
                 for i, f in enumerate(fcts):
                     props.append(proposal_desc(fg, f, sym, slot.__getitem__, base + i,
-                                               op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i]))
+                                               op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i], isinit=st))
                 prods.append(product_desc(fg.getVariable(sym).varType.manifold, [base + i for i in range(len(fcts))],
                                           slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter,
                                           partials=_partials(fcts), old_slot=slot[sym]))
@@ -446,7 +451,7 @@ def initAll(fg, backend=None, seed=0):
         prog = be.program(stages)
         prog.run()
         be.synchronize()
-        for sym, _ in plan:
+        for sym, _, _ in plan:
             pts, bw = be.slot_read(slot[sym], fg.getVariable(sym).varType.manifold)
             setValKDE(fg, sym, pts, bw, True)
         prog.close()

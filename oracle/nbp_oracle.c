@@ -526,6 +526,25 @@ void orc_build_recipe(int has_multihypo, const double *mhp, int nvars, int sfidx
   }
   int sfunc = in_list(unc, nunc, sfidx1), sfincer = in_list(R->certain, R->ncertain, sfidx1);
   R->sf_uncertain = sfunc;
+  /* :161-172 -- select only hypotheses that can be used: when fewer than nvars-1 variables are
+     initialised, the uninitialised ones (except the solve-for variable) get probability 0 in the
+     draw of mhidx; certainidx / uncertnidx keep following the factor's own p.  The isinit flags
+     travel in has_multihypo: bit 7 = flags present, bit 8+k = variable k initialised. */
+  double mhs[NBP_MAXV];
+  for (int i = 0; i < nvars; i++) mhs[i] = mhp[i];
+  if (has_multihypo & 0x80) {
+    int ninit = 0;
+    for (int i = 0; i < nvars; i++) ninit += (has_multihypo >> (8 + i)) & 1;
+    if (ninit < nvars - 1) {
+      double tot = 0;
+      for (int i = 0; i < nvars; i++) {
+        if (!((has_multihypo >> (8 + i)) & 1) && i + 1 != sfidx1) mhs[i] = 0.0;
+        tot += mhs[i];
+      }
+      for (int i = 0; i < nvars; i++) mhs[i] /= tot;
+    }
+  }
+  mhp = mhs;
   double p[NBP_MAXV + 1];
   int np = 0, pidx0;
   if (sfunc) { /* :176-183 prepend the bad-init null hypothesis */

@@ -376,3 +376,24 @@ def test_deconv(oracle_backend, hip_backend, kind, manifold, mean, sig):
         c, s = np.cos(ca[:, 2]), np.sin(ca[:, 2])
         np.testing.assert_allclose(h[0][:, 0], c * dx + s * dy, atol=2e-3)
         np.testing.assert_allclose(h[0][:, 1], -s * dx + c * dy, atol=2e-3)
+
+
+@pytest.mark.parametrize("flags,expect", [(1 | 0x80 | (1 << 9), {2}), (1 | 0x80 | (1 << 10), {3}), (1 | 0x80 | (7 << 8), {2, 3})])
+def test_multihypo_isinit_suppression(oracle_backend, hip_backend, flags, expect):
+    """uninitialised hypotheses get probability 0 in the mhidx draw (ExplicitDiscreteMarginalizations.jl:161-172)"""
+    N, man = 200, abi.EUCLID2
+    rng = np.random.default_rng(flags)
+    pts = [rand_points(rng, man, N, c, 0.2) for c in (0.0, 5.0, -5.0)]
+    d = relative_factor_desc(abi.F_LINREL, man, 3, 0, [0, 1, 2], 3, 99, [1.0, 1.0], [0.1, 0.1],
+                             multihypo=[0.0, 0.5, 0.5], mhidx_out=0)
+    d.has_multihypo = flags
+
+    def setup(be):
+        for s, p in enumerate(pts):
+            be.slot_write(s, man, p)
+
+    o, h = both(oracle_backend, hip_backend, N, 4, N, setup, lambda be: be.run_proposals([d]),
+                lambda be: (be.slot_read(3, man), be.side_read(0, N)))
+    np.testing.assert_array_equal(o[1], h[1])
+    assert set(h[1].tolist()) == expect
+    assert_points_close(man, o[0][0], h[0][0], what="multihypo with isinit flags")

@@ -69,3 +69,45 @@ def test_marginalized_variables_are_not_updated(oracle_backend):
     fg2 = build()
     iif.solveTree(fg2, backend=oracle_backend, seed=61)
     assert np.abs(fg2.getVal("x0") - frozen).max() > 0  # without the flag x0 is re-estimated
+
+
+def test_uninitialised_hypotheses_are_suppressed(oracle_backend):
+    """ExplicitDiscreteMarginalizations.jl:161-172 + GraphInit.jl:94-105 (#427): with multihypo = [1, .5, .5]
+    and only ONE of the two fractional landmarks initialised, x0 is initialised from that hypothesis alone:
+    every particle draws mhidx = 2 (the suppressed one gets probability 0), certainidx stays [1]."""
+    import numpy as np
+
+    from parity_utils import abi, iif
+
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addVariable(fg, "la", iif.ContinuousScalar)
+    iif.addVariable(fg, "lb", iif.ContinuousScalar)
+    iif.addFactor(fg, ["la"], iif.Prior(iif.Normal(10.0, 0.1)))
+    iif.addFactor(fg, ["x0", "la", "lb"], iif.LinearRelative(iif.Normal(10.0, 0.1)), multihypo=[1, 0.5, 0.5])
+    # lb has no prior and x0 no other factor: the reference allows the init of x0 from hypothesis `la`
+    plan, _ = iif.solver._init_plan(fg)
+    assert [p[0] for p in plan][:2] == ["la", "x0"] or [p[0] for p in plan][:2] == ["x0", "la"][::-1]
+    iif.initAll(fg, backend=oracle_backend, seed=70)
+    assert fg.isInitialized("x0") and fg.isInitialized("la")
+    x0 = fg.getVal("x0")[:, 0]
+    assert abs(x0.mean() - 0.0) < 0.5 and x0.std() < 1.0  # la - 10 = 0: nothing drawn towards the identity values of lb
+
+    # the recipe itself, through the proposal op: injected flags, sampled mhidx
+    N = 100
+    be = oracle_backend(N, 4, N)
+    rng = np.random.default_rng(0)
+    for s, c in ((0, 0.0), (1, 10.0), (2, 0.0)):
+        be.slot_write(s, abi.EUCLID1, rng.normal(c, 0.1, (N, 1)))
+    from parity_utils import relative_factor_desc
+    d = relative_factor_desc(abi.F_LINREL, abi.EUCLID1, 3, 0, [0, 1, 2], 3, 5, [10.0], [0.1], multihypo=[0.0, 0.5, 0.5], mhidx_out=0)
+    d.has_multihypo = 1 | 0x80 | (1 << 9)  # only variable 1 (la) initialised
+    be.run_proposals([d])
+    assert set(be.side_read(0, N).tolist()) == {2}
+    d.has_multihypo = 1 | 0x80 | (1 << 8) | (1 << 9)  # x0 and la initialised: nvars - 1 -> no suppression (:161)
+    be.run_proposals([d])
+    assert set(be.side_read(0, N).tolist()) == {2, 3}
+    d.has_multihypo = 1  # no flags: every variable counts as initialised
+    be.run_proposals([d])
+    assert set(be.side_read(0, N).tolist()) == {2, 3}
+    be.close()
