@@ -1,9 +1,9 @@
 // nbp_kernels.h -- the gfx950 kernels of libnbp (see nbp_device.h for the shared device code).
 //
-// Workgroup geometry: P x Npad lanes, Npad = roundup(N, 64), P = min(4, 1024 / Npad).
-// lane (i, p): i = tid % Npad is the particle / output sample, p = tid / Npad is its helper index.
-// All lanes of a wave share p, so the O(N) inner loops read LDS with wave-uniform addresses
-// (broadcast) and the P helpers of a particle split those loops P ways.
+// Geometries: the proposal kernel runs one lane per particle; the bandwidth fits and the
+// KD builds run P x Npad lanes (Npad = roundup(N, 64), lane (i, p): i = tid % Npad the point, p its
+// helper index, all lanes of a wave share p); the product kernel runs HL adjacent lanes per output
+// sample.  The host picks P / HL per launch from the batch size (latency vs throughput mode).
 #pragma once
 #include "nbp_device.h"
 
@@ -218,9 +218,9 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
       }
     }
   }
-  // manikde!(M, pts) (ApproxConv.jl:36-42): the bandwidth fit runs as nbp_proposal_bandwidth_kernel
-  // right behind this kernel on the same stream (P x Npad lanes; this kernel keeps one lane per
-  // particle so that the Nelder-Mead simplex stays in registers).
+  // manikde!(M, pts) (ApproxConv.jl:36-42): the bandwidth fit of this proposal runs in the prep launch
+  // of its update (nbp_prep_kernel), or in nbp_bandwidth_kernel for the immediate-mode entry points;
+  // this kernel keeps one lane per particle so that the Nelder-Mead simplex stays in registers.
   if (live)
     for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
   // diagnostics: one atomic per wave
@@ -357,10 +357,10 @@ __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, ui
 //                   leave the sorted, centred coordinates in an HBM workspace.  The tree build does
 //                   not need bandwidths, so it runs beside the LCV fits of the same update instead
 //                   of behind them.
-// nbp_product_kernel: grid (nprod, G): workgroup (p, g) draws the output samples [g*SPB, (g+1)*SPB)
-//                   of product p, SPB = Npad/G, with P' = 1024/SPB helper lanes per sample.  G > 1 is
-//                   chosen by the host when a launch has fewer products than CUs (latency-bound
-//                   tree tops); results do not depend on G (RNG is keyed by the sample index).
+// nbp_product_kernel_{l8,m4,t2}: grid (nprod, G): workgroup (p, g) draws the output samples
+//                   [g*SPB, (g+1)*SPB) of product p with HL = 8/4/2 helper lanes per sample (adjacent
+//                   lanes of one wave); results do not depend on the geometry beyond rounding (the
+//                   RNG is keyed by the sample index).
 // ================================================================================================
 // HBM workspace of one (product, density): xs[3][N] | cen[4] | idx[N] (int32)
 __host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return (size_t)3 * N + 4 + (size_t)(N + 1) / 2; }
