@@ -341,3 +341,31 @@ def case_deconv(backend):
 
 
 CASES.append(case_deconv)
+
+
+def case_four_doors(backend):
+    # test/fourdoortest.jl:5-59 (the package's canonical multimodal example; the reference only checks that
+    # it runs).  Mixture(Prior, four doors) sighted at x1, x3, x4 with odometry 50, 50, 200: the only
+    # consistent explanation is x1 = 0, x2 = 50, x3 = 100, x4 = 300, which must hold the dominant mode.
+    doors = (iif.Normal(-100, 3.0), iif.Normal(0, 3.0), iif.Normal(100, 3.0), iif.Normal(300, 3.0))
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for i in range(1, 5):
+        iif.addVariable(fg, f"x{i}", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1"], iif.Mixture(iif.Prior, doors, [0.25] * 4))
+    iif.addFactor(fg, ["x1", "x2"], iif.LinearRelative(iif.Normal(50.0, 2.0)))
+    iif.addFactor(fg, ["x2", "x3"], iif.LinearRelative(iif.Normal(50.0, 4.0)))
+    iif.addFactor(fg, ["x3"], iif.Mixture(iif.Prior, doors, [0.25] * 4))
+    iif.addFactor(fg, ["x3", "x4"], iif.LinearRelative(iif.Normal(200.0, 4.0)))
+    iif.addFactor(fg, ["x4"], iif.Mixture(iif.Prior, doors, [0.25] * 4))
+    iif.initAll(fg, backend=backend, seed=80)
+    iif.solveTree(fg, backend=backend, seed=81)
+    for v, truth in (("x1", 0.0), ("x2", 50.0), ("x3", 100.0), ("x4", 300.0)):
+        p = fg.getVal(v)[:, 0]
+        assert (np.abs(p - truth) < 15).mean() > 0.4, (v, np.round(np.sort(p)[::10]))
+    # a second solve sharpens it (the reference example solves three times while it grows)
+    iif.solveTree(fg, backend=backend, seed=82)
+    p = fg.getVal("x4")[:, 0]
+    assert (np.abs(p - 300.0) < 15).mean() > 0.5
+
+
+CASES.append(case_four_doors)
