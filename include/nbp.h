@@ -172,6 +172,27 @@ nbp_status nbp_run_proposals(nbp_ctx *ctx, const nbp_proposal_desc *descs, int32
 nbp_status nbp_run_bandwidth(nbp_ctx *ctx, const int32_t *slots, const int32_t *manifolds, int32_t n);
 /* ---- variable seam: AMP.manifoldProduct + rebandwidth (GraphProductOperations.jl:53-60) --- */
 nbp_status nbp_run_products(nbp_ctx *ctx, const nbp_product_desc *descs, int32_t n);
+/* ---- host-buffer entry points: one call per reference function ----------------------------------
+ * For callers that keep beliefs on the host (the factor / variable seams of the Julia shim).  Points are
+ * packed AoS like nbp_slot_write; the calls stage through slots 0.. of the context (which they clobber)
+ * and synchronise before returning.
+ *
+ * nbp_kde_bandwidth:     AMP.manikde!(M, pts) bandwidth selection (ApproxConv.jl:38,41; FGOSUtils.jl:118-128).
+ * nbp_conv:              approxConvBelief(dfg, fct, target) (ApproxConv.jl:4-45): `tmpl` carries the factor
+ *                        (kind, manifold, nvars, sfidx, comp, multihypo, nullhypo, ..., seed); its slot fields
+ *                        are ignored.  var_pts[i] = points of variable i (MsgPrior: [target, message KDE] and
+ *                        var_bw[1] = the KDE's bandwidth).  mhidx_in / out_mhidx nullable (needs 2N side ints);
+ *                        out_bw NULL skips the bandwidth fit.  Context: >= nvars + 1 slots.
+ * nbp_manifold_product:  AMP.manifoldProduct(dens, M; Niter, oldPoints) + rebandwidth
+ *                        (GraphProductOperations.jl:53-60).  partial_masks / old_pts / out_labels nullable.
+ *                        Context: >= F + 2 slots (and N*F side ints for the labels).                        */
+nbp_status nbp_kde_bandwidth(nbp_ctx *ctx, int32_t manifold, const double *pts_NxP, double *bw_out_D);
+nbp_status nbp_conv(nbp_ctx *ctx, const nbp_proposal_desc *tmpl, const double *const *var_pts, const double *const *var_bw,
+                    const int32_t *mhidx_in, double *out_pts_NxP, double *out_bw_D, int32_t *out_mhidx);
+nbp_status nbp_manifold_product(nbp_ctx *ctx, int32_t manifold, int32_t nfactors, const double *const *dens_pts,
+                                const double *const *dens_bw, const uint8_t *partial_masks, const double *old_pts,
+                                int32_t niter, uint64_t seed, double *out_pts_NxP, double *out_bw_D, int32_t *out_labels);
+
 /* approxDeconv(dfg, fct) (services/DeconvUtils.jl:32-160): per particle, sample a measurement and
  * search from it for the measurement that zeroes the residual between the stored points of the two
  * variables (var_slot[0], var_slot[1]).  out_slot receives the predicted measurement (tangent

@@ -82,7 +82,7 @@ EXPORTS = [
     "nbp_arena_bytes", "nbp_slot_stride_doubles", "nbp_ctx_create", "nbp_ctx_destroy",
     "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr",
     "nbp_slot_write", "nbp_slot_read", "nbp_side_write", "nbp_side_read",
-    "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv",
+    "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_finalize", "nbp_program_run",
     "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_destroy",
     "nbp_timing_enable", "nbp_timing_read", "nbp_diag_read",
@@ -125,6 +125,10 @@ def load_library(path=None):
     lib.nbp_run_proposals.argtypes = [vp, C.POINTER(ProposalDesc), i32]
     lib.nbp_run_bandwidth.argtypes = [vp, ip, ip, i32]
     lib.nbp_run_deconv.argtypes = [vp, C.POINTER(ProposalDesc), ip, i32]
+    dpp = C.POINTER(dp)
+    lib.nbp_kde_bandwidth.argtypes = [vp, i32, dp, dp]
+    lib.nbp_conv.argtypes = [vp, C.POINTER(ProposalDesc), dpp, dpp, ip, dp, dp, ip]
+    lib.nbp_manifold_product.argtypes = [vp, i32, i32, dpp, dpp, C.POINTER(C.c_uint8), dp, i32, C.c_uint64, dp, dp, ip]
     lib.nbp_run_products.argtypes = [vp, C.POINTER(ProductDesc), i32]
     lib.nbp_run_copies.argtypes = [vp, C.POINTER(CopyDesc), i32]
     lib.nbp_program_create.argtypes = [vp, C.POINTER(vp)]

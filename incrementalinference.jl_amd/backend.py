@@ -102,6 +102,51 @@ class HipBackend:
         ip = C.POINTER(C.c_int32)
         self._check(self.lib.nbp_run_bandwidth(self._ctx, s.ctypes.data_as(ip), m.ctypes.data_as(ip), s.size))
 
+    # ---- host-buffer entry points (one call per reference function) -------------------------------
+    def kde_bandwidth(self, manifold, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        bw = np.zeros(abi.MANIFOLD_DIM[manifold])
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.nbp_kde_bandwidth(self._ctx, manifold, pts.ctypes.data_as(dp), bw.ctypes.data_as(dp)))
+        return bw
+
+    def conv(self, desc, var_pts, var_bw=None, mhidx_in=None, want_mhidx=False, want_bw=True):
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        man = desc.manifold
+        pts = [np.ascontiguousarray(p, dtype=np.float64) for p in var_pts]
+        bws = [None if (var_bw is None or b is None) else np.ascontiguousarray(b, dtype=np.float64) for b in (var_bw or [None] * len(pts))]
+        ppts = (dp * len(pts))(*[p.ctypes.data_as(dp) for p in pts])
+        pbw = (dp * len(pts))(*[(b.ctypes.data_as(dp) if b is not None else C.cast(None, dp)) for b in bws])
+        out = np.zeros((self.N, abi.MANIFOLD_P[man]))
+        obw = np.zeros(abi.MANIFOLD_DIM[man])
+        mh_in = None if mhidx_in is None else np.ascontiguousarray(mhidx_in, dtype=np.int32)
+        mh_out = np.zeros(self.N, dtype=np.int32) if want_mhidx else None
+        self._check(self.lib.nbp_conv(self._ctx, C.byref(desc), ppts, pbw,
+                                      mh_in.ctypes.data_as(ip) if mh_in is not None else C.cast(None, ip),
+                                      out.ctypes.data_as(dp), obw.ctypes.data_as(dp) if want_bw else C.cast(None, dp),
+                                      mh_out.ctypes.data_as(ip) if want_mhidx else C.cast(None, ip)))
+        return (out, obw, mh_out) if want_mhidx else (out, obw)
+
+    def manifold_product(self, manifold, dens, seed, niter=1, partial_masks=None, old_pts=None, want_labels=False):
+        """dens: list of (pts N x P, bw D)"""
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        F = len(dens)
+        pts = [np.ascontiguousarray(p, dtype=np.float64) for p, _ in dens]
+        bws = [np.ascontiguousarray(b, dtype=np.float64) for _, b in dens]
+        ppts = (dp * F)(*[p.ctypes.data_as(dp) for p in pts])
+        pbw = (dp * F)(*[b.ctypes.data_as(dp) for b in bws])
+        masks = None if partial_masks is None else np.ascontiguousarray(partial_masks, dtype=np.uint8)
+        old = None if old_pts is None else np.ascontiguousarray(old_pts, dtype=np.float64)
+        out = np.zeros((self.N, abi.MANIFOLD_P[manifold]))
+        obw = np.zeros(abi.MANIFOLD_DIM[manifold])
+        lab = np.zeros(self.N * F, dtype=np.int32) if want_labels else None
+        self._check(self.lib.nbp_manifold_product(
+            self._ctx, manifold, F, ppts, pbw,
+            masks.ctypes.data_as(C.POINTER(C.c_uint8)) if masks is not None else C.cast(None, C.POINTER(C.c_uint8)),
+            old.ctypes.data_as(dp) if old is not None else C.cast(None, dp), niter, C.c_uint64(seed),
+            out.ctypes.data_as(dp), obw.ctypes.data_as(dp), lab.ctypes.data_as(ip) if want_labels else C.cast(None, ip)))
+        return (out, obw, lab) if want_labels else (out, obw)
+
     def synchronize(self):
         self._check(self.lib.nbp_synchronize(self._ctx))
 

@@ -573,6 +573,87 @@ nbp_status nbp_run_deconv(nbp_ctx *c, const nbp_proposal_desc *descs, const int3
   return NBP_OK;
 }
 
+// ---- host-buffer entry points: one call per reference function, for callers that keep beliefs on the
+// host (the Julia shim's factor / variable seams).  They stage through the first slots of the context.
+nbp_status nbp_kde_bandwidth(nbp_ctx *c, int32_t manifold, const double *pts, double *bw_out) {
+  if (!c || !pts || !bw_out) return fail(NBP_ERR_ARG, "null argument");
+  nbp_status rc = nbp_slot_write(c, 0, manifold, pts, nullptr);
+  if (rc) return rc;
+  const int32_t slot = 0;
+  rc = nbp_run_bandwidth(c, &slot, &manifold, 1);
+  if (rc) return rc;
+  std::vector<double> tmp((size_t)c->N * 6);
+  return nbp_slot_read(c, 0, manifold, tmp.data(), bw_out);
+}
+
+nbp_status nbp_conv(nbp_ctx *c, const nbp_proposal_desc *tmpl, const double *const *var_pts, const double *const *var_bw,
+                    const int32_t *mhidx_in, double *out_pts, double *out_bw, int32_t *out_mhidx) {
+  if (!c || !tmpl || !var_pts || !out_pts) return fail(NBP_ERR_ARG, "null argument");
+  nbp_proposal_desc d = *tmpl;
+  const int nin = (d.factor_kind == NBP_F_MSGPRIOR) ? 2 : d.nvars;
+  if (nin < 1 || nin > NBP_MAXV) return fail(NBP_ERR_RANGE, "conv: nvars");
+  if (c->n_slots < nin + 1) return fail(NBP_ERR_RANGE, "conv: the context needs nvars + 1 slots");
+  if ((mhidx_in || out_mhidx) && c->side_ints < 2 * c->N) return fail(NBP_ERR_RANGE, "conv: the context needs 2N side ints");
+  for (int i = 0; i < nin; i++) {
+    if (!var_pts[i]) return fail(NBP_ERR_ARG, "conv: null variable points");
+    nbp_status rc = nbp_slot_write(c, i, d.manifold, var_pts[i], var_bw ? var_bw[i] : nullptr);
+    if (rc) return rc;
+    d.var_slot[i] = i;
+  }
+  d.out_slot = nin;
+  d.mhidx_in = -1;
+  d.mhidx_out = -1;
+  if (mhidx_in) {
+    nbp_status rc = nbp_side_write(c, 0, mhidx_in, c->N);
+    if (rc) return rc;
+    d.mhidx_in = 0;
+  }
+  if (out_mhidx) d.mhidx_out = c->N;
+  d.skip_bandwidth = out_bw ? 0 : 1;
+  nbp_status rc = nbp_run_proposals(c, &d, 1);
+  if (rc) return rc;
+  rc = nbp_slot_read(c, nin, d.manifold, out_pts, out_bw);
+  if (rc) return rc;
+  if (out_mhidx) rc = nbp_side_read(c, c->N, out_mhidx, c->N);
+  return rc;
+}
+
+nbp_status nbp_manifold_product(nbp_ctx *c, int32_t manifold, int32_t F, const double *const *dens_pts, const double *const *dens_bw,
+                                const uint8_t *partial_masks, const double *old_pts, int32_t niter, uint64_t seed,
+                                double *out_pts, double *out_bw, int32_t *out_labels) {
+  if (!c || !dens_pts || !dens_bw || !out_pts) return fail(NBP_ERR_ARG, "null argument");
+  if (F < 1 || F > NBP_MAXF) return fail(NBP_ERR_RANGE, "product: nfactors");
+  if (c->n_slots < F + 2) return fail(NBP_ERR_RANGE, "product: the context needs F + 2 slots");
+  if (out_labels && c->side_ints < c->N * F) return fail(NBP_ERR_RANGE, "product: the context needs N*F side ints");
+  nbp_product_desc d;
+  memset(&d, 0, sizeof(d));
+  d.manifold = manifold;
+  d.nfactors = F;
+  d.niter = niter;
+  d.out_slot = F + 1;
+  d.labels_out = out_labels ? 0 : -1;
+  d.old_slot = -1;
+  d.seed = seed;
+  for (int j = 0; j < F; j++) {
+    if (!dens_pts[j] || !dens_bw[j]) return fail(NBP_ERR_ARG, "product: null density");
+    nbp_status rc = nbp_slot_write(c, j, manifold, dens_pts[j], dens_bw[j]);
+    if (rc) return rc;
+    d.in_slot[j] = j;
+    d.in_partial[j] = partial_masks ? partial_masks[j] : 0;
+  }
+  if (old_pts) {
+    nbp_status rc = nbp_slot_write(c, F, manifold, old_pts, nullptr);
+    if (rc) return rc;
+    d.old_slot = F;
+  }
+  nbp_status rc = nbp_run_products(c, &d, 1);
+  if (rc) return rc;
+  rc = nbp_slot_read(c, F + 1, manifold, out_pts, out_bw);
+  if (rc) return rc;
+  if (out_labels) rc = nbp_side_read(c, 0, out_labels, c->N * F);
+  return rc;
+}
+
 nbp_status nbp_run_copies(nbp_ctx *c, const nbp_copy_desc *descs, int32_t n) {
   if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
   if (n <= 0) return NBP_OK;

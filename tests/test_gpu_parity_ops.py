@@ -397,3 +397,51 @@ def test_multihypo_isinit_suppression(oracle_backend, hip_backend, flags, expect
     np.testing.assert_array_equal(o[1], h[1])
     assert set(h[1].tolist()) == expect
     assert_points_close(man, o[0][0], h[0][0], what="multihypo with isinit flags")
+
+
+# ---- host-buffer entry points: same results as the slot path (and therefore as the oracle) ----------
+@pytest.mark.parametrize("manifold", [abi.EUCLID2, abi.CIRCULAR, abi.SE2])
+def test_host_buffer_entry_points(hip_backend, manifold):
+    N = 200
+    rng = np.random.default_rng(31 + manifold)
+    D = abi.MANIFOLD_DIM[manifold]
+    a, b = rand_points(rng, manifold, N, 0.0, 0.3), rand_points(rng, manifold, N, 1.0, 0.3)
+    kind = {abi.EUCLID2: abi.F_LINREL, abi.CIRCULAR: abi.F_CIRCULAR, abi.SE2: abi.F_SE2}[manifold]
+    Z = {abi.F_LINREL: D, abi.F_CIRCULAR: 1, abi.F_SE2: 3}[kind]
+    be = hip_backend(N, 6, 3 * N)
+    # nbp_kde_bandwidth == slot path
+    be.slot_write(5, manifold, a)
+    be.run_bandwidth([5], [manifold])
+    np.testing.assert_array_equal(be.kde_bandwidth(manifold, a), be.slot_read(5, manifold)[1])
+    # nbp_conv == nbp_run_proposals
+    d = relative_factor_desc(kind, manifold, 2, 1, [0, 1], 2, 2024, [0.5, 0.2, 0.1][:Z], [0.1, 0.1, 0.05][:Z], nullhypo=0.2, mhidx_out=0)
+    be.slot_write(0, manifold, a)
+    be.slot_write(1, manifold, b)
+    be.run_proposals([d])
+    ref_pts, ref_bw = be.slot_read(2, manifold)
+    ref_mh = be.side_read(0, N)
+    pts, bw, mh = be.conv(d, [a, b], want_mhidx=True)
+    np.testing.assert_array_equal(mh, ref_mh)
+    np.testing.assert_array_equal(pts, ref_pts)
+    np.testing.assert_array_equal(bw, ref_bw)
+    # injected mhidx is honoured
+    inj = np.where(np.arange(N) % 3 == 0, 0, 1).astype(np.int32)
+    _, _, mh2 = be.conv(d, [a, b], mhidx_in=inj, want_mhidx=True)
+    np.testing.assert_array_equal(mh2, inj)
+    # nbp_manifold_product == nbp_run_products
+    dens = [(rand_points(rng, manifold, N, 0.1 * j, 0.5), np.full(D, 0.2 + 0.05 * j)) for j in range(3)]
+    for j, (p, w) in enumerate(dens):
+        be.slot_write(j, manifold, p, w)
+    be.run_products([product_desc(manifold, [0, 1, 2], 4, 777, labels_out=0)])
+    ref_pts, ref_bw = be.slot_read(4, manifold)
+    ref_lab = be.side_read(0, 3 * N)
+    pts, bw, lab = be.manifold_product(manifold, dens, 777, want_labels=True)
+    np.testing.assert_array_equal(lab, ref_lab)
+    np.testing.assert_array_equal(pts, ref_pts)
+    np.testing.assert_array_equal(bw, ref_bw)
+    # too few slots -> status, not a crash
+    small = hip_backend(N, 2, 0)
+    with pytest.raises(iif.NbpError):
+        small.manifold_product(manifold, dens, 1)
+    small.close()
+    be.close()
