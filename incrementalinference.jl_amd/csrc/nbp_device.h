@@ -342,16 +342,20 @@ __device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&
   for (int i = DN; i >= 1; i--) nm_cswap<DN>(sx, f, i);
 }
 
+// nmobjective(y, m, n) = sqrt(var(y) * m / n) <= g_tol without the square root and the divisions:
+// sum((y - mean)^2) <= g_tol^2 * n, mean by the reciprocal (one FP64 divide or sqrt costs ~30 VALU
+// instructions, and this runs once per simplex iteration).  The oracle evaluates the same expression.
 template <int DN>
-__device__ __forceinline__ double nm_objective(const double (&f)[DN + 1]) {
+__device__ __forceinline__ bool nm_converged(const double (&f)[DN + 1]) {
+  constexpr double rm = 1.0 / (DN + 1);
   double a = 0;
 #pragma unroll
   for (int i = 0; i <= DN; i++) a += f[i];
-  a /= (double)(DN + 1);
+  a *= rm;
   double v = 0;
 #pragma unroll
   for (int i = 0; i <= DN; i++) v += (f[i] - a) * (f[i] - a);
-  return sqrt(v / (double)DN);
+  return v <= 1e-16 * DN;
 }
 
 template <class OBJ, int DN>
@@ -368,7 +372,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
 #pragma unroll
   for (int i = 0; i < M; i++) f[i] = o(sx[i]);
   nm_sort_all<DN>(sx, f);
-  bool converged = nm_objective<DN>(f) <= 1e-8;
+  bool converged = nm_converged<DN>(f);
   int it = 0;
   while (!converged && it < 1000) {
     it++;
@@ -378,7 +382,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
       double s = 0;
 #pragma unroll
       for (int i = 0; i < DN; i++) s += sx[i][d];
-      xc[d] = s / (double)DN;
+      xc[d] = s * (1.0 / DN);
     }
     const double f_lowest = f[0], f_second = f[DN - 1], f_highest = f[DN];
 #pragma unroll
@@ -419,7 +423,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
       }
       nm_sort_all<DN>(sx, f);
     }
-    converged = nm_objective<DN>(f) <= 1e-8;
+    converged = nm_converged<DN>(f);
   }
   // after_while!: the better of the best vertex and the centroid of the DN best
   double xc[DN];
@@ -428,7 +432,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
     double s = 0;
 #pragma unroll
     for (int i = 0; i < DN; i++) s += sx[i][d];
-    xc[d] = s / (double)DN;
+    xc[d] = s * (1.0 / DN);
   }
   const double fcen = o(xc);
   const bool usec = fcen < f[0];

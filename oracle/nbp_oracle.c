@@ -307,18 +307,23 @@ static void nm_sort(int m, const double *f, int *ord) {
     ord[j + 1] = k;
   }
 }
-static double nm_objective(int m, int n, const double *f) {
+/* nmobjective(y, m, n) = sqrt(var(y) * m / n) <= g_tol, evaluated without the square root and with
+   multiplications by the (compile-time) reciprocals: sum((y - mean)^2) <= g_tol^2 * n.  Same predicate
+   up to rounding at the threshold; the HIP kernel evaluates exactly this expression. */
+static int nm_converged(int m, int n, const double *f) {
+  const double rm = 1.0 / m;
   double a = 0;
   for (int i = 0; i < m; i++) a += f[i];
-  a /= m;
+  a *= rm;
   double v = 0;
   for (int i = 0; i < m; i++) v += (f[i] - a) * (f[i] - a);
-  return sqrt(v / n);
+  return v <= 1e-16 * n;
 }
 
 int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: minimizer */, int *iters) {
   const int m = n + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / n, gamma = 0.75 - 1.0 / (2.0 * n), delta = 1.0 - 1.0 / n;
+  const double rn = 1.0 / n;
   double sx[4][3], f[4], xc[3], xr[3], xcache[3], xl[3];
   int ord[4];
   for (int i = 0; i < m; i++)
@@ -326,7 +331,7 @@ int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: mi
   for (int j = 0; j < n; j++) sx[j + 1][j] = (1.0 + 0.5) * sx[j + 1][j] + 0.025;
   for (int i = 0; i < m; i++) f[i] = objective(o, sx[i]);
   nm_sort(m, f, ord);
-  int converged = nm_objective(m, n, f) <= 1e-8;
+  int converged = nm_converged(m, n, f);
   int it = 0;
   while (!converged && it < 1000) {
     it++;
@@ -335,7 +340,7 @@ int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: mi
     for (int d = 0; d < n; d++) {
       double s = 0;
       for (int i = 0; i < m; i++) if (i != ih) s += sx[i][d];
-      xc[d] = s / n;
+      xc[d] = s * rn; /* centroid: times the reciprocal, like the kernel */
       xl[d] = sx[ord[0]][d];
     }
     double f_lowest = f[ord[0]], f_second = f[ord[n - 1]], f_highest = f[ih];
@@ -386,7 +391,7 @@ int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: mi
       }
       nm_sort(m, f, ord);
     }
-    converged = nm_objective(m, n, f) <= 1e-8;
+    converged = nm_converged(m, n, f);
   }
   /* after_while!: better of best vertex and centroid of the n best */
   nm_sort(m, f, ord);
@@ -394,7 +399,7 @@ int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: mi
   for (int d = 0; d < n; d++) {
     double s = 0;
     for (int i = 0; i < m; i++) if (i != ih) s += sx[i][d];
-    xc[d] = s / n;
+    xc[d] = s * rn; /* centroid: times the reciprocal, like the kernel */
   }
   double fcen = objective(o, xc);
   if (fcen < f[ord[0]])
