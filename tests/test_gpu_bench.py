@@ -44,3 +44,20 @@ def test_bench_sharded_path_one_rank():
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     _check(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_if_two_gpus():
+    """cliques sharded over 2 GPUs with RCCL point-to-point separator exchange; skipped on 1-GPU boxes
+    (the world-2 logic itself is covered on CPU by tests/test_dist_gloo.py)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29544", "bench.py", "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--nvars", "300"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _check([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["variables_per_gpu"] == 300
+    assert d["posterior_max_mean_err"] < 1.5
