@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define NBP_MAXV 6   /* variables attached to one factor (multihypo door sighting uses 5) */
-#define NBP_MAXF 8   /* densities multiplied in one manifoldProduct                        */
+#define NBP_MAXF 128 /* densities multiplied in one manifoldProduct (a landmark with many sightings);
+                        products whose node statistics do not fit the 160 KB LDS keep them in HBM/L2 */
 #define NBP_MAXD 3   /* tangent dimension                                                   */
 #define NBP_MAXC 4   /* Mixture components                                                  */
 #define NBP_MAXN 512 /* particles per belief                                                */

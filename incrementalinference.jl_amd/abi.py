@@ -6,7 +6,7 @@ descriptors are consumed by the HIP library (product) and, in tests only, by the
 import ctypes as C
 import os
 
-MAXV, MAXF, MAXD, MAXC, MAXN, COMP_STRIDE = 6, 8, 3, 4, 512, 13
+MAXV, MAXF, MAXD, MAXC, MAXN, COMP_STRIDE = 6, 128, 3, 4, 512, 13
 
 # enum nbp_manifold
 EUCLID1, EUCLID2, EUCLID3, CIRCULAR, SE2 = 1, 2, 3, 4, 5

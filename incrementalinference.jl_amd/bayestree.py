@@ -147,6 +147,21 @@ def nestedDissectionOrder(fg):
             frontier = nxt
         return levels
 
+    # dense nodes (landmarks seen from many poses) would make every BFS level structure shallow and
+    # defeat the bisection: set them aside, order the sparse remainder, eliminate them last -- the same
+    # device as the dense-row handling of AMD / COLAMD (the reference's optional ordering, ext/
+    # IncrInfrApproxMinDegreeExt.jl).  They end up in the root clique.
+    degs = sorted(len(a) for a in adj.values())
+    dense_thr = max(16, 10 * degs[len(degs) // 2]) if degs else 0
+    dense = [v for v in fg.ls() if len(adj[v]) > dense_thr]
+    if dense and len(dense) < len(adj):
+        ds = set(dense)
+        for v in dense:
+            del adj[v]
+        for v in adj:
+            adj[v] -= ds
+    else:
+        dense = []
     order = []
     work = [list(c) for c in components(adj.keys())][::-1]
     # iterative post-order: each item is ("split", nodes) or ("emit", separator)
@@ -179,7 +194,7 @@ def nestedDissectionOrder(fg):
         stack.append(("emit", sep))
         for comp in components(rest)[::-1]:
             stack.append(("split", comp))
-    return order
+    return order + dense
 
 
 # ------------------------------------------------------------------------------------------------

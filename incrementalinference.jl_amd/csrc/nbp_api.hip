@@ -33,8 +33,10 @@ struct nbp_ctx {
   nbp_levels T{};
   int32_t *lv_ints = nullptr;
   double *lv_dbls = nullptr;
-  double *ws = nullptr;  // KD workspace: [products][NBP_MAXF] x nbp_kd_ws_doubles(N)
-  int ws_products = 0;
+  double *ws = nullptr;  // KD workspace: [products][kdF] x nbp_kd_ws_doubles(N), kdF = largest F of the batch
+  size_t ws_doubles = 0;
+  double *gstats = nullptr;  // node statistics of products too large for the LDS
+  size_t gstats_doubles = 0;
   // staging for immediate-mode calls
   void *stage = nullptr;
   size_t stage_bytes = 0;
@@ -187,6 +189,7 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   hipFree(c->lv_dbls);
   if (c->stage) hipFree(c->stage);
   if (c->ws) hipFree(c->ws);
+  if (c->gstats) hipFree(c->gstats);
   hipStreamDestroy(c->stream);
   delete c;
   return NBP_OK;
@@ -323,8 +326,6 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
       if (any && D < 2) return fail(NBP_ERR_ARG, "product: partial densities need a variable of dimension >= 2");
       if (any && (p.old_slot < 0 || p.old_slot >= c->n_slots)) return fail(NBP_ERR_RANGE, "product: old_slot");
     }
-    size_t lds = nbp_product_lds_bytes(p.nfactors, manifold_dim_h(p.manifold), c->N, 256);  // largest SPB of any geometry: 8 waves x 32 samples
-    if (p.nfactors > 1 && lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: F*D*N exceeds the 160 KiB LDS");
   }
   return NBP_OK;
 }
@@ -361,12 +362,23 @@ static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[0]);
 }
-static nbp_status ensure_ws(nbp_ctx *c, int nprod) {
-  if (nprod <= c->ws_products) return NBP_OK;
+static nbp_status ensure_ws(nbp_ctx *c, int nprod, int kdF) {
+  const size_t need = (size_t)nprod * (size_t)kdF * nbp_kd_ws_doubles(c->N);
+  if (need <= c->ws_doubles) return NBP_OK;
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->ws) HIPCHK(hipFree(c->ws));
-  c->ws_products = nprod + nprod / 4 + 16;
-  HIPCHK(hipMalloc(&c->ws, (size_t)c->ws_products * NBP_MAXF * nbp_kd_ws_doubles(c->N) * 8));
+  c->ws = nullptr;
+  c->ws_doubles = need + need / 4 + 16 * nbp_kd_ws_doubles(c->N);
+  HIPCHK(hipMalloc(&c->ws, c->ws_doubles * 8));
+  return NBP_OK;
+}
+static nbp_status ensure_gstats(nbp_ctx *c, size_t need) {
+  if (need <= c->gstats_doubles) return NBP_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->gstats) HIPCHK(hipFree(c->gstats));
+  c->gstats = nullptr;
+  c->gstats_doubles = need + need / 4;
+  HIPCHK(hipMalloc(&c->gstats, c->gstats_doubles * 8));
   return NBP_OK;
 }
 
@@ -386,7 +398,7 @@ static int lcv_helpers(nbp_ctx *c, int nblocks) {
 // nbp_prep_kernel: pending bandwidth fits + KD builds of this product batch, one launch
 static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
                               const nbp_product_desc *dev, int n, int maxFD) {
-  nbp_status rc = ensure_ws(c, n);
+  nbp_status rc = ensure_ws(c, n, maxFD / 4);
   if (rc) return rc;
   rc = tic(c, c->ev[1]);
   if (rc) return rc;
@@ -412,22 +424,37 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
   *wpb = (waves + g - 1) / g;
   *G = (waves + *wpb - 1) / *wpb;
 }
+// LDS budget of a product workgroup: beyond it the node statistics live in global memory ("big")
+static const size_t NBP_PRODUCT_LDS_CAP = 150 * 1024;
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD) {
   if (n <= 0) return NBP_OK;
   int HL, wpb, G;
   product_geometry(c, n, &HL, &wpb, &G);
-  const int TB = wpb * 64, SPB = TB / HL;
   // maxFD encodes the largest (F, D) of the batch as F*4 + D
-  const size_t lds = nbp_product_lds_bytes(maxFD / 4, maxFD % 4, c->N, SPB);
-  nbp_status rc = tic(c, c->ev[2]);
+  const int F = maxFD / 4, D = maxFD % 4;
+  bool big = nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP;
+  if (big && HL != 8) {  // many densities: small sample groups keep the label table in LDS
+    product_geometry(c, 1, &HL, &wpb, &G);
+  }
+  const int TB = wpb * 64, SPB = TB / HL;
+  const size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big);
+  if (lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: too many densities for the LDS label table");
+  nbp_status rc = NBP_OK;
+  double *gs = nullptr;
+  if (big) {
+    rc = ensure_gstats(c, (size_t)n * G * 2 * (size_t)F * D * c->N);
+    if (rc) return rc;
+    gs = c->gstats;
+  }
+  rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
   if (HL == 8)
-    hipLaunchKernelGGL(nbp_product_kernel_l8, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->S, c->side, c->T);
+    hipLaunchKernelGGL(nbp_product_kernel_l8, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
   else if (HL == 4)
-    hipLaunchKernelGGL(nbp_product_kernel_m4, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->S, c->side, c->T);
+    hipLaunchKernelGGL(nbp_product_kernel_m4, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
   else
-    hipLaunchKernelGGL(nbp_product_kernel_t2, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, c->N, c->S, c->side, c->T);
+    hipLaunchKernelGGL(nbp_product_kernel_t2, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }
@@ -801,8 +828,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     p->blob.resize(p->seed_off + so.size() * 8);
     if (!so.empty()) memcpy(p->blob.data() + p->seed_off, so.data(), so.size() * 8);
   }
-  nbp_status rc = ensure_ws(p->ctx, maxprod);
-  if (rc) return rc;
+  nbp_status rc = NBP_OK;  // workspaces grow on demand in launch_prep / launch_products
   size_t bytes = p->blob.size() ? p->blob.size() : 64;
   HIPCHK(hipMalloc(&p->dev, bytes));
   if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));

@@ -467,7 +467,7 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
   const nbp_product_desc *d = descs + p;
   if (d->nfactors == 1 || j >= d->nfactors) return;
   const double *x = arena + S * d->in_slot[j];
-  double *wsj = ws + (size_t)(p * NBP_MAXF + j) * nbp_kd_ws_doubles(N);
+  double *wsj = ws + (size_t)(p * kdF + j) * nbp_kd_ws_doubles(N);
   const int mask = d->in_partial[j] ? d->in_partial[j] : 7;
   switch (mani_dim(d->manifold)) {
   case 1: kd_build<1>(x, wsj, N, Npad, T, smem, 1); break;
@@ -487,10 +487,14 @@ struct product_lds {
   int *ind;
 };
 
-__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, double *base, product_lds *L) {
+// `big` = the sorted coordinates and the per-level node statistics (3 x F x D x N doubles) do not fit the
+// LDS: they stay in global memory (the KD workspace is read in place, the statistics go to a scratch
+// area private to the workgroup) and are served by L1/L2; LDS then holds only the small per-product items.
+__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
-  size_t xs = dbl((size_t)F * D * N), lm = dbl((size_t)F * D * N), lv = dbl((size_t)F * D * N);
+  const size_t bulk = big ? 0 : (size_t)F * D * N;
+  size_t xs = dbl(bulk), lm = dbl(bulk), lv = dbl(bulk);
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
   size_t nw = dbl((size_t)N), tab = dbl(NBP_EXPTAB);
   size_t ints0 = o;
@@ -507,8 +511,8 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
 // no density informs keeps the old point (GraphProductOperations.jl:39-45).  Separate instantiation so
 // that the all-full path carries no masks.
 template <int MANI, bool PARTIAL, int HL>
-__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int N, int64_t S,
-                                             int32_t *side, const nbp_levels &T, double *smem) {
+__device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int kdF, double *gstats,
+                                             int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
   const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
@@ -516,23 +520,29 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   const int sl = tid / HL, h = tid % HL;   // sample (local), helper index
   const int s = blockIdx.y * SPB + sl;
   const bool live = s < N;
+  const bool big = gstats != nullptr;
   product_lds L;
-  product_lds_layout(F, D, N, SPB, smem, &L);
-  double *xs = L.xs, *lm = L.lm, *lv = L.lv, *cen = L.cen, *h2 = L.h2;
+  product_lds_layout(F, D, N, SPB, big, smem, &L);
+  double *cen = L.cen, *h2 = L.h2;
   int *ind = L.ind;
   double *out = arena + S * d->out_slot;
-  const double *wsp = ws + (size_t)blockIdx.x * NBP_MAXF * nbp_kd_ws_doubles(N);
+  const double *wsp = ws + (size_t)blockIdx.x * kdF * nbp_kd_ws_doubles(N);
+  // node statistics: LDS, or (big) this workgroup's private scratch in global memory
+  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * (size_t)F * D * N : nullptr;
+  double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv;
+  double *xs = L.xs;
   nbp_exp_tab_init(L.tab);
   // ---- stage the KD-sorted, centred coordinates of every density + bandwidths ------------------
-  for (int item = tid; item < F * D * N; item += TB) {
-    const int j = item / (D * N), r = item % (D * N);
-    xs[item] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + r];
-  }
-  if (tid < F * 3) {
-    const int j = tid / 3, k = tid % 3;
+  if (!big)
+    for (int item = tid; item < F * D * N; item += TB) {
+      const int j = item / (D * N), r = item % (D * N);
+      xs[item] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + r];
+    }
+  for (int t = tid; t < F * 3; t += TB) {
+    const int j = t / 3, k = t % 3;
     const double bw = arena[S * d->in_slot[j] + 3 * N + k];
-    h2[tid] = (k < D) ? bw * bw : 0.0;
-    cen[tid] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
+    h2[t] = (k < D) ? bw * bw : 0.0;
+    cen[t] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
   }
   if (h == 0)
     for (int j = 0; j < F; j++) ind[j * SPB + sl] = 0;  // levelInit!: root
@@ -543,7 +553,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     for (int item = tid; item < F * D * cnt; item += TB) {  // node statistics of this level
       const int z = item % cnt, jk = item / cnt;
       const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
-      const double *xv = xs + jk * N;
+      const double *xv = big ? wsp + (size_t)(jk / D) * nbp_kd_ws_doubles(N) + (size_t)(jk % D) * N : xs + jk * N;
       double s1 = 0, s2 = 0;
       for (int p = lo; p < hi; p++) { double v = xv[p]; s1 += v; s2 += v * v; }
       const double nn = (double)(hi - lo), mu = s1 / nn;
@@ -747,7 +757,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 }
 
 template <int HL>
-__device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
+__device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
+                                                    double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
   if (d->nfactors == 1) {  // single density: AMP returns it unchanged
     if (blockIdx.y != 0) return;
@@ -762,37 +773,37 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
   for (int j = 0; j < d->nfactors; j++) partial |= (d->in_partial[j] != 0);
   if (partial) {  // validated on the host: D >= 2
     switch (d->manifold) {
-    case NBP_EUCLID2: product_body<NBP_EUCLID2, true, HL>(d, arena, ws, N, S, side, T, smem); break;
-    case NBP_EUCLID3: product_body<NBP_EUCLID3, true, HL>(d, arena, ws, N, S, side, T, smem); break;
-    default: product_body<NBP_SE2, true, HL>(d, arena, ws, N, S, side, T, smem); break;
+    case NBP_EUCLID2: product_body<NBP_EUCLID2, true, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+    case NBP_EUCLID3: product_body<NBP_EUCLID3, true, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+    default: product_body<NBP_SE2, true, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
     }
     return;
   }
   switch (d->manifold) {
-  case NBP_EUCLID1: product_body<NBP_EUCLID1, false, HL>(d, arena, ws, N, S, side, T, smem); break;
-  case NBP_EUCLID2: product_body<NBP_EUCLID2, false, HL>(d, arena, ws, N, S, side, T, smem); break;
-  case NBP_EUCLID3: product_body<NBP_EUCLID3, false, HL>(d, arena, ws, N, S, side, T, smem); break;
-  case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false, HL>(d, arena, ws, N, S, side, T, smem); break;
-  default: product_body<NBP_SE2, false, HL>(d, arena, ws, N, S, side, T, smem); break;
+  case NBP_EUCLID1: product_body<NBP_EUCLID1, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+  case NBP_EUCLID2: product_body<NBP_EUCLID2, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+  case NBP_EUCLID3: product_body<NBP_EUCLID3, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+  case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+  default: product_body<NBP_SE2, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
   }
 }
 
 // Three entry points = three register budgets: the latency variant (HL = 8, few workgroups in flight)
 // keeps everything in registers; the throughput variants trade a few spills for 4-5 waves per SIMD.
-#define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int N, int64_t S, int32_t *side, nbp_levels T
+#define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
 __global__ void __launch_bounds__(512) nbp_product_kernel_l8(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
-  product_kernel_body<8>(descs, arena, ws, N, S, side, T, smem);
+  product_kernel_body<8>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) nbp_product_kernel_m4(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
-  product_kernel_body<4>(descs, arena, ws, N, S, side, T, smem);
+  product_kernel_body<4>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) nbp_product_kernel_t2(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
-  product_kernel_body<2>(descs, arena, ws, N, S, side, T, smem);
+  product_kernel_body<2>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
 
-static inline size_t nbp_product_lds_bytes(int F, int D, int N, int SPB) {
-  return product_lds_layout(F, D, N, SPB, nullptr, nullptr);
+static inline size_t nbp_product_lds_bytes(int F, int D, int N, int SPB, bool big) {
+  return product_lds_layout(F, D, N, SPB, big, nullptr, nullptr);
 }

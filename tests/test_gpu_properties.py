@@ -122,3 +122,29 @@ def test_product_geometries_match_oracle(oracle_backend, hip_backend, manifold, 
         np.testing.assert_array_equal(lab, ref[1])
         assert_points_close(manifold, ref[0][0], pts, what=f"product batch {batch}")
         np.testing.assert_allclose(bw, ref[0][1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("manifold,F,N", [(abi.CIRCULAR, 81, 200), (abi.EUCLID2, 40, 200), (abi.SE2, 24, 100), (abi.EUCLID1, 128, 64)])
+def test_products_of_many_densities(oracle_backend, hip_backend, manifold, F, N):
+    """A landmark with many sightings (BASELINE config 3: 80 sightings + a prior on each door): the node
+    statistics no longer fit the LDS and live in global memory; results still equal the oracle's."""
+    rng = np.random.default_rng(F + N)
+    D = abi.MANIFOLD_DIM[manifold]
+    dens = [rand_points(rng, manifold, N, 0.02 * j, 0.6) for j in range(F)]
+
+    def run(fac, nops):
+        be = fac(N, F + nops, N * F * nops)
+        for j, p in enumerate(dens):
+            be.slot_write(j, manifold, p, np.full(D, 0.5 + 0.01 * j))
+        descs = [product_desc(manifold, list(range(F)), F + i, 99, labels_out=i * N * F) for i in range(nops)]
+        be.run_products(descs)
+        out = [(be.slot_read(F + i, manifold), be.side_read(i * N * F, N * F)) for i in (0, nops - 1)]
+        be.close()
+        return out
+
+    ref = run(oracle_backend, 1)[0]
+    for nops in (1, 3):
+        for (pts, bw), lab in run(hip_backend, nops):
+            np.testing.assert_array_equal(lab, ref[1])
+            assert_points_close(manifold, ref[0][0], pts, what=f"product of {F}")
+            np.testing.assert_allclose(bw, ref[0][1], rtol=1e-9)

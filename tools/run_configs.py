@@ -1,0 +1,89 @@
+"""Full-size runs of the BASELINE.json configurations 3, 4, 5 on ONE GPU (configs 4 and 5 are 8-GPU
+targets; this records what a single MI355X does with the whole graph): host setup times, solve time,
+messages/s and a posterior sanity figure.  Usage: python tools/run_configs.py [3 4 5]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import iif_amd_loader
+
+iif = iif_amd_loader.load()
+
+
+def wrapdiff(a, b):
+    return (a - b + np.pi) % (2 * np.pi) - np.pi
+
+
+def run(name, fg, check):
+    t0 = time.perf_counter()
+    order = iif.nestedDissectionOrder(fg)
+    tree = iif.buildTreeReset(fg, order)
+    t1 = time.perf_counter()
+    iif.initAll(fg, seed=0)
+    t2 = time.perf_counter()
+    N = fg.solverParams.N
+    tp = iif.TreeProgram(fg, tree, seed=1, snapshot=True)
+    be = iif.HipBackend(N, tp.n_slots)
+    for v in fg.ls():
+        var = fg.getVariable(v)
+        be.slot_write(tp.snap[v], var.varType.manifold, var.val, var.bw)
+    prog = be.program(tp.stages)
+    t3 = time.perf_counter()
+    prog.run()
+    be.synchronize()
+    times = []
+    for k in range(2):
+        prog.reseed(100 + k)
+        t = time.perf_counter()
+        prog.run()
+        be.synchronize()
+        times.append(time.perf_counter() - t)
+    dt = min(times)
+    for v in fg.ls():
+        var = fg.getVariable(v)
+        var.val, var.bw = be.slot_read(tp.main[v], var.varType.manifold)
+    st = tp.stats()
+    print(f"{name}: variables {len(fg.ls())}, cliques {st['cliques']}, updates {st['updates_up'] + st['updates_down']}, "
+          f"tree {t1 - t0:.2f} s, init {t2 - t1:.2f} s, compile+upload {t3 - t2:.2f} s | solve {dt * 1e3:.1f} ms, "
+          f"{tp.n_messages / dt:.0f} messages/s | {check(fg)}", flush=True)
+    prog.close()
+    be.close()
+
+
+def check3(fg):
+    step = 2 * np.pi / 50
+    n = sum(1 for v in fg.ls() if v.startswith("x"))
+    frac = [(np.abs(wrapdiff(fg.getVal(f"x{i}")[:, 0], i * step)) < 0.35).mean() for i in range(0, n, 7)]
+    return f"share of particles within 0.35 rad of the truth: min {min(frac):.2f}, median {np.median(frac):.2f}"
+
+
+def check4(fg):
+    rows, cols = 50, 100
+    worst, k = 0.0, 0
+    errs = []
+    for r in range(rows):
+        for c in (range(cols) if r % 2 == 0 else range(cols - 1, -1, -1)):
+            if k % 97 == 0:
+                p = fg.getVal(f"x{k}")
+                errs.append(max(abs(p[:, 0].mean() - c), abs(p[:, 1].mean() - r)))
+            k += 1
+    return f"translation mean error: median {np.median(errs):.2f}, max {max(errs):.2f} m over {len(errs)} sampled poses"
+
+
+def check5(fg):
+    n = len(fg.ls())
+    errs = [abs(fg.getVal(f"x{i}")[:, 0].mean() - i) for i in range(0, n, 211)]
+    return f"mean error along the chain: median {np.median(errs):.2f}, max {max(errs):.2f}"
+
+
+if __name__ == "__main__":
+    which = [int(a) for a in sys.argv[1:]] or [3, 4, 5]
+    if 3 in which:
+        run("config 3 (Circular, 2000 poses, 4 doors, multihypo sightings, N=200)", iif.generateCircularDoors(2000, 200, 25), check3)
+    if 4 in which:
+        run("config 4 (SE(2) 50x100 lattice with loop closures, N=200)", iif.generateSE2Lattice(50, 100, 200, 5), check4)
+    if 5 in which:
+        run("config 5 (Euclid(3) 10000-variable Mixture chain, N=300)", iif.generateMixtureChain(10000, 300, 500), check5)
