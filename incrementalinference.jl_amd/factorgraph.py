@@ -43,7 +43,9 @@ class MvNormal:
         self.cov = cov
 
     def mean_sqrtcov(self):
-        return self.mu, np.linalg.cholesky(self.cov)
+        if getattr(self, "_chol", None) is None:
+            self._chol = np.linalg.cholesky(self.cov)
+        return self.mu, self._chol
 
 
 # ------------------------------------------------------------------------------------------------

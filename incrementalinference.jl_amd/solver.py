@@ -61,15 +61,26 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     d.sfidx = fct.variables.index(target)
     for i, v in enumerate(fct.variables):
         d.var_slot[i] = slot_of(v)
-    comps = fnc.components()
-    d.ncomp = len(comps)
-    for c, (w, mu, L) in enumerate(comps):
-        d.comp[c][0] = w
-        for i in range(min(3, len(mu))):
-            d.comp[c][1 + i] = mu[i]
-        for i in range(min(3, L.shape[0])):
-            for j in range(i + 1):
-                d.comp[c][4 + 3 * i + j] = L[i, j]
+    flat = getattr(fnc, "_comp_flat", None)  # measurement model, flattened once per factor
+    if flat is None:
+        comps = fnc.components()
+        flat = []
+        for (w, mu, L) in comps:
+            row = [0.0] * abi.COMP_STRIDE
+            row[0] = w
+            for i in range(min(3, len(mu))):
+                row[1 + i] = float(mu[i])
+            for i in range(min(3, L.shape[0])):
+                for j in range(i + 1):
+                    row[4 + 3 * i + j] = float(L[i, j])
+            flat.append(row)
+        try:
+            fnc._comp_flat = flat
+        except AttributeError:
+            pass
+    d.ncomp = len(flat)
+    for c, row in enumerate(flat):
+        d.comp[c][:] = row
     if fct.multihypo is not None:
         # isinit flags: uninitialised hypotheses are suppressed (ExplicitDiscreteMarginalizations.jl:161-172)
         flags = 1 | 0x80
