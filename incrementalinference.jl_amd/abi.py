@@ -103,6 +103,15 @@ def load_library(path=None):
             f"libnbp.so not found at {path}: build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950). The product path has no CPU fallback."
         )
+    # One HIP runtime per process.  PyTorch ships its own libamdhip64 / libhsa-runtime64 with the same
+    # SONAMEs as /opt/rocm; if libnbp pulled in the system copies first, a later `import torch` (the
+    # multi-GPU path: torch-owned arena + torch.distributed) would bring up a second runtime that cannot
+    # open the GPU ("No HIP GPUs are available").  Importing torch first makes libnbp bind to the copies
+    # torch loaded.  Without PyTorch (e.g. the Julia shim) the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int32)
