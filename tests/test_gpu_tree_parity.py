@@ -67,3 +67,50 @@ def test_torch_owned_arena_sharded_path_single_rank(hip_backend):
     assert s.global_messages == 2 * (len(s.tree.cliques) - len(s.tree.roots))
     assert s.arena.data_ptr() == s.be.arena_ptr()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("builder", ["euclid2", "se2", "circular"])
+def test_independent_seeds_agree_in_distribution(oracle_backend, hip_backend, builder):
+    """The stated posterior tolerance (north star: "within a stated KL / mean +- sigma tolerance"):
+    a GPU solve and a CPU-oracle solve with DIFFERENT random streams give, for every variable,
+    |mean_gpu - mean_cpu| <= 0.6 sigma_pooled + 0.05 and sigma_gpu / sigma_cpu in [0.55, 1.8] per coordinate."""
+    def build():
+        if builder == "euclid2":
+            return iif.generateChainEuclid(16, vardims=2, priorEvery=5, N=200)
+        if builder == "se2":
+            return iif.generateSE2Lattice(rows=2, cols=5, N=200, closeEvery=2)
+        fg = iif.initfg(iif.SolverParams(N=200))
+        iif.addVariable(fg, "x0", iif.Circular)
+        iif.addFactor(fg, ["x0"], iif.PriorCircular(iif.Normal(0.0, 0.1)))
+        for i in range(1, 8):
+            iif.addVariable(fg, f"x{i}", iif.Circular)
+            iif.addFactor(fg, [f"x{i-1}", f"x{i}"], iif.CircularCircular(iif.Normal(0.5, 0.1)))
+        iif.addFactor(fg, ["x7"], iif.PriorCircular(iif.Normal(-2.7832, 0.2)))  # 3.5 wrapped
+        return fg
+
+    def coords(fg, v):
+        p = fg.getVal(v)
+        man = fg.getVariable(v).varType.manifold
+        if man == abi.SE2:
+            return np.stack([p[:, 0], p[:, 1], np.arctan2(p[:, 3], p[:, 2])], axis=1), [False, False, True]
+        return p, [man == abi.CIRCULAR] * p.shape[1]
+
+    def stats(x, circ):
+        if circ:
+            m = np.arctan2(np.sin(x).mean(), np.cos(x).mean())
+            d = (x - m + np.pi) % (2 * np.pi) - np.pi
+            return m, np.sqrt((d ** 2).mean())
+        return x.mean(), x.std()
+
+    fa, fb = build(), build()
+    oa, ob = iif.nestedDissectionOrder(fa), iif.nestedDissectionOrder(fb)
+    iif.solveTree(fa, eliminationOrder=oa, backend=oracle_backend, seed=101)
+    iif.solveTree(fb, eliminationOrder=ob, backend=hip_backend, seed=202)
+    for v in fa.ls():
+        (ca, circ), (cb, _) = coords(fa, v), coords(fb, v)
+        for k in range(ca.shape[1]):
+            (ma, sa), (mb, sb) = stats(ca[:, k], circ[k]), stats(cb[:, k], circ[k])
+            dm = abs((ma - mb + np.pi) % (2 * np.pi) - np.pi) if circ[k] else abs(ma - mb)
+            pooled = np.sqrt(0.5 * (sa * sa + sb * sb))
+            assert dm <= 0.6 * pooled + 0.05, (v, k, ma, mb, sa, sb)
+            assert 0.55 <= sb / sa <= 1.8, (v, k, sa, sb)
