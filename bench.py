@@ -139,7 +139,8 @@ def main():
                                f"N={N} particles, nested-dissection order, full up+down solveTree",
                    "variables_per_gpu": a.nvars, "particles": N, "cliques": st["cliques_global"],
                    "messages_per_step": msgs_total, "variable_updates_per_step": st["updates_global"],
-                   "parallelism": f"cliques sharded over {world} GPU(s)" if world > 1 else "single GPU"},
+                   "parallelism": (f"cliques sharded over {world} GPU(s), separator exchange: "
+                                   f"{getattr(getattr(rs, 'impl', None), 'transport', 'none')}") if world > 1 else "single GPU"},
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": getattr(rs, "posterior_max_mean_err", None),
         "host_setup": getattr(rs, "host_setup", None),
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -9,6 +9,8 @@ payload (val N x P, bw, entities/BeliefTypes.jl:47-57) = one slot (4.9 KB at N =
 latency bound, so messages of one tree level are batched into a single group of point-to-point
 `isend/irecv` (RCCL over xGMI with backend "nccl", gloo in the CPU tests) -- no ring collective.
 """
+import sys
+
 import numpy as np
 
 from . import abi
@@ -53,13 +55,47 @@ def partition_cliques(tree, world, weight=None):
     return owner
 
 
+def choose_transport(dist, device, log=None):
+    """Agree (all ranks) on how separator slots travel.  "rccl": point-to-point on device memory, the
+    design path (RCCL over xGMI).  "staged": through host memory over a gloo group -- only if a ring
+    self-test of RCCL send/recv raises on ANY rank (the ranks agree through an all-reduce, so nobody
+    is left waiting on a transport its peer gave up).  Returns (name, gloo_group_or_None)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() != "nccl":
+        return "staged", None  # CPU tests: tensors already live on the host, default group is gloo
+    gloo = dist.new_group(backend="gloo")  # collective: every rank creates it, used or not
+    ok = 1
+    try:
+        a = torch.full((64,), float(rank), dtype=torch.float64, device=device)
+        b = torch.empty(64, dtype=torch.float64, device=device)
+        ops = [dist.P2POp(dist.isend, a, (rank + 1) % world), dist.P2POp(dist.irecv, b, (rank - 1) % world)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        torch.cuda.synchronize()
+        if float(b[0].item()) != float((rank - 1) % world):
+            ok = 0
+    except Exception as e:  # noqa: BLE001 -- any failure means "do not use this transport"
+        ok = 0
+        if log:
+            log(f"rank {rank}: RCCL point-to-point self-test failed ({type(e).__name__}: {e}); proposing host-staged exchange")
+    t = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 1:
+        return "rccl", None
+    if log and rank == 0:
+        log("separator exchange falls back to host-staged gloo send/recv on every rank")
+    return "staged", gloo
+
+
 class ShardedRunner:
     """Runs one rank's share of a TreeProgram: stage segments interleaved with slot exchanges."""
 
-    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None):
+    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None, transport="rccl", group=None):
         self.tp, self.be, self.dist = tp, backend, dist
         self.slot_tensor = slot_tensor
         self.sync_device = sync_device or (lambda: None)
+        self.transport, self.group = transport, group
         self.prog = backend.program(tp.stages)
 
     def run(self, salt=None):
@@ -75,13 +111,23 @@ class ShardedRunner:
     def _exchange(self, sends, recvs):
         dist = self.dist
         self.be.synchronize()  # the slots to send are complete
-        ops = []
+        ops, landing = [], []
         for peer, slot in sends:
-            ops.append(dist.P2POp(dist.isend, self.slot_tensor(slot), peer))
+            t = self.slot_tensor(slot)
+            if t.is_cuda and self.transport == "staged":
+                t = t.cpu()
+            ops.append(dist.P2POp(dist.isend, t, peer, group=self.group))
         for peer, slot in recvs:
-            ops.append(dist.P2POp(dist.irecv, self.slot_tensor(slot), peer))
+            t = self.slot_tensor(slot)
+            if t.is_cuda and self.transport == "staged":
+                h = t.cpu()
+                landing.append((t, h))
+                t = h
+            ops.append(dist.P2POp(dist.irecv, t, peer, group=self.group))
         for r in dist.batch_isend_irecv(ops):
             r.wait()
+        for dev, host in landing:
+            dev.copy_(host)
         self.sync_device()
 
     def close(self):
@@ -115,8 +161,11 @@ class ShardedTreeSolve:
         for v in fg.ls():
             var = fg.getVariable(v)
             self.be.slot_write(tp.snap[v], var.varType.manifold, var.val, var.bw)
+        self.transport, group = ("none", None)
+        if self.dist is not None and self.world > 1:
+            self.transport, group = choose_transport(self.dist, f"cuda:{self.local}", log=lambda m: print(m, file=sys.stderr, flush=True))
         self.runner = ShardedRunner(tp, self.be, self.dist, lambda s: self.arena[s * stride:(s + 1) * stride],
-                                    torch.cuda.synchronize)
+                                    torch.cuda.synchronize, transport=self.transport, group=group)
         st = tp.stats()
         self.global_messages = tp.n_messages
         # global totals over ranks

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import iif_amd_loader  # noqa: E402
 
 iif = iif_amd_loader.load()
-from iif_amd.dist_solver import ShardedRunner, partition_cliques  # noqa: E402
+from iif_amd.dist_solver import ShardedRunner, choose_transport, partition_cliques  # noqa: E402
 from oracle.oracle_backend import OracleBackend  # noqa: E402
 
 
@@ -38,7 +38,9 @@ def main():
         be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
     stride = iif.abi.slot_stride(100)
     arena_t = torch.from_numpy(be.arena)
-    runner = ShardedRunner(tp, be, dist, lambda s: arena_t[s * stride:(s + 1) * stride])
+    transport, group = choose_transport(dist, "cpu")
+    assert transport == "staged" and group is None  # gloo default group, host tensors
+    runner = ShardedRunner(tp, be, dist, lambda s: arena_t[s * stride:(s + 1) * stride], transport=transport, group=group)
     runner.run()
     res = {}
     for c in tp.cliques:
