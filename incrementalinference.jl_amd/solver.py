@@ -607,9 +607,14 @@ class TreeProgram:
         self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.main[v], self.B[(c, v)]) for c in self.cliques
                                      for v in tree.cliques[c].allIDs], "copy")
         allc = sorted(tree.cliques)
+        sp = fg.solverParams
+        if not sp.upsolve and not sp.downsolve:
+            raise ValueError("must attempt either up or down solve")  # CliqueStateMachine.jl:60
         # ---- up pass: leaves first ------------------------------------------------------------
+        # upsolve = false: the cliques are "up-recycled" (tryDownSolveOnly_StateMachine, :485-529): no
+        # update runs and the down solve works from the stored beliefs
         maxh = max(self.heights.values())
-        for h in range(maxh + 1):
+        for h in (range(maxh + 1) if sp.upsolve else ()):
             level = [c for c in self.cliques if self.heights[c] == h]
             nsteps = max([len(self.upsched[c]) for c in level] + [0])
             for k in range(nsteps):
@@ -634,6 +639,12 @@ class TreeProgram:
                         edges.append((owner[c], (lambda c=c, v=v: self.B[(c, v)]), owner[cl.parent],
                                       (lambda c=c, v=v: self.ghost[(c, v)])))
             self._exchange(edges)
+        if not sp.downsolve:
+            # postUpSolve -> updateFromSubgraph (:595-599): every clique hands its up-solved frontals back
+            self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in self.cliques
+                                         for v in tree.cliques[c].frontalIDs], "up")
+            self.segments.append(("run", self._seg_start, len(self.stages)))
+            return
         # roots: posterior = up-solve result (CliqueStateMachine.jl preDownSolve root branch)
         self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.B[(r, v)], self.main[v]) for r in tree.roots if owner[r] == rank
                                      for v in tree.cliques[r].frontalIDs], "down")
@@ -685,7 +696,8 @@ class TreeProgram:
     def n_messages(self):
         """one LikelihoodMessage per tree edge and direction (CliqueStateMachine.jl:590-593, 900-903);
         counted over the WHOLE tree (all ranks)"""
-        return 2 * sum(1 for c in self.tree.cliques.values() if c.parent >= 0)
+        sp = self.fg.solverParams
+        return (int(sp.upsolve) + int(sp.downsolve)) * sum(1 for c in self.tree.cliques.values() if c.parent >= 0)
 
     def stats(self):
         np_, nq = 0, 0

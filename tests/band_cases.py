@@ -369,3 +369,126 @@ def case_four_doors(backend):
 
 
 CASES.append(case_four_doors)
+
+
+def case_partial_nullhypo_3d(backend):
+    # test/testPartialNH.jl:10-53 and :56-86: partial priors on (2,3) and (1,) of Euclid(3) variables and a
+    # full LinearRelative between them, without and with nullhypo = 0.2
+    E3 = iif.ContinuousEuclid(3)
+    for nh, tol1 in ((0.0, 1.0), (0.2, 2.0)):
+        fg = iif.initfg(iif.SolverParams(N=100))
+        iif.addVariable(fg, "x0", E3)
+        iif.addFactor(fg, ["x0"], iif.PartialPrior(E3, iif.MvNormal(np.zeros(2), np.ones(2)), (2, 3)), nullhypo=nh)
+        iif.addVariable(fg, "x1", E3)
+        iif.addFactor(fg, ["x1"], iif.PartialPrior(E3, iif.Normal(10, 1), (1,)))
+        iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(iif.MvNormal([10, 0, 0.0], np.ones(3))), nullhypo=nh)
+        iif.initAll(fg, backend=backend, seed=90)
+        iif.solveTree(fg, backend=backend, seed=91)
+        np.testing.assert_allclose(fg.getVal("x0").mean(axis=0), [0, 0, 0], atol=1.0)
+        np.testing.assert_allclose(fg.getVal("x1").mean(axis=0), [10, 0, 0], atol=tol1)
+
+
+def case_multimodal_1d(backend):
+    # test/testMultimodal1D.jl:35-107: x1 measures two landmarks whose identity is uncertain
+    # (multihypo [1, 0.4, 0.6] against a new landmark lm_k and a mapped one lp_k); x1 and the lm_k start
+    # uninitialised, so x1 is initialised through the one available hypothesis (#427)
+    sp = iif.SolverParams(N=100, gibbsIters=6, spreadNH=0.3)
+    fg = iif.initfg(sp)
+    iif.addVariable(fg, "lp1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["lp1"], iif.Prior(iif.Normal(-30.0, 1.0)))
+    iif.addVariable(fg, "lp2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["lp2"], iif.Prior(iif.Normal(30.0, 1.0)))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addVariable(fg, "lm2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "lm2", "lp2"], iif.LinearRelative(iif.Normal(20.0, 1.0)), multihypo=[1.0, 0.4, 0.6])
+    iif.addVariable(fg, "lm1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "lm1", "lp1"], iif.LinearRelative(iif.Normal(-20.0, 1.0)), multihypo=[1.0, 0.4, 0.6])
+    iif.initAll(fg, backend=backend, seed=92)
+    assert all(fg.isInitialized(v) for v in fg.ls())
+    iif.solveTree(fg, eliminationOrder=["x1", "lm1", "lm2", "lp1", "lp2"], backend=backend, seed=93)
+    N = 100
+
+    def count(v, lo, hi):
+        p = fg.getVal(v)[:, 0]
+        return ((p > lo) & (p < hi)).sum()
+
+    assert 0.7 * N < count("x1", -20, 0) + count("x1", 0, 20)
+    assert 0.7 * N < count("lp1", -38, -28)
+    assert 0.7 * N < count("lp2", 28, 38)
+    assert 0.1 * N < count("lm1", -38, -25)
+    assert 0.1 * N < count("lm2", 25, 38)
+
+
+CASES += [case_partial_nullhypo_3d, case_multimodal_1d]
+
+
+def case_multihypo_and_chain(backend):
+    # test/testMultihypoAndChain.jl:7-88: two poses, two landmarks, three sightings with data association
+    # 0.99 / 0.01; a single clique (prescribed order); x0 ~ 0, x1 ~ 1, l1 ~ 1, l2 keeps a mode near 2
+    r = rng(42)
+    fg = iif.initfg(iif.SolverParams(N=100, gibbsIters=5, spreadNH=5.0))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(r.normal(0.0, 0.01), 0.01)))
+    iif.addVariable(fg, "l1", iif.ContinuousScalar)
+    iif.addVariable(fg, "l2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0", "l1", "l2"], iif.LinearRelative(iif.Normal(r.normal(1.0, 0.01), 0.01)), multihypo=[1, 0.99, 0.01])
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(iif.Normal(r.normal(1.0, 0.1), 0.1)))
+    iif.addFactor(fg, ["x1", "l1", "l2"], iif.LinearRelative(iif.Normal(r.normal(0.0, 0.01), 0.01)), multihypo=[1, 0.99, 0.01])
+    iif.addFactor(fg, ["x1", "l2", "l1"], iif.LinearRelative(iif.Normal(r.normal(1.0, 0.01), 0.01)), multihypo=[1, 0.99, 0.01])
+    iif.initAll(fg, backend=backend, seed=94)
+    iif.solveTree(fg, eliminationOrder=["l2", "x1", "x0", "l1"], backend=backend, seed=95)
+
+    def ppe(v):  # MeanMaxPPE "suggested": the mode; median is a robust stand-in for these narrow beliefs
+        return float(np.median(fg.getVal(v)[:, 0]))
+
+    assert abs(ppe("x0") - 0) < 0.2 and abs(ppe("x1") - 1) < 0.2 and abs(ppe("l1") - 1) < 0.2
+    l2 = fg.getVal("l2")[:, 0]  # "at least a mode present" (the reference compares with N(2, 0.1) by mmd < 1e-3)
+    assert (np.abs(l2 - 2.0) < 0.5).mean() > 0.2 and abs(np.median(l2) - 2.0) < 0.8, np.round(np.percentile(l2, [10, 50, 90]), 2)
+
+
+def case_mixture_prior(backend):
+    # test/testMixturePrior.jl:11-68 (#605): bi-modal Mixture(Prior, (N(-5,1), N(0,1)), [.5,.5]) stays balanced
+    N = 100
+    fg = iif.initfg(iif.SolverParams(N=N))
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Mixture(iif.Prior, (iif.Normal(-5.0, 1.0), iif.Normal(0.0, 1.0)), [0.5, 0.5]))
+    iif.initAll(fg, backend=backend, seed=96)
+    s = iif.approxConv(fg, "x0f1", "x0", backend=backend, seed=97)[:, 0]
+    assert abs((s < -2.5).sum() - (s > -2.5).sum()) < 0.35 * N
+    iif.solveTree(fg, backend=backend, seed=98)
+    m = fg.getVal("x0")[:, 0]
+    assert abs((m < -2.5).sum() - (m > -2.5).sum()) < 0.35 * N
+
+
+def case_skip_up_or_down(backend):
+    # test/testSkipUpDown.jl:5-60: a 7-pose line, first up-solve only (frontals are handed back after the
+    # up pass), then down-solve only from the stored beliefs; the estimates stay at the truth either way
+    def line():
+        fg = iif.generateGraph_LineStep(6, poseEvery=1, landmarkEvery=7, posePriorsAt=(0,), sightDistance=7,
+                                        solverParams=iif.SolverParams(N=100))
+        return fg
+
+    fg = line()
+    iif.initAll(fg, backend=backend, seed=99)
+    fg.solverParams.downsolve = False
+    _, tm = iif.solveTree(fg, backend=backend, seed=100, return_timing=True)
+    ncl = tm["messages"]
+    for v in fg.ls():
+        if v.startswith("x"):
+            assert abs(np.median(fg.getVal(v)[:, 0]) - int(v[1:])) < 0.25, v
+    fg.solverParams.upsolve, fg.solverParams.downsolve = False, True
+    _, tm2 = iif.solveTree(fg, backend=backend, seed=101, return_timing=True)
+    assert tm2["messages"] == ncl  # one message per edge in either single-direction solve
+    for v in fg.ls():
+        if v.startswith("x"):
+            assert abs(np.median(fg.getVal(v)[:, 0]) - int(v[1:])) < 0.25, v
+    fg.solverParams.upsolve = fg.solverParams.downsolve = False
+    try:
+        iif.solveTree(fg, backend=backend, seed=102)
+        raise AssertionError("expected an error")
+    except ValueError:
+        pass
+
+
+CASES += [case_multihypo_and_chain, case_mixture_prior, case_skip_up_or_down]
