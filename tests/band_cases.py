@@ -492,3 +492,42 @@ def case_skip_up_or_down(backend):
 
 
 CASES += [case_multihypo_and_chain, case_mixture_prior, case_skip_up_or_down]
+
+
+def case_orphaned_forest(backend):
+    # test/testSolveOrphanedFG.jl:9-70 (#518): two disconnected chains, one elimination order, a tree with two roots
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for a, mu, sig, pr in (("x0 x1 x2", 10.0, 0.1, iif.Normal(0, 0.1)), ("x10 x11 x12", -10.0, 1.0, iif.Normal(0, 1))):
+        vs = a.split()
+        for v in vs:
+            iif.addVariable(fg, v, iif.ContinuousScalar)
+        iif.addFactor(fg, [vs[0]], iif.Prior(pr))
+        iif.addFactor(fg, [vs[0], vs[1]], iif.LinearRelative(iif.Normal(mu, sig)))
+        iif.addFactor(fg, [vs[1], vs[2]], iif.LinearRelative(iif.Normal(mu, sig)))
+    vo = ["x12", "x2", "x0", "x11", "x1", "x10"]
+    iif.initAll(fg, backend=backend, seed=110)
+    tree = iif.solveTree(fg, eliminationOrder=vo, backend=backend, seed=111)
+    assert len(tree.roots) == 2
+    clq = {v: c for c in tree.cliques.values() for v in c.frontalIDs}
+    assert clq["x1"].parent < 0 and clq["x10"].parent < 0
+    assert len(clq["x1"].children) == 1 and len(clq["x10"].children) == 1
+    assert len(clq["x2"].children) == 0 and len(clq["x12"].children) == 0
+    for v, m, tol in (("x0", 0, 1.0), ("x1", 10, 2.0), ("x2", 20, 3.0), ("x10", 0, 2.0), ("x11", -10, 3.0), ("x12", -20, 4.0)):
+        assert abs(fg.getVal(v).mean() - m) < tol, v
+
+
+def case_translation_group_prior_and_factor(backend):
+    # test/testTranslationMani.jl:7-38: ManifoldPrior / ManifoldFactor on TranslationGroup(2) = Euclid(2)
+    E2 = iif.ContinuousEuclid(2)
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x0", E2)
+    iif.addVariable(fg, "x1", E2)
+    iif.addFactor(fg, ["x0"], iif.ManifoldPrior(np.array([10.0, 20.0]), iif.MvNormal(np.zeros(2), [1.0, 1.0])))
+    iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(iif.MvNormal([1.0, 2.0], [0.1, 0.1])))
+    iif.initAll(fg, backend=backend, seed=112)
+    iif.solveTree(fg, backend=backend, seed=113)
+    np.testing.assert_allclose(fg.getVal("x0").mean(axis=0), [10, 20], atol=0.6)
+    np.testing.assert_allclose(fg.getVal("x1").mean(axis=0), [11, 22], atol=0.6)
+
+
+CASES += [case_orphaned_forest, case_translation_group_prior_and_factor]
