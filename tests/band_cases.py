@@ -531,3 +531,34 @@ def case_translation_group_prior_and_factor(backend):
 
 
 CASES += [case_orphaned_forest, case_translation_group_prior_and_factor]
+
+
+def case_multihypothesis_api(backend):
+    # test/testmultihypothesisapi.jl:38-108: DevelopPrior = Prior, DevelopLikelihood: r = z - (x2 - x1);
+    # multihypo [1, .5, .5] parsing and the three convolution directions of the fractional factor
+    N = 100
+    fg = iif.initfg(iif.SolverParams(N=N))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1"], iif.Prior(iif.Normal(10.0, 1.0)))
+    iif.initAll(fg, backend=backend, seed=120)
+    pts = iif.approxConv(fg, "x1f1", "x1", backend=backend, seed=121)[:, 0]
+    assert (np.abs(pts - 1.0) < 5).sum() < 30 and (np.abs(pts - 10.0) < 5).sum() > 30
+    iif.addVariable(fg, "x2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "x2"], iif.LinearRelative(iif.Normal(100.0, 1.0)))
+    iif.initAll(fg, backend=backend, seed=122)
+    assert abs(fg.getVal("x2").mean() - 110.0) < 10.0
+    iif.addVariable(fg, "x3", iif.ContinuousScalar)
+    iif.addVariable(fg, "x4", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x2", "x3", "x4"], iif.LinearRelative(iif.Normal(90.0, 1.0)), multihypo=[1.0, 0.5, 0.5])
+    p = fg.getFactor("x2x3x4f1").multihypo
+    assert abs(p[0]) < 0.1 and np.abs(p[1:] - 0.5).sum() < 0.1  # 1.0 becomes 0.0 for computational convenience
+    for v, c in (("x2", 1.0), ("x3", 2.0), ("x4", 3.0)):
+        iif.initVariable(fg, v, c * np.ones((N, 1)) + 1e-6 * rng(int(c)).normal(size=(N, 1)), backend=backend)
+    pts = iif.approxConv(fg, "x2x3x4f1", "x2", backend=backend, seed=123)[:, 0]
+    assert 99 < (pts <= -70.0).sum()
+    for v, s in (("x3", 124), ("x4", 125)):
+        pts = iif.approxConv(fg, "x2x3x4f1", v, backend=backend, seed=s)[:, 0]
+        assert 15 < ((pts > 70) & (pts < 110)).sum() < 75
+
+
+CASES.append(case_multihypothesis_api)
