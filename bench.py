@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vars", type=int, default=600)
     ap.add_argument("--no-10k", action="store_true", help="skip the secondary 10 000-variable north-star measurement")
+    ap.add_argument("--python-host", action="store_true", help="build tree and schedule with the Python mirror instead of the native host")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: take the sharded multi-GPU code path (process group, torch-owned arena) even with one rank")
     return ap.parse_args()
@@ -78,7 +79,7 @@ def main():
 
     N = a.particles
     from bench_support import RankSolve
-    rs = RankSolve(iif, a.nvars, N, rank, world, local, dist)
+    rs = RankSolve(iif, a.nvars, N, rank, world, local, dist, python_host=a.python_host)
     rs.prepare()
 
     def barrier():
@@ -190,7 +191,7 @@ def main():
         if hasattr(rs, "prog"):
             rs.prog.close()
         rs.be.close()
-        rs10 = RankSolve(iif, 10000, N, 0, 1, local, None)
+        rs10 = RankSolve(iif, 10000, N, 0, 1, local, None, python_host=a.python_host)
         rs10.prepare()
         rs10.step(999)
         rs10.be.synchronize()

@@ -1,0 +1,115 @@
+/*
+ * nbp_host.h -- native (C++) host side of the clique hot path: factor graph container, sparse
+ * elimination ordering, Bayes tree, clique potentials, Gibbs id lists and the compilation of a whole
+ * up+down tree solve into a device-resident libnbp program (include/nbp.h).
+ *
+ * SURVEY.md 8(f) rank 1 ("Gibbs-schedule generator + message assembly") and rank 3 ("Bayes-tree build
+ * with sparse ordering, host C++"): the integer / symbolic work the reference does in
+ *   src/services/BayesNet.jl:139-189            buildBayesNet!
+ *   src/services/JunctionTreeUtils.jl:435-495   newPotential / buildTree!
+ *   src/services/JunctionTreeUtils.jl:1045-1083 setCliqPotentials!
+ *   src/services/JunctionTreeUtils.jl:1294-1523 compCliqAssocMatrices!, setCliqMCIDs! and friends
+ *   src/services/SolveTree.jl:164-239           upGibbsCliqueDensity (schedule)
+ *   src/CliqueStateMachine/services/CliqStateMachineUtils.jl:424-571  down sequence / products
+ *   src/services/TreeMessageUtils.jl:66-89,542-578   message factors <-> slots
+ * so that a host (the Julia shim, or the Python mirror in this repo) can hand over a graph and an
+ * elimination order and get the same staged program the Python reference implementation of this repo
+ * (bayestree.py / solver.TreeProgram) builds -- byte for byte, which is how it is tested.
+ *
+ * Variables and factors are addressed by the dense ids the add calls return (insertion order).
+ */
+#ifndef NBP_HOST_H
+#define NBP_HOST_H
+#include "nbp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbp_graph nbp_graph;
+typedef struct nbp_tree nbp_tree;
+
+/* the SolverParams fields the path reads (entities/SolverParams.jl:12-75) */
+typedef struct nbp_solver_params {
+  int32_t N;               /* particles per belief                                   */
+  int32_t gibbs_iters;     /* gibbsIters (3)                                         */
+  int32_t inflate_cycles;  /* inflateCycles (3)                                      */
+  int32_t product_niter;   /* Niter of AMP.manifoldProduct (1)                       */
+  int32_t upsolve, downsolve, limitfixeddown;
+  int32_t pad_;
+  double spread_nh;        /* spreadNH (3.0)                                         */
+  double inflation;        /* inflation (5.0): default of a factor without its own   */
+  double null_surplus_add; /* nullSurplusAdd (0.3)                                   */
+} nbp_solver_params;
+
+/* one factor: addFactor!(dfg, Xi, usrfnc; multihypo, nullhypo, inflation) (FactorGraph.jl:824-875) */
+typedef struct nbp_factor_spec {
+  int32_t factor_kind;       /* enum nbp_factor (not NBP_F_MSGPRIOR: messages are made by the compiler) */
+  int32_t nvars;
+  int32_t vars[NBP_MAXV];    /* variable ids, getVariableOrder                                       */
+  int32_t ncomp;             /* measurement model components (Mixture) */
+  int32_t has_multihypo;     /* 0 / 1 */
+  int32_t partial_mask;      /* see nbp_proposal_desc */
+  double multihypo[NBP_MAXV]; /* parsed Categorical p, certain variables 0.0 (FactorGraph.jl:639-651) */
+  double nullhypo;
+  double inflation;          /* <= 0: use nbp_solver_params.inflation */
+  double comp[NBP_MAXC][NBP_COMP_STRIDE];
+} nbp_factor_spec;
+
+nbp_status nbp_graph_create(const nbp_solver_params *params, nbp_graph **out);
+nbp_status nbp_graph_destroy(nbp_graph *g);
+/* return the new id (>= 0) or a negative status */
+int32_t nbp_graph_add_variable(nbp_graph *g, int32_t manifold);
+int32_t nbp_graph_add_factor(nbp_graph *g, const nbp_factor_spec *spec);
+nbp_status nbp_graph_set_variable_flags(nbp_graph *g, int32_t var, int32_t initialized, int32_t ismargin);
+int32_t nbp_graph_num_variables(const nbp_graph *g);
+int32_t nbp_graph_num_factors(const nbp_graph *g);
+
+/* Nested-dissection elimination order (recursive bisection on BFS level structures; dense nodes such as
+ * landmarks seen from many poses are set aside and eliminated last, as AMD / COLAMD do with dense rows).
+ * order_out[nvars].  The reference's default (dense column-pivoted QR, BayesNet.jl:40-44) stays with the
+ * caller: any order can be passed to nbp_tree_build, as solveTree!(...; eliminationOrder) allows. */
+nbp_status nbp_graph_order_nested_dissection(const nbp_graph *g, int32_t *order_out);
+
+/* buildTreeReset!(dfg, eliminationOrder) + buildCliquePotentials + the Gibbs schedules */
+nbp_status nbp_tree_build(const nbp_graph *g, const int32_t *order, int32_t n, nbp_tree **out);
+nbp_status nbp_tree_destroy(nbp_tree *t);
+int32_t nbp_tree_num_cliques(const nbp_tree *t);
+
+/* clique k (1-based like the reference's CliqueId): every out pointer may be NULL; the arrays must hold
+ * nbp_graph_num_variables / nbp_graph_num_factors entries; schedules up to nbp_tree_max_schedule(). */
+typedef struct nbp_clique_info {
+  int32_t parent;   /* 0 = root */
+  int32_t nfrontals, nseparators, nchildren, npotentials, nup, ndown;
+} nbp_clique_info;
+nbp_status nbp_tree_clique(const nbp_tree *t, int32_t k, nbp_clique_info *info, int32_t *frontals, int32_t *separators,
+                           int32_t *children, int32_t *potentials, int32_t *up_schedule, int32_t *down_schedule);
+int32_t nbp_tree_max_schedule(const nbp_tree *t);
+
+/* The slot plan of a whole-tree solve: main[v] | snap[v] (optional) | clique-local copies | scratch.
+ * Returns the number of slots the context must have. */
+int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot);
+nbp_status nbp_tree_main_slots(const nbp_tree *t, int32_t *main_out /* nvars */, int32_t *snap_out /* nvars or NULL */);
+
+/* Compile the up+down solve into a resident program on `ctx` (which must have been created with at
+ * least nbp_tree_plan_slots() slots and the graph's N).  The caller writes the initial beliefs into the
+ * main (or snap) slots and runs / reseeds / destroys the program with the nbp_program_* calls. */
+nbp_status nbp_tree_compile(nbp_tree *t, nbp_ctx *ctx, uint64_t seed, nbp_program **out);
+/* the host half of nbp_tree_compile alone: build the stage descriptors (no device needed) */
+nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed);
+
+typedef struct nbp_tree_stats {
+  int64_t stages, proposals, products, updates_up, updates_down, messages, slots;
+  int64_t alg_bytes;          /* sum of B_upd over all updates, SURVEY 8(d) */
+  int64_t alg_bytes_proposal, alg_bytes_prep, alg_bytes_product;
+} nbp_tree_stats;
+nbp_status nbp_tree_get_stats(const nbp_tree *t, nbp_tree_stats *out);
+
+/* test access: the descriptors of stage s of the last compile (kind = NBP_STAGE_*; bytes copied <= cap) */
+int32_t nbp_tree_num_stages(const nbp_tree *t);
+nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *descs_out, int64_t cap_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBP_HOST_H */

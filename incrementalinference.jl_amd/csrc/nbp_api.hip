@@ -15,6 +15,8 @@ static nbp_status fail(nbp_status code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+// shared with nbp_host.cpp (same library): sets the message nbp_last_error() returns
+extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { return fail(code, msg ? msg : ""); }
 #define HIPCHK(expr)                                                                               \
   do {                                                                                             \
     hipError_t e_ = (expr);                                                                        \

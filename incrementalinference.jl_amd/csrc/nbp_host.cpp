@@ -1,0 +1,840 @@
+// nbp_host.cpp -- native host side (include/nbp_host.h): graph, nested-dissection ordering, Bayes tree,
+// clique potentials, Gibbs id lists, and the compilation of a whole-tree solve into a libnbp program.
+// Pure host code; the arithmetic all happens in the kernels behind nbp_program_*.
+//
+// The algorithms are the ones of this repo's Python mirror (bayestree.py, solver.TreeProgram), which
+// cite the reference file:line they restate; tests/test_native_host.py checks both give identical
+// orders, cliques, schedules and descriptor bytes, and tests/test_tree_known_answers.py pins the Python
+// side against the reference's own known answers.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/nbp_host.h"
+
+extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg);
+static nbp_status hfail(nbp_status c, const char *m) { return nbp_internal_fail(c, m); }
+
+namespace {
+
+struct HVar { int manifold; bool initialized, ismargin; };
+struct HFac { nbp_factor_spec s; bool is_prior; };
+
+inline int mani_dim(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
+inline int mani_P(int m) { return m == NBP_SE2 ? 6 : mani_dim(m); }
+
+// seeds.py
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline uint64_t op_seed(uint64_t base, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  uint64_t h = splitmix64(base);
+  h = splitmix64(h ^ a);
+  h = splitmix64(h ^ b);
+  h = splitmix64(h ^ c);
+  h = splitmix64(h ^ d);
+  return h;
+}
+enum { PASS_INIT = 0, PASS_UP = 1, PASS_DOWN = 2, PASS_UNIT = 3, PRODUCT_ID = 0xFFFF };
+
+struct Clique {
+  int id = 0, parent = 0;
+  std::vector<int> frontals, seps, children, potentials, dwnPotentials, inmsg;
+  std::vector<int> directPriorMsg, directvar, itervar, msgskip, directFrtlMsg;
+  std::vector<int> upsched, dnsched;
+  std::vector<int> all() const {
+    std::vector<int> a = frontals;
+    a.insert(a.end(), seps.begin(), seps.end());
+    return a;
+  }
+};
+
+struct Stage { int kind; std::vector<char> bytes; int n; };
+
+}  // namespace
+
+struct nbp_graph {
+  nbp_solver_params sp;
+  std::vector<HVar> vars;
+  std::vector<HFac> facs;
+  std::vector<std::vector<int>> vfacs;  // variable -> factor ids, insertion order
+};
+
+struct nbp_tree {
+  const nbp_graph *g = nullptr;
+  std::vector<int> order;
+  std::vector<Clique> cl;  // cl[k-1] = clique k
+  std::vector<int> frontal_of;  // variable -> clique id
+  std::vector<int> roots;
+  // slot plan
+  int snapshot = 0, n_slots = 0;
+  std::vector<int> main_slot, snap_slot;
+  std::vector<std::map<int, int>> B;  // per clique: variable -> slot
+  std::vector<int> scratch;           // per clique: first scratch slot
+  // compile products
+  std::vector<Stage> stages;
+  nbp_tree_stats st{};
+};
+
+namespace {
+
+template <class T> bool contains(const std::vector<T> &v, const T &x) { return std::find(v.begin(), v.end(), x) != v.end(); }
+
+// ---- nested dissection (bayestree.nestedDissectionOrder) -------------------------------------------
+struct ND {
+  int n;
+  std::vector<std::set<int>> adj;
+  std::vector<char> alive;  // not dense
+  std::vector<std::vector<int>> components(const std::vector<int> &nodes) {
+    std::set<int> left(nodes.begin(), nodes.end());
+    std::vector<std::vector<int>> comps;
+    while (!left.empty()) {
+      int s = *left.begin();  // smallest index == min by insertion index
+      std::set<int> comp{s};
+      std::vector<int> stack{s};
+      while (!stack.empty()) {
+        int u = stack.back();
+        stack.pop_back();
+        for (int w : adj[u])
+          if (left.count(w) && !comp.count(w)) { comp.insert(w); stack.push_back(w); }
+      }
+      for (int v : comp) left.erase(v);
+      comps.emplace_back(comp.begin(), comp.end());  // sorted by index
+    }
+    return comps;
+  }
+  std::vector<std::vector<int>> bfs_levels(const std::vector<int> &nodes, int start) {
+    std::set<int> in(nodes.begin(), nodes.end()), seen{start};
+    std::vector<int> frontier{start};
+    std::vector<std::vector<int>> levels;
+    while (!frontier.empty()) {
+      levels.push_back(frontier);
+      std::vector<int> nxt;
+      for (int u : frontier)
+        for (int w : adj[u])  // std::set iterates in index order == sorted(adj[u], key=index)
+          if (in.count(w) && !seen.count(w)) { seen.insert(w); nxt.push_back(w); }
+      frontier = nxt;
+    }
+    return levels;
+  }
+};
+
+std::vector<int> nested_dissection(const nbp_graph *g) {
+  const int n = (int)g->vars.size();
+  ND nd;
+  nd.n = n;
+  nd.adj.assign(n, {});
+  for (const HFac &f : g->facs)
+    for (int a = 0; a < f.s.nvars; a++)
+      for (int b = 0; b < f.s.nvars; b++)
+        if (f.s.vars[a] != f.s.vars[b]) nd.adj[f.s.vars[a]].insert(f.s.vars[b]);
+  // dense nodes aside
+  std::vector<int> degs;
+  for (int v = 0; v < n; v++) degs.push_back((int)nd.adj[v].size());
+  std::vector<int> sd = degs;
+  std::sort(sd.begin(), sd.end());
+  const int thr = sd.empty() ? 0 : std::max(16, 10 * sd[sd.size() / 2]);
+  std::vector<int> dense;
+  for (int v = 0; v < n; v++)
+    if (degs[v] > thr) dense.push_back(v);
+  std::vector<int> nodes0;
+  if (!dense.empty() && (int)dense.size() < n) {
+    std::set<int> ds(dense.begin(), dense.end());
+    for (int v = 0; v < n; v++) {
+      if (ds.count(v)) { nd.adj[v].clear(); continue; }
+      for (int d : dense) nd.adj[v].erase(d);
+      nodes0.push_back(v);
+    }
+  } else {
+    dense.clear();
+    for (int v = 0; v < n; v++) nodes0.push_back(v);
+  }
+  std::vector<int> order;
+  struct Item { bool emit; std::vector<int> nodes; };
+  std::vector<Item> stack;
+  {
+    auto comps = nd.components(nodes0);
+    // Python: work = comps[::-1]; stack = [("split", c) for c in work]; pop from the end -> first component first
+    for (auto it = comps.rbegin(); it != comps.rend(); ++it) stack.push_back({false, *it});
+  }
+  while (!stack.empty()) {
+    Item it = std::move(stack.back());
+    stack.pop_back();
+    if (it.emit || it.nodes.size() <= 2) { order.insert(order.end(), it.nodes.begin(), it.nodes.end()); continue; }
+    auto lv = nd.bfs_levels(it.nodes, it.nodes[0]);
+    lv = nd.bfs_levels(it.nodes, lv.back()[0]);
+    if (lv.size() < 3) { order.insert(order.end(), it.nodes.begin(), it.nodes.end()); continue; }
+    std::vector<long> sizes;
+    long acc = 0;
+    for (auto &l : lv) { acc += (long)l.size(); sizes.push_back(acc); }
+    const long total = sizes.back();
+    long bestd = -1, bestl = -1;
+    int bestk = -1;
+    for (int k = 1; k + 1 < (int)lv.size(); k++) {
+      const long left = sizes[k - 1], right = total - sizes[k];
+      const long d = std::labs(left - right), l = (long)lv[k].size();
+      if (bestk < 0 || d < bestd || (d == bestd && l < bestl)) { bestd = d; bestl = l; bestk = k; }
+    }
+    const std::vector<int> &sep = lv[bestk];
+    std::set<int> ss(sep.begin(), sep.end());
+    std::vector<int> rest;
+    for (int v : it.nodes)
+      if (!ss.count(v)) rest.push_back(v);
+    stack.push_back({true, sep});
+    auto comps = nd.components(rest);
+    for (auto c = comps.rbegin(); c != comps.rend(); ++c) stack.push_back({false, *c});
+  }
+  order.insert(order.end(), dense.begin(), dense.end());
+  return order;
+}
+
+// ---- Bayes net + tree (bayestree.buildBayesNet / buildTree) ---------------------------------------
+void build_tree(nbp_tree *t) {
+  const nbp_graph *g = t->g;
+  const int n = (int)g->vars.size(), nf = (int)g->facs.size();
+  std::vector<std::vector<int>> fvars(nf), vfacs = g->vfacs;
+  for (int f = 0; f < nf; f++) fvars[f].assign(g->facs[f].s.vars, g->facs[f].s.vars + g->facs[f].s.nvars);
+  std::vector<char> eliminated;
+  eliminated.assign(nf, 0);
+  std::vector<std::vector<int>> sep(n);
+  for (int v : t->order) {
+    std::vector<int> Si;
+    for (size_t q = 0; q < vfacs[v].size(); q++) {
+      const int f = vfacs[v][q];
+      if (eliminated[f]) continue;
+      for (int s : fvars[f])
+        if (s != v && !contains(Si, s)) Si.push_back(s);
+      eliminated[f] = 1;
+    }
+    sep[v] = Si;
+    if (!Si.empty()) {  // the marginal over Si joins the graph
+      const int name = (int)fvars.size();
+      fvars.push_back(Si);
+      eliminated.push_back(0);
+      for (int s : Si) vfacs[s].push_back(name);
+    }
+  }
+  std::vector<int> pos(n, 0);
+  for (int i = 0; i < (int)t->order.size(); i++) pos[t->order[i]] = i;
+  t->frontal_of.assign(n, 0);
+  for (auto it = t->order.rbegin(); it != t->order.rend(); ++it) {
+    const int var = *it;
+    const std::vector<int> &Sj = sep[var];
+    if (Sj.empty()) {
+      Clique c;
+      c.id = (int)t->cl.size() + 1;
+      c.frontals = {var};
+      t->cl.push_back(c);
+      t->frontal_of[var] = c.id;
+      t->roots.push_back(c.id);
+      continue;
+    }
+    int felbl = Sj[0];
+    for (int s : Sj)
+      if (pos[s] < pos[felbl]) felbl = s;  // identifyFirstEliminatedSeparator
+    const int cp = t->frontal_of[felbl];
+    Clique &P = t->cl[cp - 1];
+    std::vector<int> a = P.all(), b = Sj;
+    std::sort(a.begin(), a.end());
+    std::sort(b.begin(), b.end());
+    if (a == b) {
+      P.frontals.push_back(var);  // appendClique!
+      t->frontal_of[var] = cp;
+    } else {
+      Clique c;
+      c.id = (int)t->cl.size() + 1;
+      c.frontals = {var};
+      c.seps = Sj;
+      c.parent = cp;
+      t->cl[cp - 1].children.push_back(c.id);
+      t->cl.push_back(c);
+      t->frontal_of[var] = c.id;
+    }
+  }
+}
+
+std::vector<int> postorder(const nbp_tree *t) {
+  std::vector<int> out;
+  // iterative post-order, children in list order (bayestree.BayesTree.postorder)
+  for (int r : t->roots) {
+    std::vector<std::pair<int, size_t>> st{{r, 0}};
+    while (!st.empty()) {
+      auto &top = st.back();
+      const Clique &c = t->cl[top.first - 1];
+      if (top.second < c.children.size()) {
+        const int ch = c.children[top.second++];
+        st.push_back({ch, 0});
+      } else {
+        out.push_back(top.first);
+        st.pop_back();
+      }
+    }
+  }
+  return out;
+}
+
+std::vector<int> stable_sort_by(const std::vector<int> &xs, const std::vector<int> &key) {
+  std::vector<int> idx(xs.size());
+  for (size_t i = 0; i < xs.size(); i++) idx[i] = (int)i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+  std::vector<int> out;
+  for (int i : idx) out.push_back(xs[i]);
+  return out;
+}
+
+nbp_status clique_potentials_and_ids(nbp_tree *t) {
+  const nbp_graph *g = t->g;
+  std::vector<char> used(g->facs.size(), 0);
+  for (int cid : postorder(t)) {
+    Clique &c = t->cl[cid - 1];
+    const std::vector<int> cols = c.all();
+    std::set<int> allv(cols.begin(), cols.end());
+    // setCliqPotentials!
+    std::vector<int> frtfcts;
+    for (int fr : c.frontals)
+      for (int f : g->vfacs[fr])
+        if (!contains(frtfcts, f)) frtfcts.push_back(f);
+    for (int f : frtfcts) {
+      if (used[f]) continue;
+      bool inside = true;
+      for (int k = 0; k < g->facs[f].s.nvars; k++) inside &= allv.count(g->facs[f].s.vars[k]) > 0;
+      if (inside) c.potentials.push_back(f);
+    }
+    for (int f : c.potentials) used[f] = 1;
+    c.dwnPotentials = frtfcts;
+    // compCliqAssocMatrices!
+    for (int ch : c.children)
+      for (int s : t->cl[ch - 1].seps) c.inmsg.push_back(s);
+    const int nc = (int)cols.size(), nA = (int)c.potentials.size(), nM = (int)c.inmsg.size(), nfr = (int)c.frontals.size();
+    std::vector<std::vector<int>> A(nA, std::vector<int>(nc, 0)), M(nM, std::vector<int>(nc, 0));
+    for (int j = 0; j < nc; j++) {
+      for (int i = 0; i < nM; i++) M[i][j] = (c.inmsg[i] == cols[j]);
+      for (int i = 0; i < nA; i++) {
+        const nbp_factor_spec &fs = g->facs[c.potentials[i]].s;
+        for (int k = 0; k < fs.nvars; k++)
+          if (fs.vars[k] == cols[j]) A[i][j] = 1;
+      }
+    }
+    // setCliqMCIDs!
+    auto colsum = [&](const std::vector<std::vector<int>> &X, int j) { int s = 0; for (auto &r : X) s += r[j]; return s; };
+    std::vector<int> sumc(nc, 0), sumA(nc, 0), sumM(nc, 0), sumsr(nc, 0);
+    long tot = 0;
+    for (int j = 0; j < nc; j++) { sumA[j] = colsum(A, j); sumM[j] = colsum(M, j); sumc[j] = sumA[j] + sumM[j]; tot += sumc[j]; }
+    auto rows_single = [&](const std::vector<std::vector<int>> &X) {
+      for (auto &r : X) {
+        int s = 0;
+        for (int x : r) s += x;
+        if (s == 1)
+          for (int j = 0; j < nc; j++) sumsr[j] += r[j];
+      }
+    };
+    rows_single(A);
+    rows_single(M);
+    for (int j = 0; j < nc; j++)
+      if (sumsr[j] - sumc[j] == 0) c.directPriorMsg.push_back(cols[j]);
+    for (int j = 0; j < nc; j++)
+      if (sumc[j] == 1 && sumA[j] == 1) c.directvar.push_back(cols[j]);
+    if (tot == 0) return hfail(NBP_ERR_ARG, "mcmcIterationIDs -- unaccounted variables");
+    std::vector<int> usset = c.directvar;
+    for (int j = 0; j < nc; j++)
+      if (sumc[j] > 1 && !contains(usset, cols[j])) usset.push_back(cols[j]);
+    std::vector<int> alliter;
+    for (int v : usset)
+      if (!contains(c.directPriorMsg, v)) alliter.push_back(v);
+    std::vector<int> upmsg;
+    for (int j = 0; j < nc; j++)
+      if (sumM[j] >= 1) upmsg.push_back(cols[j]);
+    std::vector<int> sing, nons;
+    for (int v : alliter) (contains(upmsg, v) ? sing : nons).push_back(v);
+    std::map<int, int> colidx;
+    for (int j = 0; j < nc; j++) colidx[cols[j]] = j;
+    auto keys = [&](const std::vector<int> &xs) { std::vector<int> k; for (int v : xs) k.push_back(sumc[colidx[v]]); return k; };
+    nons = stable_sort_by(nons, keys(nons));
+    sing = stable_sort_by(sing, keys(sing));
+    c.itervar = nons;
+    c.itervar.insert(c.itervar.end(), sing.begin(), sing.end());
+    for (int j = nfr; j < nc; j++)
+      if (sumc[j] == 1 && sumM[j] == 1) c.msgskip.push_back(cols[j]);
+    for (int j = 0; j < nfr; j++)
+      if (sumc[j] == 1 && sumM[j] == 1) c.directFrtlMsg.push_back(cols[j]);
+  }
+  return NBP_OK;
+}
+
+void schedules(nbp_tree *t) {
+  const nbp_graph *g = t->g;
+  const int iters = g->sp.gibbs_iters;
+  for (Clique &c : t->cl) {
+    auto fmcmc = [&](const std::vector<int> &l, int it) {
+      if (l.size() == 1) it = 1;
+      for (int k = 0; k < it; k++) c.upsched.insert(c.upsched.end(), l.begin(), l.end());
+    };
+    fmcmc(c.directFrtlMsg, 1);
+    if (!c.msgskip.empty()) fmcmc(c.msgskip, 1);
+    if (!c.itervar.empty()) fmcmc(c.itervar, iters);
+    if (!c.directPriorMsg.empty()) {
+      std::vector<int> l;
+      for (int v : c.directPriorMsg)
+        if (!contains(c.msgskip, v)) l.push_back(v);
+      fmcmc(l, 1);
+    }
+    // down: determineCliqVariableDownSequence + solveCliqDownFrontalProducts!
+    std::set<int> frs(c.frontals.begin(), c.frontals.end());
+    std::vector<int> iterv;
+    for (int f : c.dwnPotentials) {
+      std::vector<int> hit;
+      for (int k = 0; k < g->facs[f].s.nvars; k++)
+        if (frs.count(g->facs[f].s.vars[k])) hit.push_back(g->facs[f].s.vars[k]);
+      if (hit.size() > 1)
+        for (int v : hit)
+          if (!contains(iterv, v)) iterv.push_back(v);
+    }
+    std::vector<int> itf, directs;
+    for (int v : c.frontals) (contains(iterv, v) ? itf : directs).push_back(v);
+    if (g->sp.limitfixeddown) {
+      auto drop = [&](std::vector<int> &l) { l.erase(std::remove_if(l.begin(), l.end(), [&](int v) { return g->vars[v].ismargin; }), l.end()); };
+      drop(itf);
+      drop(directs);
+    }
+    c.dnsched = directs;
+    for (int k = 0; k < iters; k++) c.dnsched.insert(c.dnsched.end(), itf.begin(), itf.end());
+    if (c.parent == 0) c.dnsched.clear();
+  }
+}
+
+// ---- compile (solver.TreeProgram) -----------------------------------------------------------------
+struct Entry { bool msg; int ref; };  // factor id, or child clique id of a message
+
+void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, int msg_slot, int target, const std::map<int, int> *Bc,
+                   const std::vector<int> *main_slot, const std::set<int> *inclq, int out_slot, uint64_t seed, double nullSurplus) {
+  memset(&d, 0, sizeof(d));
+  const nbp_solver_params &sp = g->sp;
+  auto slot_of = [&](int v) { return (inclq == nullptr || inclq->count(v)) ? Bc->at(v) : (*main_slot)[v]; };
+  d.manifold = g->vars[target].manifold;
+  d.out_slot = out_slot;
+  d.inflate_cycles = sp.inflate_cycles;
+  d.mhidx_in = d.mhidx_out = -1;
+  d.spread_nh = sp.spread_nh;
+  d.seed = seed;
+  if (!fac) {  // MsgPrior (generateMsgPrior, TreeMessageUtils.jl:86-89)
+    d.factor_kind = NBP_F_MSGPRIOR;
+    d.inflation = sp.inflation;
+    d.nullhypo = std::max(0.0, nullSurplus);
+    d.nvars = 1;
+    d.sfidx = 0;
+    d.var_slot[0] = slot_of(target);
+    d.var_slot[1] = msg_slot;
+    d.ncomp = 1;
+    d.comp[0][0] = 1.0;
+    return;
+  }
+  const nbp_factor_spec &s = fac->s;
+  d.factor_kind = s.factor_kind;
+  d.partial_mask = s.partial_mask;
+  d.inflation = s.inflation > 0 ? s.inflation : sp.inflation;
+  d.nullhypo = std::max(s.nullhypo, nullSurplus);
+  d.nvars = s.nvars;
+  for (int i = 0; i < s.nvars; i++) {
+    if (s.vars[i] == target) d.sfidx = i;
+    d.var_slot[i] = slot_of(s.vars[i]);
+  }
+  d.ncomp = s.ncomp;
+  memcpy(d.comp, s.comp, sizeof(d.comp));
+  if (s.has_multihypo) {
+    int flags = 1 | 0x80;
+    for (int i = 0; i < s.nvars; i++)
+      if (g->vars[s.vars[i]].initialized) flags |= 1 << (8 + i);
+    d.has_multihypo = flags;
+    for (int i = 0; i < s.nvars; i++) d.multihypo[i] = s.multihypo[i];
+  }
+}
+
+void add_stage(nbp_tree *t, int kind, const void *descs, size_t esz, int n) {
+  Stage st;
+  st.kind = kind;
+  st.n = n;
+  st.bytes.assign((const char *)descs, (const char *)descs + esz * (size_t)n);
+  t->stages.push_back(std::move(st));
+}
+
+nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &entries, const std::set<int> *inclq, int out_slot, int passid,
+                      int step, uint64_t seed, std::vector<nbp_proposal_desc> &props, std::vector<nbp_product_desc> &prods) {
+  const nbp_graph *g = t->g;
+  const int base = t->scratch[cid - 1];
+  const std::map<int, int> &Bc = t->B[cid - 1];
+  const int F = (int)entries.size();
+  if (F > NBP_MAXF) return hfail(NBP_ERR_RANGE, "a product exceeds NBP_MAXF densities");
+  bool anymh = false;
+  for (const Entry &e : entries)
+    if (!e.msg && g->facs[e.ref].s.has_multihypo) anymh = true;
+  bool anypartial = false;
+  nbp_product_desc q;
+  memset(&q, 0, sizeof(q));
+  int F_in = 0;
+  for (int i = 0; i < F; i++) {
+    const Entry &e = entries[i];
+    const HFac *fac = e.msg ? nullptr : &g->facs[e.ref];
+    double ns = 0.0;  // _null_surplus: relative non-multihypo siblings of a multihypo factor
+    if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = g->sp.null_surplus_add;
+    const int msg_slot = e.msg ? t->B[e.ref - 1].at(v) : -1;
+    nbp_proposal_desc d;
+    fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, op_seed(seed, passid, cid, step, i + 1), ns);
+    props.push_back(d);
+    q.in_slot[i] = base + i;
+    const int pm = fac ? fac->s.partial_mask : 0;
+    q.in_partial[i] = (uint8_t)pm;
+    anypartial |= pm != 0;
+    F_in += (fac && fac->is_prior) ? 0 : 1;
+  }
+  const int man = g->vars[v].manifold;
+  q.manifold = man;
+  q.nfactors = F;
+  q.niter = g->sp.product_niter;
+  q.out_slot = out_slot;
+  q.labels_out = -1;
+  q.old_slot = -1;
+  if (anypartial) q.old_slot = (inclq == nullptr || inclq->count(v)) ? Bc.at(v) : t->main_slot[v];
+  else memset(q.in_partial, 0, sizeof(q.in_partial));
+  q.seed = op_seed(seed, passid, cid, step, PRODUCT_ID);
+  prods.push_back(q);
+  const long N = g->sp.N, P = mani_P(man), D = mani_dim(man);
+  t->st.alg_bytes += (F_in + 2) * N * P * 8 + (F_in + 1) * D * 8;
+  t->st.alg_bytes_proposal += (F_in + 1) * N * P * 8;
+  t->st.alg_bytes_prep += (F_in + 1) * D * 8;
+  t->st.alg_bytes_product += N * P * 8;
+  return NBP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+nbp_status nbp_graph_create(const nbp_solver_params *p, nbp_graph **out) {
+  if (!p || !out) return hfail(NBP_ERR_ARG, "null argument");
+  if (p->N < 8 || p->N > NBP_MAXN) return hfail(NBP_ERR_RANGE, "N must be in [8, 512]");
+  if (!p->upsolve && !p->downsolve) return hfail(NBP_ERR_ARG, "must attempt either up or down solve");
+  nbp_graph *g = new nbp_graph();
+  g->sp = *p;
+  *out = g;
+  return NBP_OK;
+}
+nbp_status nbp_graph_destroy(nbp_graph *g) {
+  delete g;
+  return NBP_OK;
+}
+int32_t nbp_graph_add_variable(nbp_graph *g, int32_t manifold) {
+  if (!g) return hfail(NBP_ERR_ARG, "null argument");
+  if (manifold < NBP_EUCLID1 || manifold > NBP_SE2) return hfail(NBP_ERR_ARG, "unknown manifold");
+  g->vars.push_back({manifold, true, false});
+  g->vfacs.emplace_back();
+  return (int32_t)g->vars.size() - 1;
+}
+int32_t nbp_graph_add_factor(nbp_graph *g, const nbp_factor_spec *s) {
+  if (!g || !s) return hfail(NBP_ERR_ARG, "null argument");
+  if (s->factor_kind < NBP_F_PRIOR || s->factor_kind > NBP_F_EUCLIDDIST || s->factor_kind == NBP_F_MSGPRIOR)
+    return hfail(NBP_ERR_ARG, "factor: unknown kind");
+  if (s->nvars < 1 || s->nvars > NBP_MAXV) return hfail(NBP_ERR_RANGE, "factor: nvars");
+  if (s->ncomp < 1 || s->ncomp > NBP_MAXC) return hfail(NBP_ERR_RANGE, "factor: ncomp");
+  const bool prior = s->factor_kind == NBP_F_PRIOR;
+  if (prior && s->nvars != 1) return hfail(NBP_ERR_ARG, "priors are unary factors");
+  for (int i = 0; i < s->nvars; i++)
+    if (s->vars[i] < 0 || s->vars[i] >= (int)g->vars.size()) return hfail(NBP_ERR_RANGE, "factor: variable id");
+  HFac f;
+  f.s = *s;
+  f.is_prior = prior;
+  const int id = (int)g->facs.size();
+  g->facs.push_back(f);
+  for (int i = 0; i < s->nvars; i++) g->vfacs[s->vars[i]].push_back(id);
+  return id;
+}
+nbp_status nbp_graph_set_variable_flags(nbp_graph *g, int32_t v, int32_t initialized, int32_t ismargin) {
+  if (!g || v < 0 || v >= (int)g->vars.size()) return hfail(NBP_ERR_RANGE, "variable id");
+  g->vars[v].initialized = initialized != 0;
+  g->vars[v].ismargin = ismargin != 0;
+  return NBP_OK;
+}
+int32_t nbp_graph_num_variables(const nbp_graph *g) { return g ? (int32_t)g->vars.size() : 0; }
+int32_t nbp_graph_num_factors(const nbp_graph *g) { return g ? (int32_t)g->facs.size() : 0; }
+
+nbp_status nbp_graph_order_nested_dissection(const nbp_graph *g, int32_t *out) {
+  if (!g || !out) return hfail(NBP_ERR_ARG, "null argument");
+  std::vector<int> o = nested_dissection(g);
+  for (size_t i = 0; i < o.size(); i++) out[i] = o[i];
+  return NBP_OK;
+}
+
+nbp_status nbp_tree_build(const nbp_graph *g, const int32_t *order, int32_t n, nbp_tree **out) {
+  if (!g || !order || !out) return hfail(NBP_ERR_ARG, "null argument");
+  if (n != (int)g->vars.size()) return hfail(NBP_ERR_ARG, "the elimination order must list every variable once");
+  std::vector<char> seen(n, 0);
+  for (int i = 0; i < n; i++) {
+    if (order[i] < 0 || order[i] >= n || seen[order[i]]) return hfail(NBP_ERR_ARG, "the elimination order must list every variable once");
+    seen[order[i]] = 1;
+  }
+  nbp_tree *t = new nbp_tree();
+  t->g = g;
+  t->order.assign(order, order + n);
+  build_tree(t);
+  nbp_status rc = clique_potentials_and_ids(t);
+  if (rc) { delete t; return rc; }
+  schedules(t);
+  *out = t;
+  return NBP_OK;
+}
+nbp_status nbp_tree_destroy(nbp_tree *t) {
+  delete t;
+  return NBP_OK;
+}
+int32_t nbp_tree_num_cliques(const nbp_tree *t) { return t ? (int32_t)t->cl.size() : 0; }
+int32_t nbp_tree_max_schedule(const nbp_tree *t) {
+  size_t m = 0;
+  if (t)
+    for (const Clique &c : t->cl) m = std::max(m, std::max(c.upsched.size(), c.dnsched.size()));
+  return (int32_t)m;
+}
+nbp_status nbp_tree_clique(const nbp_tree *t, int32_t k, nbp_clique_info *info, int32_t *fr, int32_t *sp, int32_t *ch, int32_t *pots,
+                           int32_t *up, int32_t *dn) {
+  if (!t || k < 1 || k > (int)t->cl.size()) return hfail(NBP_ERR_RANGE, "clique id");
+  const Clique &c = t->cl[k - 1];
+  if (info) {
+    info->parent = c.parent;
+    info->nfrontals = (int)c.frontals.size();
+    info->nseparators = (int)c.seps.size();
+    info->nchildren = (int)c.children.size();
+    info->npotentials = (int)c.potentials.size();
+    info->nup = (int)c.upsched.size();
+    info->ndown = (int)c.dnsched.size();
+  }
+  auto cp = [](const std::vector<int> &v, int32_t *o) { if (o) for (size_t i = 0; i < v.size(); i++) o[i] = v[i]; };
+  cp(c.frontals, fr); cp(c.seps, sp); cp(c.children, ch); cp(c.potentials, pots); cp(c.upsched, up); cp(c.dnsched, dn);
+  return NBP_OK;
+}
+
+int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
+  if (!t) return hfail(NBP_ERR_ARG, "null argument");
+  const nbp_graph *g = t->g;
+  const int n = (int)g->vars.size();
+  t->snapshot = snapshot;
+  t->main_slot.resize(n);
+  for (int v = 0; v < n; v++) t->main_slot[v] = v;
+  int nxt = n;
+  t->snap_slot.clear();
+  if (snapshot) {
+    t->snap_slot.resize(n);
+    for (int v = 0; v < n; v++) t->snap_slot[v] = nxt + v;
+    nxt += n;
+  }
+  t->B.assign(t->cl.size(), {});
+  t->scratch.assign(t->cl.size(), 0);
+  for (Clique &c : t->cl) {  // clique ids ascending == Python's iteration over tree.cliques (insertion order)
+    for (int v : c.all()) t->B[c.id - 1][v] = nxt++;
+    // widest product of this clique: up = potentials touching v + child messages on v; down = all factors of v
+    size_t maxf = 1;
+    for (int v : c.upsched) {
+      size_t k = 0;
+      for (int f : c.potentials)
+        for (int q = 0; q < g->facs[f].s.nvars; q++)
+          if (g->facs[f].s.vars[q] == v) { k++; break; }
+      for (int chd : c.children)
+        if (contains(t->cl[chd - 1].seps, v)) k++;
+      maxf = std::max(maxf, k);
+    }
+    for (int v : c.dnsched) maxf = std::max(maxf, g->vfacs[v].size());
+    t->scratch[c.id - 1] = nxt;
+    nxt += (int)maxf;
+  }
+  t->n_slots = nxt;
+  return nxt;
+}
+nbp_status nbp_tree_main_slots(const nbp_tree *t, int32_t *main_out, int32_t *snap_out) {
+  if (!t || !main_out || t->main_slot.empty()) return hfail(NBP_ERR_ARG, "plan the slots first");
+  for (size_t v = 0; v < t->main_slot.size(); v++) main_out[v] = t->main_slot[v];
+  if (snap_out && !t->snap_slot.empty())
+    for (size_t v = 0; v < t->snap_slot.size(); v++) snap_out[v] = t->snap_slot[v];
+  return NBP_OK;
+}
+
+nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
+  if (!t) return hfail(NBP_ERR_ARG, "null argument");
+  if (t->main_slot.empty()) return hfail(NBP_ERR_ARG, "plan the slots first (nbp_tree_plan_slots)");
+  const nbp_graph *g = t->g;
+  const int n = (int)g->vars.size();
+  t->stages.clear();
+  t->st = nbp_tree_stats{};
+  std::vector<nbp_copy_desc> cps;
+  if (t->snapshot) {
+    for (int v = 0; v < n; v++) cps.push_back({t->snap_slot[v], t->main_slot[v]});
+    add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+  }
+  cps.clear();
+  for (const Clique &c : t->cl)  // deep copy of the clique sub graphs (SubGraphFunctions.jl:48)
+    for (int v : c.all()) cps.push_back({t->main_slot[v], t->B[c.id - 1].at(v)});
+  add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+  // heights / depths
+  std::vector<int> height(t->cl.size() + 1, 0), depth(t->cl.size() + 1, 0);
+  for (int cid : postorder(t)) {
+    int h = 0;
+    const Clique &c = t->cl[cid - 1];
+    if (!c.children.empty()) {
+      for (int chd : c.children) h = std::max(h, height[chd]);
+      h += 1;
+    }
+    height[cid] = h;
+  }
+  int maxh = 0, maxd = 0;
+  {
+    std::vector<std::pair<int, int>> st;
+    for (int r : t->roots) st.push_back({r, 0});
+    while (!st.empty()) {
+      auto [cid, d] = st.back();
+      st.pop_back();
+      depth[cid] = d;
+      maxd = std::max(maxd, d);
+      for (int chd : t->cl[cid - 1].children) st.push_back({chd, d + 1});
+    }
+    for (size_t k = 1; k <= t->cl.size(); k++) maxh = std::max(maxh, height[k]);
+  }
+  std::vector<nbp_proposal_desc> props;
+  std::vector<nbp_product_desc> prods;
+  nbp_status rc = NBP_OK;
+  // ---- up pass: leaves first
+  if (g->sp.upsolve) {
+    for (int h = 0; h <= maxh; h++) {
+      std::vector<const Clique *> level;
+      size_t nsteps = 0;
+      // up schedule filtered like solver.TreeProgram: variables with at least one density, not marginalized
+      std::vector<std::vector<int>> sched;
+      for (const Clique &c : t->cl)
+        if (height[c.id] == h) {
+          level.push_back(&c);
+          std::vector<int> s;
+          for (int v : c.upsched) {
+            bool any = false;
+            for (int f : c.potentials)
+              for (int q = 0; q < g->facs[f].s.nvars && !any; q++) any = g->facs[f].s.vars[q] == v;
+            for (int chd : c.children) any |= contains(t->cl[chd - 1].seps, v);
+            if (any && !g->vars[v].ismargin) s.push_back(v);
+          }
+          nsteps = std::max(nsteps, s.size());
+          sched.push_back(s);
+        }
+      for (size_t k = 0; k < nsteps; k++) {
+        props.clear();
+        prods.clear();
+        for (size_t ci = 0; ci < level.size(); ci++) {
+          if (k >= sched[ci].size()) continue;
+          const Clique &c = *level[ci];
+          const int v = sched[ci][k];
+          std::vector<Entry> ent;
+          for (int f : c.potentials) {
+            bool hit = false;
+            for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
+            if (hit) ent.push_back({false, f});
+          }
+          for (int chd : c.children)
+            if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
+          rc = update_ops(t, c.id, v, ent, nullptr, t->B[c.id - 1].at(v), PASS_UP, (int)k, seed, props, prods);
+          if (rc) return rc;
+          t->st.updates_up++;
+        }
+        add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
+        add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+      }
+    }
+  }
+  if (!g->sp.downsolve) {
+    cps.clear();
+    for (const Clique &c : t->cl)
+      for (int v : c.frontals) cps.push_back({t->B[c.id - 1].at(v), t->main_slot[v]});
+    add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+  } else {
+    cps.clear();
+    for (int r : t->roots)
+      for (int v : t->cl[r - 1].frontals) cps.push_back({t->B[r - 1].at(v), t->main_slot[v]});
+    add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+    for (int dpt = 1; dpt <= maxd; dpt++) {
+      std::vector<const Clique *> level;
+      size_t nsteps = 0;
+      for (const Clique &c : t->cl)
+        if (depth[c.id] == dpt) { level.push_back(&c); nsteps = std::max(nsteps, c.dnsched.size()); }
+      cps.clear();
+      for (const Clique *c : level)
+        for (int s : c->seps) cps.push_back({t->B[c->parent - 1].at(s), t->B[c->id - 1].at(s)});
+      add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+      for (size_t k = 0; k < nsteps; k++) {
+        props.clear();
+        prods.clear();
+        for (const Clique *c : level) {
+          if (k >= c->dnsched.size()) continue;
+          const int v = c->dnsched[k];
+          const std::vector<int> allv = c->all();
+          std::set<int> inclq(allv.begin(), allv.end());
+          std::vector<Entry> ent;
+          for (int f : g->vfacs[v]) ent.push_back({false, f});
+          rc = update_ops(t, c->id, v, ent, &inclq, t->B[c->id - 1].at(v), PASS_DOWN, (int)k, seed, props, prods);
+          if (rc) return rc;
+          t->st.updates_down++;
+        }
+        add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
+        add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+      }
+      cps.clear();
+      for (const Clique *c : level)
+        for (int v : c->frontals) cps.push_back({t->B[c->id - 1].at(v), t->main_slot[v]});
+      add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+    }
+  }
+  // statistics
+  t->st.stages = (int64_t)t->stages.size();
+  for (const Stage &s : t->stages) {
+    if (s.kind == NBP_STAGE_PROPOSALS) t->st.proposals += s.n;
+    if (s.kind == NBP_STAGE_PRODUCTS) t->st.products += s.n;
+  }
+  int64_t edges = 0;
+  for (const Clique &c : t->cl) edges += c.parent != 0;
+  t->st.messages = ((g->sp.upsolve ? 1 : 0) + (g->sp.downsolve ? 1 : 0)) * edges;
+  t->st.slots = t->n_slots;
+  return NBP_OK;
+}
+
+nbp_status nbp_tree_compile(nbp_tree *t, nbp_ctx *ctx, uint64_t seed, nbp_program **out) {
+  if (!t || !ctx || !out) return hfail(NBP_ERR_ARG, "null argument");
+  nbp_status rc = nbp_tree_schedule(t, seed);
+  if (rc) return rc;
+  // hand the stages to libnbp
+  nbp_program *p = nullptr;
+  rc = nbp_program_create(ctx, &p);
+  if (rc) return rc;
+  for (const Stage &s : t->stages) {
+    rc = nbp_program_add_stage(p, s.kind, s.bytes.empty() ? nullptr : s.bytes.data(), s.n);
+    if (rc) { nbp_program_destroy(p); return rc; }
+  }
+  rc = nbp_program_finalize(p);
+  if (rc) { nbp_program_destroy(p); return rc; }
+  *out = p;
+  return NBP_OK;
+}
+
+nbp_status nbp_tree_get_stats(const nbp_tree *t, nbp_tree_stats *out) {
+  if (!t || !out) return hfail(NBP_ERR_ARG, "null argument");
+  *out = t->st;
+  return NBP_OK;
+}
+int32_t nbp_tree_num_stages(const nbp_tree *t) { return t ? (int32_t)t->stages.size() : 0; }
+nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *out, int64_t cap) {
+  if (!t || s < 0 || s >= (int)t->stages.size()) return hfail(NBP_ERR_RANGE, "stage index");
+  const Stage &st = t->stages[s];
+  if (kind) *kind = st.kind;
+  if (n) *n = st.n;
+  if (out && cap > 0) memcpy(out, st.bytes.data(), std::min<size_t>((size_t)cap, st.bytes.size()));
+  return NBP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+"""ctypes binding of the native (C++) host side, include/nbp_host.h: graph container, nested-dissection
+ordering, Bayes tree + clique potentials + Gibbs schedules, and the whole-tree schedule compiler.
+`NativeGraph.from_fg(fg)` mirrors a Python FactorGraph; everything after that runs in libnbp."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
+
+
+class SolverParamsC(C.Structure):
+    _fields_ = [("N", i32), ("gibbs_iters", i32), ("inflate_cycles", i32), ("product_niter", i32), ("upsolve", i32),
+                ("downsolve", i32), ("limitfixeddown", i32), ("pad_", i32), ("spread_nh", f64), ("inflation", f64),
+                ("null_surplus_add", f64)]
+
+
+class FactorSpec(C.Structure):
+    _fields_ = [("factor_kind", i32), ("nvars", i32), ("vars", i32 * abi.MAXV), ("ncomp", i32), ("has_multihypo", i32),
+                ("partial_mask", i32), ("multihypo", f64 * abi.MAXV), ("nullhypo", f64), ("inflation", f64),
+                ("comp", (f64 * abi.COMP_STRIDE) * abi.MAXC)]
+
+
+class CliqueInfo(C.Structure):
+    _fields_ = [(k, i32) for k in ("parent", "nfrontals", "nseparators", "nchildren", "npotentials", "nup", "ndown")]
+
+
+class TreeStats(C.Structure):
+    _fields_ = [(k, i64) for k in ("stages", "proposals", "products", "updates_up", "updates_down", "messages", "slots",
+                                   "alg_bytes", "alg_bytes_proposal", "alg_bytes_prep", "alg_bytes_product")]
+
+
+HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable", "nbp_graph_add_factor",
+                "nbp_graph_set_variable_flags", "nbp_graph_num_variables", "nbp_graph_num_factors",
+                "nbp_graph_order_nested_dissection", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
+                "nbp_tree_clique", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
+                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage"]
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = abi.load_library()
+    if not _declared:
+        vp, ip = C.c_void_p, C.POINTER(i32)
+        lib.nbp_graph_create.argtypes = [C.POINTER(SolverParamsC), C.POINTER(vp)]
+        lib.nbp_graph_destroy.argtypes = [vp]
+        lib.nbp_graph_add_variable.argtypes = [vp, i32]
+        lib.nbp_graph_add_factor.argtypes = [vp, C.POINTER(FactorSpec)]
+        lib.nbp_graph_set_variable_flags.argtypes = [vp, i32, i32, i32]
+        lib.nbp_graph_num_variables.argtypes = [vp]
+        lib.nbp_graph_num_factors.argtypes = [vp]
+        lib.nbp_graph_order_nested_dissection.argtypes = [vp, ip]
+        lib.nbp_tree_build.argtypes = [vp, ip, i32, C.POINTER(vp)]
+        lib.nbp_tree_destroy.argtypes = [vp]
+        lib.nbp_tree_num_cliques.argtypes = [vp]
+        lib.nbp_tree_clique.argtypes = [vp, i32, C.POINTER(CliqueInfo), ip, ip, ip, ip, ip, ip]
+        lib.nbp_tree_max_schedule.argtypes = [vp]
+        lib.nbp_tree_plan_slots.argtypes = [vp, i32]
+        lib.nbp_tree_main_slots.argtypes = [vp, ip, ip]
+        lib.nbp_tree_compile.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
+        lib.nbp_tree_schedule.argtypes = [vp, C.c_uint64]
+        lib.nbp_tree_get_stats.argtypes = [vp, C.POINTER(TreeStats)]
+        lib.nbp_tree_num_stages.argtypes = [vp]
+        lib.nbp_tree_stage.argtypes = [vp, i32, ip, ip, vp, i64]
+        for n in HOST_EXPORTS:
+            getattr(lib, n).restype = i32
+        _declared = True
+    return lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise RuntimeError(f"libnbp host status {rc}: {abi.load_library().nbp_last_error().decode()}")
+    return rc
+
+
+class NativeGraph:
+    def __init__(self, sp):
+        self.lib = _lib()
+        p = SolverParamsC(sp.N, sp.gibbsIters, sp.inflateCycles, sp.productNiter, int(sp.upsolve), int(sp.downsolve),
+                          int(getattr(sp, "limitfixeddown", False)), 0, sp.spreadNH, sp.inflation, sp.nullSurplusAdd)
+        self._g = C.c_void_p()
+        _check(self.lib.nbp_graph_create(C.byref(p), C.byref(self._g)))
+        self.labels, self.flabels = [], []
+
+    @classmethod
+    def from_fg(cls, fg):
+        g = cls(fg.solverParams)
+        idx = {}
+        for v in fg.ls():
+            var = fg.getVariable(v)
+            idx[v] = _check(g.lib.nbp_graph_add_variable(g._g, var.varType.manifold))
+            g.lib.nbp_graph_set_variable_flags(g._g, idx[v], int(var.initialized), int(var.ismargin))
+            g.labels.append(v)
+        for fl in fg.lsf():
+            f = fg.getFactor(fl)
+            s = FactorSpec()
+            s.factor_kind, s.nvars = f.fnc.kind, len(f.variables)
+            for i, v in enumerate(f.variables):
+                s.vars[i] = idx[v]
+            comps = f.fnc.components()
+            s.ncomp = len(comps)
+            for c, (w, mu, L) in enumerate(comps):
+                s.comp[c][0] = w
+                for i in range(min(3, len(mu))):
+                    s.comp[c][1 + i] = float(mu[i])
+                for i in range(min(3, L.shape[0])):
+                    for j in range(i + 1):
+                        s.comp[c][4 + 3 * i + j] = float(L[i, j])
+            if f.multihypo is not None:
+                s.has_multihypo = 1
+                for i, p in enumerate(f.multihypo):
+                    s.multihypo[i] = p
+            s.nullhypo, s.inflation = f.nullhypo, f.inflation
+            s.partial_mask = getattr(f.fnc, "partial_mask", 0)
+            _check(g.lib.nbp_graph_add_factor(g._g, C.byref(s)))
+            g.flabels.append(fl)
+        g.index = idx
+        return g
+
+    def order_nested_dissection(self):
+        out = (i32 * len(self.labels))()
+        _check(self.lib.nbp_graph_order_nested_dissection(self._g, out))
+        return [self.labels[i] for i in out]
+
+    def build_tree(self, order):
+        arr = (i32 * len(order))(*[self.index[v] for v in order])
+        t = C.c_void_p()
+        _check(self.lib.nbp_tree_build(self._g, arr, len(order), C.byref(t)))
+        return NativeTree(self, t)
+
+    def close(self):
+        if self._g:
+            self.lib.nbp_graph_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeTree:
+    def __init__(self, graph, handle):
+        self.g, self.lib, self._t = graph, graph.lib, handle
+
+    @property
+    def n_cliques(self):
+        return self.lib.nbp_tree_num_cliques(self._t)
+
+    def clique(self, k):
+        nv, nf, ms = len(self.g.labels), len(self.g.flabels), max(1, self.lib.nbp_tree_max_schedule(self._t))
+        info = CliqueInfo()
+        fr, sp, ch = (i32 * nv)(), (i32 * nv)(), (i32 * max(1, self.n_cliques))()
+        po, up, dn = (i32 * max(1, nf))(), (i32 * ms)(), (i32 * ms)()
+        _check(self.lib.nbp_tree_clique(self._t, k, C.byref(info), fr, sp, ch, po, up, dn))
+        L, F = self.g.labels, self.g.flabels
+        return {"parent": info.parent, "frontals": [L[fr[i]] for i in range(info.nfrontals)],
+                "separators": [L[sp[i]] for i in range(info.nseparators)], "children": [ch[i] for i in range(info.nchildren)],
+                "potentials": [F[po[i]] for i in range(info.npotentials)], "up": [L[up[i]] for i in range(info.nup)],
+                "down": [L[dn[i]] for i in range(info.ndown)]}
+
+    def plan_slots(self, snapshot=False):
+        self.n_slots = _check(self.lib.nbp_tree_plan_slots(self._t, int(snapshot)))
+        nv = len(self.g.labels)
+        m, s = (i32 * nv)(), (i32 * nv)()
+        _check(self.lib.nbp_tree_main_slots(self._t, m, s if snapshot else None))
+        self.main = {v: m[i] for i, v in enumerate(self.g.labels)}
+        self.snap = {v: s[i] for i, v in enumerate(self.g.labels)} if snapshot else None
+        return self.n_slots
+
+    def compile(self, backend, seed):
+        """-> a program object with run/reseed/close (backend.HipProgram interface) living on `backend`"""
+        from .backend import HipProgram
+        p = C.c_void_p()
+        _check(self.lib.nbp_tree_compile(self._t, backend._ctx, C.c_uint64(seed), C.byref(p)))
+        prog = HipProgram.__new__(HipProgram)
+        prog.backend, prog._p, prog.n_stages = backend, p, self.lib.nbp_tree_num_stages(self._t)
+        return prog
+
+    def schedule(self, seed):
+        """build the stage descriptors without touching a device"""
+        _check(self.lib.nbp_tree_schedule(self._t, C.c_uint64(seed)))
+
+    def stats(self):
+        st = TreeStats()
+        _check(self.lib.nbp_tree_get_stats(self._t, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in TreeStats._fields_}
+
+    def stages(self):
+        """[(kind, bytes)] of the last compile (tests compare them with solver.TreeProgram's)"""
+        out = []
+        esz = {abi.STAGE_PROPOSALS: C.sizeof(abi.ProposalDesc), abi.STAGE_PRODUCTS: C.sizeof(abi.ProductDesc),
+               abi.STAGE_COPIES: C.sizeof(abi.CopyDesc)}
+        for s in range(self.lib.nbp_tree_num_stages(self._t)):
+            kind, n = i32(), i32()
+            _check(self.lib.nbp_tree_stage(self._t, s, C.byref(kind), C.byref(n), None, 0))
+            buf = (C.c_char * max(1, n.value * esz[kind.value]))()
+            _check(self.lib.nbp_tree_stage(self._t, s, C.byref(kind), C.byref(n), buf, n.value * esz[kind.value]))
+            out.append((kind.value, bytes(buf[: n.value * esz[kind.value]])))
+        return out
+
+    def close(self):
+        if self._t:
+            self.lib.nbp_tree_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,124 @@
+"""CPU: the native (C++) host side (include/nbp_host.h) against this repo's Python implementation
+(bayestree.py / solver.TreeProgram, itself pinned to the reference's known answers in
+tests/test_tree_known_answers.py): identical elimination orders, cliques, potentials, Gibbs schedules,
+slot plans and -- byte for byte -- identical stage descriptors.  No device call is made: compiling to a
+resident program needs a context and is covered by tests/test_gpu_native_host.py."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import iif_amd_loader
+
+iif = iif_amd_loader.load()
+from iif_amd import native_host  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def graphs():
+    E2 = iif.ContinuousEuclid(2)
+    yield "chain", iif.generateChainEuclid(60, vardims=2, priorEvery=10, N=100)
+    yield "kaess", iif.generateGraph_Kaess(iif.SolverParams(N=100))
+    yield "linestep", iif.generateGraph_LineStep(8, landmarkPriorsAt=(0, 4), solverParams=iif.SolverParams(N=100))
+    yield "lattice", iif.generateSE2Lattice(rows=4, cols=7, N=100, closeEvery=2)
+    yield "doors", iif.generateCircularDoors(nposes=120, N=100, sightEvery=5)   # dense landmark nodes + multihypo
+    yield "mixture", iif.generateMixtureChain(nvars=30, N=100, priorEvery=7)
+    fg = iif.initfg(iif.SolverParams(N=100, gibbsIters=4, limitfixeddown=True))
+    for v in ("x1", "x2", "x3"):
+        iif.addVariable(fg, v, E2)
+    iif.addFactor(fg, ["x1"], iif.Prior(iif.MvNormal(np.zeros(2), np.diag([0.01, 0.01]))))
+    iif.addFactor(fg, ["x1"], iif.PartialPrior(E2, iif.Normal(2.0, 1.0), (1,)))
+    iif.addFactor(fg, ["x1", "x2"], iif.PartialLinearRelative(E2, iif.Normal(10.0, 1.0), (2,)), nullhypo=0.1)
+    iif.addFactor(fg, ["x2"], iif.PartialPrior(E2, iif.Normal(-20.0, 1.0), (1,)))
+    iif.addFactor(fg, ["x2", "x3"], iif.LinearRelative(iif.MvNormal([1.0, 1.0], [0.1, 0.1])), inflation=3.0)
+    fg.getVariable("x3").ismargin = True
+    yield "partial", fg
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for a in ("x0 x1 x2", "y0 y1 y2"):
+        vs = a.split()
+        for v in vs:
+            iif.addVariable(fg, v, iif.ContinuousScalar)
+        iif.addFactor(fg, [vs[0]], iif.Prior(iif.Normal(0, 1)))
+        iif.addFactor(fg, [vs[0], vs[1]], iif.LinearRelative(iif.Normal(1, 1)))
+        iif.addFactor(fg, [vs[1], vs[2]], iif.LinearRelative(iif.Normal(1, 1)))
+    yield "forest", fg
+
+
+GRAPHS = dict(graphs())
+
+
+def mark_initialised(fg):
+    for v in fg.ls():
+        fg.getVariable(v).initialized = True
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "nbp_host.h")).read()
+    declared = set(re.findall(r"\b(nbp_(?:graph|tree)_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(native_host.HOST_EXPORTS), declared ^ set(native_host.HOST_EXPORTS)
+    lib = iif.abi.load_library()
+    for n in declared:
+        assert hasattr(lib, n), n
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+def test_nested_dissection_order_is_identical(name):
+    fg = GRAPHS[name]
+    g = native_host.NativeGraph.from_fg(fg)
+    assert g.order_nested_dissection() == iif.nestedDissectionOrder(fg)
+    g.close()
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+@pytest.mark.parametrize("ordering", ["nd", "qr", "natural"])
+def test_tree_potentials_and_schedules_are_identical(name, ordering):
+    fg = GRAPHS[name]
+    order = {"nd": iif.nestedDissectionOrder, "qr": iif.getEliminationOrder, "natural": lambda f: f.ls()}[ordering](fg)
+    tree = iif.buildTreeReset(fg, order)
+    g = native_host.NativeGraph.from_fg(fg)
+    nt = g.build_tree(order)
+    assert nt.n_cliques == len(tree.cliques)
+    from iif_amd import bayestree
+    for k, c in tree.cliques.items():
+        n = nt.clique(k)
+        assert n["frontals"] == c.frontalIDs and n["separators"] == c.separatorIDs, k
+        assert n["parent"] == max(c.parent, 0) and n["children"] == c.children, k
+        assert n["potentials"] == c.potentials, k
+        assert n["up"] == bayestree.upGibbsSchedule(c, fg.solverParams.gibbsIters), k
+        down = bayestree.downSchedule(fg, c, fg.solverParams.gibbsIters) if c.parent >= 0 else []
+        assert n["down"] == down, k
+    nt.close()
+    g.close()
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+@pytest.mark.parametrize("snapshot", [False, True])
+def test_compiled_stages_are_byte_identical(name, snapshot):
+    fg = GRAPHS[name]
+    mark_initialised(fg)
+    order = iif.nestedDissectionOrder(fg)
+    tree = iif.buildTreeReset(fg, order)
+    tp = iif.TreeProgram(fg, tree, seed=12345, snapshot=snapshot)
+    g = native_host.NativeGraph.from_fg(fg)
+    nt = g.build_tree(order)
+    assert nt.plan_slots(snapshot) == tp.n_slots
+    assert nt.main == tp.main and nt.snap == tp.snap
+    nt.schedule(12345)  # host half only: no device needed
+    got = nt.stages()
+    ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc,
+             iif.abi.STAGE_COPIES: iif.abi.CopyDesc}
+    assert len(got) == len(tp.stages)
+    for s, ((kind, raw), (pk, descs)) in enumerate(zip(got, tp.stages)):
+        assert kind == pk, s
+        want = bytes((ctype[pk] * len(descs))(*descs)) if descs else b""
+        assert raw == want, (s, kind, len(descs))
+    st, ps = nt.stats(), tp.stats()
+    for k in ("stages", "proposals", "products", "updates_up", "updates_down", "messages", "slots", "alg_bytes"):
+        assert st[k] == ps[k], k
+    alg = tp.alg_bytes_by_kernel()
+    assert st["alg_bytes_proposal"] == alg["nbp_proposal_kernel"] and st["alg_bytes_product"] == alg["nbp_product_kernel"]
+    nt.close()
+    g.close()
