@@ -46,3 +46,18 @@ def test_native_compiled_solve_equals_python_compiled_solve(hip_backend, name):
     for v in fg.ls():
         np.testing.assert_array_equal(a[v][0], b[v][0])
         np.testing.assert_array_equal(a[v][1], b[v][1])
+
+
+def test_pure_c_example_solves_a_chain(tmp_path):
+    """examples/solve_chain.c: the whole path through include/nbp.h + include/nbp_host.h from plain C
+    (what a non-Python host such as the Julia shim sees)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "incrementalinference.jl_amd", "csrc")
+    exe = str(tmp_path / "solve_chain")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "solve_chain.c"), "-o", exe,
+                           "-L", lib, "-lnbp", f"-Wl,-rpath,{lib}", "-lm"])
+    out = subprocess.run([exe, "120", "100"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "120 variables" in out.stdout and "worst posterior mean error" in out.stdout
