@@ -1,8 +1,8 @@
 /*
  * solve_chain.c -- the whole path through the C ABI alone (include/nbp.h + include/nbp_host.h), no Python:
  * build a ContinuousEuclid(2) odometry chain with periodic priors (the shape of BASELINE config 2),
- * let the native host order it, build the Bayes tree and compile the up+down solve, run it on the GPU
- * and read the posteriors back.
+ * let the native host initialise it (initAll!), order it, build the Bayes tree and compile the up+down
+ * solve, run everything on the GPU and read the posteriors back.
  *
  *   gcc -O2 -Iinclude examples/solve_chain.c -o /tmp/solve_chain \
  *       -Lincrementalinference.jl_amd/csrc -lnbp -Wl,-rpath,$PWD/incrementalinference.jl_amd/csrc -lm
@@ -23,15 +23,6 @@
       return 1;                                                                    \
     }                                                                              \
   } while (0)
-
-static double urand(unsigned long long *s) { /* splitmix64 -> (0,1) */
-  unsigned long long z = (*s += 0x9E3779B97F4A7C15ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return ((double)(z >> 11) + 0.5) / 9007199254740992.0;
-}
-static double nrand(unsigned long long *s) { return sqrt(-2.0 * log(urand(s))) * cos(6.283185307179586 * urand(s)); }
 
 static void gaussian_factor(nbp_factor_spec *f, int kind, int nvars, int a, int b, double mx, double my, double sigma) {
   memset(f, 0, sizeof(*f));
@@ -67,15 +58,17 @@ int main(int argc, char **argv) {
   const int n_slots = nbp_tree_plan_slots(tree, 0);
   CHK(n_slots);
   CHK(nbp_tree_main_slots(tree, mainslot, NULL));
+  /* graph initialisation (initAll!): variable v lives in slot v for both programs */
+  const int init_slots = nbp_graph_init_plan(g, 7);
+  CHK(init_slots);
   nbp_ctx *ctx = NULL;
-  CHK(nbp_ctx_create(0, N, n_slots, NULL, 0, 0, &ctx));
-  /* initial beliefs: dead-reckoned guesses (what graph initialisation would hand over), sigma 0.5 */
-  double *pts = malloc(sizeof(double) * 2 * N), bw[2] = {0.2, 0.2};
-  unsigned long long s = 42;
-  for (int i = 0; i < nvars; i++) {
-    for (int n = 0; n < N; n++) { pts[2 * n] = i + 0.5 * nrand(&s); pts[2 * n + 1] = i + 0.5 * nrand(&s); }
-    CHK(nbp_slot_write(ctx, mainslot[i], NBP_EUCLID2, pts, bw));
-  }
+  CHK(nbp_ctx_create(0, N, n_slots > init_slots ? n_slots : init_slots, NULL, 0, 0, &ctx));
+  double *pts = calloc(2 * (size_t)N, sizeof(double)), bw[2] = {1.0, 1.0};
+  for (int i = 0; i < nvars; i++) CHK(nbp_slot_write(ctx, mainslot[i], NBP_EUCLID2, pts, bw)); /* identity points */
+  nbp_program *init = NULL;
+  CHK(nbp_graph_init_compile(g, ctx, &init));
+  CHK(nbp_program_run(init, 0, -1));
+  CHK(nbp_program_destroy(init));
   nbp_program *prog = NULL;
   CHK(nbp_tree_compile(tree, ctx, 2024, &prog));
   CHK(nbp_program_run(prog, 0, -1));

@@ -61,9 +61,24 @@ nbp_status nbp_graph_destroy(nbp_graph *g);
 /* return the new id (>= 0) or a negative status */
 int32_t nbp_graph_add_variable(nbp_graph *g, int32_t manifold);
 int32_t nbp_graph_add_factor(nbp_graph *g, const nbp_factor_spec *spec);
+/* A new variable is NOT initialised (like addVariable!): run the graph-initialisation program below, or
+ * write a belief yourself (nbp_slot_write) and say so here. */
 nbp_status nbp_graph_set_variable_flags(nbp_graph *g, int32_t var, int32_t initialized, int32_t ismargin);
 int32_t nbp_graph_num_variables(const nbp_graph *g);
 int32_t nbp_graph_num_factors(const nbp_graph *g);
+
+/* Graph initialisation -- initAll! / doautoinit! (services/GraphInit.jl:61-199): every uninitialised
+ * variable gets a belief from the factors whose other variables are initialised (multihypo factors: at
+ * least one hypothesis available, #427), in add order; independent initialisations share a stage.
+ * nbp_graph_init_plan builds the stage descriptors and returns the slots the context needs; belief of
+ * variable v lives in slot v.  nbp_graph_init_compile makes the resident program (run it once) and marks
+ * the planned variables initialised in the graph. */
+int32_t nbp_graph_init_plan(nbp_graph *g, uint64_t seed);
+int32_t nbp_graph_init_num_variables(const nbp_graph *g);
+nbp_status nbp_graph_init_variables(const nbp_graph *g, int32_t *vars_out);
+int32_t nbp_graph_init_num_stages(const nbp_graph *g);
+nbp_status nbp_graph_init_stage(const nbp_graph *g, int32_t s, int32_t *kind, int32_t *n, void *descs_out, int64_t cap_bytes);
+nbp_status nbp_graph_init_compile(nbp_graph *g, nbp_ctx *ctx, nbp_program **out);
 
 /* Nested-dissection elimination order (recursive bisection on BFS level structures; dense nodes such as
  * landmarks seen from many poses are set aside and eliminated last, as AMD / COLAMD do with dense rows).

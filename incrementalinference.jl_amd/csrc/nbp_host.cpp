@@ -65,6 +65,10 @@ struct nbp_graph {
   std::vector<HVar> vars;
   std::vector<HFac> facs;
   std::vector<std::vector<int>> vfacs;  // variable -> factor ids, insertion order
+  // graph initialisation (initAll!): last plan
+  std::vector<int> init_vars;
+  std::vector<Stage> init_stages;
+  int init_slots = 0;
 };
 
 struct nbp_tree {
@@ -413,10 +417,11 @@ void schedules(nbp_tree *t) {
 struct Entry { bool msg; int ref; };  // factor id, or child clique id of a message
 
 void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, int msg_slot, int target, const std::map<int, int> *Bc,
-                   const std::vector<int> *main_slot, const std::set<int> *inclq, int out_slot, uint64_t seed, double nullSurplus) {
+                   const std::vector<int> *main_slot, const std::set<int> *inclq, int out_slot, uint64_t seed, double nullSurplus,
+                   const std::vector<char> *isinit = nullptr) {
   memset(&d, 0, sizeof(d));
   const nbp_solver_params &sp = g->sp;
-  auto slot_of = [&](int v) { return (inclq == nullptr || inclq->count(v)) ? Bc->at(v) : (*main_slot)[v]; };
+  auto slot_of = [&](int v) { return Bc == nullptr ? v : ((inclq == nullptr || inclq->count(v)) ? Bc->at(v) : (*main_slot)[v]); };
   d.manifold = g->vars[target].manifold;
   d.out_slot = out_slot;
   d.inflate_cycles = sp.inflate_cycles;
@@ -450,7 +455,7 @@ void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, in
   if (s.has_multihypo) {
     int flags = 1 | 0x80;
     for (int i = 0; i < s.nvars; i++)
-      if (g->vars[s.vars[i]].initialized) flags |= 1 << (8 + i);
+      if (isinit ? (*isinit)[s.vars[i]] != 0 : g->vars[s.vars[i]].initialized) flags |= 1 << (8 + i);
     d.has_multihypo = flags;
     for (int i = 0; i < s.nvars; i++) d.multihypo[i] = s.multihypo[i];
   }
@@ -532,7 +537,7 @@ nbp_status nbp_graph_destroy(nbp_graph *g) {
 int32_t nbp_graph_add_variable(nbp_graph *g, int32_t manifold) {
   if (!g) return hfail(NBP_ERR_ARG, "null argument");
   if (manifold < NBP_EUCLID1 || manifold > NBP_SE2) return hfail(NBP_ERR_ARG, "unknown manifold");
-  g->vars.push_back({manifold, true, false});
+  g->vars.push_back({manifold, false, false});  // like addVariable!: not initialised until a belief is set
   g->vfacs.emplace_back();
   return (int32_t)g->vars.size() - 1;
 }
@@ -827,6 +832,139 @@ nbp_status nbp_tree_get_stats(const nbp_tree *t, nbp_tree_stats *out) {
   *out = t->st;
   return NBP_OK;
 }
+// ---- graph initialisation: initAll! / doautoinit! (GraphInit.jl:61-199), solver.initStages ---------
+int32_t nbp_graph_init_plan(nbp_graph *g, uint64_t seed) {
+  if (!g) return hfail(NBP_ERR_ARG, "null argument");
+  const int V = (int)g->vars.size();
+  std::vector<char> init(V);
+  for (int v = 0; v < V; v++) init[v] = g->vars[v].initialized;
+  struct PlanItem { int sym; std::vector<int> use; std::vector<char> state; };
+  std::vector<PlanItem> plan;
+  for (int sweep = 0; sweep < 10; sweep++) {
+    bool repeat = false;
+    for (int sym = 0; sym < V; sym++) {
+      if (init[sym]) continue;
+      std::vector<int> use;
+      for (int fl : g->vfacs[sym]) {
+        const nbp_factor_spec &f = g->facs[fl].s;
+        bool ok = true;  // priors and general n-ary cases: everything else initialised (GraphInit.jl:90)
+        for (int k = 0; k < f.nvars; k++)
+          if (f.vars[k] != sym && !init[f.vars[k]]) ok = false;
+        if (!ok && f.has_multihypo) {  // at least one hypothesis available (:94-105, FactorGraph.jl:772-784)
+          bool sym_cer = false, sym_unc = false, any_unc = false, all_cer = true;
+          for (int k = 0; k < f.nvars; k++) {
+            const bool cer = f.multihypo[k] == 0.0, unc = f.multihypo[k] > 0.0;
+            if (f.vars[k] == sym) { sym_cer |= cer; sym_unc |= unc; }
+            if (unc && init[f.vars[k]]) any_unc = true;
+            if (cer && !init[f.vars[k]]) all_cer = false;
+          }
+          ok = (sym_cer && any_unc) || (sym_unc && all_cer);
+        }
+        if (ok) use.push_back(fl);
+      }
+      if (!use.empty()) {
+        plan.push_back({sym, use, init});
+        init[sym] = 1;
+      } else
+        repeat = true;
+    }
+    if (!repeat) break;
+  }
+  g->init_vars.clear();
+  g->init_stages.clear();
+  g->init_slots = V;
+  if (plan.empty()) return V;
+  size_t maxF = 0;
+  for (auto &p : plan) maxF = std::max(maxF, p.use.size());
+  if (maxF > NBP_MAXF) return hfail(NBP_ERR_RANGE, "graph init: a product exceeds NBP_MAXF densities");
+  std::vector<std::vector<const PlanItem *>> groups(1);
+  std::set<int> produced;
+  for (auto &p : plan) {
+    bool dep = false;
+    for (int fl : p.use)
+      for (int k = 0; k < g->facs[fl].s.nvars; k++)
+        if (g->facs[fl].s.vars[k] != p.sym && produced.count(g->facs[fl].s.vars[k])) dep = true;
+    if (dep) {
+      groups.emplace_back();
+      produced.clear();
+    }
+    groups.back().push_back(&p);
+    produced.insert(p.sym);
+  }
+  size_t width = 0;
+  for (auto &gr : groups) width = std::max(width, gr.size());
+  nbp_tree tmp;  // only for add_stage's container
+  tmp.g = g;
+  for (auto &gr : groups) {
+    std::vector<nbp_proposal_desc> props;
+    std::vector<nbp_product_desc> prods;
+    for (size_t ci = 0; ci < gr.size(); ci++) {
+      const PlanItem &p = *gr[ci];
+      bool anymh = false, anypartial = false;
+      for (int fl : p.use) anymh |= g->facs[fl].s.has_multihypo != 0;
+      const int base = V + (int)(ci * maxF);
+      nbp_product_desc q;
+      memset(&q, 0, sizeof(q));
+      for (size_t i = 0; i < p.use.size(); i++) {
+        const HFac &fac = g->facs[p.use[i]];
+        const double ns = (anymh && !fac.is_prior && !fac.s.has_multihypo) ? g->sp.null_surplus_add : 0.0;
+        nbp_proposal_desc d;
+        fill_proposal(g, d, &fac, -1, p.sym, nullptr, nullptr, nullptr, base + (int)i, op_seed(seed, PASS_INIT, p.sym, 0, i + 1), ns, &p.state);
+        props.push_back(d);
+        q.in_slot[i] = base + (int)i;
+        q.in_partial[i] = (uint8_t)fac.s.partial_mask;
+        anypartial |= fac.s.partial_mask != 0;
+      }
+      q.manifold = g->vars[p.sym].manifold;
+      q.nfactors = (int)p.use.size();
+      q.niter = g->sp.product_niter;
+      q.out_slot = p.sym;
+      q.labels_out = -1;
+      q.old_slot = anypartial ? p.sym : -1;
+      if (!anypartial) memset(q.in_partial, 0, sizeof(q.in_partial));
+      q.seed = op_seed(seed, PASS_INIT, p.sym, 0, PRODUCT_ID);
+      prods.push_back(q);
+    }
+    add_stage(&tmp, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
+    add_stage(&tmp, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+  }
+  g->init_stages = std::move(tmp.stages);
+  for (auto &p : plan) g->init_vars.push_back(p.sym);
+  g->init_slots = V + (int)(width * maxF);
+  return g->init_slots;
+}
+
+int32_t nbp_graph_init_num_variables(const nbp_graph *g) { return g ? (int32_t)g->init_vars.size() : 0; }
+nbp_status nbp_graph_init_variables(const nbp_graph *g, int32_t *out) {
+  if (!g || !out) return hfail(NBP_ERR_ARG, "null argument");
+  for (size_t i = 0; i < g->init_vars.size(); i++) out[i] = g->init_vars[i];
+  return NBP_OK;
+}
+int32_t nbp_graph_init_num_stages(const nbp_graph *g) { return g ? (int32_t)g->init_stages.size() : 0; }
+nbp_status nbp_graph_init_stage(const nbp_graph *g, int32_t s, int32_t *kind, int32_t *n, void *out, int64_t cap) {
+  if (!g || s < 0 || s >= (int)g->init_stages.size()) return hfail(NBP_ERR_RANGE, "stage index");
+  const Stage &st = g->init_stages[s];
+  if (kind) *kind = st.kind;
+  if (n) *n = st.n;
+  if (out && cap > 0) memcpy(out, st.bytes.data(), std::min<size_t>((size_t)cap, st.bytes.size()));
+  return NBP_OK;
+}
+nbp_status nbp_graph_init_compile(nbp_graph *g, nbp_ctx *ctx, nbp_program **out) {
+  if (!g || !ctx || !out) return hfail(NBP_ERR_ARG, "null argument");
+  nbp_program *p = nullptr;
+  nbp_status rc = nbp_program_create(ctx, &p);
+  if (rc) return rc;
+  for (const Stage &s : g->init_stages) {
+    rc = nbp_program_add_stage(p, s.kind, s.bytes.empty() ? nullptr : s.bytes.data(), s.n);
+    if (rc) { nbp_program_destroy(p); return rc; }
+  }
+  rc = nbp_program_finalize(p);
+  if (rc) { nbp_program_destroy(p); return rc; }
+  for (int v : g->init_vars) g->vars[v].initialized = true;  // what the program does when it is run
+  *out = p;
+  return NBP_OK;
+}
+
 int32_t nbp_tree_num_stages(const nbp_tree *t) { return t ? (int32_t)t->stages.size() : 0; }
 nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *out, int64_t cap) {
   if (!t || s < 0 || s >= (int)t->stages.size()) return hfail(NBP_ERR_RANGE, "stage index");

@@ -33,7 +33,8 @@ class TreeStats(C.Structure):
 
 HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable", "nbp_graph_add_factor",
                 "nbp_graph_set_variable_flags", "nbp_graph_num_variables", "nbp_graph_num_factors",
-                "nbp_graph_order_nested_dissection", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
+                "nbp_graph_order_nested_dissection", "nbp_graph_init_plan", "nbp_graph_init_num_variables", "nbp_graph_init_variables",
+                "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
                 "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage"]
 
@@ -53,6 +54,12 @@ def _lib():
         lib.nbp_graph_num_variables.argtypes = [vp]
         lib.nbp_graph_num_factors.argtypes = [vp]
         lib.nbp_graph_order_nested_dissection.argtypes = [vp, ip]
+        lib.nbp_graph_init_plan.argtypes = [vp, C.c_uint64]
+        lib.nbp_graph_init_num_variables.argtypes = [vp]
+        lib.nbp_graph_init_variables.argtypes = [vp, ip]
+        lib.nbp_graph_init_num_stages.argtypes = [vp]
+        lib.nbp_graph_init_stage.argtypes = [vp, i32, ip, ip, vp, i64]
+        lib.nbp_graph_init_compile.argtypes = [vp, vp, C.POINTER(vp)]
         lib.nbp_tree_build.argtypes = [vp, ip, i32, C.POINTER(vp)]
         lib.nbp_tree_destroy.argtypes = [vp]
         lib.nbp_tree_num_cliques.argtypes = [vp]
@@ -75,6 +82,20 @@ def _check(rc):
     if rc < 0:
         raise RuntimeError(f"libnbp host status {rc}: {abi.load_library().nbp_last_error().decode()}")
     return rc
+
+
+def _stages_of(getter, count):
+    esz = {abi.STAGE_PROPOSALS: C.sizeof(abi.ProposalDesc), abi.STAGE_PRODUCTS: C.sizeof(abi.ProductDesc),
+           abi.STAGE_COPIES: C.sizeof(abi.CopyDesc)}
+    out = []
+    for s in range(count):
+        kind, n = i32(), i32()
+        _check(getter(s, C.byref(kind), C.byref(n), None, 0))
+        nb = n.value * esz[kind.value]
+        buf = (C.c_char * max(1, nb))()
+        _check(getter(s, C.byref(kind), C.byref(n), buf, nb))
+        out.append((kind.value, bytes(buf[:nb])))
+    return out
 
 
 class NativeGraph:
@@ -120,6 +141,26 @@ class NativeGraph:
             g.flabels.append(fl)
         g.index = idx
         return g
+
+    def init_plan(self, seed):
+        """-> (slots needed, [labels initialised by the plan])"""
+        n = _check(self.lib.nbp_graph_init_plan(self._g, C.c_uint64(seed)))
+        k = self.lib.nbp_graph_init_num_variables(self._g)
+        out = (i32 * max(1, k))()
+        _check(self.lib.nbp_graph_init_variables(self._g, out))
+        return n, [self.labels[out[i]] for i in range(k)]
+
+    def init_stages(self):
+        return _stages_of(lambda s, kind, n, buf, cap: self.lib.nbp_graph_init_stage(self._g, s, kind, n, buf, cap),
+                          self.lib.nbp_graph_init_num_stages(self._g))
+
+    def init_compile(self, backend):
+        from .backend import HipProgram
+        p = C.c_void_p()
+        _check(self.lib.nbp_graph_init_compile(self._g, backend._ctx, C.byref(p)))
+        prog = HipProgram.__new__(HipProgram)
+        prog.backend, prog._p, prog.n_stages = backend, p, self.lib.nbp_graph_init_num_stages(self._g)
+        return prog
 
     def order_nested_dissection(self):
         out = (i32 * len(self.labels))()
@@ -193,16 +234,8 @@ class NativeTree:
 
     def stages(self):
         """[(kind, bytes)] of the last compile (tests compare them with solver.TreeProgram's)"""
-        out = []
-        esz = {abi.STAGE_PROPOSALS: C.sizeof(abi.ProposalDesc), abi.STAGE_PRODUCTS: C.sizeof(abi.ProductDesc),
-               abi.STAGE_COPIES: C.sizeof(abi.CopyDesc)}
-        for s in range(self.lib.nbp_tree_num_stages(self._t)):
-            kind, n = i32(), i32()
-            _check(self.lib.nbp_tree_stage(self._t, s, C.byref(kind), C.byref(n), None, 0))
-            buf = (C.c_char * max(1, n.value * esz[kind.value]))()
-            _check(self.lib.nbp_tree_stage(self._t, s, C.byref(kind), C.byref(n), buf, n.value * esz[kind.value]))
-            out.append((kind.value, bytes(buf[: n.value * esz[kind.value]])))
-        return out
+        return _stages_of(lambda s, kind, n, buf, cap: self.lib.nbp_tree_stage(self._t, s, kind, n, buf, cap),
+                          self.lib.nbp_tree_num_stages(self._t))
 
     def close(self):
         if self._t:

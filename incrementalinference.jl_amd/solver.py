@@ -412,18 +412,16 @@ def _init_plan(fg):
     return plan, init
 
 
-def initAll(fg, backend=None, seed=0):
-    """initAll!(dfg): initialise every variable from already-initialised neighbours in add-history
-    order; each init is a propagateBelief over the usable factors.  Independent inits are batched
-    into one launch."""
+def initStages(fg, seed=0):
+    """The stage list of initAll!: (plan, slot map, n_slots, stages).  Independent inits are batched into
+    one PROPOSALS + PRODUCTS stage pair; slots 0..V-1 are the variables (add order), the rest scratch."""
     sp = fg.solverParams
-    N = sp.N
     plan, _ = _init_plan(fg)
-    if not plan:
-        return 0
     labels = fg.ls()
     slot = {v: i for i, v in enumerate(labels)}
     V = len(labels)
+    if not plan:
+        return plan, slot, V, []
     maxF = max(len(u) for _, u, _ in plan)
     # group consecutive independent inits into stages
     groups, cur, produced = [], [], set()
@@ -439,26 +437,37 @@ def initAll(fg, backend=None, seed=0):
     if cur:
         groups.append(cur)
     width = max(len(g) for g in groups)
-    be, own = _make_backend(backend, N, V + width * maxF)
+    stages = []
+    for gi, g in enumerate(groups):
+        props, prods = [], []
+        for ci, (sym, use, st) in enumerate(g):
+            fcts = [fg.getFactor(f) for f in use]
+            ns = _null_surplus(fg, fcts)
+            base = V + ci * maxF
+            for i, f in enumerate(fcts):
+                props.append(proposal_desc(fg, f, sym, slot.__getitem__, base + i,
+                                           op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i], isinit=st))
+            prods.append(product_desc(fg.getVariable(sym).varType.manifold, [base + i for i in range(len(fcts))],
+                                      slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter,
+                                      partials=_partials(fcts), old_slot=slot[sym]))
+        stages.append((abi.STAGE_PROPOSALS, props))
+        stages.append((abi.STAGE_PRODUCTS, prods))
+    return plan, slot, V + width * maxF, stages
+
+
+def initAll(fg, backend=None, seed=0):
+    """initAll!(dfg): initialise every variable from already-initialised neighbours in add-history
+    order; each init is a propagateBelief over the usable factors.  Independent inits are batched
+    into one launch."""
+    N = fg.solverParams.N
+    plan, slot, n_slots, stages = initStages(fg, seed)
+    if not plan:
+        return 0
+    be, own = _make_backend(backend, N, n_slots)
     try:
-        for v in labels:
+        for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
-        stages = []
-        for gi, g in enumerate(groups):
-            props, prods = [], []
-            for ci, (sym, use, st) in enumerate(g):
-                fcts = [fg.getFactor(f) for f in use]
-                ns = _null_surplus(fg, fcts)
-                base = V + ci * maxF
-                for i, f in enumerate(fcts):
-                    props.append(proposal_desc(fg, f, sym, slot.__getitem__, base + i,
-                                               op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i], isinit=st))
-                prods.append(product_desc(fg.getVariable(sym).varType.manifold, [base + i for i in range(len(fcts))],
-                                          slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter,
-                                          partials=_partials(fcts), old_slot=slot[sym]))
-            stages.append((abi.STAGE_PROPOSALS, props))
-            stages.append((abi.STAGE_PRODUCTS, prods))
         prog = be.program(stages)
         prog.run()
         be.synchronize()

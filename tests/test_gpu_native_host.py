@@ -61,3 +61,28 @@ def test_pure_c_example_solves_a_chain(tmp_path):
     out = subprocess.run([exe, "120", "100"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "120 variables" in out.stdout and "worst posterior mean error" in out.stdout
+
+
+def test_native_graph_init_equals_python_init_all(hip_backend):
+    from iif_amd import native_host
+    def fresh():
+        return iif.generateCircularDoors(nposes=30, N=100, sightEvery=5)
+    fa = fresh()
+    iif.initAll(fa, backend=hip_backend, seed=31)
+    fb = fresh()
+    g = native_host.NativeGraph.from_fg(fb)
+    need, planned = g.init_plan(31)
+    be = hip_backend(100, need)
+    for i, v in enumerate(fb.ls()):
+        var = fb.getVariable(v)
+        be.slot_write(i, var.varType.manifold, var.val, var.bw)
+    prog = g.init_compile(be)
+    prog.run()
+    be.synchronize()
+    assert set(planned) == set(fb.ls())
+    for i, v in enumerate(fb.ls()):
+        pts, bw = be.slot_read(i, fb.getVariable(v).varType.manifold)
+        np.testing.assert_array_equal(pts, fa.getVal(v))
+        np.testing.assert_array_equal(bw, fa.getVariable(v).bw)
+    prog.close()
+    be.close()

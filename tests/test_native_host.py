@@ -122,3 +122,23 @@ def test_compiled_stages_are_byte_identical(name, snapshot):
     assert st["alg_bytes_proposal"] == alg["nbp_proposal_kernel"] and st["alg_bytes_product"] == alg["nbp_product_kernel"]
     nt.close()
     g.close()
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+def test_graph_init_plan_and_stages_are_byte_identical(name):
+    """initAll!: same initialisation order, same batching into stages, same descriptors (solver.initStages)"""
+    fg = GRAPHS[name]
+    for v in fg.ls():
+        fg.getVariable(v).initialized = False
+    plan, slot, n_slots, stages = iif.solver.initStages(fg, seed=4242)
+    g = native_host.NativeGraph.from_fg(fg)
+    need, planned = g.init_plan(4242)
+    assert planned == [p[0] for p in plan]
+    assert need == n_slots
+    got = g.init_stages()
+    ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc}
+    assert len(got) == len(stages)
+    for s, ((kind, raw), (pk, descs)) in enumerate(zip(got, stages)):
+        assert kind == pk and raw == bytes((ctype[pk] * len(descs))(*descs)), s
+    g.close()
+    mark_initialised(fg)
