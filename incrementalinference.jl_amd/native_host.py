@@ -80,7 +80,8 @@ def _lib():
 
 def _check(rc):
     if rc < 0:
-        raise RuntimeError(f"libnbp host status {rc}: {abi.load_library().nbp_last_error().decode()}")
+        msg = f"libnbp host status {rc}: {abi.load_library().nbp_last_error().decode()}"
+        raise (ValueError if rc in (-1, -4) else RuntimeError)(msg)  # NBP_ERR_ARG / NBP_ERR_RANGE: bad input
     return rc
 
 

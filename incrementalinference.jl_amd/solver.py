@@ -720,7 +720,7 @@ class TreeProgram:
                 "alg_bytes": self.alg_bytes, "cliques": len(self.cliques)}
 
 
-def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, ordering="qr", return_timing=False):
+def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, ordering="qr", return_timing=False, native=None):
     """solveTree!(dfg; eliminationOrder) -> tree   (SolverAPI.jl:326-493).
     graphinit -> buildTreeReset! -> up pass -> down pass -> posteriors written back to `fg`."""
     sp = fg.solverParams
@@ -731,13 +731,23 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
     if tree is None:
         tree = bayestree.buildTreeReset(fg, eliminationOrder, ordering)
     t2 = time.perf_counter()
-    tp = TreeProgram(fg, tree, seed=seed)
+    # the schedule is compiled by the native host (nbp_host.h) when the solve runs on libnbp, by the
+    # Python mirror otherwise (oracle backend in the tests); both produce the same descriptors
+    use_native = native if native is not None else (backend is None or backend is HipBackend or isinstance(backend, HipBackend)
+                                                    or getattr(backend, "is_hip", False))
+    if use_native:
+        from . import native_host
+        ng = native_host.NativeGraph.from_fg(fg)
+        tp = ng.build_tree(tree.eliminationOrder)
+        tp.plan_slots(False)
+    else:
+        tp = TreeProgram(fg, tree, seed=seed)
     be, own = _make_backend(backend, sp.N, tp.n_slots)
     try:
         for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
-        prog = be.program(tp.stages)
+        prog = tp.compile(be, seed) if use_native else be.program(tp.stages)
         t3 = time.perf_counter()
         prog.run()
         be.synchronize()
@@ -752,5 +762,7 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
         if own:
             be.close()
     if return_timing:
-        return tree, {"init_s": t1 - t0, "tree_s": t2 - t1, "compile_s": t3 - t2, "solve_s": t4 - t3, **tp.stats()}
+        st = tp.stats()
+        st.setdefault("cliques", len(tree.cliques))
+        return tree, {"init_s": t1 - t0, "tree_s": t2 - t1, "compile_s": t3 - t2, "solve_s": t4 - t3, **st}
     return tree

@@ -36,4 +36,5 @@ def hip_backend(iif):
     def make(N, n_slots, side_ints=0):
         return iif.HipBackend(N, n_slots, side_ints=side_ints)
 
+    make.is_hip = True  # solveTree compiles the schedule with the native host for libnbp backends
     return make
