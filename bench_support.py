@@ -34,7 +34,7 @@ class RankSolve:
             t4 = time.perf_counter()
             tp = iif.TreeProgram(fg, tree, seed=1, snapshot=True)
             self.be = mk(self.N, tp.n_slots)
-            self.prog = self.be.program(tp.stages)
+            self.prog = self.be.program(tp.stages, lazy_bandwidth=True)
             t5 = time.perf_counter()
             self.main, snap, st = tp.main, tp.snap, tp.stats()
             self.global_messages = tp.n_messages

@@ -211,6 +211,15 @@ typedef struct nbp_program nbp_program;
 enum nbp_stage_kind { NBP_STAGE_PROPOSALS = 1, NBP_STAGE_PRODUCTS = 2, NBP_STAGE_COPIES = 3 };
 nbp_status nbp_program_create(nbp_ctx *ctx, nbp_program **out);
 nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *descs, int32_t n);
+/* Program options, to be set before nbp_program_finalize.
+ * NBP_OPT_LAZY_BANDWIDTH (default 0): skip the bandwidth fit of a product output that a later stage
+ * overwrites before anything reads its bandwidth (readers: a MsgPrior proposal sampling the slot, a
+ * product taking it as input, slot copies; an EMPTY copy stage counts as "everything is read").  The
+ * reference fits a bandwidth on every setBelief! (FactorGraph.jl:250-263), but inside a clique's Gibbs
+ * sweeps only the last one of each variable is ever looked at, so no result changes.  With the option
+ * on, the bandwidth of such an intermediate belief is undefined between stages. */
+enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1 };
+nbp_status nbp_program_set_option(nbp_program *prog, int32_t option, int32_t value);
 nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
 nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);
 nbp_status nbp_program_reseed(nbp_program *prog, uint64_t salt); /* xor-mix all op seeds on device */

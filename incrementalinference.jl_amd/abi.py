@@ -13,6 +13,7 @@ EUCLID1, EUCLID2, EUCLID3, CIRCULAR, SE2 = 1, 2, 3, 4, 5
 # enum nbp_factor
 F_PRIOR, F_MSGPRIOR, F_LINREL, F_CIRCULAR, F_SE2, F_EUCLIDDIST = 1, 2, 3, 4, 5, 6
 STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES = 1, 2, 3
+OPT_LAZY_BANDWIDTH = 1
 
 MANIFOLD_DIM = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 3}
 MANIFOLD_P = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 6}
@@ -83,7 +84,7 @@ EXPORTS = [
     "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr",
     "nbp_slot_write", "nbp_slot_read", "nbp_side_write", "nbp_side_read",
     "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
-    "nbp_program_create", "nbp_program_add_stage", "nbp_program_finalize", "nbp_program_run",
+    "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
     "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_destroy",
     "nbp_timing_enable", "nbp_timing_read", "nbp_diag_read",
 ]
@@ -142,6 +143,7 @@ def load_library(path=None):
     lib.nbp_run_copies.argtypes = [vp, C.POINTER(CopyDesc), i32]
     lib.nbp_program_create.argtypes = [vp, C.POINTER(vp)]
     lib.nbp_program_add_stage.argtypes = [vp, i32, vp, i32]
+    lib.nbp_program_set_option.argtypes = [vp, i32, i32]
     lib.nbp_program_finalize.argtypes = [vp]
     lib.nbp_program_run.argtypes = [vp, i32, i32]
     lib.nbp_program_reseed.argtypes = [vp, C.c_uint64]

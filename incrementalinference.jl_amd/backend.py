@@ -151,8 +151,8 @@ class HipBackend:
         self._check(self.lib.nbp_synchronize(self._ctx))
 
     # ---- resident programs (clique seam) -----------------------------------------------------
-    def program(self, stages):
-        return HipProgram(self, stages)
+    def program(self, stages, lazy_bandwidth=False):
+        return HipProgram(self, stages, lazy_bandwidth)
 
     def timing_enable(self, on=True):
         self._check(self.lib.nbp_timing_enable(self._ctx, int(on)))
@@ -185,10 +185,12 @@ _STAGE_CTYPE = {abi.STAGE_PROPOSALS: abi.ProposalDesc, abi.STAGE_PRODUCTS: abi.P
 class HipProgram:
     """A device-resident schedule: list of (kind, descriptor-array) stages uploaded once."""
 
-    def __init__(self, backend, stages):
+    def __init__(self, backend, stages, lazy_bandwidth=False):
         self.backend, lib = backend, backend.lib
         self._p = C.c_void_p()
         backend._check(lib.nbp_program_create(backend._ctx, C.byref(self._p)))
+        if lazy_bandwidth:  # whole-solve programs: intermediate bandwidths nobody reads are not fitted
+            backend._check(lib.nbp_program_set_option(self._p, abi.OPT_LAZY_BANDWIDTH, 1))
         for kind, descs in stages:
             arr, n = _as_array(descs, _STAGE_CTYPE[kind])
             backend._check(lib.nbp_program_add_stage(self._p, kind, C.cast(arr, C.c_void_p), n))

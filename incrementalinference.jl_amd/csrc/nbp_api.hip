@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include <unordered_map>
+
 #include "nbp_kernels.h"
 
 static thread_local std::string g_err;
@@ -737,6 +739,7 @@ struct nbp_program {
   std::vector<char> blob;
   char *dev = nullptr;
   bool finalized = false;
+  bool lazy_bw = false;  // NBP_OPT_LAZY_BANDWIDTH
   int n_user_stages = 0;
   size_t seed_off = 0;  // table of the blob offsets of every descriptor's seed field (one reseed launch)
   int n_seeds = 0;
@@ -776,6 +779,52 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
   return NBP_OK;
 }
 
+nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value) {
+  if (!p) return fail(NBP_ERR_ARG, "null argument");
+  if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
+  if (option == NBP_OPT_LAZY_BANDWIDTH) { p->lazy_bw = value != 0; return NBP_OK; }
+  return fail(NBP_ERR_ARG, "unknown program option");
+}
+
+// Liveness of product rebandwidths (NBP_OPT_LAZY_BANDWIDTH): the bandwidth of a product's output is read
+// only by a MsgPrior proposal sampling that slot, by a product taking it as input, and by slot copies
+// (which carry it along).  dead[s][i] = the output of product i of stage s is overwritten by a later
+// product / copy / proposal before any of those happens, so its fit can be skipped without changing any
+// result.  An EMPTY copy stage is a barrier ("everything may be read now": slots leave the device).
+static std::vector<std::vector<char>> product_liveness(const nbp_program *p) {
+  std::vector<std::vector<char>> dead(p->n_user_stages);
+  std::unordered_map<int32_t, std::pair<int, int>> open;  // slot -> (stage, index) of the unresolved product
+  auto kill = [&](int32_t slot) {
+    auto it = open.find(slot);
+    if (it != open.end()) { dead[it->second.first][it->second.second] = 1; open.erase(it); }
+  };
+  for (int s = 0; s < p->n_user_stages; s++) {
+    const nbp_stage &st = p->stages[s];
+    const char *d = p->blob.data() + st.offset;
+    if (st.kind == NBP_STAGE_PROPOSALS) {
+      const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
+      for (int i = 0; i < st.n; i++)
+        if (pd[i].factor_kind == NBP_F_MSGPRIOR) open.erase(pd[i].var_slot[1]);  // read: live
+      for (int i = 0; i < st.n; i++) kill(pd[i].out_slot);                        // overwritten
+    } else if (st.kind == NBP_STAGE_COPIES) {
+      const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
+      if (st.n == 0) open.clear();  // barrier: all live
+      for (int i = 0; i < st.n; i++) open.erase(cd[i].src_slot);
+      for (int i = 0; i < st.n; i++) kill(cd[i].dst_slot);
+    } else if (st.kind == NBP_STAGE_PRODUCTS) {
+      const nbp_product_desc *qd = (const nbp_product_desc *)d;
+      dead[s].assign(st.n, 0);
+      for (int i = 0; i < st.n; i++)
+        for (int j = 0; j < qd[i].nfactors; j++) open.erase(qd[i].in_slot[j]);   // input KDE: bandwidth read
+      for (int i = 0; i < st.n; i++) {
+        kill(qd[i].out_slot);
+        if (qd[i].nfactors > 1) open[qd[i].out_slot] = {s, i};
+      }
+    }
+  }
+  return dead;  // whatever is still open is flushed at the end of the program: live
+}
+
 nbp_status nbp_program_finalize(nbp_program *p) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
   if (p->finalized) return NBP_OK;
@@ -785,7 +834,11 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   p->stages.back().kind = 0;
   std::vector<int32_t> pend_s, pend_m;
   int maxprod = 0;
+  std::vector<std::vector<char>> dead;
+  if (p->lazy_bw) dead = product_liveness(p);
+  int sidx = -1;
   for (nbp_stage &st : p->stages) {
+    sidx++;
     const char *d = p->blob.data() + st.offset;
     st.ent_s = pend_s;
     st.ent_m = pend_m;
@@ -800,7 +853,12 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       jobs_of_proposals((const nbp_proposal_desc *)d, st.n, pend_s, pend_m);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       pend_s.clear(); pend_m.clear();  // the entry fits run inside this stage's prep launch
-      jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
+      if (p->lazy_bw) {
+        const nbp_product_desc *qd = (const nbp_product_desc *)d;
+        for (int i = 0; i < st.n; i++)
+          if (qd[i].nfactors > 1 && !dead[sidx][i]) { pend_s.push_back(qd[i].out_slot); pend_m.push_back(qd[i].manifold); }
+      } else
+        jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
       if (st.n > maxprod) maxprod = st.n;
     } else {  // copies (move bandwidths too) and the trailing pseudo stage
       st.flush_before = true;

@@ -817,6 +817,9 @@ nbp_status nbp_tree_compile(nbp_tree *t, nbp_ctx *ctx, uint64_t seed, nbp_progra
   nbp_program *p = nullptr;
   rc = nbp_program_create(ctx, &p);
   if (rc) return rc;
+  // a whole solve: the bandwidth of a belief that the same program overwrites before reading is dead
+  rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
+  if (rc) { nbp_program_destroy(p); return rc; }
   for (const Stage &s : t->stages) {
     rc = nbp_program_add_stage(p, s.kind, s.bytes.empty() ? nullptr : s.bytes.data(), s.n);
     if (rc) { nbp_program_destroy(p); return rc; }

@@ -96,7 +96,7 @@ class ShardedRunner:
         self.slot_tensor = slot_tensor
         self.sync_device = sync_device or (lambda: None)
         self.transport, self.group = transport, group
-        self.prog = backend.program(tp.stages)
+        self.prog = backend.program(tp.stages, lazy_bandwidth=True)  # exchanges sit behind empty copy stages (barriers)
 
     def run(self, salt=None):
         if salt is not None:

@@ -747,7 +747,7 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
         for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
-        prog = tp.compile(be, seed) if use_native else be.program(tp.stages)
+        prog = tp.compile(be, seed) if use_native else be.program(tp.stages, lazy_bandwidth=True)
         t3 = time.perf_counter()
         prog.run()
         be.synchronize()

@@ -142,8 +142,8 @@ class OracleBackend:
     def synchronize(self):
         pass
 
-    def program(self, stages):
-        return OracleProgram(self, stages)
+    def program(self, stages, lazy_bandwidth=False):
+        return OracleProgram(self, stages)  # the oracle always fits every bandwidth
 
     def diag(self, reset=False):
         d = (C.c_int64 * 5)()
