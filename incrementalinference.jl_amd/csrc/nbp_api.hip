@@ -791,38 +791,60 @@ nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value)
 // (which carry it along).  dead[s][i] = the output of product i of stage s is overwritten by a later
 // product / copy / proposal before any of those happens, so its fit can be skipped without changing any
 // result.  An EMPTY copy stage is a barrier ("everything may be read now": slots leave the device).
-static std::vector<std::vector<char>> product_liveness(const nbp_program *p) {
-  std::vector<std::vector<char>> dead(p->n_user_stages);
-  std::unordered_map<int32_t, std::pair<int, int>> open;  // slot -> (stage, index) of the unresolved product
+struct nbp_liveness {
+  std::vector<std::vector<char>> dead_product, dead_proposal;  // [stage][descriptor]
+};
+static nbp_liveness product_liveness(const nbp_program *p) {
+  nbp_liveness L;
+  L.dead_product.resize(p->n_user_stages);
+  L.dead_proposal.resize(p->n_user_stages);
+  struct Open { int stage, idx, pstage, pidx; };  // pstage >= 0: pass-through of that proposal's KDE
+  std::unordered_map<int32_t, Open> open;                        // slot -> unresolved product output
+  std::unordered_map<int32_t, std::pair<int, int>> last_prop;    // scratch slot -> proposal that wrote it
   auto kill = [&](int32_t slot) {
     auto it = open.find(slot);
-    if (it != open.end()) { dead[it->second.first][it->second.second] = 1; open.erase(it); }
+    if (it == open.end()) return;
+    const Open &o = it->second;
+    if (o.pstage >= 0) L.dead_proposal[o.pstage][o.pidx] = 1;  // a pass-through hands on the proposal's own fit
+    else L.dead_product[o.stage][o.idx] = 1;
+    open.erase(it);
   };
   for (int s = 0; s < p->n_user_stages; s++) {
     const nbp_stage &st = p->stages[s];
     const char *d = p->blob.data() + st.offset;
     if (st.kind == NBP_STAGE_PROPOSALS) {
       const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
+      L.dead_proposal[s].assign(st.n, 0);
       for (int i = 0; i < st.n; i++)
         if (pd[i].factor_kind == NBP_F_MSGPRIOR) open.erase(pd[i].var_slot[1]);  // read: live
-      for (int i = 0; i < st.n; i++) kill(pd[i].out_slot);                        // overwritten
+      for (int i = 0; i < st.n; i++) {
+        kill(pd[i].out_slot);  // overwritten
+        last_prop[pd[i].out_slot] = {s, i};
+      }
     } else if (st.kind == NBP_STAGE_COPIES) {
       const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
       if (st.n == 0) open.clear();  // barrier: all live
       for (int i = 0; i < st.n; i++) open.erase(cd[i].src_slot);
-      for (int i = 0; i < st.n; i++) kill(cd[i].dst_slot);
+      for (int i = 0; i < st.n; i++) { kill(cd[i].dst_slot); last_prop.erase(cd[i].dst_slot); }
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *qd = (const nbp_product_desc *)d;
-      dead[s].assign(st.n, 0);
+      L.dead_product[s].assign(st.n, 0);
       for (int i = 0; i < st.n; i++)
         for (int j = 0; j < qd[i].nfactors; j++) open.erase(qd[i].in_slot[j]);   // input KDE: bandwidth read
       for (int i = 0; i < st.n; i++) {
         kill(qd[i].out_slot);
-        if (qd[i].nfactors > 1) open[qd[i].out_slot] = {s, i};
+        if (qd[i].nfactors > 1) {
+          open[qd[i].out_slot] = {s, i, -1, -1};
+        } else {  // pass-through: the output carries the bandwidth fitted for the proposal
+          auto lp = last_prop.find(qd[i].in_slot[0]);
+          if (lp != last_prop.end() && !((const nbp_proposal_desc *)(p->blob.data() + p->stages[lp->second.first].offset))[lp->second.second].skip_bandwidth)
+            open[qd[i].out_slot] = {s, i, lp->second.first, lp->second.second};
+        }
+        last_prop.erase(qd[i].out_slot);
       }
     }
   }
-  return dead;  // whatever is still open is flushed at the end of the program: live
+  return L;  // whatever is still open is flushed at the end of the program: live
 }
 
 nbp_status nbp_program_finalize(nbp_program *p) {
@@ -834,8 +856,8 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   p->stages.back().kind = 0;
   std::vector<int32_t> pend_s, pend_m;
   int maxprod = 0;
-  std::vector<std::vector<char>> dead;
-  if (p->lazy_bw) dead = product_liveness(p);
+  nbp_liveness live;
+  if (p->lazy_bw) live = product_liveness(p);
   int sidx = -1;
   for (nbp_stage &st : p->stages) {
     sidx++;
@@ -850,13 +872,18 @@ nbp_status nbp_program_finalize(nbp_program *p) {
         for (int32_t ps : pend_s) st.flush_before |= (ps == pd.var_slot[1]);
       }
       if (st.flush_before) { pend_s.clear(); pend_m.clear(); }
-      jobs_of_proposals((const nbp_proposal_desc *)d, st.n, pend_s, pend_m);
+      if (p->lazy_bw) {
+        const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
+        for (int i = 0; i < st.n; i++)
+          if (!pd[i].skip_bandwidth && !live.dead_proposal[sidx][i]) { pend_s.push_back(pd[i].out_slot); pend_m.push_back(pd[i].manifold); }
+      } else
+        jobs_of_proposals((const nbp_proposal_desc *)d, st.n, pend_s, pend_m);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       pend_s.clear(); pend_m.clear();  // the entry fits run inside this stage's prep launch
       if (p->lazy_bw) {
         const nbp_product_desc *qd = (const nbp_product_desc *)d;
         for (int i = 0; i < st.n; i++)
-          if (qd[i].nfactors > 1 && !dead[sidx][i]) { pend_s.push_back(qd[i].out_slot); pend_m.push_back(qd[i].manifold); }
+          if (qd[i].nfactors > 1 && !live.dead_product[sidx][i]) { pend_s.push_back(qd[i].out_slot); pend_m.push_back(qd[i].manifold); }
       } else
         jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
       if (st.n > maxprod) maxprod = st.n;
