@@ -184,6 +184,10 @@ def main():
                                "sample": f"{a.cpu_sample_vars}-variable chain of the same shape, N={N}, one full "
                                          f"up+down solve ({m} messages) in {secs:.1f} s, OpenMP over stage ops, "
                                          f"best of 16/32/64 threads on a {ncpu}-thread host"}
+        # also the single-thread rate of the same restatement (smaller sample: it is slow)
+        v1, secs1, m1 = cpu_baseline(iif, max(40, a.cpu_sample_vars // 10), N, 1)
+        out["cpu_baseline"]["single_thread"] = {"value": v1, "unit": "messages/s", "cores": 1,
+                                                "sample": f"{max(40, a.cpu_sample_vars // 10)}-variable chain, {m1} messages in {secs1:.1f} s"}
         out["vs_cpu_baseline"] = value / v
     if world == 1 and dist is None and not a.no_10k and a.nvars != 10000:
         # BASELINE.md config 2': the same chain with 10 000 variables is the graph the north-star target
