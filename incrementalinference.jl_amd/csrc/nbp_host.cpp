@@ -643,6 +643,7 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
     // widest product of this clique: up = potentials touching v + child messages on v; down = all factors of v
     size_t maxf = 1;
     for (int v : c.upsched) {
+      if (g->vars[v].ismargin) continue;  // never updated in the up solve (SolveTree.jl:61)
       size_t k = 0;
       for (int f : c.potentials)
         for (int q = 0; q < g->facs[f].s.nvars; q++)

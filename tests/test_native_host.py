@@ -142,3 +142,74 @@ def test_graph_init_plan_and_stages_are_byte_identical(name):
         assert kind == pk and raw == bytes((ctype[pk] * len(descs))(*descs)), s
     g.close()
     mark_initialised(fg)
+
+
+def random_graph(seed):
+    """random sparse graph: a spanning tree of relative factors plus loop closures, priors, multihypo
+    triples, mixtures and nullhypo, on a random manifold"""
+    r = np.random.default_rng(seed)
+    kind = r.integers(0, 3)
+    vt, rel, pri = [(iif.ContinuousScalar, lambda: iif.LinearRelative(iif.Normal(1.0, 0.1)), lambda: iif.Prior(iif.Normal(0.0, 1.0))),
+                    (iif.ContinuousEuclid(2), lambda: iif.LinearRelative(iif.MvNormal([1.0, 0.0], [0.1, 0.1])),
+                     lambda: iif.Prior(iif.MvNormal(np.zeros(2), [1.0, 1.0]))),
+                    (iif.Circular, lambda: iif.CircularCircular(iif.Normal(0.3, 0.1)), lambda: iif.PriorCircular(iif.Normal(0.0, 0.2)))][kind]
+    n = int(r.integers(4, 40))
+    fg = iif.initfg(iif.SolverParams(N=64, gibbsIters=int(r.integers(1, 5))))
+    for i in range(n):
+        iif.addVariable(fg, f"v{i}", vt)
+    iif.addFactor(fg, ["v0"], pri())
+    for i in range(1, n):
+        j = int(r.integers(max(0, i - 6), i))
+        nh = 0.1 if r.random() < 0.15 else 0.0
+        if kind == 0 and r.random() < 0.15:
+            iif.addFactor(fg, [f"v{j}", f"v{i}"], iif.Mixture(iif.LinearRelative, (iif.Normal(1.0, 0.1), iif.Normal(2.0, 0.5)), [0.7, 0.3]))
+        else:
+            iif.addFactor(fg, [f"v{j}", f"v{i}"], rel(), nullhypo=nh)
+    for _ in range(int(r.integers(0, n // 3 + 1))):  # loop closures / extra priors / multihypo sightings
+        a, b, c = (int(x) for x in r.choice(n, size=3, replace=False))
+        u = r.random()
+        if u < 0.4:
+            iif.addFactor(fg, [f"v{a}", f"v{b}"], rel())
+        elif u < 0.6:
+            iif.addFactor(fg, [f"v{a}"], pri())
+        else:
+            iif.addFactor(fg, [f"v{a}", f"v{b}", f"v{c}"], rel(), multihypo=[1.0, 0.5, 0.5])
+    if r.random() < 0.3:
+        fg.getVariable(f"v{int(r.integers(0, n))}").ismargin = True
+    return fg
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_graphs_native_equals_python(seed):
+    fg = random_graph(seed)
+    g = native_host.NativeGraph.from_fg(fg)
+    # graph initialisation plan from the uninitialised graph
+    plan, slot, n_slots, stages = iif.solver.initStages(fg, seed=seed)
+    need, planned = g.init_plan(seed)
+    assert planned == [p[0] for p in plan] and need == n_slots
+    ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc,
+             iif.abi.STAGE_COPIES: iif.abi.CopyDesc}
+    for (kind, raw), (pk, descs) in zip(g.init_stages(), stages):
+        assert kind == pk and raw == bytes((ctype[pk] * len(descs))(*descs))
+    g.close()
+    # whole-tree program from the initialised graph, two orderings
+    mark_initialised(fg)
+    g = native_host.NativeGraph.from_fg(fg)
+    nd = iif.nestedDissectionOrder(fg)
+    assert g.order_nested_dissection() == nd
+    for order in (nd, iif.getEliminationOrder(fg)):
+        tree = iif.buildTreeReset(fg, order)
+        try:
+            tp = iif.TreeProgram(fg, tree, seed=seed, snapshot=bool(seed % 2))
+        except ValueError:
+            continue  # a product wider than NBP_MAXF: both sides refuse
+        nt = g.build_tree(order)
+        assert nt.plan_slots(bool(seed % 2)) == tp.n_slots
+        nt.schedule(seed)
+        got = nt.stages()
+        assert len(got) == len(tp.stages)
+        for s, ((kind, raw), (pk, descs)) in enumerate(zip(got, tp.stages)):
+            assert kind == pk, s
+            assert raw == (bytes((ctype[pk] * len(descs))(*descs)) if descs else b""), (s, kind)
+        nt.close()
+    g.close()
