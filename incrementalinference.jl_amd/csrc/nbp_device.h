@@ -105,6 +105,12 @@ __device__ __forceinline__ bool is_circ(int m, int d) {
   return (m == NBP_CIRCULAR && d == 0) || (m == NBP_SE2 && d == 2);
 }
 // Manifolds.sym_rem -> [-pi, pi); exact identity on the principal interval
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: wave-uniform
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wrap_pi(double a) {
   if (a >= -NBP_PI && a < NBP_PI) return a;
   double r = fmod(a + NBP_PI, NBP_TWO_PI);
@@ -216,13 +222,23 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
   double mu;
   if (is_circ(manifold, d)) {
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+      // Order-dependent running mean: N dependent steps.  Wave 0 walks it with every lane carrying the
+      // same m; the points and the weights 1/(i+1) are produced 64 at a time by the lanes in parallel
+      // (the divisions are off the chain) and handed to the walk through v_readlane.
+      const int lane = threadIdx.x;
       double m = x[0];
-      for (int i = 1; i < N; i++) {
-        double dl = wrap_pi(x[i] - m);
-        m = wrap_pi(m + dl / (double)(i + 1));
+      for (int base = 0; base < N; base += 64) {
+        const int idx = base + lane;
+        const double xv = idx < N ? x[idx] : 0.0;
+        const double rv = 1.0 / (double)(idx + 1);
+        const int cnt = (N - base < 64) ? N - base : 64;
+        for (int k = (base == 0) ? 1 : 0; k < cnt; k++) {
+          const double xi = readlane_f64(xv, k), ri = readlane_f64(rv, k);
+          m = wrap_pi(m + wrap_pi(xi - m) * ri);
+        }
       }
-      red[32] = m;
+      if (lane == 0) red[32] = m;
     }
     __syncthreads();
     mu = red[32];
@@ -270,6 +286,7 @@ __device__ __forceinline__ double std_basic_spread(const double *x, int stride, 
 template <int KIND, int DN>
 struct objective_t {
   double z[3], other[3];
+  double sn_fixed, cs_fixed;  // SE(2), solve_b: sin/cos of the fixed pose's heading (hoisted out of the search)
   int solve_b;
   unsigned int evals;
   __device__ __forceinline__ double normsq(const double *a, const double *b) const {
@@ -285,7 +302,8 @@ struct objective_t {
       acc = r * r;
     } else if (KIND == NBP_F_SE2) {  // Factors/GenericFunctions.jl:39-44
       double s, c;
-      sincos(a[2], &s, &c);
+      if (solve_b) { s = sn_fixed; c = cs_fixed; }  // a is the fixed pose: its rotation was evaluated once
+      else sincos(a[2], &s, &c);
       double r0 = (a[0] + c * z[0] - s * z[1]) - b[0];
       double r1 = (a[1] + s * z[0] + c * z[1]) - b[1];
       double r2 = wrap_pi((a[2] + z[2]) - b[2]);
@@ -491,6 +509,9 @@ __device__ __forceinline__ void solve_particle_t(int manifold, const double *z, 
   o.evals = 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
+  o.sn_fixed = 0.0;
+  o.cs_fixed = 1.0;
+  if (KIND == NBP_F_SE2 && solve_b) sincos(other[2], &o.sn_fixed, &o.cs_fixed);
   double xc[DN];
 #pragma unroll
   for (int d = 0; d < DN; d++) xc[d] = x[d];
@@ -539,6 +560,9 @@ struct deconv_objective_t {
   __device__ __forceinline__ double operator()(const double (&zz)[ZD]) {
     evals++;
     objective_t<KIND, DN> o;
+    o.solve_b = 0;
+    o.sn_fixed = 0.0;
+    o.cs_fixed = 1.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) o.z[k] = 0.0;
 #pragma unroll

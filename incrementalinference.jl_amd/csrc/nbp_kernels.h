@@ -90,6 +90,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
   double *out = arena + S * d->out_slot;
   unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
 
+  NBP_CTICK_INIT();
   if (n == 0) build_recipe(d, &R);
   {
     const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR) ? 0 : d->sfidx];
@@ -184,8 +185,10 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           if (D > 2) oth[2] = O[2 * N + n];
         }
         for (int c = 0; c < d->inflate_cycles; c++) {  // :184-207
+          NBP_CTICK(30);  // everything before / between cycles
           const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->inflation, red);
           __syncthreads();
+          NBP_CTICK(31);  // spread statistics (workgroup reductions)
           if (myh == hyp) {
             double x[3] = {X[n], X[N + n], X[2 * N + n]};
             add_entropy(M, D, x, n, spread, d->seed, (g * 8 + c) * 2, pmask);
@@ -202,7 +205,9 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
             if (D > 1) X[N + n] = x[1];
             if (D > 2) X[2 * N + n] = x[2];
           }
+          NBP_CTICK(32);  // entropy + per-particle solve (this lane)
           __syncthreads();
+          NBP_CTICK(33);  // waiting for the slowest lane / wave
         }
       } else {  // other-hypothesis (:208-220) / nullhypo (:222-231): entropy only
         const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->spread_nh, red);

@@ -189,7 +189,7 @@ static void mean_geodesic(int manifold, const double *x, int N, double *mu) {
     for (int i = 1; i < N; i++) {
       double dl = x[d * N + i] - m;
       if (is_circ(manifold, d)) dl = orc_wrap(dl);
-      m = m + dl / (double)(i + 1);
+      m = m + dl * (1.0 / (double)(i + 1)); /* weight as a reciprocal, like the kernel's recurrence */
       if (is_circ(manifold, d)) m = orc_wrap(m);
     }
     mu[d] = m;

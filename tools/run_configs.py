@@ -30,7 +30,7 @@ def run(name, fg, check):
     for v in fg.ls():
         var = fg.getVariable(v)
         be.slot_write(tp.snap[v], var.varType.manifold, var.val, var.bw)
-    prog = be.program(tp.stages)
+    prog = be.program(tp.stages, lazy_bandwidth=True)
     t3 = time.perf_counter()
     prog.run()
     be.synchronize()
@@ -42,13 +42,19 @@ def run(name, fg, check):
         be.synchronize()
         times.append(time.perf_counter() - t)
     dt = min(times)
+    be.timing_enable(True)  # per-kernel split (HIP events around every launch: slower than the plain run above)
+    prog.reseed(99)
+    prog.run()
+    be.synchronize()
+    split = ", ".join(f"{k.replace('nbp_', '').replace('_kernel', '')} {ms:.1f} ms / {n}" for k, (ms, n) in be.timing_read().items())
+    be.timing_enable(False)
     for v in fg.ls():
         var = fg.getVariable(v)
         var.val, var.bw = be.slot_read(tp.main[v], var.varType.manifold)
     st = tp.stats()
     print(f"{name}: variables {len(fg.ls())}, cliques {st['cliques']}, updates {st['updates_up'] + st['updates_down']}, "
           f"tree {t1 - t0:.2f} s, init {t2 - t1:.2f} s, compile+upload {t3 - t2:.2f} s | solve {dt * 1e3:.1f} ms, "
-          f"{tp.n_messages / dt:.0f} messages/s | {check(fg)}", flush=True)
+          f"{tp.n_messages / dt:.0f} messages/s | kernels: {split} | {check(fg)}", flush=True)
     prog.close()
     be.close()
 
