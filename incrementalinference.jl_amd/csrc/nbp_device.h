@@ -111,11 +111,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: w
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// mod(a + pi, 2pi) - pi.  Sums and differences of wrapped angles stay within a few pi, where fmod is one
+// exact subtraction (Sterbenz), so that range is done with selects -- same roundings as the fmod form,
+// no divergent slow path inside the dependent chains that call this.  Anything larger (or NaN) takes fmod.
 __device__ __forceinline__ double wrap_pi(double a) {
-  if (a >= -NBP_PI && a < NBP_PI) return a;
-  double r = fmod(a + NBP_PI, NBP_TWO_PI);
-  if (r < 0) r += NBP_TWO_PI;
-  return r - NBP_PI;
+  const double t = a + NBP_PI;
+  double r = (t >= NBP_TWO_PI) ? t - NBP_TWO_PI : t;
+  r = (t < 0.0) ? t + NBP_TWO_PI : r;
+  double res = (a >= -NBP_PI && a < NBP_PI) ? a : r - NBP_PI;
+  if (!(fabs(a) < 2.9 * NBP_PI)) {
+    double q = fmod(t, NBP_TWO_PI);
+    if (q < 0) q += NBP_TWO_PI;
+    res = q - NBP_PI;
+  }
+  return res;
 }
 
 // exp(x) for x <= ~0 in the O(N^2) kernel sums (arguments are -d^2/(2h^2) or weights relative to
@@ -233,9 +242,28 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
         const double xv = idx < N ? x[idx] : 0.0;
         const double rv = 1.0 / (double)(idx + 1);
         const int cnt = (N - base < 64) ? N - base : 64;
-        for (int k = (base == 0) ? 1 : 0; k < cnt; k++) {
+        const int k0 = (base == 0) ? 1 : 0;
+        // Speculate that no step of this block of 64 wraps (the rule, for a belief that does not straddle
+        // +-pi): the chain is then one subtract and one fma per step, the range checks ride beside it.
+        // A block that did wrap is walked again with the wraps in place -- same values either way.
+        const double m0 = m;
+        bool inside = true;
+        for (int k = k0; k < cnt; k++) {
           const double xi = readlane_f64(xv, k), ri = readlane_f64(rv, k);
-          m = wrap_pi(m + wrap_pi(xi - m) * ri);
+          const double dl = xi - m;
+          m = fma(dl, ri, m);
+          inside = inside && (fabs(dl) < NBP_PI) && (fabs(m) < NBP_PI);
+        }
+        if (!inside) {
+          m = m0;
+          for (int k = k0; k < cnt; k++) {
+            const double xi = readlane_f64(xv, k), ri = readlane_f64(rv, k);
+            // every lane carries the same values: the (frequent) no-wrap case is skipped by a scalar branch
+            double dl = xi - m;
+            if (__builtin_amdgcn_ballot_w64(!(fabs(dl) < NBP_PI)) != 0) dl = wrap_pi(dl);
+            m = fma(dl, ri, m);
+            if (__builtin_amdgcn_ballot_w64(!(fabs(m) < NBP_PI)) != 0) m = wrap_pi(m);
+          }
         }
       }
       if (lane == 0) red[32] = m;
