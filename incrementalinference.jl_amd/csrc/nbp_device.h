@@ -677,6 +677,13 @@ __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { if (v < -
 __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
 #endif
 
+// squared geodesic distance on the circle for a difference within (-2pi, 2pi): min(|d|, 2pi - |d|)^2,
+// two VALU operations instead of a wrap (equal to wrap_pi(d)^2 up to the rounding of one subtraction)
+__device__ __forceinline__ double circ_sq(double d) {
+  const double a = fmin(fabs(d), NBP_TWO_PI - fabs(d));
+  return a * a;
+}
+
 template <bool CIRC>
 __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta, int n4, int nt, bool extra, double xi, double c,
                                                 double *accw, const double *tab) {
@@ -691,10 +698,11 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
   nbp_lds_double *ap = (nbp_lds_double *)(accw + pi + ta);
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   for (int k = 0; k < n4; k++, xp += 4, ap += 4) {
-    double d0 = xi - xp[0], d1 = xi - xp[1], d2 = xi - xp[2], d3 = xi - xp[3];
-    if (CIRC) { d0 = wrap_pi(d0); d1 = wrap_pi(d1); d2 = wrap_pi(d2); d3 = wrap_pi(d3); }
-    const double e0 = exp_nonpos(-d0 * d0 * c, tab), e1 = exp_nonpos(-d1 * d1 * c, tab);
-    const double e2 = exp_nonpos(-d2 * d2 * c, tab), e3 = exp_nonpos(-d3 * d3 * c, tab);
+    const double d0 = xi - xp[0], d1 = xi - xp[1], d2 = xi - xp[2], d3 = xi - xp[3];
+    const double q0 = CIRC ? circ_sq(d0) : d0 * d0, q1 = CIRC ? circ_sq(d1) : d1 * d1;
+    const double q2 = CIRC ? circ_sq(d2) : d2 * d2, q3 = CIRC ? circ_sq(d3) : d3 * d3;
+    const double e0 = exp_nonpos(-q0 * c, tab), e1 = exp_nonpos(-q1 * c, tab);
+    const double e2 = exp_nonpos(-q2 * c, tab), e3 = exp_nonpos(-q3 * c, tab);
     s0 += e0;
     s1 += e1;
     s2 += e2;
@@ -705,16 +713,14 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
     lds_add(ap + 3, e3);
   }
   for (int k = 0; k < nt; k++) {
-    double d0 = xi - xp[k];
-    if (CIRC) d0 = wrap_pi(d0);
-    const double e0 = exp_nonpos(-d0 * d0 * c, tab);
+    const double d0 = xi - xp[k];
+    const double e0 = exp_nonpos(-(CIRC ? circ_sq(d0) : d0 * d0) * c, tab);
     s0 += e0;
     lds_add(ap + k, e0);
   }
   if (extra) {
-    double d0 = xi - xp[nt];
-    if (CIRC) d0 = wrap_pi(d0);
-    const double e0 = exp_nonpos(-d0 * d0 * c, tab);
+    const double d0 = xi - xp[nt];
+    const double e0 = exp_nonpos(-(CIRC ? circ_sq(d0) : d0 * d0) * c, tab);
     s1 += e0;
     lds_add(ap + nt, e0);
   }
@@ -761,9 +767,8 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     }
     if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair
       const int j = i + N / 2;
-      double d = x[i] - x[j];
-      if (circ) d = wrap_pi(d);
-      const double e = exp_nonpos(-d * d * inv2h2, tab);
+      const double d = x[i] - x[j];
+      const double e = exp_nonpos(-(circ ? circ_sq(d) : d * d) * inv2h2, tab);
       lds_add((nbp_lds_double *)(part + p * Npad + i), e);
       lds_add((nbp_lds_double *)(acc + w * 2 * N + j), e);
     }

@@ -302,7 +302,12 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   const int P = blockDim.x / Npad;
   double *X = smem, *part = smem + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N, *tab = red + NBP_RED;
   nbp_exp_tab_init(tab);
-  if (n < N) X[n] = X[n + N] = s[k * N + n];
+  // circular coordinates are staged wrapped (the identity for stored beliefs): every pair difference of
+  // the fit is then within (-2pi, 2pi), which is what circ_sqdist relies on
+  if (n < N) {
+    const double v = s[k * N + n];
+    X[n] = X[n + N] = is_circ(M, k) ? wrap_pi(v) : v;
+  }
   __syncthreads();
   double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red, tab, ctr);
   if (n == 0) s[3 * N + k] = h;
