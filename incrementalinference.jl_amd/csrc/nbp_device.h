@@ -677,10 +677,10 @@ __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { if (v < -
 __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
 #endif
 
-// squared geodesic distance on the circle for a difference within (-2pi, 2pi): min(|d|, 2pi - |d|)^2,
+// squared geodesic distance on the circle for a difference within (-3pi, 3pi): min(|d|, ||d| - 2pi|)^2,
 // two VALU operations instead of a wrap (equal to wrap_pi(d)^2 up to the rounding of one subtraction)
 __device__ __forceinline__ double circ_sq(double d) {
-  const double a = fmin(fabs(d), NBP_TWO_PI - fabs(d));
+  const double a = fmin(fabs(d), fabs(fabs(d) - NBP_TWO_PI));
   return a * a;
 }
 

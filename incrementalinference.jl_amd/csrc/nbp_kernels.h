@@ -602,9 +602,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           double t[D], v[D];
 #pragma unroll
           for (int k = 0; k < D; k++) {
-            double tmp = mj[k * N + z] - mn[k];
-            if (circ[k]) tmp = wrap_pi(tmp);
-            t[k] = tmp * tmp;
+            const double tmp = mj[k * N + z] - mn[k];  // node mean in [-2pi, 2pi), mn in [-pi, pi]
+            t[k] = circ[k] ? circ_sq(tmp) : tmp * tmp;
             v[k] = vj[k * N + z] + vn[k];
             if (PARTIAL && !use[k]) { t[k] = 0.0; v[k] = 1.0; }
           }
