@@ -100,6 +100,13 @@ typedef struct nbp_proposal_desc {
                                  only those coordinates (setPointPartial!, EvalFactor.jl:457-538), a
                                  partial relative factor solves and inflates only them (:184-198);
                                  all other coordinates keep the target's current values          */
+  int32_t meas_kde;           /* 0: the measurement model is `comp`.  k+1: the measurement is a kernel density
+                                 estimate held in slot k (points + bandwidth), sampled as random kernel +
+                                 bw*randn: the "differential" relative factors LinearRelative(::MKD) /
+                                 CircularCircular(::MKD) of the useMsgLikelihoods upward messages
+                                 (TreeMessageUtils.jl:279-335, Factors/LinearRelative.jl:32,
+                                 manifolds/services/ManifoldSampling.jl:13-19); relative factors only */
+  int32_t reserved_;
   double multihypo[NBP_MAXV]; /* parsed Categorical p: certain variables carry 0.0
                                  (services/FactorGraph.jl:639-651)                            */
   double nullhypo;            /* max(ccw.nullhypo, nullSurplus)   EvalFactor.jl:352            */
@@ -208,7 +215,16 @@ nbp_status nbp_run_copies(nbp_ctx *ctx, const nbp_copy_desc *descs, int32_t n);
  * ordered list of stages; a stage is a batch of independent proposals, products or copies.
  * Upload once, replay per solve.                                                              */
 typedef struct nbp_program nbp_program;
-enum nbp_stage_kind { NBP_STAGE_PROPOSALS = 1, NBP_STAGE_PRODUCTS = 2, NBP_STAGE_COPIES = 3 };
+enum nbp_stage_kind {
+  NBP_STAGE_PROPOSALS = 1,
+  NBP_STAGE_PRODUCTS = 2,
+  NBP_STAGE_COPIES = 3,
+  NBP_STAGE_DECONV = 4  /* nbp_proposal_desc[]: approxDeconv of a relative factor between var_slot[0] and
+                           var_slot[1] (like nbp_run_deconv); out_slot receives the predicted measurements
+                           AND their fitted bandwidth (manikde!), i.e. a KDE a later proposal can name in
+                           meas_kde -- the child side of the differential messages
+                           (addLikelihoodsDifferentialCHILD!, TreeMessageUtils.jl:279-335) */
+};
 nbp_status nbp_program_create(nbp_ctx *ctx, nbp_program **out);
 nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *descs, int32_t n);
 /* Program options, to be set before nbp_program_finalize.

@@ -302,6 +302,12 @@ static nbp_status check_proposals(nbp_ctx *c, const nbp_proposal_desc *d, int n)
       } else if (p.factor_kind != NBP_F_PRIOR)
         return fail(NBP_ERR_ARG, "proposal: partial_mask is supported for Prior and LinearRelative factors");
     }
+    if (p.meas_kde) {
+      if (p.meas_kde < 0 || p.meas_kde > c->n_slots) return fail(NBP_ERR_RANGE, "proposal: meas_kde");
+      if (p.factor_kind != NBP_F_LINREL && p.factor_kind != NBP_F_CIRCULAR && p.factor_kind != NBP_F_SE2)
+        return fail(NBP_ERR_ARG, "proposal: a KDE measurement needs a relative factor whose measurement lives on the variable's manifold");
+      if (p.partial_mask) return fail(NBP_ERR_ARG, "proposal: a KDE measurement cannot be partial");
+    }
     if (p.has_multihypo) {
       int ncert = 0;
       for (int k = 0; k < p.nvars; k++) ncert += (p.multihypo[k] == 0.0);
@@ -572,18 +578,34 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   return NBP_OK;
 }
 
-nbp_status nbp_run_deconv(nbp_ctx *c, const nbp_proposal_desc *descs, const int32_t *meas_slots, int32_t n) {
-  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
-  if (n <= 0) return NBP_OK;
-  HIPCHK(hipSetDevice(c->device));
+static nbp_status check_deconv(nbp_ctx *c, const nbp_proposal_desc *descs, int n) {
   nbp_status rc = check_proposals(c, descs, n);
   if (rc) return rc;
-  std::vector<int32_t> ms((size_t)n, -1), none;
   for (int i = 0; i < n; i++) {
     const nbp_proposal_desc &p = descs[i];
     if (p.factor_kind < NBP_F_LINREL) return fail(NBP_ERR_ARG, "deconv: relative factors only (a prior's predicted measurement is the point itself)");
     if (p.has_multihypo || p.nvars != 2) return fail(NBP_ERR_ARG, "deconv: multihypo is not supported (reference issue #467/#927)");
     if (p.partial_mask) return fail(NBP_ERR_ARG, "deconv: partial factors are not supported");
+  }
+  return NBP_OK;
+}
+
+static nbp_status launch_deconv(nbp_ctx *c, const nbp_proposal_desc *dev_descs, const int32_t *dev_meas, int n) {
+  if (n <= 0) return NBP_OK;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_deconv_kernel, dim3(n), dim3(c->Npad), 0, c->stream, dev_descs, dev_meas, c->arena, c->N, c->S, c->counters);
+  HIPCHK(hipGetLastError());
+  return NBP_OK;
+}
+
+nbp_status nbp_run_deconv(nbp_ctx *c, const nbp_proposal_desc *descs, const int32_t *meas_slots, int32_t n) {
+  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  nbp_status rc = check_deconv(c, descs, n);
+  if (rc) return rc;
+  std::vector<int32_t> ms((size_t)n, -1), none;
+  for (int i = 0; i < n; i++) {
     if (meas_slots) {
       if (meas_slots[i] >= c->n_slots) return fail(NBP_ERR_RANGE, "deconv: meas_slot");
       ms[i] = meas_slots[i];
@@ -594,10 +616,8 @@ nbp_status nbp_run_deconv(nbp_ctx *c, const nbp_proposal_desc *descs, const int3
   if (rc) return rc;
   rc = tic(c, c->ev[0]);
   if (rc) return rc;
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(nbp_deconv_kernel, dim3(n), dim3(c->Npad), 0, c->stream, (const nbp_proposal_desc *)c->stage, ds, c->arena,
-                     c->N, c->S, c->counters);
-  HIPCHK(hipGetLastError());
+  rc = launch_deconv(c, (const nbp_proposal_desc *)c->stage, ds, n);
+  if (rc) return rc;
   rc = toc(c, c->ev[0]);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -768,6 +788,7 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
     st.maxfd = products_maxfd((const nbp_product_desc *)descs, n);
     break;
   case NBP_STAGE_COPIES: esz = sizeof(nbp_copy_desc); rc = check_copies(p->ctx, (const nbp_copy_desc *)descs, n); break;
+  case NBP_STAGE_DECONV: esz = sizeof(nbp_proposal_desc); rc = check_deconv(p->ctx, (const nbp_proposal_desc *)descs, n); break;
   default: return fail(NBP_ERR_ARG, "unknown stage kind");
   }
   if (rc) return rc;
@@ -815,12 +836,17 @@ static nbp_liveness product_liveness(const nbp_program *p) {
     if (st.kind == NBP_STAGE_PROPOSALS) {
       const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
       L.dead_proposal[s].assign(st.n, 0);
-      for (int i = 0; i < st.n; i++)
+      for (int i = 0; i < st.n; i++) {
         if (pd[i].factor_kind == NBP_F_MSGPRIOR) open.erase(pd[i].var_slot[1]);  // read: live
+        if (pd[i].meas_kde > 0) open.erase(pd[i].meas_kde - 1);
+      }
       for (int i = 0; i < st.n; i++) {
         kill(pd[i].out_slot);  // overwritten
         last_prop[pd[i].out_slot] = {s, i};
       }
+    } else if (st.kind == NBP_STAGE_DECONV) {  // reads points only; its outputs are always fitted
+      const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
+      for (int i = 0; i < st.n; i++) { kill(pd[i].out_slot); last_prop.erase(pd[i].out_slot); }
     } else if (st.kind == NBP_STAGE_COPIES) {
       const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
       if (st.n == 0) open.clear();  // barrier: all live
@@ -868,8 +894,10 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       // a MsgPrior samples from the KDE in var_slot[1] (points AND bandwidth)
       for (int i = 0; i < st.n && !st.flush_before; i++) {
         const nbp_proposal_desc &pd = ((const nbp_proposal_desc *)d)[i];
-        if (pd.factor_kind != NBP_F_MSGPRIOR) continue;
-        for (int32_t ps : pend_s) st.flush_before |= (ps == pd.var_slot[1]);
+        if (pd.factor_kind == NBP_F_MSGPRIOR)
+          for (int32_t ps : pend_s) st.flush_before |= (ps == pd.var_slot[1]);
+        if (pd.meas_kde > 0)  // a measurement KDE: points and bandwidth
+          for (int32_t ps : pend_s) st.flush_before |= (ps == pd.meas_kde - 1);
       }
       if (st.flush_before) { pend_s.clear(); pend_m.clear(); }
       if (p->lazy_bw) {
@@ -887,6 +915,16 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       } else
         jobs_of_products((const nbp_product_desc *)d, st.n, pend_s, pend_m);
       if (st.n > maxprod) maxprod = st.n;
+    } else if (st.kind == NBP_STAGE_DECONV) {  // reads points only; queues the fits of its outputs
+      const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
+      for (int i = 0; i < st.n; i++) {
+        // an output slot that still has an older fit pending: that fit would see the new points, drop it
+        for (size_t q = 0; q < pend_s.size(); q++)
+          if (pend_s[q] == pd[i].out_slot) { pend_s.erase(pend_s.begin() + q); pend_m.erase(pend_m.begin() + q); q--; }
+      }
+      st.ent_s = pend_s;
+      st.ent_m = pend_m;
+      for (int i = 0; i < st.n; i++) { pend_s.push_back(pd[i].out_slot); pend_m.push_back(pd[i].manifold); }
     } else {  // copies (move bandwidths too) and the trailing pseudo stage
       st.flush_before = true;
       pend_s.clear(); pend_m.clear();
@@ -905,7 +943,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     std::vector<int64_t> so;
     for (int s = 0; s < p->n_user_stages; s++) {
       const nbp_stage &st = p->stages[s];
-      if (st.kind == NBP_STAGE_PROPOSALS)
+      if (st.kind == NBP_STAGE_PROPOSALS || st.kind == NBP_STAGE_DECONV)
         for (int i = 0; i < st.n; i++) so.push_back((int64_t)(st.offset + (size_t)i * sizeof(nbp_proposal_desc) + offsetof(nbp_proposal_desc, seed)));
       else if (st.kind == NBP_STAGE_PRODUCTS)
         for (int i = 0; i < st.n; i++) so.push_back((int64_t)(st.offset + (size_t)i * sizeof(nbp_product_desc) + offsetof(nbp_product_desc, seed)));
@@ -944,6 +982,8 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
       rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd);
+    } else if (st.kind == NBP_STAGE_DECONV) {
+      rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);
     } else {
       rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
     }

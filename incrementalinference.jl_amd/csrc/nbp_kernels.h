@@ -14,7 +14,23 @@
 // LDS: X[3][N] target scratch (the deepcopy of CalcFactor.jl:543-548), mhidx[N], LCV partial sums.
 // HBM traffic: reads the operand beliefs once (coalesced, 8 B/lane), writes the proposal once.
 // ================================================================================================
-__device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z) {
+__device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, const double *arena,
+                                                   int64_t S, int N) {
+  if (d->meas_kde > 0) {
+    // the measurement is a KDE (differential message factor): sample(belief) = random kernel + bw*randn
+    // (manifolds/services/ManifoldSampling.jl:13-19), like the MsgPrior draw below
+    const double *msg = arena + S * (d->meas_kde - 1);
+    double ua, ub, n0, n1, n2 = 0, n3 = 0;
+    uniform_pair(d->seed, n, PURP_KDESEL, 0, ua, ub);
+    int i = (int)(ua * N);
+    if (i >= N) i = N - 1;
+    normal_pair(d->seed, n, PURP_KDENOISE, 0, n0, n1);
+    if (zdim > 2) normal_pair(d->seed, n, PURP_KDENOISE, 1, n2, n3);
+    z[0] = msg[i] + msg[3 * N] * n0;
+    z[1] = (zdim > 1) ? msg[N + i] + msg[3 * N + 1] * n1 : 0.0;
+    z[2] = (zdim > 2) ? msg[2 * N + i] + msg[3 * N + 2] * n2 : 0.0;
+    return;
+  }
   int c = 0;
   if (d->ncomp > 1) {  // Mixture.sampleFactor, Factors/Mixture.jl:114-155
     double ua, ub, cum = 0;
@@ -124,14 +140,14 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           // partial prior: setPointPartial! on the partial coordinates only (:457-538)
           const int pmk = d->partial_mask;
           double z[3];
-          sample_measurement(d, n, __popc(pmk & 7), z);
+          sample_measurement(d, n, __popc(pmk & 7), z, arena, S, N);
           int pk = 0;
           if (pmk & 1) { x[0] = is_circ(M, 0) ? wrap_pi(z[0]) : z[0]; pk = 1; }
           if (pmk & 2) { x[1] = z[pk]; pk++; }
           if (pmk & 4) { const double v = (pk == 0) ? z[0] : (pk == 1 ? z[1] : z[2]); x[2] = is_circ(M, 2) ? wrap_pi(v) : v; }
         } else if (kind == NBP_F_PRIOR) {
           double z[3];
-          sample_measurement(d, n, D, z);
+          sample_measurement(d, n, D, z, arena, S, N);
           x[0] = is_circ(M, 0) ? wrap_pi(z[0]) : z[0];
           x[1] = z[1];
           x[2] = is_circ(M, 2) ? wrap_pi(z[2]) : z[2];
@@ -164,7 +180,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     const int pmask = d->partial_mask, pdim = pmask ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;
     const int zdim = pmask ? 1 : ((kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1));
     double z[3] = {0, 0, 0};
-    if (live) sample_measurement(d, n, zdim, z);  // sampleFactor!, CalcFactor.jl:578
+    if (live) sample_measurement(d, n, zdim, z, arena, S, N);  // sampleFactor!, CalcFactor.jl:578
     const int sf1 = d->sfidx + 1;
     const int myh = live ? mh[n] : -1000;
     // computeAcrossHypothesis!, EvalFactor.jl:145-237
@@ -262,7 +278,7 @@ nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, dou
   unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
   if (n < N) {
     double z[3], a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
-    sample_measurement(d, n, zdim, z);
+    sample_measurement(d, n, zdim, z, arena, S, N);
     if (ms)
       for (int k = 0; k < 3; k++) ms[k * N + n] = (k < zdim) ? z[k] : 0.0;
     a[0] = A[n]; b[0] = B[n];

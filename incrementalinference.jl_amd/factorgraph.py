@@ -220,6 +220,20 @@ class MsgPrior(_Factor):
         return [(1.0, np.zeros(1), np.zeros((1, 1)))]
 
 
+class DifferentialRelative(_Factor):
+    """LinearRelative(::MKD) / CircularCircular(::MKD) / their SE(2) twin: a relative factor whose
+    measurement is the kernel density estimate held in device slot `meas_slot` -- the differential factors of
+    the useMsgLikelihoods upward messages (services/TreeMessageUtils.jl:279-335,
+    Factors/LinearRelative.jl:32).  kind = abi.F_LINREL / F_CIRCULAR / F_SE2."""
+
+    def __init__(self, kind, meas_slot):
+        self.kind, self.meas_slot = kind, meas_slot
+        self.zdim = {abi.F_CIRCULAR: 1, abi.F_SE2: 3}.get(kind)
+
+    def components(self):
+        return [(1.0, np.zeros(3), np.eye(3))]  # unused by the device when meas_kde is set
+
+
 # ------------------------------------------------------------------------------------------------
 # SolverParams (entities/SolverParams.jl:12-75) -- hot-path knobs only
 # ------------------------------------------------------------------------------------------------
@@ -237,6 +251,7 @@ class SolverParams:
     downsolve: bool = True
     limitfixeddown: bool = False  # skip marginalized frontals in the down solve (CliqStateMachineUtils.jl:499)
     productNiter: int = 1  # AMP.manifoldProduct(...; Niter=1), GraphProductOperations.jl:56
+    useMsgLikelihoods: bool = False  # upward messages as joint likelihoods (SolverParams.jl:25, jointmsg.py)
 
 
 @dataclass
@@ -310,6 +325,14 @@ class FactorGraph:
 
     def isInitialized(self, label):
         return self.variables[label].initialized
+
+
+def deleteFactor(fg, label):
+    """deleteFactor!(dfg, label)"""
+    f = fg.factors.pop(label)
+    for v in f.variables:
+        fg._adj[v].remove(label)
+    return f
 
 
 def initfg(solverParams=None):

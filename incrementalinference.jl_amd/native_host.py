@@ -110,6 +110,8 @@ class NativeGraph:
 
     @classmethod
     def from_fg(cls, fg):
+        if getattr(fg.solverParams, "useMsgLikelihoods", False):
+            raise NotImplementedError("useMsgLikelihoods: the joint-message plan is compiled by the Python host (solver.TreeProgram)")
         g = cls(fg.solverParams)
         idx = {}
         for v in fg.ls():

@@ -19,9 +19,9 @@ import time
 
 import numpy as np
 
-from . import abi, bayestree
+from . import abi, bayestree, jointmsg
 from .backend import HipBackend
-from .factorgraph import MsgPrior
+from .factorgraph import DFGFactor, DifferentialRelative, MsgPrior
 from .seeds import op_seed
 
 PASS_INIT, PASS_UP, PASS_DOWN, PASS_UNIT = 0, 1, 2, 3
@@ -81,6 +81,8 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     d.ncomp = len(flat)
     for c, row in enumerate(flat):
         d.comp[c][:] = row
+    if getattr(fnc, "meas_slot", None) is not None:  # measurement = the KDE in that slot
+        d.meas_kde = fnc.meas_slot + 1
     if fct.multihypo is not None:
         # isinit flags: uninitialised hypotheses are suppressed (ExplicitDiscreteMarginalizations.jl:161-172)
         flags = 1 | 0x80
@@ -484,6 +486,17 @@ def initAll(fg, backend=None, seed=0):
 # ------------------------------------------------------------------------------------------------
 # tree solve
 # ------------------------------------------------------------------------------------------------
+def _default_relative(kind, varType):
+    """`_sft()` of addLikelihoodsDifferentialCHILD!: the default-constructed relative factor whose samples
+    start the deconvolution search (LinearRelative{N}() = MvNormal(0, I), Factors/LinearRelative.jl:17-22)"""
+    from .factorgraph import CircularCircular, LinearRelative, ManifoldFactor, MvNormal, Normal
+    if kind == abi.F_LINREL:
+        return LinearRelative(MvNormal(np.zeros(varType.dim), np.eye(varType.dim)))
+    if kind == abi.F_CIRCULAR:
+        return CircularCircular(Normal(0.0, 1.0))
+    return ManifoldFactor(MvNormal(np.zeros(3), np.eye(3)))
+
+
 class TreeProgram:
     """The whole up+down solve of a Bayes tree compiled into libnbp stages.
 
@@ -514,6 +527,13 @@ class TreeProgram:
         self.B = {}
         self.ghost = {}
         self.scratch = {}
+        # useMsgLikelihoods: the symbolic plan of the joint messages (jointmsg.py); D[(c, i)] = slot of the
+        # KDE of the i-th differential factor clique c sends up
+        self.joint, self.D = None, {}
+        if getattr(sp, "useMsgLikelihoods", False):
+            if any(o != rank for o in self.owner.values()):
+                raise NotImplementedError("useMsgLikelihoods with cliques on several ranks")
+            self.joint = jointmsg.plan_joint_messages(fg, tree)
         self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
         self.heights, self.depths = tree.heights(), tree.depths()
         mine = [c for c in tree.cliques if self.owner[c] == rank]
@@ -531,17 +551,37 @@ class TreeProgram:
             # up-solve factor lists per variable: clique potentials touching v + child messages on v
             upf = {}
             for v in cl.allIDs:
-                lst = [("f", f) for f in cl.potentials if v in fg.getFactor(f).variables]
-                for ch in cl.children:
-                    if v in tree.cliques[ch].separatorIDs:
-                        lst.append(("m", ch))
+                if self.joint is not None:  # potentials + the children's differentials + their common priors
+                    lst = [(f.tag, f.ref) if f.tag != "p" else ("m", f.ref[0]) for f in self.joint[cid].factors if v in f.variables]
+                else:
+                    lst = [("f", f) for f in cl.potentials if v in fg.getFactor(f).variables]
+                    for ch in cl.children:
+                        if v in tree.cliques[ch].separatorIDs:
+                            lst.append(("m", ch))
                 upf[v] = lst
+            if self.joint is not None:
+                for i in range(len(self.joint[cid].relatives)):
+                    self.D[(cid, i)] = nxt
+                    nxt += 1
             # doFMCIteration skips marginalized variables (SolveTree.jl:61)
             sched = [v for v in bayestree.upGibbsSchedule(cl, sp.gibbsIters) if upf[v] and not fg.getVariable(v).ismargin]
             self.upsched[cid], self.upfacs[cid] = sched, upf
-            dnf = {v: [f for f in fg.ls(v)] for v in cl.frontalIDs}
+            if self.joint is None:
+                dnf = {v: [("f", f) for f in fg.ls(v)] for v in cl.frontalIDs}
+                dsch = bayestree.downSchedule(fg, cl, sp.gibbsIters) if cl.parent >= 0 else []
+            else:
+                # no addDownVariableFactors! (CliqueStateMachine.jl:823): the down solve works on the clique sub
+                # graph as the up solve left it -- potentials + the children's differentials (:558 removes
+                # only the __UPWARD_COMMON__ priors)
+                kept = [f for f in self.joint[cid].factors if f.tag != "p"]
+                dnf = {v: [(f.tag, f.ref) for f in kept if v in f.variables] for v in cl.frontalIDs}
+                frs = set(cl.frontalIDs)
+                itv = {v for f in kept if len([u for u in f.variables if u in frs]) > 1 for v in f.variables if v in frs}
+                skip = {v for v in cl.frontalIDs if sp.limitfixeddown and fg.getVariable(v).ismargin}
+                dsch = ([v for v in cl.frontalIDs if v not in itv and v not in skip and dnf[v]]
+                        + [v for v in cl.frontalIDs if v in itv and v not in skip] * sp.gibbsIters) if cl.parent >= 0 else []
             self.dnfacs[cid] = dnf
-            self.dnsched[cid] = bayestree.downSchedule(fg, cl, sp.gibbsIters) if cl.parent >= 0 else []
+            self.dnsched[cid] = dsch
             maxf = max([len(upf[v]) for v in sched] + [len(dnf[v]) for v in self.dnsched[cid]] + [1])
             if maxf > abi.MAXF:
                 raise ValueError(f"clique {cid}: {maxf} densities in one product exceeds NBP_MAXF")
@@ -580,8 +620,10 @@ class TreeProgram:
         for kind, ref in entries:
             if kind == "f":
                 fcts.append(fg.getFactor(ref))
+            elif kind == "d":  # differential factor of a child's joint message (addLikelihoodsDifferential!)
+                a, b, _, fk = self.joint[ref[0]].relatives[ref[1]]
+                fcts.append(DFGFactor(f"diff{ref[0]}_{ref[1]}", [a, b], DifferentialRelative(fk, self.D[ref]), None, 0.0, sp.inflation))
             else:  # child message -> MsgPrior (generateMsgPrior, TreeMessageUtils.jl:86-89)
-                from .factorgraph import DFGFactor
                 fcts.append(DFGFactor(f"msg{ref}_{v}", [v], MsgPrior(self._msg_slot(ref, v)), None, 0.0, sp.inflation))
         ns = _null_surplus(fg, fcts)
         props = [proposal_desc(fg, f, v, slot_of, base + i, op_seed(self.seed, passid, cid, step, i + 1), nullSurplus=ns[i])
@@ -639,6 +681,17 @@ class TreeProgram:
                     self.n_updates_up += 1
                 self._add(abi.STAGE_PROPOSALS, props, "up")
                 self._add(abi.STAGE_PRODUCTS, prods, "up")
+            if self.joint is not None:
+                # prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD!: approxDeconv between the solved separator
+                # beliefs of every differential pair, manikde! of the predicted measurements
+                dec = []
+                for c in level:
+                    for i, (a, b, _, fk) in enumerate(self.joint[c].relatives):
+                        dflt = DFGFactor(f"dummy{c}_{i}", [a, b], _default_relative(fk, fg.getVariable(a).varType), None, 0.0, sp.inflation)
+                        dec.append(proposal_desc(fg, dflt, b, lambda u, c=c: self.B[(c, u)], self.D[(c, i)],
+                                                 op_seed(self.seed, PASS_UP, c, 0x4000 + i, 0)))
+                if dec:
+                    self._add(abi.STAGE_DECONV, dec, "up")
             # up messages that cross a rank boundary: child's separator beliefs -> parent's ghost slots
             edges = []
             for c in allc:
@@ -687,7 +740,7 @@ class TreeProgram:
                     def slot_of(u, c=c, inclq=inclq):
                         return self.B[(c, u)] if u in inclq else self.main[u]
 
-                    p, q = self._update_ops(c, v, [("f", f) for f in self.dnfacs[c][v]], slot_of, self.B[(c, v)], PASS_DOWN, k)
+                    p, q = self._update_ops(c, v, self.dnfacs[c][v], slot_of, self.B[(c, v)], PASS_DOWN, k)
                     props += p
                     prods.append(q)
                     self.n_updates_down += 1
@@ -735,6 +788,8 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
     # Python mirror otherwise (oracle backend in the tests); both produce the same descriptors
     use_native = native if native is not None else (backend is None or backend is HipBackend or isinstance(backend, HipBackend)
                                                     or getattr(backend, "is_hip", False))
+    if getattr(sp, "useMsgLikelihoods", False):
+        use_native = False  # the joint-message plan is compiled by the Python host (jointmsg.py)
     if use_native:
         from . import native_host
         ng = native_host.NativeGraph.from_fg(fg)

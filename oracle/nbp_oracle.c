@@ -680,7 +680,22 @@ void orc_run_bandwidth(double *arena, int32_t N, int32_t slot, int32_t manifold)
 /* ------------------------------------------------------------------------------------------ */
 /* Proposal = approxConvBelief (ApproxConv.jl:4-45)                                            */
 /* ------------------------------------------------------------------------------------------ */
-static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, int *label) {
+static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, int *label, const double *arena, int N) {
+  if (d->meas_kde > 0) {
+    /* the measurement is a KDE (LinearRelative(::MKD) / CircularCircular(::MKD), the differential factors
+     * of TreeMessageUtils.jl:279-335): sampleTangent(M, ::MKD) = sample(belief, 1) = random kernel +
+     * bw*randn (manifolds/services/ManifoldSampling.jl:13-19) */
+    const double *msg = arena + orc_slot_stride(N) * (d->meas_kde - 1);
+    double ua, ub, nn[4];
+    orc_uniform_pair(d->seed, n, PURP_KDESEL, 0, &ua, &ub);
+    int i = (int)(ua * N);
+    if (i >= N) i = N - 1;
+    orc_normal_pair(d->seed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
+    if (zdim > 2) orc_normal_pair(d->seed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
+    for (int k = 0; k < 3; k++) z[k] = k < zdim ? msg[k * N + i] + msg[3 * N + k] * nn[k] : 0.0;
+    if (label) *label = 0;
+    return;
+  }
   /* Mixture.sampleFactor (Factors/Mixture.jl:114-155): label ~ Categorical(diversity) */
   int c = 0;
   if (d->ncomp > 1) {
@@ -770,12 +785,12 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
           double z[3];
           int zd = 0, pk = 0;
           for (int k = 0; k < D; k++) zd += (d->partial_mask >> k) & 1;
-          sample_measurement(d, n, zd, z, 0);
+          sample_measurement(d, n, zd, z, 0, arena, N);
           for (int k = 0; k < D; k++)
             if ((d->partial_mask >> k) & 1) { X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[pk]) : z[pk]; pk++; }
         } else if (d->factor_kind == NBP_F_PRIOR) {
           double z[3];
-          sample_measurement(d, n, D, z, 0);
+          sample_measurement(d, n, D, z, 0, arena, N);
           for (int k = 0; k < D; k++) X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[k]) : z[k];
         } else { /* MsgPrior{MKD}: sample(belief,1): random kernel + bw*randn, Factors/MsgPrior.jl:27-30 */
           const double *msg = arena + S * d->var_slot[1];
@@ -809,7 +824,7 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     double *X = out; /* ccwl.varValsAll[sfidx] = deepcopy(target), CalcFactor.jl:543-548 */
     memmove(X, arena + S * d->var_slot[d->sfidx], sizeof(double) * 3 * N);
     double *Z = (double *)malloc(sizeof(double) * 3 * N);
-    for (int n = 0; n < N; n++) sample_measurement(d, n, zdim, Z + 3 * n, 0); /* sampleFactor!, :578 */
+    for (int n = 0; n < N; n++) sample_measurement(d, n, zdim, Z + 3 * n, 0, arena, N); /* sampleFactor!, :578 */
 
     /* computeAcrossHypothesis!, EvalFactor.jl:145-237 */
     for (int g = 0; g < R.ngroups; g++) {
@@ -1078,7 +1093,7 @@ int32_t orc_run_deconv(double *arena, int32_t N, const nbp_proposal_desc *d, int
   double *out = arena + S * d->out_slot, *ms = meas_slot >= 0 ? arena + S * meas_slot : 0;
   for (int n = 0; n < N; n++) {
     double z[3];
-    sample_measurement(d, n, zdim, z, 0);
+    sample_measurement(d, n, zdim, z, 0, arena, N);
     if (ms) for (int k = 0; k < 3; k++) ms[k * N + n] = k < zdim ? z[k] : 0.0;
     objective_t o;
     o.kind = d->factor_kind; o.manifold = d->manifold; o.D = D; o.solve_b = 2;

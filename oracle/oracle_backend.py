@@ -156,7 +156,8 @@ class OracleProgram:
         self.backend = backend
         self.stages = [(k, backend._arr(d, {abi.STAGE_PROPOSALS: abi.ProposalDesc,
                                             abi.STAGE_PRODUCTS: abi.ProductDesc,
-                                            abi.STAGE_COPIES: abi.CopyDesc}[k])[0]) for k, d in stages]
+                                            abi.STAGE_COPIES: abi.CopyDesc,
+                                            abi.STAGE_DECONV: abi.ProposalDesc}[k])[0]) for k, d in stages]
         self.n_stages = len(stages)
 
     def run(self, first=0, last=-1):
@@ -166,6 +167,10 @@ class OracleProgram:
                 self.backend.run_proposals(arr)
             elif kind == abi.STAGE_PRODUCTS:
                 self.backend.run_products(arr)
+            elif kind == abi.STAGE_DECONV:  # predicted measurements + manikde! of them
+                if len(arr):
+                    self.backend.run_deconv(arr)
+                    self.backend.run_bandwidth([d.out_slot for d in arr], [d.manifold for d in arr])
             else:
                 self.backend.run_copies(arr)
 

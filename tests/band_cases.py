@@ -562,3 +562,79 @@ def case_multihypothesis_api(backend):
 
 
 CASES.append(case_multihypothesis_api)
+
+
+def case_joint_messages_circular(backend):
+    # test/testCircular.jl:7-29: five Circular poses, prior at 0, CircularCircular(N(1, 0.1)) odometry, solved
+    # with useMsgLikelihoods = true; PPE ~ rem2pi(0:4) within 0.35
+    fg = iif.initfg(iif.SolverParams(N=100, useMsgLikelihoods=True))
+    for i in range(5):
+        iif.addVariable(fg, f"x{i}", iif.Circular)
+    iif.addFactor(fg, ["x0"], iif.PriorCircular(iif.Normal(0.0, 0.1)))
+    for i in range(4):
+        iif.addFactor(fg, [f"x{i}", f"x{i + 1}"], iif.CircularCircular(iif.Normal(1.0, 0.1)))
+    iif.solveTree(fg, backend=backend, seed=130)
+    for i in range(5):
+        th = fg.getVal(f"x{i}")[:, 0]
+        m = np.arctan2(np.sin(th).mean(), np.cos(th).mean())
+        gt = (i + np.pi) % (2 * np.pi) - np.pi
+        assert abs((m - gt + np.pi) % (2 * np.pi) - np.pi) < 0.35, (i, m, gt)
+
+
+def case_joint_messages_has_priors(backend):
+    # test/testHasPriors913.jl:7-50: a 5-pose line with one landmark seen from both ends, initialised from a
+    # WRONG prior (x0 ~ 5) and solved with the right one (x0 ~ 0) and useMsgLikelihoods: the common message
+    # priors only travel up where a prior exists below (msg.hasPriors), the differential factors carry the
+    # rest; after three solves x_i ~ i within 0.7
+    def line(mu0):
+        fg = iif.generateGraph_LineStep(4, poseEvery=1, landmarkEvery=5, posePriorsAt=(), landmarkPriorsAt=(), sightDistance=5,
+                                        solverParams=iif.SolverParams(N=100))
+        for i in (1, 2, 3):
+            iif.deleteFactor(fg, f"x{i}lm0f1")
+        iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(mu0, 0.01)))
+        return fg
+
+    wrong = line(5.0)
+    iif.initAll(wrong, backend=backend, seed=131)
+    fg = line(0.0)
+    for v in fg.ls():
+        iif.initVariable(fg, v, wrong.getVal(v), backend=backend)
+    fg.solverParams.useMsgLikelihoods = True
+    fg.solverParams.graphinit = False
+    for k in range(3):
+        iif.solveTree(fg, backend=backend, seed=132 + k)
+    for i in range(5):
+        assert abs(float(np.median(fg.getVal(f"x{i}")[:, 0])) - i) < 0.7, (i, np.median(fg.getVal(f"x{i}")[:, 0]))
+
+
+def case_joint_messages_caesar_ring(backend):
+    # test/testUseMsgLikelihoods.jl:10-105: the 1-D Caesar ring solved upward only with useMsgLikelihoods and the
+    # test's elimination order (the structural assertions of that test live in tests/test_joint_messages.py);
+    # and test/testSpecialEuclidean2Mani.jl:206-211: an SE(2) graph solves in this mode
+    fg = iif.initfg(iif.SolverParams(N=100, useMsgLikelihoods=True, downsolve=False))
+    for v in ["x0", "x1", "x2", "x3", "x4", "x5", "x6"]:
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal()))
+    for a, b in [("x0", "x1"), ("x1", "x2"), ("x2", "x3"), ("x3", "x4"), ("x4", "x5"), ("x5", "x6")]:
+        iif.addFactor(fg, [a, b], iif.LinearRelative(iif.Normal()))
+    iif.addVariable(fg, "l1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0", "l1"], iif.LinearRelative(iif.Normal()))
+    iif.addFactor(fg, ["x6", "l1"], iif.LinearRelative(iif.Normal()))
+    iif.solveTree(fg, eliminationOrder=["x3", "x5", "l1", "x1", "x6", "x4", "x2", "x0"], backend=backend, seed=136)
+    for v in fg.ls():  # every belief stays a proper, centred density (all measurements are N(0, 1))
+        x = fg.getVal(v)[:, 0]
+        assert np.isfinite(x).all() and abs(x.mean()) < 2.5 and 0.3 < x.std() < 6.0, (v, x.mean(), x.std())
+    fg = iif.initfg(iif.SolverParams(N=100, useMsgLikelihoods=True))
+    for i in range(4):
+        iif.addVariable(fg, f"x{i}", iif.SpecialEuclidean2)
+    iif.addFactor(fg, ["x0"], iif.ManifoldPrior([0.0, 0.0, 0.0], iif.MvNormal(np.zeros(3), np.diag([0.1, 0.1, 0.01]) ** 2)))
+    for i in range(3):
+        iif.addFactor(fg, [f"x{i}", f"x{i + 1}"], iif.ManifoldFactor(iif.MvNormal([1.0, 0.0, 0.0], np.diag([0.1, 0.1, 0.01]) ** 2)))
+    iif.addFactor(fg, ["x0", "x3"], iif.ManifoldFactor(iif.MvNormal([3.0, 0.0, 0.0], np.diag([0.1, 0.1, 0.01]) ** 2)))
+    iif.solveTree(fg, eliminationOrder=["x1", "x2", "x3", "x0"], backend=backend, seed=137)
+    for i in range(4):
+        x, y, th = se2_mean(fg.getVal(f"x{i}"))
+        assert abs(x - i) < 0.5 and abs(y) < 0.5 and abs(th) < 0.3, (i, x, y, th)
+
+
+CASES += [case_joint_messages_circular, case_joint_messages_has_priors, case_joint_messages_caesar_ring]

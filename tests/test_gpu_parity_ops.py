@@ -3,7 +3,7 @@ Floating point: <= 1e-9 relative per particle; integers (mhidx, product labels) 
 import numpy as np
 import pytest
 
-from parity_utils import (abi, assert_points_close, both, iif, product_desc, rand_points,
+from parity_utils import (abi, assert_points_close, both, coord_diff, iif, product_desc, rand_points,
                           relative_factor_desc)
 
 pytestmark = pytest.mark.gpu
@@ -444,4 +444,60 @@ def test_host_buffer_entry_points(hip_backend, manifold):
     with pytest.raises(iif.NbpError):
         small.manifold_product(manifold, dens, 1)
     small.close()
+    be.close()
+
+
+# ---- useMsgLikelihoods: differential factors (TreeMessageUtils.jl:279-335) ---------------------------
+@pytest.mark.parametrize("kind,manifold,mean,sig", [c for c in CASES if c[0] != abi.F_EUCLIDDIST])
+def test_differential_factor_program(oracle_backend, hip_backend, kind, manifold, mean, sig):
+    """a resident program: deconvolution between two beliefs (NBP_STAGE_DECONV: predicted measurements + their
+    manikde! bandwidth), then the relative factor whose measurement is that KDE (meas_kde) convolved both ways,
+    then a product -- GPU against the oracle"""
+    N = 200
+    rng = np.random.default_rng(5000 + 10 * kind + manifold)
+    a = rand_points(rng, manifold, N, center=0.3, spread=0.3)
+    b = rand_points(rng, manifold, N, center=1.2, spread=0.3)
+    dec = relative_factor_desc(kind, manifold, 2, 1, [0, 1], 2, 901 + kind, [0.0] * len(mean), [1.0] * len(mean))
+    fwd = relative_factor_desc(kind, manifold, 2, 1, [0, 1], 3, 902 + kind, mean, sig)
+    rev = relative_factor_desc(kind, manifold, 2, 0, [0, 1], 4, 903 + kind, mean, sig)
+    fwd.meas_kde = rev.meas_kde = 2 + 1
+    prod = product_desc(manifold, [3, 1], 5, 904)
+
+    def setup(be):
+        be.slot_write(0, manifold, a)
+        be.slot_write(1, manifold, b)
+        be.run_bandwidth([0, 1], [manifold, manifold])
+
+    def run(be):
+        prog = be.program([(abi.STAGE_DECONV, [dec]), (abi.STAGE_PROPOSALS, [fwd, rev]), (abi.STAGE_PRODUCTS, [prod])])
+        prog.run()
+        be.synchronize() if hasattr(be, "synchronize") else None
+        prog.close()
+
+    def read(be):
+        return [be.slot_read(s, manifold) for s in (2, 3, 4, 5)]
+
+    o, h = both(oracle_backend, hip_backend, N, 6, 0, setup, run, read)
+    assert_points_close(manifold, h[0][0], o[0][0], rtol=1e-8, what="predicted measurements")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-6)  # the KDE's bandwidth
+    for k in (1, 2):  # both convolution directions through the KDE-measurement factor
+        assert_points_close(manifold, h[k][0], o[k][0], rtol=1e-6, max_bad=2, what=f"proposal {k}")
+    # the forward convolution lands on b's belief
+    assert np.abs(coord_diff(manifold, h[1][0], b).mean(axis=0)).max() < 0.2
+    assert np.isfinite(h[3][0]).all()
+
+
+def test_differential_factor_validation(hip_backend):
+    be = hip_backend(64, 4, 0)
+    d = relative_factor_desc(abi.F_EUCLIDDIST, abi.EUCLID2, 2, 1, [0, 1], 2, 1, [1.0], [1.0])
+    d.meas_kde = 4
+    with pytest.raises(iif.NbpError):  # the measurement of a distance factor does not live on the variable's manifold
+        be.run_proposals([d])
+    d = relative_factor_desc(abi.F_LINREL, abi.EUCLID2, 2, 1, [0, 1], 2, 1, [1.0, 1.0], [1.0, 1.0])
+    d.meas_kde = 6  # slot 5 of 4
+    with pytest.raises(iif.NbpError):
+        be.run_proposals([d])
+    p = relative_factor_desc(abi.F_PRIOR, abi.EUCLID2, 1, 0, [0], 1, 1, [1.0, 1.0], [1.0, 1.0])
+    with pytest.raises(iif.NbpError):  # deconvolution stages take relative factors
+        be.program([(abi.STAGE_DECONV, [p])])
     be.close()
