@@ -558,6 +558,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv;
   double *xs = L.xs;
   nbp_exp_tab_init(L.tab);
+  NBP_CTICK_INIT();
   // ---- stage the KD-sorted, centred coordinates of every density + bandwidths ------------------
   if (!big)
     for (int item = tid; item < F * D * N; item += TB) {
@@ -576,6 +577,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   for (int l = 1; l <= T.L; l++) {
     const int cnt = T.cnt[l], off = T.off[l];
     __syncthreads();
+    NBP_CTICK(40);  // staging (first level) / Gibbs draws of the previous level
     for (int item = tid; item < F * D * cnt; item += TB) {  // node statistics of this level
       const int z = item % cnt, jk = item / cnt;
       const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
@@ -593,6 +595,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     if (h == 0 && live)
       for (int j = 0; j < F; j++) ind[j * SPB + sl] = T.node_child[T.off[l - 1] + ind[j * SPB + sl]];  // levelDown!
     __syncthreads();
+    NBP_CTICK(41);  // node statistics + levelDown
     const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range
     const bool leaf = (l == T.L);
     for (int it = 0; it < d->niter; it++) {
@@ -739,6 +742,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       }
     }
   }
+  NBP_CTICK(40);
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
   if (h == 0 && live) {
     double res[D];
@@ -779,6 +783,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k * N + s] = (k < D) ? res[k < D ? k : 0] : 0.0;
   }
+  NBP_CTICK(42);  // final draw
 }
 
 template <int HL>

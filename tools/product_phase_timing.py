@@ -1,0 +1,32 @@
+"""shader-clock split of one manifold product (last workgroup of the launch); needs tools/libnbp_dbg.so built
+with -DNBP_PHASE_TIMING"""
+import ctypes as C
+import os
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+from parity_utils import abi, iif, product_desc, rand_points
+
+lib = abi.load_library(os.path.join(R, "tools", "libnbp_dbg.so"))
+abi._lib = lib
+names = ["staging + Gibbs draws", "node statistics", "final draw"]
+for man, F in ((abi.EUCLID2, 2), (abi.EUCLID2, 3), (abi.SE2, 3)):
+    for nops in (1, 2048):
+        N = 200
+        be = iif.HipBackend(N, F + 1, 0)
+        rng = np.random.default_rng(0)
+        for j in range(F):
+            be.slot_write(j, man, rand_points(rng, man, N, 1.0 + 0.1 * j, 0.3))
+        be.run_bandwidth(list(range(F)), [man] * F)
+        descs = [product_desc(man, list(range(F)), F, 5 + i) for i in range(nops)]
+        out = (C.c_longlong * 64)()
+        be.run_products(descs)
+        lib.nbp_debug_phase_read(out, 64, 1)
+        be.run_products(descs)
+        lib.nbp_debug_phase_read(out, 64, 1)
+        tot = sum(out[40:43])
+        print(f"manifold {man} F={F} batch {nops}: {tot} cycles | " + ", ".join(f"{n} {out[40 + i]}" for i, n in enumerate(names)))
+        be.close()
