@@ -103,6 +103,7 @@ static nbp_status build_levels(nbp_ctx *c) {
   std::vector<double> dbls;
   int total = 0;
   for (int i = 0; i <= L; i++) { c->T.cnt[i] = (int)lo[i].size(); c->T.off[i] = total; total += c->T.cnt[i]; }
+  if ((size_t)total > nbp_kd_nodes_cap(N)) return fail(NBP_ERR_RANGE, "level tables exceed the node-sum workspace");
   std::vector<int32_t> nlo(total), nhi(total), nch(total, 0), pos((size_t)(L + 1) * N);
   dbls.resize(2 * (size_t)total);
   for (int i = 0; i <= L; i++)
@@ -428,8 +429,8 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
 // several small workgroups per product; throughput mode: HL = 2 so that one workgroup covers all
 // samples and the node statistics of a product are computed once.
 static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
-  *HL = n >= 192 ? 2 : (n >= 48 ? 4 : 8);
-  const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL == 8) ? 6 : 8;
+  *HL = n >= 192 ? 2 : (n >= 48 ? 4 : (n >= 16 ? 8 : 16));
+  const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL >= 8) ? 6 : 8;
   int g = (waves + cap - 1) / cap;
   *wpb = (waves + g - 1) / g;
   *G = (waves + *wpb - 1) / *wpb;
@@ -444,7 +445,7 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   const int F = maxFD / 4, D = maxFD % 4;
   bool big = nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP;
   if (big && HL != 8) {  // many densities: small sample groups keep the label table in LDS
-    product_geometry(c, 1, &HL, &wpb, &G);
+    product_geometry(c, 16, &HL, &wpb, &G);
   }
   const int TB = wpb * 64, SPB = TB / HL;
   const size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big);
@@ -452,14 +453,16 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   nbp_status rc = NBP_OK;
   double *gs = nullptr;
   if (big) {
-    rc = ensure_gstats(c, (size_t)n * G * 2 * (size_t)F * D * c->N);
+    rc = ensure_gstats(c, (size_t)n * G * 3 * (size_t)F * D * c->N);
     if (rc) return rc;
     gs = c->gstats;
   }
   rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  if (HL == 8)
+  if (HL == 16)
+    hipLaunchKernelGGL(nbp_product_kernel_x16, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
+  else if (HL == 8)
     hipLaunchKernelGGL(nbp_product_kernel_l8, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
   else if (HL == 4)
     hipLaunchKernelGGL(nbp_product_kernel_m4, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);

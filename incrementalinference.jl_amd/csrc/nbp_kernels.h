@@ -388,8 +388,12 @@ __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, ui
 //                   lanes of one wave); results do not depend on the geometry beyond rounding (the
 //                   RNG is keyed by the sample index).
 // ================================================================================================
-// HBM workspace of one (product, density): xs[3][N] | cen[4] | idx[N] (int32)
-__host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return (size_t)3 * N + 4 + (size_t)(N + 1) / 2; }
+// HBM workspace of one (product, density): xs[3][N] | cen[4] | idx[N] (int32) | node sums st[3][2][TOT]
+// (st[k][0][g] = sum, st[k][1][g] = sum of squares of the sorted, centred coordinate k over the leaves of
+// node g, g = position in the level tables; TOT = nbp_kd_nodes_cap(N) >= number of nodes of all levels)
+__host__ __device__ inline size_t nbp_kd_nodes_cap(int N) { return (size_t)3 * N + 8; }
+__host__ __device__ inline size_t nbp_kd_stats_offset(int N) { return (size_t)3 * N + 4 + (size_t)(N + 1) / 2; }
+__host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return nbp_kd_stats_offset(N) + 6 * nbp_kd_nodes_cap(N); }
 
 // KD-tree permutation of one density: median split of the widest coordinate, by rank counting
 // inside each segment (P helper lanes per position, no sort network).
@@ -466,13 +470,34 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
     int *t = pa; pa = pb; pb = t;
   }
   int *widx = (int *)(wsj + 3 * N + 4);
+  double *srt = ext;  // [D][Npad] sorted, centred coordinates (the extent scratch is free now)
 #pragma unroll
   for (int k = 0; k < D; k++) {
     double c = block_sum(tid < N ? raw[k * N + tid] : 0.0, red) / (double)N;
     if (tid == 0) wsj[3 * N + k] = c;
-    if (tid < N) wsj[k * N + tid] = raw[k * N + pa[tid]] - c;
+    if (tid < N) {
+      const double v = raw[k * N + pa[tid]] - c;
+      wsj[k * N + tid] = v;
+      srt[k * Npad + tid] = v;
+    }
   }
   if (tid < N) widx[tid] = pa[tid];
+  __syncthreads();
+  // node sums of every level (the moment-matched Gaussians of the product's multiscale sampler): done here,
+  // beside the bandwidth fits of the same launch, so that the product kernel only reads them
+  {
+    const int g0 = T.off[1], TOT = T.off[T.L] + T.cnt[T.L];
+    double *st = wsj + nbp_kd_stats_offset(N);
+    const size_t cap = nbp_kd_nodes_cap(N);
+    for (int item = tid; item < (TOT - g0) * D; item += TB) {
+      const int g = g0 + item % (TOT - g0), k = item / (TOT - g0);
+      const int lo = T.node_lo[g], hi = T.node_hi[g];
+      double s1 = 0, s2 = 0;
+      for (int p = lo; p < hi; p++) { const double v = srt[k * Npad + p]; s1 += v; s2 += v * v; }
+      st[(size_t)(k * 2) * cap + g] = s1;
+      st[(size_t)(k * 2 + 1) * cap + g] = s2;
+    }
+  }
 }
 
 static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
@@ -509,23 +534,23 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
 // launch: 8 when the launch cannot fill the chip (latency: short ranges, several small workgroups per
 // product), 4 or 2 when it can (throughput: one workgroup per product computes the node statistics once).
 struct product_lds {
-  double *xs, *lm, *lv, *cen, *h2, *nw, *tab;
+  double *lm, *lv, *lr, *cen, *h2, *nw, *tab;
   int *ind;
 };
 
-// `big` = the sorted coordinates and the per-level node statistics (3 x F x D x N doubles) do not fit the
-// LDS: they stay in global memory (the KD workspace is read in place, the statistics go to a scratch
-// area private to the workgroup) and are served by L1/L2; LDS then holds only the small per-product items.
+// `big` = the per-level node statistics (3 x F x D x N doubles) do not fit the LDS: they go to a scratch
+// area private to the workgroup in global memory and are served by L1/L2; LDS then holds only the small
+// per-product items.
 __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
   const size_t bulk = big ? 0 : (size_t)F * D * N;
-  size_t xs = dbl(bulk), lm = dbl(bulk), lv = dbl(bulk);
+  size_t lm = dbl(bulk), lv = dbl(bulk), lr = dbl(bulk);
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
   size_t nw = dbl((size_t)N), tab = dbl(NBP_EXPTAB);
   size_t ints0 = o;
   if (L) {
-    L->xs = base + xs; L->lm = base + lm; L->lv = base + lv; L->cen = base + cen; L->h2 = base + h2;
+    L->lm = base + lm; L->lv = base + lv; L->lr = base + lr; L->cen = base + cen; L->h2 = base + h2;
     L->nw = base + nw; L->tab = base + tab;
     L->ind = (int *)(base + ints0);
   }
@@ -554,17 +579,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   double *out = arena + S * d->out_slot;
   const double *wsp = ws + (size_t)blockIdx.x * kdF * nbp_kd_ws_doubles(N);
   // node statistics: LDS, or (big) this workgroup's private scratch in global memory
-  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * (size_t)F * D * N : nullptr;
-  double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv;
-  double *xs = L.xs;
+  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 * (size_t)F * D * N : nullptr;
+  double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv, *lr = big ? gs + 2 * (size_t)F * D * N : L.lr;
   nbp_exp_tab_init(L.tab);
   NBP_CTICK_INIT();
-  // ---- stage the KD-sorted, centred coordinates of every density + bandwidths ------------------
-  if (!big)
-    for (int item = tid; item < F * D * N; item += TB) {
-      const int j = item / (D * N), r = item % (D * N);
-      xs[item] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + r];
-    }
+  // ---- bandwidths and centres of every density -------------------------------------------------
+  const size_t stcap = nbp_kd_nodes_cap(N);
   for (int t = tid; t < F * 3; t += TB) {
     const int j = t / 3, k = t % 3;
     const double bw = arena[S * d->in_slot[j] + 3 * N + k];
@@ -581,15 +601,17 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     for (int item = tid; item < F * D * cnt; item += TB) {  // node statistics of this level
       const int z = item % cnt, jk = item / cnt;
       const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
-      const double *xv = big ? wsp + (size_t)(jk / D) * nbp_kd_ws_doubles(N) + (size_t)(jk % D) * N : xs + jk * N;
-      double s1 = 0, s2 = 0;
-      for (int p = lo; p < hi; p++) { double v = xv[p]; s1 += v; s2 += v * v; }
+      const int j = jk / D, k = jk % D;
+      // the node sums were left by the KD build of this density (nbp_prep_kernel)
+      const double *st = wsp + (size_t)j * nbp_kd_ws_doubles(N) + nbp_kd_stats_offset(N) + (size_t)(k * 2) * stcap + off + z;
+      const double s1 = st[0], s2 = st[stcap];
       const double nn = (double)(hi - lo), mu = s1 / nn;
       double var = s2 / nn - mu * mu;
       if (var < 0) var = 0;
-      const int j = jk / D, k = jk % D;
       lm[jk * N + z] = cen[j * 3 + k] + mu;
-      lv[jk * N + z] = var + h2[j * 3 + k];
+      const double vz = var + h2[j * 3 + k];
+      lv[jk * N + z] = vz;
+      lr[jk * N + z] = 1.0 / vz;  // the precision, once per node: the draws below only multiply
     }
     for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
     if (h == 0 && live)
@@ -642,7 +664,9 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             g = r * L.nw[z];
           }
         };
-        const int zr = z1 - z0, csz = (zr + NCH - 1) / NCH;  // chunk size of this helper's range
+        // chunk size of this helper's range: a multiple of 4, the pass-1 loop takes the nodes four at a time
+        const int zr = z1 - z0, csz = (((zr + NCH - 1) / NCH) + 3) & ~3;
+        NBP_CTICK(40);
         if (live) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
@@ -651,15 +675,15 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               if (q == j) continue;
               if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
               const int iq = ind[q * SPB + sl];
-              const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
-              prec += 1.0 / vq;
+              const double mq = lm[(q * D + k) * N + iq], rq = lr[(q * D + k) * N + iq];
+              prec += rq;
               if (circ[k]) {
                 double sn, cs_;
                 sincos(mq, &sn, &cs_);
-                ss += sn / vq;
-                sc += cs_ / vq;
+                ss += sn * rq;
+                sc += cs_ * rq;
               } else
-                acc += mq / vq;
+                acc += mq * rq;
             }
             if (PARTIAL) {
               use[k] = ((pmj >> k) & 1) && prec > 0;
@@ -674,11 +698,33 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           }
           double ub;
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
+          NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
 #pragma unroll
           for (int c = 0; c < NCH; c++) {
             double cur = 0;
             const int za = z0 + c * csz, zb = min(z1, za + csz);
-            for (int z = za; z < zb; z++) {
+            int z = za;
+            // four nodes per step: four independent weight evaluations in flight (a lone wave on its SIMD is
+            // bound by the dependent-chain latency of one) and one running-max update instead of four
+            for (; z + 3 < zb; z += 4) {
+              double a0, a1, a2, a3, g0, g1, g2, g3;
+              node_w(z, a0, g0);
+              node_w(z + 1, a1, g1);
+              node_w(z + 2, a2, g2);
+              node_w(z + 3, a3, g3);
+              const double am = fmax(fmax(a0, a1), fmax(a2, a3));
+              if (am > m) {
+                const double f = exp_nonpos(m - am, L.tab);  // m == -inf -> 0
+                tot *= f;
+                cur *= f;
+                m = am;
+              }
+              const double w = (exp_nonpos(a0 - m, L.tab) * g0 + exp_nonpos(a1 - m, L.tab) * g1) +
+                               (exp_nonpos(a2 - m, L.tab) * g2 + exp_nonpos(a3 - m, L.tab) * g3);
+              tot += w;
+              cur += w;
+            }
+            for (; z < zb; z++) {
               double a, g;
               node_w(z, a, g);
               if (a > m) {
@@ -695,6 +741,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             ms[c] = m;
           }
         }
+        NBP_CTICK(44);  // pass 1: node weights of this helper's range
         // combine over the HL helper lanes of the sample (adjacent lanes of this wave): common max,
         // shares rescaled to it, inclusive prefix sum -> the one helper whose interval holds u * total
         double Mx = m;
@@ -709,6 +756,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         }
         const double total = __shfl(incl, HL - 1, HL), target = ua * total, before = incl - share;
         int choice = -1;
+        NBP_CTICK(45);  // shuffle combine
         if (live && share > 0 && target >= before && target < incl) {
           // pass 2 inside this helper's own range: find the chunk that holds `target`, rescan only it
           double cacc = before;
@@ -739,6 +787,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         for (int o = 1; o < HL; o <<= 1) choice = max(choice, __shfl_xor(choice, o, HL));
         if (choice < 0) choice = cnt - 1;  // rounding left u * total beyond the last share
         if (h == 0 && live) ind[j * SPB + sl] = choice;
+        NBP_CTICK(46);  // pass 2: rescan of the chosen chunk + broadcast of the choice
       }
     }
   }
@@ -756,15 +805,15 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       for (int q = 0; q < F; q++) {
         if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
         const int iq = ind[q * SPB + sl];
-        const double mq = lm[(q * D + k) * N + iq], vq = lv[(q * D + k) * N + iq];
-        prec += 1.0 / vq;
+        const double mq = lm[(q * D + k) * N + iq], rq = lr[(q * D + k) * N + iq];
+        prec += rq;
         if (circ[k]) {
           double sn, cs_;
           sincos(mq, &sn, &cs_);
-          ss += sn / vq;
-          sc += cs_ / vq;
+          ss += sn * rq;
+          sc += cs_ * rq;
         } else
-          acc += mq / vq;
+          acc += mq * rq;
       }
       if (PARTIAL && !(prec > 0)) {  // uninformed coordinate: oldPoints
         res[k] = (d->old_slot >= 0) ? arena[S * d->old_slot + k * N + s] : 0.0;
@@ -818,9 +867,13 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
   }
 }
 
-// Three entry points = three register budgets: the latency variant (HL = 8, few workgroups in flight)
-// keeps everything in registers; the throughput variants trade a few spills for 4-5 waves per SIMD.
+// Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in
+// flight) keep everything in registers; the throughput variants trade a few spills for 4-5 waves per SIMD.
 #define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
+__global__ void __launch_bounds__(512) nbp_product_kernel_x16(NBP_PRODUCT_ARGS) {
+  extern __shared__ double smem[];
+  product_kernel_body<16>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
+}
 __global__ void __launch_bounds__(512) nbp_product_kernel_l8(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<8>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);

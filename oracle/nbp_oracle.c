@@ -958,7 +958,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   /* per density: sorted, centred coordinates and per-level node statistics */
   int *idx[NBP_MAXF];
   double *xs[NBP_MAXF], ctr[NBP_MAXF][3], h2[NBP_MAXF][3];
-  double *nmean[NBP_MAXF][12], *nvar[NBP_MAXF][12];
+  double *nmean[NBP_MAXF][12], *nvar[NBP_MAXF][12], *nprec[NBP_MAXF][12];
   for (int j = 0; j < F; j++) {
     const double *x = arena + S * d->in_slot[j];
     idx[j] = (int *)malloc(sizeof(int) * N);
@@ -976,6 +976,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     for (int l = 0; l <= T.L; l++) {
       nmean[j][l] = (double *)malloc(sizeof(double) * 3 * T.cnt[l]);
       nvar[j][l] = (double *)malloc(sizeof(double) * 3 * T.cnt[l]);
+      nprec[j][l] = (double *)malloc(sizeof(double) * 3 * T.cnt[l]);
       for (int z = 0; z < T.cnt[l]; z++) {
         int lo = T.lo[l][z], hi = T.hi[l][z], n = hi - lo;
         for (int k = 0; k < D; k++) {
@@ -985,6 +986,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
           if (var < 0) var = 0;
           nmean[j][l][k * T.cnt[l] + z] = ctr[j][k] + mu;
           nvar[j][l][k * T.cnt[l] + z] = var + h2[j][k]; /* moment-matched Gaussian of the sub-mixture */
+          nprec[j][l][k * T.cnt[l] + z] = 1.0 / (var + h2[j][k]); /* its precision, once per node */
         }
       }
     }
@@ -1004,10 +1006,10 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             double prec = 0, acc = 0, ss = 0, sc = 0;
             for (int q = 0; q < F; q++) {
               if (q == j || !((pm[q] >> k) & 1)) continue;
-              double mq = nmean[q][l][k * cnt + ind[q]], vq = nvar[q][l][k * cnt + ind[q]];
-              prec += 1.0 / vq;
-              if (is_circ(M, k)) { ss += sin(mq) / vq; sc += cos(mq) / vq; }
-              else acc += mq / vq;
+              double mq = nmean[q][l][k * cnt + ind[q]], rq = nprec[q][l][k * cnt + ind[q]];
+              prec += rq;
+              if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
+              else acc += mq * rq;
             }
             use[k] = ((pm[j] >> k) & 1) && prec > 0;
             vn[k] = 1.0 / prec;
@@ -1049,10 +1051,10 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
       double prec = 0, acc = 0, ss = 0, sc = 0;
       for (int q = 0; q < F; q++) {
         if (!((pm[q] >> k) & 1)) continue;
-        double mq = nmean[q][T.L][k * cnt + ind[q]], vq = nvar[q][T.L][k * cnt + ind[q]];
-        prec += 1.0 / vq;
-        if (is_circ(M, k)) { ss += sin(mq) / vq; sc += cos(mq) / vq; }
-        else acc += mq / vq;
+        double mq = nmean[q][T.L][k * cnt + ind[q]], rq = nprec[q][T.L][k * cnt + ind[q]];
+        prec += rq;
+        if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
+        else acc += mq * rq;
       }
       if (!(prec > 0)) { res[k * N + s] = old ? old[k * N + s] : 0.0; continue; } /* uninformed coordinate */
       double mu = is_circ(M, k) ? atan2(ss, sc) : acc / prec;
@@ -1067,7 +1069,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   free(res);
   for (int j = 0; j < F; j++) {
     free(idx[j]); free(xs[j]);
-    for (int l = 0; l <= T.L; l++) { free(nmean[j][l]); free(nvar[j][l]); }
+    for (int l = 0; l <= T.L; l++) { free(nmean[j][l]); free(nvar[j][l]); free(nprec[j][l]); }
   }
   levels_free(&T);
   fit_bandwidth(out, N, M); /* rebandwidth of the product */

@@ -12,7 +12,8 @@ from parity_utils import abi, iif, product_desc, rand_points
 
 lib = abi.load_library(os.path.join(R, "tools", "libnbp_dbg.so"))
 abi._lib = lib
-names = ["staging + Gibbs draws", "node statistics", "final draw"]
+names = ["staging + level bookkeeping", "node statistics", "final draw", "draw: conditional moments + uniform", "draw: pass 1 node weights",
+         "draw: shuffle combine", "draw: pass 2 rescan + broadcast"]
 for man, F in ((abi.EUCLID2, 2), (abi.EUCLID2, 3), (abi.SE2, 3)):
     for nops in (1, 2048):
         N = 200
@@ -27,6 +28,6 @@ for man, F in ((abi.EUCLID2, 2), (abi.EUCLID2, 3), (abi.SE2, 3)):
         lib.nbp_debug_phase_read(out, 64, 1)
         be.run_products(descs)
         lib.nbp_debug_phase_read(out, 64, 1)
-        tot = sum(out[40:43])
+        tot = sum(out[40:47])
         print(f"manifold {man} F={F} batch {nops}: {tot} cycles | " + ", ".join(f"{n} {out[40 + i]}" for i, n in enumerate(names)))
         be.close()
