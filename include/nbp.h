@@ -114,6 +114,11 @@ typedef struct nbp_proposal_desc {
   double spread_nh;           /* SolverParams.spreadNH (3.0)                                   */
   double comp[NBP_MAXC][NBP_COMP_STRIDE]; /* measurement model, see NBP_COMP_STRIDE            */
   uint64_t seed;              /* Philox key of this op (counter-based RNG)          */
+  uint64_t meas_seed;         /* 0: fresh measurements, drawn from `seed`.  Otherwise the measurement samples
+                                 (and Mixture labels / KDE draws) are those of the op with this seed: the
+                                 stored ccw.measurement reused when needFreshMeasurements = false, i.e. Gibbs
+                                 iterations > 1 with SolverParams.alwaysFreshMeasurements = false
+                                 (SolveTree.jl:119, services/CalcFactor.jl:492-510)            */
 } nbp_proposal_desc;
 
 /*

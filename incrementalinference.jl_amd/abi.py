@@ -42,6 +42,7 @@ class ProposalDesc(C.Structure):
         ("spread_nh", C.c_double),
         ("comp", (C.c_double * COMP_STRIDE) * MAXC),
         ("seed", C.c_uint64),
+        ("meas_seed", C.c_uint64),
     ]
 
 

@@ -377,17 +377,19 @@ def buildTreeReset(fg, eliminationOrder=None, ordering="qr"):
     return buildTreeFromOrdering(fg, order)
 
 
-def upGibbsSchedule(cliq, gibbsIters=3):
+def upGibbsSchedule(cliq, gibbsIters=3, with_iteration=False):
     """The ordered list of variable updates of upGibbsCliqueDensity (SolveTree.jl:164-239):
     fmcmc!(directFrtlMsgIDs,1); fmcmc!(msgskipIDs,1); fmcmc!(itervarIDs,iters);
-    fmcmc!(directPriorMsgIDs \\ msgskipIDs, 1).  fmcmc! forces MCMCIter=1 for a single label (:106-108)."""
+    fmcmc!(directPriorMsgIDs \\ msgskipIDs, 1).  fmcmc! forces MCMCIter=1 for a single label (:106-108).
+    with_iteration: (label, iteration of its fmcmc! call) pairs -- iteration 1 always samples fresh
+    measurements, later ones only if alwaysFreshMeasurements (:119)."""
     sched = []
 
     def fmcmc(lbls, iters):
         if len(lbls) == 1:
             iters = 1
-        for _ in range(iters):
-            sched.extend(lbls)
+        for it in range(iters):
+            sched.extend([(v, it + 1) for v in lbls] if with_iteration else lbls)
 
     fmcmc(cliq.directFrtlMsgIDs, 1)
     if cliq.msgskipIDs:

@@ -947,7 +947,12 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     for (int s = 0; s < p->n_user_stages; s++) {
       const nbp_stage &st = p->stages[s];
       if (st.kind == NBP_STAGE_PROPOSALS || st.kind == NBP_STAGE_DECONV)
-        for (int i = 0; i < st.n; i++) so.push_back((int64_t)(st.offset + (size_t)i * sizeof(nbp_proposal_desc) + offsetof(nbp_proposal_desc, seed)));
+        for (int i = 0; i < st.n; i++) {
+          const size_t o = st.offset + (size_t)i * sizeof(nbp_proposal_desc);
+          so.push_back((int64_t)(o + offsetof(nbp_proposal_desc, seed)));
+          // a reused measurement names another op's seed: re-keyed the same way, it keeps naming that op
+          if (((const nbp_proposal_desc *)(p->blob.data() + o))->meas_seed) so.push_back((int64_t)(o + offsetof(nbp_proposal_desc, meas_seed)));
+        }
       else if (st.kind == NBP_STAGE_PRODUCTS)
         for (int i = 0; i < st.n; i++) so.push_back((int64_t)(st.offset + (size_t)i * sizeof(nbp_product_desc) + offsetof(nbp_product_desc, seed)));
     }

@@ -16,16 +16,17 @@
 // ================================================================================================
 __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, const double *arena,
                                                    int64_t S, int N) {
+  const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;  // stored measurement of an earlier op, or fresh
   if (d->meas_kde > 0) {
     // the measurement is a KDE (differential message factor): sample(belief) = random kernel + bw*randn
     // (manifolds/services/ManifoldSampling.jl:13-19), like the MsgPrior draw below
     const double *msg = arena + S * (d->meas_kde - 1);
     double ua, ub, n0, n1, n2 = 0, n3 = 0;
-    uniform_pair(d->seed, n, PURP_KDESEL, 0, ua, ub);
+    uniform_pair(mseed, n, PURP_KDESEL, 0, ua, ub);
     int i = (int)(ua * N);
     if (i >= N) i = N - 1;
-    normal_pair(d->seed, n, PURP_KDENOISE, 0, n0, n1);
-    if (zdim > 2) normal_pair(d->seed, n, PURP_KDENOISE, 1, n2, n3);
+    normal_pair(mseed, n, PURP_KDENOISE, 0, n0, n1);
+    if (zdim > 2) normal_pair(mseed, n, PURP_KDENOISE, 1, n2, n3);
     z[0] = msg[i] + msg[3 * N] * n0;
     z[1] = (zdim > 1) ? msg[N + i] + msg[3 * N + 1] * n1 : 0.0;
     z[2] = (zdim > 2) ? msg[2 * N + i] + msg[3 * N + 2] * n2 : 0.0;
@@ -34,7 +35,7 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
   int c = 0;
   if (d->ncomp > 1) {  // Mixture.sampleFactor, Factors/Mixture.jl:114-155
     double ua, ub, cum = 0;
-    uniform_pair(d->seed, n, PURP_MIXLBL, 0, ua, ub);
+    uniform_pair(mseed, n, PURP_MIXLBL, 0, ua, ub);
     int last = 0;
     c = -1;
     for (int i = 0; i < d->ncomp; i++) {
@@ -47,8 +48,8 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
   }
   const double *cp = d->comp[c];
   double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-  normal_pair(d->seed, n, PURP_MEAS, 0, n0, n1);
-  if (zdim > 2) normal_pair(d->seed, n, PURP_MEAS, 1, n2, n3);
+  normal_pair(mseed, n, PURP_MEAS, 0, n0, n1);
+  if (zdim > 2) normal_pair(mseed, n, PURP_MEAS, 1, n2, n3);
   z[0] = cp[1] + cp[4] * n0;
   z[1] = (zdim > 1) ? cp[2] + cp[7] * n0 + cp[8] * n1 : 0.0;
   z[2] = (zdim > 2) ? cp[3] + cp[10] * n0 + cp[11] * n1 + cp[12] * n2 : 0.0;
@@ -153,12 +154,13 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           x[2] = is_circ(M, 2) ? wrap_pi(z[2]) : z[2];
         } else {  // MsgPrior{MKD}: sample(belief): random kernel + bw*randn (Factors/MsgPrior.jl:27-30)
           const double *msg = arena + S * d->var_slot[1];
+          const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
           double ua, ub, n0, n1, n2 = 0, n3 = 0;
-          uniform_pair(d->seed, n, PURP_KDESEL, 0, ua, ub);
+          uniform_pair(mseed, n, PURP_KDESEL, 0, ua, ub);
           int i = (int)(ua * N);
           if (i >= N) i = N - 1;
-          normal_pair(d->seed, n, PURP_KDENOISE, 0, n0, n1);
-          if (D > 2) normal_pair(d->seed, n, PURP_KDENOISE, 1, n2, n3);
+          normal_pair(mseed, n, PURP_KDENOISE, 0, n0, n1);
+          if (D > 2) normal_pair(mseed, n, PURP_KDENOISE, 1, n2, n3);
           double v0 = msg[i] + msg[3 * N] * n0;
           x[0] = is_circ(M, 0) ? wrap_pi(v0) : v0;
           if (D > 1) x[1] = msg[N + i] + msg[3 * N + 1] * n1;

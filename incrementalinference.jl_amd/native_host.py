@@ -112,6 +112,8 @@ class NativeGraph:
     def from_fg(cls, fg):
         if getattr(fg.solverParams, "useMsgLikelihoods", False):
             raise NotImplementedError("useMsgLikelihoods: the joint-message plan is compiled by the Python host (solver.TreeProgram)")
+        if not fg.solverParams.alwaysFreshMeasurements:
+            raise NotImplementedError("alwaysFreshMeasurements = false: compiled by the Python host (solver.TreeProgram)")
         g = cls(fg.solverParams)
         idx = {}
         for v in fg.ls():

@@ -32,7 +32,7 @@ PRODUCT_ID = 0xFFFF
 # descriptor builders
 # ------------------------------------------------------------------------------------------------
 def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhidx_in=-1, mhidx_out=-1,
-                  skip_bandwidth=False, inflateCycles=None, isinit=None):
+                  skip_bandwidth=False, inflateCycles=None, isinit=None, meas_seed=0):
     """One approxConvBelief(dfg, fct, target) as a libnbp descriptor (ApproxConv.jl:4-45 +
     evalFactor kwargs, EvalFactor.jl:571-603)."""
     sp = fg.solverParams
@@ -50,6 +50,7 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     d.spread_nh = sp.spreadNH
     d.nullhypo = max(fct.nullhypo, nullSurplus)  # EvalFactor.jl:352
     d.seed = seed
+    d.meas_seed = meas_seed  # needFreshMeasurements = false: reuse the samples of the op with that seed
     if isinstance(fnc, MsgPrior):
         d.nvars, d.sfidx = 1, 0
         d.var_slot[0] = slot_of(target)
@@ -535,6 +536,8 @@ class TreeProgram:
                 raise NotImplementedError("useMsgLikelihoods with cliques on several ranks")
             self.joint = jointmsg.plan_joint_messages(fg, tree)
         self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
+        self.upfresh = {}     # per clique: does step k of the up schedule draw fresh measurements?
+        self._meas_seed = {}  # (clique, factor entry) -> seed of the op that last drew its measurements
         self.heights, self.depths = tree.heights(), tree.depths()
         mine = [c for c in tree.cliques if self.owner[c] == rank]
         self.cliques = mine
@@ -564,7 +567,11 @@ class TreeProgram:
                     self.D[(cid, i)] = nxt
                     nxt += 1
             # doFMCIteration skips marginalized variables (SolveTree.jl:61)
-            sched = [v for v in bayestree.upGibbsSchedule(cl, sp.gibbsIters) if upf[v] and not fg.getVariable(v).ismargin]
+            full = [(v, it) for v, it in bayestree.upGibbsSchedule(cl, sp.gibbsIters, with_iteration=True)
+                    if upf[v] and not fg.getVariable(v).ismargin]
+            sched = [v for v, _ in full]
+            # needFreshMeasurements = iter == 1 || alwaysFreshMeasurements (SolveTree.jl:119)
+            self.upfresh[cid] = [it == 1 or sp.alwaysFreshMeasurements for _, it in full]
             self.upsched[cid], self.upfacs[cid] = sched, upf
             if self.joint is None:
                 dnf = {v: [("f", f) for f in fg.ls(v)] for v in cl.frontalIDs}
@@ -613,7 +620,7 @@ class TreeProgram:
     def _msg_slot(self, child, v):
         return self.B[(child, v)] if self.owner[child] == self.rank else self.ghost[(child, v)]
 
-    def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step):
+    def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step, fresh=True):
         fg, sp = self.fg, self.fg.solverParams
         base, _ = self.scratch[cid]
         fcts = []
@@ -626,8 +633,13 @@ class TreeProgram:
             else:  # child message -> MsgPrior (generateMsgPrior, TreeMessageUtils.jl:86-89)
                 fcts.append(DFGFactor(f"msg{ref}_{v}", [v], MsgPrior(self._msg_slot(ref, v)), None, 0.0, sp.inflation))
         ns = _null_surplus(fg, fcts)
-        props = [proposal_desc(fg, f, v, slot_of, base + i, op_seed(self.seed, passid, cid, step, i + 1), nullSurplus=ns[i])
-                 for i, f in enumerate(fcts)]
+        props = []
+        for i, f in enumerate(fcts):
+            sd, key = op_seed(self.seed, passid, cid, step, i + 1), (cid, entries[i])
+            if fresh:  # the factor's ccw.measurement is overwritten (CalcFactor.jl:492-510)
+                self._meas_seed[key] = sd
+            props.append(proposal_desc(fg, f, v, slot_of, base + i, sd, nullSurplus=ns[i],
+                                       meas_seed=0 if fresh else self._meas_seed.get(key, 0)))
         man = fg.getVariable(v).varType.manifold
         prod = product_desc(man, [base + i for i in range(len(fcts))], out_slot,
                             op_seed(self.seed, passid, cid, step, PRODUCT_ID), sp.productNiter,
@@ -675,7 +687,8 @@ class TreeProgram:
                     if k >= len(sched):
                         continue
                     v = sched[k]
-                    p, q = self._update_ops(c, v, self.upfacs[c][v], lambda u, c=c: self.B[(c, u)], self.B[(c, v)], PASS_UP, k)
+                    p, q = self._update_ops(c, v, self.upfacs[c][v], lambda u, c=c: self.B[(c, u)], self.B[(c, v)], PASS_UP, k,
+                                            fresh=self.upfresh[c][k])
                     props += p
                     prods.append(q)
                     self.n_updates_up += 1
@@ -779,7 +792,9 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
     sp = fg.solverParams
     t0 = time.perf_counter()
     if sp.graphinit:
-        initAll(fg, backend=backend if (backend is None or not hasattr(backend, 'slot_write')) else None, seed=seed)
+        # a backend INSTANCE is sized for the tree solve: graph initialisation makes its own from the same class
+        initAll(fg, backend=backend if (backend is None or isinstance(backend, type) or not hasattr(backend, 'slot_write'))
+                else type(backend), seed=seed)
     t1 = time.perf_counter()
     if tree is None:
         tree = bayestree.buildTreeReset(fg, eliminationOrder, ordering)
@@ -788,8 +803,8 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
     # Python mirror otherwise (oracle backend in the tests); both produce the same descriptors
     use_native = native if native is not None else (backend is None or backend is HipBackend or isinstance(backend, HipBackend)
                                                     or getattr(backend, "is_hip", False))
-    if getattr(sp, "useMsgLikelihoods", False):
-        use_native = False  # the joint-message plan is compiled by the Python host (jointmsg.py)
+    if getattr(sp, "useMsgLikelihoods", False) or not sp.alwaysFreshMeasurements:
+        use_native = False  # joint messages (jointmsg.py) and stored measurements: compiled by the Python host
     if use_native:
         from . import native_host
         ng = native_host.NativeGraph.from_fg(fg)

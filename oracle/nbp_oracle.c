@@ -681,17 +681,19 @@ void orc_run_bandwidth(double *arena, int32_t N, int32_t slot, int32_t manifold)
 /* Proposal = approxConvBelief (ApproxConv.jl:4-45)                                            */
 /* ------------------------------------------------------------------------------------------ */
 static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, int *label, const double *arena, int N) {
+  /* needFreshMeasurements = false (SolveTree.jl:119): the samples are the ones an earlier op drew */
+  const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
   if (d->meas_kde > 0) {
     /* the measurement is a KDE (LinearRelative(::MKD) / CircularCircular(::MKD), the differential factors
      * of TreeMessageUtils.jl:279-335): sampleTangent(M, ::MKD) = sample(belief, 1) = random kernel +
      * bw*randn (manifolds/services/ManifoldSampling.jl:13-19) */
     const double *msg = arena + orc_slot_stride(N) * (d->meas_kde - 1);
     double ua, ub, nn[4];
-    orc_uniform_pair(d->seed, n, PURP_KDESEL, 0, &ua, &ub);
+    orc_uniform_pair(mseed, n, PURP_KDESEL, 0, &ua, &ub);
     int i = (int)(ua * N);
     if (i >= N) i = N - 1;
-    orc_normal_pair(d->seed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
-    if (zdim > 2) orc_normal_pair(d->seed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
+    orc_normal_pair(mseed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
+    if (zdim > 2) orc_normal_pair(mseed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
     for (int k = 0; k < 3; k++) z[k] = k < zdim ? msg[k * N + i] + msg[3 * N + k] * nn[k] : 0.0;
     if (label) *label = 0;
     return;
@@ -701,14 +703,14 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
   if (d->ncomp > 1) {
     double w[NBP_MAXC], ua, ub;
     for (int i = 0; i < d->ncomp; i++) w[i] = d->comp[i][0];
-    orc_uniform_pair(d->seed, n, PURP_MIXLBL, 0, &ua, &ub);
+    orc_uniform_pair(mseed, n, PURP_MIXLBL, 0, &ua, &ub);
     c = categorical(w, d->ncomp, ua);
   }
   if (label) *label = c;
   const double *cp = d->comp[c];
   double nn[4];
-  orc_normal_pair(d->seed, n, PURP_MEAS, 0, &nn[0], &nn[1]);
-  if (zdim > 2) orc_normal_pair(d->seed, n, PURP_MEAS, 1, &nn[2], &nn[3]);
+  orc_normal_pair(mseed, n, PURP_MEAS, 0, &nn[0], &nn[1]);
+  if (zdim > 2) orc_normal_pair(mseed, n, PURP_MEAS, 1, &nn[2], &nn[3]);
   for (int i = 0; i < zdim; i++) { /* rand(MvNormal(mu, L L')) */
     double acc = cp[1 + i];
     for (int j = 0; j <= i; j++) acc += cp[4 + i * 3 + j] * nn[j];
@@ -794,12 +796,13 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
           for (int k = 0; k < D; k++) X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[k]) : z[k];
         } else { /* MsgPrior{MKD}: sample(belief,1): random kernel + bw*randn, Factors/MsgPrior.jl:27-30 */
           const double *msg = arena + S * d->var_slot[1];
+          const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
           double ua, ub, nn[4];
-          orc_uniform_pair(d->seed, n, PURP_KDESEL, 0, &ua, &ub);
+          orc_uniform_pair(mseed, n, PURP_KDESEL, 0, &ua, &ub);
           int i = (int)(ua * N);
           if (i >= N) i = N - 1;
-          orc_normal_pair(d->seed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
-          if (D > 2) orc_normal_pair(d->seed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
+          orc_normal_pair(mseed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
+          if (D > 2) orc_normal_pair(mseed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
           for (int k = 0; k < D; k++) {
             double v = msg[k * N + i] + msg[3 * N + k] * nn[k];
             X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(v) : v;

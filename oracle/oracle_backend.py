@@ -180,6 +180,8 @@ class OracleProgram:
             if kind != abi.STAGE_COPIES:
                 for d in arr:
                     d.seed = mix_seed(d.seed, salt)
+                    if kind != abi.STAGE_PRODUCTS and d.meas_seed:
+                        d.meas_seed = mix_seed(d.meas_seed, salt)
 
     def close(self):
         pass

@@ -501,3 +501,25 @@ def test_differential_factor_validation(hip_backend):
     with pytest.raises(iif.NbpError):  # deconvolution stages take relative factors
         be.program([(abi.STAGE_DECONV, [p])])
     be.close()
+
+
+def test_stored_measurements_gpu(oracle_backend, hip_backend):
+    """needFreshMeasurements = false: `meas_seed` (SolveTree.jl:119) on the device, incl. program re-keying,
+    and the same proposals GPU against oracle"""
+    from test_stored_measurements import check_stored_measurements
+    check_stored_measurements(hip_backend)
+    N, man = 200, abi.EUCLID2
+    rng = np.random.default_rng(77)
+    a, b = rand_points(rng, man, N, 0.0, 0.3), rand_points(rng, man, N, 2.0, 0.3)
+    d1 = relative_factor_desc(abi.F_LINREL, man, 2, 1, [0, 1], 2, 31, [1.0, 1.0], [0.3, 0.3])
+    d2 = relative_factor_desc(abi.F_LINREL, man, 2, 0, [0, 1], 3, 32, [1.0, 1.0], [0.3, 0.3])
+    d2.meas_seed = 31
+
+    def setup(be):
+        be.slot_write(0, man, a)
+        be.slot_write(1, man, b)
+
+    o, h = both(oracle_backend, hip_backend, N, 4, 0, setup, lambda be: be.run_proposals([d1, d2]),
+                lambda be: [be.slot_read(s, man)[0] for s in (2, 3)])
+    for k in range(2):
+        assert_points_close(man, h[k], o[k], rtol=1e-8, max_bad=1, what=f"proposal {k}")
