@@ -671,11 +671,7 @@ __device__ long long nbp_phase_clk[64];
 #endif
 
 typedef __attribute__((address_space(3))) double nbp_lds_double;
-#ifdef NBP_EXPERIMENT_NO_PARTNER_ACC
-__device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { if (v < -1.0) (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
-#else
 __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
-#endif
 
 // squared geodesic distance on the circle for a difference within (-3pi, 3pi): min(|d|, ||d| - 2pi|)^2,
 // two VALU operations instead of a wrap (equal to wrap_pi(d)^2 up to the rounding of one subtraction)
