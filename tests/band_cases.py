@@ -638,3 +638,110 @@ def case_joint_messages_caesar_ring(backend):
 
 
 CASES += [case_joint_messages_circular, case_joint_messages_has_priors, case_joint_messages_caesar_ring]
+
+
+def _ppe(fg, v):
+    return float(np.median(fg.getVal(v)[:, 0]))
+
+
+def case_two_priors_tight_links(backend):
+    # test/priorusetest.jl:12-123: priors N(-1, 1) and N(+1, 1) at the two ends of very tight links (sigma 0.01):
+    # every mean within 1.0 (1.2 for landmarks) of 0 and all of them within 0.4 / 0.3 of their average
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for v in ("x0", "x1", "x2"):
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(-1.0, 1.0)))
+    iif.addFactor(fg, ["x2"], iif.Prior(iif.Normal(+1.0, 1.0)))
+    iif.addFactor(fg, ["x0", "x1"], iif.LinearRelative(iif.Normal(0.0, 0.01)))
+    iif.addFactor(fg, ["x1", "x2"], iif.LinearRelative(iif.Normal(0.0, 0.01)))
+    iif.solveTree(fg, backend=backend, seed=140)
+    m = np.array([fg.getVal(v)[:, 0].mean() for v in ("x0", "x1", "x2")])
+    assert (np.abs(m) < 1.0).all() and (np.abs(m - m.mean()) < 0.4).all(), m
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for v in ("x0", "l0", "l1", "x1", "x2"):
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(-1.0, 1.0)))
+    iif.addFactor(fg, ["l0"], iif.Prior(iif.Normal(+1.0, 1.0)))
+    for a, b in (("x0", "l0"), ("x0", "l1"), ("x0", "x1"), ("x1", "x2"), ("x2", "l0"), ("x2", "l1")):
+        iif.addFactor(fg, [a, b], iif.LinearRelative(iif.Normal(0.0, 0.01)))
+    iif.solveTree(fg, backend=backend, seed=141)
+    m = np.array([fg.getVal(v)[:, 0].mean() for v in ("x0", "x1", "x2", "l0", "l1")])
+    assert (np.abs(m[:3]) < 1.0).all() and (np.abs(m[3:]) < 1.2).all() and (np.abs(m - m.mean()) < 0.3).all(), m
+
+
+def case_pose_pose_constraint(backend):
+    # test/testlocalconstraintexamples.jl:8-44: a wide prior at the door (the reference builds it from a one-point
+    # KDE with bandwidth 3) and LinearRelative(N(50, 2)): the convolution and the solved x2 sit at 50 +- 15
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1"], iif.Prior(iif.Normal(0.0, 3.0)))
+    iif.addVariable(fg, "x2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "x2"], iif.LinearRelative(iif.Normal(50.0, 2.0)))
+    iif.initAll(fg, backend=backend, seed=142)
+    pts = iif.approxConv(fg, "x1x2f1", "x2", backend=backend, seed=143)
+    assert abs(pts[:, 0].mean() - 50.0) < 15.0
+    iif.solveTree(fg, backend=backend, seed=144)
+    assert abs(fg.getVal("x2")[:, 0].mean() - 50.0) < 15.0
+
+
+def case_multihypo_three_landmarks(backend):
+    # test/TestCSMMultihypo.jl:9-73 (#427: no runaway on the up solve) and test/testCalcFactorHypos.jl:41-78
+    # (#424: the multihypo vector must have one entry per variable; the fractional factor solves)
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for v, mu in (("l1", 50.0), ("l2", -50.0)):
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+        iif.addFactor(fg, [v], iif.Prior(iif.Normal(mu, 0.1)))
+    for v in ("l1_0", "l2_0", "x1"):
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "l1", "l1_0"], iif.LinearRelative(iif.Normal(40.0, 0.25)), multihypo=[1.0, 0.5, 0.5])
+    iif.addVariable(fg, "x2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "x2"], iif.LinearRelative(iif.Normal(0.0, 0.1)))
+    iif.addFactor(fg, ["x2", "l2", "l2_0"], iif.LinearRelative(iif.Normal(-40.0, 0.25)), multihypo=[1.0, 0.5, 0.5])
+    iif.solveTree(fg, backend=backend, seed=145)
+    for v in fg.ls():
+        assert np.isfinite(fg.getVal(v)).all()
+    for v, mu in (("l1", 50.0), ("l2", -50.0)):  # the landmarks with priors stay put
+        assert abs(_ppe(fg, v) - mu) < 1.0
+    fg = iif.initfg(iif.SolverParams(N=100))
+    for v in ("x0", "x1_a", "x1_b"):
+        iif.addVariable(fg, v, iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal()))
+    try:
+        iif.addFactor(fg, ["x0", "x1_a", "x1_b"], iif.LinearRelative(iif.Normal(10.0, 1.0)), multihypo=[0.5, 0.5])
+        raise AssertionError("a multihypo vector shorter than the variable list must be rejected (#424)")
+    except ValueError:
+        pass
+    f = iif.addFactor(fg, ["x0", "x1_a", "x1_b"], iif.LinearRelative(iif.Normal(10.0, 1.0)), multihypo=[1, 0.5, 0.5])
+    assert f.isMultihypo and not fg.getFactor("x0f1").isMultihypo
+    iif.solveTree(fg, backend=backend, seed=146)
+    assert abs(_ppe(fg, "x0")) < 1.0
+
+
+def case_joint_messages_xstroke(backend):
+    # test/testExpXstroke.jl:10-128 (#754, the endless-cycle graphs), all with useMsgLikelihoods = true:
+    # PPE of every variable at its index within 0.2 / 0.4 / 0.45
+    def solve(fg, seed):
+        fg.solverParams.useMsgLikelihoods = True
+        iif.solveTree(fg, backend=backend, seed=seed)
+
+    sp = lambda: iif.SolverParams(N=100)
+    fg = iif.generateGraph_LineStep(5, poseEvery=1, landmarkEvery=5, posePriorsAt=(0, 2), sightDistance=4, solverParams=sp())
+    solve(fg, 147)
+    for v in fg.ls():
+        assert abs(_ppe(fg, v) - int(v.lstrip("xlm"))) < 0.2, (v, _ppe(fg, v))
+    N = 8
+    fg = iif.generateGraph_LineStep(N, poseEvery=1, landmarkEvery=N + 1, posePriorsAt=(0,), landmarkPriorsAt=(), sightDistance=N + 1,
+                                    solverParams=sp())
+    for i in range(1, N):
+        iif.deleteFactor(fg, f"x{i}lm0f1")
+    solve(fg, 148)
+    for v in fg.ls():
+        assert abs(_ppe(fg, v) - int(v.lstrip("xlm"))) < 0.4, (v, _ppe(fg, v))
+    fg = iif.generateGraph_LineStep(15, poseEvery=1, landmarkEvery=3, posePriorsAt=(0, 7, 12), landmarkPriorsAt=(0, 3), sightDistance=2,
+                                    solverParams=sp())
+    solve(fg, 149)
+    for v in fg.ls():
+        assert abs(_ppe(fg, v) - int(v.lstrip("xlm"))) < 0.45, (v, _ppe(fg, v))
+
+
+CASES += [case_two_priors_tight_links, case_pose_pose_constraint, case_multihypo_three_landmarks, case_joint_messages_xstroke]
