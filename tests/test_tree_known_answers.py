@@ -123,3 +123,58 @@ def test_linestep_clique_frontals_separators_potentials():
     assert set(c2.frontalIDs) == {"x4", "lm4"} and c2.separatorIDs == ["x2"]
     assert set(c2.potentials) == {"x2lm4f1", "x2x4f1", "x4lm4f1", "lm4f1"}
     assert clique_of(tree, "x2") is c1 and c2.parent == 1
+
+
+def test_isam2_example_has_three_cliques():
+    # test/testBayesTreeiSAM2Example.jl:5-52: the iSAM2 paper example, order [l1, l2, x1, x2, x3] -> 3 cliques
+    fg = iif.initfg(iif.SolverParams(N=100))
+    iif.addVariable(fg, "x1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1"], iif.Prior(iif.Normal()))
+    iif.addVariable(fg, "x2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "x2"], iif.LinearRelative(iif.Normal()))
+    iif.addVariable(fg, "x3", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x2", "x3"], iif.LinearRelative(iif.Normal()))
+    iif.addVariable(fg, "l1", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x1", "l1"], iif.LinearRelative(iif.Normal()))
+    iif.addFactor(fg, ["x2", "l1"], iif.LinearRelative(iif.Normal()))
+    iif.addVariable(fg, "l2", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x3", "l2"], iif.LinearRelative(iif.Normal()))
+    tree = iif.buildTreeReset(fg, ["l1", "l2", "x1", "x2", "x3"])
+    assert len(tree.cliques) == 3
+    # every factor is the potential of exactly one clique
+    pots = [f for cl in tree.cliques.values() for f in cl.potentials]
+    assert sorted(pots) == sorted(fg.lsf())
+
+
+def test_tree_message_utils_structure():
+    # test/testTreeMessageUtils.jl:6-43: LineStep(8) with only the two end sightings of lm0, fixed elimination
+    # order: cliques 2..8 send up messages, clique 2's message carries {x0, x4}, the messages stacked by
+    # variable cover {lm0, x0, x2, x4, x6, x7}, x0 is in three of them, x4 in those of cliques (depth)
+    # 4 (2), 6 (3), 2 (1), 8 (1); clique 7 is a child of clique 3
+    N = 8
+    fg = iif.generateGraph_LineStep(N, poseEvery=1, landmarkEvery=N + 1, posePriorsAt=(0,), landmarkPriorsAt=(), sightDistance=N + 1)
+    for i in range(1, N):
+        iif.deleteFactor(fg, f"x{i}lm0f1")
+    tree = iif.buildTreeReset(fg, ["x3", "x8", "x5", "x1", "x6", "lm0", "x7", "x4", "x2", "x0"])
+    senders = sorted(c for c, cl in tree.cliques.items() if cl.parent >= 0)
+    assert senders == list(range(2, 9))
+    assert sorted(tree.cliques[2].separatorIDs) == ["x0", "x4"]
+    stacked = {}
+    depths = tree.depths()
+    for c in senders:
+        for v in tree.cliques[c].separatorIDs:
+            stacked.setdefault(v, []).append((c, depths[c]))
+    assert sorted(stacked) == ["lm0", "x0", "x2", "x4", "x6", "x7"]
+    assert len(stacked["x0"]) == 3
+    assert sorted(stacked["x4"]) == sorted([(4, 2), (6, 3), (2, 1), (8, 1)])
+    assert tree.cliques[7].parent == 3
+    # the native host builds the same tree
+    from iif_amd import native_host
+    g = native_host.NativeGraph.from_fg(fg)
+    nt = g.build_tree(tree.eliminationOrder)
+    assert nt.n_cliques == 8
+    for c in range(1, 9):
+        info = nt.clique(c)
+        assert sorted(info["frontals"]) == sorted(tree.cliques[c].frontalIDs)
+        assert sorted(info["separators"]) == sorted(tree.cliques[c].separatorIDs)
+        assert info["parent"] == max(tree.cliques[c].parent, 0)
