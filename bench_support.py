@@ -93,7 +93,7 @@ class RankSolve:
             pts, _ = self.be.slot_read(self.main[f"x{i}"], fg.getVariable(f"x{i}").varType.manifold)
             worst = max(worst, float(np.abs(pts.mean(axis=0) - i).max()))
         self.posterior_max_mean_err = worst
-        # NBP posteriors carry Monte-Carlo error of the order of the posterior sigma (~0.5 midway
-        # between priors); the CPU oracle shows the same level (tests/test_gpu_tree_parity.py)
-        if not worst < 1.5:
+        # NBP posteriors carry Monte-Carlo error of a fraction of the posterior sigma (~0.5-0.7 midway
+        # between priors; observed worst mean error ~0.3); the CPU oracle shows the same level
+        if not worst < 1.0:
             raise RuntimeError(f"posterior means off by {worst}: result invalid")

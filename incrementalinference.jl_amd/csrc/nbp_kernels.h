@@ -556,7 +556,7 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
     L->nw = base + nw; L->tab = base + tab;
     L->ind = (int *)(base + ints0);
   }
-  return ints0 * 8 + (size_t)F * SPB * 4;
+  return ints0 * 8 + (size_t)F * SPB * 4 * 2;  // ind[F][SPB] | nxt[F][SPB]
 }
 
 // PARTIAL: some input density is partial (AMP.marginal(propBel, pardims), ApproxConv.jl:287-291): a
@@ -593,6 +593,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     h2[t] = (k < D) ? bw * bw : 0.0;
     cen[t] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
   }
+  int *nxt = ind + F * SPB;  // the child each selected node hands its label to on the next level
   if (h == 0)
     for (int j = 0; j < F; j++) ind[j * SPB + sl] = 0;  // levelInit!: root
   // ---- multiscale Gibbs ---------------------------------------------------------------------
@@ -616,8 +617,17 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       lr[jk * N + z] = 1.0 / vz;  // the precision, once per node: the draws below only multiply
     }
     for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
+    // levelDown!: the label moves to a child of the selected node drawn by its share of the leaves (always
+    // taking the same child biases the product towards that side of every split); the coin is the spare
+    // uniform of the density's last draw on the level above, or a draw of its own below the root
     if (h == 0 && live)
-      for (int j = 0; j < F; j++) ind[j * SPB + sl] = T.node_child[T.off[l - 1] + ind[j * SPB + sl]];  // levelDown!
+      for (int j = 0; j < F; j++) {
+        if (l > 1) { ind[j * SPB + sl] = nxt[j * SPB + sl]; continue; }
+        double ua, ub;
+        uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)j, ua, ub);
+        const int len = T.node_hi[0] - T.node_lo[0], last = T.node_child[0];
+        ind[j * SPB + sl] = (len <= 1 || !(ua * (double)len < (double)((len + 1) / 2))) ? last : last - 1;
+      }
     __syncthreads();
     NBP_CTICK(41);  // node statistics + levelDown
     const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range
@@ -633,7 +643,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         // Pass 1 (all helpers, NCH chunks each): rescaled totals -> shuffle max / prefix sum.
         // Pass 2 (the helper whose share holds u * total): locate the chunk, re-evaluate just that chunk.
         constexpr int NCH = 4;
-        double mn[D], vn[D], ua = 0, m = -INFINITY, tot = 0;
+        double mn[D], vn[D], ua = 0, ub = 0, m = -INFINITY, tot = 0;
         double cs[NCH], ms[NCH];
         const double *mj = lm + j * D * N, *vj = lv + j * D * N;
         double linv[D];
@@ -698,7 +708,6 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
             for (int k = 0; k < D; k++) linv[k] = (PARTIAL && !use[k]) ? 0.0 : 1.0 / (h2[j * 3 + k] + vn[k]);
           }
-          double ub;
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
           NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
 #pragma unroll
@@ -788,7 +797,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
         for (int o = 1; o < HL; o <<= 1) choice = max(choice, __shfl_xor(choice, o, HL));
         if (choice < 0) choice = cnt - 1;  // rounding left u * total beyond the last share
-        if (h == 0 && live) ind[j * SPB + sl] = choice;
+        if (h == 0 && live) {
+          ind[j * SPB + sl] = choice;
+          if (!leaf) {
+            const int len = T.node_hi[off + choice] - T.node_lo[off + choice], last = T.node_child[off + choice];
+            nxt[j * SPB + sl] = (len <= 1 || !(ub * (double)len < (double)((len + 1) / 2))) ? last : last - 1;
+          }
+        }
         NBP_CTICK(46);  // pass 2: rescan of the chosen chunk + broadcast of the choice
       }
     }

@@ -786,6 +786,30 @@ class TreeProgram:
                 "alg_bytes": self.alg_bytes, "cliques": len(self.cliques)}
 
 
+def _initialised_subgraph(fg):
+    """The part of the graph a tree solve can work on.  Variables graph initialisation could not reach (no
+    path to a prior) stay uninitialised and unsolved in the reference -- their cliques give up in tree
+    initialisation (CliqueStateMachine.jl:562-575, test/testBasicTreeInit.jl:81-106) -- so they and the factors
+    touching them are left out here.  Returns `fg` itself when everything is initialised."""
+    out = [v for v in fg.ls() if not fg.getVariable(v).initialized]
+    if not out:
+        return fg
+    from .factorgraph import FactorGraph
+    sub = FactorGraph(fg.solverParams)
+    drop = set(out)
+    for v in fg.ls():
+        if v not in drop:
+            sub.variables[v] = fg.getVariable(v)  # shared objects: results land in the caller's graph
+            sub._adj[v] = []
+    for f in fg.lsf():
+        fc = fg.getFactor(f)
+        if not drop.intersection(fc.variables):
+            sub.factors[f] = fc
+            for v in fc.variables:
+                sub._adj[v].append(f)
+    return sub
+
+
 def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, ordering="qr", return_timing=False, native=None):
     """solveTree!(dfg; eliminationOrder) -> tree   (SolverAPI.jl:326-493).
     graphinit -> buildTreeReset! -> up pass -> down pass -> posteriors written back to `fg`."""
@@ -796,6 +820,14 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
         initAll(fg, backend=backend if (backend is None or isinstance(backend, type) or not hasattr(backend, 'slot_write'))
                 else type(backend), seed=seed)
     t1 = time.perf_counter()
+    whole = fg
+    fg = _initialised_subgraph(fg)
+    if fg is not whole:
+        if tree is not None:
+            raise ValueError("a prebuilt tree needs every variable initialised: "
+                             + ", ".join(v for v in whole.ls() if not whole.getVariable(v).initialized))
+        if eliminationOrder is not None:
+            eliminationOrder = [v for v in eliminationOrder if v in fg.variables]
     if tree is None:
         tree = bayestree.buildTreeReset(fg, eliminationOrder, ordering)
     t2 = time.perf_counter()

@@ -997,9 +997,18 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   double *res = (double *)malloc(sizeof(double) * 3 * N);
   for (int s = 0; s < N; s++) {
     int ind[NBP_MAXF];
-    for (int j = 0; j < F; j++) ind[j] = 0; /* levelInit!: root */
+    double coin[NBP_MAXF];
+    for (int j = 0; j < F; j++) { ind[j] = 0; coin[j] = 0.0; } /* levelInit!: root */
     for (int l = 1; l <= T.L; l++) {
-      for (int j = 0; j < F; j++) ind[j] = T.child[l - 1][ind[j]]; /* levelDown! */
+      for (int j = 0; j < F; j++) { /* levelDown!: a child of the selected node, drawn by its share of the leaves */
+        const int z = ind[j], len = T.hi[l - 1][z] - T.lo[l - 1][z], last = T.child[l - 1][z];
+        if (len <= 1) { ind[j] = last; continue; } /* a leaf is carried down as its own only child */
+        double ua, ub;
+        if (l == 1) orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)j, &ua, &ub); /* level 0 has no draw of its own */
+        else ua = coin[j]; /* the spare uniform of this density's last draw on the level above */
+        const int nleft = (len + 1) / 2;
+        ind[j] = (ua * (double)len < (double)nleft) ? last - 1 : last;
+      }
       const int cnt = T.cnt[l];
       for (int it = 0; it < d->niter; it++) {
         for (int j = 0; j < F; j++) { /* sequential Gibbs sweep: sampleIndex(j) */
@@ -1042,6 +1051,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             if (choice < 0) choice = cnt - 1;
           }
           if (choice >= 0) ind[j] = choice;
+          coin[j] = ub;
         }
       }
     }

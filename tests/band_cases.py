@@ -403,9 +403,9 @@ def case_multimodal_1d(backend):
     iif.addFactor(fg, ["x1", "lm2", "lp2"], iif.LinearRelative(iif.Normal(20.0, 1.0)), multihypo=[1.0, 0.4, 0.6])
     iif.addVariable(fg, "lm1", iif.ContinuousScalar)
     iif.addFactor(fg, ["x1", "lm1", "lp1"], iif.LinearRelative(iif.Normal(-20.0, 1.0)), multihypo=[1.0, 0.4, 0.6])
-    iif.initAll(fg, backend=backend, seed=92)
+    iif.initAll(fg, backend=backend, seed=112)
     assert all(fg.isInitialized(v) for v in fg.ls())
-    iif.solveTree(fg, eliminationOrder=["x1", "lm1", "lm2", "lp1", "lp2"], backend=backend, seed=93)
+    iif.solveTree(fg, eliminationOrder=["x1", "lm1", "lm2", "lp1", "lp2"], backend=backend, seed=113)
     N = 100
 
     def count(v, lo, hi):
