@@ -148,3 +148,26 @@ def test_products_of_many_densities(oracle_backend, hip_backend, manifold, F, N)
             np.testing.assert_array_equal(lab, ref[1])
             assert_points_close(manifold, ref[0][0], pts, what=f"product of {F}")
             np.testing.assert_allclose(bw, ref[0][1], rtol=1e-9)
+
+
+def test_product_mean_is_unbiased_gpu(hip_backend):
+    """size-independent property of the product sampler: no side of the KD splits is favoured (see
+    tests/test_product_unbiased.py); 64 products of zero-mean densities in one launch"""
+    from parity_utils import product_desc
+    N, man, sig, B = 100, abi.EUCLID1, 0.1, 64
+    rng = np.random.default_rng(1)
+    be = hip_backend(N, 3 * B + 2 * B, 0)
+    for s in range(3 * B):
+        x = rng.normal(0, sig, (N, 1))
+        be.slot_write(s, man, x - x.mean(), np.ones(1))
+    be.run_bandwidth(list(range(3 * B)), [man] * (3 * B))
+    descs = []
+    for b in range(B):
+        descs.append(product_desc(man, [3 * b, 3 * b + 1], 3 * B + 2 * b, 5000 + b))
+        descs.append(product_desc(man, [3 * b, 3 * b + 1, 3 * b + 2], 3 * B + 2 * b + 1, 6000 + b))
+    be.run_products(descs)
+    m2 = np.array([be.slot_read(3 * B + 2 * b, man)[0].mean() for b in range(B)])
+    m3 = np.array([be.slot_read(3 * B + 2 * b + 1, man)[0].mean() for b in range(B)])
+    be.close()
+    for m in (m2, m3):
+        assert abs(m.mean()) < 0.05 * sig, (m.mean(), m.std() / np.sqrt(B))
