@@ -12,7 +12,7 @@ def main(path, steps, lps=67):
     for r in rows:
         name = r["Kernel_Name"].split("(")[0]
         if name.startswith("nbp_product_kernel"):
-            name = "nbp_product_kernel(l8|m4|t2)"  # one launch per stage, three geometries
+            name = "nbp_product_kernel(x16|l8|m4|t2)"  # one launch per stage, three geometries
         if name.startswith("nbp_"):
             by[name].append(r)
     print(f"{'kernel':34s} {'launches':>8s} {'avg_us':>10s} {'total_ms':>9s} | avg_us by grid size (blocks): <=8, <=64, <=300, >300")
