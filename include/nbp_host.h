@@ -12,6 +12,7 @@
  *   src/services/SolveTree.jl:164-239           upGibbsCliqueDensity (schedule)
  *   src/CliqueStateMachine/services/CliqStateMachineUtils.jl:424-571  down sequence / products
  *   src/services/TreeMessageUtils.jl:66-89,542-578   message factors <-> slots
+ *   src/services/TreeMessageUtils.jl:126-193,279-456  joint upward messages (useMsgLikelihoods, a solver flag)
  * so that a host (the Julia shim, or the Python mirror in this repo) can hand over a graph and an
  * elimination order and get the same staged program the Python reference implementation of this repo
  * (bayestree.py / solver.TreeProgram) builds -- byte for byte, which is how it is tested.
@@ -36,11 +37,17 @@ typedef struct nbp_solver_params {
   int32_t inflate_cycles;  /* inflateCycles (3)                                      */
   int32_t product_niter;   /* Niter of AMP.manifoldProduct (1)                       */
   int32_t upsolve, downsolve, limitfixeddown;
-  int32_t pad_;
+  int32_t flags;           /* 0 = the reference's defaults; enum nbp_solver_flag                */
   double spread_nh;        /* spreadNH (3.0)                                         */
   double inflation;        /* inflation (5.0): default of a factor without its own   */
   double null_surplus_add; /* nullSurplusAdd (0.3)                                   */
 } nbp_solver_params;
+
+enum nbp_solver_flag {
+  NBP_SOLVER_STORED_MEASUREMENTS = 1, /* alwaysFreshMeasurements = false (SolverParams.jl:69, SolveTree.jl:119) */
+  NBP_SOLVER_MSG_LIKELIHOODS = 2      /* useMsgLikelihoods = true: joint upward messages (SolverParams.jl:25,
+                                         TreeMessageUtils.jl:279-456, 538-578)                                  */
+};
 
 /* one factor: addFactor!(dfg, Xi, usrfnc; multihypo, nullhypo, inflation) (FactorGraph.jl:824-875) */
 typedef struct nbp_factor_spec {

@@ -7,6 +7,8 @@
 // orders, cliques, schedules and descriptor bytes, and tests/test_tree_known_answers.py pins the Python
 // side against the reference's own known answers.
 #include <algorithm>
+#include <array>
+#include <deque>
 #include <cstring>
 #include <map>
 #include <set>
@@ -49,6 +51,14 @@ struct Clique {
   std::vector<int> frontals, seps, children, potentials, dwnPotentials, inmsg;
   std::vector<int> directPriorMsg, directvar, itervar, msgskip, directFrtlMsg;
   std::vector<int> upsched, dnsched;
+  std::vector<int> upiter;  // iteration (1-based) of the fmcmc! call each up-schedule entry belongs to
+  // useMsgLikelihoods (jointmsg.py): the clique sub graph during the up solve and the joint message sent up
+  struct SubFac { char tag; int a, b; std::vector<int> vars; int tname; bool is_prior; int kind; };
+  std::vector<SubFac> jf;                  // 'f': a = factor id | 'd': a = child, b = index | 'p': a = child, b = variable
+  std::vector<std::array<int, 4>> rel;     // differential factors sent up: (sym1, sym2, type name, factor kind)
+  std::vector<int> jpriors;                // separators that get a MsgPrior in the message
+  bool hasPriors = false;
+  std::vector<int> Dslot;                  // slot of the KDE of each differential factor
   std::vector<int> all() const {
     std::vector<int> a = frontals;
     a.insert(a.end(), seps.begin(), seps.end());
@@ -85,6 +95,10 @@ struct nbp_tree {
   // compile products
   std::vector<Stage> stages;
   nbp_tree_stats st{};
+  bool joint = false;   // NBP_SOLVER_MSG_LIKELIHOODS
+  bool stored = false;  // NBP_SOLVER_STORED_MEASUREMENTS
+  std::vector<std::vector<int>> jdnsched;  // joint mode: down schedule per clique
+  std::map<std::array<int, 5>, uint64_t> meas_seed;  // (clique, tag, a, b, variable of a message) -> seed of the last fresh draw
 };
 
 namespace {
@@ -378,7 +392,10 @@ void schedules(nbp_tree *t) {
   for (Clique &c : t->cl) {
     auto fmcmc = [&](const std::vector<int> &l, int it) {
       if (l.size() == 1) it = 1;
-      for (int k = 0; k < it; k++) c.upsched.insert(c.upsched.end(), l.begin(), l.end());
+      for (int k = 0; k < it; k++) {
+        c.upsched.insert(c.upsched.end(), l.begin(), l.end());
+        c.upiter.insert(c.upiter.end(), l.size(), k + 1);
+      }
     };
     fmcmc(c.directFrtlMsg, 1);
     if (!c.msgskip.empty()) fmcmc(c.msgskip, 1);
@@ -414,7 +431,169 @@ void schedules(nbp_tree *t) {
 }
 
 // ---- compile (solver.TreeProgram) -----------------------------------------------------------------
-struct Entry { bool msg; int ref; };  // factor id, or child clique id of a message
+// one density of a variable update: a factor ('f', a = factor id), the message prior of a child ('m', a = child
+// clique) or a differential factor of a child's joint message ('d', a = child clique, b = index)
+struct Entry {
+  char tag; int a, b;
+  Entry(bool msg, int ref) : tag(msg ? 'm' : 'f'), a(ref), b(0) {}
+  Entry(char t, int a_, int b_) : tag(t), a(a_), b(b_) {}
+};
+
+int factor_type_name(const nbp_factor_spec &s) {  // type(fnc).__name__ of the Python mirror, as a code
+  if (s.ncomp > 1) return 1000;                    // Mixture, whatever its mechanics
+  return s.factor_kind * 2 + (s.partial_mask ? 1 : 0);
+}
+// selectFactorType (services/DefaultNodeTypes.jl:12-31): the default relative factor between two variables
+bool select_factor_type(int m1, int m2, int *tname, int *kind) {
+  if (m1 != m2) return false;
+  if (m1 >= NBP_EUCLID1 && m1 <= NBP_EUCLID3) *kind = NBP_F_LINREL;
+  else if (m1 == NBP_CIRCULAR) *kind = NBP_F_CIRCULAR;
+  else if (m1 == NBP_SE2) *kind = NBP_F_SE2;
+  else return false;
+  *tname = *kind * 2;
+  return true;
+}
+
+// findShortestPathDijkstra on the clique sub graph (unit weights, breadth first in the order of jointmsg.py):
+// the factors along one shortest path; false when `to` cannot be reached.  tname >= 0: only such factors.
+bool shortest_path_factors(const std::vector<int> &vars, const std::vector<Clique::SubFac> &facs, int frm, int to, int tname,
+                           std::vector<int> *path) {
+  path->clear();
+  if (frm == to) return true;
+  std::map<int, std::vector<int>> by_var;
+  for (int v : vars) by_var[v];
+  for (size_t i = 0; i < facs.size(); i++) {
+    if (tname >= 0 && facs[i].tname != tname) continue;
+    for (int v : facs[i].vars)
+      if (by_var.count(v)) by_var[v].push_back((int)i);
+  }
+  std::map<int, std::pair<int, int>> prev;  // variable -> (previous variable, factor)
+  prev[frm] = {-1, -1};
+  std::deque<int> dq{frm};
+  while (!dq.empty()) {
+    const int v = dq.front();
+    dq.pop_front();
+    for (int i : by_var[v])
+      for (int u : facs[i].vars)
+        if (by_var.count(u) && !prev.count(u)) {
+          prev[u] = {v, i};
+          if (u == to) {
+            for (int w = u; prev[w].first >= 0; w = prev[w].first) path->push_back(prev[w].second);
+            std::reverse(path->begin(), path->end());
+            return true;
+          }
+          dq.push_back(u);
+        }
+  }
+  return false;
+}
+
+// plan_joint_messages (jointmsg.py): children before parents
+void plan_joint(nbp_tree *t) {
+  const nbp_graph *g = t->g;
+  std::vector<int> height(t->cl.size() + 1, 0);
+  for (int cid : postorder(t)) {
+    int h = 0;
+    const Clique &c = t->cl[cid - 1];
+    if (!c.children.empty()) {
+      for (int chd : c.children) h = std::max(h, height[chd]);
+      h += 1;
+    }
+    height[cid] = h;
+  }
+  std::vector<int> ids;
+  for (const Clique &c : t->cl) ids.push_back(c.id);
+  std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return height[a] != height[b] ? height[a] < height[b] : a < b; });
+  for (int cid : ids) {
+    Clique &c = t->cl[cid - 1];
+    c.jf.clear(); c.rel.clear(); c.jpriors.clear();
+    for (int f : c.potentials) {
+      const nbp_factor_spec &fs = g->facs[f].s;
+      c.jf.push_back({'f', f, 0, std::vector<int>(fs.vars, fs.vars + fs.nvars), factor_type_name(fs), g->facs[f].is_prior, fs.factor_kind});
+    }
+    for (int ch : c.children) {  // addMsgFactors!(subfg, msg, UpwardPass)
+      const Clique &M = t->cl[ch - 1];
+      for (size_t i = 0; i < M.rel.size(); i++)
+        c.jf.push_back({'d', ch, (int)i, {M.rel[i][0], M.rel[i][1]}, M.rel[i][2], false, M.rel[i][3]});
+      for (int v : M.jpriors) {  // addLikelihoodPriorCommon!
+        bool touched = false;
+        for (const auto &f : c.jf) touched |= contains(f.vars, v);
+        if (M.hasPriors || !touched) c.jf.push_back({'p', ch, v, {v}, -2, true, NBP_F_MSGPRIOR});
+      }
+    }
+    c.hasPriors = false;
+    bool own_priors = false;
+    for (const auto &f : c.jf) { c.hasPriors |= f.is_prior; own_priors |= (f.is_prior && f.tag == 'f'); }
+    if (c.parent == 0) continue;
+    const std::vector<int> allv = c.all();
+    std::vector<int> dec = c.seps;  // sortperm(dims; rev = true), stable
+    std::stable_sort(dec.begin(), dec.end(), [&](int a, int b) { return mani_dim(g->vars[a].manifold) > mani_dim(g->vars[b].manifold); });
+    std::vector<int> acc(dec.rbegin(), dec.rend()), already, path;
+    for (int s1 : dec) {
+      already.push_back(s1);
+      for (int s2 : acc) {
+        if (contains(already, s2)) continue;
+        if (!shortest_path_factors(allv, c.jf, s1, s2, -1, &path)) continue;
+        std::vector<int> types;
+        for (int fi : path)
+          if (!contains(types, c.jf[fi].tname)) types.push_back(c.jf[fi].tname);
+        int tn, kind;
+        if (types.size() != 1 || !select_factor_type(g->vars[s1].manifold, g->vars[s2].manifold, &tn, &kind) || tn != types[0]) continue;
+        c.rel.push_back({s1, s2, tn, kind});
+      }
+    }
+    // _findSubgraphsFactorType + _generateSubgraphMsgPriors
+    std::map<int, int> count, cls;
+    for (int s_ : c.seps) count[s_] = 0;
+    for (const auto &r : c.rel) { count[r[0]]++; count[r[1]]++; }
+    int nw = 0;
+    for (int s_ : c.seps)
+      if (count[s_] == 0) cls[s_] = ++nw;
+    std::vector<int> outer;
+    for (int s_ : c.seps)
+      if (!cls.count(s_)) outer.push_back(s_);
+    for (int k1 : outer) {
+      if (!cls.count(k1)) cls[k1] = ++nw;
+      std::vector<int> inner;
+      for (int s_ : c.seps)
+        if (!cls.count(s_)) inner.push_back(s_);
+      for (int k2 : inner) {
+        int tn, kind;
+        const bool sel = select_factor_type(g->vars[k1].manifold, g->vars[k2].manifold, &tn, &kind);
+        const bool conn = sel && shortest_path_factors(allv, c.jf, k1, k2, tn, &path) && !path.empty();
+        cls[k2] = conn ? cls[k1] : ++nw;
+      }
+    }
+    std::map<int, std::vector<int>> classes;
+    for (int s_ : c.seps) classes[cls[s_]].push_back(s_);
+    for (const auto &kv : classes) {
+      const std::vector<int> &syms = kv.second;
+      if (!(syms.size() == 1 || own_priors)) continue;
+      int md = 0;  // _calcCandidatePriorBest: highest dimension, then most factors in the sub graph
+      for (int s_ : syms) md = std::max(md, mani_dim(g->vars[s_].manifold));
+      int best = -1, bestadj = -1;
+      for (int s_ : syms) {
+        if (mani_dim(g->vars[s_].manifold) != md) continue;
+        int adj = 0;
+        for (const auto &f : c.jf) adj += contains(f.vars, s_) ? 1 : 0;
+        if (adj > bestadj) { bestadj = adj; best = s_; }
+      }
+      c.jpriors.push_back(best);
+    }
+  }
+}
+
+// the densities of variable v in clique c: up solve (with the common message priors) or down solve (without)
+std::vector<Entry> joint_entries(const Clique &c, int v, bool down) {
+  std::vector<Entry> e;
+  for (const auto &f : c.jf) {
+    if (!contains(f.vars, v) || (down && f.tag == 'p')) continue;
+    if (f.tag == 'f') e.push_back(Entry('f', f.a, 0));
+    else if (f.tag == 'd') e.push_back(Entry('d', f.a, f.b));
+    else e.push_back(Entry('m', f.a, 0));
+  }
+  return e;
+}
 
 void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, int msg_slot, int target, const std::map<int, int> *Bc,
                    const std::vector<int> *main_slot, const std::set<int> *inclq, int out_slot, uint64_t seed, double nullSurplus,
@@ -470,7 +649,8 @@ void add_stage(nbp_tree *t, int kind, const void *descs, size_t esz, int n) {
 }
 
 nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &entries, const std::set<int> *inclq, int out_slot, int passid,
-                      int step, uint64_t seed, std::vector<nbp_proposal_desc> &props, std::vector<nbp_product_desc> &prods) {
+                      int step, uint64_t seed, std::vector<nbp_proposal_desc> &props, std::vector<nbp_product_desc> &prods,
+                      bool fresh = true) {
   const nbp_graph *g = t->g;
   const int base = t->scratch[cid - 1];
   const std::map<int, int> &Bc = t->B[cid - 1];
@@ -478,19 +658,43 @@ nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &ent
   if (F > NBP_MAXF) return hfail(NBP_ERR_RANGE, "a product exceeds NBP_MAXF densities");
   bool anymh = false;
   for (const Entry &e : entries)
-    if (!e.msg && g->facs[e.ref].s.has_multihypo) anymh = true;
+    if (e.tag == 'f' && g->facs[e.a].s.has_multihypo) anymh = true;
   bool anypartial = false;
   nbp_product_desc q;
   memset(&q, 0, sizeof(q));
   int F_in = 0;
   for (int i = 0; i < F; i++) {
     const Entry &e = entries[i];
-    const HFac *fac = e.msg ? nullptr : &g->facs[e.ref];
+    HFac diff;  // 'd': LinearRelative(::MKD) & co. between the two separators, measurement = the child's KDE slot
+    const HFac *fac = e.tag == 'f' ? &g->facs[e.a] : nullptr;
+    if (e.tag == 'd') {
+      const auto &r = t->cl[e.a - 1].rel[e.b];
+      memset(&diff, 0, sizeof(diff));
+      diff.is_prior = false;
+      diff.s.factor_kind = r[3];
+      diff.s.nvars = 2;
+      diff.s.vars[0] = r[0];
+      diff.s.vars[1] = r[1];
+      diff.s.ncomp = 1;
+      diff.s.comp[0][0] = 1.0;
+      diff.s.comp[0][4] = diff.s.comp[0][8] = diff.s.comp[0][12] = 1.0;
+      fac = &diff;
+    }
     double ns = 0.0;  // _null_surplus: relative non-multihypo siblings of a multihypo factor
     if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = g->sp.null_surplus_add;
-    const int msg_slot = e.msg ? t->B[e.ref - 1].at(v) : -1;
+    const int msg_slot = e.tag == 'm' ? t->B[e.a - 1].at(v) : -1;
     nbp_proposal_desc d;
-    fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, op_seed(seed, passid, cid, step, i + 1), ns);
+    const uint64_t sd = op_seed(seed, passid, cid, step, i + 1);
+    fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, sd, ns);
+    if (e.tag == 'd') d.meas_kde = t->cl[e.a - 1].Dslot[e.b] + 1;
+    {  // needFreshMeasurements (SolveTree.jl:119): one stored measurement per factor object
+      const std::array<int, 5> key{cid, (int)e.tag, e.a, e.b, e.tag == 'm' ? v : -1};
+      if (fresh) t->meas_seed[key] = sd;
+      else {
+        auto it = t->meas_seed.find(key);
+        d.meas_seed = it == t->meas_seed.end() ? 0 : it->second;
+      }
+    }
     props.push_back(d);
     q.in_slot[i] = base + i;
     const int pm = fac ? fac->s.partial_mask : 0;
@@ -590,6 +794,33 @@ nbp_status nbp_tree_build(const nbp_graph *g, const int32_t *order, int32_t n, n
   nbp_status rc = clique_potentials_and_ids(t);
   if (rc) { delete t; return rc; }
   schedules(t);
+  t->joint = (g->sp.flags & NBP_SOLVER_MSG_LIKELIHOODS) != 0;
+  t->stored = (g->sp.flags & NBP_SOLVER_STORED_MEASUREMENTS) != 0;
+  if (t->joint) {
+    plan_joint(t);
+    // no addDownVariableFactors! (CliqueStateMachine.jl:823): the down solve works on the clique sub graph as the
+    // up solve left it, minus the common priors
+    t->jdnsched.assign(t->cl.size(), {});
+    for (Clique &c : t->cl) {
+      if (c.parent == 0) continue;
+      std::set<int> frs(c.frontals.begin(), c.frontals.end()), itv;
+      for (const auto &f : c.jf) {
+        if (f.tag == 'p') continue;
+        int nfr = 0;
+        for (int u : f.vars) nfr += frs.count(u) ? 1 : 0;
+        if (nfr > 1)
+          for (int u : f.vars)
+            if (frs.count(u)) itv.insert(u);
+      }
+      auto skip = [&](int v) { return g->sp.limitfixeddown && g->vars[v].ismargin; };
+      std::vector<int> &d = t->jdnsched[c.id - 1];
+      for (int v : c.frontals)
+        if (!itv.count(v) && !skip(v) && !joint_entries(c, v, true).empty()) d.push_back(v);
+      for (int k = 0; k < g->sp.gibbs_iters; k++)
+        for (int v : c.frontals)
+          if (itv.count(v) && !skip(v)) d.push_back(v);
+    }
+  }
   *out = t;
   return NBP_OK;
 }
@@ -642,6 +873,16 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
     for (int v : c.all()) t->B[c.id - 1][v] = nxt++;
     // widest product of this clique: up = potentials touching v + child messages on v; down = all factors of v
     size_t maxf = 1;
+    if (t->joint) {
+      c.Dslot.clear();
+      for (size_t i = 0; i < c.rel.size(); i++) c.Dslot.push_back(nxt++);
+      for (int v : c.upsched)
+        if (!g->vars[v].ismargin) maxf = std::max(maxf, joint_entries(c, v, false).size());
+      for (int v : t->jdnsched[c.id - 1]) maxf = std::max(maxf, joint_entries(c, v, true).size());
+      t->scratch[c.id - 1] = nxt;
+      nxt += (int)maxf;
+      continue;
+    }
     for (int v : c.upsched) {
       if (g->vars[v].ismargin) continue;  // never updated in the up solve (SolveTree.jl:61)
       size_t k = 0;
@@ -673,6 +914,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
   const nbp_graph *g = t->g;
   const int n = (int)g->vars.size();
   t->stages.clear();
+  t->meas_seed.clear();
   t->st = nbp_tree_stats{};
   std::vector<nbp_copy_desc> cps;
   if (t->snapshot) {
@@ -716,20 +958,25 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       std::vector<const Clique *> level;
       size_t nsteps = 0;
       // up schedule filtered like solver.TreeProgram: variables with at least one density, not marginalized
-      std::vector<std::vector<int>> sched;
+      std::vector<std::vector<int>> sched, iters;
       for (const Clique &c : t->cl)
         if (height[c.id] == h) {
           level.push_back(&c);
-          std::vector<int> s;
-          for (int v : c.upsched) {
+          std::vector<int> s, it;
+          for (size_t k = 0; k < c.upsched.size(); k++) {
+            const int v = c.upsched[k];
             bool any = false;
-            for (int f : c.potentials)
-              for (int q = 0; q < g->facs[f].s.nvars && !any; q++) any = g->facs[f].s.vars[q] == v;
-            for (int chd : c.children) any |= contains(t->cl[chd - 1].seps, v);
-            if (any && !g->vars[v].ismargin) s.push_back(v);
+            if (t->joint) any = !joint_entries(c, v, false).empty();
+            else {
+              for (int f : c.potentials)
+                for (int q = 0; q < g->facs[f].s.nvars && !any; q++) any = g->facs[f].s.vars[q] == v;
+              for (int chd : c.children) any |= contains(t->cl[chd - 1].seps, v);
+            }
+            if (any && !g->vars[v].ismargin) { s.push_back(v); it.push_back(c.upiter[k]); }
           }
           nsteps = std::max(nsteps, s.size());
           sched.push_back(s);
+          iters.push_back(it);
         }
       for (size_t k = 0; k < nsteps; k++) {
         props.clear();
@@ -739,19 +986,46 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
           const Clique &c = *level[ci];
           const int v = sched[ci][k];
           std::vector<Entry> ent;
-          for (int f : c.potentials) {
-            bool hit = false;
-            for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
-            if (hit) ent.push_back({false, f});
+          if (t->joint) ent = joint_entries(c, v, false);
+          else {
+            for (int f : c.potentials) {
+              bool hit = false;
+              for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
+              if (hit) ent.push_back({false, f});
+            }
+            for (int chd : c.children)
+              if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
           }
-          for (int chd : c.children)
-            if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
-          rc = update_ops(t, c.id, v, ent, nullptr, t->B[c.id - 1].at(v), PASS_UP, (int)k, seed, props, prods);
+          const bool fresh = iters[ci][k] == 1 || !t->stored;
+          rc = update_ops(t, c.id, v, ent, nullptr, t->B[c.id - 1].at(v), PASS_UP, (int)k, seed, props, prods, fresh);
           if (rc) return rc;
           t->st.updates_up++;
         }
         add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
         add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+      }
+      if (t->joint) {
+        // prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD!: approxDeconv between the solved separator beliefs of
+        // every differential pair (searched from samples of the default-constructed factor), manikde! of the result
+        props.clear();
+        for (const Clique *c : level)
+          for (size_t i = 0; i < c->rel.size(); i++) {
+            HFac dflt;
+            memset(&dflt, 0, sizeof(dflt));
+            dflt.s.factor_kind = c->rel[i][3];
+            dflt.s.nvars = 2;
+            dflt.s.vars[0] = c->rel[i][0];
+            dflt.s.vars[1] = c->rel[i][1];
+            dflt.s.ncomp = 1;
+            dflt.s.comp[0][0] = 1.0;
+            const int zd = dflt.s.factor_kind == NBP_F_LINREL ? mani_dim(g->vars[c->rel[i][0]].manifold) : (dflt.s.factor_kind == NBP_F_SE2 ? 3 : 1);
+            for (int q = 0; q < zd; q++) dflt.s.comp[0][4 + 4 * q] = 1.0;  // identity square-root covariance
+            nbp_proposal_desc d;
+            fill_proposal(g, d, &dflt, -1, c->rel[i][1], &t->B[c->id - 1], &t->main_slot, nullptr, c->Dslot[i],
+                          op_seed(seed, PASS_UP, c->id, 0x4000 + (int)i, 0), 0.0);
+            props.push_back(d);
+          }
+        if (!props.empty()) add_stage(t, NBP_STAGE_DECONV, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
       }
     }
   }
@@ -769,7 +1043,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       std::vector<const Clique *> level;
       size_t nsteps = 0;
       for (const Clique &c : t->cl)
-        if (depth[c.id] == dpt) { level.push_back(&c); nsteps = std::max(nsteps, c.dnsched.size()); }
+        if (depth[c.id] == dpt) { level.push_back(&c); nsteps = std::max(nsteps, (t->joint ? t->jdnsched[c.id - 1] : c.dnsched).size()); }
       cps.clear();
       for (const Clique *c : level)
         for (int s : c->seps) cps.push_back({t->B[c->parent - 1].at(s), t->B[c->id - 1].at(s)});
@@ -778,12 +1052,15 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         props.clear();
         prods.clear();
         for (const Clique *c : level) {
-          if (k >= c->dnsched.size()) continue;
-          const int v = c->dnsched[k];
+          const std::vector<int> &dsch = t->joint ? t->jdnsched[c->id - 1] : c->dnsched;
+          if (k >= dsch.size()) continue;
+          const int v = dsch[k];
           const std::vector<int> allv = c->all();
           std::set<int> inclq(allv.begin(), allv.end());
           std::vector<Entry> ent;
-          for (int f : g->vfacs[v]) ent.push_back({false, f});
+          if (t->joint) ent = joint_entries(*c, v, true);
+          else
+            for (int f : g->vfacs[v]) ent.push_back({false, f});
           rc = update_ops(t, c->id, v, ent, &inclq, t->B[c->id - 1].at(v), PASS_DOWN, (int)k, seed, props, prods);
           if (rc) return rc;
           t->st.updates_down++;

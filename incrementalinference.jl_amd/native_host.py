@@ -10,9 +10,12 @@ from . import abi
 i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
 
 
+SOLVER_STORED_MEASUREMENTS, SOLVER_MSG_LIKELIHOODS = 1, 2  # enum nbp_solver_flag
+
+
 class SolverParamsC(C.Structure):
     _fields_ = [("N", i32), ("gibbs_iters", i32), ("inflate_cycles", i32), ("product_niter", i32), ("upsolve", i32),
-                ("downsolve", i32), ("limitfixeddown", i32), ("pad_", i32), ("spread_nh", f64), ("inflation", f64),
+                ("downsolve", i32), ("limitfixeddown", i32), ("flags", i32), ("spread_nh", f64), ("inflation", f64),
                 ("null_surplus_add", f64)]
 
 
@@ -87,7 +90,7 @@ def _check(rc):
 
 def _stages_of(getter, count):
     esz = {abi.STAGE_PROPOSALS: C.sizeof(abi.ProposalDesc), abi.STAGE_PRODUCTS: C.sizeof(abi.ProductDesc),
-           abi.STAGE_COPIES: C.sizeof(abi.CopyDesc)}
+           abi.STAGE_COPIES: C.sizeof(abi.CopyDesc), abi.STAGE_DECONV: C.sizeof(abi.ProposalDesc)}
     out = []
     for s in range(count):
         kind, n = i32(), i32()
@@ -102,18 +105,16 @@ def _stages_of(getter, count):
 class NativeGraph:
     def __init__(self, sp):
         self.lib = _lib()
+        flags = (0 if sp.alwaysFreshMeasurements else SOLVER_STORED_MEASUREMENTS) | \
+                (SOLVER_MSG_LIKELIHOODS if getattr(sp, "useMsgLikelihoods", False) else 0)
         p = SolverParamsC(sp.N, sp.gibbsIters, sp.inflateCycles, sp.productNiter, int(sp.upsolve), int(sp.downsolve),
-                          int(getattr(sp, "limitfixeddown", False)), 0, sp.spreadNH, sp.inflation, sp.nullSurplusAdd)
+                          int(getattr(sp, "limitfixeddown", False)), flags, sp.spreadNH, sp.inflation, sp.nullSurplusAdd)
         self._g = C.c_void_p()
         _check(self.lib.nbp_graph_create(C.byref(p), C.byref(self._g)))
         self.labels, self.flabels = [], []
 
     @classmethod
     def from_fg(cls, fg):
-        if getattr(fg.solverParams, "useMsgLikelihoods", False):
-            raise NotImplementedError("useMsgLikelihoods: the joint-message plan is compiled by the Python host (solver.TreeProgram)")
-        if not fg.solverParams.alwaysFreshMeasurements:
-            raise NotImplementedError("alwaysFreshMeasurements = false: compiled by the Python host (solver.TreeProgram)")
         g = cls(fg.solverParams)
         idx = {}
         for v in fg.ls():

@@ -635,7 +635,9 @@ class TreeProgram:
         ns = _null_surplus(fg, fcts)
         props = []
         for i, f in enumerate(fcts):
-            sd, key = op_seed(self.seed, passid, cid, step, i + 1), (cid, entries[i])
+            # one stored measurement per factor object: a user / differential factor is shared by its variables,
+            # a message is one MsgPrior factor per separator variable
+            sd, key = op_seed(self.seed, passid, cid, step, i + 1), (cid, entries[i], v if entries[i][0] == "m" else None)
             if fresh:  # the factor's ccw.measurement is overwritten (CalcFactor.jl:492-510)
                 self._meas_seed[key] = sd
             props.append(proposal_desc(fg, f, v, slot_of, base + i, sd, nullSurplus=ns[i],
@@ -835,8 +837,6 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
     # Python mirror otherwise (oracle backend in the tests); both produce the same descriptors
     use_native = native if native is not None else (backend is None or backend is HipBackend or isinstance(backend, HipBackend)
                                                     or getattr(backend, "is_hip", False))
-    if getattr(sp, "useMsgLikelihoods", False) or not sp.alwaysFreshMeasurements:
-        use_native = False  # joint messages (jointmsg.py) and stored measurements: compiled by the Python host
     if use_native:
         from . import native_host
         ng = native_host.NativeGraph.from_fg(fg)

@@ -182,13 +182,16 @@ def random_graph(seed):
 @pytest.mark.parametrize("seed", range(60))
 def test_random_graphs_native_equals_python(seed):
     fg = random_graph(seed)
+    # every third graph also exercises the non-default message / measurement modes of the compiler
+    fg.solverParams.useMsgLikelihoods = seed % 3 == 1
+    fg.solverParams.alwaysFreshMeasurements = seed % 3 != 2
     g = native_host.NativeGraph.from_fg(fg)
     # graph initialisation plan from the uninitialised graph
     plan, slot, n_slots, stages = iif.solver.initStages(fg, seed=seed)
     need, planned = g.init_plan(seed)
     assert planned == [p[0] for p in plan] and need == n_slots
     ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc,
-             iif.abi.STAGE_COPIES: iif.abi.CopyDesc}
+             iif.abi.STAGE_COPIES: iif.abi.CopyDesc, iif.abi.STAGE_DECONV: iif.abi.ProposalDesc}
     for (kind, raw), (pk, descs) in zip(g.init_stages(), stages):
         assert kind == pk and raw == bytes((ctype[pk] * len(descs))(*descs))
     g.close()
