@@ -115,3 +115,10 @@ def test_independent_seeds_agree_in_distribution(oracle_backend, hip_backend, bu
             pooled = np.sqrt(0.5 * (sa * sa + sb * sb))
             assert dm <= 0.75 * pooled + 0.05, (v, k, ma, mb, sa, sb)
             assert 0.55 <= sb / sa <= 1.8, (v, k, sa, sb)
+
+
+@pytest.mark.parametrize("seed", [3, 17])
+def test_gpu_solve_matches_exact_gaussian_posterior(hip_backend, seed):
+    """the HIP solve against the exact posterior of a linear-Gaussian chain (tests/exact_gaussian.py)"""
+    from exact_gaussian import check_against_exact
+    check_against_exact(hip_backend, seed)
