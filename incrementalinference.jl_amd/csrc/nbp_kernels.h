@@ -717,7 +717,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             int z = za;
             // four nodes per step: four independent weight evaluations in flight (a lone wave on its SIMD is
             // bound by the dependent-chain latency of one) and one running-max update instead of four
-            for (; z + 3 < zb; z += 4) {
+            // (the register-capped throughput variants take this path only where it does not spill more: D <= 2)
+            for (; (HL >= 8 || D <= 2) && z + 3 < zb; z += 4) {
               double a0, a1, a2, a3, g0, g1, g2, g3;
               node_w(z, a0, g0);
               node_w(z + 1, a1, g1);
