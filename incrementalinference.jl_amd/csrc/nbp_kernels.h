@@ -886,7 +886,7 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
 }
 
 // Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in
-// flight) keep everything in registers; the throughput variants trade a few spills for 4-5 waves per SIMD.
+// flight) keep everything in registers (236 VGPRs); the throughput variants trade a few spills for 4-5 waves per SIMD.
 #define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
 __global__ void __launch_bounds__(512) nbp_product_kernel_x16(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) n
   extern __shared__ double smem[];
   product_kernel_body<4>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5))) nbp_product_kernel_t2(NBP_PRODUCT_ARGS) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) nbp_product_kernel_t2(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<2>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
