@@ -12,7 +12,7 @@ MAXV, MAXF, MAXD, MAXC, MAXN, COMP_STRIDE = 6, 128, 3, 4, 512, 13
 EUCLID1, EUCLID2, EUCLID3, CIRCULAR, SE2 = 1, 2, 3, 4, 5
 # enum nbp_factor
 F_PRIOR, F_MSGPRIOR, F_LINREL, F_CIRCULAR, F_SE2, F_EUCLIDDIST = 1, 2, 3, 4, 5, 6
-STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES, STAGE_DECONV = 1, 2, 3, 4
+STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES, STAGE_DECONV, STAGE_COPY_POINTS = 1, 2, 3, 4, 5
 OPT_LAZY_BANDWIDTH = 1
 
 MANIFOLD_DIM = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 3}

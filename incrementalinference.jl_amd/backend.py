@@ -179,7 +179,8 @@ class HipBackend:
 
 
 _STAGE_CTYPE = {abi.STAGE_PROPOSALS: abi.ProposalDesc, abi.STAGE_PRODUCTS: abi.ProductDesc,
-                abi.STAGE_COPIES: abi.CopyDesc, abi.STAGE_DECONV: abi.ProposalDesc}
+                abi.STAGE_COPIES: abi.CopyDesc, abi.STAGE_DECONV: abi.ProposalDesc,
+                abi.STAGE_COPY_POINTS: abi.CopyDesc}
 
 
 class HipProgram:

@@ -512,6 +512,14 @@ static nbp_status launch_copies(nbp_ctx *c, const nbp_copy_desc *dev, int n) {
   return NBP_OK;
 }
 
+static nbp_status launch_copy_points(nbp_ctx *c, const nbp_copy_desc *dev, int n) {
+  if (n <= 0) return NBP_OK;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_copy_points_kernel, dim3(n), dim3(256), 0, c->stream, dev, c->arena, c->S, c->N);
+  HIPCHK(hipGetLastError());
+  return NBP_OK;
+}
+
 static nbp_status stage_upload(nbp_ctx *c, const void *src, size_t bytes) {
   if (bytes > c->stage_bytes) {
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -790,7 +798,8 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
     rc = check_products(p->ctx, (const nbp_product_desc *)descs, n);
     st.maxfd = products_maxfd((const nbp_product_desc *)descs, n);
     break;
-  case NBP_STAGE_COPIES: esz = sizeof(nbp_copy_desc); rc = check_copies(p->ctx, (const nbp_copy_desc *)descs, n); break;
+  case NBP_STAGE_COPIES:
+  case NBP_STAGE_COPY_POINTS: esz = sizeof(nbp_copy_desc); rc = check_copies(p->ctx, (const nbp_copy_desc *)descs, n); break;
   case NBP_STAGE_DECONV: esz = sizeof(nbp_proposal_desc); rc = check_deconv(p->ctx, (const nbp_proposal_desc *)descs, n); break;
   default: return fail(NBP_ERR_ARG, "unknown stage kind");
   }
@@ -850,6 +859,9 @@ static nbp_liveness product_liveness(const nbp_program *p) {
     } else if (st.kind == NBP_STAGE_DECONV) {  // reads points only; its outputs are always fitted
       const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
       for (int i = 0; i < st.n; i++) { kill(pd[i].out_slot); last_prop.erase(pd[i].out_slot); }
+    } else if (st.kind == NBP_STAGE_COPY_POINTS) {  // not a reader of the source's bandwidth; the destination is overwritten
+      const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
+      for (int i = 0; i < st.n; i++) { kill(cd[i].dst_slot); last_prop.erase(cd[i].dst_slot); }
     } else if (st.kind == NBP_STAGE_COPIES) {
       const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
       if (st.n == 0) open.clear();  // barrier: all live
@@ -928,6 +940,13 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       st.ent_s = pend_s;
       st.ent_m = pend_m;
       for (int i = 0; i < st.n; i++) { pend_s.push_back(pd[i].out_slot); pend_m.push_back(pd[i].manifold); }
+    } else if (st.kind == NBP_STAGE_COPY_POINTS) {  // nothing is flushed; a fit still queued for a destination is void
+      const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
+      for (int i = 0; i < st.n; i++)
+        for (size_t q = 0; q < pend_s.size(); q++)
+          if (pend_s[q] == cd[i].dst_slot) { pend_s.erase(pend_s.begin() + q); pend_m.erase(pend_m.begin() + q); q--; }
+      st.ent_s = pend_s;
+      st.ent_m = pend_m;
     } else {  // copies (move bandwidths too) and the trailing pseudo stage
       st.flush_before = true;
       pend_s.clear(); pend_m.clear();
@@ -992,6 +1011,8 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd);
     } else if (st.kind == NBP_STAGE_DECONV) {
       rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);
+    } else if (st.kind == NBP_STAGE_COPY_POINTS) {
+      rc = launch_copy_points(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
     } else {
       rc = launch_copies(c, (const nbp_copy_desc *)(p->dev + st.offset), st.n);
     }

@@ -1039,6 +1039,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
     for (int r : t->roots)
       for (int v : t->cl[r - 1].frontals) cps.push_back({t->B[r - 1].at(v), t->main_slot[v]});
     add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+    std::vector<nbp_copy_desc> final_cps;
     for (int dpt = 1; dpt <= maxd; dpt++) {
       std::vector<const Clique *> level;
       size_t nsteps = 0;
@@ -1047,7 +1048,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       cps.clear();
       for (const Clique *c : level)
         for (int s : c->seps) cps.push_back({t->B[c->parent - 1].at(s), t->B[c->id - 1].at(s)});
-      add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+      add_stage(t, NBP_STAGE_COPY_POINTS, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());  // read as points only
       for (size_t k = 0; k < nsteps; k++) {
         props.clear();
         prods.clear();
@@ -1068,11 +1069,11 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
         add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
       }
-      cps.clear();
       for (const Clique *c : level)
-        for (int v : c->frontals) cps.push_back({t->B[c->id - 1].at(v), t->main_slot[v]});
-      add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
+        for (int v : c->frontals) final_cps.push_back({t->B[c->id - 1].at(v), t->main_slot[v]});
     }
+    // transferUpdateSubGraph!, once for the whole pass (see solver.TreeProgram)
+    add_stage(t, NBP_STAGE_COPIES, final_cps.data(), sizeof(nbp_copy_desc), (int)final_cps.size());
   }
   // statistics
   t->st.stages = (int64_t)t->stages.size();

@@ -354,6 +354,13 @@ __global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S
   for (int64_t i = threadIdx.x; i < S; i += blockDim.x) dst[i] = src[i];
 }
 
+// points only (NBP_STAGE_COPY_POINTS): 3N doubles, the bandwidth entries of the destination are not touched
+__global__ void nbp_copy_points_kernel(const nbp_copy_desc *c, double *arena, int64_t S, int N) {
+  const double *src = arena + S * c[blockIdx.x].src_slot;
+  double *dst = arena + S * c[blockIdx.x].dst_slot;
+  for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) dst[i] = src[i];
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   uint64_t z = x;

@@ -90,7 +90,8 @@ def _check(rc):
 
 def _stages_of(getter, count):
     esz = {abi.STAGE_PROPOSALS: C.sizeof(abi.ProposalDesc), abi.STAGE_PRODUCTS: C.sizeof(abi.ProductDesc),
-           abi.STAGE_COPIES: C.sizeof(abi.CopyDesc), abi.STAGE_DECONV: C.sizeof(abi.ProposalDesc)}
+           abi.STAGE_COPIES: C.sizeof(abi.CopyDesc), abi.STAGE_DECONV: C.sizeof(abi.ProposalDesc),
+           abi.STAGE_COPY_POINTS: C.sizeof(abi.CopyDesc)}
     out = []
     for s in range(count):
         kind, n = i32(), i32()

@@ -727,6 +727,7 @@ class TreeProgram:
                                      for v in tree.cliques[r].frontalIDs], "down")
         # ---- down pass: root first --------------------------------------------------------------
         maxd = max(self.depths.values())
+        done = []
         for dpt in range(1, maxd + 1):
             # down messages that cross a rank boundary: parent's values of the child's separators
             edges = []
@@ -738,10 +739,12 @@ class TreeProgram:
                                       (lambda c=c, v=v: self.B[(c, v)])))
             self._exchange(edges)
             level = [c for c in self.cliques if self.depths[c] == dpt]
-            # down message: separators := parent's values (updateSubFgFromDownMsgs!)
+            # down message: separators := parent's values (updateSubFgFromDownMsgs!).  The child reads them as
+            # points (relative proposals), never as a density: a points-only copy, which does not wait for the
+            # parent's pending bandwidth fits -- those ride with the next prep launch instead
             msg = [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)]) for c in level
                    if owner[tree.cliques[c].parent] == rank for s in tree.cliques[c].separatorIDs]
-            self._add(abi.STAGE_COPIES, msg, "down")
+            self._add(abi.STAGE_COPY_POINTS, msg, "down")
             nsteps = max([len(self.dnsched[c]) for c in level] + [0])
             for k in range(nsteps):
                 props, prods = [], []
@@ -761,9 +764,13 @@ class TreeProgram:
                     self.n_updates_down += 1
                 self._add(abi.STAGE_PROPOSALS, props, "down")
                 self._add(abi.STAGE_PRODUCTS, prods, "down")
-            # transferUpdateSubGraph!: frontals -> main graph (CliqueStateMachine.jl:928-966)
-            self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in level
-                                         for v in tree.cliques[c].frontalIDs], "down")
+            done += level
+        # transferUpdateSubGraph!: frontals -> main graph (CliqueStateMachine.jl:928-966), once for the whole pass:
+        # during the pass main[u] is only read for variables of cliques further down, which are written later
+        # anyway, so the deferral changes no value -- and the bandwidth fits of all those beliefs run in one
+        # chip-filling launch instead of one small launch per tree level
+        self._add(abi.STAGE_COPIES, [abi.CopyDesc(self.B[(c, v)], self.main[v]) for c in done
+                                     for v in tree.cliques[c].frontalIDs], "down")
         self.segments.append(("run", self._seg_start, len(self.stages)))
 
     def alg_bytes_by_kernel(self):

@@ -135,6 +135,13 @@ class OracleBackend:
         arr, n = self._arr(descs, abi.CopyDesc)
         self.lib.orc_run_copies(_dp(self.arena), self.N, arr, n)
 
+    def run_copy_points(self, descs):
+        """NBP_STAGE_COPY_POINTS: points only, the destination's bandwidth stays as it is"""
+        S = 3 * self.N + 8
+        a = self.arena.reshape(-1, S)
+        for d in descs:
+            a[d.dst_slot, :3 * self.N] = a[d.src_slot, :3 * self.N]
+
     def run_bandwidth(self, slots, manifolds):
         for s, m in zip(slots, manifolds):
             self.lib.orc_run_bandwidth(_dp(self.arena), self.N, int(s), int(m))
@@ -157,7 +164,8 @@ class OracleProgram:
         self.stages = [(k, backend._arr(d, {abi.STAGE_PROPOSALS: abi.ProposalDesc,
                                             abi.STAGE_PRODUCTS: abi.ProductDesc,
                                             abi.STAGE_COPIES: abi.CopyDesc,
-                                            abi.STAGE_DECONV: abi.ProposalDesc}[k])[0]) for k, d in stages]
+                                            abi.STAGE_DECONV: abi.ProposalDesc,
+                                            abi.STAGE_COPY_POINTS: abi.CopyDesc}[k])[0]) for k, d in stages]
         self.n_stages = len(stages)
 
     def run(self, first=0, last=-1):
@@ -171,13 +179,15 @@ class OracleProgram:
                 if len(arr):
                     self.backend.run_deconv(arr)
                     self.backend.run_bandwidth([d.out_slot for d in arr], [d.manifold for d in arr])
+            elif kind == abi.STAGE_COPY_POINTS:
+                self.backend.run_copy_points(arr)
             else:
                 self.backend.run_copies(arr)
 
     def reseed(self, salt):
         from iif_amd.seeds import mix_seed
         for kind, arr in self.stages:
-            if kind != abi.STAGE_COPIES:
+            if kind not in (abi.STAGE_COPIES, abi.STAGE_COPY_POINTS):
                 for d in arr:
                     d.seed = mix_seed(d.seed, salt)
                     if kind != abi.STAGE_PRODUCTS and d.meas_seed:

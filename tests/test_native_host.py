@@ -109,7 +109,7 @@ def test_compiled_stages_are_byte_identical(name, snapshot):
     nt.schedule(12345)  # host half only: no device needed
     got = nt.stages()
     ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc,
-             iif.abi.STAGE_COPIES: iif.abi.CopyDesc}
+             iif.abi.STAGE_COPIES: iif.abi.CopyDesc, iif.abi.STAGE_COPY_POINTS: iif.abi.CopyDesc}
     assert len(got) == len(tp.stages)
     for s, ((kind, raw), (pk, descs)) in enumerate(zip(got, tp.stages)):
         assert kind == pk, s
@@ -191,7 +191,8 @@ def test_random_graphs_native_equals_python(seed):
     need, planned = g.init_plan(seed)
     assert planned == [p[0] for p in plan] and need == n_slots
     ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc,
-             iif.abi.STAGE_COPIES: iif.abi.CopyDesc, iif.abi.STAGE_DECONV: iif.abi.ProposalDesc}
+             iif.abi.STAGE_COPIES: iif.abi.CopyDesc, iif.abi.STAGE_DECONV: iif.abi.ProposalDesc,
+             iif.abi.STAGE_COPY_POINTS: iif.abi.CopyDesc}
     for (kind, raw), (pk, descs) in zip(g.init_stages(), stages):
         assert kind == pk and raw == bytes((ctype[pk] * len(descs))(*descs))
     g.close()
