@@ -224,15 +224,15 @@ enum nbp_stage_kind {
   NBP_STAGE_PROPOSALS = 1,
   NBP_STAGE_PRODUCTS = 2,
   NBP_STAGE_COPIES = 3,
-  NBP_STAGE_COPY_POINTS = 5, /* nbp_copy_desc[]: copies the points of a slot only.  The destination's bandwidth is
-                           left unspecified, nothing waits for a pending fit of the source: for values that are read
-                           as points and never as a density -- the separator values a down message hands to a child
-                           (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84) */
-  NBP_STAGE_DECONV = 4  /* nbp_proposal_desc[]: approxDeconv of a relative factor between var_slot[0] and
+  NBP_STAGE_DECONV = 4, /* nbp_proposal_desc[]: approxDeconv of a relative factor between var_slot[0] and
                            var_slot[1] (like nbp_run_deconv); out_slot receives the predicted measurements
                            AND their fitted bandwidth (manikde!), i.e. a KDE a later proposal can name in
                            meas_kde -- the child side of the differential messages
                            (addLikelihoodsDifferentialCHILD!, TreeMessageUtils.jl:279-335) */
+  NBP_STAGE_COPY_POINTS = 5  /* nbp_copy_desc[]: copies the points of a slot only.  The destination's bandwidth is
+                           left unspecified, nothing waits for a pending fit of the source: for values that are read
+                           as points and never as a density -- the separator values a down message hands to a child
+                           (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84) */
 };
 nbp_status nbp_program_create(nbp_ctx *ctx, nbp_program **out);
 nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *descs, int32_t n);
