@@ -18,7 +18,7 @@ def main(path, steps, lps=67):
     print(f"{'kernel':34s} {'launches':>8s} {'avg_us':>10s} {'total_ms':>9s} | avg_us by grid size (blocks): <=8, <=64, <=300, >300")
     out = {}
     for name, rs in sorted(by.items()):
-        if name in ("nbp_reseed_kernel", "nbp_copy_kernel"):
+        if name in ("nbp_reseed_kernel", "nbp_copy_kernel", "nbp_copy_points_kernel"):
             tail = rs
         else:
             tail = rs[-steps * lps:]
