@@ -532,9 +532,7 @@ class TreeProgram:
         # KDE of the i-th differential factor clique c sends up
         self.joint, self.D = None, {}
         if getattr(sp, "useMsgLikelihoods", False):
-            if any(o != rank for o in self.owner.values()):
-                raise NotImplementedError("useMsgLikelihoods with cliques on several ranks")
-            self.joint = jointmsg.plan_joint_messages(fg, tree)
+            self.joint = jointmsg.plan_joint_messages(fg, tree)  # the same plan on every rank
         self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
         self.upfresh = {}     # per clique: does step k of the up schedule draw fresh measurements?
         self._meas_seed = {}  # (clique, factor entry) -> seed of the op that last drew its measurements
@@ -551,6 +549,10 @@ class TreeProgram:
                     for v in tree.cliques[ch].separatorIDs:
                         self.ghost[(ch, v)] = nxt
                         nxt += 1
+                    if self.joint is not None:  # ... and so do the KDEs of its differential factors
+                        for i in range(len(self.joint[ch].relatives)):
+                            self.D[(ch, i)] = nxt
+                            nxt += 1
             # up-solve factor lists per variable: clique potentials touching v + child messages on v
             upf = {}
             for v in cl.allIDs:
@@ -715,6 +717,10 @@ class TreeProgram:
                     for v in cl.separatorIDs:
                         edges.append((owner[c], (lambda c=c, v=v: self.B[(c, v)]), owner[cl.parent],
                                       (lambda c=c, v=v: self.ghost[(c, v)])))
+                    for i in range(len(self.joint[c].relatives) if self.joint is not None else 0):
+                        # D[(c, i)] names the sender's own slot on its rank and the landing slot on the parent's
+                        edges.append((owner[c], (lambda c=c, i=i: self.D[(c, i)]), owner[cl.parent],
+                                      (lambda c=c, i=i: self.D[(c, i)])))
             self._exchange(edges)
         if not sp.downsolve:
             # postUpSolve -> updateFromSubgraph (:595-599): every clique hands its up-solved frontals back

@@ -10,11 +10,12 @@ from parity_utils import abi, iif
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,nvars", [(2, 48), (4, 48), (8, 128)])
-def test_emulated_ranks_equal_single_rank(hip_backend, world, nvars):
+@pytest.mark.parametrize("world,nvars,joint", [(2, 48, False), (4, 48, False), (8, 128, False), (2, 48, True), (4, 64, True)])
+def test_emulated_ranks_equal_single_rank(hip_backend, world, nvars, joint):
     from iif_amd.dist_solver import partition_cliques
     N = 100
     fg = iif.generateChainEuclid(nvars, vardims=2, priorEvery=8, N=N)
+    fg.solverParams.useMsgLikelihoods = joint  # joint messages: the differential-factor KDEs travel too
     iif.initAll(fg, backend=hip_backend, seed=0)
     tree = iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
     man = abi.EUCLID2
