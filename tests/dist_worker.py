@@ -16,8 +16,9 @@ from iif_amd.dist_solver import ShardedRunner, choose_transport, partition_cliqu
 from oracle.oracle_backend import OracleBackend  # noqa: E402
 
 
-def build():
+def build(joint=False):
     fg = iif.generateChainEuclid(24, vardims=2, priorEvery=8, N=100)
+    fg.solverParams.useMsgLikelihoods = joint
     for v in fg.ls():  # deterministic synthetic "initialised" beliefs (no initAll needed here)
         i = int(v[1:])
         rng = np.random.default_rng(i)
@@ -29,7 +30,7 @@ def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    fg, tree = build()
+    fg, tree = build(len(sys.argv) > 5 and sys.argv[5] == "joint")
     owner = partition_cliques(tree, world)
     tp = iif.TreeProgram(fg, tree, seed=7, owner=owner, rank=rank)
     be = OracleBackend(100, tp.n_slots, 0, threads=2)

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import dist_worker
 from iif_amd.dist_solver import partition_cliques
@@ -28,18 +29,19 @@ def test_partition_covers_tree_and_balances():
         assert cross <= 2 * world  # only the top of the tree crosses ranks
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("mode", ["priors", "joint"])
+def test_two_rank_gloo_matches_single_process(tmp_path, mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = str(s.getsockname()[1])
     s.close()
     outs = [str(tmp_path / f"r{r}.npz") for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", port, outs[r]])
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), "2", port, outs[r], mode])
              for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     # single-process reference with the same seeds
-    fg, tree = dist_worker.build()
+    fg, tree = dist_worker.build(mode == "joint")
     tp = iif.TreeProgram(fg, tree, seed=7)
     be = OracleBackend(100, tp.n_slots, 0, threads=4)
     for v in fg.ls():
