@@ -327,6 +327,11 @@ class FactorGraph:
         return self.variables[label].initialized
 
 
+def isPartial(fct):
+    """isPartial(fct) (test/testPartialFactors.jl:6-25): does the factor inform only some coordinates?"""
+    return getattr(fct.fnc if hasattr(fct, "fnc") else fct, "partial_mask", 0) != 0
+
+
 def deleteFactor(fg, label):
     """deleteFactor!(dfg, label)"""
     f = fg.factors.pop(label)

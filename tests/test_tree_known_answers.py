@@ -178,3 +178,16 @@ def test_tree_message_utils_structure():
         assert sorted(info["frontals"]) == sorted(tree.cliques[c].frontalIDs)
         assert sorted(info["separators"]) == sorted(tree.cliques[c].separatorIDs)
         assert info["parent"] == max(tree.cliques[c].parent, 0)
+
+
+def test_is_partial():
+    # test/testPartialFactors.jl:6-25
+    fg = iif.initfg()
+    iif.addVariable(fg, "x0", iif.ContinuousScalar)
+    iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal()))
+    assert not iif.isPartial(fg.getFactor("x0f1"))
+    fg = iif.initfg()
+    E2 = iif.ContinuousEuclid(2)
+    iif.addVariable(fg, "x1", E2)
+    iif.addFactor(fg, ["x1"], iif.PartialPrior(E2, iif.Normal(), (1,)))
+    assert iif.isPartial(fg.getFactor("x1f1"))
