@@ -21,7 +21,9 @@
  *    Manifolds 0.10 / ManifoldsBase -- exp/log/compose/vee/hat for TranslationGroup(D),
  *                                      RealCircleGroup, SpecialEuclidean(2; Hybrid tangent repr.)
  * The oracle is pinned *in distribution* by the acceptance bands of the reference's own tests
- * (tests/test_oracle_reference_bands.py cites each test file:line).
+ * (tests/test_oracle_reference_bands.py and tests/band_cases.py cite each test file:line), by the exact
+ * Gaussian posterior of a linear chain (tests/exact_gaussian.py) and by closed-form moments of its
+ * operations (tests/test_analytic_ops.py, tests/test_product_unbiased.py).
  *
  * All file:line citations are relative to the IncrementalInference.jl v0.35.6 source tree.
  *
