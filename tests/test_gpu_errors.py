@@ -113,3 +113,10 @@ def test_program_misuse(hip_backend):
     assert lib.nbp_program_run(p, 0, -1) == 0          # an empty program runs
     assert lib.nbp_program_destroy(p) == 0
     be.close()
+
+
+@pytest.mark.timeout(120)
+def test_degenerate_inputs_terminate_and_stay_finite(hip_backend):
+    """identical points, far-apart clusters, huge offsets, a NaN particle (tests/degenerate_inputs.py)"""
+    from degenerate_inputs import run_degenerate
+    run_degenerate(hip_backend)
