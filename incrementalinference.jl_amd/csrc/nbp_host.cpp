@@ -952,81 +952,85 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
   std::vector<nbp_proposal_desc> props;
   std::vector<nbp_product_desc> prods;
   nbp_status rc = NBP_OK;
-  // ---- up pass: leaves first
+  // ---- up pass: a clique starts its schedule in the stage after its last child finished (the rendezvous of the
+  // CliqueStateMachine, :221-234); stage t batches step t - start[c] of every running clique (solver.TreeProgram)
   if (g->sp.upsolve) {
-    for (int h = 0; h <= maxh; h++) {
-      std::vector<const Clique *> level;
-      size_t nsteps = 0;
-      // up schedule filtered like solver.TreeProgram: variables with at least one density, not marginalized
-      std::vector<std::vector<int>> sched, iters;
-      for (const Clique &c : t->cl)
-        if (height[c.id] == h) {
-          level.push_back(&c);
-          std::vector<int> s, it;
-          for (size_t k = 0; k < c.upsched.size(); k++) {
-            const int v = c.upsched[k];
-            bool any = false;
-            if (t->joint) any = !joint_entries(c, v, false).empty();
-            else {
-              for (int f : c.potentials)
-                for (int q = 0; q < g->facs[f].s.nvars && !any; q++) any = g->facs[f].s.vars[q] == v;
-              for (int chd : c.children) any |= contains(t->cl[chd - 1].seps, v);
-            }
-            if (any && !g->vars[v].ismargin) { s.push_back(v); it.push_back(c.upiter[k]); }
-          }
-          nsteps = std::max(nsteps, s.size());
-          sched.push_back(s);
-          iters.push_back(it);
+    const size_t nc = t->cl.size();
+    // up schedule filtered like solver.TreeProgram: variables with at least one density, not marginalized
+    std::vector<std::vector<int>> sched(nc + 1), iters(nc + 1);
+    for (const Clique &c : t->cl)
+      for (size_t k = 0; k < c.upsched.size(); k++) {
+        const int v = c.upsched[k];
+        bool any = false;
+        if (t->joint) any = !joint_entries(c, v, false).empty();
+        else {
+          for (int f : c.potentials)
+            for (int q = 0; q < g->facs[f].s.nvars && !any; q++) any = g->facs[f].s.vars[q] == v;
+          for (int chd : c.children) any |= contains(t->cl[chd - 1].seps, v);
         }
-      for (size_t k = 0; k < nsteps; k++) {
-        props.clear();
-        prods.clear();
-        for (size_t ci = 0; ci < level.size(); ci++) {
-          if (k >= sched[ci].size()) continue;
-          const Clique &c = *level[ci];
-          const int v = sched[ci][k];
-          std::vector<Entry> ent;
-          if (t->joint) ent = joint_entries(c, v, false);
-          else {
-            for (int f : c.potentials) {
-              bool hit = false;
-              for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
-              if (hit) ent.push_back({false, f});
-            }
-            for (int chd : c.children)
-              if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
-          }
-          const bool fresh = iters[ci][k] == 1 || !t->stored;
-          rc = update_ops(t, c.id, v, ent, nullptr, t->B[c.id - 1].at(v), PASS_UP, (int)k, seed, props, prods, fresh);
-          if (rc) return rc;
-          t->st.updates_up++;
-        }
-        add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
-        add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+        if (any && !g->vars[v].ismargin) { sched[c.id].push_back(v); iters[c.id].push_back(c.upiter[k]); }
       }
+    std::vector<int> ids, start(nc + 1, 0), finish(nc + 1, 0);
+    for (const Clique &c : t->cl) ids.push_back(c.id);
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return height[a] != height[b] ? height[a] < height[b] : a < b; });
+    int T = 0;
+    for (int cid : ids) {
+      int st = 0;
+      for (int chd : t->cl[cid - 1].children) st = std::max(st, finish[chd]);
+      start[cid] = st;
+      finish[cid] = st + (int)sched[cid].size();
+      T = std::max(T, finish[cid]);
+    }
+    for (int tt = 0; tt < T; tt++) {
       if (t->joint) {
-        // prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD!: approxDeconv between the solved separator beliefs of
-        // every differential pair (searched from samples of the default-constructed factor), manikde! of the result
+        // prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD! of the cliques that have just finished: approxDeconv
+        // between the solved separator beliefs of every differential pair (searched from samples of the
+        // default-constructed factor), manikde! of the result
         props.clear();
-        for (const Clique *c : level)
-          for (size_t i = 0; i < c->rel.size(); i++) {
+        for (const Clique &c : t->cl) {
+          if (finish[c.id] != tt || c.parent == 0) continue;
+          for (size_t i = 0; i < c.rel.size(); i++) {
             HFac dflt;
             memset(&dflt, 0, sizeof(dflt));
-            dflt.s.factor_kind = c->rel[i][3];
+            dflt.s.factor_kind = c.rel[i][3];
             dflt.s.nvars = 2;
-            dflt.s.vars[0] = c->rel[i][0];
-            dflt.s.vars[1] = c->rel[i][1];
+            dflt.s.vars[0] = c.rel[i][0];
+            dflt.s.vars[1] = c.rel[i][1];
             dflt.s.ncomp = 1;
             dflt.s.comp[0][0] = 1.0;
-            const int zd = dflt.s.factor_kind == NBP_F_LINREL ? mani_dim(g->vars[c->rel[i][0]].manifold) : (dflt.s.factor_kind == NBP_F_SE2 ? 3 : 1);
+            const int zd = dflt.s.factor_kind == NBP_F_LINREL ? mani_dim(g->vars[c.rel[i][0]].manifold) : (dflt.s.factor_kind == NBP_F_SE2 ? 3 : 1);
             for (int q = 0; q < zd; q++) dflt.s.comp[0][4 + 4 * q] = 1.0;  // identity square-root covariance
             nbp_proposal_desc d;
-            fill_proposal(g, d, &dflt, -1, c->rel[i][1], &t->B[c->id - 1], &t->main_slot, nullptr, c->Dslot[i],
-                          op_seed(seed, PASS_UP, c->id, 0x4000 + (int)i, 0), 0.0);
+            fill_proposal(g, d, &dflt, -1, c.rel[i][1], &t->B[c.id - 1], &t->main_slot, nullptr, c.Dslot[i],
+                          op_seed(seed, PASS_UP, c.id, 0x4000 + (int)i, 0), 0.0);
             props.push_back(d);
           }
+        }
         if (!props.empty()) add_stage(t, NBP_STAGE_DECONV, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
       }
+      props.clear();
+      prods.clear();
+      for (const Clique &c : t->cl) {
+        if (!(start[c.id] <= tt && tt < finish[c.id])) continue;
+        const int k = tt - start[c.id], v = sched[c.id][k];
+        std::vector<Entry> ent;
+        if (t->joint) ent = joint_entries(c, v, false);
+        else {
+          for (int f : c.potentials) {
+            bool hit = false;
+            for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
+            if (hit) ent.push_back({false, f});
+          }
+          for (int chd : c.children)
+            if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
+        }
+        const bool fresh = iters[c.id][k] == 1 || !t->stored;
+        rc = update_ops(t, c.id, v, ent, nullptr, t->B[c.id - 1].at(v), PASS_UP, k, seed, props, prods, fresh);
+        if (rc) return rc;
+        t->st.updates_up++;
+      }
+      add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
+      add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
     }
   }
   if (!g->sp.downsolve) {

@@ -666,6 +666,47 @@ class TreeProgram:
             self.segments.append(("xchg", sends, recvs))
             self._seg_start = len(self.stages)
 
+    def _deconv_descs(self, cliques):
+        """prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD!: approxDeconv between the solved separator beliefs
+        of every differential pair, manikde! of the predicted measurements"""
+        fg, sp, dec = self.fg, self.fg.solverParams, []
+        for c in cliques:
+            for i, (a, b, _, fk) in enumerate(self.joint[c].relatives):
+                dflt = DFGFactor(f"dummy{c}_{i}", [a, b], _default_relative(fk, fg.getVariable(a).varType), None, 0.0, sp.inflation)
+                dec.append(proposal_desc(fg, dflt, b, lambda u, c=c: self.B[(c, u)], self.D[(c, i)],
+                                         op_seed(self.seed, PASS_UP, c, 0x4000 + i, 0)))
+        return dec
+
+    def _compile_up_asap(self):
+        """Up pass on one rank: a clique starts its schedule in the stage after its last child finished (the
+        rendezvous of the CliqueStateMachine, CliqueStateMachine.jl:221-234: a parent waits for its own children,
+        not for a whole tree level).  Stage t batches step t - start[c] of every clique that is running; the
+        critical path is the longest root-to-leaf sum of schedule lengths instead of the sum of the per-level
+        maxima.  The random streams are keyed by (clique, step), so the results do not depend on the batching."""
+        tree = self.tree
+        start, finish = {}, {}
+        for c in sorted(self.cliques, key=lambda c: (self.heights[c], c)):
+            start[c] = max([finish[x] for x in tree.cliques[c].children] + [0])
+            finish[c] = start[c] + len(self.upsched[c])
+        for t in range(max(finish.values()) if finish else 0):
+            if self.joint is not None:  # the joint messages of the cliques that have just finished
+                dec = self._deconv_descs([c for c in self.cliques if finish[c] == t and tree.cliques[c].parent >= 0])
+                if dec:
+                    self._add(abi.STAGE_DECONV, dec, "up")
+            props, prods = [], []
+            for c in self.cliques:
+                if not (start[c] <= t < finish[c]):
+                    continue
+                k = t - start[c]
+                v = self.upsched[c][k]
+                p, q = self._update_ops(c, v, self.upfacs[c][v], lambda u, c=c: self.B[(c, u)], self.B[(c, v)], PASS_UP, k,
+                                        fresh=self.upfresh[c][k])
+                props += p
+                prods.append(q)
+                self.n_updates_up += 1
+            self._add(abi.STAGE_PROPOSALS, props, "up")
+            self._add(abi.STAGE_PRODUCTS, prods, "up")
+
     def _compile(self):
         tree, fg, rank, owner = self.tree, self.fg, self.rank, self.owner
         if self.snap is not None:
@@ -681,7 +722,10 @@ class TreeProgram:
         # upsolve = false: the cliques are "up-recycled" (tryDownSolveOnly_StateMachine, :485-529): no
         # update runs and the down solve works from the stored beliefs
         maxh = max(self.heights.values())
-        for h in (range(maxh + 1) if sp.upsolve else ()):
+        single = all(o == rank for o in owner.values())
+        if sp.upsolve and single:
+            self._compile_up_asap()
+        for h in (range(maxh + 1) if sp.upsolve and not single else ()):
             level = [c for c in self.cliques if self.heights[c] == h]
             nsteps = max([len(self.upsched[c]) for c in level] + [0])
             for k in range(nsteps):
@@ -699,14 +743,7 @@ class TreeProgram:
                 self._add(abi.STAGE_PROPOSALS, props, "up")
                 self._add(abi.STAGE_PRODUCTS, prods, "up")
             if self.joint is not None:
-                # prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD!: approxDeconv between the solved separator
-                # beliefs of every differential pair, manikde! of the predicted measurements
-                dec = []
-                for c in level:
-                    for i, (a, b, _, fk) in enumerate(self.joint[c].relatives):
-                        dflt = DFGFactor(f"dummy{c}_{i}", [a, b], _default_relative(fk, fg.getVariable(a).varType), None, 0.0, sp.inflation)
-                        dec.append(proposal_desc(fg, dflt, b, lambda u, c=c: self.B[(c, u)], self.D[(c, i)],
-                                                 op_seed(self.seed, PASS_UP, c, 0x4000 + i, 0)))
+                dec = self._deconv_descs(level)
                 if dec:
                     self._add(abi.STAGE_DECONV, dec, "up")
             # up messages that cross a rank boundary: child's separator beliefs -> parent's ghost slots
