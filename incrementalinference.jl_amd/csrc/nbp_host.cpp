@@ -1044,37 +1044,56 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       for (int v : t->cl[r - 1].frontals) cps.push_back({t->B[r - 1].at(v), t->main_slot[v]});
     add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
     std::vector<nbp_copy_desc> final_cps;
-    for (int dpt = 1; dpt <= maxd; dpt++) {
-      std::vector<const Clique *> level;
-      size_t nsteps = 0;
+    for (int dpt = 1; dpt <= maxd; dpt++)
       for (const Clique &c : t->cl)
-        if (depth[c.id] == dpt) { level.push_back(&c); nsteps = std::max(nsteps, (t->joint ? t->jdnsched[c.id - 1] : c.dnsched).size()); }
-      cps.clear();
-      for (const Clique *c : level)
-        for (int s : c->seps) cps.push_back({t->B[c->parent - 1].at(s), t->B[c->id - 1].at(s)});
-      add_stage(t, NBP_STAGE_COPY_POINTS, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());  // read as points only
-      for (size_t k = 0; k < nsteps; k++) {
+        if (depth[c.id] == dpt)
+          for (int v : c.frontals) final_cps.push_back({t->B[c.id - 1].at(v), t->main_slot[v]});
+    // batched by dependency like the up pass: a clique receives its parent's separator values (points-only copy)
+    // and starts in the stage after the parent's last update (solver.TreeProgram._compile_down_asap)
+    {
+      const size_t nc = t->cl.size();
+      auto dsched = [&](const Clique &c) -> const std::vector<int> & { return t->joint ? t->jdnsched[c.id - 1] : c.dnsched; };
+      std::vector<int> ids, start(nc + 1, 0), finish(nc + 1, 0);
+      for (const Clique &c : t->cl) ids.push_back(c.id);
+      std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return depth[a] != depth[b] ? depth[a] < depth[b] : a < b; });
+      int T = 0;
+      for (int cid : ids) {
+        const Clique &c = t->cl[cid - 1];
+        start[cid] = c.parent ? finish[c.parent] : 0;
+        finish[cid] = start[cid] + (int)dsched(c).size();
+        T = std::max(T, finish[cid]);
+      }
+      for (int tt = 0; tt <= T; tt++) {
+        std::set<int> depths;
+        for (const Clique &c : t->cl)
+          if (start[c.id] == tt && c.parent) depths.insert(depth[c.id]);
+        for (int dpt : depths) {  // shallower cliques first: values are handed on within the same time step
+          cps.clear();
+          for (const Clique &c : t->cl)
+            if (start[c.id] == tt && c.parent && depth[c.id] == dpt)
+              for (int s : c.seps) cps.push_back({t->B[c.parent - 1].at(s), t->B[c.id - 1].at(s)});
+          add_stage(t, NBP_STAGE_COPY_POINTS, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());  // read as points only
+        }
         props.clear();
         prods.clear();
-        for (const Clique *c : level) {
-          const std::vector<int> &dsch = t->joint ? t->jdnsched[c->id - 1] : c->dnsched;
-          if (k >= dsch.size()) continue;
-          const int v = dsch[k];
-          const std::vector<int> allv = c->all();
+        for (const Clique &c : t->cl) {
+          if (!(start[c.id] <= tt && tt < finish[c.id])) continue;
+          const int k = tt - start[c.id], v = dsched(c)[k];
+          const std::vector<int> allv = c.all();
           std::set<int> inclq(allv.begin(), allv.end());
           std::vector<Entry> ent;
-          if (t->joint) ent = joint_entries(*c, v, true);
+          if (t->joint) ent = joint_entries(c, v, true);
           else
             for (int f : g->vfacs[v]) ent.push_back({false, f});
-          rc = update_ops(t, c->id, v, ent, &inclq, t->B[c->id - 1].at(v), PASS_DOWN, (int)k, seed, props, prods);
+          rc = update_ops(t, c.id, v, ent, &inclq, t->B[c.id - 1].at(v), PASS_DOWN, k, seed, props, prods);
           if (rc) return rc;
           t->st.updates_down++;
         }
-        add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
-        add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+        if (!prods.empty()) {
+          add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
+          add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+        }
       }
-      for (const Clique *c : level)
-        for (int v : c->frontals) final_cps.push_back({t->B[c->id - 1].at(v), t->main_slot[v]});
     }
     // transferUpdateSubGraph!, once for the whole pass (see solver.TreeProgram)
     add_stage(t, NBP_STAGE_COPIES, final_cps.data(), sizeof(nbp_copy_desc), (int)final_cps.size());

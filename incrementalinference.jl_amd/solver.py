@@ -707,6 +707,41 @@ class TreeProgram:
             self._add(abi.STAGE_PROPOSALS, props, "up")
             self._add(abi.STAGE_PRODUCTS, prods, "up")
 
+    def _compile_down_asap(self):
+        """Down pass on one rank, batched by dependency like the up pass: a clique receives its parent's
+        separator values (points-only copy) and starts in the stage after the parent's last update."""
+        tree = self.tree
+        start, finish = {}, {}
+        for c in sorted(self.cliques, key=lambda c: (self.depths[c], c)):
+            par = tree.cliques[c].parent
+            start[c] = finish[par] if par >= 0 else 0
+            finish[c] = start[c] + len(self.dnsched[c])
+        for t in range(max(finish.values()) + 1 if finish else 0):
+            # down messages of the cliques that start now, shallower cliques first (a clique without updates of
+            # its own hands the values on within the same time step)
+            starting = [c for c in self.cliques if start[c] == t and tree.cliques[c].parent >= 0]
+            for dpt in sorted({self.depths[c] for c in starting}):
+                self._add(abi.STAGE_COPY_POINTS, [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)])
+                                                  for c in starting if self.depths[c] == dpt for s in tree.cliques[c].separatorIDs], "down")
+            props, prods = [], []
+            for c in self.cliques:
+                if not (start[c] <= t < finish[c]):
+                    continue
+                k = t - start[c]
+                v = self.dnsched[c][k]
+                inclq = set(tree.cliques[c].allIDs)
+
+                def slot_of(u, c=c, inclq=inclq):
+                    return self.B[(c, u)] if u in inclq else self.main[u]
+
+                p, q = self._update_ops(c, v, self.dnfacs[c][v], slot_of, self.B[(c, v)], PASS_DOWN, k)
+                props += p
+                prods.append(q)
+                self.n_updates_down += 1
+            if prods:
+                self._add(abi.STAGE_PROPOSALS, props, "down")
+                self._add(abi.STAGE_PRODUCTS, prods, "down")
+
     def _compile(self):
         tree, fg, rank, owner = self.tree, self.fg, self.rank, self.owner
         if self.snap is not None:
@@ -771,7 +806,10 @@ class TreeProgram:
         # ---- down pass: root first --------------------------------------------------------------
         maxd = max(self.depths.values())
         done = []
-        for dpt in range(1, maxd + 1):
+        if single:
+            done = [c for dpt in range(1, maxd + 1) for c in self.cliques if self.depths[c] == dpt]
+            self._compile_down_asap()
+        for dpt in (range(1, maxd + 1) if not single else ()):
             # down messages that cross a rank boundary: parent's values of the child's separators
             edges = []
             for c in allc:
