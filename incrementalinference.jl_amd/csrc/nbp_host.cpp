@@ -1064,14 +1064,24 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         T = std::max(T, finish[cid]);
       }
       for (int tt = 0; tt <= T; tt++) {
-        std::set<int> depths;
-        for (const Clique &c : t->cl)
-          if (start[c.id] == tt && c.parent) depths.insert(depth[c.id]);
-        for (int dpt : depths) {  // shallower cliques first: values are handed on within the same time step
+        // one copy stage, or one more per link of a chain of cliques without updates of their own, which hand
+        // the values on within the same time step
+        std::map<int, int> rnd;
+        int nrounds = 0;
+        for (int cid : ids) {  // depth order
+          const Clique &c = t->cl[cid - 1];
+          if (start[cid] != tt || !c.parent) continue;
+          auto it = rnd.find(c.parent);
+          rnd[cid] = it == rnd.end() ? 0 : it->second + 1;
+          nrounds = std::max(nrounds, rnd[cid] + 1);
+        }
+        for (int r = 0; r < nrounds; r++) {
           cps.clear();
-          for (const Clique &c : t->cl)
-            if (start[c.id] == tt && c.parent && depth[c.id] == dpt)
-              for (int s : c.seps) cps.push_back({t->B[c.parent - 1].at(s), t->B[c.id - 1].at(s)});
+          for (const Clique &c : t->cl) {
+            auto it = rnd.find(c.id);
+            if (it == rnd.end() || it->second != r) continue;
+            for (int s : c.seps) cps.push_back({t->B[c.parent - 1].at(s), t->B[c.id - 1].at(s)});
+          }
           add_stage(t, NBP_STAGE_COPY_POINTS, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());  // read as points only
         }
         props.clear();

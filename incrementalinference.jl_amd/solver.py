@@ -717,12 +717,15 @@ class TreeProgram:
             start[c] = finish[par] if par >= 0 else 0
             finish[c] = start[c] + len(self.dnsched[c])
         for t in range(max(finish.values()) + 1 if finish else 0):
-            # down messages of the cliques that start now, shallower cliques first (a clique without updates of
-            # its own hands the values on within the same time step)
+            # down messages of the cliques that start now: one copy stage, or one more per link of a chain of
+            # cliques without updates of their own, which hand the values on within the same time step
             starting = [c for c in self.cliques if start[c] == t and tree.cliques[c].parent >= 0]
-            for dpt in sorted({self.depths[c] for c in starting}):
+            rnd = {}
+            for c in sorted(starting, key=lambda c: (self.depths[c], c)):
+                rnd[c] = rnd[tree.cliques[c].parent] + 1 if tree.cliques[c].parent in rnd else 0
+            for r in sorted(set(rnd.values())):
                 self._add(abi.STAGE_COPY_POINTS, [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)])
-                                                  for c in starting if self.depths[c] == dpt for s in tree.cliques[c].separatorIDs], "down")
+                                                  for c in starting if rnd[c] == r for s in tree.cliques[c].separatorIDs], "down")
             props, prods = [], []
             for c in self.cliques:
                 if not (start[c] <= t < finish[c]):

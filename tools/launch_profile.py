@@ -1,10 +1,10 @@
 """Per-launch durations of one step from a rocprofv3 --kernel-trace CSV, sorted by grid size.
-Usage: launch_profile.py <kernel_trace.csv> [launches_per_step=67]"""
+Usage: launch_profile.py <kernel_trace.csv> [launches_per_step=60]"""
 import csv
 import sys
 
 
-def main(path, lps=67):
+def main(path, lps=60):
     rows = list(csv.DictReader(open(path)))
     for kn in ("nbp_proposal_kernel", "nbp_prep_kernel", "nbp_product_kernel"):
         rs = [r for r in rows if r["Kernel_Name"].startswith(kn)][-lps:]
@@ -18,4 +18,4 @@ def main(path, lps=67):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 67)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60)

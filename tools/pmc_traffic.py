@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum,TCC_MISS_sum; one pass each,
-no tracing) of `bench.py --steps K`: per-kernel averages over the TIMED region (the last K x 67
+no tracing) of `bench.py --steps K`: per-kernel averages over the TIMED region (the last K x 60
 dispatches of each kernel), the nbp_copy_kernel calibration of the counters' units (a copy launch
 moves exactly blocks x slot_stride x 8 bytes each way in the same 8 B/lane access pattern the other
 kernels use), and the corrected HBM bytes per launch.
@@ -21,7 +21,7 @@ def load(d):
     return list(csv.DictReader(fh))
 
 
-def per_kernel(rows, counter, steps, lps=67):
+def per_kernel(rows, counter, steps, lps=60):
     by = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] != counter:

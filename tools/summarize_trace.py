@@ -6,7 +6,7 @@ import collections
 import sys
 
 
-def main(path, steps, lps=67):
+def main(path, steps, lps=60):
     rows = list(csv.DictReader(open(path)))
     by = collections.defaultdict(list)
     for r in rows:
@@ -35,4 +35,4 @@ def main(path, steps, lps=67):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 67)
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 60)
