@@ -511,8 +511,9 @@ class TreeProgram:
     edges whose two cliques live on different ranks become exchange items between the stage
     segments (`self.segments`): the separator beliefs are sent slot-by-slot, point to point."""
 
-    def __init__(self, fg, tree, seed=0, snapshot=False, owner=None, rank=0):
+    def __init__(self, fg, tree, seed=0, snapshot=False, owner=None, rank=0, asap=None):
         self.fg, self.tree, self.seed = fg, tree, seed
+        self.asap = asap  # None: batch by dependency on one rank, by tree level across ranks; False forces levels
         self.rank = rank
         self.owner = owner or {c: 0 for c in tree.cliques}
         sp = fg.solverParams
@@ -760,7 +761,7 @@ class TreeProgram:
         # upsolve = false: the cliques are "up-recycled" (tryDownSolveOnly_StateMachine, :485-529): no
         # update runs and the down solve works from the stored beliefs
         maxh = max(self.heights.values())
-        single = all(o == rank for o in owner.values())
+        single = all(o == rank for o in owner.values()) if self.asap is None else bool(self.asap)
         if sp.upsolve and single:
             self._compile_up_asap()
         for h in (range(maxh + 1) if sp.upsolve and not single else ()):

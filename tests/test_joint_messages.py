@@ -120,3 +120,30 @@ def test_differential_factor_roundtrip_on_the_oracle():
     out, _ = be.slot_read(3, man)
     assert np.abs(out.mean(axis=0) - b.mean(axis=0)).max() < 0.15
     be.close()
+
+
+def test_batching_by_dependency_or_by_level_gives_the_same_posteriors():
+    # the random streams are keyed by (pass, clique, step): how cliques are batched into stages changes nothing
+    from test_native_host import mark_initialised, random_graph
+    for seed in (1, 4, 8, 11):  # plain, joint-message and stored-measurement graphs
+        fg = random_graph(seed)
+        fg.solverParams.useMsgLikelihoods = seed % 3 == 1
+        fg.solverParams.alwaysFreshMeasurements = seed % 3 != 2
+        mark_initialised(fg)
+        tree = iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
+        res = []
+        for asap in (True, False):
+            tp = iif.TreeProgram(fg, tree, seed=seed, asap=asap)
+            be = OracleBackend(fg.solverParams.N, tp.n_slots, 0, threads=4)
+            for v in fg.ls():
+                var = fg.getVariable(v)
+                be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+            be.program(tp.stages).run()
+            res.append({v: be.slot_read(tp.main[v], fg.getVariable(v).varType.manifold) for v in fg.ls()})
+            be.close()
+        n_dep = sum(1 for k, _ in iif.TreeProgram(fg, tree, seed=seed, asap=True).stages if k == abi.STAGE_PRODUCTS)
+        n_lev = sum(1 for k, _ in iif.TreeProgram(fg, tree, seed=seed, asap=False).stages if k == abi.STAGE_PRODUCTS)
+        assert n_dep <= n_lev
+        for v in fg.ls():
+            np.testing.assert_array_equal(res[0][v][0], res[1][v][0])
+            np.testing.assert_array_equal(res[0][v][1], res[1][v][1])
