@@ -540,6 +540,8 @@ class TreeProgram:
         self.heights, self.depths = tree.heights(), tree.depths()
         mine = [c for c in tree.cliques if self.owner[c] == rank]
         self.cliques = mine
+        for cid in tree.cliques:
+            self._plan_symbolic(cid)
         for cid in mine:
             cl = tree.cliques[cid]
             for v in cl.allIDs:
@@ -554,44 +556,11 @@ class TreeProgram:
                         for i in range(len(self.joint[ch].relatives)):
                             self.D[(ch, i)] = nxt
                             nxt += 1
-            # up-solve factor lists per variable: clique potentials touching v + child messages on v
-            upf = {}
-            for v in cl.allIDs:
-                if self.joint is not None:  # potentials + the children's differentials + their common priors
-                    lst = [(f.tag, f.ref) if f.tag != "p" else ("m", f.ref[0]) for f in self.joint[cid].factors if v in f.variables]
-                else:
-                    lst = [("f", f) for f in cl.potentials if v in fg.getFactor(f).variables]
-                    for ch in cl.children:
-                        if v in tree.cliques[ch].separatorIDs:
-                            lst.append(("m", ch))
-                upf[v] = lst
             if self.joint is not None:
                 for i in range(len(self.joint[cid].relatives)):
                     self.D[(cid, i)] = nxt
                     nxt += 1
-            # doFMCIteration skips marginalized variables (SolveTree.jl:61)
-            full = [(v, it) for v, it in bayestree.upGibbsSchedule(cl, sp.gibbsIters, with_iteration=True)
-                    if upf[v] and not fg.getVariable(v).ismargin]
-            sched = [v for v, _ in full]
-            # needFreshMeasurements = iter == 1 || alwaysFreshMeasurements (SolveTree.jl:119)
-            self.upfresh[cid] = [it == 1 or sp.alwaysFreshMeasurements for _, it in full]
-            self.upsched[cid], self.upfacs[cid] = sched, upf
-            if self.joint is None:
-                dnf = {v: [("f", f) for f in fg.ls(v)] for v in cl.frontalIDs}
-                dsch = bayestree.downSchedule(fg, cl, sp.gibbsIters) if cl.parent >= 0 else []
-            else:
-                # no addDownVariableFactors! (CliqueStateMachine.jl:823): the down solve works on the clique sub
-                # graph as the up solve left it -- potentials + the children's differentials (:558 removes
-                # only the __UPWARD_COMMON__ priors)
-                kept = [f for f in self.joint[cid].factors if f.tag != "p"]
-                dnf = {v: [(f.tag, f.ref) for f in kept if v in f.variables] for v in cl.frontalIDs}
-                frs = set(cl.frontalIDs)
-                itv = {v for f in kept if len([u for u in f.variables if u in frs]) > 1 for v in f.variables if v in frs}
-                skip = {v for v in cl.frontalIDs if sp.limitfixeddown and fg.getVariable(v).ismargin}
-                dsch = ([v for v in cl.frontalIDs if v not in itv and v not in skip and dnf[v]]
-                        + [v for v in cl.frontalIDs if v in itv and v not in skip] * sp.gibbsIters) if cl.parent >= 0 else []
-            self.dnfacs[cid] = dnf
-            self.dnsched[cid] = dsch
+            upf, sched, dnf = self.upfacs[cid], self.upsched[cid], self.dnfacs[cid]
             maxf = max([len(upf[v]) for v in sched] + [len(dnf[v]) for v in self.dnsched[cid]] + [1])
             if maxf > abi.MAXF:
                 raise ValueError(f"clique {cid}: {maxf} densities in one product exceeds NBP_MAXF")
@@ -607,6 +576,47 @@ class TreeProgram:
         self.alg_bytes = 0
         self.alg = {"nbp_proposal_kernel": 0, "nbp_prep_kernel": 0, "nbp_product_kernel": 0, "nbp_bandwidth_kernel": 0}
         self._compile()
+
+    def _plan_symbolic(self, cid):
+        """the symbolic half of one clique's plan (no slots): factor lists and schedules of its up and down solve --
+        computed for EVERY clique on every rank, because the stage times of a rank's cliques depend on the
+        schedule lengths of cliques elsewhere in the tree"""
+        fg, tree, sp = self.fg, self.tree, self.fg.solverParams
+        cl = tree.cliques[cid]
+        # up-solve factor lists per variable: clique potentials touching v + child messages on v
+        upf = {}
+        for v in cl.allIDs:
+            if self.joint is not None:  # potentials + the children's differentials + their common priors
+                lst = [(f.tag, f.ref) if f.tag != "p" else ("m", f.ref[0]) for f in self.joint[cid].factors if v in f.variables]
+            else:
+                lst = [("f", f) for f in cl.potentials if v in fg.getFactor(f).variables]
+                for ch in cl.children:
+                    if v in tree.cliques[ch].separatorIDs:
+                        lst.append(("m", ch))
+            upf[v] = lst
+        # doFMCIteration skips marginalized variables (SolveTree.jl:61)
+        full = [(v, it) for v, it in bayestree.upGibbsSchedule(cl, sp.gibbsIters, with_iteration=True)
+                if upf[v] and not fg.getVariable(v).ismargin]
+        sched = [v for v, _ in full]
+        # needFreshMeasurements = iter == 1 || alwaysFreshMeasurements (SolveTree.jl:119)
+        self.upfresh[cid] = [it == 1 or sp.alwaysFreshMeasurements for _, it in full]
+        self.upsched[cid], self.upfacs[cid] = sched, upf
+        if self.joint is None:
+            dnf = {v: [("f", f) for f in fg.ls(v)] for v in cl.frontalIDs}
+            dsch = bayestree.downSchedule(fg, cl, sp.gibbsIters) if cl.parent >= 0 else []
+        else:
+            # no addDownVariableFactors! (CliqueStateMachine.jl:823): the down solve works on the clique sub
+            # graph as the up solve left it -- potentials + the children's differentials (:558 removes
+            # only the __UPWARD_COMMON__ priors)
+            kept = [f for f in self.joint[cid].factors if f.tag != "p"]
+            dnf = {v: [(f.tag, f.ref) for f in kept if v in f.variables] for v in cl.frontalIDs}
+            frs = set(cl.frontalIDs)
+            itv = {v for f in kept if len([u for u in f.variables if u in frs]) > 1 for v in f.variables if v in frs}
+            skip = {v for v in cl.frontalIDs if sp.limitfixeddown and fg.getVariable(v).ismargin}
+            dsch = ([v for v in cl.frontalIDs if v not in itv and v not in skip and dnf[v]]
+                    + [v for v in cl.frontalIDs if v in itv and v not in skip] * sp.gibbsIters) if cl.parent >= 0 else []
+        self.dnfacs[cid] = dnf
+        self.dnsched[cid] = dsch
 
     # -- helpers ------------------------------------------------------------------------------
     def _account(self, man, F_in):
