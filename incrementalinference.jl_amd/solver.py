@@ -513,7 +513,7 @@ class TreeProgram:
 
     def __init__(self, fg, tree, seed=0, snapshot=False, owner=None, rank=0, asap=None):
         self.fg, self.tree, self.seed = fg, tree, seed
-        self.asap = asap  # None: batch by dependency on one rank, by tree level across ranks; False forces levels
+        self.asap = asap  # None / True: cliques batched by dependency; False: by tree level (kept for the equivalence test)
         self.rank = rank
         self.owner = owner or {c: 0 for c in tree.cliques}
         sp = fg.solverParams
@@ -689,21 +689,25 @@ class TreeProgram:
         return dec
 
     def _compile_up_asap(self):
-        """Up pass on one rank: a clique starts its schedule in the stage after its last child finished (the
-        rendezvous of the CliqueStateMachine, CliqueStateMachine.jl:221-234: a parent waits for its own children,
-        not for a whole tree level).  Stage t batches step t - start[c] of every clique that is running; the
+        """Up pass: a clique starts its schedule in the stage after its last child finished (the rendezvous of
+        the CliqueStateMachine, CliqueStateMachine.jl:221-234: a parent waits for its own children, not for a
+        whole tree level).  Stage t batches step t - start[c] of every clique of this rank that is running; the
         critical path is the longest root-to-leaf sum of schedule lengths instead of the sum of the per-level
-        maxima.  The random streams are keyed by (clique, step), so the results do not depend on the batching."""
-        tree = self.tree
+        maxima.  The stage times are those of the WHOLE tree (the same on every rank), so a message that crosses
+        ranks is exchanged at a point both sides agree on: before stage t for the cliques that finished at t.
+        The random streams are keyed by (clique, step), so the results do not depend on the batching."""
+        tree, owner, rank = self.tree, self.owner, self.rank
         start, finish = {}, {}
-        for c in sorted(self.cliques, key=lambda c: (self.heights[c], c)):
+        for c in sorted(tree.cliques, key=lambda c: (self.heights[c], c)):
             start[c] = max([finish[x] for x in tree.cliques[c].children] + [0])
             finish[c] = start[c] + len(self.upsched[c])
         for t in range(max(finish.values()) if finish else 0):
+            done = [c for c in sorted(tree.cliques) if finish[c] == t and tree.cliques[c].parent >= 0]
             if self.joint is not None:  # the joint messages of the cliques that have just finished
-                dec = self._deconv_descs([c for c in self.cliques if finish[c] == t and tree.cliques[c].parent >= 0])
+                dec = self._deconv_descs([c for c in self.cliques if c in done])
                 if dec:
                     self._add(abi.STAGE_DECONV, dec, "up")
+            self._exchange(self._up_edges([c for c in done if owner[c] != owner[tree.cliques[c].parent]]))
             props, prods = [], []
             for c in self.cliques:
                 if not (start[c] <= t < finish[c]):
@@ -715,28 +719,50 @@ class TreeProgram:
                 props += p
                 prods.append(q)
                 self.n_updates_up += 1
-            self._add(abi.STAGE_PROPOSALS, props, "up")
-            self._add(abi.STAGE_PRODUCTS, prods, "up")
+            if prods:
+                self._add(abi.STAGE_PROPOSALS, props, "up")
+                self._add(abi.STAGE_PRODUCTS, prods, "up")
+
+    def _up_edges(self, cliques):
+        """up messages that cross a rank boundary: the child's separator beliefs (and, in joint-message mode, the
+        KDEs of its differential factors) -> the parent rank's landing slots"""
+        tree, owner, edges = self.tree, self.owner, []
+        for c in cliques:
+            cl = tree.cliques[c]
+            for v in cl.separatorIDs:
+                edges.append((owner[c], (lambda c=c, v=v: self.B[(c, v)]), owner[cl.parent], (lambda c=c, v=v: self.ghost[(c, v)])))
+            for i in range(len(self.joint[c].relatives) if self.joint is not None else 0):
+                # D[(c, i)] names the sender's own slot on its rank and the landing slot on the parent's
+                edges.append((owner[c], (lambda c=c, i=i: self.D[(c, i)]), owner[cl.parent], (lambda c=c, i=i: self.D[(c, i)])))
+        return edges
 
     def _compile_down_asap(self):
-        """Down pass on one rank, batched by dependency like the up pass: a clique receives its parent's
-        separator values (points-only copy) and starts in the stage after the parent's last update."""
-        tree = self.tree
+        """Down pass, batched by dependency like the up pass: a clique receives its parent's separator values
+        (a points-only copy, or an exchange when the parent lives on another rank) and starts in the stage after
+        the parent's last update."""
+        tree, owner, rank = self.tree, self.owner, self.rank
         start, finish = {}, {}
-        for c in sorted(self.cliques, key=lambda c: (self.depths[c], c)):
+        for c in sorted(tree.cliques, key=lambda c: (self.depths[c], c)):
             par = tree.cliques[c].parent
             start[c] = finish[par] if par >= 0 else 0
             finish[c] = start[c] + len(self.dnsched[c])
         for t in range(max(finish.values()) + 1 if finish else 0):
-            # down messages of the cliques that start now: one copy stage, or one more per link of a chain of
-            # cliques without updates of their own, which hand the values on within the same time step
-            starting = [c for c in self.cliques if start[c] == t and tree.cliques[c].parent >= 0]
+            # down messages of the cliques that start now: one round, or one more per link of a chain of cliques
+            # without updates of their own, which hand the values on within the same time step
+            starting = [c for c in sorted(tree.cliques) if start[c] == t and tree.cliques[c].parent >= 0]
             rnd = {}
             for c in sorted(starting, key=lambda c: (self.depths[c], c)):
                 rnd[c] = rnd[tree.cliques[c].parent] + 1 if tree.cliques[c].parent in rnd else 0
             for r in sorted(set(rnd.values())):
-                self._add(abi.STAGE_COPY_POINTS, [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)])
-                                                  for c in starting if rnd[c] == r for s in tree.cliques[c].separatorIDs], "down")
+                self._exchange([(owner[tree.cliques[c].parent], (lambda p=tree.cliques[c].parent, v=v: self.B[(p, v)]), owner[c],
+                                 (lambda c=c, v=v: self.B[(c, v)]))
+                                for c in starting if rnd[c] == r and owner[c] != owner[tree.cliques[c].parent]
+                                for v in tree.cliques[c].separatorIDs])
+                msg = [abi.CopyDesc(self.B[(tree.cliques[c].parent, s)], self.B[(c, s)])
+                       for c in self.cliques if c in rnd and rnd[c] == r and owner[tree.cliques[c].parent] == rank
+                       for s in tree.cliques[c].separatorIDs]
+                if msg:
+                    self._add(abi.STAGE_COPY_POINTS, msg, "down")
             props, prods = [], []
             for c in self.cliques:
                 if not (start[c] <= t < finish[c]):
@@ -771,7 +797,7 @@ class TreeProgram:
         # upsolve = false: the cliques are "up-recycled" (tryDownSolveOnly_StateMachine, :485-529): no
         # update runs and the down solve works from the stored beliefs
         maxh = max(self.heights.values())
-        single = all(o == rank for o in owner.values()) if self.asap is None else bool(self.asap)
+        single = True if self.asap is None else bool(self.asap)  # "single": batch by dependency (every program by default)
         if sp.upsolve and single:
             self._compile_up_asap()
         for h in (range(maxh + 1) if sp.upsolve and not single else ()):
