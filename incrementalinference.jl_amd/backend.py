@@ -6,6 +6,7 @@ The product backend is :class:`HipBackend`.  (The CPU oracle implements the same
 ``oracle/`` -- test infrastructure, never imported from this package.)
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -32,6 +33,7 @@ class HipBackend:
         self.lib = abi.load_library()
         self.N, self.n_slots = int(N), int(n_slots)
         self._ctx = C.c_void_p()
+        self._programs = weakref.WeakSet()  # live HipPrograms: closed before the context (close())
         self._check(self.lib.nbp_ctx_create(device, self.N, self.n_slots, arena_ptr, arena_bytes,
                                             max(int(side_ints), 1), C.byref(self._ctx)))
 
@@ -42,6 +44,8 @@ class HipBackend:
 
     def close(self):
         if self._ctx:
+            for prog in list(getattr(self, "_programs", ())):  # a program must not outlive its context
+                prog.close()
             self.lib.nbp_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -190,6 +194,7 @@ class HipProgram:
         self.backend, lib = backend, backend.lib
         self._p = C.c_void_p()
         backend._check(lib.nbp_program_create(backend._ctx, C.byref(self._p)))
+        backend._programs.add(self)
         if lazy_bandwidth:  # whole-solve programs: intermediate bandwidths nobody reads are not fitted
             backend._check(lib.nbp_program_set_option(self._p, abi.OPT_LAZY_BANDWIDTH, 1))
         for kind, descs in stages:

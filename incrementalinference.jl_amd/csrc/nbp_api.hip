@@ -26,7 +26,9 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
       return fail(NBP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
   } while (0)
 
+struct nbp_program;
 struct nbp_ctx {
+  std::vector<nbp_program *> programs;  // live programs: detached (device blob freed, ctx = null) by nbp_ctx_destroy
   int device = 0, N = 0, n_slots = 0, side_ints = 0, threads = 0, Npad = 0, P = 1;
   int64_t S = 0;
   double *arena = nullptr;
@@ -145,6 +147,11 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   if (device < 0 || device >= ndev) return fail(NBP_ERR_ARG, "bad device index");
   HIPCHK(hipSetDevice(device));
   nbp_ctx *c = new nbp_ctx();
+  // any failure below releases the half-built context (stream, side buffer, counters, arena)
+  struct guard_t {
+    nbp_ctx *c;
+    ~guard_t() { if (c) nbp_ctx_destroy(c); }
+  } guard{c};
   c->device = device;
   c->N = N;
   c->n_slots = n_slots;
@@ -156,7 +163,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   c->threads = c->P * c->Npad;
   c->side_ints = side_ints > 0 ? side_ints : 1;
   if (arena) {
-    if (arena_bytes < nbp_arena_bytes(N, n_slots)) { delete c; return fail(NBP_ERR_ARG, "arena too small"); }
+    if (arena_bytes < nbp_arena_bytes(N, n_slots)) return fail(NBP_ERR_ARG, "arena too small");
     c->arena = (double *)arena;
   } else {
     HIPCHK(hipMalloc(&c->arena, nbp_arena_bytes(N, n_slots)));
@@ -171,31 +178,37 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_x16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_l8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_m4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_t2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
+  guard.c = nullptr;
   *out = c;
   return NBP_OK;
 }
 
+static void program_detach(nbp_program *p);
+
 nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (!c) return NBP_OK;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (nbp_program *p : c->programs) program_detach(p);  // a program outliving its context must not touch it
+  c->programs.clear();
   for (auto &v : c->ev)
     for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   if (c->own_arena) hipFree(c->arena);
-  hipFree(c->side);
-  hipFree(c->counters);
-  hipFree(c->lv_ints);
-  hipFree(c->lv_dbls);
+  if (c->side) hipFree(c->side);
+  if (c->counters) hipFree(c->counters);
+  if (c->lv_ints) hipFree(c->lv_ints);
+  if (c->lv_dbls) hipFree(c->lv_dbls);
   if (c->stage) hipFree(c->stage);
   if (c->ws) hipFree(c->ws);
   if (c->gstats) hipFree(c->gstats);
-  hipStreamDestroy(c->stream);
+  if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return NBP_OK;
 }
@@ -780,12 +793,21 @@ nbp_status nbp_program_create(nbp_ctx *c, nbp_program **out) {
   if (!c || !out) return fail(NBP_ERR_ARG, "null argument");
   nbp_program *p = new nbp_program();
   p->ctx = c;
+  c->programs.push_back(p);
   *out = p;
   return NBP_OK;
 }
+// the context is going away: free the device blob while the context's device is still current
+static void program_detach(nbp_program *p) {
+  if (p->dev) hipFree(p->dev);
+  p->dev = nullptr;
+  p->ctx = nullptr;
+}
+#define PROG_ALIVE(p) do { if (!(p)->ctx) return fail(NBP_ERR_ARG, "the program's context was destroyed"); } while (0)
 
 nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs, int32_t n) {
   if (!p || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  PROG_ALIVE(p);
   if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
   if (n < 0) return fail(NBP_ERR_ARG, "n < 0");
   size_t esz;
@@ -834,6 +856,15 @@ static nbp_liveness product_liveness(const nbp_program *p) {
   struct Open { int stage, idx, pstage, pidx; };  // pstage >= 0: pass-through of that proposal's KDE
   std::unordered_map<int32_t, Open> open;                        // slot -> unresolved product output
   std::unordered_map<int32_t, std::pair<int, int>> last_prop;    // scratch slot -> proposal that wrote it
+  // proposals whose own KDE (points + bandwidth) is read directly: an input of a real product, the message of a
+  // MsgPrior, a measurement KDE or the source of a slot copy.  Such a fit is live whatever happens to the output of
+  // a pass-through product that also carries it.
+  std::vector<std::pair<int, int>> needed;
+  auto read_kde = [&](int32_t slot) {
+    open.erase(slot);
+    auto lp = last_prop.find(slot);
+    if (lp != last_prop.end()) needed.push_back(lp->second);
+  };
   auto kill = [&](int32_t slot) {
     auto it = open.find(slot);
     if (it == open.end()) return;
@@ -849,8 +880,8 @@ static nbp_liveness product_liveness(const nbp_program *p) {
       const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
       L.dead_proposal[s].assign(st.n, 0);
       for (int i = 0; i < st.n; i++) {
-        if (pd[i].factor_kind == NBP_F_MSGPRIOR) open.erase(pd[i].var_slot[1]);  // read: live
-        if (pd[i].meas_kde > 0) open.erase(pd[i].meas_kde - 1);
+        if (pd[i].factor_kind == NBP_F_MSGPRIOR) read_kde(pd[i].var_slot[1]);  // read: live
+        if (pd[i].meas_kde > 0) read_kde(pd[i].meas_kde - 1);
       }
       for (int i = 0; i < st.n; i++) {
         kill(pd[i].out_slot);  // overwritten
@@ -864,14 +895,20 @@ static nbp_liveness product_liveness(const nbp_program *p) {
       for (int i = 0; i < st.n; i++) { kill(cd[i].dst_slot); last_prop.erase(cd[i].dst_slot); }
     } else if (st.kind == NBP_STAGE_COPIES) {
       const nbp_copy_desc *cd = (const nbp_copy_desc *)d;
-      if (st.n == 0) open.clear();  // barrier: all live
-      for (int i = 0; i < st.n; i++) open.erase(cd[i].src_slot);
+      if (st.n == 0) {  // barrier: all live
+        open.clear();
+        for (auto &lp : last_prop) needed.push_back(lp.second);
+      }
+      for (int i = 0; i < st.n; i++) read_kde(cd[i].src_slot);
       for (int i = 0; i < st.n; i++) { kill(cd[i].dst_slot); last_prop.erase(cd[i].dst_slot); }
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *qd = (const nbp_product_desc *)d;
       L.dead_product[s].assign(st.n, 0);
       for (int i = 0; i < st.n; i++)
-        for (int j = 0; j < qd[i].nfactors; j++) open.erase(qd[i].in_slot[j]);   // input KDE: bandwidth read
+        for (int j = 0; j < qd[i].nfactors; j++) {  // input KDE: bandwidth read
+          if (qd[i].nfactors > 1) read_kde(qd[i].in_slot[j]);
+          else open.erase(qd[i].in_slot[j]);  // pass-through: the proposal's fit travels with the output (below)
+        }
       for (int i = 0; i < st.n; i++) {
         kill(qd[i].out_slot);
         if (qd[i].nfactors > 1) {
@@ -885,11 +922,13 @@ static nbp_liveness product_liveness(const nbp_program *p) {
       }
     }
   }
+  for (auto &nd : needed) L.dead_proposal[nd.first][nd.second] = 0;
   return L;  // whatever is still open is flushed at the end of the program: live
 }
 
 nbp_status nbp_program_finalize(nbp_program *p) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
+  PROG_ALIVE(p);
   if (p->finalized) return NBP_OK;
   HIPCHK(hipSetDevice(p->ctx->device));
   p->n_user_stages = (int)p->stages.size();
@@ -990,6 +1029,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
 
 nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
+  PROG_ALIVE(p);
   if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
   nbp_ctx *c = p->ctx;
   HIPCHK(hipSetDevice(c->device));
@@ -1026,6 +1066,7 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
 
 nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
   if (!p || !p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+  PROG_ALIVE(p);
   nbp_ctx *c = p->ctx;
   HIPCHK(hipSetDevice(c->device));
   (void)hipGetLastError();
@@ -1044,10 +1085,13 @@ nbp_status nbp_program_num_stages(nbp_program *p, int32_t *out) {
 
 nbp_status nbp_program_destroy(nbp_program *p) {
   if (!p) return NBP_OK;
-  if (p->dev) {
+  if (p->ctx) {  // (a program whose context is gone was detached by nbp_ctx_destroy: nothing left on the device)
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    hipFree(p->dev);
+    if (p->dev) hipFree(p->dev);
+    auto &v = p->ctx->programs;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i] == p) { v.erase(v.begin() + i); break; }
   }
   delete p;
   return NBP_OK;

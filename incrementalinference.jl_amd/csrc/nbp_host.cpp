@@ -44,6 +44,7 @@ inline uint64_t op_seed(uint64_t base, uint64_t a, uint64_t b, uint64_t c, uint6
   h = splitmix64(h ^ d);
   return h;
 }
+enum { NBP_DOWN_MCITERS = 3 };
 enum { PASS_INIT = 0, PASS_UP = 1, PASS_DOWN = 2, PASS_UNIT = 3, PRODUCT_ID = 0xFFFF };
 
 struct Clique {
@@ -425,7 +426,9 @@ void schedules(nbp_tree *t) {
       drop(directs);
     }
     c.dnsched = directs;
-    for (int k = 0; k < iters; k++) c.dnsched.insert(c.dnsched.end(), itf.begin(), itf.end());
+    // MCIters = 3 is solveCliqDownFrontalProducts!'s own keyword default (CliqStateMachineUtils.jl:485); its only
+    // caller (CliqueStateMachine.jl:838) does not pass gibbsIters
+    for (int k = 0; k < NBP_DOWN_MCITERS; k++) c.dnsched.insert(c.dnsched.end(), itf.begin(), itf.end());
     if (c.parent == 0) c.dnsched.clear();
   }
 }
@@ -816,7 +819,7 @@ nbp_status nbp_tree_build(const nbp_graph *g, const int32_t *order, int32_t n, n
       std::vector<int> &d = t->jdnsched[c.id - 1];
       for (int v : c.frontals)
         if (!itv.count(v) && !skip(v) && !joint_entries(c, v, true).empty()) d.push_back(v);
-      for (int k = 0; k < g->sp.gibbs_iters; k++)
+      for (int k = 0; k < NBP_DOWN_MCITERS; k++)
         for (int v : c.frontals)
           if (itv.count(v) && !skip(v)) d.push_back(v);
     }

@@ -167,6 +167,7 @@ class NativeGraph:
         _check(self.lib.nbp_graph_init_compile(self._g, backend._ctx, C.byref(p)))
         prog = HipProgram.__new__(HipProgram)
         prog.backend, prog._p, prog.n_stages = backend, p, self.lib.nbp_graph_init_num_stages(self._g)
+        backend._programs.add(prog)
         return prog
 
     def order_nested_dissection(self):
@@ -228,6 +229,7 @@ class NativeTree:
         _check(self.lib.nbp_tree_compile(self._t, backend._ctx, C.c_uint64(seed), C.byref(p)))
         prog = HipProgram.__new__(HipProgram)
         prog.backend, prog._p, prog.n_stages = backend, p, self.lib.nbp_tree_num_stages(self._t)
+        backend._programs.add(prog)
         return prog
 
     def schedule(self, seed):

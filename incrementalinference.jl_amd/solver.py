@@ -471,13 +471,17 @@ def initAll(fg, backend=None, seed=0):
         for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
-        prog = be.program(stages)
-        prog.run()
-        be.synchronize()
-        for sym, _, _ in plan:
-            pts, bw = be.slot_read(slot[sym], fg.getVariable(sym).varType.manifold)
-            setValKDE(fg, sym, pts, bw, True)
-        prog.close()
+        prog = None
+        try:
+            prog = be.program(stages)
+            prog.run()
+            be.synchronize()
+            for sym, _, _ in plan:
+                pts, bw = be.slot_read(slot[sym], fg.getVariable(sym).varType.manifold)
+                setValKDE(fg, sym, pts, bw, True)
+        finally:  # the program goes before its context, on the error path too
+            if prog is not None:
+                prog.close()
     finally:
         if own:
             be.close()
@@ -603,7 +607,7 @@ class TreeProgram:
         self.upsched[cid], self.upfacs[cid] = sched, upf
         if self.joint is None:
             dnf = {v: [("f", f) for f in fg.ls(v)] for v in cl.frontalIDs}
-            dsch = bayestree.downSchedule(fg, cl, sp.gibbsIters) if cl.parent >= 0 else []
+            dsch = bayestree.downSchedule(fg, cl) if cl.parent >= 0 else []  # MCIters = 3: its own default (:485), not gibbsIters
         else:
             # no addDownVariableFactors! (CliqueStateMachine.jl:823): the down solve works on the clique sub
             # graph as the up solve left it -- potentials + the children's differentials (:558 removes
@@ -614,7 +618,7 @@ class TreeProgram:
             itv = {v for f in kept if len([u for u in f.variables if u in frs]) > 1 for v in f.variables if v in frs}
             skip = {v for v in cl.frontalIDs if sp.limitfixeddown and fg.getVariable(v).ismargin}
             dsch = ([v for v in cl.frontalIDs if v not in itv and v not in skip and dnf[v]]
-                    + [v for v in cl.frontalIDs if v in itv and v not in skip] * sp.gibbsIters) if cl.parent >= 0 else []
+                    + [v for v in cl.frontalIDs if v in itv and v not in skip] * 3) if cl.parent >= 0 else []  # MCIters = 3
         self.dnfacs[cid] = dnf
         self.dnsched[cid] = dsch
 
@@ -977,17 +981,21 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
         for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
-        prog = tp.compile(be, seed) if use_native else be.program(tp.stages, lazy_bandwidth=True)
-        t3 = time.perf_counter()
-        prog.run()
-        be.synchronize()
-        t4 = time.perf_counter()
-        for v in fg.ls():
-            var = fg.getVariable(v)
-            pts, bw = be.slot_read(tp.main[v], var.varType.manifold)
-            setValKDE(fg, v, pts, bw, True)
-            var.solvedCount += 1
-        prog.close()
+        prog = None
+        try:
+            prog = tp.compile(be, seed) if use_native else be.program(tp.stages, lazy_bandwidth=True)
+            t3 = time.perf_counter()
+            prog.run()
+            be.synchronize()
+            t4 = time.perf_counter()
+            for v in fg.ls():
+                var = fg.getVariable(v)
+                pts, bw = be.slot_read(tp.main[v], var.varType.manifold)
+                setValKDE(fg, v, pts, bw, True)
+                var.solvedCount += 1
+        finally:  # the program goes before its context, on the error path too
+            if prog is not None:
+                prog.close()
     finally:
         if own:
             be.close()
