@@ -388,9 +388,10 @@ __device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&
   for (int i = DN; i >= 1; i--) nm_cswap<DN>(sx, f, i);
 }
 
-// nmobjective(y, m, n) = sqrt(var(y) * m / n) <= g_tol without the square root and the divisions:
-// sum((y - mean)^2) <= g_tol^2 * n, mean by the reciprocal (one FP64 divide or sqrt costs ~30 VALU
-// instructions, and this runs once per simplex iteration).  The oracle evaluates the same expression.
+// Optim's convergence test: nmobjective(f_simplex, n, m) = sqrt(var(y) * n / (n + 1)) <= g_tol, i.e. the population
+// standard deviation of the vertex values (oracle/nbp_oracle.c:nm_converged spells it the way Optim does).
+// Here the same predicate without the square root and the divisions: sum((y - mean)^2) <= g_tol^2 * (n + 1)
+// (one FP64 divide or sqrt costs ~30 VALU instructions, and this runs once per simplex iteration).
 template <int DN>
 __device__ __forceinline__ bool nm_converged(const double (&f)[DN + 1]) {
   constexpr double rm = 1.0 / (DN + 1);
@@ -401,7 +402,7 @@ __device__ __forceinline__ bool nm_converged(const double (&f)[DN + 1]) {
   double v = 0;
 #pragma unroll
   for (int i = 0; i <= DN; i++) v += (f[i] - a) * (f[i] - a);
-  return v <= 1e-16 * DN;
+  return v <= 1e-16 * (DN + 1);
 }
 
 template <class OBJ, int DN>

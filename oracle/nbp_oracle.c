@@ -298,7 +298,7 @@ static double objective(const objective_t *o, const double *x) {
 
 /* ------------------------------------------------------------------------------------------ */
 /* Optim.NelderMead restated: AdaptiveParameters (Gao & Han 2012), AffineSimplexer(a=0.025,     */
-/* b=0.5), g_tol = 1e-8 on sqrt(var(f_simplex)*(n+1)/n... ) [nmobjective], iterations = 1000.   */
+/* b=0.5), g_tol = 1e-8 on nmobjective (see nm_converged), iterations = 1000.                   */
 /* Call site: NumericalCalculations.jl:108,122-126.                                            */
 /* ------------------------------------------------------------------------------------------ */
 static void nm_sort(int m, const double *f, int *ord) {
@@ -309,17 +309,24 @@ static void nm_sort(int m, const double *f, int *ord) {
     ord[j + 1] = k;
   }
 }
-/* nmobjective(y, m, n) = sqrt(var(y) * m / n) <= g_tol, evaluated without the square root and with
-   multiplications by the (compile-time) reciprocals: sum((y - mean)^2) <= g_tol^2 * n.  Same predicate
-   up to rounding at the threshold; the HIP kernel evaluates exactly this expression. */
+/* Optim's convergence measure, written the way Optim writes it (multivariate/solvers/zeroth_order/nelder_mead.jl,
+   Optim 1.x):
+       nmobjective(y::Vector, m::Integer, n::Integer) = sqrt(var(y) * (m / n))
+   called as  nmobjective(f_simplex, n, m)  with n = length(x), m = n + 1 vertices -- i.e. the corrected sample
+   variance (Statistics.var divides by m - 1 = n) times n / (n + 1): the population standard deviation of the
+   vertex values, sqrt(sum((y - mean(y))^2) / (n + 1)), compared with g_tol = 1e-8 (Optim.Options default;
+   the reference passes no g_tol, NumericalCalculations.jl:122-126).
+   Plain divisions and the square root on purpose: this file follows the reference's arithmetic, not the kernels'
+   (the HIP kernel tests the same predicate as sum <= g_tol^2 * (n + 1); the two can only disagree when the sum is
+   within rounding of the threshold, which the parity tolerances absorb). */
 static int nm_converged(int m, int n, const double *f) {
-  const double rm = 1.0 / m;
   double a = 0;
   for (int i = 0; i < m; i++) a += f[i];
-  a *= rm;
+  a = a / m;
   double v = 0;
   for (int i = 0; i < m; i++) v += (f[i] - a) * (f[i] - a);
-  return v <= 1e-16 * n;
+  const double var = v / (m - 1);                    /* Statistics.var, corrected */
+  return sqrt(var * ((double)n / (double)m)) <= 1e-8; /* nmobjective(f_simplex, n, m) <= g_abstol */
 }
 
 int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: minimizer */, int *iters) {
@@ -342,7 +349,7 @@ int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: mi
     for (int d = 0; d < n; d++) {
       double s = 0;
       for (int i = 0; i < m; i++) if (i != ih) s += sx[i][d];
-      xc[d] = s * rn; /* centroid: times the reciprocal, like the kernel */
+      xc[d] = s * rn; /* Optim's centroid!: sum over the other vertices, then rmul!(c, T(1)/n) */
       xl[d] = sx[ord[0]][d];
     }
     double f_lowest = f[ord[0]], f_second = f[ord[n - 1]], f_highest = f[ih];
@@ -401,7 +408,7 @@ int orc_nelder_mead(const objective_t *o, int n, double *x /* in: start, out: mi
   for (int d = 0; d < n; d++) {
     double s = 0;
     for (int i = 0; i < m; i++) if (i != ih) s += sx[i][d];
-    xc[d] = s * rn; /* centroid: times the reciprocal, like the kernel */
+    xc[d] = s * rn; /* centroid!, as above */
   }
   double fcen = objective(o, xc);
   if (fcen < f[ord[0]])
