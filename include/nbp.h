@@ -22,7 +22,8 @@
  *    NBP_SE2         : P = 6, ArrayPartition(t[2], R[2x2] column-major) = x,y,R11,R21,R12,R22
  *                      (test/testSpecialEuclidean2Mani.jl:14)
  * Device layout ("slot"): tangent coordinates at the identity, SoA: coord d of particle n at
- *    slot_base + d*N + n, d < D (SE2 is stored as x,y,theta), then bw[3], see DESIGN.md.
+ *    slot_base + d*N + n, d < D (SE2 is stored as x,y,theta), then bw[3], infoPerCoord[3], see DESIGN.md:
+ *    a slot is the device form of a TreeBelief (val, bw, infoPerCoord; entities/BeliefTypes.jl:47-57).
  */
 #ifndef NBP_H
 #define NBP_H
@@ -176,6 +177,16 @@ nbp_status nbp_slot_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const do
                           const double *bw_D /* nullable */);
 nbp_status nbp_slot_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP,
                          double *bw_D /* nullable */);
+/* The full TreeBelief / VariableNodeData triple (val, bw, infoPerCoord; BeliefTypes.jl:47-57, FactorGraph.jl:250-263).
+ * infoPerCoord is produced on the device like the reference produces it: a proposal carries ones(D), zeroed outside
+ * the factor's `.partial` (EvalFactor.jl:383-391); a variable update carries the sum over its factors of ones(D)
+ * (proposalbeliefs!, ApproxConv.jl:277,298-303 -- the reference's `fct_ipc = ones(vardim)`, partial factors
+ * included); slot copies (tree messages) carry it along.  nbp_slot_write stores zeros (a fresh VariableNodeData).
+ * n_pts: particle count of the belief; this version requires n_pts == N of the context (read returns N). */
+nbp_status nbp_belief_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP, int32_t n_pts,
+                            const double *bw_D /* nullable */, const double *ipc_D /* nullable: zeros */);
+nbp_status nbp_belief_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP, int32_t *n_pts /* nullable */,
+                           double *bw_D /* nullable */, double *ipc_D /* nullable */);
 nbp_status nbp_side_write(nbp_ctx *ctx, int32_t offset, const int32_t *src, int32_t n);
 nbp_status nbp_side_read(nbp_ctx *ctx, int32_t offset, int32_t *dst, int32_t n);
 

@@ -127,6 +127,67 @@ typedef struct nbp_tree_stats {
 } nbp_tree_stats;
 nbp_status nbp_tree_get_stats(const nbp_tree *t, nbp_tree_stats *out);
 
+/* ---- the clique seam, one clique at a time -----------------------------------------------------------------
+ * For a host that keeps the tree and the CliqueStateMachine (the north star: scheduling stays in Julia): the two
+ * calls the CSM makes per clique,
+ *     upGibbsCliqueDensity(dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger) -> Dict{Symbol,TreeBelief}
+ *         src/services/SolveTree.jl:164-239, called (remotecall_fetch'ed) from approxCliqMarginalUp!,
+ *         src/CliqueStateMachine/services/CliqStateMachineUtils.jl:375-385
+ *     solveCliqDownFrontalProducts!(subfg, cliq, opts, logger)
+ *         src/CliqueStateMachine/services/CliqStateMachineUtils.jl:479-571, called at CliqueStateMachine.jl:838
+ * as one C call each: beliefs in, the whole Gibbs schedule on the device, beliefs (val, bw, infoPerCoord) out.
+ * The random streams are keyed by (seed, pass, clique_id, step, factor) exactly like nbp_tree_compile keys them,
+ * so a clique solved here and the same clique inside a whole-tree program give the same particles. */
+
+/* TreeBelief (entities/BeliefTypes.jl:47-57): val, bw, infoPerCoord; host buffers owned by the caller */
+typedef struct nbp_tree_belief {
+  double *pts;      /* n_pts x P doubles, packed AoS like nbp_slot_write                          */
+  double *bw;       /* D                                                                          */
+  double *ipc;      /* D: infoPerCoord (in: may be NULL = zeros; out: written when not NULL)      */
+  int32_t n_pts;    /* in: particles held (this version: == N); out: N                            */
+  int32_t reserved_;
+} nbp_tree_belief;
+
+/* CliqStatus (entities/BeliefTypes.jl:8), the status a LikelihoodMessage carries */
+enum nbp_cliq_status {
+  NBP_CLIQ_NULL = 0, NBP_CLIQ_NO_INIT = 1, NBP_CLIQ_INITIALIZED = 2, NBP_CLIQ_UPSOLVED = 3, NBP_CLIQ_MARGINALIZED = 4,
+  NBP_CLIQ_DOWNSOLVED = 5, NBP_CLIQ_UPRECYCLED = 6, NBP_CLIQ_ERROR_STATUS = 7
+};
+
+typedef struct nbp_clique_desc {
+  int32_t clique_id;           /* CliqueId.value: keys the random streams                                     */
+  int32_t nvars;               /* variables of the clique sub graph: the frontals first, then the separators,
+                                  then (down solve only) the other variables the factors of the frontals touch
+                                  (addDownVariableFactors!, CliqueStateMachine.jl:823-835)                      */
+  int32_t nfrontals, nseparators;
+  const int32_t *manifold;     /* [nvars] enum nbp_manifold                                                   */
+  const int32_t *ismargin;     /* [nvars] or NULL: marginalized variables are never updated (SolveTree.jl:61;
+                                  down solve: skipped when params.limitfixeddown)                              */
+  int32_t nfactors;            /* up solve: the clique's potentials; down solve: every factor of its frontals  */
+  const nbp_factor_spec *factors; /* vars[] index the variable list above                                      */
+  /* up solve: the Gibbs id lists of getCliqueData(cliq), as indices into the variable list
+   * (setCliqMCIDs!, JunctionTreeUtils.jl:1352-1523).  Ignored by the down solve. */
+  int32_t n_direct_frtl_msg, n_msgskip, n_itervar, n_direct_prior_msg;
+  const int32_t *direct_frtl_msg, *msgskip, *itervar, *direct_prior_msg;
+  /* up solve: the children's upward messages, one entry per (child, separator variable): a MsgPrior{MKD} on that
+   * variable (addMsgFactors!, TreeMessageUtils.jl:542-578, generateMsgPrior :86-89), in the order the caller lists
+   * them.  Ignored by the down solve, whose parent message is already IN the separator beliefs
+   * (updateSubFgFromDownMsgs!, TreeMessageUtils.jl:66-84). */
+  int32_t nmsgs;
+  const int32_t *msg_var;            /* [nmsgs] index into the variable list */
+  const nbp_tree_belief *msg_belief; /* [nmsgs] */
+} nbp_clique_desc;
+
+/* slots a context needs for this clique (nbp_ctx_create(..., n_slots >= this)) */
+int32_t nbp_clique_slots(const nbp_clique_desc *cliq);
+/* beliefs_inout[nvars]: in = the beliefs of the clique sub graph (the deep copy the CSM made); out = the belief of
+ * every variable the schedule updated (the others are left as they were).  status_out (nullable) = NBP_CLIQ_UPSOLVED /
+ * NBP_CLIQ_DOWNSOLVED.  Hard errors return < 0 (the shim raises, the CSM monitor propagates ERROR_STATUS). */
+nbp_status nbp_clique_upsolve(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,
+                              nbp_tree_belief *beliefs_inout, int32_t *status_out);
+nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,
+                                nbp_tree_belief *beliefs_inout, int32_t *status_out);
+
 /* test access: the descriptors of stage s of the last compile (kind = NBP_STAGE_*; bytes copied <= cap) */
 int32_t nbp_tree_num_stages(const nbp_tree *t);
 nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *descs_out, int64_t cap_bytes);

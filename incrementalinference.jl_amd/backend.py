@@ -73,6 +73,25 @@ class HipBackend:
                                            bw.ctypes.data_as(C.POINTER(C.c_double))))
         return pts, bw
 
+    def belief_write(self, slot, manifold, pts, bw=None, ipc=None):
+        """the full TreeBelief triple (val, bw, infoPerCoord)"""
+        dp = C.POINTER(C.c_double)
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, abi.MANIFOLD_P[manifold])
+        bw = None if bw is None else np.ascontiguousarray(bw, dtype=np.float64)
+        ipc = None if ipc is None else np.ascontiguousarray(ipc, dtype=np.float64)
+        self._check(self.lib.nbp_belief_write(self._ctx, slot, manifold, pts.ctypes.data_as(dp), pts.shape[0],
+                                              bw.ctypes.data_as(dp) if bw is not None else None,
+                                              ipc.ctypes.data_as(dp) if ipc is not None else None))
+
+    def belief_read(self, slot, manifold):
+        dp = C.POINTER(C.c_double)
+        pts = np.empty((self.N, abi.MANIFOLD_P[manifold]))
+        bw, ipc = np.empty(abi.MANIFOLD_DIM[manifold]), np.empty(abi.MANIFOLD_DIM[manifold])
+        n = C.c_int32(0)
+        self._check(self.lib.nbp_belief_read(self._ctx, slot, manifold, pts.ctypes.data_as(dp), C.byref(n),
+                                             bw.ctypes.data_as(dp), ipc.ctypes.data_as(dp)))
+        return pts[:n.value], bw, ipc
+
     def side_write(self, offset, ints):
         a = np.ascontiguousarray(ints, dtype=np.int32)
         self._check(self.lib.nbp_side_write(self._ctx, offset, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))

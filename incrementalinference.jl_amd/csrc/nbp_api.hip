@@ -223,7 +223,16 @@ void *nbp_stream_ptr(nbp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 // ---- belief I/O --------------------------------------------------------------------------------
 nbp_status nbp_slot_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, const double *bw) {
+  return nbp_belief_write(c, slot, manifold, pts, c ? c->N : 0, bw, nullptr);
+}
+nbp_status nbp_slot_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts, double *bw) {
+  return nbp_belief_read(c, slot, manifold, pts, nullptr, bw, nullptr);
+}
+
+nbp_status nbp_belief_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, int32_t n_pts, const double *bw,
+                            const double *ipc) {
   if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
+  if (n_pts != c->N) return fail(NBP_ERR_RANGE, "belief: n_pts must equal the context's N");
   if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
   if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
   const int N = c->N, D = manifold_dim_h(manifold), P = manifold_P_h(manifold);
@@ -241,12 +250,13 @@ nbp_status nbp_slot_write(nbp_ctx *c, int32_t slot, int32_t manifold, const doub
     }
   }
   for (int d = 0; d < D; d++) s[3 * N + d] = bw ? bw[d] : 0.0;
+  for (int d = 0; d < D; d++) s[3 * N + 3 + d] = ipc ? ipc[d] : 0.0;  // a fresh VariableNodeData carries infoPerCoord = 0
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(c->arena + c->S * slot, s.data(), c->S * 8, hipMemcpyHostToDevice));
   return NBP_OK;
 }
 
-nbp_status nbp_slot_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts, double *bw) {
+nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts, int32_t *n_pts, double *bw, double *ipc) {
   if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
   if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
   if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
@@ -266,6 +276,9 @@ nbp_status nbp_slot_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts
   }
   if (bw)
     for (int d = 0; d < D; d++) bw[d] = s[3 * N + d];
+  if (ipc)
+    for (int d = 0; d < D; d++) ipc[d] = s[3 * N + 3 + d];
+  if (n_pts) *n_pts = N;
   return NBP_OK;
 }
 

@@ -1283,6 +1283,214 @@ nbp_status nbp_graph_init_compile(nbp_graph *g, nbp_ctx *ctx, nbp_program **out)
   return NBP_OK;
 }
 
+// ---- the clique seam, one clique at a time (upGibbsCliqueDensity / solveCliqDownFrontalProducts!) ---------
+static nbp_status clique_check(const nbp_solver_params *sp, const nbp_clique_desc *q) {
+  if (!sp || !q) return hfail(NBP_ERR_ARG, "null argument");
+  if (sp->flags & NBP_SOLVER_MSG_LIKELIHOODS) return hfail(NBP_ERR_ARG, "clique entry: useMsgLikelihoods needs the whole-tree compile");
+  if (q->nvars < 1 || q->nfrontals < 1 || q->nseparators < 0 || q->nfrontals + q->nseparators > q->nvars)
+    return hfail(NBP_ERR_RANGE, "clique: variable counts");
+  if (!q->manifold || (q->nfactors > 0 && !q->factors) || (q->nmsgs > 0 && (!q->msg_var || !q->msg_belief)))
+    return hfail(NBP_ERR_ARG, "clique: null array");
+  for (int v = 0; v < q->nvars; v++)
+    if (q->manifold[v] < NBP_EUCLID1 || q->manifold[v] > NBP_SE2) return hfail(NBP_ERR_ARG, "clique: unknown manifold");
+  for (int f = 0; f < q->nfactors; f++) {
+    const nbp_factor_spec &s = q->factors[f];
+    if (s.factor_kind < NBP_F_PRIOR || s.factor_kind > NBP_F_EUCLIDDIST || s.factor_kind == NBP_F_MSGPRIOR) return hfail(NBP_ERR_ARG, "clique: factor kind");
+    if (s.nvars < 1 || s.nvars > NBP_MAXV || s.ncomp < 1 || s.ncomp > NBP_MAXC) return hfail(NBP_ERR_RANGE, "clique: factor shape");
+    for (int i = 0; i < s.nvars; i++)
+      if (s.vars[i] < 0 || s.vars[i] >= q->nvars) return hfail(NBP_ERR_RANGE, "clique: factor variable index");
+  }
+  for (int i = 0; i < q->nmsgs; i++)
+    if (q->msg_var[i] < 0 || q->msg_var[i] >= q->nvars) return hfail(NBP_ERR_RANGE, "clique: message variable index");
+  auto chk = [&](const int32_t *l, int n) {
+    if (n < 0 || (n > 0 && !l)) return false;
+    for (int i = 0; i < n; i++)
+      if (l[i] < 0 || l[i] >= q->nvars) return false;
+    return true;
+  };
+  if (!chk(q->direct_frtl_msg, q->n_direct_frtl_msg) || !chk(q->msgskip, q->n_msgskip) || !chk(q->itervar, q->n_itervar) ||
+      !chk(q->direct_prior_msg, q->n_direct_prior_msg))
+    return hfail(NBP_ERR_RANGE, "clique: Gibbs id list");
+  return NBP_OK;
+}
+
+// the densities of variable v: the factors that touch it (in the caller's order), then the messages on it
+static void clique_entries(const nbp_clique_desc *q, int v, bool with_msgs, std::vector<int> &facs, std::vector<int> &msgs) {
+  facs.clear();
+  msgs.clear();
+  for (int f = 0; f < q->nfactors; f++)
+    for (int i = 0; i < q->factors[f].nvars; i++)
+      if (q->factors[f].vars[i] == v) { facs.push_back(f); break; }
+  if (with_msgs)
+    for (int i = 0; i < q->nmsgs; i++)
+      if (q->msg_var[i] == v) msgs.push_back(i);
+}
+
+int32_t nbp_clique_slots(const nbp_clique_desc *q) {
+  if (!q) return hfail(NBP_ERR_ARG, "null argument");
+  size_t maxf = 1;
+  std::vector<int> fa, ms;
+  for (int v = 0; v < q->nvars; v++) {
+    clique_entries(q, v, true, fa, ms);
+    maxf = std::max(maxf, fa.size() + ms.size());
+  }
+  return q->nvars + q->nmsgs + (int32_t)maxf;
+}
+
+static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
+                               nbp_tree_belief *bel, int32_t *status_out, bool down) {
+  nbp_status rc = clique_check(sp, q);
+  if (rc) return rc;
+  if (!ctx || !bel) return hfail(NBP_ERR_ARG, "null argument");
+  // a throw-away graph object carries the solver parameters and the variables for fill_proposal
+  nbp_graph g;
+  g.sp = *sp;
+  for (int v = 0; v < q->nvars; v++) g.vars.push_back({q->manifold[v], true, q->ismargin ? q->ismargin[v] != 0 : false});
+  std::vector<HFac> facs(q->nfactors);
+  for (int f = 0; f < q->nfactors; f++) { facs[f].s = q->factors[f]; facs[f].is_prior = q->factors[f].factor_kind == NBP_F_PRIOR; }
+  // slot plan: the clique's variables | the message beliefs | proposal scratch
+  const int msg0 = q->nvars, base = q->nvars + q->nmsgs;
+  // ---- schedule ------------------------------------------------------------------------------------------
+  std::vector<int> sched, iter;
+  std::vector<int> fa, ms;
+  if (!down) {  // upGibbsCliqueDensity: four fmcmc! passes (SolveTree.jl:193-235); one label -> one iteration (:106-108)
+    auto fmcmc = [&](const std::vector<int> &l, int it) {
+      if (l.size() == 1) it = 1;
+      for (int k = 0; k < it; k++)
+        for (int v : l) { sched.push_back(v); iter.push_back(k + 1); }
+    };
+    auto vec = [](const int32_t *l, int n) { return std::vector<int>(l, l + n); };
+    const std::vector<int> skip = vec(q->msgskip, q->n_msgskip);
+    fmcmc(vec(q->direct_frtl_msg, q->n_direct_frtl_msg), 1);
+    if (!skip.empty()) fmcmc(skip, 1);
+    if (q->n_itervar > 0) fmcmc(vec(q->itervar, q->n_itervar), sp->gibbs_iters);
+    if (q->n_direct_prior_msg > 0) {
+      std::vector<int> l;
+      for (int i = 0; i < q->n_direct_prior_msg; i++)
+        if (!contains(skip, (int)q->direct_prior_msg[i])) l.push_back(q->direct_prior_msg[i]);
+      fmcmc(l, 1);
+    }
+    // doFMCIteration: marginalized variables and variables without any density are passed over (:61)
+    std::vector<int> s2, i2;
+    for (size_t k = 0; k < sched.size(); k++) {
+      clique_entries(q, sched[k], true, fa, ms);
+      if ((fa.empty() && ms.empty()) || g.vars[sched[k]].ismargin) continue;
+      s2.push_back(sched[k]);
+      i2.push_back(iter[k]);
+    }
+    sched.swap(s2);
+    iter.swap(i2);
+  } else {  // determineCliqVariableDownSequence + solveCliqDownFrontalProducts! (CliqStateMachineUtils.jl:424-571)
+    std::vector<int> iterv;
+    for (int f = 0; f < q->nfactors; f++) {
+      std::vector<int> hit;
+      for (int i = 0; i < q->factors[f].nvars; i++)
+        if (q->factors[f].vars[i] < q->nfrontals) hit.push_back(q->factors[f].vars[i]);
+      if (hit.size() > 1)
+        for (int v : hit)
+          if (!contains(iterv, v)) iterv.push_back(v);
+    }
+    std::vector<int> itf, directs;
+    for (int v = 0; v < q->nfrontals; v++) {
+      if (sp->limitfixeddown && g.vars[v].ismargin) continue;
+      (contains(iterv, v) ? itf : directs).push_back(v);
+    }
+    for (int v : directs) { sched.push_back(v); iter.push_back(1); }
+    for (int k = 0; k < NBP_DOWN_MCITERS; k++)
+      for (int v : itf) { sched.push_back(v); iter.push_back(k + 1); }
+  }
+  // ---- beliefs in ----------------------------------------------------------------------------------------
+  for (int v = 0; v < q->nvars; v++) {
+    if (!bel[v].pts) return hfail(NBP_ERR_ARG, "clique: null belief");
+    rc = nbp_belief_write(ctx, v, q->manifold[v], bel[v].pts, bel[v].n_pts, bel[v].bw, bel[v].ipc);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < (down ? 0 : q->nmsgs); i++) {
+    const nbp_tree_belief &m = q->msg_belief[i];
+    if (!m.pts || !m.bw) return hfail(NBP_ERR_ARG, "clique: a message needs points and bandwidth");
+    rc = nbp_belief_write(ctx, msg0 + i, q->manifold[q->msg_var[i]], m.pts, m.n_pts, m.bw, m.ipc);
+    if (rc) return rc;
+  }
+  // ---- the schedule as a resident program ------------------------------------------------------------------
+  nbp_program *p = nullptr;
+  rc = nbp_program_create(ctx, &p);
+  if (rc) return rc;
+  struct prog_guard { nbp_program *p; ~prog_guard() { nbp_program_destroy(p); } } guard{p};
+  rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
+  if (rc) return rc;
+  const bool stored = (sp->flags & NBP_SOLVER_STORED_MEASUREMENTS) != 0;
+  std::map<std::pair<int, int>, uint64_t> meas_seed;  // (0 = factor | 1 = message, index) -> seed of its last fresh draw
+  const int passid = down ? PASS_DOWN : PASS_UP;
+  std::vector<char> updated(q->nvars, 0);
+  for (size_t k = 0; k < sched.size(); k++) {
+    const int v = sched[k];
+    clique_entries(q, v, !down, fa, ms);
+    const int F = (int)(fa.size() + ms.size());
+    if (F == 0) continue;
+    if (F > NBP_MAXF) return hfail(NBP_ERR_RANGE, "a product exceeds NBP_MAXF densities");
+    bool anymh = false;
+    for (int f : fa) anymh |= facs[f].s.has_multihypo != 0;
+    std::vector<nbp_proposal_desc> props;
+    nbp_product_desc pq;
+    memset(&pq, 0, sizeof(pq));
+    bool anypartial = false;
+    const bool fresh = iter[k] == 1 || !stored || down;
+    for (int i = 0; i < F; i++) {
+      const bool ismsg = i >= (int)fa.size();
+      const HFac *fac = ismsg ? nullptr : &facs[fa[i]];
+      const int mi = ismsg ? ms[i - fa.size()] : -1;
+      double ns = 0.0;  // proposalbeliefs!: relative non-multihypo siblings of a multihypo factor (ApproxConv.jl:255-265)
+      if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = sp->null_surplus_add;
+      nbp_proposal_desc d;
+      const uint64_t sd = op_seed(seed, passid, q->clique_id, (uint64_t)k, (uint64_t)(i + 1));
+      fill_proposal(&g, d, fac, ismsg ? msg0 + mi : -1, v, nullptr, nullptr, nullptr, base + i, sd, ns);
+      const std::pair<int, int> key{ismsg ? 1 : 0, ismsg ? mi : fa[i]};
+      if (fresh) meas_seed[key] = sd;
+      else {
+        auto it = meas_seed.find(key);
+        d.meas_seed = it == meas_seed.end() ? 0 : it->second;
+      }
+      props.push_back(d);
+      pq.in_slot[i] = base + i;
+      pq.in_partial[i] = (uint8_t)(fac ? fac->s.partial_mask : 0);
+      anypartial |= pq.in_partial[i] != 0;
+    }
+    pq.manifold = q->manifold[v];
+    pq.nfactors = F;
+    pq.niter = sp->product_niter;
+    pq.out_slot = v;
+    pq.labels_out = -1;
+    pq.old_slot = anypartial ? v : -1;
+    if (!anypartial) memset(pq.in_partial, 0, sizeof(pq.in_partial));
+    pq.seed = op_seed(seed, passid, q->clique_id, (uint64_t)k, PRODUCT_ID);
+    rc = nbp_program_add_stage(p, NBP_STAGE_PROPOSALS, props.data(), (int)props.size());
+    if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, &pq, 1);
+    if (rc) return rc;
+    updated[v] = 1;
+  }
+  rc = nbp_program_finalize(p);
+  if (!rc) rc = nbp_program_run(p, 0, -1);
+  if (!rc) rc = nbp_synchronize(ctx);
+  if (rc) return rc;
+  // ---- beliefs out: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the schedule touched
+  for (int v = 0; v < q->nvars; v++) {
+    if (!updated[v]) continue;
+    rc = nbp_belief_read(ctx, v, q->manifold[v], bel[v].pts, &bel[v].n_pts, bel[v].bw, bel[v].ipc);
+    if (rc) return rc;
+  }
+  if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
+  return NBP_OK;
+}
+
+nbp_status nbp_clique_upsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
+                              nbp_tree_belief *bel, int32_t *status_out) {
+  return clique_solve(ctx, sp, q, seed, bel, status_out, false);
+}
+nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
+                                nbp_tree_belief *bel, int32_t *status_out) {
+  return clique_solve(ctx, sp, q, seed, bel, status_out, true);
+}
+
 int32_t nbp_tree_num_stages(const nbp_tree *t) { return t ? (int32_t)t->stages.size() : 0; }
 nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *out, int64_t cap) {
   if (!t || s < 0 || s >= (int)t->stages.size()) return hfail(NBP_ERR_RANGE, "stage index");

@@ -246,6 +246,8 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
   // this kernel keeps one lane per particle so that the Nelder-Mead simplex stays in registers.
   if (live)
     for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
+  // infoPerCoord of the proposal: ones(D), zeroed outside the factor's `.partial` (EvalFactor.jl:383-391, :534-540)
+  if (n < 3) out[3 * N + 3 + n] = (n < D && (!d->partial_mask || ((d->partial_mask >> n) & 1))) ? 1.0 : 0.0;
   // diagnostics: one atomic per wave
   {
     unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
@@ -869,10 +871,14 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
     const double *src = arena + S * d->in_slot[0];
     double *out = arena + S * d->out_slot;
     for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
+    // infoPerCoord of the update: the sum over its factors of ones(D) (proposalbeliefs!, ApproxConv.jl:277,298-303)
+    if (threadIdx.x < 3) out[3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? 1.0 : 0.0;
     if (d->labels_out >= 0)
       for (int i = threadIdx.x; i < N; i += blockDim.x) side[d->labels_out + i] = i;
     return;
   }
+  if (blockIdx.y == 0 && threadIdx.x < 3)
+    arena[S * d->out_slot + 3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? (double)d->nfactors : 0.0;
   bool partial = false;
   for (int j = 0; j < d->nfactors; j++) partial |= (d->in_partial[j] != 0);
   if (partial) {  // validated on the host: D >= 2

@@ -34,12 +34,28 @@ class TreeStats(C.Structure):
                                    "alg_bytes", "alg_bytes_proposal", "alg_bytes_prep", "alg_bytes_product")]
 
 
+class TreeBeliefC(C.Structure):
+    """nbp_tree_belief: TreeBelief (val, bw, infoPerCoord) in host buffers"""
+    _fields_ = [("pts", C.POINTER(f64)), ("bw", C.POINTER(f64)), ("ipc", C.POINTER(f64)), ("n_pts", i32), ("reserved_", i32)]
+
+
+class CliqueDescC(C.Structure):
+    _fields_ = [("clique_id", i32), ("nvars", i32), ("nfrontals", i32), ("nseparators", i32),
+                ("manifold", C.POINTER(i32)), ("ismargin", C.POINTER(i32)), ("nfactors", i32), ("factors", C.POINTER(FactorSpec)),
+                ("n_direct_frtl_msg", i32), ("n_msgskip", i32), ("n_itervar", i32), ("n_direct_prior_msg", i32),
+                ("direct_frtl_msg", C.POINTER(i32)), ("msgskip", C.POINTER(i32)), ("itervar", C.POINTER(i32)),
+                ("direct_prior_msg", C.POINTER(i32)), ("nmsgs", i32), ("msg_var", C.POINTER(i32)),
+                ("msg_belief", C.POINTER(TreeBeliefC))]
+
+
+CLIQ_UPSOLVED, CLIQ_DOWNSOLVED = 3, 5  # enum nbp_cliq_status
+
 HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable", "nbp_graph_add_factor",
                 "nbp_graph_set_variable_flags", "nbp_graph_num_variables", "nbp_graph_num_factors",
                 "nbp_graph_order_nested_dissection", "nbp_graph_init_plan", "nbp_graph_init_num_variables", "nbp_graph_init_variables",
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
-                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage"]
+                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve"]
 
 _declared = False
 
@@ -75,6 +91,9 @@ def _lib():
         lib.nbp_tree_get_stats.argtypes = [vp, C.POINTER(TreeStats)]
         lib.nbp_tree_num_stages.argtypes = [vp]
         lib.nbp_tree_stage.argtypes = [vp, i32, ip, ip, vp, i64]
+        lib.nbp_clique_slots.argtypes = [C.POINTER(CliqueDescC)]
+        for fn in (lib.nbp_clique_upsolve, lib.nbp_clique_downsolve):
+            fn.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC), ip]
         for n in HOST_EXPORTS:
             getattr(lib, n).restype = i32
         _declared = True
@@ -103,13 +122,98 @@ def _stages_of(getter, count):
     return out
 
 
+def solver_params_c(sp):
+    flags = (0 if sp.alwaysFreshMeasurements else SOLVER_STORED_MEASUREMENTS) | \
+            (SOLVER_MSG_LIKELIHOODS if getattr(sp, "useMsgLikelihoods", False) else 0)
+    return SolverParamsC(sp.N, sp.gibbsIters, sp.inflateCycles, sp.productNiter, int(sp.upsolve), int(sp.downsolve),
+                         int(getattr(sp, "limitfixeddown", False)), flags, sp.spreadNH, sp.inflation, sp.nullSurplusAdd)
+
+
+def factor_spec(f, index):
+    """DFGFactor -> nbp_factor_spec; `index`: label -> variable id"""
+    s = FactorSpec()
+    s.factor_kind, s.nvars = f.fnc.kind, len(f.variables)
+    for i, v in enumerate(f.variables):
+        s.vars[i] = index[v]
+    comps = f.fnc.components()
+    s.ncomp = len(comps)
+    for c, (w, mu, L) in enumerate(comps):
+        s.comp[c][0] = w
+        for i in range(min(3, len(mu))):
+            s.comp[c][1 + i] = float(mu[i])
+        for i in range(min(3, L.shape[0])):
+            for j in range(i + 1):
+                s.comp[c][4 + 3 * i + j] = float(L[i, j])
+    if f.multihypo is not None:
+        s.has_multihypo = 1
+        for i, p in enumerate(f.multihypo):
+            s.multihypo[i] = p
+    s.nullhypo, s.inflation = f.nullhypo, f.inflation
+    s.partial_mask = getattr(f.fnc, "partial_mask", 0)
+    return s
+
+
+class Belief:
+    """host-side TreeBelief: pts (N x P), bw (D), ipc (D)"""
+
+    def __init__(self, manifold, pts, bw=None, ipc=None):
+        D = abi.MANIFOLD_DIM[manifold]
+        self.manifold = manifold
+        self.pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, abi.MANIFOLD_P[manifold]).copy()
+        self.bw = np.zeros(D) if bw is None else np.ascontiguousarray(bw, dtype=np.float64).copy()
+        self.ipc = np.zeros(D) if ipc is None else np.ascontiguousarray(ipc, dtype=np.float64).copy()
+
+    def copy(self):
+        return Belief(self.manifold, self.pts, self.bw, self.ipc)
+
+    def c(self):
+        dp = C.POINTER(f64)
+        return TreeBeliefC(self.pts.ctypes.data_as(dp), self.bw.ctypes.data_as(dp), self.ipc.ctypes.data_as(dp), self.pts.shape[0], 0)
+
+
+def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, manifolds, factors, beliefs, seed, down=False,
+                 ismargin=None, lists=None, msgs=()):
+    """nbp_clique_upsolve / nbp_clique_downsolve (include/nbp_host.h) -- the per-clique seam of the CliqueStateMachine:
+    upGibbsCliqueDensity (SolveTree.jl:164-239) / solveCliqDownFrontalProducts! (CliqStateMachineUtils.jl:479-571).
+
+    variables: labels, frontals first, then separators, then (down) the others; factors: DFGFactor list; beliefs:
+    {label: Belief} (updated in place); lists: {"directFrtlMsg", "msgskip", "itervar", "directPriorMsg"} of labels;
+    msgs: [(label, Belief)] the children's up messages.  Returns the CliqStatus code."""
+    lib = _lib()
+    idx = {v: i for i, v in enumerate(variables)}
+    q = CliqueDescC()
+    q.clique_id, q.nvars, q.nfrontals, q.nseparators = clique_id, len(variables), nfrontals, nseparators
+    man = (i32 * len(variables))(*manifolds)
+    q.manifold = man
+    mg = (i32 * len(variables))(*[int(bool(m)) for m in (ismargin or [0] * len(variables))])
+    q.ismargin = mg
+    specs = (FactorSpec * max(1, len(factors)))(*[factor_spec(f, idx) for f in factors])
+    q.nfactors, q.factors = len(factors), specs
+    keep = [man, mg, specs]
+    for name, field in (("directFrtlMsg", "direct_frtl_msg"), ("msgskip", "msgskip"), ("itervar", "itervar"), ("directPriorMsg", "direct_prior_msg")):
+        l = [idx[v] for v in (lists or {}).get(name, [])]
+        arr = (i32 * max(1, len(l)))(*l)
+        keep.append(arr)
+        setattr(q, "n_" + field, len(l))
+        setattr(q, field, arr)
+    mv = (i32 * max(1, len(msgs)))(*[idx[v] for v, _ in msgs])
+    mb = (TreeBeliefC * max(1, len(msgs)))(*[b.c() for _, b in msgs])
+    q.nmsgs, q.msg_var, q.msg_belief = len(msgs), mv, mb
+    need = _check(lib.nbp_clique_slots(C.byref(q)))
+    if need > backend.n_slots:
+        raise ValueError(f"the context has {backend.n_slots} slots, this clique needs {need}")
+    bel = (TreeBeliefC * len(variables))(*[beliefs[v].c() for v in variables])
+    status = i32(0)
+    p = solver_params_c(sp)
+    fn = lib.nbp_clique_downsolve if down else lib.nbp_clique_upsolve
+    _check(fn(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, C.byref(status)))
+    return status.value
+
+
 class NativeGraph:
     def __init__(self, sp):
         self.lib = _lib()
-        flags = (0 if sp.alwaysFreshMeasurements else SOLVER_STORED_MEASUREMENTS) | \
-                (SOLVER_MSG_LIKELIHOODS if getattr(sp, "useMsgLikelihoods", False) else 0)
-        p = SolverParamsC(sp.N, sp.gibbsIters, sp.inflateCycles, sp.productNiter, int(sp.upsolve), int(sp.downsolve),
-                          int(getattr(sp, "limitfixeddown", False)), flags, sp.spreadNH, sp.inflation, sp.nullSurplusAdd)
+        p = solver_params_c(sp)
         self._g = C.c_void_p()
         _check(self.lib.nbp_graph_create(C.byref(p), C.byref(self._g)))
         self.labels, self.flabels = [], []
@@ -124,26 +228,7 @@ class NativeGraph:
             g.lib.nbp_graph_set_variable_flags(g._g, idx[v], int(var.initialized), int(var.ismargin))
             g.labels.append(v)
         for fl in fg.lsf():
-            f = fg.getFactor(fl)
-            s = FactorSpec()
-            s.factor_kind, s.nvars = f.fnc.kind, len(f.variables)
-            for i, v in enumerate(f.variables):
-                s.vars[i] = idx[v]
-            comps = f.fnc.components()
-            s.ncomp = len(comps)
-            for c, (w, mu, L) in enumerate(comps):
-                s.comp[c][0] = w
-                for i in range(min(3, len(mu))):
-                    s.comp[c][1 + i] = float(mu[i])
-                for i in range(min(3, L.shape[0])):
-                    for j in range(i + 1):
-                        s.comp[c][4 + 3 * i + j] = float(L[i, j])
-            if f.multihypo is not None:
-                s.has_multihypo = 1
-                for i, p in enumerate(f.multihypo):
-                    s.multihypo[i] = p
-            s.nullhypo, s.inflation = f.nullhypo, f.inflation
-            s.partial_mask = getattr(f.fnc, "partial_mask", 0)
+            s = factor_spec(fg.getFactor(fl), idx)
             _check(g.lib.nbp_graph_add_factor(g._g, C.byref(s)))
             g.flabels.append(fl)
         g.index = idx

@@ -164,6 +164,16 @@ void orc_slot_write(double *arena, int32_t N, int32_t slot, int32_t manifold, co
     }
   }
   for (int d = 0; d < 3; d++) s[3 * N + d] = (bw && d < D) ? bw[d] : 0.0;
+  for (int d = 0; d < 3; d++) s[3 * N + 3 + d] = 0.0; /* infoPerCoord of a fresh VariableNodeData */
+}
+/* infoPerCoord of a slot (TreeBelief.infoPerCoord, BeliefTypes.jl:47-57) */
+void orc_slot_ipc_write(double *arena, int32_t N, int32_t slot, int32_t manifold, const double *ipc) {
+  double *s = arena + orc_slot_stride(N) * slot;
+  for (int d = 0; d < 3; d++) s[3 * N + 3 + d] = d < mani_dim(manifold) ? ipc[d] : 0.0;
+}
+void orc_slot_ipc_read(const double *arena, int32_t N, int32_t slot, int32_t manifold, double *ipc) {
+  const double *s = arena + orc_slot_stride(N) * slot;
+  for (int d = 0; d < mani_dim(manifold); d++) ipc[d] = s[3 * N + 3 + d];
 }
 
 void orc_slot_read(const double *arena, int32_t N, int32_t slot, int32_t manifold, double *pts, double *bw) {
@@ -877,6 +887,9 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     free(Z);
   }
   free(mhidx);
+  /* ipc = ones(D), zeroed outside `.partial` (EvalFactor.jl:383-391 relative, :534-540 prior) */
+  for (int k = 0; k < 3; k++)
+    out[3 * N + 3 + k] = (k < mani_dim(d->manifold) && (!d->partial_mask || ((d->partial_mask >> k) & 1))) ? 1.0 : 0.0;
   if (!d->skip_bandwidth) fit_bandwidth(out, N, d->manifold); /* manikde!, ApproxConv.jl:36-42 */
   return NBP_OK;
 }
@@ -957,6 +970,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   double *out = arena + S * d->out_slot;
   if (F == 1) { /* single density: AMP returns it as is */
     memmove(out, arena + S * d->in_slot[0], sizeof(double) * (3 * N + 3));
+    for (int k = 0; k < 3; k++) out[3 * N + 3 + k] = k < D ? 1.0 : 0.0; /* proposalbeliefs!: ipc = sum of ones(D) */
     if (d->labels_out >= 0) for (int n = 0; n < N; n++) side[d->labels_out + n] = n;
     return NBP_OK;
   }
@@ -1094,6 +1108,8 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     for (int l = 0; l <= T.L; l++) { free(nmean[j][l]); free(nvar[j][l]); free(nprec[j][l]); }
   }
   levels_free(&T);
+  /* proposalbeliefs! (ApproxConv.jl:277,298-303): fct_ipc = ones(vardim) for every factor, summed */
+  for (int k = 0; k < 3; k++) out[3 * N + 3 + k] = k < D ? (double)F : 0.0;
   fit_bandwidth(out, N, M); /* rebandwidth of the product */
   return NBP_OK;
 }

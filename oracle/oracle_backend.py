@@ -32,6 +32,10 @@ def lib():
         L.orc_slot_write.restype = None
         L.orc_slot_read.argtypes = [dp, i32, i32, i32, dp, dp]
         L.orc_slot_read.restype = None
+        L.orc_slot_ipc_write.argtypes = [dp, i32, i32, i32, dp]
+        L.orc_slot_ipc_write.restype = None
+        L.orc_slot_ipc_read.argtypes = [dp, i32, i32, i32, dp]
+        L.orc_slot_ipc_read.restype = None
         L.orc_run_proposals.argtypes = [dp, i32, ip, C.POINTER(abi.ProposalDesc), i32]
         L.orc_run_products.argtypes = [dp, i32, ip, C.POINTER(abi.ProductDesc), i32]
         L.orc_run_deconvs.argtypes = [dp, i32, C.POINTER(abi.ProposalDesc), ip, i32]
@@ -96,6 +100,17 @@ class OracleBackend:
         bw = np.empty(abi.MANIFOLD_DIM[manifold])
         self.lib.orc_slot_read(_dp(self.arena), self.N, slot, manifold, _dp(pts), _dp(bw))
         return pts, bw
+
+    def belief_write(self, slot, manifold, pts, bw=None, ipc=None):
+        self.slot_write(slot, manifold, pts, bw)
+        if ipc is not None:
+            self.lib.orc_slot_ipc_write(_dp(self.arena), self.N, slot, manifold, _dp(np.ascontiguousarray(ipc, dtype=np.float64)))
+
+    def belief_read(self, slot, manifold):
+        pts, bw = self.slot_read(slot, manifold)
+        ipc = np.zeros(abi.MANIFOLD_DIM[manifold])
+        self.lib.orc_slot_ipc_read(_dp(self.arena), self.N, slot, manifold, _dp(ipc))
+        return pts, bw, ipc
 
     def side_write(self, offset, ints):
         a = np.asarray(ints, dtype=np.int32)

@@ -1,0 +1,64 @@
+"""A minimal stand-in for the reference's CliqueStateMachine in the tests: it walks the Bayes tree on the host and
+makes, per clique, exactly the two calls the CSM makes -- upGibbsCliqueDensity (SolveTree.jl:164-239, called at
+CliqStateMachineUtils.jl:375-385) and solveCliqDownFrontalProducts! (CliqStateMachineUtils.jl:479-571) -- through the
+per-clique C entry points nbp_clique_upsolve / nbp_clique_downsolve.  Message assembly (separator beliefs up, parent
+values down, frontals back to the graph) is done here in numpy, as the Julia CSM does it in Julia."""
+from parity_utils import iif
+
+from iif_amd.native_host import Belief, clique_solve
+
+
+def solve_tree_by_clique_calls(fg, tree, backend, seed):
+    """-> {label: Belief} posteriors after one up + one down pass; `fg` must be initialised; `backend`: a HipBackend"""
+    sp = fg.solverParams
+    man = {v: fg.getVariable(v).varType.manifold for v in fg.ls()}
+    marg = {v: fg.getVariable(v).ismargin for v in fg.ls()}
+    main = {v: Belief(man[v], fg.getVariable(v).val, fg.getVariable(v).bw) for v in fg.ls()}
+    sub = {}      # clique -> {label: Belief}: the clique sub graph (deep copy, SubGraphFunctions.jl:48)
+    status = {}
+    # ---- up pass: children before parents ---------------------------------------------------------------------
+    for cid in tree.postorder():
+        cl = tree.cliques[cid]
+        labels = list(cl.frontalIDs) + list(cl.separatorIDs)
+        bel = {v: main[v].copy() for v in labels}
+        msgs = [(v, sub[ch][v]) for ch in cl.children for v in tree.cliques[ch].separatorIDs]  # prepCliqueMsgUp of the children
+        lists = {"directFrtlMsg": cl.directFrtlMsgIDs, "msgskip": cl.msgskipIDs, "itervar": cl.itervarIDs,
+                 "directPriorMsg": cl.directPriorMsgIDs}
+        status[cid] = clique_solve(backend, sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels],
+                                   [fg.getFactor(f) for f in cl.potentials], bel, seed, down=False,
+                                   ismargin=[marg[v] for v in labels], lists=lists, msgs=msgs)
+        sub[cid] = bel
+    # ---- roots: the up-solved frontals are the posterior (CliqueStateMachine.jl, preDownSolve root branch) ----------
+    post = {}
+    for r in tree.roots:
+        for v in tree.cliques[r].frontalIDs:
+            main[v] = sub[r][v].copy()
+            post[v] = main[v]
+    # ---- down pass: parents before children ---------------------------------------------------------------------
+    depths = tree.depths()
+    for cid in sorted(tree.cliques, key=lambda c: (depths[c], c)):
+        cl = tree.cliques[cid]
+        if cl.parent < 0:
+            continue
+        for s in cl.separatorIDs:  # updateSubFgFromDownMsgs! (TreeMessageUtils.jl:66-84): the parent's values
+            sub[cid][s].pts[:] = sub[cl.parent][s].pts
+        factors = []
+        for v in cl.frontalIDs:  # every factor of the frontals (addDownVariableFactors!, CliqueStateMachine.jl:823-835)
+            for f in fg.ls(v):
+                if f not in factors:
+                    factors.append(f)
+        inclq = list(cl.frontalIDs) + list(cl.separatorIDs)
+        others = []
+        for f in factors:
+            for u in fg.getFactor(f).variables:
+                if u not in inclq and u not in others:
+                    others.append(u)
+        labels = inclq + others
+        bel = {v: (sub[cid][v] if v in sub[cid] else main[v].copy()) for v in labels}
+        # the factor order of a variable's product is the graph's (fg.ls(v)), as in the whole-tree compile
+        order = [f for f in fg.lsf() if f in factors]
+        status[cid] = clique_solve(backend, sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels],
+                                   [fg.getFactor(f) for f in order], bel, seed, down=True, ismargin=[marg[v] for v in labels])
+        for v in cl.frontalIDs:
+            post[v] = bel[v]
+    return post, status

@@ -79,6 +79,7 @@ def both(oracle_factory, hip_factory, N, n_slots, side_ints, setup, run, read):
     out = []
     for fac in (oracle_factory, hip_factory):
         be = fac(N, n_slots, side_ints)
+        be.diag(reset=True)  # the oracle's counters are process-wide: start every comparison from zero
         setup(be)
         run(be)
         out.append(read(be))

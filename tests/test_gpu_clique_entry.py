@@ -1,0 +1,70 @@
+"""-m gpu: the per-clique C entry points (nbp_clique_upsolve / nbp_clique_downsolve, include/nbp_host.h): a host-side
+stand-in for the CliqueStateMachine drives the tree one clique call at a time (tests/clique_csm.py) and must arrive at
+the particles the whole-tree resident program (nbp_tree_compile) produces for the same seed -- bit for bit where the
+launch geometries coincide (trees with fewer than 16 concurrent updates), to rounding otherwise."""
+import numpy as np
+import pytest
+
+from clique_csm import solve_tree_by_clique_calls
+from parity_utils import abi, assert_points_close, iif
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs():
+    def kaess():
+        return iif.generateGraph_Kaess(iif.SolverParams(N=100))
+
+    def chain():
+        return iif.generateChainEuclid(12, vardims=2, priorEvery=5, N=200)
+
+    def doors():
+        return iif.generateCircularDoors(nposes=8, N=128, sightEvery=4)
+
+    def lattice():
+        return iif.generateSE2Lattice(rows=2, cols=4, N=128, closeEvery=2)
+
+    return {"kaess": kaess, "euclid2_chain": chain, "circular_doors_multihypo": doors, "se2_lattice": lattice}
+
+
+@pytest.mark.parametrize("name", list(_graphs()))
+def test_clique_calls_equal_whole_tree_program(hip_backend, name):
+    build = _graphs()[name]
+    fa, fb = build(), build()
+    iif.initAll(fa, backend=hip_backend, seed=0)
+    iif.initAll(fb, backend=hip_backend, seed=0)
+    order = iif.nestedDissectionOrder(fa)
+    tree = iif.buildTreeReset(fa, order)
+    fa.solverParams.graphinit = fb.solverParams.graphinit = False
+    iif.solveTree(fa, tree=iif.buildTreeReset(fa, order), backend=hip_backend, seed=77)
+    be = hip_backend(fb.solverParams.N, 64)
+    try:
+        post, status = solve_tree_by_clique_calls(fb, tree, be, 77)
+    finally:
+        be.close()
+    assert set(post) == set(fb.ls())
+    roots = set(tree.roots)
+    assert all(s == (3 if c in roots else 5) for c, s in status.items())  # UPSOLVED at the roots, DOWNSOLVED elsewhere
+    nbit = 0
+    for v in fa.ls():
+        man = fa.getVariable(v).varType.manifold
+        assert_points_close(man, fa.getVal(v), post[v].pts, rtol=1e-9, what=f"{name}:{v}")
+        np.testing.assert_allclose(post[v].bw, fa.getVariable(v).bw, rtol=1e-9)
+        nbit += int(np.array_equal(fa.getVal(v), post[v].pts))
+        # infoPerCoord: the number of densities of the variable's last update, on every coordinate (ApproxConv.jl:277,298-303)
+        D = abi.MANIFOLD_DIM[man]
+        assert post[v].ipc.shape == (D,) and np.all(post[v].ipc >= 1.0) and np.all(post[v].ipc == post[v].ipc[0])
+    assert nbit == len(fa.ls()), f"{nbit} of {len(fa.ls())} variables bit-identical"
+
+
+def test_clique_entry_rejects_bad_input(hip_backend):
+    from iif_amd.native_host import Belief, clique_solve
+    fg = iif.generateChainEuclid(4, vardims=2, priorEvery=2, N=64)
+    be = hip_backend(64, 8)
+    try:
+        bel = {v: Belief(abi.EUCLID2, np.zeros((64, 2)), np.ones(2)) for v in ("x0", "x1")}
+        with pytest.raises(ValueError):  # a Gibbs id list naming a variable outside the clique
+            clique_solve(be, fg.solverParams, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [fg.getFactor(fg.ls("x0")[0])], bel, 1,
+                         lists={"itervar": ["x0", "x1", "x1"], "directFrtlMsg": []}, msgs=[("x1", Belief(abi.EUCLID2, np.zeros((32, 2)), np.ones(2)))])
+    finally:
+        be.close()
