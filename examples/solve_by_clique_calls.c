@@ -1,0 +1,184 @@
+/*
+ * solve_by_clique_calls.c -- the clique seam from plain C: a host that keeps the tree and the per-clique control
+ * flow (what IncrementalInference.jl's CliqueStateMachine does in Julia) and calls libnbp once per clique,
+ *     nbp_clique_upsolve    = upGibbsCliqueDensity            (SolveTree.jl:164-239)
+ *     nbp_clique_downsolve  = solveCliqDownFrontalProducts!   (CliqStateMachineUtils.jl:479-571)
+ * with message assembly (separator beliefs up, parent values down) done on the host.  The result is compared, byte
+ * for byte, with the whole-tree resident program (nbp_tree_compile) run from the same initial beliefs and seed.
+ *
+ *   gcc -O2 -Iinclude examples/solve_by_clique_calls.c -o /tmp/clique_calls \
+ *       -Lincrementalinference.jl_amd/csrc -lnbp -Wl,-rpath,$PWD/incrementalinference.jl_amd/csrc -lm
+ *   /tmp/clique_calls [nvars=12] [N=128]
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "nbp_host.h"
+
+#define CHK(call)                                                                  \
+  do {                                                                             \
+    int rc_ = (call);                                                              \
+    if (rc_ < 0) {                                                                 \
+      fprintf(stderr, "%s -> %d: %s\n", #call, rc_, nbp_last_error());             \
+      return 1;                                                                    \
+    }                                                                              \
+  } while (0)
+
+enum { D = 2, MAXCL = 64 };
+typedef struct { double *pts, bw[D], ipc[D]; } belief; /* one TreeBelief on the host */
+
+static int N;
+static belief belief_new(void) { belief b; memset(&b, 0, sizeof(b)); b.pts = calloc((size_t)N * D, sizeof(double)); return b; }
+static void belief_copy(belief *dst, const belief *src) {
+  memcpy(dst->pts, src->pts, sizeof(double) * N * D);
+  memcpy(dst->bw, src->bw, sizeof(dst->bw));
+  memcpy(dst->ipc, src->ipc, sizeof(dst->ipc));
+}
+static nbp_tree_belief view(belief *b) { nbp_tree_belief v = {b->pts, b->bw, b->ipc, N, 0}; return v; }
+
+static void gaussian_factor(nbp_factor_spec *f, int kind, int nvars, int a, int b, double mx, double my, double sigma) {
+  memset(f, 0, sizeof(*f));
+  f->factor_kind = kind; f->nvars = nvars; f->vars[0] = a; f->vars[1] = b; f->ncomp = 1;
+  f->comp[0][0] = 1.0; f->comp[0][1] = mx; f->comp[0][2] = my; f->comp[0][4] = sigma; f->comp[0][8] = sigma;
+}
+static int find(const int32_t *l, int n, int v) { for (int i = 0; i < n; i++) if (l[i] == v) return i; return -1; }
+
+int main(int argc, char **argv) {
+  const int nvars = argc > 1 ? atoi(argv[1]) : 12;
+  N = argc > 2 ? atoi(argv[2]) : 128;
+  const uint64_t seed = 2024;
+  nbp_solver_params sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.N = N; sp.gibbs_iters = 3; sp.inflate_cycles = 3; sp.product_niter = 1; sp.upsolve = sp.downsolve = 1;
+  sp.spread_nh = 3.0; sp.inflation = 5.0; sp.null_surplus_add = 0.3;
+  /* ---- the graph: Euclid(2) odometry chain, a prior every 5th pose --------------------------------------- */
+  nbp_graph *g = NULL;
+  CHK(nbp_graph_create(&sp, &g));
+  for (int i = 0; i < nvars; i++) CHK(nbp_graph_add_variable(g, NBP_EUCLID2));
+  nbp_factor_spec *fac = calloc(2 * (size_t)nvars, sizeof(*fac));
+  int nfac = 0;
+  for (int i = 0; i < nvars; i++) {
+    if (i % 5 == 0) { gaussian_factor(&fac[nfac], NBP_F_PRIOR, 1, i, 0, i, i, 0.1); CHK(nbp_graph_add_factor(g, &fac[nfac++])); }
+    if (i + 1 < nvars) { gaussian_factor(&fac[nfac], NBP_F_LINREL, 2, i, i + 1, 1.0, 1.0, 0.1); CHK(nbp_graph_add_factor(g, &fac[nfac++])); }
+  }
+  int32_t *order = malloc(sizeof(int32_t) * nvars), *mainslot = malloc(sizeof(int32_t) * nvars);
+  CHK(nbp_graph_order_nested_dissection(g, order));
+  nbp_tree *tree = NULL;
+  CHK(nbp_tree_build(g, order, nvars, &tree));
+  const int ncl = nbp_tree_num_cliques(tree);
+  if (ncl > MAXCL) { fprintf(stderr, "too many cliques for this example\n"); return 1; }
+  const int n_slots = nbp_tree_plan_slots(tree, 0), init_slots = nbp_graph_init_plan(g, 7);
+  CHK(n_slots); CHK(init_slots);
+  CHK(nbp_tree_main_slots(tree, mainslot, NULL));
+  nbp_ctx *ctx = NULL;
+  CHK(nbp_ctx_create(0, N, (n_slots > init_slots ? n_slots : init_slots) + 64, NULL, 0, 0, &ctx));
+  /* ---- initAll!, then keep the initial beliefs on the host: the "graph" both solves start from ------------ */
+  belief *graph = malloc(sizeof(belief) * nvars), *post = malloc(sizeof(belief) * nvars), *whole = malloc(sizeof(belief) * nvars);
+  double one[D] = {1.0, 1.0};
+  for (int v = 0; v < nvars; v++) { graph[v] = belief_new(); post[v] = belief_new(); whole[v] = belief_new(); CHK(nbp_slot_write(ctx, v, NBP_EUCLID2, graph[v].pts, one)); }
+  nbp_program *prog = NULL;
+  CHK(nbp_graph_init_compile(g, ctx, &prog));
+  CHK(nbp_program_run(prog, 0, -1));
+  CHK(nbp_program_destroy(prog));
+  for (int v = 0; v < nvars; v++) CHK(nbp_belief_read(ctx, v, NBP_EUCLID2, graph[v].pts, NULL, graph[v].bw, graph[v].ipc));
+  /* ---- (A) the whole tree as one resident program --------------------------------------------------------- */
+  for (int v = 0; v < nvars; v++) CHK(nbp_belief_write(ctx, mainslot[v], NBP_EUCLID2, graph[v].pts, N, graph[v].bw, graph[v].ipc));
+  CHK(nbp_tree_compile(tree, ctx, seed, &prog));
+  CHK(nbp_program_run(prog, 0, -1));
+  CHK(nbp_synchronize(ctx));
+  for (int v = 0; v < nvars; v++) CHK(nbp_belief_read(ctx, mainslot[v], NBP_EUCLID2, whole[v].pts, NULL, whole[v].bw, whole[v].ipc));
+  CHK(nbp_program_destroy(prog));
+  /* ---- (B) one C call per clique ----------------------------------------------------------------------------- */
+  nbp_clique_info info[MAXCL + 1];
+  int32_t *fr[MAXCL + 1], *se[MAXCL + 1], *ch[MAXCL + 1], *po[MAXCL + 1], depth[MAXCL + 1];
+  belief *sub[MAXCL + 1]; /* sub[c][i]: belief of the i-th variable (frontals, then separators) of clique c's sub graph */
+  int maxdepth = 0;
+  for (int c = 1; c <= ncl; c++) {
+    fr[c] = malloc(sizeof(int32_t) * nvars); se[c] = malloc(sizeof(int32_t) * nvars);
+    ch[c] = malloc(sizeof(int32_t) * ncl); po[c] = malloc(sizeof(int32_t) * (nfac + 1));
+    CHK(nbp_tree_clique(tree, c, &info[c], fr[c], se[c], ch[c], po[c], NULL, NULL));
+  }
+  for (int c = 1; c <= ncl; c++) { int d = 0; for (int p = info[c].parent; p; p = info[p].parent) d++; depth[c] = d; if (d > maxdepth) maxdepth = d; }
+  int32_t *vars = malloc(sizeof(int32_t) * nvars), *mani = malloc(sizeof(int32_t) * nvars), *lists[4], counts[4];
+  for (int k = 0; k < 4; k++) lists[k] = malloc(sizeof(int32_t) * nvars);
+  nbp_factor_spec *cf = calloc((size_t)nfac + 1, sizeof(*cf));
+  nbp_tree_belief *bel = malloc(sizeof(nbp_tree_belief) * nvars), *msgb = malloc(sizeof(nbp_tree_belief) * nvars);
+  int32_t *msgv = malloc(sizeof(int32_t) * nvars);
+  for (int v = 0; v < nvars; v++) mani[v] = NBP_EUCLID2;
+  int32_t status = 0;
+  for (int d = maxdepth; d >= 0; d--)  /* up pass: children before parents */
+    for (int c = 1; c <= ncl; c++) {
+      if (depth[c] != d) continue;
+      const int nf = info[c].nfrontals, ns = info[c].nseparators, nv = nf + ns;
+      memcpy(vars, fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, se[c], sizeof(int32_t) * ns);
+      sub[c] = malloc(sizeof(belief) * nv);
+      for (int i = 0; i < nv; i++) { sub[c][i] = belief_new(); belief_copy(&sub[c][i], &graph[vars[i]]); bel[i] = view(&sub[c][i]); } /* deep copy */
+      nbp_clique_desc q;
+      memset(&q, 0, sizeof(q));
+      q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = mani;
+      for (int i = 0; i < info[c].npotentials; i++) { /* the clique's potentials, variable ids -> positions in `vars` */
+        cf[i] = fac[po[c][i]];
+        for (int k = 0; k < cf[i].nvars; k++) cf[i].vars[k] = find(vars, nv, cf[i].vars[k]);
+      }
+      q.nfactors = info[c].npotentials; q.factors = cf;
+      CHK(nbp_tree_clique_idlists(tree, c, counts, lists[0], lists[1], lists[2], lists[3]));
+      for (int k = 0; k < 4; k++) for (int i = 0; i < counts[k]; i++) lists[k][i] = find(vars, nv, lists[k][i]);
+      q.n_direct_frtl_msg = counts[0]; q.n_msgskip = counts[1]; q.n_itervar = counts[2]; q.n_direct_prior_msg = counts[3];
+      q.direct_frtl_msg = lists[0]; q.msgskip = lists[1]; q.itervar = lists[2]; q.direct_prior_msg = lists[3];
+      int nm = 0; /* the children's upward messages: their separator beliefs */
+      for (int j = 0; j < info[c].nchildren; j++) {
+        const int cc = ch[c][j];
+        for (int i = 0; i < info[cc].nseparators; i++) { msgv[nm] = find(vars, nv, se[cc][i]); msgb[nm++] = view(&sub[cc][info[cc].nfrontals + i]); }
+      }
+      q.nmsgs = nm; q.msg_var = msgv; q.msg_belief = msgb;
+      CHK(nbp_clique_upsolve(ctx, &sp, &q, seed, bel, &status));
+      if (status != NBP_CLIQ_UPSOLVED) return 4;
+      if (info[c].parent == 0) for (int i = 0; i < nf; i++) { belief_copy(&post[vars[i]], &sub[c][i]); belief_copy(&graph[vars[i]], &sub[c][i]); } /* root */
+    }
+  for (int d = 1; d <= maxdepth; d++)  /* down pass: parents before children */
+    for (int c = 1; c <= ncl; c++) {
+      if (depth[c] != d) continue;
+      const int p = info[c].parent, nf = info[c].nfrontals, ns = info[c].nseparators;
+      int nv = nf + ns;
+      memcpy(vars, fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, se[c], sizeof(int32_t) * ns);
+      for (int i = 0; i < ns; i++) { /* the down message: the parent's values of the separators */
+        int pi = find(fr[p], info[p].nfrontals, se[c][i]);
+        pi = pi >= 0 ? pi : info[p].nfrontals + find(se[p], info[p].nseparators, se[c][i]);
+        memcpy(sub[c][nf + i].pts, sub[p][pi].pts, sizeof(double) * N * D);
+      }
+      int ncf = 0; /* every factor of the frontals, in graph order; their other variables come from the graph */
+      for (int f = 0; f < nfac; f++) {
+        int hit = 0;
+        for (int k = 0; k < fac[f].nvars; k++) hit |= find(fr[c], nf, fac[f].vars[k]) >= 0;
+        if (!hit) continue;
+        cf[ncf] = fac[f];
+        for (int k = 0; k < fac[f].nvars; k++) if (find(vars, nv, fac[f].vars[k]) < 0) vars[nv++] = fac[f].vars[k];
+        ncf++;
+      }
+      for (int i = 0; i < ncf; i++) for (int k = 0; k < cf[i].nvars; k++) cf[i].vars[k] = find(vars, nv, cf[i].vars[k]);
+      for (int i = 0; i < nv; i++) bel[i] = i < nf + ns ? view(&sub[c][i]) : view(&graph[vars[i]]);
+      nbp_clique_desc q;
+      memset(&q, 0, sizeof(q));
+      q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = mani; q.nfactors = ncf; q.factors = cf;
+      CHK(nbp_clique_downsolve(ctx, &sp, &q, seed, bel, &status));
+      if (status != NBP_CLIQ_DOWNSOLVED) return 4;
+      for (int i = 0; i < nf; i++) belief_copy(&post[vars[i]], &sub[c][i]);
+    }
+  /* ---- compare -------------------------------------------------------------------------------------------------- */
+  int same = 0;
+  double worst = 0;
+  for (int v = 0; v < nvars; v++) {
+    same += memcmp(post[v].pts, whole[v].pts, sizeof(double) * N * D) == 0 && memcmp(post[v].bw, whole[v].bw, sizeof(post[v].bw)) == 0;
+    double mx = 0;
+    for (int n = 0; n < N; n++) mx += post[v].pts[2 * n];
+    if (fabs(mx / N - v) > worst) worst = fabs(mx / N - v);
+  }
+  printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program; "
+         "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f\n", nvars, ncl, same, nvars, post[0].ipc[0], post[0].ipc[1], worst);
+  nbp_ctx_destroy(ctx);
+  nbp_tree_destroy(tree);
+  nbp_graph_destroy(g);
+  return same == nvars && worst < 1.5 ? 0 : 3;
+}

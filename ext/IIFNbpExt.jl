@@ -1,0 +1,550 @@
+# IIFNbpExt.jl -- the Julia side of the libnbp boundary (include/nbp.h, include/nbp_host.h).
+#
+# A package extension a maintainer of IncrementalInference.jl adds (Project.toml: [extensions] IIFNbpExt = "..."):
+# methods that are MORE SPECIFIC than the generic ones for the factor types libnbp implements, forwarding to
+# `libnbp.so` with `ccall`.  The CliqueStateMachine, the Bayes tree, DistributedFactorGraphs and message passing stay
+# in Julia; per clique the CSM makes the two calls it makes today,
+#     upGibbsCliqueDensity(dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)   src/services/SolveTree.jl:164-239
+#     solveCliqDownFrontalProducts!(subfg, cliq, opts, logger)                    CliqStateMachineUtils.jl:479-571
+# and each becomes ONE ccall (nbp_clique_upsolve / nbp_clique_downsolve).
+#
+# Julia is not part of the build image of libnbp, so this file has not been executed there.  What IS machine-checked
+# is the part that silently corrupts memory when it drifts: every `struct` below is parsed by
+# tests/test_julia_shim_layout.py and compared, field by field (name, offset, size), with what gcc computes from the C
+# headers.  Keep one field per `name::Type` and C field names.
+module IIFNbpExt
+
+using IncrementalInference
+using DistributedFactorGraphs
+using ApproxManifoldProducts
+using Manifolds
+using StaticArrays
+using RecursiveArrayTools: ArrayPartition
+using Distributions
+using LinearAlgebra
+
+import IncrementalInference: upGibbsCliqueDensity, solveCliqDownFrontalProducts!, approxConvBelief,
+                             getSolverParams, getVariableType, getFactorType, getCliqueData, _getCCW,
+                             TreeBelief, TreeClique, MsgPrior, setValKDE!
+
+const libnbp = get(ENV, "LIBNBP", "libnbp.so")
+
+# ---- constants and enums of include/nbp.h -------------------------------------------------------------------
+const NBP_MAXV = 6
+const NBP_MAXF = 128
+const NBP_MAXC = 4
+const NBP_COMP_STRIDE = 13
+
+const NBP_EUCLID1, NBP_EUCLID2, NBP_EUCLID3, NBP_CIRCULAR, NBP_SE2 = Int32(1), Int32(2), Int32(3), Int32(4), Int32(5)
+const NBP_F_PRIOR, NBP_F_MSGPRIOR, NBP_F_LINREL, NBP_F_CIRCULAR, NBP_F_SE2, NBP_F_EUCLIDDIST =
+  Int32(1), Int32(2), Int32(3), Int32(4), Int32(5), Int32(6)
+const NBP_SOLVER_STORED_MEASUREMENTS, NBP_SOLVER_MSG_LIKELIHOODS = Int32(1), Int32(2)
+
+# ---- structs: byte-for-byte mirrors (checked by tests/test_julia_shim_layout.py) ----------------------------------
+# nbp_proposal_desc (include/nbp.h): one approxConvBelief
+struct NbpProposalDesc
+  factor_kind::Int32
+  manifold::Int32
+  nvars::Int32
+  sfidx::Int32
+  var_slot::NTuple{NBP_MAXV, Int32}
+  out_slot::Int32
+  ncomp::Int32
+  has_multihypo::Int32
+  inflate_cycles::Int32
+  mhidx_in::Int32
+  mhidx_out::Int32
+  skip_bandwidth::Int32
+  partial_mask::Int32
+  meas_kde::Int32
+  reserved_::Int32
+  multihypo::NTuple{NBP_MAXV, Float64}
+  nullhypo::Float64
+  inflation::Float64
+  spread_nh::Float64
+  comp::NTuple{NBP_MAXC * NBP_COMP_STRIDE, Float64}
+  seed::UInt64
+  meas_seed::UInt64
+end
+
+# nbp_product_desc (include/nbp.h): one AMP.manifoldProduct + rebandwidth
+struct NbpProductDesc
+  manifold::Int32
+  nfactors::Int32
+  niter::Int32
+  out_slot::Int32
+  in_slot::NTuple{NBP_MAXF, Int32}
+  labels_out::Int32
+  old_slot::Int32
+  in_partial::NTuple{NBP_MAXF, UInt8}
+  seed::UInt64
+end
+
+# nbp_copy_desc
+struct NbpCopyDesc
+  src_slot::Int32
+  dst_slot::Int32
+end
+
+# nbp_diag
+struct NbpDiag
+  solves::Int64
+  nonconverged::Int64
+  nan_results::Int64
+  residual_evals::Int64
+  lcv_evals::Int64
+end
+
+# nbp_solver_params (include/nbp_host.h): the SolverParams fields the path reads (entities/SolverParams.jl:12-75)
+struct NbpSolverParams
+  N::Int32
+  gibbs_iters::Int32
+  inflate_cycles::Int32
+  product_niter::Int32
+  upsolve::Int32
+  downsolve::Int32
+  limitfixeddown::Int32
+  flags::Int32
+  spread_nh::Float64
+  inflation::Float64
+  null_surplus_add::Float64
+end
+
+# nbp_factor_spec (include/nbp_host.h): addFactor!(dfg, Xi, usrfnc; multihypo, nullhypo, inflation)
+struct NbpFactorSpec
+  factor_kind::Int32
+  nvars::Int32
+  vars::NTuple{NBP_MAXV, Int32}
+  ncomp::Int32
+  has_multihypo::Int32
+  partial_mask::Int32
+  multihypo::NTuple{NBP_MAXV, Float64}
+  nullhypo::Float64
+  inflation::Float64
+  comp::NTuple{NBP_MAXC * NBP_COMP_STRIDE, Float64}
+end
+
+# nbp_tree_belief (include/nbp_host.h): TreeBelief (val, bw, infoPerCoord) in caller-owned buffers
+struct NbpTreeBelief
+  pts::Ptr{Float64}
+  bw::Ptr{Float64}
+  ipc::Ptr{Float64}
+  n_pts::Int32
+  reserved_::Int32
+end
+
+# nbp_clique_desc (include/nbp_host.h)
+struct NbpCliqueDesc
+  clique_id::Int32
+  nvars::Int32
+  nfrontals::Int32
+  nseparators::Int32
+  manifold::Ptr{Int32}
+  ismargin::Ptr{Int32}
+  nfactors::Int32
+  factors::Ptr{NbpFactorSpec}
+  n_direct_frtl_msg::Int32
+  n_msgskip::Int32
+  n_itervar::Int32
+  n_direct_prior_msg::Int32
+  direct_frtl_msg::Ptr{Int32}
+  msgskip::Ptr{Int32}
+  itervar::Ptr{Int32}
+  direct_prior_msg::Ptr{Int32}
+  nmsgs::Int32
+  msg_var::Ptr{Int32}
+  msg_belief::Ptr{NbpTreeBelief}
+end
+
+# ---- error mapping: status < 0 -> error() -> the clique Task fails -> monitorCSMs puts ERROR_STATUS on every
+#      channel -> solveTree! throws CompositeException (CliqStateMachineUtils.jl:184-246, test/testCSMMonitor.jl:51)
+function chk(rc::Integer)
+  rc >= 0 && return Int(rc)
+  return error("libnbp status $rc: " * unsafe_string(ccall((:nbp_last_error, libnbp), Cstring, ())))
+end
+
+# ---- contexts: pooled, one per concurrently running clique Task --------------------------------------------------
+# A context owns its HIP stream and arena; creating one costs a few hipMallocs, so they are kept and reused.
+mutable struct NbpCtx
+  ptr::Ptr{Cvoid}
+  N::Int
+  nslots::Int
+end
+
+function NbpCtx(N::Int, nslots::Int; device::Int = 0, side::Int = 0)
+  r = Ref{Ptr{Cvoid}}(C_NULL)
+  chk(ccall((:nbp_ctx_create, libnbp), Int32,
+            (Int32, Int32, Int32, Ptr{Cvoid}, Int64, Int32, Ref{Ptr{Cvoid}}),
+            device, N, nslots, C_NULL, 0, side, r))
+  c = NbpCtx(r[], N, nslots)
+  finalizer(x -> ccall((:nbp_ctx_destroy, libnbp), Int32, (Ptr{Cvoid},), x.ptr), c)
+  return c
+end
+
+const _POOL = Dict{Int, Vector{NbpCtx}}()      # N => idle contexts
+const _POOL_LOCK = ReentrantLock()
+const _POOL_SLOTS = 512                         # slots per pooled context (a clique needs nvars + nmsgs + maxF)
+
+"borrow a context for N particles and at least `nslots` slots; give it back with `release!`"
+function acquire(N::Int, nslots::Int)
+  lock(_POOL_LOCK) do
+    idle = get!(_POOL, N, NbpCtx[])
+    i = findfirst(c -> c.nslots >= nslots, idle)
+    i === nothing || return splice!(idle, i)
+    return NbpCtx(N, max(nslots, _POOL_SLOTS); side = 2N)
+  end
+end
+release!(c::NbpCtx) = lock(() -> push!(get!(_POOL, c.N, NbpCtx[]), c), _POOL_LOCK)
+
+function withctx(f, N::Int, nslots::Int)
+  c = acquire(N, nslots)
+  try
+    return f(c)
+  finally
+    release!(c)
+  end
+end
+
+# ---- manifolds and point layouts (include/nbp.h, "Host point layout") -------------------------------------------
+manifoldcode(::Position{1}) = NBP_EUCLID1          # ContinuousScalar = Position{1}
+manifoldcode(::Position{2}) = NBP_EUCLID2
+manifoldcode(::Position{3}) = NBP_EUCLID3
+manifoldcode(::Circular) = NBP_CIRCULAR
+manifoldcode(vt::InferenceVariable) =
+  getManifold(vt) isa typeof(SpecialEuclidean(2; vectors = HybridTangentRepresentation())) ? NBP_SE2 :
+  error("libnbp: unsupported variable type $(typeof(vt))")
+
+pointdoubles(code::Int32) = code == NBP_SE2 ? 6 : (code == NBP_CIRCULAR ? 1 : Int(code))
+tangentdim(code::Int32) = code == NBP_SE2 ? 3 : (code == NBP_CIRCULAR ? 1 : Int(code))
+
+"points of a belief -> packed AoS Float64 (N x P)"
+function packpoints(code::Int32, pts::AbstractVector)::Vector{Float64}
+  P = pointdoubles(code)
+  buf = Vector{Float64}(undef, P * length(pts))
+  for (n, p) in enumerate(pts)
+    o = (n - 1) * P
+    if code == NBP_SE2                       # ArrayPartition(t::SVector{2}, R::SMatrix{2,2}): x, y, R11, R21, R12, R22
+      t, R = p.x[1], p.x[2]
+      buf[o + 1] = t[1]; buf[o + 2] = t[2]
+      buf[o + 3] = R[1, 1]; buf[o + 4] = R[2, 1]; buf[o + 5] = R[1, 2]; buf[o + 6] = R[2, 2]
+    else
+      for d in 1:P
+        buf[o + d] = p[d]
+      end
+    end
+  end
+  return buf
+end
+
+"packed AoS Float64 -> the point type the variable stores"
+function wrappoints(vt::InferenceVariable, code::Int32, buf::Vector{Float64}, N::Int)
+  P = pointdoubles(code)
+  if code == NBP_SE2
+    return [ArrayPartition(SVector{2, Float64}(buf[o + 1], buf[o + 2]),
+                           SMatrix{2, 2, Float64}(buf[o + 3], buf[o + 4], buf[o + 5], buf[o + 6])) for o in 0:P:(P * (N - 1))]
+  elseif code == NBP_CIRCULAR
+    return [Float64[buf[n]] for n in 1:N]                       # Circular stores Vector{Vector{Float64}}
+  else
+    return [SVector{P, Float64}(ntuple(d -> buf[(n - 1) * P + d], P)) for n in 1:N]
+  end
+end
+
+# ---- factors: the closed set libnbp implements (SURVEY a10) ---------------------------------------------------------
+const NbpRelative = Union{LinearRelative, CircularCircular, EuclidDistance, ManifoldFactor}
+const NbpPrior = Union{Prior, PriorCircular, ManifoldPrior}
+const NbpUser = Union{NbpRelative, NbpPrior, Mixture}
+
+factorkind(::Union{Prior, PriorCircular, ManifoldPrior}) = NBP_F_PRIOR
+factorkind(::LinearRelative) = NBP_F_LINREL
+factorkind(::CircularCircular) = NBP_F_CIRCULAR
+factorkind(::ManifoldFactor) = NBP_F_SE2
+factorkind(::EuclidDistance) = NBP_F_EUCLIDDIST
+factorkind(m::Mixture) = factorkind(m.mechanics)
+
+"one measurement-model component: weight, mean[3], lower Cholesky factor L[3][3] row-major (NBP_COMP_STRIDE doubles)"
+function component(w::Real, Z)::Vector{Float64}
+  row = zeros(Float64, NBP_COMP_STRIDE)
+  row[1] = w
+  mu = Z isa Normal ? [mean(Z)] : collect(mean(Z))
+  L = Z isa Normal ? fill(std(Z), 1, 1) : Matrix(cholesky(Symmetric(Matrix(cov(Z)))).L)
+  for i in 1:min(3, length(mu))
+    row[1 + i] = mu[i]
+  end
+  for i in 1:min(3, size(L, 1)), j in 1:i
+    row[4 + 3 * (i - 1) + j] = L[i, j]
+  end
+  return row
+end
+
+function components(fnc)::Vector{Float64}
+  if fnc isa Mixture                                   # Factors/Mixture.jl: components + diversity (Categorical)
+    zs = collect(values(fnc.components))
+    ws = probs(fnc.diversity)
+    length(zs) <= NBP_MAXC || error("libnbp: at most $NBP_MAXC mixture components")
+    flat = reduce(vcat, [component(ws[i], zs[i]) for i in eachindex(zs)])
+    return vcat(flat, zeros(Float64, NBP_MAXC * NBP_COMP_STRIDE - length(flat)))
+  end
+  return vcat(component(1.0, fnc.Z), zeros(Float64, (NBP_MAXC - 1) * NBP_COMP_STRIDE))
+end
+ncomponents(fnc) = fnc isa Mixture ? length(fnc.components) : 1
+
+partialmask(fnc) = hasfield(typeof(fnc), :partial) ? Int32(sum(1 << (k - 1) for k in fnc.partial)) : Int32(0)
+
+pad(v::AbstractVector{T}, n::Int, z::T) where {T} = ntuple(i -> i <= length(v) ? v[i] : z, n)
+
+"nbp_factor_spec of a DFG factor; `index`: variable label -> 0-based position in the clique's variable list"
+function factorspec(fct::DFGFactor, index::Dict{Symbol, Int})::NbpFactorSpec
+  ccw = _getCCW(fct)
+  fnc = getFactorType(fct)
+  vars = Int32[index[v] for v in getVariableOrder(fct)]
+  mh = ccw.hyporecipe.hypotheses                         # parsed Categorical, certain variables carry 0.0 (FactorGraph.jl:639-651)
+  return NbpFactorSpec(factorkind(fnc), Int32(length(vars)), pad(vars, NBP_MAXV, Int32(0)), Int32(ncomponents(fnc)),
+                       Int32(mh === nothing ? 0 : 1), partialmask(fnc),
+                       pad(mh === nothing ? Float64[] : collect(Float64, mh.p), NBP_MAXV, 0.0),
+                       Float64(ccw.nullhypo), Float64(ccw.inflation), Tuple(components(fnc)))
+end
+
+solverparams(sp, N::Int) = NbpSolverParams(Int32(N), Int32(sp.gibbsIters), Int32(sp.inflateCycles), Int32(1),
+                                           Int32(sp.upsolve), Int32(sp.downsolve), Int32(sp.limitfixeddown),
+                                           sp.alwaysFreshMeasurements ? Int32(0) : NBP_SOLVER_STORED_MEASUREMENTS,
+                                           Float64(sp.spreadNH), Float64(sp.inflation), Float64(sp.nullSurplusAdd))
+
+supported(fct::DFGFactor) = getFactorType(fct) isa Union{NbpUser, MsgPrior{<:ManifoldKernelDensity}}
+
+# ---- beliefs at the boundary ------------------------------------------------------------------------------------------
+"host buffers of one TreeBelief; keeps them alive next to the C view"
+struct BeliefBuf
+  pts::Vector{Float64}
+  bw::Vector{Float64}
+  ipc::Vector{Float64}
+  n::Int
+end
+function BeliefBuf(code::Int32, pts::AbstractVector, bw::AbstractVector, ipc::AbstractVector, N::Int)
+  D = tangentdim(code)
+  buf = packpoints(code, pts)
+  resize!(buf, max(length(buf), N * pointdoubles(code)))          # room for the N points that come back
+  ipc_ = length(ipc) == D ? collect(Float64, ipc) : zeros(Float64, D)
+  return BeliefBuf(buf, collect(Float64, bw[1:D]), ipc_, length(pts))
+end
+cview(b::BeliefBuf) = NbpTreeBelief(pointer(b.pts), pointer(b.bw), pointer(b.ipc), Int32(b.n), Int32(0))
+
+function BeliefBuf(dfg::AbstractDFG, sym::Symbol, solveKey::Symbol, N::Int)
+  vnd = getSolverData(getVariable(dfg, sym), solveKey)
+  code = manifoldcode(getVariableType(dfg, sym))
+  return BeliefBuf(code, vnd.val, vnd.bw[:, 1], vnd.infoPerCoord, N)
+end
+function BeliefBuf(mkd::ManifoldKernelDensity, code::Int32, ipc, N::Int)
+  return BeliefBuf(code, getPoints(mkd, false), getBW(mkd)[:, 1], ipc, N)
+end
+
+# ---- the clique seam --------------------------------------------------------------------------------------------------
+"everything one nbp_clique_* call needs, with the Julia arrays the C struct points into"
+struct CliquePack
+  labels::Vector{Symbol}
+  codes::Vector{Int32}
+  margin::Vector{Int32}
+  specs::Vector{NbpFactorSpec}
+  lists::NTuple{4, Vector{Int32}}
+  msgvar::Vector{Int32}
+  msgbuf::Vector{BeliefBuf}
+  msgs::Vector{NbpTreeBelief}
+  bufs::Vector{BeliefBuf}
+  beliefs::Vector{NbpTreeBelief}
+end
+
+function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, labels::Vector{Symbol}, factors::Vector{<:DFGFactor})
+  cd = getCliqueData(cliq)
+  index = Dict{Symbol, Int}(l => i - 1 for (i, l) in enumerate(labels))
+  all(supported, factors) || error("libnbp: unsupported factor type in clique $(cliq.id)")
+  user = [f for f in factors if !(getFactorType(f) isa MsgPrior)]
+  msgf = [f for f in factors if getFactorType(f) isa MsgPrior]
+  codes = Int32[manifoldcode(getVariableType(dfg, l)) for l in labels]
+  margin = Int32[getSolverData(getVariable(dfg, l), solveKey).ismargin ? 1 : 0 for l in labels]
+  specs = NbpFactorSpec[factorspec(f, index) for f in user]
+  ids(v) = Int32[index[s] for s in v if haskey(index, s)]
+  lists = (ids(cd.directFrtlMsgIDs), ids(cd.msgskipIDs), ids(cd.itervarIDs), ids(cd.directPriorMsgIDs))
+  msgvar = Int32[index[getVariableOrder(f)[1]] for f in msgf]
+  msgbuf = BeliefBuf[BeliefBuf(getFactorType(f).Z, codes[index[getVariableOrder(f)[1]] + 1], getFactorType(f).infoPerCoord, N) for f in msgf]
+  bufs = BeliefBuf[BeliefBuf(dfg, l, solveKey, N) for l in labels]
+  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs))
+end
+
+ptr_or_null(v::Vector{T}) where {T} = isempty(v) ? Ptr{T}(C_NULL) : pointer(v)
+
+function cliquedesc(cliq::TreeClique, p::CliquePack, nfrontals::Int, nseparators::Int)
+  return NbpCliqueDesc(Int32(cliq.id.value), Int32(length(p.labels)), Int32(nfrontals), Int32(nseparators),
+                       pointer(p.codes), pointer(p.margin), Int32(length(p.specs)), ptr_or_null(p.specs),
+                       Int32(length(p.lists[1])), Int32(length(p.lists[2])), Int32(length(p.lists[3])), Int32(length(p.lists[4])),
+                       ptr_or_null(p.lists[1]), ptr_or_null(p.lists[2]), ptr_or_null(p.lists[3]), ptr_or_null(p.lists[4]),
+                       Int32(length(p.msgvar)), ptr_or_null(p.msgvar), ptr_or_null(p.msgs))
+end
+
+"write the beliefs libnbp returned back into the sub graph: setValKDE!(vnd, pts, bw, setinit, ipc) (FactorGraph.jl:250-297)"
+function unpack!(dfg::AbstractDFG, p::CliquePack, solveKey::Symbol, N::Int, which)
+  for (i, l) in enumerate(p.labels)
+    l in which || continue
+    vt = getVariableType(dfg, l)
+    b = p.bufs[i]
+    setValKDE!(getSolverData(getVariable(dfg, l), solveKey), wrappoints(vt, p.codes[i], b.pts, N), reshape(b.bw, :, 1), true, b.ipc)
+  end
+  return nothing
+end
+
+function runclique(sym::Symbol, dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, p::CliquePack, nfr::Int, nsep::Int, seed::UInt64)
+  q = cliquedesc(cliq, p, nfr, nsep)
+  sp = solverparams(getSolverParams(dfg), N)
+  status = Ref{Int32}(0)
+  GC.@preserve p begin
+    need = chk(ccall((:nbp_clique_slots, libnbp), Int32, (Ref{NbpCliqueDesc},), q))
+    withctx(N, need) do ctx
+      if sym === :up
+        chk(ccall((:nbp_clique_upsolve, libnbp), Int32,
+                  (Ptr{Cvoid}, Ref{NbpSolverParams}, Ref{NbpCliqueDesc}, UInt64, Ptr{NbpTreeBelief}, Ref{Int32}),
+                  ctx.ptr, sp, q, seed, p.beliefs, status))
+      else
+        chk(ccall((:nbp_clique_downsolve, libnbp), Int32,
+                  (Ptr{Cvoid}, Ref{NbpSolverParams}, Ref{NbpCliqueDesc}, UInt64, Ptr{NbpTreeBelief}, Ref{Int32}),
+                  ctx.ptr, sp, q, seed, p.beliefs, status))
+      end
+    end
+  end
+  return status[]
+end
+
+"""
+    upGibbsCliqueDensity(dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)
+
+The clique up solve on the device: src/services/SolveTree.jl:164-239 (called from approxCliqMarginalUp!,
+CliqStateMachineUtils.jl:375-385).  `dfg` is the clique sub graph with the children's messages already added as
+MsgPrior factors (addMsgFactors!, TreeMessageUtils.jl:542-578); like the reference it is updated in place
+(setBelief! of every variable the schedule touches) and the beliefs are returned as `Dict{Symbol,TreeBelief}`.
+"""
+function upGibbsCliqueDensity(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, inmsgs, N::Int = getSolverParams(dfg).N,
+                              dbg::Bool = false, iters::Int = 3, logger = nothing)
+  cd = getCliqueData(cliq)
+  labels = Symbol[cd.frontalIDs; cd.separatorIDs]
+  factors = DFGFactor[getFactor(dfg, f) for f in lsf(dfg)]
+  all(supported, factors) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
+                                           dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)      # generic CPU path
+  p = packclique(dfg, cliq, solveKey, N, labels, factors)
+  runclique(:up, dfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64))
+  unpack!(dfg, p, solveKey, N, labels)
+  d = Dict{Symbol, TreeBelief}()
+  for l in labels                                            # compileFMCMessages, SolveTree.jl:32-45
+    d[l] = TreeBelief(getVariable(dfg, l), solveKey)
+  end
+  return d
+end
+
+"""
+    solveCliqDownFrontalProducts!(subfg, cliq, opts, logger; solveKey, MCIters)
+
+The clique down solve on the device (CliqStateMachineUtils.jl:479-571): `subfg` already holds the parent's separator
+values (updateSubFgFromDownMsgs!) and every factor of the frontals (addDownVariableFactors!, CliqueStateMachine.jl:823-835).
+"""
+function solveCliqDownFrontalProducts!(subfg::AbstractDFG, cliq::TreeClique, opts::SolverParams, logger = nothing;
+                                       solveKey::Symbol = :default, MCIters::Int = 3)
+  cd = getCliqueData(cliq)
+  inclq = Symbol[cd.frontalIDs; cd.separatorIDs]
+  factors = DFGFactor[]
+  for v in cd.frontalIDs, f in ls(subfg, v)
+    fc = getFactor(subfg, f)
+    (getFactorType(fc) isa MsgPrior || fc in factors) || push!(factors, fc)
+  end
+  MCIters == 3 && all(supported, factors) || return invoke(solveCliqDownFrontalProducts!, Tuple{AbstractDFG, TreeClique, SolverParams, Any},
+                                                           subfg, cliq, opts, logger; solveKey, MCIters)
+  others = Symbol[]
+  for fc in factors, u in getVariableOrder(fc)
+    (u in inclq || u in others) || push!(others, u)
+  end
+  labels = Symbol[inclq; others]
+  N = opts.N
+  p = packclique(subfg, cliq, solveKey, N, labels, factors)
+  runclique(:down, subfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64))
+  unpack!(subfg, p, solveKey, N, cd.frontalIDs)
+  return nothing
+end
+
+# ---- the finer seams (host buffers, one ccall per reference function) ---------------------------------------------------
+"AMP.manikde!(M, pts) bandwidth selection (ApproxConv.jl:38,41; FGOSUtils.jl:118-128)"
+function nbpbandwidth(vt::InferenceVariable, pts::AbstractVector)
+  code = manifoldcode(vt)
+  buf = packpoints(code, pts)
+  bw = Vector{Float64}(undef, tangentdim(code))
+  withctx(length(pts), 4) do ctx
+    GC.@preserve buf bw chk(ccall((:nbp_kde_bandwidth, libnbp), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}),
+                                  ctx.ptr, code, buf, bw))
+  end
+  return bw
+end
+
+"AMP.manifoldProduct(dens, M; Niter, oldPoints, N) + rebandwidth (GraphProductOperations.jl:53-60)"
+function nbpproduct(vt::InferenceVariable, dens::Vector{<:ManifoldKernelDensity}; Niter::Int = 1, oldPoints = nothing,
+                    N::Int = Npts(dens[1]), partials::Vector{UInt8} = zeros(UInt8, length(dens)))
+  code = manifoldcode(vt)
+  F = length(dens)
+  pts = [packpoints(code, getPoints(d, false)) for d in dens]
+  bws = [collect(Float64, getBW(d)[:, 1]) for d in dens]
+  old = oldPoints === nothing ? Float64[] : packpoints(code, oldPoints)
+  out = Vector{Float64}(undef, N * pointdoubles(code))
+  bw = Vector{Float64}(undef, tangentdim(code))
+  lbl = Vector{Int32}(undef, N * F)
+  withctx(N, F + 2) do ctx
+    GC.@preserve pts bws old out bw lbl partials begin
+      pp, pb = pointer.(pts), pointer.(bws)
+      chk(ccall((:nbp_manifold_product, libnbp), Int32,
+                (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{UInt8}, Ptr{Float64}, Int32, UInt64,
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                ctx.ptr, code, F, pp, pb, partials, isempty(old) ? Ptr{Float64}(C_NULL) : pointer(old), Niter, rand(UInt64), out, bw, lbl))
+    end
+  end
+  return manikde!(getManifold(vt), wrappoints(vt, code, out, N); bw), reshape(lbl, F, N)
+end
+
+"nbp_proposal_desc of approxConvBelief(dfg, fct, target): the slot fields stay 0 (nbp_conv fills them)"
+function proposaldesc(dfg::AbstractDFG, fct::DFGFactor, target::Symbol; nullSurplus::Real = 0.0, seed::UInt64 = rand(UInt64))
+  ccw = _getCCW(fct)
+  fnc = getFactorType(fct)
+  sp = getSolverParams(dfg)
+  order = getVariableOrder(fct)
+  mh = ccw.hyporecipe.hypotheses
+  flags = Int32(0)
+  if mh !== nothing          # bit 0: multihypo; bit 7: isinit flags present; bit 8+k: variable k initialised
+    flags = Int32(1 | 0x80)
+    for (k, v) in enumerate(order)
+      isInitialized(dfg, v) && (flags |= Int32(1) << (7 + k))
+    end
+  end
+  return NbpProposalDesc(factorkind(fnc), manifoldcode(getVariableType(dfg, target)), Int32(length(order)),
+                         Int32(findfirst(==(target), order) - 1), ntuple(_ -> Int32(0), NBP_MAXV), Int32(0),
+                         Int32(ncomponents(fnc)), flags, Int32(sp.inflateCycles), Int32(-1), Int32(-1), Int32(0),
+                         partialmask(fnc), Int32(0), Int32(0),
+                         pad(mh === nothing ? Float64[] : collect(Float64, mh.p), NBP_MAXV, 0.0),
+                         Float64(max(ccw.nullhypo, nullSurplus)), Float64(ccw.inflation), Float64(sp.spreadNH),
+                         Tuple(components(fnc)), seed, UInt64(0))
+end
+
+"factor seam: approxConvBelief(dfg, fct, target) (ApproxConv.jl:4-45) as one nbp_conv call"
+function approxConvBelief(dfg::AbstractDFG, fct::DFGFactor{<:CommonConvWrapper{<:NbpUser}}, target::Symbol,
+                          measurement::AbstractVector = Tuple[]; solveKey::Symbol = :default,
+                          N::Int = getSolverParams(dfg).N, nullSurplus::Real = 0, skipSolve::Bool = false)
+  order = getVariableOrder(fct)
+  vt = getVariableType(dfg, target)
+  code = manifoldcode(vt)
+  bufs = [packpoints(manifoldcode(getVariableType(dfg, v)), getVal(getVariable(dfg, v); solveKey)) for v in order]
+  d = proposaldesc(dfg, fct, target; nullSurplus)
+  out = Vector{Float64}(undef, N * pointdoubles(code))
+  bw = Vector{Float64}(undef, tangentdim(code))
+  mh = Vector{Int32}(undef, N)
+  withctx(N, length(order) + 1) do ctx
+    GC.@preserve bufs out bw mh begin
+      ptrs = pointer.(bufs)
+      chk(ccall((:nbp_conv, libnbp), Int32,
+                (Ptr{Cvoid}, Ref{NbpProposalDesc}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                ctx.ptr, d, ptrs, C_NULL, C_NULL, out, bw, mh))
+    end
+  end
+  return manikde!(getManifold(vt), wrappoints(vt, code, out, N); bw)
+end
+
+end # module

@@ -107,6 +107,11 @@ typedef struct nbp_clique_info {
 nbp_status nbp_tree_clique(const nbp_tree *t, int32_t k, nbp_clique_info *info, int32_t *frontals, int32_t *separators,
                            int32_t *children, int32_t *potentials, int32_t *up_schedule, int32_t *down_schedule);
 int32_t nbp_tree_max_schedule(const nbp_tree *t);
+/* the four Gibbs id lists of clique k (getCliqueData(cliq).directFrtlMsgIDs / msgskipIDs / itervarIDs /
+ * directPriorMsgIDs; setCliqMCIDs!, JunctionTreeUtils.jl:1352-1523) as variable ids: counts[4], then one array per
+ * list (each nullable, nbp_graph_num_variables entries at most) -- what nbp_clique_upsolve takes */
+nbp_status nbp_tree_clique_idlists(const nbp_tree *t, int32_t k, int32_t *counts, int32_t *direct_frtl_msg, int32_t *msgskip,
+                                   int32_t *itervar, int32_t *direct_prior_msg);
 
 /* The slot plan of a whole-tree solve: main[v] | snap[v] (optional) | clique-local copies | scratch.
  * Returns the number of slots the context must have. */

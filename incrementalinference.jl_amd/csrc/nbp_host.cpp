@@ -856,6 +856,17 @@ nbp_status nbp_tree_clique(const nbp_tree *t, int32_t k, nbp_clique_info *info, 
   return NBP_OK;
 }
 
+nbp_status nbp_tree_clique_idlists(const nbp_tree *t, int32_t k, int32_t *counts, int32_t *dfm, int32_t *ms, int32_t *iv, int32_t *dpm) {
+  if (!t || k < 1 || k > (int)t->cl.size()) return hfail(NBP_ERR_RANGE, "clique id");
+  if (!counts) return hfail(NBP_ERR_ARG, "null argument");
+  const Clique &c = t->cl[k - 1];
+  auto cp = [](const std::vector<int> &v, int32_t *o) { if (o) for (size_t i = 0; i < v.size(); i++) o[i] = v[i]; };
+  counts[0] = (int32_t)c.directFrtlMsg.size(); counts[1] = (int32_t)c.msgskip.size();
+  counts[2] = (int32_t)c.itervar.size(); counts[3] = (int32_t)c.directPriorMsg.size();
+  cp(c.directFrtlMsg, dfm); cp(c.msgskip, ms); cp(c.itervar, iv); cp(c.directPriorMsg, dpm);
+  return NBP_OK;
+}
+
 int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
   if (!t) return hfail(NBP_ERR_ARG, "null argument");
   const nbp_graph *g = t->g;

@@ -54,7 +54,7 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_graph_set_variable_flags", "nbp_graph_num_variables", "nbp_graph_num_factors",
                 "nbp_graph_order_nested_dissection", "nbp_graph_init_plan", "nbp_graph_init_num_variables", "nbp_graph_init_variables",
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
-                "nbp_tree_clique", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
+                "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
                 "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve"]
 
 _declared = False
@@ -84,6 +84,7 @@ def _lib():
         lib.nbp_tree_num_cliques.argtypes = [vp]
         lib.nbp_tree_clique.argtypes = [vp, i32, C.POINTER(CliqueInfo), ip, ip, ip, ip, ip, ip]
         lib.nbp_tree_max_schedule.argtypes = [vp]
+        lib.nbp_tree_clique_idlists.argtypes = [vp, i32, ip, ip, ip, ip, ip]
         lib.nbp_tree_plan_slots.argtypes = [vp, i32]
         lib.nbp_tree_main_slots.argtypes = [vp, ip, ip]
         lib.nbp_tree_compile.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]

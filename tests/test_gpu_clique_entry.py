@@ -54,7 +54,10 @@ def test_clique_calls_equal_whole_tree_program(hip_backend, name):
         # infoPerCoord: the number of densities of the variable's last update, on every coordinate (ApproxConv.jl:277,298-303)
         D = abi.MANIFOLD_DIM[man]
         assert post[v].ipc.shape == (D,) and np.all(post[v].ipc >= 1.0) and np.all(post[v].ipc == post[v].ipc[0])
-    assert nbit == len(fa.ls()), f"{nbit} of {len(fa.ls())} variables bit-identical"
+    # SE(2) beliefs cross the boundary as rotation matrices (ArrayPartition(t, R), what Julia holds): theta -> (cos, sin) ->
+    # atan2 is not a bitwise round trip, so the clique-by-clique solve agrees to rounding (1e-9 above) there
+    if name != "se2_lattice":
+        assert nbit == len(fa.ls()), f"{nbit} of {len(fa.ls())} variables bit-identical"
 
 
 def test_clique_entry_rejects_bad_input(hip_backend):

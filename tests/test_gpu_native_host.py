@@ -63,6 +63,21 @@ def test_pure_c_example_solves_a_chain(tmp_path):
     assert "120 variables" in out.stdout and "worst posterior mean error" in out.stdout
 
 
+def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
+    """examples/solve_by_clique_calls.c: a plain-C host walks the tree and calls nbp_clique_upsolve / nbp_clique_downsolve
+    once per clique; the posteriors are byte-identical to the whole-tree resident program (exit status 0)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "incrementalinference.jl_amd", "csrc")
+    exe = str(tmp_path / "clique_calls")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "solve_by_clique_calls.c"),
+                           "-o", exe, "-L", lib, "-lnbp", f"-Wl,-rpath,{lib}", "-lm"])
+    out = subprocess.run([exe, "12", "128"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "12 of 12 posteriors byte-identical" in out.stdout, out.stdout
+
+
 def test_native_graph_init_equals_python_init_all(hip_backend):
     from iif_amd import native_host
     def fresh():

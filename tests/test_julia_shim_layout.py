@@ -1,0 +1,114 @@
+"""CPU: the structs of the Julia shim (ext/IIFNbpExt.jl) against the C headers.  Julia is not installed here, so the
+file is parsed: every `struct Nbp... end` block gives (field name, Julia type) pairs, a C-ABI layout is computed
+from them (natural alignment, NTuple = inline array, Ptr = 8 bytes) and compared with sizeof / offsetof / field order
+of the corresponding C struct as gcc sees it.  A shim that drifts from the header fails here instead of corrupting
+descriptor arrays at run time."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "ext", "IIFNbpExt.jl")
+
+C_NAME = {"NbpProposalDesc": "nbp_proposal_desc", "NbpProductDesc": "nbp_product_desc", "NbpCopyDesc": "nbp_copy_desc",
+          "NbpDiag": "nbp_diag", "NbpSolverParams": "nbp_solver_params", "NbpFactorSpec": "nbp_factor_spec",
+          "NbpTreeBelief": "nbp_tree_belief", "NbpCliqueDesc": "nbp_clique_desc"}
+PRIM = {"Int32": 4, "UInt32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "UInt8": 1, "Int8": 1}
+
+
+def parse_shim():
+    src = open(SHIM).read()
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"^const (NBP_[A-Z_]+) = (\d+)\s*$", src, re.M)}
+    structs = {}
+    for m in re.finditer(r"^struct (Nbp\w+)\n(.*?)^end", src, re.M | re.S):
+        fields = []
+        for line in m.group(2).splitlines():
+            line = line.split("#")[0].strip()
+            if not line:
+                continue
+            fm = re.fullmatch(r"(\w+)::(.+)", line)
+            assert fm, f"{m.group(1)}: one `name::Type` per line, got {line!r}"
+            fields.append((fm.group(1), fm.group(2).strip()))
+        structs[m.group(1)] = fields
+    return consts, structs
+
+
+def size_align(jtype, consts):
+    if jtype in PRIM:
+        return PRIM[jtype], PRIM[jtype]
+    if jtype.startswith("Ptr{"):
+        return 8, 8
+    m = re.fullmatch(r"NTuple\{(.+),\s*(\w+)\}", jtype)
+    assert m, f"unsupported field type {jtype}"
+    n = eval(m.group(1), {}, consts)
+    s, a = size_align(m.group(2), consts)
+    return n * s, a
+
+
+def julia_layout(fields, consts):
+    off, amax, out = 0, 1, []
+    for name, jt in fields:
+        s, a = size_align(jt, consts)
+        off = (off + a - 1) // a * a
+        out.append((name, off, s))
+        off += s
+        amax = max(amax, a)
+    return out, (off + amax - 1) // amax * amax
+
+
+def c_layout(cname, names, tmp_path):
+    probe = ['#include <stdio.h>', '#include <stddef.h>', '#include "nbp_host.h"', 'int main(){', f'  {cname} x; (void)x;',
+             f'  printf("%zu\\n", sizeof({cname}));']
+    for n in names:
+        probe.append(f'  printf("{n} %zu %zu\\n", offsetof({cname}, {n}), sizeof(x.{n}));')
+    probe.append("  return 0;}")
+    src = tmp_path / f"{cname}.c"
+    src.write_text("\n".join(probe))
+    exe = tmp_path / cname
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)]).decode().split("\n")
+    return [(p[0], int(p[1]), int(p[2])) for p in (l.split() for l in lines[1:] if l)], int(lines[0])
+
+
+def c_field_names(cname):
+    hdr = open(os.path.join(ROOT, "include", "nbp.h")).read() + open(os.path.join(ROOT, "include", "nbp_host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):  # `int32_t a, b;` and `const int32_t *a, *b;`
+            names.append(re.search(r"(\w+)\s*(?:\[[^\]]*\])*\s*$", part.strip()).group(1))
+    return names
+
+
+def test_every_boundary_struct_is_mirrored():
+    consts, structs = parse_shim()
+    assert set(C_NAME) == set(structs), set(C_NAME) ^ set(structs)
+    for k, v in (("NBP_MAXV", 6), ("NBP_MAXF", 128), ("NBP_MAXC", 4), ("NBP_COMP_STRIDE", 13)):
+        assert consts[k] == v
+        assert re.search(r"#define %s %d\b" % (k, v), open(os.path.join(ROOT, "include", "nbp.h")).read())
+
+
+def test_julia_structs_match_the_headers(tmp_path):
+    consts, structs = parse_shim()
+    for jname, cname in C_NAME.items():
+        fields = structs[jname]
+        assert [n for n, _ in fields] == c_field_names(cname), (jname, "field names / order differ from the header")
+        jl, jsize = julia_layout(fields, consts)
+        cl, csize = c_layout(cname, [n for n, _ in fields], tmp_path)
+        assert jl == cl, (jname, [(a, b) for a, b in zip(jl, cl) if a != b])
+        assert jsize == csize, (jname, jsize, csize)
+    # the figures DESIGN.md / INTEGRATION.md quote
+    assert julia_layout(structs["NbpProposalDesc"], consts)[1] == 584
+
+
+def test_shim_ccalls_name_exported_symbols():
+    from parity_utils import abi
+    from iif_amd import native_host
+    called = set(re.findall(r"ccall\(\(:(\w+), libnbp\)", open(SHIM).read()))
+    assert called and called <= set(abi.EXPORTS) | set(native_host.HOST_EXPORTS), called - set(abi.EXPORTS) - set(native_host.HOST_EXPORTS)
+    for need in ("nbp_clique_upsolve", "nbp_clique_downsolve", "nbp_conv", "nbp_manifold_product", "nbp_kde_bandwidth", "nbp_ctx_create"):
+        assert need in called
