@@ -15,8 +15,16 @@ from parity_utils import abi
 
 
 def compare_solves(f_oracle, f_gpu, f_oracle_other=None, bound=0.05):
-    """returns (share of variables whose particles agree to 1e-6, {var: symKL(gpu, oracle)}); asserts the criterion"""
+    """returns (share of variables whose particles agree to 1e-6, {var: symKL(gpu, oracle)}); asserts the criterion.
+    f_oracle_other: a second oracle solve (another seed), or a callable that makes one -- only called when some
+    variable's particles differ"""
     same, kl, ref = 0, {}, {}
+    if callable(f_oracle_other):
+        differs = any(np.abs(f_oracle.getVal(v) - f_gpu.getVal(v)).max() >= 1e-6 * max(1.0, np.abs(f_oracle.getVal(v)).max())
+                      for v in f_oracle.ls())
+        f_oracle_other = f_oracle_other() if differs else None
+        if not differs:
+            return 1.0, {v: 0.0 for v in f_oracle.ls()}
     for v in f_oracle.ls():
         man = f_oracle.getVariable(v).varType.manifold
         a, b = f_oracle.getVal(v), f_gpu.getVal(v)

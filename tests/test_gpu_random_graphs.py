@@ -4,6 +4,7 @@ Python mirror's schedule, identical seeds."""
 import numpy as np
 import pytest
 
+from kl_parity import compare_solves
 from parity_utils import abi, iif
 from test_native_host import random_graph
 
@@ -19,20 +20,17 @@ def test_random_graph_solve_matches_oracle(oracle_backend, hip_backend, seed):
     except ValueError:
         pytest.skip("a product wider than NBP_MAXF")
     iif.solveTree(fb, eliminationOrder=order, backend=hip_backend, seed=seed)
-    # Identical streams do NOT give identical particles through a whole solve: a Nelder-Mead search stops at
-    # g_tol = 1e-8 on the objective spread, i.e. ~1e-4 in the argument, and 1e-10 differences of its inputs
-    # (FMA contraction on the device) flip branches of the search, after which Gibbs labels flip too.  Both
-    # runs are equally valid draws, so the criterion is agreement in distribution, per variable and coordinate.
-    exact = 0
-    for v in fa.ls():
-        a, b = fa.getVal(v), fb.getVal(v)
-        if fa.getVariable(v).varType.manifold == abi.CIRCULAR:
-            ref = np.arctan2(np.sin(a).mean(), np.cos(a).mean())
-            a = (a - ref + np.pi) % (2 * np.pi) - np.pi
-            b = (b - ref + np.pi) % (2 * np.pi) - np.pi
-        exact += int(np.abs(a - b).max() < 1e-6)
-        for k in range(a.shape[1]):
-            sa, sb = a[:, k].std() + 1e-3, b[:, k].std() + 1e-3
-            assert abs(np.median(a[:, k]) - np.median(b[:, k])) <= 1.0 * max(sa, sb) + 0.05, (v, k)
-            assert 0.33 <= sb / sa <= 3.0, (v, k, sa, sb)
-    print(f"seed {seed}: {exact} of {len(fa.ls())} variables agree particle by particle")
+
+    def another_oracle_solve():
+        fc = random_graph(seed)
+        iif.solveTree(fc, eliminationOrder=order, backend=oracle_backend, seed=seed + 1000)
+        return fc
+
+    # Identical streams give identical particles until a data-dependent branch (a Nelder-Mead comparison, a
+    # golden-section step) resolves differently on the two sides; from there on the two runs are independent draws of
+    # the same sampler, and these graphs -- inconsistent multihypo loops, nullhypo -- have multi-modal posteriors whose
+    # independent draws differ by whole modes (two ORACLE solves of graph 9 with different seeds put v19 at 3.4 and at
+    # 0.5 with a spread of 0.1).  Criterion (tests/kl_parity.py): particle-identical, or no further from the oracle
+    # solve in symmetric KL than a second oracle solve with another seed is.
+    share, kl = compare_solves(fa, fb, another_oracle_solve)
+    print(f"seed {seed}: {share:.0%} of {len(fa.ls())} variables agree particle by particle; symKL max {max(kl.values()):.3f}")

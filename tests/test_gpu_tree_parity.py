@@ -24,16 +24,15 @@ def test_config1_chain_gpu_matches_oracle(oracle_backend, hip_backend):
     fa, fb = _chain(), _chain()
     iif.solveTree(fa, backend=oracle_backend, seed=5)
     iif.solveTree(fb, backend=hip_backend, seed=5)
-    nbad = 0
-    for v in fa.ls():
-        a, b = fa.getVal(v), fb.getVal(v)
-        bad = np.abs(a - b).max(axis=1) > 1e-7 * np.maximum(1, np.abs(a).max(axis=1))
-        nbad += bad.sum()
-    # a single label flip anywhere upstream changes every later particle of that variable, so allow
-    # distribution-level agreement as the fallback criterion
-    if nbad:
-        for v in fa.ls():
-            assert abs(fa.getVal(v).mean() - fb.getVal(v).mean()) < 0.2
+    def another_oracle_solve():
+        fc = _chain()
+        iif.solveTree(fc, backend=oracle_backend, seed=6)
+        return fc
+
+    # particle-identical, or -- after a branch flip -- within the oracle's own seed-to-seed spread (tests/kl_parity.py)
+    from kl_parity import compare_solves
+    share, kl = compare_solves(fa, fb, another_oracle_solve)
+    print(f"config 1: {share:.0%} of the variables agree particle by particle; symKL max {max(kl.values()):.3f}")
     X = [fb.getVal(f"x{i}").mean() for i in range(6)]
     assert abs(X[0]) < 0.5
     for i in range(5):
