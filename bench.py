@@ -1,13 +1,20 @@
 #!/usr/bin/env python
 """bench.py -- clique-messages/s of the MI355X-native nonparametric belief-propagation solve.
 
-A "step" is one full up+down solveTree pass (every clique up-solved and down-solved once) over the
-BASELINE.json config-2 graph: ContinuousEuclid(2) odometry chain with periodic priors, N=200
-particles, nested-dissection elimination order; beliefs are resident in HBM when the timed region
-starts (the init beliefs are restored from a device-side snapshot at the start of every step).
+A "step" is one full up+down solveTree pass (every clique up-solved and down-solved once) over one BASELINE.json
+configuration; the default is config 2, the configuration the metric is quoted on: ContinuousEuclid(2) 1000-variable
+odometry chain with periodic priors, N = 200 particles, nested-dissection elimination order.  `--config 2p|3|4|5`
+runs the other configurations at full size (3, 4, 5 are 8-GPU targets for 4 and 5: the graph grows with --gpus).
+Beliefs are resident in HBM when the timed region starts (the initial beliefs are restored from a device-side
+snapshot at the start of every step).
 
-Prints ONE JSON line (see the driver contract).  value = clique messages (one per tree edge and
-direction, CliqueStateMachine.jl:590-593/900-903) per second over all ranks.
+Timed region: K steps between barriers, nothing else -- no per-kernel events, the staged program replayed as a
+hipGraph.  The per-kernel split, the roofline figures and the counters come from a separate profiling pass of the
+same steps with HIP events around every launch (on the library's stream), which is slower and is NOT what `value` is
+computed from.
+
+Prints ONE JSON line (see the driver contract).  value = clique messages (one per tree edge and direction,
+CliqueStateMachine.jl:590-593/900-903) per second over all ranks.
 """
 import argparse
 import json
@@ -20,35 +27,50 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (MI355X_MICROARCH.md): 256 CUs x 128 flop/clk x 2.4 GHz
+HBM_PEAK_FALLBACK_GBPS = 8000.0
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nvars", type=int, default=1000, help="variables per GPU (config 2: 1000; north-star 2': 10000)")
-    ap.add_argument("--particles", type=int, default=200)
+    ap.add_argument("--config", default="2", choices=["2", "2p", "3", "4", "5"], help="BASELINE.json configuration (default 2: the metric's)")
+    ap.add_argument("--nvars", type=int, default=None, help="override the per-GPU size of the configuration (variables / poses / lattice rows)")
+    ap.add_argument("--particles", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vars", type=int, default=600)
     ap.add_argument("--no-10k", action="store_true", help="skip the secondary 10 000-variable north-star measurement")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the per-kernel profiling pass (roofline fields become null)")
     ap.add_argument("--python-host", action="store_true", help="build tree and schedule with the Python mirror instead of the native host")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: take the sharded multi-GPU code path (process group, torch-owned arena) even with one rank")
     return ap.parse_args()
 
 
-def build_workload(iif, nvars, N, seed):
-    fg = iif.generateChainEuclid(nvars, vardims=2, priorEvery=100, N=N)
-    order = iif.nestedDissectionOrder(fg)
-    tree = iif.buildTreeReset(fg, order)
-    return fg, order, tree
+def hbm_peak_gbps(device):
+    """peak HBM bandwidth from the device properties (memory clock x bus width, double data rate); the datasheet
+    figure of MI355X_MICROARCH.md when the runtime does not report them"""
+    import torch
+    try:
+        p = torch.cuda.get_device_properties(device)
+        clk, width = getattr(p, "memory_clock_rate", 0), getattr(p, "memory_bus_width", 0)
+        gbps = 2.0 * clk * 1e3 * width / 8 / 1e9
+        if 2000.0 < gbps < 20000.0:
+            return gbps, f"device properties: {clk / 1e3:.0f} MHz x {width} bit x 2"
+    except Exception:  # noqa: BLE001
+        pass
+    return HBM_PEAK_FALLBACK_GBPS, "MI355X_MICROARCH.md (the runtime reports no memory clock / bus width)"
 
 
 def cpu_baseline(iif, nvars, N, threads):
-    """the CPU restatement (oracle/, kind="port") on a bounded sample: the same chain shape with
-    fewer variables, one full up+down solve, OpenMP over the independent ops of a stage."""
+    """the CPU restatement (oracle/, kind="port") on a bounded sample: the config-2 chain shape with fewer variables,
+    one full up+down solve, OpenMP over the independent ops of a stage."""
     from oracle.oracle_backend import OracleBackend
-    fg, order, tree = build_workload(iif, nvars, N, 0)
+    fg = iif.generateChainEuclid(nvars, vardims=2, priorEvery=100, N=N)
+    order = iif.nestedDissectionOrder(fg)
+    tree = iif.buildTreeReset(fg, order)
     mk = lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=threads)
     iif.initAll(fg, backend=mk, seed=0)
     tp = iif.TreeProgram(fg, tree, seed=1)
@@ -61,6 +83,17 @@ def cpu_baseline(iif, nvars, N, threads):
     prog.run()
     dt = time.perf_counter() - t0
     return tp.n_messages / dt, dt, tp.n_messages
+
+
+def timed_steps(rs, steps, warmup, barrier):
+    for w in range(warmup):
+        rs.step(1000 + w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        rs.step(k)
+    barrier()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -77,9 +110,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
-    N = a.particles
-    from bench_support import RankSolve
-    rs = RankSolve(iif, a.nvars, N, rank, world, local, dist, python_host=a.python_host)
+    from bench_support import RankSolve, workloads
+    wl = workloads(iif)[a.config]
+    N = a.particles or wl.N
+    size = a.nvars or wl.size
+    rs = RankSolve(iif, wl, size, N, rank, world, local, dist, python_host=a.python_host)
     rs.prepare()
 
     def barrier():
@@ -88,128 +123,133 @@ def main():
         torch.cuda.synchronize()
         rs.be.synchronize()
 
-    for w in range(a.warmup):
-        rs.step(1000 + w)
-    rs.be.timing_enable(True)
-    rs.be.timing_read()
-    rs.be.diag(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        rs.step(k)
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---- timed region ------------------------------------------------------------------------------------------------
+    rs.be.timing_enable(False)
+    dt = timed_steps(rs, a.steps, a.warmup, barrier)
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    tim = rs.be.timing_read()
-    diag = rs.be.diag()
-    rs.be.timing_enable(False)
     rs.check_posteriors()
-
     msgs_total = rs.global_messages
     value = msgs_total * a.steps / dt
     st = rs.stats
-    # roofline of the dominant kernel (HIP events on the library stream, timed region only)
-    per_step = {k: v[0] / a.steps for k, v in tim.items()}
-    dominant = max(per_step, key=per_step.get)
-    launches = tim[dominant][1] / a.steps
-    avg_ms = tim[dominant][0] / max(tim[dominant][1], 1)
-    bytes_per_launch = st["alg_bytes"][dominant] / max(launches, 1)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of
-    # this same command, calibrated on nbp_copy_kernel's known byte count: tools/pmc_traffic.py).  A PMC
-    # pass cannot run inside this process, so the committed summary is quoted for the workload it was
-    # collected on and the field stays null for any other.
-    traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if world == 1 and a.nvars == 1000 and N == 200 and os.path.exists(pmc):
-        try:
-            k = json.load(open(pmc))["kernels"][dominant]
-            traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
-        except Exception:
-            pass
-    alg_total = sum(st["alg_bytes"].values())
-    kern_s = sum(per_step.values()) * 1e-3
+
+    # ---- profiling pass (not timed): HIP events around every launch, counters ------------------------------------------
+    prof = None
+    psteps = min(a.steps, 5)
+    if not a.no_profile_pass:
+        rs.be.timing_enable(True)
+        rs.be.timing_read()
+        rs.be.diag(reset=True)
+        tprof = timed_steps(rs, psteps, 0, barrier)
+        tim = rs.be.timing_read()
+        diag = rs.be.diag()
+        rs.be.timing_enable(False)
+        prof = (tim, diag, tprof)
+
+    peak, peak_src = hbm_peak_gbps(local)
     out = {
         "metric": "clique-messages/sec", "value": value, "unit": "messages/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"ContinuousEuclid(2) {a.nvars * world}-variable odometry chain + priors every 100, "
-                               f"N={N} particles, nested-dissection order, full up+down solveTree",
-                   "variables_per_gpu": a.nvars, "particles": N, "cliques": st["cliques_global"],
-                   "messages_per_step": msgs_total, "variable_updates_per_step": st["updates_global"],
+        "config": {"workload": wl.name.format(size=size * world) + f", N={N} particles, nested-dissection order, full up+down solveTree",
+                   "baseline_config": a.config, f"{wl.unit_name}_per_gpu": size, "variables_per_gpu": len(rs.fg.ls()) // world,
+                   "particles": N, "cliques": st["cliques_global"], "messages_per_step": msgs_total,
+                   "variable_updates_per_step": st["updates_global"],
+                   "launch": "staged program replayed as a hipGraph; per-kernel events only in the separate profiling pass",
                    "parallelism": (f"cliques sharded over {world} GPU(s), separator exchange: "
                                    f"{getattr(getattr(rs, 'impl', None), 'transport', 'none')}") if world > 1 else "single GPU"},
-        "solve_wall_s": dt / a.steps, "posterior_max_mean_err": getattr(rs, "posterior_max_mean_err", None),
-        "host_setup": getattr(rs, "host_setup", None),
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                     "whole_update_GBps": alg_total / kern_s / 1e9 if kern_s > 0 else 0.0,
-                     "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms,
-                     "launches_per_step": launches,
-                     "kernel_ms_per_step": per_step,
-                     "note": "HBM is the roofline the north star names; the path is FP64-VALU bound by construction "
-                             "(~13 KB algorithmic bytes per variable update vs ~1e6 FP64 kernel pairs): see roofline_valu"},
+        "solve_wall_s": dt / a.steps, "posterior_max_mean_err": rs.posterior_max_mean_err,
+        "posterior_mode_share_min_median": rs.posterior_mode_share, "host_setup": rs.host_setup,
     }
     hs = out["host_setup"]
     if hs:
         tb = hs["elimination_order_s"] + hs["tree_build_s"] + hs["schedule_compile_s"]
         out["value_incl_tree_build"] = msgs_total / (dt / a.steps + tb)
-    # secondary, honest roofline: FP64 vector rate of the leave-one-out likelihood evaluations, which
-    # dominate nbp_prep_kernel.  One LCV evaluation = N(N-1)/2 kernel pairs, 25 FP64 flop per pair
-    # (16 FP64 instructions, 9 of them FMA: counted in the ISA of the inner loop).
-    pairs = N * (N - 1) / 2
-    lcv_flop = diag["lcv_evals"] * pairs * 25.0
-    prep_s = (tim["nbp_prep_kernel"][0] + tim["nbp_bandwidth_kernel"][0]) * 1e-3
-    out["roofline_valu"] = {"bound": "fp64_valu", "kernel": "nbp_prep_kernel", "unit": "TFLOP/s", "peak": 78.6,
-                            "achieved": lcv_flop / prep_s / 1e12 if prep_s > 0 else 0.0,
-                            "frac": lcv_flop / prep_s / 1e12 / 78.6 if prep_s > 0 else 0.0,
-                            "lcv_evals_per_step": diag["lcv_evals"] / a.steps,
-                            "residual_evals_per_step": diag["residual_evals"] / a.steps,
-                            "nonconverged_solves": diag["nonconverged"], "nan_results": diag["nan_results"]}
-    if rank == 0 and not a.no_cpu_baseline and world == 1:
-        # the OpenMP port parallelises over the independent ops of a stage; with hundreds of threads
-        # it is oversubscribed (measured on the MI355X host: 32 threads is the sweet spot), so the
-        # baseline is the best of a few thread counts and `cores` is the count actually used
+        # solveTree! runs initAll! first when graphinit = true (SolverAPI.jl:368-377): the end-to-end rate of one solve
+        out["value_incl_graph_init"] = msgs_total / (dt / a.steps + tb + hs["graph_init_s"])
+    if prof is not None:
+        tim, diag, tprof = prof
+        per_step = {k: v[0] / psteps for k, v in tim.items()}
+        dominant = max(per_step, key=per_step.get)
+        launches = tim[dominant][1] / psteps
+        avg_ms = tim[dominant][0] / max(tim[dominant][1], 1)
+        # algorithmic bytes = B_upd of every variable update (this rank's), all of it charged to the
+        # launches of the dominant kernel: B_upd x (updates per launch) / (average launch duration of that kernel)
+        alg_rank = float(sum(st["alg_bytes"].values()))
+        bytes_per_launch = alg_rank / max(launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if world == 1 and a.config == "2" and size == 1000 and N == 200 and os.path.exists(pmc):
+            try:
+                k = json.load(open(pmc))["kernels"][dominant]
+                traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json"
+            except Exception:  # noqa: BLE001
+                pass
+        kern_s = sum(per_step.values()) * 1e-3
+        pairs = N * (N - 1) / 2
+        lcv_flop = diag["lcv_evals"] * pairs * 25.0
+        prep_s = (tim["nbp_prep_kernel"][0] + tim["nbp_bandwidth_kernel"][0]) * 1e-3
+        valu = lcv_flop / prep_s / 1e12 if prep_s > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            "traffic": traffic, "traffic_source": traffic_src, "peak_source": peak_src,
+            "alg_bytes_per_launch": bytes_per_launch, "alg_bytes_per_step": alg_rank, "avg_launch_ms": avg_ms,
+            "launches_per_step": launches, "whole_solve_GBps": alg_rank / (dt / a.steps) / 1e9,
+            "kernel_ms_per_step": per_step, "profiling_pass_ms_per_step": tprof / psteps * 1e3,
+            "within_2x_of_a_ceiling": "neither" if (achieved / peak < 0.5 and valu / FP64_VALU_PEAK_TFLOPS < 0.5) else
+                                      ("hbm" if achieved / peak >= 0.5 else "fp64_valu"),
+            "note": "SURVEY 8(d) formula: B_upd of every update of the step charged to the launches of the dominant kernel.  HBM is "
+                    "the roofline the north star names; the path is FP64-VALU / latency bound by construction (~13 KB algorithmic "
+                    "bytes per variable update against ~1e6 FP64 kernel pairs): see roofline_valu"}
+        # secondary, honest roofline: FP64 vector rate of the leave-one-out likelihood evaluations, which dominate
+        # nbp_prep_kernel.  One LCV evaluation = N(N-1)/2 kernel pairs, 25 FP64 flop per pair (16 FP64 instructions, 9 of
+        # them FMA: counted in the ISA of the inner loop).
+        out["roofline_valu"] = {"bound": "fp64_valu", "kernel": "nbp_prep_kernel", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
+                                "achieved": valu, "frac": valu / FP64_VALU_PEAK_TFLOPS,
+                                "lcv_evals_per_step": diag["lcv_evals"] / psteps, "residual_evals_per_step": diag["residual_evals"] / psteps,
+                                "nonconverged_solves": diag["nonconverged"], "nan_results": diag["nan_results"]}
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": None, "peak": peak, "unit": "GB/s", "frac": None, "traffic": None,
+                           "peak_source": peak_src}
+    if rank == 0 and not a.no_cpu_baseline and world == 1 and dist is None:
+        # the OpenMP port parallelises over the independent ops of a stage; with hundreds of threads it is oversubscribed
+        # (measured on the MI355X host: 16-32 threads is the sweet spot), so the baseline is the best of a few thread counts
+        # and `cores` is the count actually used
         ncpu = os.cpu_count() or 1
         best = None
         for threads in sorted({min(ncpu, t) for t in (16, 32, 64)}):
-            v, secs, m = cpu_baseline(iif, a.cpu_sample_vars, N, threads)
+            v, secs, m = cpu_baseline(iif, a.cpu_sample_vars, 200, threads)
             if best is None or v > best[0]:
                 best = (v, secs, m, threads)
         v, secs, m, threads = best
         out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port",
-                               "sample": f"{a.cpu_sample_vars}-variable chain of the same shape, N={N}, one full "
-                                         f"up+down solve ({m} messages) in {secs:.1f} s, OpenMP over stage ops, "
-                                         f"best of 16/32/64 threads on a {ncpu}-thread host"}
+                               "sample": f"config-2 chain shape with {a.cpu_sample_vars} variables, N=200, one full up+down solve "
+                                         f"({m} messages) in {secs:.1f} s, OpenMP over stage ops, best of 16/32/64 threads on a "
+                                         f"{ncpu}-thread host; the restatement baseline, not the Julia package (no Julia on the box)"}
         # also the single-thread rate of the same restatement (smaller sample: it is slow)
-        v1, secs1, m1 = cpu_baseline(iif, max(40, a.cpu_sample_vars // 10), N, 1)
+        v1, secs1, m1 = cpu_baseline(iif, max(40, a.cpu_sample_vars // 10), 200, 1)
         out["cpu_baseline"]["single_thread"] = {"value": v1, "unit": "messages/s", "cores": 1,
                                                 "sample": f"{max(40, a.cpu_sample_vars // 10)}-variable chain, {m1} messages in {secs1:.1f} s"}
-        out["vs_cpu_baseline"] = value / v
-    if world == 1 and dist is None and not a.no_10k and a.nvars != 10000:
-        # BASELINE.md config 2': the same chain with 10 000 variables is the graph the north-star target
-        # (>= 20x the CPU baseline) is stated on; measured the same way, reported beside the headline value
-        if hasattr(rs, "prog"):
-            rs.prog.close()
-        rs.be.close()
-        rs10 = RankSolve(iif, 10000, N, 0, 1, local, None, python_host=a.python_host)
+        if a.config in ("2", "2p"):
+            out["vs_cpu_baseline"] = value / v
+    if world == 1 and dist is None and not a.no_10k and a.config == "2":
+        # BASELINE.md config 2': the same chain with 10 000 variables is the graph the north-star target (>= 20x the CPU
+        # baseline) is stated on; measured the same way (same --steps / --warmup), reported beside the headline value
+        rs.close()
+        rs10 = RankSolve(iif, workloads(iif)["2p"], 10000, N, 0, 1, local, None, python_host=a.python_host)
         rs10.prepare()
-        rs10.step(999)
-        rs10.be.synchronize()
-        t0 = time.perf_counter()
-        for k in range(3):
-            rs10.step(k)
-        rs10.be.synchronize()
-        dt10 = (time.perf_counter() - t0) / 3
+        dt10 = timed_steps(rs10, a.steps, a.warmup, lambda: rs10.be.synchronize()) / a.steps
         rs10.check_posteriors()
         out["north_star_10k"] = {"workload": f"ContinuousEuclid(2) 10000-variable chain, N={N}", "value": rs10.global_messages / dt10,
                                  "unit": "messages/s", "ms_per_step": dt10 * 1e3, "messages_per_step": rs10.global_messages,
-                                 "steps": 3, "posterior_max_mean_err": rs10.posterior_max_mean_err,
+                                 "steps": a.steps, "warmup": a.warmup, "posterior_max_mean_err": rs10.posterior_max_mean_err,
+                                 "graph_init_s": rs10.host_setup["graph_init_s"],
                                  "vs_cpu_baseline": (rs10.global_messages / dt10) / out["cpu_baseline"]["value"]
                                  if "cpu_baseline" in out else None, "target_vs_cpu_baseline": 20.0}
+        rs10.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

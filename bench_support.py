@@ -1,51 +1,104 @@
-"""Per-rank solve object used by bench.py (single GPU now; sharded multi-GPU in dist_solver)."""
+"""Workloads of bench.py (the BASELINE.json configurations) and the per-rank solve object.
+
+One rank: ordering, Bayes tree, Gibbs schedules and stage descriptors come from the native C++ host
+(include/nbp_host.h).  Several ranks: the cliques are sharded (dist_solver.ShardedTreeSolve) and every rank compiles
+its share.  Weak scaling: the graph grows with the number of ranks (`scale` = per-GPU size x world)."""
+import time
+
 import numpy as np
 
 
+def _wrapdiff(a, b):
+    return (a - b + np.pi) % (2 * np.pi) - np.pi
+
+
+class Workload:
+    def __init__(self, key, name, N, size, build, truth, tol, unit_name):
+        self.key, self.name, self.N, self.size, self.build, self.truth, self.tol, self.unit_name = key, name, N, size, build, truth, tol, unit_name
+
+
+def workloads(iif):
+    """config key -> Workload.  `size` = the per-GPU size parameter at BASELINE scale; build(size_total, N) -> graph;
+    truth(label, size_total) -> expected posterior location of a pose (tangent coordinates) or None; tol = largest accepted
+    |posterior mean - truth| of the sampled poses (Monte-Carlo error of the NBP posterior included)."""
+    def chain2(n, N):
+        return iif.generateChainEuclid(n, vardims=2, priorEvery=100, N=N)
+
+    def doors(n, N):
+        return iif.generateCircularDoors(nposes=n, N=N, sightEvery=25)
+
+    def lattice(rows, N):
+        return iif.generateSE2Lattice(rows=rows, cols=100, N=N, closeEvery=5)
+
+    def mixture(n, N):
+        return iif.generateMixtureChain(nvars=n, N=N, priorEvery=500)
+
+    def truth_chain(v, n):
+        return np.array([float(v[1:])] * 2) if v.startswith("x") else None
+
+    def truth_lattice(v, rows):
+        k = int(v[1:])
+        r, c = divmod(k, 100)
+        c = c if r % 2 == 0 else 99 - c
+        return np.array([float(c), float(r)])  # translation only
+
+    def truth_mix(v, n):
+        return np.array([float(v[1:]), 0.0, 0.0])
+
+    return {
+        "2": Workload("2", "config 2: ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 1000, chain2, truth_chain, 1.0, "variables"),
+        "2p": Workload("2p", "config 2' (north-star target): ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 10000, chain2, truth_chain, 1.0, "variables"),
+        "3": Workload("3", "config 3: Circular {size}-pose chain, 4 door landmarks, multihypo sightings every 25 poses", 200, 2000, doors, None, None, "poses"),
+        "4": Workload("4", "config 4: SE(2) {size}x100 boustrophedon lattice with loop closures every 5th column", 200, 50, lattice, truth_lattice, 3.5, "rows"),
+        "5": Workload("5", "config 5: ContinuousEuclid(3) {size}-variable chain of Mixture(LinearRelative, [0.8, 0.2]) factors, priors every 500", 300, 10000, mixture, truth_mix, 2.5, "variables"),
+    }
+
+
 class RankSolve:
-    def __init__(self, iif, nvars, N, rank, world, local, dist, python_host=False):
-        self.python_host = python_host
-        self.iif, self.nvars, self.N = iif, nvars, N
+    def __init__(self, iif, wl, size, N, rank, world, local, dist, python_host=False):
+        self.iif, self.wl, self.size, self.N = iif, wl, size, N
         self.rank, self.world, self.local, self.dist = rank, world, local, dist
+        self.python_host = python_host
+        self.size_total = size * world
 
     def prepare(self):
         iif = self.iif
         self.sharded = self.world > 1 or self.dist is not None
+        t0 = time.perf_counter()
+        fg = self.wl.build(self.size_total, self.N)
+        self.fg = fg
+        t_graph = time.perf_counter() - t0
+        mk = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints, device=self.local)
         if self.sharded:
             from iif_amd.dist_solver import ShardedTreeSolve
-            self.impl = ShardedTreeSolve(iif, self.nvars * self.world, self.N, self.rank, self.world, self.local, self.dist)
+            self.impl = ShardedTreeSolve(iif, fg, self.N, self.rank, self.world, self.local, self.dist)
             self.impl.prepare()
-            self.be = self.impl.be
-            self.global_messages = self.impl.global_messages
-            self.stats = self.impl.stats
+            self.be, self.main = self.impl.be, self.impl.tp.main
+            self.global_messages, self.stats = self.impl.global_messages, self.impl.stats
+            self.host_setup = self.impl.host_setup
+            self.mine = self.impl.mine
             return
-        import time
-        t0 = time.perf_counter()
-        fg = iif.generateChainEuclid(self.nvars, vardims=2, priorEvery=100, N=self.N)
-        t1 = time.perf_counter()
-        mk = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints, device=self.local)
-        self.fg = fg
         if self.python_host:
+            t1 = time.perf_counter()
             order = iif.nestedDissectionOrder(fg)
             t2 = time.perf_counter()
             tree = iif.buildTreeReset(fg, order)
             t3 = time.perf_counter()
             iif.initAll(fg, backend=mk, seed=0)
-            t4 = time.perf_counter()
+            t_init = time.perf_counter() - t3
+            ta = time.perf_counter()
             tp = iif.TreeProgram(fg, tree, seed=1, snapshot=True)
             self.be = mk(self.N, tp.n_slots)
             self.prog = self.be.program(tp.stages, lazy_bandwidth=True)
-            t5 = time.perf_counter()
+            t_comp = time.perf_counter() - ta
             self.main, snap, st = tp.main, tp.snap, tp.stats()
-            self.global_messages = tp.n_messages
             alg = tp.alg_bytes_by_kernel()
             mirror = 0.0
         else:
-            # native host (include/nbp_host.h): ordering, Bayes tree, Gibbs schedules and the stage
-            # descriptors are built in C++; Python only mirrors the graph into it
             from iif_amd import native_host
+            ti = time.perf_counter()
             iif.initAll(fg, backend=mk, seed=0)
-            t_init = time.perf_counter() - t1
+            t_init = time.perf_counter() - ti
             tm = time.perf_counter()
             g = native_host.NativeGraph.from_fg(fg)
             mirror = time.perf_counter() - tm
@@ -54,26 +107,25 @@ class RankSolve:
             t2 = time.perf_counter()
             nt = g.build_tree(order)
             t3 = time.perf_counter()
-            t4 = t3 + t_init  # keeps graph_init_s = t4 - t3 below
             n_slots = nt.plan_slots(True)
             self.be = mk(self.N, n_slots)
-            ta = time.perf_counter()
             self.prog = nt.compile(self.be, 1)
-            t5 = t4 + (time.perf_counter() - ta) + (ta - t3)
+            t_comp = time.perf_counter() - t3
             self.main, snap, st = nt.main, nt.snap, nt.stats()
-            self.global_messages = st["messages"]
             st["cliques"] = nt.n_cliques
             alg = {"nbp_proposal_kernel": st["alg_bytes_proposal"], "nbp_prep_kernel": st["alg_bytes_prep"],
                    "nbp_product_kernel": st["alg_bytes_product"], "nbp_bandwidth_kernel": 0}
             self._native = (g, nt)
-        # host-side setup, outside the timed region; BASELINE.md 3 asks for the rate with and without the tree build
-        self.host_setup = {"host": "python" if self.python_host else "native C++ (nbp_host.h)", "graph_s": (t1 - t0) if self.python_host else None,
+        self.host_setup = {"host": "python mirror" if self.python_host else "native C++ (nbp_host.h)", "graph_s": t_graph,
                            "graph_mirror_s": mirror, "elimination_order_s": t2 - t1, "tree_build_s": t3 - t2,
-                           "graph_init_s": t4 - t3, "schedule_compile_s": t5 - t4}
+                           "graph_init_s": t_init, "schedule_compile_s": t_comp}
         for v in fg.ls():
             var = fg.getVariable(v)
             self.be.slot_write(snap[v], var.varType.manifold, var.val, var.bw)
-        self.stats = {"cliques_global": st["cliques"], "updates_global": st["updates_up"] + st["updates_down"], "alg_bytes": alg}
+        self.global_messages = st["messages"]
+        self.stats = {"cliques_global": st["cliques"], "updates_global": st["updates_up"] + st["updates_down"],
+                      "alg_bytes": alg, "alg_bytes_total": st["alg_bytes"]}
+        self.mine = list(fg.ls())
 
     def step(self, k):
         if self.sharded:
@@ -82,18 +134,31 @@ class RankSolve:
         self.prog.run()
 
     def check_posteriors(self):
-        """posteriors within the BASELINE.md tolerance of the ground truth x_i = (i, i)"""
+        """posterior means of a sample of this rank's poses against the ground truth of the synthetic graph; every
+        belief finite.  Config 3 is multi-modal by construction: the share of particles at the true pose is reported."""
+        fg, wl = self.fg, self.wl
+        poses = [v for v in self.mine if v.startswith("x")]
+        sample = poses[:: max(1, len(poses) // 64)]
+        worst, shares = 0.0, []
+        for v in sample:
+            man = fg.getVariable(v).varType.manifold
+            pts, bw = self.be.slot_read(self.main[v], man)
+            if not (np.isfinite(pts).all() and np.isfinite(bw).all() and (bw > 0).all()):
+                raise RuntimeError(f"{v}: non-finite posterior")
+            if wl.truth is not None:
+                t = wl.truth(v, self.size_total)
+                worst = max(worst, float(np.abs(pts[:, :len(t)].mean(axis=0) - t).max()))
+            else:
+                step = 2 * np.pi / 50
+                shares.append(float((np.abs(_wrapdiff(pts[:, 0], int(v[1:]) * step)) < 0.35).mean()))
+        self.posterior_max_mean_err = worst if wl.truth is not None else None
+        self.posterior_mode_share = (float(np.min(shares)), float(np.median(shares))) if shares else None
+        if wl.truth is not None and not worst < wl.tol:
+            raise RuntimeError(f"posterior means off by {worst} (tolerance {wl.tol}): result invalid")
+
+    def close(self):
         if self.sharded:
-            self.impl.check_posteriors()
-            self.posterior_max_mean_err = self.impl.posterior_max_mean_err
+            self.impl.close()
             return
-        fg = self.fg
-        worst = 0.0
-        for i in range(0, self.nvars, max(1, self.nvars // 64)):
-            pts, _ = self.be.slot_read(self.main[f"x{i}"], fg.getVariable(f"x{i}").varType.manifold)
-            worst = max(worst, float(np.abs(pts.mean(axis=0) - i).max()))
-        self.posterior_max_mean_err = worst
-        # NBP posteriors carry Monte-Carlo error of a fraction of the posterior sigma (~0.5-0.7 midway
-        # between priors; observed worst mean error ~0.3); the CPU oracle shows the same level
-        if not worst < 1.0:
-            raise RuntimeError(f"posterior means off by {worst}: result invalid")
+        self.prog.close()
+        self.be.close()

@@ -253,8 +253,11 @@ nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *de
  * product taking it as input, slot copies; an EMPTY copy stage counts as "everything is read").  The
  * reference fits a bandwidth on every setBelief! (FactorGraph.jl:250-263), but inside a clique's Gibbs
  * sweeps only the last one of each variable is ever looked at, so no result changes.  With the option
- * on, the bandwidth of such an intermediate belief is undefined between stages. */
-enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1 };
+ * on, the bandwidth of such an intermediate belief is undefined between stages.
+ * NBP_OPT_GRAPH_REPLAY (default 1): nbp_program_run captures the launch sequence of a stage range into a hipGraph the
+ * second time it runs and replays the graph afterwards (one submission instead of ~3 launches per variable update).
+ * Ignored while per-kernel timing is enabled. */
+enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2 };
 nbp_status nbp_program_set_option(nbp_program *prog, int32_t option, int32_t value);
 nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
 nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);

@@ -14,6 +14,7 @@ EUCLID1, EUCLID2, EUCLID3, CIRCULAR, SE2 = 1, 2, 3, 4, 5
 F_PRIOR, F_MSGPRIOR, F_LINREL, F_CIRCULAR, F_SE2, F_EUCLIDDIST = 1, 2, 3, 4, 5, 6
 STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES, STAGE_DECONV, STAGE_COPY_POINTS = 1, 2, 3, 4, 5
 OPT_LAZY_BANDWIDTH = 1
+OPT_GRAPH_REPLAY = 2
 
 MANIFOLD_DIM = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 3}
 MANIFOLD_P = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 6}

@@ -498,6 +498,20 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   return toc(c, c->ev[2]);
 }
 
+// the allocations launch_prep / launch_products would make on demand for a batch of n products
+static nbp_status presize_products(nbp_ctx *c, int n, int maxFD) {
+  nbp_status rc = ensure_ws(c, n, maxFD / 4);
+  if (rc) return rc;
+  int HL, wpb, G;
+  product_geometry(c, n, &HL, &wpb, &G);
+  const int F = maxFD / 4, D = maxFD % 4;
+  if (nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) {
+    if (HL != 8) product_geometry(c, 16, &HL, &wpb, &G);
+    rc = ensure_gstats(c, (size_t)n * G * 3 * (size_t)F * D * c->N);
+  }
+  return rc;
+}
+
 static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const int32_t *dev_manis, int n) {
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev[3]);
@@ -789,6 +803,7 @@ struct nbp_stage {
   std::vector<int32_t> ent_s, ent_m;  // fits pending at ENTRY of the stage
   size_t ent_off = 0;
   bool flush_before = false;    // run the pending fits in a plain bandwidth launch before the stage
+  bool need_prep = true;        // products: some product multiplies > 1 densities (KD builds; the entry fits run beside them)
 };
 struct nbp_program {
   nbp_ctx *ctx = nullptr;
@@ -797,7 +812,11 @@ struct nbp_program {
   char *dev = nullptr;
   bool finalized = false;
   bool lazy_bw = false;  // NBP_OPT_LAZY_BANDWIDTH
+  bool use_graph = true; // NBP_OPT_GRAPH_REPLAY
   int n_user_stages = 0;
+  // captured launch sequences of nbp_program_run(first, last): key = first * 2^32 + last
+  std::unordered_map<uint64_t, hipGraphExec_t> graphs;
+  std::unordered_map<uint64_t, int> runs;
   size_t seed_off = 0;  // table of the blob offsets of every descriptor's seed field (one reseed launch)
   int n_seeds = 0;
 };
@@ -812,6 +831,8 @@ nbp_status nbp_program_create(nbp_ctx *c, nbp_program **out) {
 }
 // the context is going away: free the device blob while the context's device is still current
 static void program_detach(nbp_program *p) {
+  for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second);
+  p->graphs.clear();
   if (p->dev) hipFree(p->dev);
   p->dev = nullptr;
   p->ctx = nullptr;
@@ -851,6 +872,7 @@ nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value)
   if (!p) return fail(NBP_ERR_ARG, "null argument");
   if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
   if (option == NBP_OPT_LAZY_BANDWIDTH) { p->lazy_bw = value != 0; return NBP_OK; }
+  if (option == NBP_OPT_GRAPH_REPLAY) { p->use_graph = value != 0; return NBP_OK; }
   return fail(NBP_ERR_ARG, "unknown program option");
 }
 
@@ -974,7 +996,25 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       } else
         jobs_of_proposals((const nbp_proposal_desc *)d, st.n, pend_s, pend_m);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
-      pend_s.clear(); pend_m.clear();  // the entry fits run inside this stage's prep launch
+      const nbp_product_desc *qd0 = (const nbp_product_desc *)d;
+      st.need_prep = false;
+      for (int i = 0; i < st.n; i++) st.need_prep |= qd0[i].nfactors > 1;
+      if (st.need_prep) {
+        pend_s.clear(); pend_m.clear();  // the entry fits run inside this stage's prep launch
+      } else {
+        // Only pass-through products (AMP returns the single density): nothing here reads a bandwidth, so nothing is
+        // launched for the fits.  A pending fit of a density that is handed on moves with it -- same points, same
+        // bandwidth, fitted in the output slot when the next launch with fits comes along (graph initialisation of a
+        // chain: one proposal + one copy per variable on the critical path, all the fits in one launch at the end).
+        for (int i = 0; i < st.n; i++)
+          for (size_t q = 0; q < pend_s.size(); q++)
+            if (pend_s[q] == qd0[i].in_slot[0]) pend_s[q] = qd0[i].out_slot;
+        // (an output slot whose OLD points still had a fit queued: that fit would now see the new points -- which is what
+        //  the reference's setBelief! does anyway: manikde! of the points it stores)
+        for (size_t q = 0; q < pend_s.size(); q++)  // one fit per slot
+          for (size_t r = q + 1; r < pend_s.size(); r++)
+            if (pend_s[r] == pend_s[q]) { pend_s.erase(pend_s.begin() + r); pend_m.erase(pend_m.begin() + r); r--; }
+      }
       if (p->lazy_bw) {
         const nbp_product_desc *qd = (const nbp_product_desc *)d;
         for (int i = 0; i < st.n; i++)
@@ -1032,7 +1072,13 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     p->blob.resize(p->seed_off + so.size() * 8);
     if (!so.empty()) memcpy(p->blob.data() + p->seed_off, so.data(), so.size() * 8);
   }
-  nbp_status rc = NBP_OK;  // workspaces grow on demand in launch_prep / launch_products
+  // size the workspaces now: nothing may allocate once a launch sequence is being captured
+  nbp_status rc = NBP_OK;
+  for (const nbp_stage &st : p->stages)
+    if (st.kind == NBP_STAGE_PRODUCTS && st.n > 0) {
+      rc = presize_products(p->ctx, st.n, st.maxfd);
+      if (rc) return rc;
+    }
   size_t bytes = p->blob.size() ? p->blob.size() : 64;
   HIPCHK(hipMalloc(&p->dev, bytes));
   if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
@@ -1040,15 +1086,8 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   return NBP_OK;
 }
 
-nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
-  if (!p) return fail(NBP_ERR_ARG, "null argument");
-  PROG_ALIVE(p);
-  if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+static nbp_status run_range(nbp_program *p, int first, int last) {
   nbp_ctx *c = p->ctx;
-  HIPCHK(hipSetDevice(c->device));
-  const int nuser = p->n_user_stages;
-  if (last < 0 || last > nuser) last = nuser;
-  if (first < 0) first = 0;
   auto ent_s = [&](const nbp_stage &st) { return (const int32_t *)(p->dev + st.ent_off); };
   for (int s = first; s < last; s++) {
     const nbp_stage &st = p->stages[s];
@@ -1060,7 +1099,7 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
-      rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);
+      if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd);
     } else if (st.kind == NBP_STAGE_DECONV) {
       rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);
@@ -1074,6 +1113,47 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   // leave every slot consistent: run whatever is still pending at the end of the range
   const nbp_stage &nx = p->stages[last];
   return launch_bandwidth(c, ent_s(nx), ent_s(nx) + nx.ent_s.size(), (int)nx.ent_s.size());
+}
+
+nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
+  if (!p) return fail(NBP_ERR_ARG, "null argument");
+  PROG_ALIVE(p);
+  if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+  nbp_ctx *c = p->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int nuser = p->n_user_stages;
+  if (last < 0 || last > nuser) last = nuser;
+  if (first < 0) first = 0;
+  // Replay: the launch sequence of a range is captured into a hipGraph the second time it runs and launched as one
+  // graph from then on (the descriptors live in device memory, so nbp_program_reseed still takes effect).  Per-kernel
+  // event timing (nbp_timing_enable) and programs of a handful of launches take the plain path.
+  if (c->timing || !p->use_graph || last - first < 4) return run_range(p, first, last);
+  const uint64_t key = ((uint64_t)(uint32_t)first << 32) | (uint32_t)last;
+  auto it = p->graphs.find(key);
+  if (it == p->graphs.end() && p->runs[key]++ == 0) return run_range(p, first, last);  // a program that runs once never pays for a capture
+  if (it == p->graphs.end()) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    nbp_status rc = run_range(p, first, last);
+    hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) {  // capture is not available: run directly from now on
+      (void)hipGetLastError();
+      p->use_graph = false;
+      return run_range(p, first, last);
+    }
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      p->use_graph = false;
+      return run_range(p, first, last);
+    }
+    it = p->graphs.emplace(key, ge).first;
+  }
+  HIPCHK(hipGraphLaunch(it->second, c->stream));
+  return NBP_OK;
   // asynchronous: nbp_synchronize / nbp_slot_read wait for completion
 }
 
@@ -1102,6 +1182,7 @@ nbp_status nbp_program_destroy(nbp_program *p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     if (p->dev) hipFree(p->dev);
+    for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second);
     auto &v = p->ctx->programs;
     for (size_t i = 0; i < v.size(); i++)
       if (v[i] == p) { v.erase(v.begin() + i); break; }

@@ -57,15 +57,17 @@ def test_torch_owned_arena_sharded_path_single_rank(hip_backend):
     import torch
     from iif_amd.dist_solver import ShardedTreeSolve
 
-    s = ShardedTreeSolve(iif, 60, 100, rank=0, world=1, local=0, dist=None)
+    fg = iif.generateChainEuclid(60, vardims=2, priorEvery=100, N=100)
+    s = ShardedTreeSolve(iif, fg, 100, rank=0, world=1, local=0, dist=None)
     s.prepare()
     s.step(0)
     s.be.synchronize()
-    s.check_posteriors()
-    assert s.posterior_max_mean_err < 1.0
+    worst = max(float(np.abs(s.be.slot_read(s.tp.main[v], abi.EUCLID2)[0].mean(axis=0) - int(v[1:])).max()) for v in s.mine[::4])
+    assert worst < 1.0
     assert s.global_messages == 2 * (len(s.tree.cliques) - len(s.tree.roots))
     assert s.arena.data_ptr() == s.be.arena_ptr()
     torch.cuda.synchronize()
+    s.close()
 
 
 @pytest.mark.parametrize("builder", ["euclid2", "se2", "circular"])
