@@ -44,10 +44,11 @@ def test_against_exact_gaussian():
     assert 0.3 < far < 0.6, far  # closed form 0.5
 
 
-def test_oracle_solves_with_different_seeds_stay_under_the_kl_bound(oracle_backend):
-    """two oracle solves of the config-1 chain with independent streams: median symmetric KL per variable well under
-    0.05 nats; the largest is the Monte-Carlo spread of the NBP posterior itself (posterior means move by a fraction of
-    sigma from seed to seed)"""
+def test_independent_solves_differ_by_far_more_than_the_bound(oracle_backend):
+    """Why the 0.05-nat figure is a common-random-numbers figure: two oracle solves of the config-1 chain with
+    INDEPENDENT streams read 0.5-1.9 nats per variable (the posteriors of this algorithm are narrower than the
+    spread of their means from seed to seed -- sigma 0.3-0.4 against mean offsets of +-0.3), while the same seed gives
+    the same particles.  tests/kl_parity.py builds the whole-solve criterion on exactly this."""
     def chain():
         fg = iif.initfg(iif.SolverParams(N=100))
         for i in range(6):
@@ -56,11 +57,10 @@ def test_oracle_solves_with_different_seeds_stay_under_the_kl_bound(oracle_backe
         for i in range(5):
             iif.addFactor(fg, [f"x{i}", f"x{i+1}"], iif.LinearRelative(iif.Normal(1.0, 0.1)))
         return fg
-    fa, fb = chain(), chain()
+    fa, fb, fc = chain(), chain(), chain()
     iif.solveTree(fa, backend=oracle_backend, seed=11)
     iif.solveTree(fb, backend=oracle_backend, seed=12)
-    kl = kl_tools.kl_table(abi, fa, fb)
-    assert np.median(list(kl.values())) < 0.05, kl
-    fc = chain()
     iif.solveTree(fc, backend=oracle_backend, seed=11)
     assert max(kl_tools.kl_table(abi, fa, fc).values()) < 1e-12  # same seed: the same particles
+    kl = kl_tools.kl_table(abi, fa, fb)
+    assert np.median(list(kl.values())) > 0.05, kl
