@@ -49,8 +49,8 @@ def workloads(iif):
         "2": Workload("2", "config 2: ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 1000, chain2, truth_chain, 1.0, "variables"),
         "2p": Workload("2p", "config 2' (north-star target): ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 10000, chain2, truth_chain, 1.0, "variables"),
         "3": Workload("3", "config 3: Circular {size}-pose chain, 4 door landmarks, multihypo sightings every 25 poses", 200, 2000, doors, None, None, "poses"),
-        "4": Workload("4", "config 4: SE(2) {size}x100 boustrophedon lattice with loop closures every 5th column", 200, 50, lattice, truth_lattice, 3.5, "rows"),
-        "5": Workload("5", "config 5: ContinuousEuclid(3) {size}-variable chain of Mixture(LinearRelative, [0.8, 0.2]) factors, priors every 500", 300, 10000, mixture, truth_mix, 2.5, "variables"),
+        "4": Workload("4", "config 4: SE(2) {size}x100 boustrophedon lattice with loop closures every 5th column", 200, 50, lattice, truth_lattice, 2.0, "rows"),
+        "5": Workload("5", "config 5: ContinuousEuclid(3) {size}-variable chain of Mixture(LinearRelative, [0.8, 0.2]) factors, priors every 500", 300, 10000, mixture, truth_mix, 6.0, "variables"),
     }
 
 
@@ -95,10 +95,9 @@ class RankSolve:
             alg = tp.alg_bytes_by_kernel()
             mirror = 0.0
         else:
+            # everything after the graph itself happens behind the C ABI: graph initialisation (initAll!), ordering, tree,
+            # schedules, descriptors; the beliefs never visit the host between initialisation and solve
             from iif_amd import native_host
-            ti = time.perf_counter()
-            iif.initAll(fg, backend=mk, seed=0)
-            t_init = time.perf_counter() - ti
             tm = time.perf_counter()
             g = native_host.NativeGraph.from_fg(fg)
             mirror = time.perf_counter() - tm
@@ -108,9 +107,22 @@ class RankSolve:
             nt = g.build_tree(order)
             t3 = time.perf_counter()
             n_slots = nt.plan_slots(True)
-            self.be = mk(self.N, n_slots)
+            ti = time.perf_counter()
+            need, _ = g.init_plan(0)
+            self.be = mk(self.N, max(n_slots, need))
+            for i, v in enumerate(fg.ls()):  # a fresh arena is all zeros = N points at the identity, what addVariable! leaves
+                var = fg.getVariable(v)
+                if np.any(var.val[:, :var.varType.dim] if var.varType.manifold != iif.abi.SE2 else var.val[:, :2]) or var.initialized:
+                    self.be.slot_write(i, var.varType.manifold, var.val, var.bw)
+            iprog = g.init_compile(self.be)   # also marks the planned variables initialised for the tree compile
+            iprog.run()
+            self.be.synchronize()
+            iprog.close()
+            self.be.run_copies([iif.abi.CopyDesc(nt.main[v], nt.snap[v]) for v in fg.ls()])
+            t_init = time.perf_counter() - ti
+            tc = time.perf_counter()
             self.prog = nt.compile(self.be, 1)
-            t_comp = time.perf_counter() - t3
+            t_comp = time.perf_counter() - tc
             self.main, snap, st = nt.main, nt.snap, nt.stats()
             st["cliques"] = nt.n_cliques
             alg = {"nbp_proposal_kernel": st["alg_bytes_proposal"], "nbp_prep_kernel": st["alg_bytes_prep"],
@@ -119,9 +131,10 @@ class RankSolve:
         self.host_setup = {"host": "python mirror" if self.python_host else "native C++ (nbp_host.h)", "graph_s": t_graph,
                            "graph_mirror_s": mirror, "elimination_order_s": t2 - t1, "tree_build_s": t3 - t2,
                            "graph_init_s": t_init, "schedule_compile_s": t_comp}
-        for v in fg.ls():
-            var = fg.getVariable(v)
-            self.be.slot_write(snap[v], var.varType.manifold, var.val, var.bw)
+        if self.python_host:
+            for v in fg.ls():
+                var = fg.getVariable(v)
+                self.be.slot_write(snap[v], var.varType.manifold, var.val, var.bw)
         self.global_messages = st["messages"]
         self.stats = {"cliques_global": st["cliques"], "updates_global": st["updates_up"] + st["updates_down"],
                       "alg_bytes": alg, "alg_bytes_total": st["alg_bytes"]}

@@ -23,16 +23,20 @@ def load(d):
 
 def per_kernel(rows, counter, steps, lps=60):
     by = collections.defaultdict(list)
+    rows = [r for r in rows if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    # the timed region starts at the `steps`-th last nbp_reseed_kernel dispatch (one per step)
+    rs_ = [int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"].startswith("nbp_reseed_kernel")]
+    d0 = rs_[-steps] if len(rs_) >= steps else 0
     for r in rows:
-        if r["Counter_Name"] != counter:
+        if int(r["Dispatch_Id"]) < d0 and not r["Kernel_Name"].startswith("nbp_copy_kernel"):
             continue
         name = r["Kernel_Name"].split("(")[0]
         if name.startswith("nbp_"):
             by[name].append((float(r["Counter_Value"]), int(r["Grid_Size"]) // int(r["Workgroup_Size"])))
     out = {}
     for k, v in by.items():
-        tail = v if k in ("nbp_copy_kernel", "nbp_reseed_kernel") else v[-steps * lps:]
-        out[k] = tail
+        out[k] = v
     return out
 
 

@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace CSV for the TIMED region of bench.py: the last
-`steps` x launches_per_step dispatches of each libnbp kernel (earlier dispatches belong to graph
-initialisation and warm-up).  Usage: summarize_trace.py <kernel_trace.csv> <steps> [launches_per_step]"""
+`steps` steps, delimited by the nbp_reseed_kernel launch that starts every step (earlier dispatches belong to
+graph initialisation and warm-up).  Usage: summarize_trace.py <kernel_trace.csv> <steps> [launches_per_step]"""
 import csv
 import collections
 import sys
@@ -8,6 +8,16 @@ import sys
 
 def main(path, steps, lps=60):
     rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # every step of bench.py starts with one nbp_reseed_kernel launch: the timed region begins at the `steps`-th from last
+    rs_ = [int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"].startswith("nbp_reseed_kernel")]
+    t_begin = rs_[-steps] if len(rs_) >= steps else 0
+    region = [r for r in rows if int(r["Start_Timestamp"]) >= t_begin]
+    if region:
+        span = (max(int(r["End_Timestamp"]) for r in region) - t_begin) / 1e6
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in region) / 1e6
+        print(f"timed region (from the {steps}-th last reseed launch): {span / steps:.2f} ms per step wall, {busy / steps:.2f} ms per step inside kernels, {len(region) / steps:.0f} launches per step")
+    rows = region
     by = collections.defaultdict(list)
     for r in rows:
         name = r["Kernel_Name"].split("(")[0]
@@ -18,10 +28,7 @@ def main(path, steps, lps=60):
     print(f"{'kernel':34s} {'launches':>8s} {'avg_us':>10s} {'total_ms':>9s} | avg_us by grid size (blocks): <=8, <=64, <=300, >300")
     out = {}
     for name, rs in sorted(by.items()):
-        if name in ("nbp_reseed_kernel", "nbp_copy_kernel", "nbp_copy_points_kernel"):
-            tail = rs
-        else:
-            tail = rs[-steps * lps:]
+        tail = rs
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tail]
         g = [int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) for r in tail]
         buckets = collections.defaultdict(list)
