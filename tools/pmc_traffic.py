@@ -13,12 +13,10 @@ import sys
 
 
 def load(d):
-    fs = glob.glob(f"{d}/*counter_collection.csv*")
-    if not fs:
-        return []
-    f = fs[0]
-    fh = gzip.open(f, "rt") if f.endswith(".gz") else open(f)
-    return list(csv.DictReader(fh))
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from rocpd import counter_rows
+    return counter_rows(d)
 
 
 def per_kernel(rows, counter, steps, lps=60):

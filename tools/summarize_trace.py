@@ -1,13 +1,16 @@
 """Summarise a rocprofv3 --kernel-trace CSV for the TIMED region of bench.py: the last
 `steps` steps, delimited by the nbp_reseed_kernel launch that starts every step (earlier dispatches belong to
 graph initialisation and warm-up).  Usage: summarize_trace.py <kernel_trace.csv> <steps> [launches_per_step]"""
-import csv
 import collections
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main(path, steps, lps=60):
-    rows = list(csv.DictReader(open(path)))
+    from rocpd import kernel_rows
+    rows = kernel_rows(path)
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # every step of bench.py starts with one nbp_reseed_kernel launch: the timed region begins at the `steps`-th from last
     rs_ = [int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"].startswith("nbp_reseed_kernel")]
