@@ -182,6 +182,11 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_l8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_m4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_t2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (const void *k : {(const void *)nbp_product_kernel_t2_e1, (const void *)nbp_product_kernel_t2_e2, (const void *)nbp_product_kernel_t2_e3,
+                        (const void *)nbp_product_kernel_t2_ci, (const void *)nbp_product_kernel_t2_se, (const void *)nbp_product_kernel_m4_e1,
+                        (const void *)nbp_product_kernel_m4_e2, (const void *)nbp_product_kernel_m4_e3, (const void *)nbp_product_kernel_m4_ci,
+                        (const void *)nbp_product_kernel_m4_se})
+    HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
@@ -463,7 +468,44 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
 }
 // LDS budget of a product workgroup: beyond it the node statistics live in global memory ("big")
 static const size_t NBP_PRODUCT_LDS_CAP = 150 * 1024;
-static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD) {
+typedef void (*nbp_product_fn)(const nbp_product_desc *, double *, const double *, int, double *, int, int64_t, int32_t *, nbp_levels);
+// the kernel of a product launch: HL helper lanes per sample; `mani` != 0: every multi-density product of the batch lives
+// on that manifold and has only full inputs (the throughput variants then run the single-instantiation kernels)
+static nbp_product_fn product_kernel_for(int HL, int mani) {
+  if (HL == 16) return nbp_product_kernel_x16;
+  if (HL == 8) return nbp_product_kernel_l8;
+  if (HL == 4) {
+    switch (mani) {
+    case NBP_EUCLID1: return nbp_product_kernel_m4_e1;
+    case NBP_EUCLID2: return nbp_product_kernel_m4_e2;
+    case NBP_EUCLID3: return nbp_product_kernel_m4_e3;
+    case NBP_CIRCULAR: return nbp_product_kernel_m4_ci;
+    case NBP_SE2: return nbp_product_kernel_m4_se;
+    default: return nbp_product_kernel_m4;
+    }
+  }
+  switch (mani) {
+  case NBP_EUCLID1: return nbp_product_kernel_t2_e1;
+  case NBP_EUCLID2: return nbp_product_kernel_t2_e2;
+  case NBP_EUCLID3: return nbp_product_kernel_t2_e3;
+  case NBP_CIRCULAR: return nbp_product_kernel_t2_ci;
+  case NBP_SE2: return nbp_product_kernel_t2_se;
+  default: return nbp_product_kernel_t2;
+  }
+}
+// 0 unless all products with more than one density share a manifold and none has a partial input
+static int products_uniform_manifold(const nbp_product_desc *d, int n) {
+  int mani = -1;
+  for (int i = 0; i < n; i++) {
+    if (d[i].nfactors <= 1) continue;
+    for (int j = 0; j < d[i].nfactors; j++)
+      if (d[i].in_partial[j]) return 0;
+    if (mani == -1) mani = d[i].manifold;
+    else if (mani != d[i].manifold) return 0;
+  }
+  return mani > 0 ? mani : 0;
+}
+static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD, int mani = 0) {
   if (n <= 0) return NBP_OK;
   int HL, wpb, G;
   product_geometry(c, n, &HL, &wpb, &G);
@@ -479,21 +521,14 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   nbp_status rc = NBP_OK;
   double *gs = nullptr;
   if (big) {
-    rc = ensure_gstats(c, (size_t)n * G * 3 * (size_t)F * D * c->N);
+    rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, D, c->N));
     if (rc) return rc;
     gs = c->gstats;
   }
   rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  if (HL == 16)
-    hipLaunchKernelGGL(nbp_product_kernel_x16, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
-  else if (HL == 8)
-    hipLaunchKernelGGL(nbp_product_kernel_l8, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
-  else if (HL == 4)
-    hipLaunchKernelGGL(nbp_product_kernel_m4, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
-  else
-    hipLaunchKernelGGL(nbp_product_kernel_t2, dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
+  hipLaunchKernelGGL(product_kernel_for(HL, mani), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }
@@ -507,7 +542,7 @@ static nbp_status presize_products(nbp_ctx *c, int n, int maxFD) {
   const int F = maxFD / 4, D = maxFD % 4;
   if (nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) {
     if (HL != 8) product_geometry(c, 16, &HL, &wpb, &G);
-    rc = ensure_gstats(c, (size_t)n * G * 3 * (size_t)F * D * c->N);
+    rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, D, c->N));
   }
   return rc;
 }
@@ -621,7 +656,7 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   if (rc) return rc;
   rc = launch_prep(c, nullptr, nullptr, 0, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n));  // KD trees
   if (rc) return rc;
-  rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n));
+  rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n), products_uniform_manifold(descs, n));
   if (rc) return rc;
   rc = launch_bandwidth(c, ds, dm, (int)js.size());  // rebandwidth of the product
   if (rc) return rc;
@@ -798,7 +833,7 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
 // proposal sampling from it, or a copy stage moving whole slots.  Per update the critical path is
 // proposal -> prep (LCV || KD) -> product.
 struct nbp_stage {
-  int kind = 0, n = 0, maxfd = 0;
+  int kind = 0, n = 0, maxfd = 0, mani = 0;  // mani: products_uniform_manifold
   size_t offset = 0;            // byte offset of the descriptors in the program blob
   std::vector<int32_t> ent_s, ent_m;  // fits pending at ENTRY of the stage
   size_t ent_off = 0;
@@ -853,6 +888,7 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
     esz = sizeof(nbp_product_desc);
     rc = check_products(p->ctx, (const nbp_product_desc *)descs, n);
     st.maxfd = products_maxfd((const nbp_product_desc *)descs, n);
+    st.mani = products_uniform_manifold((const nbp_product_desc *)descs, n);
     break;
   case NBP_STAGE_COPIES:
   case NBP_STAGE_COPY_POINTS: esz = sizeof(nbp_copy_desc); rc = check_copies(p->ctx, (const nbp_copy_desc *)descs, n); break;
@@ -1100,7 +1136,7 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
       if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);
-      if (!rc) rc = launch_products(c, dd, st.n, st.maxfd);
+      if (!rc) rc = launch_products(c, dd, st.n, st.maxfd, st.mani);
     } else if (st.kind == NBP_STAGE_DECONV) {
       rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);
     } else if (st.kind == NBP_STAGE_COPY_POINTS) {

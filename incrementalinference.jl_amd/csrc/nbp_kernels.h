@@ -545,23 +545,27 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
 // launch: 8 when the launch cannot fill the chip (latency: short ranges, several small workgroups per
 // product), 4 or 2 when it can (throughput: one workgroup per product computes the node statistics once).
 struct product_lds {
-  double *lm, *lv, *lr, *cen, *h2, *nw, *tab;
+  double *lm, *lv, *lr, *ls, *lc, *cen, *h2, *nw, *tab;
   int *ind;
 };
 
 // `big` = the per-level node statistics (3 x F x D x N doubles) do not fit the LDS: they go to a scratch
 // area private to the workgroup in global memory and are served by L1/L2; LDS then holds only the small
 // per-product items.
+__host__ __device__ inline size_t nbp_product_gstats_doubles(int F, int D, int N) { return (3 * (size_t)F * D + 2 * (size_t)F) * N; }
 __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
   const size_t bulk = big ? 0 : (size_t)F * D * N;
   size_t lm = dbl(bulk), lv = dbl(bulk), lr = dbl(bulk);
+  // circular coordinate (one per manifold at most): sin / cos of every node mean times its precision, so that the
+  // conditional mean of a draw is two sums and one atan2 instead of a sincos per density
+  size_t ls = dbl(big ? 0 : (size_t)F * N), lc = dbl(big ? 0 : (size_t)F * N);
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
   size_t nw = dbl((size_t)N), tab = dbl(NBP_EXPTAB);
   size_t ints0 = o;
   if (L) {
-    L->lm = base + lm; L->lv = base + lv; L->lr = base + lr; L->cen = base + cen; L->h2 = base + h2;
+    L->lm = base + lm; L->lv = base + lv; L->lr = base + lr; L->ls = base + ls; L->lc = base + lc; L->cen = base + cen; L->h2 = base + h2;
     L->nw = base + nw; L->tab = base + tab;
     L->ind = (int *)(base + ints0);
   }
@@ -590,8 +594,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   double *out = arena + S * d->out_slot;
   const double *wsp = ws + (size_t)blockIdx.x * kdF * nbp_kd_ws_doubles(N);
   // node statistics: LDS, or (big) this workgroup's private scratch in global memory
-  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 * (size_t)F * D * N : nullptr;
+  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * nbp_product_gstats_doubles(F, D, N) : nullptr;
   double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv, *lr = big ? gs + 2 * (size_t)F * D * N : L.lr;
+  double *lsn = big ? gs + 3 * (size_t)F * D * N : L.ls, *lcs = big ? gs + (3 * (size_t)F * D + F) * N : L.lc;
+  constexpr int KC = (MANI == NBP_CIRCULAR) ? 0 : (MANI == NBP_SE2 ? 2 : -1);  // the circular coordinate, if any
   nbp_exp_tab_init(L.tab);
   NBP_CTICK_INIT();
   // ---- bandwidths and centres of every density -------------------------------------------------
@@ -623,7 +629,14 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       lm[jk * N + z] = cen[j * 3 + k] + mu;
       const double vz = var + h2[j * 3 + k];
       lv[jk * N + z] = vz;
-      lr[jk * N + z] = 1.0 / vz;  // the precision, once per node: the draws below only multiply
+      const double rz = 1.0 / vz;  // the precision, once per node: the draws below only multiply
+      lr[jk * N + z] = rz;
+      if (KC >= 0 && k == KC) {
+        double sn, cs_;
+        sincos(cen[j * 3 + k] + mu, &sn, &cs_);
+        lsn[j * N + z] = sn * rz;
+        lcs[j * N + z] = cs_ * rz;
+      }
     }
     for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
     // levelDown!: the label moves to a child of the selected node drawn by its share of the leaves (always
@@ -696,15 +709,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               if (q == j) continue;
               if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
               const int iq = ind[q * SPB + sl];
-              const double mq = lm[(q * D + k) * N + iq], rq = lr[(q * D + k) * N + iq];
+              const double rq = lr[(q * D + k) * N + iq];
               prec += rq;
               if (circ[k]) {
-                double sn, cs_;
-                sincos(mq, &sn, &cs_);
-                ss += sn * rq;
-                sc += cs_ * rq;
+                ss += lsn[q * N + iq];
+                sc += lcs[q * N + iq];
               } else
-                acc += mq * rq;
+                acc += lm[(q * D + k) * N + iq] * rq;
             }
             if (PARTIAL) {
               use[k] = ((pmj >> k) & 1) && prec > 0;
@@ -832,15 +843,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       for (int q = 0; q < F; q++) {
         if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
         const int iq = ind[q * SPB + sl];
-        const double mq = lm[(q * D + k) * N + iq], rq = lr[(q * D + k) * N + iq];
+        const double rq = lr[(q * D + k) * N + iq];
         prec += rq;
         if (circ[k]) {
-          double sn, cs_;
-          sincos(mq, &sn, &cs_);
-          ss += sn * rq;
-          sc += cs_ * rq;
+          ss += lsn[q * N + iq];
+          sc += lcs[q * N + iq];
         } else
-          acc += mq * rq;
+          acc += lm[(q * D + k) * N + iq] * rq;
       }
       if (PARTIAL && !(prec > 0)) {  // uninformed coordinate: oldPoints
         res[k] = (d->old_slot >= 0) ? arena[S * d->old_slot + k * N + s] : 0.0;
@@ -862,23 +871,28 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   NBP_CTICK(42);  // final draw
 }
 
+// single density: AMP returns it unchanged
+__device__ __forceinline__ void product_passthrough(const nbp_product_desc *d, double *arena, int N, int64_t S, int32_t *side) {
+  if (blockIdx.y != 0) return;
+  const double *src = arena + S * d->in_slot[0];
+  double *out = arena + S * d->out_slot;
+  for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
+  // infoPerCoord of the update: the sum over its factors of ones(D) (proposalbeliefs!, ApproxConv.jl:277,298-303)
+  if (threadIdx.x < 3) out[3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? 1.0 : 0.0;
+  if (d->labels_out >= 0)
+    for (int i = threadIdx.x; i < N; i += blockDim.x) side[d->labels_out + i] = i;
+}
+__device__ __forceinline__ void product_write_ipc(const nbp_product_desc *d, double *arena, int N, int64_t S) {
+  if (blockIdx.y == 0 && threadIdx.x < 3)
+    arena[S * d->out_slot + 3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? (double)d->nfactors : 0.0;
+}
+
 template <int HL>
 __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
                                                     double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
-  if (d->nfactors == 1) {  // single density: AMP returns it unchanged
-    if (blockIdx.y != 0) return;
-    const double *src = arena + S * d->in_slot[0];
-    double *out = arena + S * d->out_slot;
-    for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
-    // infoPerCoord of the update: the sum over its factors of ones(D) (proposalbeliefs!, ApproxConv.jl:277,298-303)
-    if (threadIdx.x < 3) out[3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? 1.0 : 0.0;
-    if (d->labels_out >= 0)
-      for (int i = threadIdx.x; i < N; i += blockDim.x) side[d->labels_out + i] = i;
-    return;
-  }
-  if (blockIdx.y == 0 && threadIdx.x < 3)
-    arena[S * d->out_slot + 3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? (double)d->nfactors : 0.0;
+  if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
+  product_write_ipc(d, arena, N, S);
   bool partial = false;
   for (int j = 0; j < d->nfactors; j++) partial |= (d->in_partial[j] != 0);
   if (partial) {  // validated on the host: D >= 2
@@ -896,6 +910,19 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
   case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
   default: product_body<NBP_SE2, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
   }
+}
+
+// A batch whose multi-density products all live on ONE manifold and have no partial inputs (every stage of a
+// homogeneous graph) runs a kernel that holds that one instantiation: the register allocation of the throughput
+// variants is then the body's own need instead of the maximum over all manifolds (scratch per lane at 4 waves per
+// SIMD: generic 308-328 B, Euclid(1) 0, Euclid(2) 64 B, Euclid(3) 52 B).
+template <int MANI, int HL>
+__device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
+                                                       double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
+  const nbp_product_desc *d = descs + blockIdx.x;
+  if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
+  product_write_ipc(d, arena, N, S);
+  product_body<MANI, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
 
 // Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in
@@ -917,6 +944,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) n
   extern __shared__ double smem[];
   product_kernel_body<2>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
+#define NBP_PRODUCT_UNIFORM(NAME, MANI, HL)                                                                        \
+  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) NAME(NBP_PRODUCT_ARGS) {          \
+    extern __shared__ double smem[];                                                                               \
+    product_kernel_uniform<MANI, HL>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                           \
+  }
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e1, NBP_EUCLID1, 2)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e2, NBP_EUCLID2, 2)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e3, NBP_EUCLID3, 2)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_ci, NBP_CIRCULAR, 2)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_se, NBP_SE2, 2)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_e1, NBP_EUCLID1, 4)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_e2, NBP_EUCLID2, 4)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_e3, NBP_EUCLID3, 4)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_ci, NBP_CIRCULAR, 4)
+NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_se, NBP_SE2, 4)
 
 static inline size_t nbp_product_lds_bytes(int F, int D, int N, int SPB, bool big) {
   return product_lds_layout(F, D, N, SPB, big, nullptr, nullptr);
