@@ -182,11 +182,21 @@ nbp_status nbp_slot_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *p
  * the factor's `.partial` (EvalFactor.jl:383-391); a variable update carries the sum over its factors of ones(D)
  * (proposalbeliefs!, ApproxConv.jl:277,298-303 -- the reference's `fct_ipc = ones(vardim)`, partial factors
  * included); slot copies (tree messages) carry it along.  nbp_slot_write stores zeros (a fresh VariableNodeData).
- * n_pts: particle count of the belief; this version requires n_pts == N of the context (read returns N). */
+ * n_pts: particle count of the belief.  A slot holds up to N points (N of the context).  Fewer: the belief keeps its
+ * own count (it must come with its bandwidth) and every consumer does what the reference does with a belief shorter
+ * than N -- a convolution reads a random element for the particles beyond its end (_getindex_anyn,
+ * NumericalCalculations.jl:377-381), the scratch copy of a target is filled up with the point default
+ * (CalcFactor.jl:555-565), a MsgPrior / KDE measurement samples among the points it has, the oldPoints of a product are
+ * topped up with sample(oldBel, N - Npts) (GraphProductOperations.jl:39-45), manikde! fits the points there are; every
+ * kernel output holds N points.  More than N: the first N are kept (`_pts[1:N]`, GraphProductOperations.jl:44).
+ * nbp_belief_read returns the count in *n_pts and fills the first *n_pts points. */
 nbp_status nbp_belief_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP, int32_t n_pts,
                             const double *bw_D /* nullable */, const double *ipc_D /* nullable: zeros */);
 nbp_status nbp_belief_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP, int32_t *n_pts /* nullable */,
                            double *bw_D /* nullable */, double *ipc_D /* nullable */);
+/* sample(oldBel, N - Npts) in place: beliefs with fewer than N points are topped up to N with draws from their own KDE
+ * (random kernel + bw * randn); the points they hold stay.  Multinomial resampling of a belief to the solver's N. */
+nbp_status nbp_run_resample(nbp_ctx *ctx, const int32_t *slots, const int32_t *manifolds, int32_t n, uint64_t seed);
 nbp_status nbp_side_write(nbp_ctx *ctx, int32_t offset, const int32_t *src, int32_t n);
 nbp_status nbp_side_read(nbp_ctx *ctx, int32_t offset, int32_t *dst, int32_t n);
 

@@ -125,6 +125,13 @@ class HipBackend:
         ip = C.POINTER(C.c_int32)
         self._check(self.lib.nbp_run_bandwidth(self._ctx, s.ctypes.data_as(ip), m.ctypes.data_as(ip), s.size))
 
+    def run_resample(self, slots, manifolds, seed=0):
+        """sample(oldBel, N - Npts): top beliefs with fewer than N points up to N, in place"""
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        m = np.ascontiguousarray(manifolds, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._check(self.lib.nbp_run_resample(self._ctx, s.ctypes.data_as(ip), m.ctypes.data_as(ip), s.size, C.c_uint64(seed)))
+
     # ---- host-buffer entry points (one call per reference function) -------------------------------
     def kde_bandwidth(self, manifold, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float64)

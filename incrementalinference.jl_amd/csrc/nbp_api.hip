@@ -237,12 +237,15 @@ nbp_status nbp_slot_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts
 nbp_status nbp_belief_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, int32_t n_pts, const double *bw,
                             const double *ipc) {
   if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
-  if (n_pts != c->N) return fail(NBP_ERR_RANGE, "belief: n_pts must equal the context's N");
+  if (n_pts < 1) return fail(NBP_ERR_RANGE, "belief: n_pts < 1");
+  if (n_pts < c->N && !bw) return fail(NBP_ERR_ARG, "belief: a belief with fewer than N points needs its bandwidth (it is a density, not a point set)");
   if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
   if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
   const int N = c->N, D = manifold_dim_h(manifold), P = manifold_P_h(manifold);
   std::vector<double> s(c->S, 0.0);
-  for (int n = 0; n < N; n++) {
+  const int cnt = n_pts < N ? n_pts : N;  // more than N points: the first N (GraphProductOperations.jl:44, `_pts[1:N]`)
+  s[3 * N + 6] = cnt < N ? (double)cnt : 0.0;
+  for (int n = 0; n < cnt; n++) {
     const double *p = pts + (size_t)n * P;
     if (manifold == NBP_SE2) {
       s[n] = p[0];
@@ -283,7 +286,7 @@ nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *p
     for (int d = 0; d < D; d++) bw[d] = s[3 * N + d];
   if (ipc)
     for (int d = 0; d < D; d++) ipc[d] = s[3 * N + 3 + d];
-  if (n_pts) *n_pts = N;
+  if (n_pts) *n_pts = (s[3 * N + 6] > 0.0 && s[3 * N + 6] < (double)N) ? (int)s[3 * N + 6] : N;
   return NBP_OK;
 }
 
@@ -820,6 +823,26 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
   const int32_t *ds = (const int32_t *)c->stage;
   rc = launch_bandwidth(c, ds, ds + n, n);
   if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return NBP_OK;
+}
+
+nbp_status nbp_run_resample(nbp_ctx *c, const int32_t *slots, const int32_t *manifolds, int32_t n, uint64_t seed) {
+  if (!c || ((!slots || !manifolds) && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; i++) {
+    if (slots[i] < 0 || slots[i] >= c->n_slots) return fail(NBP_ERR_RANGE, "resample: slot out of range");
+    if (!manifold_ok(manifolds[i])) return fail(NBP_ERR_ARG, "resample: unknown manifold");
+  }
+  std::vector<int32_t> both(slots, slots + n);
+  both.insert(both.end(), manifolds, manifolds + n);
+  nbp_status rc = stage_upload(c, both.data(), both.size() * 4);
+  if (rc) return rc;
+  const int32_t *ds = (const int32_t *)c->stage;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_resample_kernel, dim3(n), dim3(256), 0, c->stream, ds, ds + n, c->arena, c->N, c->S, seed);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
 }

@@ -33,6 +33,9 @@
 #define PURP_KDENOISE 6
 #define PURP_PGIBBS 9
 #define PURP_PFINAL 10
+#define PURP_ANYN 11      // _getindex_anyn: the element a particle beyond the end of a shorter operand reads
+#define PURP_OLDSEL 12    // sample(oldBel, nn): kernel pick / noise of the top-up of a belief with fewer than N points
+#define PURP_OLDNOISE 13
 #define NBP_TAG 0x4E4250u
 
 #define NBP_MAXLEVELS 12
@@ -95,6 +98,26 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t 
   sincos(th, &s, &c);
   na = r * c;
   nb = r * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// particle count of a belief: a slot holds up to N points; slot[3N + 6] = the count, 0 meaning N (what every
+// kernel output has).  Beliefs with fewer points come from the host (nbp_belief_write): a variable initialised with
+// another N, a message of a clique solved with another N.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slot_count(const double *s, int N) {
+  const double c = s[3 * N + 6];
+  return (c > 0.0 && c < (double)N) ? (int)c : N;
+}
+// _getindex_anyn(vec, n) = vec[n <= len ? n : rand(1:len)] (NumericalCalculations.jl:377-381).  The reference draws
+// a new element at every evaluation of the residual; here the draw is one per (op, particle, operand), which keeps the
+// objective of a particle's search a function.
+__device__ __forceinline__ int anyn_index(int n, int cnt, uint64_t seed, int operand) {
+  if (n < cnt) return n;
+  double ua, ub;
+  uniform_pair(seed, n, PURP_ANYN, (uint32_t)operand, ua, ub);
+  const int i = (int)(ua * cnt);
+  return i < cnt ? i : cnt - 1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -21,10 +21,11 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
     // the measurement is a KDE (differential message factor): sample(belief) = random kernel + bw*randn
     // (manifolds/services/ManifoldSampling.jl:13-19), like the MsgPrior draw below
     const double *msg = arena + S * (d->meas_kde - 1);
+    const int cm = slot_count(msg, N);
     double ua, ub, n0, n1, n2 = 0, n3 = 0;
     uniform_pair(mseed, n, PURP_KDESEL, 0, ua, ub);
-    int i = (int)(ua * N);
-    if (i >= N) i = N - 1;
+    int i = (int)(ua * cm);
+    if (i >= cm) i = cm - 1;
     normal_pair(mseed, n, PURP_KDENOISE, 0, n0, n1);
     if (zdim > 2) normal_pair(mseed, n, PURP_KDENOISE, 1, n2, n3);
     z[0] = msg[i] + msg[3 * N] * n0;
@@ -82,10 +83,11 @@ __device__ __forceinline__ double var_distance_expected_fractional(const nbp_pro
   double best = 1e-2;
   for (int i = 1; i <= d->nvars; i++) {
     const double *pts = (i == sf1) ? X : arena + S * d->var_slot[i - 1];
+    const int ci = (i == sf1) ? N : slot_count(pts, N);  // the scratch copy of the target always has N entries
     const bool cer = in_list(R->certain, R->ncertain, i);
     double acc = 0;
     for (int k = 0; k < D; k++) {
-      double mu = cer ? mean_geodesic_coord(pts + k * N, N, M, k, red) : mean_default_coord(pts + k * N, N, M, k, red);
+      double mu = cer ? mean_geodesic_coord(pts + k * N, ci, M, k, red) : mean_default_coord(pts + k * N, ci, M, k, red);
       acc += (ref[k] - mu) * (ref[k] - mu);
     }
     best = fmax(best, sqrt(acc));
@@ -111,8 +113,10 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
   if (n == 0) build_recipe(d, &R);
   {
     const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR) ? 0 : d->sfidx];
+    // resize!(target copy, N): entries beyond the belief's own count are the point default (CalcFactor.jl:555-565)
+    const int ct = slot_count(src, N);
     if (live)
-      for (int k = 0; k < 3; k++) X[k * N + n] = src[k * N + n];
+      for (int k = 0; k < 3; k++) X[k * N + n] = (n < ct) ? src[k * N + n] : 0.0;
   }
   __syncthreads();
   // mhidx: injected or rand(Categorical)  (ExplicitDiscreteMarginalizations.jl:186,261)
@@ -154,11 +158,12 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           x[2] = is_circ(M, 2) ? wrap_pi(z[2]) : z[2];
         } else {  // MsgPrior{MKD}: sample(belief): random kernel + bw*randn (Factors/MsgPrior.jl:27-30)
           const double *msg = arena + S * d->var_slot[1];
+          const int cm = slot_count(msg, N);
           const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
           double ua, ub, n0, n1, n2 = 0, n3 = 0;
           uniform_pair(mseed, n, PURP_KDESEL, 0, ua, ub);
-          int i = (int)(ua * N);
-          if (i >= N) i = N - 1;
+          int i = (int)(ua * cm);
+          if (i >= cm) i = cm - 1;
           normal_pair(mseed, n, PURP_KDENOISE, 0, n0, n1);
           if (D > 2) normal_pair(mseed, n, PURP_KDENOISE, 1, n2, n3);
           double v0 = msg[i] + msg[3 * N] * n0;
@@ -198,9 +203,10 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
         const double *O = arena + S * d->var_slot[vother - 1];
         double oth[3] = {0, 0, 0};
         if (myh == hyp) {
-          oth[0] = O[n];
-          if (D > 1) oth[1] = O[N + n];
-          if (D > 2) oth[2] = O[2 * N + n];
+          const int io = anyn_index(n, slot_count(O, N), d->seed, vother);  // _getindex_anyn
+          oth[0] = O[io];
+          if (D > 1) oth[1] = O[N + io];
+          if (D > 2) oth[2] = O[2 * N + io];
         }
         for (int c = 0; c < d->inflate_cycles; c++) {  // :184-207
           NBP_CTICK(30);  // everything before / between cycles
@@ -248,6 +254,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
   // infoPerCoord of the proposal: ones(D), zeroed outside the factor's `.partial` (EvalFactor.jl:383-391, :534-540)
   if (n < 3) out[3 * N + 3 + n] = (n < D && (!d->partial_mask || ((d->partial_mask >> n) & 1))) ? 1.0 : 0.0;
+  if (n == 0) out[3 * N + 6] = 0.0;  // a proposal always holds N points
   // diagnostics: one atomic per wave
   {
     unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
@@ -285,15 +292,20 @@ nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, dou
     sample_measurement(d, n, zdim, z, arena, S, N);
     if (ms)
       for (int k = 0; k < 3; k++) ms[k * N + n] = (k < zdim) ? z[k] : 0.0;
-    a[0] = A[n]; b[0] = B[n];
-    if (D > 1) { a[1] = A[N + n]; b[1] = B[N + n]; }
-    if (D > 2) { a[2] = A[2 * N + n]; b[2] = B[2 * N + n]; }
+    const int ia = anyn_index(n, slot_count(A, N), d->seed, 1), ib = anyn_index(n, slot_count(B, N), d->seed, 2);
+    a[0] = A[ia]; b[0] = B[ib];
+    if (D > 1) { a[1] = A[N + ia]; b[1] = B[N + ib]; }
+    if (D > 2) { a[2] = A[2 * N + ia]; b[2] = B[2 * N + ib]; }
     deconv_particle(kind, M, a, b, z, n_solves, n_nonconv, n_nan, n_evals);
     for (int k = 0; k < 3; k++) out[k * N + n] = (k < zdim) ? z[k] : 0.0;
   }
   if (n < 3) {
     out[3 * N + n] = 0.0;
     if (ms) ms[3 * N + n] = 0.0;
+  }
+  if (n == 0) {
+    out[3 * N + 6] = 0.0;
+    if (ms) ms[3 * N + 6] = 0.0;
   }
   unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
 #pragma unroll
@@ -313,24 +325,25 @@ nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, dou
 static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
 
 // fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)
-__device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int N, int Npad, double *smem, nbp_counters *ctr) {
+__device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int Ncap, int Npad, double *smem, nbp_counters *ctr) {
   const int D = mani_dim(M), n = threadIdx.x;
   if (k >= D) {
-    if (n == 0) s[3 * N + k] = 0.0;
+    if (n == 0) s[3 * Ncap + k] = 0.0;
     return;
   }
+  const int N = slot_count(s, Ncap);  // manikde! of the points the belief holds (Ncap = slot capacity = stride)
   const int P = blockDim.x / Npad;
   double *X = smem, *part = smem + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N, *tab = red + NBP_RED;
   nbp_exp_tab_init(tab);
   // circular coordinates are staged wrapped (the identity for stored beliefs): every pair difference of
   // the fit is then within (-2pi, 2pi), which is what circ_sqdist relies on
   if (n < N) {
-    const double v = s[k * N + n];
+    const double v = s[k * Ncap + n];
     X[n] = X[n + N] = is_circ(M, k) ? wrap_pi(v) : v;
   }
   __syncthreads();
   double h = lcv_bandwidth_1d(X, N, Npad, is_circ(M, k), part, red, tab, ctr);
-  if (n == 0) s[3 * N + k] = h;
+  if (n == 0) s[3 * Ncap + k] = h;
 }
 
 // ================================================================================================
@@ -361,6 +374,7 @@ __global__ void nbp_copy_points_kernel(const nbp_copy_desc *c, double *arena, in
   const double *src = arena + S * c[blockIdx.x].src_slot;
   double *dst = arena + S * c[blockIdx.x].dst_slot;
   for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0) dst[3 * N + 6] = src[3 * N + 6];  // the particle count belongs to the points
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -511,6 +525,31 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
   }
 }
 
+// sample(oldBel, nn) (GraphProductOperations.jl:39-45): a belief that holds fewer than N points is topped up, in
+// place, with draws from its own KDE (random kernel + bw * randn); the points it has stay where they are.  One
+// workgroup per slot.  Used for the oldPoints of a product (prep launch) and by nbp_run_resample.
+__device__ __forceinline__ void topup_slot(double *s, int N, int manifold, uint64_t seed) {
+  const int cnt = slot_count(s, N), D = mani_dim(manifold);
+  if (cnt >= N) return;  // block-uniform
+  for (int n = cnt + threadIdx.x; n < N; n += blockDim.x) {
+    double ua, ub, nn[4] = {0, 0, 0, 0};
+    uniform_pair(seed, n, PURP_OLDSEL, 0, ua, ub);
+    int i = (int)(ua * cnt);
+    if (i >= cnt) i = cnt - 1;
+    normal_pair(seed, n, PURP_OLDNOISE, 0, nn[0], nn[1]);
+    if (D > 2) normal_pair(seed, n, PURP_OLDNOISE, 1, nn[2], nn[3]);
+    for (int k = 0; k < 3; k++) {
+      const double v = (k < D) ? s[k * N + i] + s[3 * N + k] * nn[k] : 0.0;
+      s[k * N + n] = is_circ(manifold, k) ? wrap_pi(v) : v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) s[3 * N + 6] = 0.0;
+}
+__global__ void nbp_resample_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int64_t S, uint64_t seed) {
+  topup_slot(arena + S * slots[blockIdx.x], N, manifolds[blockIdx.x], seed + 0x9E3779B97F4A7C15ull * (uint64_t)(blockIdx.x + 1));
+}
+
 static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
   return ((size_t)D * N + 3 * Npad + NBP_RED) * 8 + ((size_t)2 * N + (size_t)P * Npad + Npad) * 4;
 }
@@ -531,6 +570,7 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
   const double *x = arena + S * d->in_slot[j];
   double *wsj = ws + (size_t)(p * kdF + j) * nbp_kd_ws_doubles(N);
   const int mask = d->in_partial[j] ? d->in_partial[j] : 7;
+  if (j == 0 && d->old_slot >= 0) topup_slot(arena + S * d->old_slot, N, d->manifold, d->seed);  // oldPoints of the product
   switch (mani_dim(d->manifold)) {
   case 1: kd_build<1>(x, wsj, N, Npad, T, smem, 1); break;
   case 2: kd_build<2>(x, wsj, N, Npad, T, smem, mask); break;
@@ -851,7 +891,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         } else
           acc += lm[(q * D + k) * N + iq] * rq;
       }
-      if (PARTIAL && !(prec > 0)) {  // uninformed coordinate: oldPoints
+      if (PARTIAL && !(prec > 0)) {  // uninformed coordinate: oldPoints (topped up to N by the prep launch of this stage)
         res[k] = (d->old_slot >= 0) ? arena[S * d->old_slot + k * N + s] : 0.0;
         continue;
       }
@@ -879,13 +919,16 @@ __device__ __forceinline__ void product_passthrough(const nbp_product_desc *d, d
   for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
   // infoPerCoord of the update: the sum over its factors of ones(D) (proposalbeliefs!, ApproxConv.jl:277,298-303)
   if (threadIdx.x < 3) out[3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? 1.0 : 0.0;
+  if (threadIdx.x == 0) out[3 * N + 6] = src[3 * N + 6];
   if (d->labels_out >= 0)
     for (int i = threadIdx.x; i < N; i += blockDim.x) side[d->labels_out + i] = i;
 }
 __device__ __forceinline__ void product_write_ipc(const nbp_product_desc *d, double *arena, int N, int64_t S) {
   if (blockIdx.y == 0 && threadIdx.x < 3)
     arena[S * d->out_slot + 3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? (double)d->nfactors : 0.0;
+  if (blockIdx.y == 0 && threadIdx.x == 0) arena[S * d->out_slot + 3 * N + 6] = 0.0;  // N points
 }
+
 
 template <int HL>
 __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,

@@ -167,9 +167,21 @@ class Belief:
     def copy(self):
         return Belief(self.manifold, self.pts, self.bw, self.ipc)
 
-    def c(self):
+    def c(self, capacity=None):
+        """the C view; `capacity`: room for that many points (a clique call hands N points back whatever came in)"""
         dp = C.POINTER(f64)
-        return TreeBeliefC(self.pts.ctypes.data_as(dp), self.bw.ctypes.data_as(dp), self.ipc.ctypes.data_as(dp), self.pts.shape[0], 0)
+        n = self.pts.shape[0]
+        if capacity is not None and capacity > n:
+            buf = np.zeros((capacity, self.pts.shape[1]))
+            buf[:n] = self.pts
+            self._buf, self._n_in = buf, n
+        else:
+            self._buf, self._n_in = self.pts, n
+        return TreeBeliefC(self._buf.ctypes.data_as(dp), self.bw.ctypes.data_as(dp), self.ipc.ctypes.data_as(dp), n, 0)
+
+    def take(self, cview):
+        """after a call that wrote this belief: adopt the points that came back"""
+        self.pts = self._buf[:cview.n_pts]
 
 
 def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, manifolds, factors, beliefs, seed, down=False,
@@ -203,11 +215,13 @@ def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, mani
     need = _check(lib.nbp_clique_slots(C.byref(q)))
     if need > backend.n_slots:
         raise ValueError(f"the context has {backend.n_slots} slots, this clique needs {need}")
-    bel = (TreeBeliefC * len(variables))(*[beliefs[v].c() for v in variables])
+    bel = (TreeBeliefC * len(variables))(*[beliefs[v].c(capacity=sp.N) for v in variables])
     status = i32(0)
     p = solver_params_c(sp)
     fn = lib.nbp_clique_downsolve if down else lib.nbp_clique_upsolve
     _check(fn(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, C.byref(status)))
+    for i, v in enumerate(variables):
+        beliefs[v].take(bel[i])
     return status.value
 
 

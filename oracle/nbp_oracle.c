@@ -48,6 +48,9 @@
 #define PURP_KDENOISE 6
 #define PURP_PGIBBS 9
 #define PURP_PFINAL 10
+#define PURP_ANYN 11
+#define PURP_OLDSEL 12
+#define PURP_OLDNOISE 13
 #define NBP_TAG 0x4E4250u
 
 typedef struct {
@@ -120,6 +123,22 @@ void orc_normal_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k, do
   *nb = r * sin(th);
 }
 
+/* particle count of a belief: a slot holds up to N points, slot[3N + 6] = the count (0 = N) */
+static int slot_count(const double *s, int N) {
+  const double c = s[3 * N + 6];
+  return (c > 0.0 && c < (double)N) ? (int)c : N;
+}
+/* _getindex_anyn(vec, n) = vec[n <= len ? n : rand(1:len)]  (NumericalCalculations.jl:377-381).  The reference
+ * draws again at every evaluation of the residual (the objective of that particle's search is then not a function);
+ * the restatement draws once per (op, particle, operand). */
+static int anyn_index(int n, int cnt, uint64_t seed, int operand) {
+  if (n < cnt) return n;
+  double ua, ub;
+  orc_uniform_pair(seed, n, PURP_ANYN, (uint32_t)operand, &ua, &ub);
+  int i = (int)(ua * cnt);
+  return i < cnt ? i : cnt - 1;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Manifolds in tangent coordinates at the identity                                            */
 /* ------------------------------------------------------------------------------------------ */
@@ -148,10 +167,18 @@ int32_t orc_manifold_dim(int32_t m) { return mani_dim(m); }
 int32_t orc_manifold_P(int32_t m) { return mani_P(m); }
 
 /* host AoS points (N x P) -> slot coordinates (vee(M, e, log(M, e, p)), what AMP.manikde! stores) */
+void orc_belief_write(double *arena, int32_t N, int32_t slot, int32_t manifold, const double *pts, int32_t n_pts, const double *bw);
 void orc_slot_write(double *arena, int32_t N, int32_t slot, int32_t manifold, const double *pts, const double *bw) {
+  orc_belief_write(arena, N, slot, manifold, pts, N, bw);
+}
+/* n_pts < N: the belief keeps its count; n_pts > N: the first N points (GraphProductOperations.jl:44) */
+void orc_belief_write(double *arena, int32_t N, int32_t slot, int32_t manifold, const double *pts, int32_t n_pts, const double *bw) {
   double *s = arena + orc_slot_stride(N) * slot;
   int D = mani_dim(manifold), P = mani_P(manifold);
-  for (int n = 0; n < N; n++) {
+  const int cnt = n_pts < N ? n_pts : N;
+  memset(s, 0, sizeof(double) * (3 * N + 8));
+  s[3 * N + 6] = cnt < N ? (double)cnt : 0.0;
+  for (int n = 0; n < cnt; n++) {
     const double *p = pts + (size_t)n * P;
     if (manifold == NBP_SE2) {
       s[0 * N + n] = p[0];
@@ -166,6 +193,7 @@ void orc_slot_write(double *arena, int32_t N, int32_t slot, int32_t manifold, co
   for (int d = 0; d < 3; d++) s[3 * N + d] = (bw && d < D) ? bw[d] : 0.0;
   for (int d = 0; d < 3; d++) s[3 * N + 3 + d] = 0.0; /* infoPerCoord of a fresh VariableNodeData */
 }
+int32_t orc_slot_count(const double *arena, int32_t N, int32_t slot) { return slot_count(arena + orc_slot_stride(N) * slot, N); }
 /* infoPerCoord of a slot (TreeBelief.infoPerCoord, BeliefTypes.jl:47-57) */
 void orc_slot_ipc_write(double *arena, int32_t N, int32_t slot, int32_t manifold, const double *ipc) {
   double *s = arena + orc_slot_stride(N) * slot;
@@ -194,11 +222,14 @@ void orc_slot_read(const double *arena, int32_t N, int32_t slot, int32_t manifol
 
 /* mean(M, pts, GeodesicInterpolation()) : running geodesic interpolation, Manifolds.jl.
  * services/VariableStatistics.jl:30 */
-static void mean_geodesic(int manifold, const double *x, int N, double *mu) {
+static void mean_geodesic_n(int manifold, const double *x, int N, int cnt, double *mu);
+static void mean_geodesic(int manifold, const double *x, int N, double *mu) { mean_geodesic_n(manifold, x, N, N, mu); }
+/* N = stride of the coordinate arrays, cnt = points held */
+static void mean_geodesic_n(int manifold, const double *x, int N, int cnt, double *mu) {
   int D = mani_dim(manifold);
   for (int d = 0; d < D; d++) {
     double m = x[d * N];
-    for (int i = 1; i < N; i++) {
+    for (int i = 1; i < cnt; i++) {
       double dl = x[d * N + i] - m;
       if (is_circ(manifold, d)) dl = orc_wrap(dl);
       m = m + dl * (1.0 / (double)(i + 1)); /* weight as a reciprocal, like the kernel's recurrence */
@@ -209,20 +240,21 @@ static void mean_geodesic(int manifold, const double *x, int N, double *mu) {
 }
 
 /* default mean(M, pts): arithmetic on Euclidean coordinates, extrinsic on the circle */
-static void mean_default(int manifold, const double *x, int N, double *mu) {
+static void mean_default_n(int manifold, const double *x, int N, int cnt, double *mu) {
   int D = mani_dim(manifold);
   for (int d = 0; d < D; d++) {
     if (is_circ(manifold, d)) {
       double sc = 0, ss = 0;
-      for (int i = 0; i < N; i++) { sc += cos(x[d * N + i]); ss += sin(x[d * N + i]); }
+      for (int i = 0; i < cnt; i++) { sc += cos(x[d * N + i]); ss += sin(x[d * N + i]); }
       mu[d] = atan2(ss, sc);
     } else {
       double s = 0;
-      for (int i = 0; i < N; i++) s += x[d * N + i];
-      mu[d] = s / N;
+      for (int i = 0; i < cnt; i++) s += x[d * N + i];
+      mu[d] = s / cnt;
     }
   }
 }
+static void mean_default(int manifold, const double *x, int N, double *mu) { mean_default_n(manifold, x, N, N, mu); }
 
 /* calcStdBasicSpread, services/VariableStatistics.jl:22-36: sigma = sqrt(sum d(mu,x_i)^2/(N-1)),
  * 1.0 if sigma < 1e-10.  Rotation part of SE(2) carries the Frobenius metric (||skew(w)||^2 = 2w^2). */
@@ -688,7 +720,8 @@ double orc_lcv_bandwidth_1d(const double *x, int32_t N, int32_t circ) {
 
 static void fit_bandwidth(double *slot, int N, int manifold) {
   int D = mani_dim(manifold);
-  for (int d = 0; d < D; d++) slot[3 * N + d] = orc_lcv_bandwidth_1d(slot + d * N, N, is_circ(manifold, d));
+  const int cnt = slot_count(slot, N); /* manikde! of the points the belief holds */
+  for (int d = 0; d < D; d++) slot[3 * N + d] = orc_lcv_bandwidth_1d(slot + d * N, cnt, is_circ(manifold, d));
   for (int d = D; d < 3; d++) slot[3 * N + d] = 0.0;
 }
 
@@ -707,10 +740,11 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
      * of TreeMessageUtils.jl:279-335): sampleTangent(M, ::MKD) = sample(belief, 1) = random kernel +
      * bw*randn (manifolds/services/ManifoldSampling.jl:13-19) */
     const double *msg = arena + orc_slot_stride(N) * (d->meas_kde - 1);
+    const int cm = slot_count(msg, N);
     double ua, ub, nn[4];
     orc_uniform_pair(mseed, n, PURP_KDESEL, 0, &ua, &ub);
-    int i = (int)(ua * N);
-    if (i >= N) i = N - 1;
+    int i = (int)(ua * cm);
+    if (i >= cm) i = cm - 1;
     orc_normal_pair(mseed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
     if (zdim > 2) orc_normal_pair(mseed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
     for (int k = 0; k < 3; k++) z[k] = k < zdim ? msg[k * N + i] + msg[3 * N + k] * nn[k] : 0.0;
@@ -762,8 +796,9 @@ static double var_distance_expected_fractional(const nbp_proposal_desc *d, const
   mean_default(d->manifold, X, N, ref);
   for (int i = 1; i <= d->nvars; i++) {
     const double *pts = (i == sf1) ? X : arena + orc_slot_stride(N) * d->var_slot[i - 1];
-    if (in_list(R->certain, R->ncertain, i)) mean_geodesic(d->manifold, pts, N, mu);
-    else mean_default(d->manifold, pts, N, mu);
+    const int ci = (i == sf1) ? N : slot_count(pts, N); /* the scratch copy of the target always has N entries */
+    if (in_list(R->certain, R->ncertain, i)) mean_geodesic_n(d->manifold, pts, N, ci, mu);
+    else mean_default_n(d->manifold, pts, N, ci, mu);
     double acc = 0;
     for (int k = 0; k < D; k++) acc += (ref[k] - mu[k]) * (ref[k] - mu[k]);
     double dist = sqrt(acc);
@@ -798,6 +833,8 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     const double *cur = arena + S * d->var_slot[0];
     double *X = (double *)malloc(sizeof(double) * 3 * N);
     memcpy(X, cur, sizeof(double) * 3 * N); /* addEntr = deepcopy(solveForPts) */
+    for (int n = slot_count(cur, N); n < N; n++) /* resized to N: new entries are the point default */
+      for (int k = 0; k < 3; k++) X[k * N + n] = 0.0;
     double spread = d->spread_nh * orc_std_basic_spread(d->manifold, X, N); /* :464 */
     for (int n = 0; n < N; n++) {
       if (mhidx[n] == 1) {
@@ -815,11 +852,12 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
           for (int k = 0; k < D; k++) X[k * N + n] = is_circ(d->manifold, k) ? orc_wrap(z[k]) : z[k];
         } else { /* MsgPrior{MKD}: sample(belief,1): random kernel + bw*randn, Factors/MsgPrior.jl:27-30 */
           const double *msg = arena + S * d->var_slot[1];
+          const int cm = slot_count(msg, N);
           const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
           double ua, ub, nn[4];
           orc_uniform_pair(mseed, n, PURP_KDESEL, 0, &ua, &ub);
-          int i = (int)(ua * N);
-          if (i >= N) i = N - 1;
+          int i = (int)(ua * cm);
+          if (i >= cm) i = cm - 1;
           orc_normal_pair(mseed, n, PURP_KDENOISE, 0, &nn[0], &nn[1]);
           if (D > 2) orc_normal_pair(mseed, n, PURP_KDENOISE, 1, &nn[2], &nn[3]);
           for (int k = 0; k < D; k++) {
@@ -844,7 +882,13 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
       zdim = 1;
     }
     double *X = out; /* ccwl.varValsAll[sfidx] = deepcopy(target), CalcFactor.jl:543-548 */
-    memmove(X, arena + S * d->var_slot[d->sfidx], sizeof(double) * 3 * N);
+    {
+      const double *tsrc = arena + S * d->var_slot[d->sfidx];
+      const int ct = slot_count(tsrc, N);
+      memmove(X, tsrc, sizeof(double) * 3 * N);
+      for (int n = ct; n < N; n++) /* resize!(..., N) + getPointDefault for the new entries, CalcFactor.jl:555-565 */
+        for (int k = 0; k < 3; k++) X[k * N + n] = 0.0;
+    }
     double *Z = (double *)malloc(sizeof(double) * 3 * N);
     for (int n = 0; n < N; n++) sample_measurement(d, n, zdim, Z + 3 * n, 0, arena, N); /* sampleFactor!, :578 */
 
@@ -869,7 +913,8 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
           for (int n = 0; n < N; n++) { /* approxConvOnElements!, :14-27 */
             if (mhidx[n] != hyp) continue;
             double x[3], oth[3];
-            for (int k = 0; k < D; k++) { x[k] = X[k * N + n]; oth[k] = O[k * N + n]; }
+            const int io = anyn_index(n, slot_count(O, N), d->seed, vother); /* _getindex_anyn */
+            for (int k = 0; k < D; k++) { x[k] = X[k * N + n]; oth[k] = O[k * N + io]; }
             if (pdim >= 0) /* `.partial` -> islen1 -> BFGS (NumericalCalculations.jl:424); the gradient is
                               zero off the partial coordinate, so the search runs on that coordinate alone */
               solve_particle(NBP_F_LINREL, NBP_EUCLID1, Z + 3 * n, oth + pdim, solve_b, x + pdim);
@@ -887,6 +932,7 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     free(Z);
   }
   free(mhidx);
+  out[3 * N + 6] = 0.0; /* a proposal always holds N points */
   /* ipc = ones(D), zeroed outside `.partial` (EvalFactor.jl:383-391 relative, :534-540 prior) */
   for (int k = 0; k < 3; k++)
     out[3 * N + 3 + k] = (k < mani_dim(d->manifold) && (!d->partial_mask || ((d->partial_mask >> k) & 1))) ? 1.0 : 0.0;
@@ -964,6 +1010,31 @@ static void kd_build(const double *x, int N, int D, int mask, int *idx, int lo, 
   kd_build(x, N, D, mask, idx, mid, hi);
 }
 
+/* sample(oldBel, nn) (GraphProductOperations.jl:39-45): a belief with fewer than N points is topped up with draws
+ * from its own KDE -- random kernel + bw * randn (manifolds/services/ManifoldSampling.jl:13-19); the points it holds
+ * stay where they are */
+void orc_topup_slot(double *s, int32_t N, int32_t manifold, uint64_t seed) {
+  const int cnt = slot_count(s, N), D = mani_dim(manifold);
+  if (cnt >= N) return;
+  for (int n = cnt; n < N; n++) {
+    double ua, ub, nn[4] = {0, 0, 0, 0};
+    orc_uniform_pair(seed, n, PURP_OLDSEL, 0, &ua, &ub);
+    int i = (int)(ua * cnt);
+    if (i >= cnt) i = cnt - 1;
+    orc_normal_pair(seed, n, PURP_OLDNOISE, 0, &nn[0], &nn[1]);
+    if (D > 2) orc_normal_pair(seed, n, PURP_OLDNOISE, 1, &nn[2], &nn[3]);
+    for (int k = 0; k < 3; k++) {
+      double v = k < D ? s[k * N + i] + s[3 * N + k] * nn[k] : 0.0;
+      s[k * N + n] = is_circ(manifold, k) ? orc_wrap(v) : v;
+    }
+  }
+  s[3 * N + 6] = 0.0;
+}
+void orc_run_resample(double *arena, int32_t N, const int32_t *slots, const int32_t *manifolds, int32_t n, uint64_t seed) {
+  for (int i = 0; i < n; i++)
+    orc_topup_slot(arena + orc_slot_stride(N) * slots[i], N, manifolds[i], seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+}
+
 int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d) {
   const int64_t S = orc_slot_stride(N);
   const int D = mani_dim(d->manifold), F = d->nfactors, M = d->manifold;
@@ -971,6 +1042,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   if (F == 1) { /* single density: AMP returns it as is */
     memmove(out, arena + S * d->in_slot[0], sizeof(double) * (3 * N + 3));
     for (int k = 0; k < 3; k++) out[3 * N + 3 + k] = k < D ? 1.0 : 0.0; /* proposalbeliefs!: ipc = sum of ones(D) */
+    out[3 * N + 6] = (arena + S * d->in_slot[0])[3 * N + 6];
     if (d->labels_out >= 0) for (int n = 0; n < N; n++) side[d->labels_out + n] = n;
     return NBP_OK;
   }
@@ -978,6 +1050,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
      a coordinate no density informs keeps the old point (GraphProductOperations.jl:39-45) */
   int pm[NBP_MAXF];
   for (int j = 0; j < F; j++) pm[j] = d->in_partial[j] ? d->in_partial[j] : (1 << D) - 1;
+  if (d->old_slot >= 0) orc_topup_slot(arena + S * d->old_slot, N, M, d->seed); /* oldPoints, GraphProductOperations.jl:39-45 */
   const double *old = d->old_slot >= 0 ? arena + S * d->old_slot : 0;
   levels_t T;
   levels_build(&T, N);
@@ -1110,6 +1183,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   levels_free(&T);
   /* proposalbeliefs! (ApproxConv.jl:277,298-303): fct_ipc = ones(vardim) for every factor, summed */
   for (int k = 0; k < 3; k++) out[3 * N + 3 + k] = k < D ? (double)F : 0.0;
+  out[3 * N + 6] = 0.0; /* N points */
   fit_bandwidth(out, N, M); /* rebandwidth of the product */
   return NBP_OK;
 }
@@ -1137,7 +1211,8 @@ int32_t orc_run_deconv(double *arena, int32_t N, const nbp_proposal_desc *d, int
     if (ms) for (int k = 0; k < 3; k++) ms[k * N + n] = k < zdim ? z[k] : 0.0;
     objective_t o;
     o.kind = d->factor_kind; o.manifold = d->manifold; o.D = D; o.solve_b = 2;
-    for (int k = 0; k < 3; k++) { o.z[k] = k < D ? A[k * N + n] : 0.0; o.other[k] = k < D ? B[k * N + n] : 0.0; }
+    const int ia = anyn_index(n, slot_count(A, N), d->seed, 1), ib = anyn_index(n, slot_count(B, N), d->seed, 2);
+    for (int k = 0; k < 3; k++) { o.z[k] = k < D ? A[k * N + ia] : 0.0; o.other[k] = k < D ? B[k * N + ib] : 0.0; }
     double zc[3] = {z[0], z[1], z[2]};
     int conv;
     t_diag.solves++;
@@ -1150,6 +1225,8 @@ int32_t orc_run_deconv(double *arena, int32_t N, const nbp_proposal_desc *d, int
     for (int k = 0; k < 3; k++) out[k * N + n] = k < zdim ? zc[k] : 0.0;
   }
   for (int k = 0; k < 3; k++) { out[3 * N + k] = 0.0; if (ms) ms[3 * N + k] = 0.0; }
+  out[3 * N + 6] = 0.0;
+  if (ms) ms[3 * N + 6] = 0.0;
   return NBP_OK;
 }
 

@@ -32,6 +32,12 @@ def lib():
         L.orc_slot_write.restype = None
         L.orc_slot_read.argtypes = [dp, i32, i32, i32, dp, dp]
         L.orc_slot_read.restype = None
+        L.orc_belief_write.argtypes = [dp, i32, i32, i32, dp, i32, dp]
+        L.orc_belief_write.restype = None
+        L.orc_slot_count.argtypes = [dp, i32, i32]
+        L.orc_slot_count.restype = i32
+        L.orc_run_resample.argtypes = [dp, i32, ip, ip, i32, C.c_uint64]
+        L.orc_run_resample.restype = None
         L.orc_slot_ipc_write.argtypes = [dp, i32, i32, i32, dp]
         L.orc_slot_ipc_write.restype = None
         L.orc_slot_ipc_read.argtypes = [dp, i32, i32, i32, dp]
@@ -102,7 +108,9 @@ class OracleBackend:
         return pts, bw
 
     def belief_write(self, slot, manifold, pts, bw=None, ipc=None):
-        self.slot_write(slot, manifold, pts, bw)
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, abi.MANIFOLD_P[manifold])
+        bwa = None if bw is None else np.ascontiguousarray(bw, dtype=np.float64)
+        self.lib.orc_belief_write(_dp(self.arena), self.N, slot, manifold, _dp(pts), pts.shape[0], _dp(bwa) if bwa is not None else None)
         if ipc is not None:
             self.lib.orc_slot_ipc_write(_dp(self.arena), self.N, slot, manifold, _dp(np.ascontiguousarray(ipc, dtype=np.float64)))
 
@@ -110,7 +118,13 @@ class OracleBackend:
         pts, bw = self.slot_read(slot, manifold)
         ipc = np.zeros(abi.MANIFOLD_DIM[manifold])
         self.lib.orc_slot_ipc_read(_dp(self.arena), self.N, slot, manifold, _dp(ipc))
-        return pts, bw, ipc
+        return pts[:self.lib.orc_slot_count(_dp(self.arena), self.N, slot)], bw, ipc
+
+    def run_resample(self, slots, manifolds, seed=0):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        m = np.ascontiguousarray(manifolds, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self.lib.orc_run_resample(_dp(self.arena), self.N, s.ctypes.data_as(ip), m.ctypes.data_as(ip), s.size, C.c_uint64(seed))
 
     def side_write(self, offset, ints):
         a = np.asarray(ints, dtype=np.int32)
@@ -156,6 +170,7 @@ class OracleBackend:
         a = self.arena.reshape(-1, S)
         for d in descs:
             a[d.dst_slot, :3 * self.N] = a[d.src_slot, :3 * self.N]
+            a[d.dst_slot, 3 * self.N + 6] = a[d.src_slot, 3 * self.N + 6]  # the particle count belongs to the points
 
     def run_bandwidth(self, slots, manifolds):
         for s, m in zip(slots, manifolds):
