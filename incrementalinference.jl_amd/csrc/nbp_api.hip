@@ -333,7 +333,7 @@ static nbp_status check_proposals(nbp_ctx *c, const nbp_proposal_desc *d, int n)
       const int D = manifold_dim_h(p.manifold);
       if (p.partial_mask < 0 || p.partial_mask >= (1 << D)) return fail(NBP_ERR_RANGE, "proposal: partial_mask");
       if (p.factor_kind == NBP_F_LINREL) {
-        if (__builtin_popcount(p.partial_mask) != 1) return fail(NBP_ERR_ARG, "partial LinearRelative: one partial coordinate");
+        if (__builtin_popcount(p.partial_mask) > 2) return fail(NBP_ERR_ARG, "partial LinearRelative: one or two partial coordinates");
       } else if (p.factor_kind != NBP_F_PRIOR)
         return fail(NBP_ERR_ARG, "proposal: partial_mask is supported for Prior and LinearRelative factors");
     }

@@ -551,8 +551,114 @@ __device__ __forceinline__ bool bfgs_1d(OBJ &o, double (&x)[1]) {
   return converged;
 }
 
+// Optim.BFGS for an n-dimensional decision variable: what a partial factor over more than one coordinate runs
+// (`alg = islen1 ? BFGS : NelderMead` with islen1 true for every partial factor, NumericalCalculations.jl:108,424; the
+// gradient is zero off the partial coordinates, so the search is one over those).  Initial inverse Hessian I, central
+// finite differences, g_tol = 1e-8 on the max-norm of the gradient, the Armijo / quadratic-interpolation line search of
+// bfgs_1d (to which this reduces for DN = 1).
+template <class OBJ, int DN>
+__device__ __forceinline__ void fd_grad_nd(OBJ &o, const double (&x)[DN], double (&g)[DN]) {
+#pragma unroll
+  for (int k = 0; k < DN; k++) {
+    const double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x[k]));
+    double xp[DN], xm[DN];
+#pragma unroll
+    for (int q = 0; q < DN; q++) { xp[q] = x[q]; xm[q] = x[q]; }
+    xp[k] += h;
+    xm[k] -= h;
+    g[k] = (o(xp) - o(xm)) / (2.0 * h);
+  }
+}
+template <class OBJ, int DN>
+__device__ __forceinline__ bool bfgs_nd(OBJ &o, double (&x)[DN]) {
+  double xc[DN], g[DN], H[DN][DN];
+#pragma unroll
+  for (int k = 0; k < DN; k++) {
+    xc[k] = x[k];
+#pragma unroll
+    for (int q = 0; q < DN; q++) H[k][q] = (k == q) ? 1.0 : 0.0;
+  }
+  double fx = o(xc);
+  fd_grad_nd<OBJ, DN>(o, xc, g);
+  bool converged = false;
+  for (int it = 0; it < 1000; it++) {
+    double gmax = 0;
+#pragma unroll
+    for (int k = 0; k < DN; k++) gmax = fmax(gmax, fabs(g[k]));
+    if (gmax <= 1e-8) { converged = true; break; }
+    double s[DN], dphi0 = 0;
+#pragma unroll
+    for (int k = 0; k < DN; k++) {
+      double a = 0;
+#pragma unroll
+      for (int q = 0; q < DN; q++) a -= H[k][q] * g[q];
+      s[k] = a;
+      dphi0 += g[k] * a;
+    }
+    if (dphi0 >= 0) {  // not a descent direction: restart from steepest descent
+      dphi0 = 0;
+#pragma unroll
+      for (int k = 0; k < DN; k++) {
+#pragma unroll
+        for (int q = 0; q < DN; q++) H[k][q] = (k == q) ? 1.0 : 0.0;
+        s[k] = -g[k];
+        dphi0 -= g[k] * g[k];
+      }
+    }
+    double al = 1.0, fn = fx, xn[DN];
+    bool ok = false;
+    for (int ls = 0; ls < 50; ls++) {
+#pragma unroll
+      for (int k = 0; k < DN; k++) xn[k] = xc[k] + al * s[k];
+      fn = o(xn);
+      if (fn <= fx + 1e-4 * al * dphi0) { ok = true; break; }
+      double aq = -dphi0 * al * al / (2.0 * (fn - fx - dphi0 * al));
+      if (!(aq >= 0.1 * al)) aq = 0.1 * al;
+      if (aq > 0.5 * al) aq = 0.5 * al;
+      al = aq;
+    }
+    if (!ok) break;
+    double gn[DN], dx[DN], dg[DN], sy = 0, gnmax = 0;
+    fd_grad_nd<OBJ, DN>(o, xn, gn);
+    bool moved = false;
+#pragma unroll
+    for (int k = 0; k < DN; k++) {
+      dx[k] = xn[k] - xc[k];
+      dg[k] = gn[k] - g[k];
+      sy += dx[k] * dg[k];
+      moved |= dx[k] != 0.0;
+      gnmax = fmax(gnmax, fabs(gn[k]));
+    }
+    if (!moved) { converged = gnmax <= 1e-8; break; }
+    if (sy > 0) {  // H <- (I - rho dx dg') H (I - rho dg dx') + rho dx dx'
+      const double rho = 1.0 / sy;
+      double Hy[DN], yHy = 0;
+#pragma unroll
+      for (int k = 0; k < DN; k++) {
+        double a = 0;
+#pragma unroll
+        for (int q = 0; q < DN; q++) a += H[k][q] * dg[q];
+        Hy[k] = a;
+      }
+#pragma unroll
+      for (int k = 0; k < DN; k++) yHy += dg[k] * Hy[k];
+#pragma unroll
+      for (int k = 0; k < DN; k++)
+#pragma unroll
+        for (int q = 0; q < DN; q++)
+          H[k][q] += rho * ((1.0 + rho * yHy) * dx[k] * dx[q] - Hy[k] * dx[q] - dx[k] * Hy[q]);
+    }
+#pragma unroll
+    for (int k = 0; k < DN; k++) { xc[k] = xn[k]; g[k] = gn[k]; }
+    fx = fn;
+  }
+#pragma unroll
+  for (int k = 0; k < DN; k++) x[k] = xc[k];
+  return converged;
+}
+
 // _solveCCWNumeric! for one particle (NumericalCalculations.jl:413-452, :90-133)
-template <int KIND, int DN>
+template <int KIND, int DN, bool PARTIAL_BFGS = false>
 __device__ __forceinline__ void solve_particle_t(int manifold, const double *z, const double *other, int solve_b, double *x,
                                                  unsigned int &n_solves, unsigned int &n_nonconv, unsigned int &n_nan,
                                                  unsigned int &n_evals) {
@@ -569,6 +675,7 @@ __device__ __forceinline__ void solve_particle_t(int manifold, const double *z, 
   for (int d = 0; d < DN; d++) xc[d] = x[d];
   bool conv;
   if constexpr (DN == 1) conv = bfgs_1d(o, xc);
+  else if constexpr (PARTIAL_BFGS) conv = bfgs_nd<objective_t<KIND, DN>, DN>(o, xc);
   else conv = nelder_mead(o, xc);
   n_solves++;
   n_evals += o.evals;
@@ -579,6 +686,11 @@ __device__ __forceinline__ void solve_particle_t(int manifold, const double *z, 
   if (bad) { n_nan++; return; }
 #pragma unroll
   for (int d = 0; d < DN; d++) x[d] = is_circ(manifold, d) ? wrap_pi(xc[d]) : xc[d];
+}
+// a partial LinearRelative over two coordinates: BFGS on those two (the Euclid(2) objective with their values)
+__device__ __forceinline__ void solve_particle_partial2(const double *z, const double *other, int solve_b, double *x, unsigned int &a,
+                                                        unsigned int &b, unsigned int &c, unsigned int &e) {
+  solve_particle_t<NBP_F_LINREL, 2, true>(NBP_EUCLID2, z, other, solve_b, x, a, b, c, e);
 }
 
 // wave-uniform dispatch on (factor kind, tangent dimension)

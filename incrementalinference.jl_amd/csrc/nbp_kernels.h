@@ -184,8 +184,12 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     // evalPotentialSpecific(relative), EvalFactor.jl:321-395
     // a partial relative factor (one partial coordinate, validated on the host) measures, inflates
     // and solves that coordinate only (EvalFactor.jl:184-198, NumericalCalculations.jl:424)
-    const int pmask = d->partial_mask, pdim = pmask ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;
-    const int zdim = pmask ? 1 : ((kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1));
+    // a partial relative factor measures, inflates and solves its `.partial` coordinates only (validated on the host:
+    // LinearRelative, one or two of the variable's coordinates)
+    const int pmask = d->partial_mask, npd = __popc(pmask & 7);
+    const int pdim = pmask ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;                  // first partial coordinate
+    const int pdim2 = (npd > 1) ? ((pmask & 1) && (pmask & 2) ? 1 : 2) : -1;              // second one
+    const int zdim = pmask ? npd : ((kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1));
     double z[3] = {0, 0, 0};
     if (live) sample_measurement(d, n, zdim, z, arena, S, N);  // sampleFactor!, CalcFactor.jl:578
     const int sf1 = d->sfidx + 1;
@@ -216,7 +220,15 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
           if (myh == hyp) {
             double x[3] = {X[n], X[N + n], X[2 * N + n]};
             add_entropy(M, D, x, n, spread, d->seed, (g * 8 + c) * 2, pmask);
-            if (pdim >= 0) {
+            if (pdim2 >= 0) {  // two partial coordinates: BFGS on the pair (NumericalCalculations.jl:108,424)
+              double x2[3] = {pdim == 0 ? x[0] : x[1], pdim2 == 1 ? x[1] : x[2], 0};
+              const double o2[3] = {pdim == 0 ? oth[0] : oth[1], pdim2 == 1 ? oth[1] : oth[2], 0};
+              solve_particle_partial2(z, o2, solve_b, x2, n_solves, n_nonconv, n_nan, n_evals);
+              if (pdim == 0) x[0] = x2[0];
+              else x[1] = x2[0];
+              if (pdim2 == 1) x[1] = x2[1];
+              else x[2] = x2[1];
+            } else if (pdim >= 0) {
               double x1[3] = {pdim == 0 ? x[0] : (pdim == 1 ? x[1] : x[2]), 0, 0};
               const double o1[3] = {pdim == 0 ? oth[0] : (pdim == 1 ? oth[1] : oth[2]), 0, 0};
               solve_particle(NBP_F_LINREL, NBP_EUCLID1, z, o1, solve_b, x1, n_solves, n_nonconv, n_nan, n_evals);

@@ -150,14 +150,15 @@ class PartialPrior(Prior):
 
 
 class PartialLinearRelative(LinearRelative):
-    """r = z - (x2[k] - x1[k]) on one coordinate k = partial[0]: the `DevelopPartialPairwise` factor of
-    test/testpartialconstraint.jl:31-45 (`.partial` relative factors solve, and inflate, only their
-    partial coordinates: EvalFactor.jl:184-198, NumericalCalculations.jl:424)."""
+    """r = z - (x2[k] - x1[k]) on the coordinates k in `partial` (one or two of them): the `DevelopPartialPairwise`
+    factor of test/testpartialconstraint.jl:31-45 and its two-coordinate sibling (`.partial` relative factors solve, and
+    inflate, only their partial coordinates -- with BFGS whatever their number: EvalFactor.jl:184-198,
+    NumericalCalculations.jl:108,424).  Z has len(partial) dimensions."""
 
     def __init__(self, varType, Z, partial=(2,)):
         self.Z, self.partial = Z, tuple(partial)
-        if len(self.partial) != 1:
-            raise ValueError("PartialLinearRelative supports one partial coordinate")
+        if not 1 <= len(self.partial) <= 2 or len(self.partial) >= varType.dim:
+            raise ValueError("PartialLinearRelative: one or two partial coordinates, fewer than the variable has")
         self.partial_mask = _partial_mask(partial, varType.dim)
 
 

@@ -499,6 +499,80 @@ int orc_bfgs_1d(const objective_t *o, double *x, int *iters) {
   return converged;
 }
 
+/* Optim.BFGS, n-dimensional: the solver of every partial factor (`alg = islen1 ? BFGS : NelderMead`, islen1 true when
+ * ccw.partial, NumericalCalculations.jl:108,424).  Initial inverse Hessian I, central finite differences, g_tol = 1e-8 on
+ * the max-norm of the gradient; the line search is the Armijo / quadratic-interpolation one of orc_bfgs_1d (documented
+ * deviation from HagerZhang), to which this reduces for n = 1. */
+static void fd_grad_nd(const objective_t *o, int n, const double *x, double *g) {
+  for (int k = 0; k < n; k++) {
+    double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x[k])), xp[3], xm[3];
+    for (int q = 0; q < n; q++) { xp[q] = x[q]; xm[q] = x[q]; }
+    xp[k] += h; xm[k] -= h;
+    g[k] = (objective(o, xp) - objective(o, xm)) / (2.0 * h);
+  }
+}
+int orc_bfgs_nd(const objective_t *o, int n, double *x, int *iters) {
+  double xc[3], g[3], H[3][3], fx;
+  for (int k = 0; k < n; k++) { xc[k] = x[k]; for (int q = 0; q < n; q++) H[k][q] = k == q ? 1.0 : 0.0; }
+  fx = objective(o, xc);
+  fd_grad_nd(o, n, xc, g);
+  int converged = 0, it = 0;
+  for (it = 0; it < 1000; it++) {
+    double gmax = 0;
+    for (int k = 0; k < n; k++) gmax = fmax(gmax, fabs(g[k]));
+    if (gmax <= 1e-8) { converged = 1; break; }
+    double s[3], dphi0 = 0;
+    for (int k = 0; k < n; k++) {
+      double a = 0;
+      for (int q = 0; q < n; q++) a -= H[k][q] * g[q];
+      s[k] = a;
+      dphi0 += g[k] * a;
+    }
+    if (dphi0 >= 0) {
+      dphi0 = 0;
+      for (int k = 0; k < n; k++) {
+        for (int q = 0; q < n; q++) H[k][q] = k == q ? 1.0 : 0.0;
+        s[k] = -g[k];
+        dphi0 -= g[k] * g[k];
+      }
+    }
+    double al = 1.0, fn = fx, xn[3];
+    int ok = 0;
+    for (int ls = 0; ls < 50; ls++) {
+      for (int k = 0; k < n; k++) xn[k] = xc[k] + al * s[k];
+      fn = objective(o, xn);
+      if (fn <= fx + 1e-4 * al * dphi0) { ok = 1; break; }
+      double aq = -dphi0 * al * al / (2.0 * (fn - fx - dphi0 * al));
+      if (!(aq >= 0.1 * al)) aq = 0.1 * al;
+      if (aq > 0.5 * al) aq = 0.5 * al;
+      al = aq;
+    }
+    if (!ok) break;
+    double gn[3], dx[3], dg[3], sy = 0, gnmax = 0;
+    int moved = 0;
+    fd_grad_nd(o, n, xn, gn);
+    for (int k = 0; k < n; k++) {
+      dx[k] = xn[k] - xc[k]; dg[k] = gn[k] - g[k];
+      sy += dx[k] * dg[k];
+      moved |= dx[k] != 0.0;
+      gnmax = fmax(gnmax, fabs(gn[k]));
+    }
+    if (!moved) { converged = gnmax <= 1e-8; break; }
+    if (sy > 0) { /* H <- (I - rho dx dg') H (I - rho dg dx') + rho dx dx' */
+      double rho = 1.0 / sy, Hy[3], yHy = 0;
+      for (int k = 0; k < n; k++) { double a = 0; for (int q = 0; q < n; q++) a += H[k][q] * dg[q]; Hy[k] = a; }
+      for (int k = 0; k < n; k++) yHy += dg[k] * Hy[k];
+      for (int k = 0; k < n; k++)
+        for (int q = 0; q < n; q++) H[k][q] += rho * ((1.0 + rho * yHy) * dx[k] * dx[q] - Hy[k] * dx[q] - dx[k] * Hy[q]);
+    }
+    for (int k = 0; k < n; k++) { xc[k] = xn[k]; g[k] = gn[k]; }
+    fx = fn;
+  }
+  for (int k = 0; k < n; k++) x[k] = xc[k];
+  if (iters) *iters = it;
+  return converged;
+}
+
 /* _solveCCWNumeric! for one particle, NumericalCalculations.jl:413-452 + :90-133 */
 static void solve_particle(int kind, int manifold, const double *z, const double *other, int solve_b, double *x) {
   objective_t o;
@@ -874,12 +948,12 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
   } else {
     /* evalPotentialSpecific(relative), EvalFactor.jl:321-395 */
     int zdim = factor_zdim(d->factor_kind, d->manifold);
-    int pdim = -1; /* the one partial coordinate of a partial relative factor */
+    int pdim = -1, pdim2 = -1; /* the partial coordinates (one or two) of a partial relative factor */
     if (d->partial_mask) {
       int cnt = 0;
-      for (int k = 0; k < D; k++) if ((d->partial_mask >> k) & 1) { cnt++; pdim = k; }
-      if (d->factor_kind != NBP_F_LINREL || cnt != 1 || is_circ(d->manifold, pdim)) { free(mhidx); return NBP_ERR_ARG; }
-      zdim = 1;
+      for (int k = 0; k < D; k++) if ((d->partial_mask >> k) & 1) { if (cnt == 0) pdim = k; else pdim2 = k; cnt++; }
+      if (d->factor_kind != NBP_F_LINREL || cnt < 1 || cnt > 2) { free(mhidx); return NBP_ERR_ARG; }
+      zdim = cnt;
     }
     double *X = out; /* ccwl.varValsAll[sfidx] = deepcopy(target), CalcFactor.jl:543-548 */
     {
@@ -915,7 +989,17 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
             double x[3], oth[3];
             const int io = anyn_index(n, slot_count(O, N), d->seed, vother); /* _getindex_anyn */
             for (int k = 0; k < D; k++) { x[k] = X[k * N + n]; oth[k] = O[k * N + io]; }
-            if (pdim >= 0) /* `.partial` -> islen1 -> BFGS (NumericalCalculations.jl:424); the gradient is
+            if (pdim2 >= 0) { /* two partial coordinates: n-D BFGS on the pair */
+              objective_t o2;
+              o2.kind = NBP_F_LINREL; o2.manifold = NBP_EUCLID2; o2.D = 2; o2.solve_b = solve_b;
+              for (int k = 0; k < 3; k++) { o2.z[k] = Z[3 * n + k]; o2.other[k] = 0.0; }
+              o2.other[0] = oth[pdim]; o2.other[1] = oth[pdim2];
+              double x2[3] = {x[pdim], x[pdim2], 0};
+              t_diag.solves++;
+              if (!orc_bfgs_nd(&o2, 2, x2, 0)) t_diag.nonconverged++;
+              if (isnan(x2[0]) || isnan(x2[1])) t_diag.nan_results++;
+              else { x[pdim] = x2[0]; x[pdim2] = x2[1]; }
+            } else if (pdim >= 0) /* `.partial` -> islen1 -> BFGS (NumericalCalculations.jl:424); the gradient is
                               zero off the partial coordinate, so the search runs on that coordinate alone */
               solve_particle(NBP_F_LINREL, NBP_EUCLID1, Z + 3 * n, oth + pdim, solve_b, x + pdim);
             else

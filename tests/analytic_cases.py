@@ -471,3 +471,36 @@ def case_euclid_distance_ring(backend, N=128):
             out[(man, solve_b)] = r.max()
             assert np.median(r) < 2e-4 and (r < 2e-3).mean() > 0.97, (man, solve_b, np.median(r), r.max())
     return out
+
+
+def case_partial_relative_over_two_coordinates(backend, N=128):
+    """A `.partial` relative factor over two of three coordinates (BFGS on the pair: NumericalCalculations.jl:108,424):
+    the partial coordinates land on the root of the residual, the third keeps the target's own value bit for bit (it gets
+    neither entropy nor a solve, EvalFactor.jl:184-198)."""
+    rng = np.random.default_rng(11)
+    man = abi.EUCLID3
+    out = {}
+    for mask, coords in ((0b101, (0, 2)), (0b011, (0, 1)), (0b110, (1, 2))):
+        o = rng.normal(0.0, 2.0, (N, 3))
+        x0 = rng.normal(0.0, 2.0, (N, 3))
+        z = [4.0, -1.5]
+        for solve_b in (1, 0):
+            be = backend(N, 3)
+            try:
+                be.slot_write(0, man, o if solve_b else x0, np.ones(3))
+                be.slot_write(1, man, x0 if solve_b else o, np.ones(3))
+                d = relative_factor_desc(abi.F_LINREL, man, 2, 1 if solve_b else 0, [0, 1], 2, 555 + solve_b, z, [0.0, 0.0])
+                d.partial_mask, d.skip_bandwidth = mask, 1
+                be.run_proposals([d])
+                got, _, ipc = be.belief_read(2, man)
+            finally:
+                be.close()
+            sign = 1.0 if solve_b else -1.0
+            for i, k in enumerate(coords):
+                err = np.abs(got[:, k] - (o[:, k] + sign * z[i])).max()
+                out[(mask, solve_b, k)] = err
+                assert err < 1e-6, (mask, solve_b, k, err)
+            free = [k for k in range(3) if k not in coords][0]
+            assert np.array_equal(got[:, free], x0[:, free])
+            assert list(ipc) == [float((mask >> k) & 1) for k in range(3)]  # ones on `.partial`, EvalFactor.jl:383-391
+    return out

@@ -30,3 +30,7 @@ def test_solver_finds_the_residual_root(oracle_backend):
 
 def test_euclid_distance_ring(oracle_backend):
     ac.case_euclid_distance_ring(oracle_backend)
+
+
+def test_partial_relative_over_two_coordinates(oracle_backend):
+    ac.case_partial_relative_over_two_coordinates(oracle_backend)

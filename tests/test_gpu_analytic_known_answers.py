@@ -33,3 +33,7 @@ def test_solver_finds_the_residual_root(hip_backend):
 
 def test_euclid_distance_ring(hip_backend):
     ac.case_euclid_distance_ring(hip_backend)
+
+
+def test_partial_relative_over_two_coordinates(hip_backend):
+    ac.case_partial_relative_over_two_coordinates(hip_backend)

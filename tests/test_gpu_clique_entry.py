@@ -66,8 +66,16 @@ def test_clique_entry_rejects_bad_input(hip_backend):
     be = hip_backend(64, 8)
     try:
         bel = {v: Belief(abi.EUCLID2, np.zeros((64, 2)), np.ones(2)) for v in ("x0", "x1")}
-        with pytest.raises(ValueError):  # a Gibbs id list naming a variable outside the clique
-            clique_solve(be, fg.solverParams, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [fg.getFactor(fg.ls("x0")[0])], bel, 1,
-                         lists={"itervar": ["x0", "x1", "x1"], "directFrtlMsg": []}, msgs=[("x1", Belief(abi.EUCLID2, np.zeros((32, 2)), np.ones(2)))])
+        f = fg.getFactor(fg.ls("x0")[0])
+        with pytest.raises(ValueError):  # unknown manifold code
+            clique_solve(be, fg.solverParams, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2, 9], [f], bel, 1, lists={"itervar": ["x0"]})
+        with pytest.raises(ValueError):  # more frontals + separators than variables
+            clique_solve(be, fg.solverParams, 1, ["x0", "x1"], 2, 1, [abi.EUCLID2] * 2, [f], bel, 1, lists={"itervar": ["x0"]})
+        with pytest.raises(ValueError):  # a context with too few slots for the clique
+            small = hip_backend(64, 2)
+            try:
+                clique_solve(small, fg.solverParams, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [f], bel, 1, lists={"itervar": ["x0"]})
+            finally:
+                small.close()
     finally:
         be.close()

@@ -1,0 +1,46 @@
+"""-m gpu: the BASELINE.json configurations 2', 3, 4 and 5 at FULL size on one MI355X (4 and 5 are 8-GPU targets; one GPU
+holds them whole), through the same object bench.py times: native host (graph initialisation, ordering, tree, compile
+behind the C ABI), one solve, size-independent properties of the result:
+  * one message per tree edge and direction, every clique solved;
+  * every sampled posterior finite with positive bandwidths;
+  * posterior means of the sampled poses within the configuration's tolerance of the synthetic ground truth
+    (config 3 is multi-modal by construction: the share of particles at the true pose is reported instead);
+  * a second solve with another seed gives the same figures (the program is replayed as a hipGraph)."""
+import sys
+import os
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from parity_utils import iif
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("key", ["2p", "3", "4", "5"])
+def test_full_size_configuration(key):
+    from bench_support import RankSolve, workloads
+    wl = workloads(iif)[key]
+    rs = RankSolve(iif, wl, wl.size, wl.N, 0, 1, 0, None)
+    rs.prepare()
+    try:
+        nvars = len(rs.fg.ls())
+        assert nvars >= {"2p": 10000, "3": 2004, "4": 5000, "5": 10000}[key]
+        assert rs.global_messages == 2 * (rs.stats["cliques_global"] - 1)
+        assert rs.stats["updates_global"] >= 2 * nvars  # every variable is updated on the way up and on the way down
+        res = []
+        for seed in (0, 1, 2):  # the third run replays the captured graph
+            rs.step(seed)
+            rs.be.synchronize()
+            rs.check_posteriors()
+            res.append((rs.posterior_max_mean_err, rs.posterior_mode_share))
+        d = rs.be.diag()
+        assert d["nan_results"] == 0 and d["solves"] > 0
+        assert d["nonconverged"] <= 2e-3 * d["solves"]  # the degenerate-simplex starts of Optim's AffineSimplexer
+        if key == "3":
+            assert all(r[1][1] > 0.1 for r in res), res  # median share of particles within 0.35 rad of the true pose
+        print(f"config {key}: {nvars} variables, {rs.stats['cliques_global']} cliques, {rs.stats['updates_global']} updates; "
+              f"posterior figures over three seeds: {res}")
+    finally:
+        rs.close()

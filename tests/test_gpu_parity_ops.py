@@ -256,14 +256,16 @@ def test_partial_prior_proposal(oracle_backend, hip_backend, manifold, mask, nul
             assert np.abs(c1[:, k] - c0[:, k]).max() > 1e-3
 
 
-@pytest.mark.parametrize("manifold,mask", [(abi.EUCLID2, 2), (abi.EUCLID2, 1), (abi.EUCLID3, 4)])
+@pytest.mark.parametrize("manifold,mask", [(abi.EUCLID2, 2), (abi.EUCLID2, 1), (abi.EUCLID3, 4), (abi.EUCLID3, 5), (abi.EUCLID3, 6), (abi.EUCLID2, 3)])
 @pytest.mark.parametrize("sfidx", [0, 1])
 def test_partial_relative_conv(oracle_backend, hip_backend, manifold, mask, sfidx):
     N = 200
     rng = np.random.default_rng(300 + manifold + mask + sfidx)
     a = rand_points(rng, manifold, N, center=0.0, spread=0.3)
     b = rand_points(rng, manifold, N, center=1.0, spread=0.3)
-    d = relative_factor_desc(abi.F_LINREL, manifold, 2, sfidx, [0, 1], 2, 888 + mask + sfidx, [10.0], [1.0])
+    two = bin(mask).count("1") == 2  # two partial coordinates: n-D BFGS on the pair
+    d = relative_factor_desc(abi.F_LINREL, manifold, 2, sfidx, [0, 1], 2, 888 + mask + sfidx, [10.0, -4.0] if two else [10.0],
+                             [1.0, 0.5] if two else [1.0])
     d.partial_mask = mask
 
     def setup(be):
@@ -274,10 +276,11 @@ def test_partial_relative_conv(oracle_backend, hip_backend, manifold, mask, sfid
                 lambda be: be.slot_read(2, manifold))
     assert_points_close(manifold, o[0], h[0], what="partial relative conv")
     np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
-    k = {1: 0, 2: 1, 4: 2}[mask]
+    ks = [k for k in range(3) if (mask >> k) & 1]
     tgt, oth = (b, a) if sfidx == 1 else (a, b)
     sign = 1.0 if sfidx == 1 else -1.0
-    assert abs((h[0][:, k] - oth[:, k]).mean() - sign * 10.0) < 0.5
+    for k, zm in zip(ks, [10.0, -4.0]):
+        assert abs((h[0][:, k] - oth[:, k]).mean() - sign * zm) < 0.5
     for kk in range(abi.MANIFOLD_DIM[manifold]):
         if kk != k:
             np.testing.assert_allclose(h[0][:, kk], tgt[:, kk], atol=1e-12)
@@ -328,8 +331,8 @@ def test_partial_product(oracle_backend, hip_backend, manifold, masks, N):
 
 def test_partial_descriptors_are_validated(hip_backend):
     be = hip_backend(64, 4, 0)
-    d = relative_factor_desc(abi.F_LINREL, abi.EUCLID2, 2, 1, [0, 1], 2, 1, [1.0], [1.0])
-    d.partial_mask = 3  # two partial coordinates on a relative factor: not supported
+    d = relative_factor_desc(abi.F_LINREL, abi.EUCLID3, 2, 1, [0, 1], 2, 1, [1.0], [1.0])
+    d.partial_mask = 7  # three partial coordinates on a relative factor: not supported (one or two are)
     with pytest.raises(iif.NbpError):
         be.run_proposals([d])
     d = relative_factor_desc(abi.F_PRIOR, abi.EUCLID2, 1, 0, [0], 1, 1, [1.0], [1.0])
