@@ -73,7 +73,7 @@ class RankSolve:
             from iif_amd.dist_solver import ShardedTreeSolve
             self.impl = ShardedTreeSolve(iif, fg, self.N, self.rank, self.world, self.local, self.dist)
             self.impl.prepare()
-            self.be, self.main = self.impl.be, self.impl.tp.main
+            self.be, self.main = self.impl.be, self.impl.main
             self.global_messages, self.stats = self.impl.global_messages, self.impl.stats
             self.host_setup = self.impl.host_setup
             self.mine = self.impl.mine

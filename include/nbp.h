@@ -275,6 +275,24 @@ nbp_status nbp_program_reseed(nbp_program *prog, uint64_t salt); /* xor-mix all 
 nbp_status nbp_program_num_stages(nbp_program *prog, int32_t *out);
 nbp_status nbp_program_destroy(nbp_program *prog);
 
+/* ---- separator exchange between ranks (one process per GPU) -------------------------------------------------------
+ * The reference moves a LikelihoodMessage through a Channel per tree edge (JunctionTreeUtils.jl:943-956,
+ * CliqueStateMachine.jl:221-234/617-629); across GPUs the payload -- whole slots = TreeBelief (val, bw, infoPerCoord,
+ * count) -- travels point to point over RCCL (xGMI), all messages of one exchange point in ONE grouped call on the
+ * library's stream: stream-ordered with the producing and consuming kernels, no host synchronisation.
+ * nbp_comm_unique_id: rank 0 makes the id (NBP_COMM_ID_BYTES bytes) and hands it to every rank by whatever means the
+ * host has (a broadcast over torch.distributed, MPI, a file); nbp_comm_create is collective over the ranks. */
+#define NBP_COMM_ID_BYTES 128
+typedef struct nbp_comm nbp_comm;
+#ifndef NBP_XFER_DEFINED
+#define NBP_XFER_DEFINED
+typedef struct nbp_xfer { int32_t peer; int32_t slot; } nbp_xfer;
+#endif
+nbp_status nbp_comm_unique_id(void *id_out /* NBP_COMM_ID_BYTES */);
+nbp_status nbp_comm_create(nbp_ctx *ctx, int32_t world, int32_t rank, const void *id, nbp_comm **out);
+nbp_status nbp_comm_destroy(nbp_comm *comm);
+nbp_status nbp_exchange(nbp_ctx *ctx, nbp_comm *comm, const nbp_xfer *sends, int32_t n_sends, const nbp_xfer *recvs, int32_t n_recvs);
+
 /* per-kernel timing with HIP events on the library stream (bench.py roofline leg) */
 nbp_status nbp_timing_enable(nbp_ctx *ctx, int32_t on);
 /* ms[4] / launches[4] per kernel: 0 = proposal kernel, 1 = prep kernel = bandwidth fits + KD-tree builds,

@@ -125,6 +125,20 @@ nbp_status nbp_tree_compile(nbp_tree *t, nbp_ctx *ctx, uint64_t seed, nbp_progra
 /* the host half of nbp_tree_compile alone: build the stage descriptors (no device needed) */
 nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed);
 
+/* ---- multi-rank compile: the cliques of a tree sharded over `world` ranks (one process per GPU) --------------------
+ * nbp_tree_partition proposes an owner per clique (connected subtrees of balanced work + the cliques above the cut);
+ * nbp_tree_set_owner makes the tree compile THIS rank's share: slots and stages for its own cliques only, landing
+ * ("ghost") slots for the up messages of children that live elsewhere, and between the stage segments the exchanges
+ * of separator beliefs on tree edges that cross ranks.  Every rank computes the same stage times for the whole tree,
+ * so both ends of an exchange agree on where it sits.  Call before nbp_tree_plan_slots.  The segment list of the last
+ * compile: kind 0 = run stages [first, last) (nbp_program_run), kind 1 = exchange (nbp_exchange). */
+/* nbp_xfer (peer rank, slot) is declared in nbp.h */
+nbp_status nbp_tree_partition(const nbp_tree *t, int32_t world, int32_t *owner_out /* [cliques] */);
+nbp_status nbp_tree_set_owner(nbp_tree *t, const int32_t *owner /* [cliques]; NULL = single rank */, int32_t rank);
+int32_t nbp_tree_num_segments(const nbp_tree *t);
+nbp_status nbp_tree_segment(const nbp_tree *t, int32_t i, int32_t *kind, int32_t *first, int32_t *last, int32_t *nsend, int32_t *nrecv,
+                            nbp_xfer *sends, nbp_xfer *recvs, int32_t cap);
+
 typedef struct nbp_tree_stats {
   int64_t stages, proposals, products, updates_up, updates_down, messages, slots;
   int64_t alg_bytes;          /* sum of B_upd over all updates, SURVEY 8(d) */

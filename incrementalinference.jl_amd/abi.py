@@ -65,6 +65,13 @@ class CopyDesc(C.Structure):
     _fields_ = [("src_slot", C.c_int32), ("dst_slot", C.c_int32)]
 
 
+class Xfer(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("slot", C.c_int32)]
+
+
+COMM_ID_BYTES = 128
+
+
 class Diag(C.Structure):
     _fields_ = [
         ("solves", C.c_int64),
@@ -91,6 +98,7 @@ EXPORTS = [
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
     "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_destroy",
     "nbp_timing_enable", "nbp_timing_read", "nbp_diag_read",
+    "nbp_comm_unique_id", "nbp_comm_create", "nbp_comm_destroy", "nbp_exchange",
 ]
 
 _lib = None
@@ -156,6 +164,10 @@ def load_library(path=None):
     lib.nbp_program_reseed.argtypes = [vp, C.c_uint64]
     lib.nbp_program_num_stages.argtypes = [vp, ip]
     lib.nbp_program_destroy.argtypes = [vp]
+    lib.nbp_comm_unique_id.argtypes = [vp]
+    lib.nbp_comm_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    lib.nbp_comm_destroy.argtypes = [vp]
+    lib.nbp_exchange.argtypes = [vp, vp, C.POINTER(Xfer), i32, C.POINTER(Xfer), i32]
     lib.nbp_timing_enable.argtypes = [vp, i32]
     lib.nbp_timing_read.argtypes = [vp, dp, C.POINTER(i64)]
     lib.nbp_diag_read.argtypes = [vp, C.POINTER(Diag), i32]

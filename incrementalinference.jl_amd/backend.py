@@ -46,6 +46,7 @@ class HipBackend:
         if self._ctx:
             for prog in list(getattr(self, "_programs", ())):  # a program must not outlive its context
                 prog.close()
+            self.comm_destroy()
             self.lib.nbp_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -179,6 +180,30 @@ class HipBackend:
 
     def synchronize(self):
         self._check(self.lib.nbp_synchronize(self._ctx))
+
+    # ---- separator exchange between ranks: RCCL point-to-point from C, on the library stream -----------------------------
+    def comm_unique_id(self):
+        buf = (C.c_char * abi.COMM_ID_BYTES)()
+        self._check(self.lib.nbp_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_create(self, world, rank, uid):
+        h = C.c_void_p()
+        buf = (C.c_char * abi.COMM_ID_BYTES).from_buffer_copy(uid)
+        self._check(self.lib.nbp_comm_create(self._ctx, world, rank, buf, C.byref(h)))
+        self._comm = h
+        return h
+
+    def comm_destroy(self):
+        if getattr(self, "_comm", None):
+            self.lib.nbp_comm_destroy(self._comm)
+            self._comm = None
+
+    def exchange(self, sends, recvs):
+        """one grouped ncclSend / ncclRecv of whole slots: sends / recvs = [(peer rank, slot)]; asynchronous (stream-ordered)"""
+        sx = (abi.Xfer * max(1, len(sends)))(*[abi.Xfer(p, s) for p, s in sends])
+        rx = (abi.Xfer * max(1, len(recvs)))(*[abi.Xfer(p, s) for p, s in recvs])
+        self._check(self.lib.nbp_exchange(self._ctx, self._comm, sx, len(sends), rx, len(recvs)))
 
     # ---- resident programs (clique seam) -----------------------------------------------------
     def program(self, stages, lazy_bandwidth=False):

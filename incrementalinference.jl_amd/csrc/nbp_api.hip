@@ -10,6 +10,9 @@
 
 #include <unordered_map>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the entry points are resolved with dlsym (see rccl_api)
+
 #include "nbp_kernels.h"
 
 static thread_local std::string g_err;
@@ -1248,6 +1251,113 @@ nbp_status nbp_program_destroy(nbp_program *p) {
   }
   delete p;
   return NBP_OK;
+}
+
+// ---- separator exchange between ranks: RCCL point-to-point over xGMI, from C -----------------------------------------
+// The messages of a tree solve are single slots (4.9 KB at N = 200) on the few tree edges that cross a rank boundary:
+// latency-bound traffic, so all messages of one exchange point go into ONE ncclGroupStart / ncclGroupEnd of ncclSend /
+// ncclRecv on the library's own stream -- stream-ordered with the kernels that produce and consume the slots, no host
+// synchronisation, no ring collective.  RCCL is bound at run time (dlopen + dlsym): a process that already has RCCL loaded
+// (PyTorch brings its own) keeps exactly one copy, and libnbp.so has no link-time dependency on it.
+struct rccl_api {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static rccl_api g_rccl;
+static nbp_status rccl_load() {
+  if (g_rccl.Send) return NBP_OK;
+  const char *env = getenv("NBP_RCCL_LIB");
+  const char *names[] = {env, "librccl.so", "librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names)  // a copy that is already mapped first
+    if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  for (const char *n : names)
+    if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(NBP_ERR_HIP, std::string("RCCL not found (librccl.so): ") + (dlerror() ? dlerror() : ""));
+  g_rccl.h = h;
+#define NBP_RCCL_SYM(F) g_rccl.F = (decltype(g_rccl.F))dlsym(h, "nccl" #F); if (!g_rccl.F) return fail(NBP_ERR_HIP, "RCCL: missing symbol nccl" #F)
+  NBP_RCCL_SYM(GetUniqueId);
+  NBP_RCCL_SYM(CommInitRank);
+  NBP_RCCL_SYM(CommDestroy);
+  NBP_RCCL_SYM(GroupStart);
+  NBP_RCCL_SYM(GroupEnd);
+  NBP_RCCL_SYM(Recv);
+  NBP_RCCL_SYM(GetErrorString);
+  NBP_RCCL_SYM(Send);
+#undef NBP_RCCL_SYM
+  return NBP_OK;
+}
+#define RCCLCHK(expr)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) return fail(NBP_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+struct nbp_comm {
+  ncclComm_t comm = nullptr;
+  nbp_ctx *ctx = nullptr;
+  int world = 0, rank = 0;
+};
+
+nbp_status nbp_comm_unique_id(void *id_out) {
+  if (!id_out) return fail(NBP_ERR_ARG, "null argument");
+  nbp_status rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId id;
+  RCCLCHK(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, NBP_COMM_ID_BYTES);
+  return NBP_OK;
+}
+
+nbp_status nbp_comm_create(nbp_ctx *c, int32_t world, int32_t rank, const void *id, nbp_comm **out) {
+  if (!c || !id || !out) return fail(NBP_ERR_ARG, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(NBP_ERR_RANGE, "comm: rank / world");
+  nbp_status rc = rccl_load();
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId uid;
+  static_assert(sizeof(uid) == NBP_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(&uid, id, sizeof(uid));
+  nbp_comm *m = new nbp_comm();
+  m->ctx = c; m->world = world; m->rank = rank;
+  ncclResult_t r = g_rccl.CommInitRank(&m->comm, world, uid, rank);
+  if (r != ncclSuccess) { delete m; return fail(NBP_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+  *out = m;
+  return NBP_OK;
+}
+
+nbp_status nbp_comm_destroy(nbp_comm *m) {
+  if (!m) return NBP_OK;
+  if (m->comm && g_rccl.CommDestroy) {
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    g_rccl.CommDestroy(m->comm);
+  }
+  delete m;
+  return NBP_OK;
+}
+
+nbp_status nbp_exchange(nbp_ctx *c, nbp_comm *m, const nbp_xfer *sends, int32_t ns, const nbp_xfer *recvs, int32_t nr) {
+  if (!c || !m || (ns > 0 && !sends) || (nr > 0 && !recvs)) return fail(NBP_ERR_ARG, "null argument");
+  if (m->ctx != c) return fail(NBP_ERR_ARG, "exchange: the communicator belongs to another context");
+  for (int i = 0; i < ns; i++)
+    if (sends[i].peer < 0 || sends[i].peer >= m->world || sends[i].slot < 0 || sends[i].slot >= c->n_slots) return fail(NBP_ERR_RANGE, "exchange: send");
+  for (int i = 0; i < nr; i++)
+    if (recvs[i].peer < 0 || recvs[i].peer >= m->world || recvs[i].slot < 0 || recvs[i].slot >= c->n_slots) return fail(NBP_ERR_RANGE, "exchange: recv");
+  if (ns + nr == 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  RCCLCHK(g_rccl.GroupStart());
+  for (int i = 0; i < ns; i++) RCCLCHK(g_rccl.Send(c->arena + c->S * sends[i].slot, (size_t)c->S, ncclDouble, sends[i].peer, m->comm, c->stream));
+  for (int i = 0; i < nr; i++) RCCLCHK(g_rccl.Recv(c->arena + c->S * recvs[i].slot, (size_t)c->S, ncclDouble, recvs[i].peer, m->comm, c->stream));
+  RCCLCHK(g_rccl.GroupEnd());
+  return NBP_OK;  // stream-ordered: the next launch on the library stream sees the received slots
 }
 
 // ---- timing / diagnostics -------------------------------------------------------------------------------

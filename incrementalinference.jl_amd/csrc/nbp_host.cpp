@@ -100,6 +100,18 @@ struct nbp_tree {
   bool stored = false;  // NBP_SOLVER_STORED_MEASUREMENTS
   std::vector<std::vector<int>> jdnsched;  // joint mode: down schedule per clique
   std::map<std::array<int, 5>, uint64_t> meas_seed;  // (clique, tag, a, b, variable of a message) -> seed of the last fresh draw
+  // multi-rank compile (solver.TreeProgram(owner=, rank=)): owner[c] = rank of clique c (index c - 1); this rank compiles
+  // only its own cliques; tree edges that cross a rank boundary become exchange segments between the stage segments
+  std::vector<int> owner;
+  int rank = 0;
+  std::vector<std::map<int, int>> ghost;   // per clique: variable -> landing slot of its up message (children on other ranks)
+  struct Segment { int kind, first, last; std::vector<std::array<int, 2>> sends, recvs; };  // kind 0 = run [first, last), 1 = exchange (peer, slot)
+  std::vector<Segment> segments;
+  int seg_start = 0;
+  bool mine(int cid) const { return owner.empty() || owner[cid - 1] == rank; }
+  int own(int cid) const { return owner.empty() ? 0 : owner[cid - 1]; }
+  // the slot a parent's MsgPrior reads for variable v of child `chd`
+  int msg_slot(int chd, int v) const { return mine(chd) ? B[chd - 1].at(v) : ghost[chd - 1].at(v); }
 };
 
 namespace {
@@ -651,6 +663,40 @@ void add_stage(nbp_tree *t, int kind, const void *descs, size_t esz, int n) {
   t->stages.push_back(std::move(st));
 }
 
+// solver.TreeProgram._exchange: `edges` = (src rank, src slot or -1, dst rank, dst slot or -1) in a globally agreed order;
+// a rank only knows the slots on its own side.  An empty copy stage makes libnbp flush the deferred bandwidth fits before
+// slots travel; the stage list is cut there and an exchange segment recorded.
+struct Edge { int src_rank, src_slot, dst_rank, dst_slot; };
+void rank_exchange(nbp_tree *t, const std::vector<Edge> &edges) {
+  nbp_tree::Segment x;
+  x.kind = 1;
+  x.first = x.last = 0;
+  for (const Edge &e : edges) {
+    if (e.src_rank == t->rank && e.dst_rank != t->rank) x.sends.push_back({e.dst_rank, e.src_slot});
+    if (e.dst_rank == t->rank && e.src_rank != t->rank) x.recvs.push_back({e.src_rank, e.dst_slot});
+  }
+  if (x.sends.empty() && x.recvs.empty()) return;
+  add_stage(t, NBP_STAGE_COPIES, nullptr, sizeof(nbp_copy_desc), 0);
+  t->segments.push_back({0, t->seg_start, (int)t->stages.size(), {}, {}});
+  t->segments.push_back(x);
+  t->seg_start = (int)t->stages.size();
+}
+// up messages that cross a rank boundary: the child's separator beliefs (and, in joint-message mode, the KDEs of its
+// differential factors) -> the parent rank's landing slots
+void up_edges(const nbp_tree *t, const std::vector<int> &cliques, std::vector<Edge> &edges) {
+  for (int cid : cliques) {
+    const Clique &c = t->cl[cid - 1];
+    const int so = t->own(cid), dn = t->own(c.parent);
+    for (int v : c.seps)
+      edges.push_back({so, so == t->rank ? t->B[cid - 1].at(v) : -1, dn, dn == t->rank ? t->ghost[cid - 1].at(v) : -1});
+    if (t->joint)
+      for (size_t i = 0; i < c.rel.size(); i++) {
+        const int slot = (so == t->rank || dn == t->rank) ? c.Dslot[i] : -1;  // the sender's own slot / the landing slot
+        edges.push_back({so, slot, dn, slot});
+      }
+  }
+}
+
 nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &entries, const std::set<int> *inclq, int out_slot, int passid,
                       int step, uint64_t seed, std::vector<nbp_proposal_desc> &props, std::vector<nbp_product_desc> &prods,
                       bool fresh = true) {
@@ -685,7 +731,7 @@ nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &ent
     }
     double ns = 0.0;  // _null_surplus: relative non-multihypo siblings of a multihypo factor
     if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = g->sp.null_surplus_add;
-    const int msg_slot = e.tag == 'm' ? t->B[e.a - 1].at(v) : -1;
+    const int msg_slot = e.tag == 'm' ? t->msg_slot(e.a, v) : -1;
     nbp_proposal_desc d;
     const uint64_t sd = op_seed(seed, passid, cid, step, i + 1);
     fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, sd, ns);
@@ -882,9 +928,20 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
     nxt += n;
   }
   t->B.assign(t->cl.size(), {});
+  t->ghost.assign(t->cl.size(), {});
   t->scratch.assign(t->cl.size(), 0);
   for (Clique &c : t->cl) {  // clique ids ascending == Python's iteration over tree.cliques (insertion order)
+    if (!t->mine(c.id)) continue;
     for (int v : c.all()) t->B[c.id - 1][v] = nxt++;
+    for (int chd : c.children) {  // messages from children that live on another rank land in ghost slots
+      if (t->mine(chd)) continue;
+      Clique &cc = t->cl[chd - 1];
+      for (int v : cc.seps) t->ghost[chd - 1][v] = nxt++;
+      if (t->joint) {  // ... and so do the KDEs of its differential factors
+        cc.Dslot.clear();
+        for (size_t i = 0; i < cc.rel.size(); i++) cc.Dslot.push_back(nxt++);
+      }
+    }
     // widest product of this clique: up = potentials touching v + child messages on v; down = all factors of v
     size_t maxf = 1;
     if (t->joint) {
@@ -928,6 +985,8 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
   const nbp_graph *g = t->g;
   const int n = (int)g->vars.size();
   t->stages.clear();
+  t->segments.clear();
+  t->seg_start = 0;
   t->meas_seed.clear();
   t->st = nbp_tree_stats{};
   std::vector<nbp_copy_desc> cps;
@@ -937,7 +996,8 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
   }
   cps.clear();
   for (const Clique &c : t->cl)  // deep copy of the clique sub graphs (SubGraphFunctions.jl:48)
-    for (int v : c.all()) cps.push_back({t->main_slot[v], t->B[c.id - 1].at(v)});
+    if (t->mine(c.id))
+      for (int v : c.all()) cps.push_back({t->main_slot[v], t->B[c.id - 1].at(v)});
   add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
   // heights / depths
   std::vector<int> height(t->cl.size() + 1, 0), depth(t->cl.size() + 1, 0);
@@ -1002,7 +1062,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         // default-constructed factor), manikde! of the result
         props.clear();
         for (const Clique &c : t->cl) {
-          if (finish[c.id] != tt || c.parent == 0) continue;
+          if (finish[c.id] != tt || c.parent == 0 || !t->mine(c.id)) continue;
           for (size_t i = 0; i < c.rel.size(); i++) {
             HFac dflt;
             memset(&dflt, 0, sizeof(dflt));
@@ -1022,10 +1082,18 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         }
         if (!props.empty()) add_stage(t, NBP_STAGE_DECONV, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
       }
+      {  // up messages of the cliques that finished at tt and whose parent lives on another rank
+        std::vector<int> crossing;
+        for (const Clique &c : t->cl)
+          if (finish[c.id] == tt && c.parent != 0 && t->own(c.id) != t->own(c.parent)) crossing.push_back(c.id);
+        std::vector<Edge> edges;
+        up_edges(t, crossing, edges);
+        rank_exchange(t, edges);
+      }
       props.clear();
       prods.clear();
       for (const Clique &c : t->cl) {
-        if (!(start[c.id] <= tt && tt < finish[c.id])) continue;
+        if (!(start[c.id] <= tt && tt < finish[c.id]) || !t->mine(c.id)) continue;
         const int k = tt - start[c.id], v = sched[c.id][k];
         std::vector<Entry> ent;
         if (t->joint) ent = joint_entries(c, v, false);
@@ -1043,24 +1111,28 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         if (rc) return rc;
         t->st.updates_up++;
       }
-      add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
-      add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+      if (!prods.empty()) {
+        add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
+        add_stage(t, NBP_STAGE_PRODUCTS, prods.data(), sizeof(nbp_product_desc), (int)prods.size());
+      }
     }
   }
   if (!g->sp.downsolve) {
     cps.clear();
     for (const Clique &c : t->cl)
-      for (int v : c.frontals) cps.push_back({t->B[c.id - 1].at(v), t->main_slot[v]});
+      if (t->mine(c.id))
+        for (int v : c.frontals) cps.push_back({t->B[c.id - 1].at(v), t->main_slot[v]});
     add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
   } else {
     cps.clear();
     for (int r : t->roots)
-      for (int v : t->cl[r - 1].frontals) cps.push_back({t->B[r - 1].at(v), t->main_slot[v]});
+      if (t->mine(r))
+        for (int v : t->cl[r - 1].frontals) cps.push_back({t->B[r - 1].at(v), t->main_slot[v]});
     add_stage(t, NBP_STAGE_COPIES, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());
     std::vector<nbp_copy_desc> final_cps;
     for (int dpt = 1; dpt <= maxd; dpt++)
       for (const Clique &c : t->cl)
-        if (depth[c.id] == dpt)
+        if (depth[c.id] == dpt && t->mine(c.id))
           for (int v : c.frontals) final_cps.push_back({t->B[c.id - 1].at(v), t->main_slot[v]});
     // batched by dependency like the up pass: a clique receives its parent's separator values (points-only copy)
     // and starts in the stage after the parent's last update (solver.TreeProgram._compile_down_asap)
@@ -1090,18 +1162,27 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
           nrounds = std::max(nrounds, rnd[cid] + 1);
         }
         for (int r = 0; r < nrounds; r++) {
+          std::vector<Edge> edges;  // down messages that cross a rank boundary: the parent's values of the child's separators
+          for (const Clique &c : t->cl) {
+            auto it = rnd.find(c.id);
+            if (it == rnd.end() || it->second != r || t->own(c.id) == t->own(c.parent)) continue;
+            for (int s : c.seps)
+              edges.push_back({t->own(c.parent), t->mine(c.parent) ? t->B[c.parent - 1].at(s) : -1, t->own(c.id),
+                               t->mine(c.id) ? t->B[c.id - 1].at(s) : -1});
+          }
+          rank_exchange(t, edges);
           cps.clear();
           for (const Clique &c : t->cl) {
             auto it = rnd.find(c.id);
-            if (it == rnd.end() || it->second != r) continue;
+            if (it == rnd.end() || it->second != r || !t->mine(c.id) || !t->mine(c.parent)) continue;
             for (int s : c.seps) cps.push_back({t->B[c.parent - 1].at(s), t->B[c.id - 1].at(s)});
           }
-          add_stage(t, NBP_STAGE_COPY_POINTS, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());  // read as points only
+          if (!cps.empty()) add_stage(t, NBP_STAGE_COPY_POINTS, cps.data(), sizeof(nbp_copy_desc), (int)cps.size());  // read as points only
         }
         props.clear();
         prods.clear();
         for (const Clique &c : t->cl) {
-          if (!(start[c.id] <= tt && tt < finish[c.id])) continue;
+          if (!(start[c.id] <= tt && tt < finish[c.id]) || !t->mine(c.id)) continue;
           const int k = tt - start[c.id], v = dsched(c)[k];
           const std::vector<int> allv = c.all();
           std::set<int> inclq(allv.begin(), allv.end());
@@ -1122,6 +1203,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
     // transferUpdateSubGraph!, once for the whole pass (see solver.TreeProgram)
     add_stage(t, NBP_STAGE_COPIES, final_cps.data(), sizeof(nbp_copy_desc), (int)final_cps.size());
   }
+  t->segments.push_back({0, t->seg_start, (int)t->stages.size(), {}, {}});
   // statistics
   t->st.stages = (int64_t)t->stages.size();
   for (const Stage &s : t->stages) {
@@ -1153,6 +1235,87 @@ nbp_status nbp_tree_compile(nbp_tree *t, nbp_ctx *ctx, uint64_t seed, nbp_progra
   rc = nbp_program_finalize(p);
   if (rc) { nbp_program_destroy(p); return rc; }
   *out = p;
+  return NBP_OK;
+}
+
+// ---- multi-rank compile ---------------------------------------------------------------------------------------------
+nbp_status nbp_tree_set_owner(nbp_tree *t, const int32_t *owner, int32_t rank) {
+  if (!t) return hfail(NBP_ERR_ARG, "null argument");
+  if (!owner) { t->owner.clear(); t->rank = 0; return NBP_OK; }
+  if (rank < 0) return hfail(NBP_ERR_ARG, "rank < 0");
+  t->owner.assign(owner, owner + t->cl.size());
+  for (int o : t->owner)
+    if (o < 0) return hfail(NBP_ERR_RANGE, "owner: negative rank");
+  t->rank = rank;
+  t->main_slot.clear();  // the slot plan depends on the ownership: plan again
+  return NBP_OK;
+}
+
+// dist_solver.partition_cliques: cut the tree into >= world subtrees by repeatedly splitting the heaviest one, place the
+// subtrees largest-first on the least loaded rank, give every clique above the cut to the rank of its heaviest child.
+// weight of a clique = 1 + the variable updates of its up schedule.
+nbp_status nbp_tree_partition(const nbp_tree *t, int32_t world, int32_t *owner_out) {
+  if (!t || !owner_out || world < 1) return hfail(NBP_ERR_ARG, "bad argument");
+  const size_t nc = t->cl.size();
+  std::vector<double> w(nc + 1, 0.0), sub(nc + 1, 0.0);
+  for (const Clique &c : t->cl) w[c.id] = 1.0 + (double)c.upsched.size();
+  for (int cid : postorder(t)) {
+    sub[cid] = w[cid];
+    for (int chd : t->cl[cid - 1].children) sub[cid] += sub[chd];
+  }
+  double total = 0;
+  for (size_t k = 1; k <= nc; k++) total += w[k];
+  std::vector<int> roots(t->roots.begin(), t->roots.end()), top;
+  while ((int)roots.size() < 6 * world) {
+    int best = -1;
+    for (int r : roots)
+      if (!t->cl[r - 1].children.empty() && (best < 0 || sub[r] > sub[best])) best = r;  // first maximum, like Python's max()
+    if (best < 0) break;
+    if ((int)roots.size() >= world && sub[best] <= 0.6 * total / world) break;
+    roots.erase(std::find(roots.begin(), roots.end(), best));
+    top.push_back(best);
+    for (int chd : t->cl[best - 1].children) roots.push_back(chd);
+  }
+  std::vector<int> owner(nc + 1, 0);
+  std::vector<double> load(world, 0.0);
+  std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return sub[a] > sub[b]; });
+  for (int r : roots) {
+    int k = 0;
+    for (int q = 1; q < world; q++)
+      if (load[q] < load[k]) k = q;  // argmin: first minimum
+    load[k] += sub[r];
+    std::vector<int> st{r};
+    while (!st.empty()) {
+      const int c = st.back();
+      st.pop_back();
+      owner[c] = k;
+      for (int chd : t->cl[c - 1].children) st.push_back(chd);
+    }
+  }
+  for (auto it = top.rbegin(); it != top.rend(); ++it) {  // children before parents
+    const Clique &c = t->cl[*it - 1];
+    int best = c.children[0];
+    for (int chd : c.children)
+      if (sub[chd] > sub[best]) best = chd;
+    owner[*it] = owner[best];
+    load[owner[*it]] += w[*it];
+  }
+  for (size_t k = 1; k <= nc; k++) owner_out[k - 1] = owner[k];
+  return NBP_OK;
+}
+
+int32_t nbp_tree_num_segments(const nbp_tree *t) { return t ? (int32_t)t->segments.size() : 0; }
+nbp_status nbp_tree_segment(const nbp_tree *t, int32_t i, int32_t *kind, int32_t *first, int32_t *last, int32_t *nsend, int32_t *nrecv,
+                            nbp_xfer *sends, nbp_xfer *recvs, int32_t cap) {
+  if (!t || i < 0 || i >= (int)t->segments.size()) return hfail(NBP_ERR_RANGE, "segment index");
+  const nbp_tree::Segment &x = t->segments[i];
+  if (kind) *kind = x.kind;
+  if (first) *first = x.first;
+  if (last) *last = x.last;
+  if (nsend) *nsend = (int32_t)x.sends.size();
+  if (nrecv) *nrecv = (int32_t)x.recvs.size();
+  for (size_t k = 0; sends && k < x.sends.size() && (int)k < cap; k++) sends[k] = {x.sends[k][0], x.sends[k][1]};
+  for (size_t k = 0; recvs && k < x.recvs.size() && (int)k < cap; k++) recvs[k] = {x.recvs[k][0], x.recvs[k][1]};
   return NBP_OK;
 }
 

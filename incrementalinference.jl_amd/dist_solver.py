@@ -91,12 +91,13 @@ def choose_transport(dist, device, log=None):
 class ShardedRunner:
     """Runs one rank's share of a TreeProgram: stage segments interleaved with slot exchanges."""
 
-    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None, transport="rccl", group=None):
+    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None, transport="rccl", group=None, prog=None):
         self.tp, self.be, self.dist = tp, backend, dist
         self.slot_tensor = slot_tensor
         self.sync_device = sync_device or (lambda: None)
         self.transport, self.group = transport, group
-        self.prog = backend.program(tp.stages, lazy_bandwidth=True)  # exchanges sit behind empty copy stages (barriers)
+        # exchanges sit behind empty copy stages (barriers for the deferred bandwidth fits)
+        self.prog = prog if prog is not None else backend.program(tp.stages, lazy_bandwidth=True)
 
     def run(self, salt=None):
         if salt is not None:
@@ -109,6 +110,10 @@ class ShardedRunner:
                 self._exchange(seg[1], seg[2])
 
     def _exchange(self, sends, recvs):
+        if self.transport == "rccl-native":
+            # grouped ncclSend / ncclRecv issued by libnbp on its own stream: ordered with the kernels, no host sync
+            self.be.exchange(sends, recvs)
+            return
         dist = self.dist
         self.be.synchronize()  # the slots to send are complete
         ops, landing = [], []
@@ -134,10 +139,47 @@ class ShardedRunner:
         self.prog.close()
 
 
+class _NativeShard:
+    """what ShardedRunner needs from a compiled share: the segment list (native_host.NativeTree.segments())"""
+
+    def __init__(self, segments):
+        self.segments = segments
+
+
+def native_comm(be, dist, device, log=None):
+    """RCCL communicator owned by libnbp (nbp_comm_create): rank 0 makes the id, torch.distributed carries it; then a ring
+    self-test of nbp_exchange on two scratch slots.  Returns True on every rank or False on every rank."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ok = 1
+    try:
+        box = [be.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        be.comm_create(world, rank, box[0])
+        a, b = be.n_slots - 2, be.n_slots - 1  # the two slots the caller reserved for this
+        from . import abi
+        be.slot_write(a, abi.EUCLID1, np.full((be.N, 1), float(rank)), np.ones(1))
+        be.exchange([((rank + 1) % world, a)], [((rank - 1) % world, b)])
+        be.synchronize()
+        got = be.slot_read(b, abi.EUCLID1)[0]
+        if not np.all(got == float((rank - 1) % world)):
+            ok = 0
+    except Exception as e:  # noqa: BLE001 -- any failure means "do not use this transport"
+        ok = 0
+        if log:
+            log(f"rank {rank}: libnbp RCCL exchange self-test failed ({type(e).__name__}: {e})")
+    t = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 class ShardedTreeSolve:
     """bench.py's multi-GPU leg: ANY graph (every BASELINE configuration), its cliques sharded over the ranks, one
-    process per GPU, arena owned by torch so that RCCL can move slots.  Weak scaling is the caller's business (it
-    hands over a graph grown with the number of ranks)."""
+    process per GPU.  Everything behind the C ABI: the native host partitions the tree, compiles this rank's share and
+    lists the exchange points (nbp_tree_partition / nbp_tree_set_owner / nbp_tree_segment); separator slots move with
+    nbp_exchange (grouped RCCL send/recv on the library stream).  The arena is owned by torch so that the fallback
+    transports (torch.distributed point-to-point, host-staged gloo) can address slots too.  Weak scaling is the
+    caller's business (it hands over a graph grown with the number of ranks)."""
 
     def __init__(self, iif, fg, N, rank, world, local, dist):
         self.iif, self.fg, self.N = iif, fg, N
@@ -147,49 +189,63 @@ class ShardedTreeSolve:
         import time
 
         import torch
+        from . import native_host
         iif, fg = self.iif, self.fg
+        dev = f"cuda:{self.local}"
+        tm = time.perf_counter()
+        g = native_host.NativeGraph.from_fg(fg)
+        mirror = time.perf_counter() - tm
         t0 = time.perf_counter()
-        order = iif.nestedDissectionOrder(fg)
+        order = g.order_nested_dissection()
         t1 = time.perf_counter()
-        tree = iif.buildTreeReset(fg, order)
+        nt = g.build_tree(order)
+        owner = nt.partition(self.world)
+        nt.set_owner(owner, self.rank)
         t2 = time.perf_counter()
-        mk = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints, device=self.local)
-        iif.initAll(fg, backend=mk, seed=0)  # replicated: every rank computes the same initial beliefs
-        t3 = time.perf_counter()
-        self.tree = tree
-        # balance by the work of a clique: the variable updates of its up schedule (wide separators iterate longer)
-        from . import bayestree
-        gi = fg.solverParams.gibbsIters
-        owner = partition_cliques(tree, self.world, weight=lambda c: 1 + len(bayestree.upGibbsSchedule(tree.cliques[c], gi)))
-        tp = TreeProgram(fg, tree, seed=1, snapshot=True, owner=owner, rank=self.rank)
-        self.tp = tp
+        n_slots = nt.plan_slots(True)
+        need, _ = g.init_plan(0)  # replicated: every rank computes the same initial beliefs (graph initialisation is a chain)
+        total = max(n_slots, need) + 2  # + two scratch slots for the transport self-test
         stride = abi.slot_stride(self.N)
-        self.arena = torch.zeros(tp.n_slots * stride, dtype=torch.float64, device=f"cuda:{self.local}")
-        self.be = iif.HipBackend(self.N, tp.n_slots, device=self.local, arena_ptr=self.arena.data_ptr(),
-                                 arena_bytes=self.arena.numel() * 8)
-        for v in fg.ls():
+        self.arena = torch.zeros(total * stride, dtype=torch.float64, device=dev)
+        self.be = iif.HipBackend(self.N, total, device=self.local, arena_ptr=self.arena.data_ptr(), arena_bytes=self.arena.numel() * 8)
+        for i, v in enumerate(fg.ls()):
             var = fg.getVariable(v)
-            self.be.slot_write(tp.snap[v], var.varType.manifold, var.val, var.bw)
+            if var.initialized:
+                self.be.slot_write(i, var.varType.manifold, var.val, var.bw)
+        iprog = g.init_compile(self.be)
+        iprog.run()
+        self.be.synchronize()
+        iprog.close()
+        self.be.run_copies([abi.CopyDesc(nt.main[v], nt.snap[v]) for v in fg.ls()])
+        t3 = time.perf_counter()
+        prog = nt.compile(self.be, 1)
+        self.tp = _NativeShard(nt.segments())
+        self.tp.main = nt.main
+        self.main = nt.main
+        t4 = time.perf_counter()
         self.transport, group = ("none", None)
         if self.dist is not None and self.world > 1:
-            self.transport, group = choose_transport(self.dist, f"cuda:{self.local}", log=lambda m: print(m, file=sys.stderr, flush=True))
-        self.runner = ShardedRunner(tp, self.be, self.dist, lambda s: self.arena[s * stride:(s + 1) * stride],
-                                    torch.cuda.synchronize, transport=self.transport, group=group)
-        t4 = time.perf_counter()
-        self.host_setup = {"host": "python mirror (sharded compile)", "graph_s": None, "graph_mirror_s": 0.0,
+            log = lambda m: print(m, file=sys.stderr, flush=True)
+            if self.dist.get_backend() == "nccl" and native_comm(self.be, self.dist, dev, log):
+                self.transport = "rccl-native"
+            else:
+                self.transport, group = choose_transport(self.dist, dev, log=log)
+        self.runner = ShardedRunner(self.tp, self.be, self.dist, lambda s: self.arena[s * stride:(s + 1) * stride],
+                                    torch.cuda.synchronize, transport=self.transport, group=group, prog=prog)
+        self.host_setup = {"host": "native C++ (nbp_host.h), sharded compile", "graph_s": None, "graph_mirror_s": mirror,
                            "elimination_order_s": t1 - t0, "tree_build_s": t2 - t1, "graph_init_s": t3 - t2,
                            "schedule_compile_s": t4 - t3}
-        st = tp.stats()
-        self.global_messages = tp.n_messages
-        # global totals over ranks
-        keys = sorted(tp.alg)
-        t = torch.tensor([float(st["updates_up"] + st["updates_down"]), float(tp.alg_bytes)] + [float(tp.alg[k]) for k in keys],
-                         device=f"cuda:{self.local}", dtype=torch.float64)
+        st = nt.stats()
+        self.global_messages = st["messages"]
+        alg = {"nbp_proposal_kernel": st["alg_bytes_proposal"], "nbp_prep_kernel": st["alg_bytes_prep"],
+               "nbp_product_kernel": st["alg_bytes_product"], "nbp_bandwidth_kernel": 0}
+        t = torch.tensor([float(st["updates_up"] + st["updates_down"]), float(st["alg_bytes"])], device=dev, dtype=torch.float64)
         if self.dist is not None:
             self.dist.all_reduce(t)
-        self.stats = {"cliques_global": len(tree.cliques), "updates_global": int(t[0].item()), "alg_bytes_total": float(t[1].item()),
-                      "alg_bytes": dict(tp.alg), "alg_bytes_global": {k: float(t[2 + i].item()) for i, k in enumerate(keys)}}
-        self.mine = [v for c in tp.cliques for v in tree.cliques[c].frontalIDs]
+        self.stats = {"cliques_global": nt.n_cliques, "updates_global": int(t[0].item()), "alg_bytes_total": float(t[1].item()), "alg_bytes": alg}
+        self.n_cliques = nt.n_cliques
+        self.mine = [v for k in range(1, nt.n_cliques + 1) if owner[k] == self.rank for v in nt.clique(k)["frontals"]]
+        self._native = (g, nt)
 
     def step(self, k):
         self.runner.run(salt=0x9E37 + k)

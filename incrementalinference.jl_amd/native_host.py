@@ -34,6 +34,9 @@ class TreeStats(C.Structure):
                                    "alg_bytes", "alg_bytes_proposal", "alg_bytes_prep", "alg_bytes_product")]
 
 
+Xfer = abi.Xfer
+
+
 class TreeBeliefC(C.Structure):
     """nbp_tree_belief: TreeBelief (val, bw, infoPerCoord) in host buffers"""
     _fields_ = [("pts", C.POINTER(f64)), ("bw", C.POINTER(f64)), ("ipc", C.POINTER(f64)), ("n_pts", i32), ("reserved_", i32)]
@@ -55,7 +58,8 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_graph_order_nested_dissection", "nbp_graph_init_plan", "nbp_graph_init_num_variables", "nbp_graph_init_variables",
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
-                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve"]
+                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve",
+                "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment"]
 
 _declared = False
 
@@ -92,6 +96,10 @@ def _lib():
         lib.nbp_tree_get_stats.argtypes = [vp, C.POINTER(TreeStats)]
         lib.nbp_tree_num_stages.argtypes = [vp]
         lib.nbp_tree_stage.argtypes = [vp, i32, ip, ip, vp, i64]
+        lib.nbp_tree_partition.argtypes = [vp, i32, ip]
+        lib.nbp_tree_set_owner.argtypes = [vp, ip, i32]
+        lib.nbp_tree_num_segments.argtypes = [vp]
+        lib.nbp_tree_segment.argtypes = [vp, i32, ip, ip, ip, ip, ip, C.POINTER(Xfer), C.POINTER(Xfer), i32]
         lib.nbp_clique_slots.argtypes = [C.POINTER(CliqueDescC)]
         for fn in (lib.nbp_clique_upsolve, lib.nbp_clique_downsolve):
             fn.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC), ip]
@@ -312,6 +320,35 @@ class NativeTree:
                 "separators": [L[sp[i]] for i in range(info.nseparators)], "children": [ch[i] for i in range(info.nchildren)],
                 "potentials": [F[po[i]] for i in range(info.npotentials)], "up": [L[up[i]] for i in range(info.nup)],
                 "down": [L[dn[i]] for i in range(info.ndown)]}
+
+    def partition(self, world):
+        """owner rank of every clique: {clique id: rank} (dist_solver.partition_cliques in C++)"""
+        out = (i32 * max(1, self.n_cliques))()
+        _check(self.lib.nbp_tree_partition(self._t, world, out))
+        return {k + 1: out[k] for k in range(self.n_cliques)}
+
+    def set_owner(self, owner, rank):
+        """compile this rank's share only (owner: {clique id: rank} or None for a single rank)"""
+        if owner is None:
+            _check(self.lib.nbp_tree_set_owner(self._t, None, 0))
+            return
+        arr = (i32 * self.n_cliques)(*[owner[k + 1] for k in range(self.n_cliques)])
+        _check(self.lib.nbp_tree_set_owner(self._t, arr, rank))
+
+    def segments(self):
+        """[("run", first, last) | ("xchg", [(peer, slot)], [(peer, slot)])] of the last compile (solver.TreeProgram.segments)"""
+        out = []
+        for i in range(self.lib.nbp_tree_num_segments(self._t)):
+            kind, a, b, ns, nr = i32(), i32(), i32(), i32(), i32()
+            _check(self.lib.nbp_tree_segment(self._t, i, C.byref(kind), C.byref(a), C.byref(b), C.byref(ns), C.byref(nr), None, None, 0))
+            if kind.value == 0:
+                out.append(("run", a.value, b.value))
+                continue
+            cap = max(1, ns.value, nr.value)
+            sx, rx = (Xfer * cap)(), (Xfer * cap)()
+            _check(self.lib.nbp_tree_segment(self._t, i, None, None, None, None, None, sx, rx, cap))
+            out.append(("xchg", [(sx[k].peer, sx[k].slot) for k in range(ns.value)], [(rx[k].peer, rx[k].slot) for k in range(nr.value)]))
+        return out
 
     def plan_slots(self, snapshot=False):
         self.n_slots = _check(self.lib.nbp_tree_plan_slots(self._t, int(snapshot)))

@@ -64,7 +64,7 @@ def test_torch_owned_arena_sharded_path_single_rank(hip_backend):
     s.be.synchronize()
     worst = max(float(np.abs(s.be.slot_read(s.tp.main[v], abi.EUCLID2)[0].mean(axis=0) - int(v[1:])).max()) for v in s.mine[::4])
     assert worst < 1.0
-    assert s.global_messages == 2 * (len(s.tree.cliques) - len(s.tree.roots))
+    assert s.global_messages == 2 * (s.n_cliques - 1)
     assert s.arena.data_ptr() == s.be.arena_ptr()
     torch.cuda.synchronize()
     s.close()
@@ -123,3 +123,27 @@ def test_gpu_solve_matches_exact_gaussian_posterior(hip_backend, seed):
     """the HIP solve against the exact posterior of a linear-Gaussian chain (tests/exact_gaussian.py)"""
     from exact_gaussian import check_against_exact
     check_against_exact(hip_backend, seed)
+
+
+def test_native_rccl_exchange_one_rank(hip_backend):
+    """nbp_comm_create / nbp_exchange (RCCL bound with dlopen, grouped ncclSend / ncclRecv on the library stream) with a
+    world of one: a slot sent to oneself arrives, stream-ordered, without a host synchronisation in between"""
+    N = 64
+    be = hip_backend(N, 4)
+    try:
+        uid = be.comm_unique_id()
+        assert len(uid) == abi.COMM_ID_BYTES
+        be.comm_create(1, 0, uid)
+        rng = np.random.default_rng(0)
+        pts = rng.normal(size=(N, 2))
+        be.belief_write(0, abi.EUCLID2, pts, np.array([0.3, 0.4]), np.array([2.0, 2.0]))
+        be.exchange([(0, 0)], [(0, 1)])
+        be.run_copies([abi.CopyDesc(1, 2)])  # a consumer on the same stream, no synchronize in between
+        got, bw, ipc = be.belief_read(2, abi.EUCLID2)
+        np.testing.assert_array_equal(got, pts)
+        np.testing.assert_array_equal(bw, [0.3, 0.4])
+        np.testing.assert_array_equal(ipc, [2.0, 2.0])
+        with pytest.raises(iif.NbpError):
+            be.exchange([(1, 0)], [])  # peer outside the world
+    finally:
+        be.close()

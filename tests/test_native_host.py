@@ -217,3 +217,39 @@ def test_random_graphs_native_equals_python(seed):
             assert raw == (bytes((ctype[pk] * len(descs))(*descs)) if descs else b""), (s, kind)
         nt.close()
     g.close()
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_partition_and_sharded_compile_are_identical(name, world):
+    """the multi-rank compile of the native host (nbp_tree_partition / nbp_tree_set_owner) against the Python mirror
+    (dist_solver.partition_cliques, solver.TreeProgram(owner=, rank=)): owners, slots, stage bytes and exchange segments
+    of EVERY rank"""
+    from iif_amd import bayestree
+    from iif_amd.dist_solver import partition_cliques
+    fg = GRAPHS[name]
+    mark_initialised(fg)
+    order = iif.nestedDissectionOrder(fg)
+    tree = iif.buildTreeReset(fg, order)
+    gi = fg.solverParams.gibbsIters
+    owner = partition_cliques(tree, world, weight=lambda c: 1 + len(bayestree.upGibbsSchedule(tree.cliques[c], gi)))
+    g = native_host.NativeGraph.from_fg(fg)
+    nt = g.build_tree(order)
+    assert nt.partition(world) == owner
+    ctype = {iif.abi.STAGE_PROPOSALS: iif.abi.ProposalDesc, iif.abi.STAGE_PRODUCTS: iif.abi.ProductDesc,
+             iif.abi.STAGE_COPIES: iif.abi.CopyDesc, iif.abi.STAGE_COPY_POINTS: iif.abi.CopyDesc, iif.abi.STAGE_DECONV: iif.abi.ProposalDesc}
+    for rank in range(world):
+        tp = iif.TreeProgram(fg, tree, seed=777, snapshot=True, owner=owner, rank=rank)
+        nt.set_owner(owner, rank)
+        assert nt.plan_slots(True) == tp.n_slots, rank
+        nt.schedule(777)
+        got = nt.stages()
+        assert len(got) == len(tp.stages), (rank, len(got), len(tp.stages))
+        for s, ((kind, raw), (pk, descs)) in enumerate(zip(got, tp.stages)):
+            assert kind == pk, (rank, s)
+            want = bytes((ctype[pk] * len(descs))(*descs)) if descs else b""
+            assert raw == want, (rank, s, kind, len(descs))
+        assert nt.segments() == [tuple(x) if x[0] == "run" else (x[0], list(x[1]), list(x[2])) for x in tp.segments], rank
+    nt.set_owner(None, 0)
+    nt.close()
+    g.close()
