@@ -1,0 +1,52 @@
+"""Config 3 (Circular poses, four door landmarks, multihypo sightings) -- where the mass goes.  Run on the oracle
+(tests/test_doors_mode_share.py) and on the GPU (tests/test_gpu_doors_mode_share.py).
+
+Full size (2000 poses) ends with a median of ~0.25 of the particles at the true pose.  That is not a defect of either
+implementation: the four doors are (almost) equally spaced, so a trajectory shifted by one door spacing explains every
+sighting equally well, and the only thing that tells the aliases apart is the prior on x0 carried along by odometry, whose
+uncertainty grows like 0.05 sqrt(i) rad -- beyond a few hundred poses the exact posterior itself has four comparable
+modes.  What CAN be pinned: where odometry is still informative the sighting is resolved correctly."""
+import numpy as np
+
+from parity_utils import iif
+
+
+def wrapdiff(a, b):
+    return (a - b + np.pi) % (2 * np.pi) - np.pi
+
+
+STEP = 2 * np.pi / 50
+
+
+def share(fg, i):
+    return float((np.abs(wrapdiff(fg.getVal(f"x{i}")[:, 0], i * STEP)) < 0.35).mean())
+
+
+def case_sighting_is_resolved_by_odometry(backend):
+    """at a sighting pose the multihypo proposal carries ~25 % per door (exact-match semantics of the recipe: one door
+    per particle), its relative siblings carry nullSurplusAdd = 0.3 of spread particles (ApproxConv.jl:255-265), and the
+    product puts > 90 % of the mass at the true pose"""
+    fg = iif.generateCircularDoors(nposes=6, N=200, sightEvery=3)
+    iif.initAll(fg, backend=backend, seed=3)
+    (pts, bw), ipc, props = iif.propagateBelief(fg, "x3", backend=backend, seed=5, return_proposals=True)
+    at = lambda p: float((np.abs(wrapdiff(p[:, 0], 3 * STEP)) < 0.35).mean())
+    by = dict(zip(fg.ls("x3"), [at(p) for p, _ in props]))
+    mh = [f for f in by if "l0" in f][0]
+    assert 0.15 < by[mh] < 0.4, by            # ~1/4 of the particles per door hypothesis
+    for f, v in by.items():
+        if f != mh:
+            assert 0.55 < v < 0.9, by         # 1 - nullSurplusAdd of the sibling's particles, the rest spread
+    assert at(pts) > 0.9, at(pts)
+    assert list(ipc) == [3.0]
+    return by, at(pts)
+
+
+def case_short_chains_keep_the_true_mode(backend):
+    out = {}
+    for nposes, se in ((6, 3), (26, 25)):
+        fg = iif.generateCircularDoors(nposes=nposes, N=200, sightEvery=se)
+        iif.solveTree(fg, eliminationOrder=iif.nestedDissectionOrder(fg), backend=backend, seed=1)
+        s = [share(fg, i) for i in range(nposes)]
+        out[nposes] = (min(s), float(np.median(s)))
+        assert min(s) > 0.8, (nposes, min(s))
+    return out
