@@ -150,6 +150,34 @@ __device__ __forceinline__ double wrap_pi(double a) {
   return res;
 }
 
+// sin and cos of an angle of moderate size (|a| < ~1e5; here: sums of a few wrapped angles).  The device library's
+// sincos carries the Payne-Hanek reduction for huge arguments and costs several hundred cycles of a lone wave; the
+// per-particle searches on SE(2) call it at every evaluation of a reverse residual.  Cody-Waite reduction by pi/2 in two
+// parts + the fdlibm kernels (|r| <= pi/4): < 1 ulp, ~35 FP64 operations, no branches.
+__device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) {
+  const double t = fma(a, 6.36619772367581382433e-01, 6755399441055744.0);  // a * 2/pi + 1.5 * 2^52
+  const int k = __double2loint(t);
+  const double kf = t - 6755399441055744.0;
+  double r = fma(kf, -1.57079632673412561417e+00, a);   // pio2_1 (33 bits: k * pio2_1 is exact)
+  r = fma(kf, -6.07710050650619224932e-11, r);          // pio2_1t
+  const double z = r * r;
+  // __kernel_sin
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                         -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double s = fma(r * z, ps, r);
+  // __kernel_cos (the qx form keeps < 1 ulp up to pi/4)
+  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                          2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double ar = fabs(r);
+  const double qx = (ar > 0.78125) ? 0.28125 : __hiloint2double(__double2hiint(ar) - 0x00200000, 0);
+  const double qq = (ar < 0.3) ? 0.0 : qx;
+  const double c = (1.0 - qq) - ((0.5 * z - qq) - z * pc);
+  const bool swap = k & 1;
+  const double ss = swap ? c : s, cc = swap ? s : c;
+  *sn = (k & 2) ? -ss : ss;
+  *cs = ((k + 1) & 2) ? -cc : cc;
+}
+
 // exp(x) for x <= ~0 in the O(N^2) kernel sums (arguments are -d^2/(2h^2) or weights relative to
 // their max).  Table-driven: x = (32k + j) ln2/32 + r, |r| <= ln2/64, exp(x) = 2^k * 2^(j/32) * p(r)
 // with a degree-6 polynomial; the integer n = 32k + j is taken from the low mantissa bits after
@@ -253,6 +281,20 @@ __device__ __forceinline__ double block_max(double v, double *red) {
 __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, int manifold, int d, double *red) {
   double mu;
   if (is_circ(manifold, d)) {
+    // When every point lies within an arc shorter than pi (the rule for a belief that is not spread around the circle),
+    // no step of the running geodesic mean wraps relative to the first point, and the recurrence
+    // m <- m + (x_i - m) / (i + 1) is the arithmetic mean of the offsets d_i = wrap(x_i - x_0): a parallel reduction
+    // instead of N dependent steps (equal to the walk up to rounding).  Otherwise: the walk below.
+    {
+      const double x0 = x[0];
+      const double di = (threadIdx.x < N) ? wrap_pi(x[threadIdx.x] - x0) : 0.0;
+      const double dmin = block_min((threadIdx.x < N) ? di : INFINITY, red);
+      const double dmax = block_max((threadIdx.x < N) ? di : -INFINITY, red);
+      if (dmax - dmin < 3.0) {  // block-uniform
+        const double mo = block_sum(di, red) / (double)N;
+        return wrap_pi(x0 + mo);
+      }
+    }
     __syncthreads();
     if (threadIdx.x < 64) {
       // Order-dependent running mean: N dependent steps.  Wave 0 walks it with every lane carrying the
@@ -304,7 +346,7 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
 __device__ __forceinline__ double mean_default_coord(const double *x, int N, int manifold, int d, double *red) {
   if (is_circ(manifold, d)) {
     double s = 0, c = 0;
-    if (threadIdx.x < N) sincos(x[threadIdx.x], &s, &c);
+    if (threadIdx.x < N) sincos_fast(x[threadIdx.x], &s, &c);
     double ss = block_sum(s, red), sc = block_sum(c, red);
     return atan2(ss, sc);
   }
@@ -354,7 +396,7 @@ struct objective_t {
     } else if (KIND == NBP_F_SE2) {  // Factors/GenericFunctions.jl:39-44
       double s, c;
       if (solve_b) { s = sn_fixed; c = cs_fixed; }  // a is the fixed pose: its rotation was evaluated once
-      else sincos(a[2], &s, &c);
+      else sincos_fast(a[2], &s, &c);
       double r0 = (a[0] + c * z[0] - s * z[1]) - b[0];
       double r1 = (a[1] + s * z[0] + c * z[1]) - b[1];
       double r2 = wrap_pi((a[2] + z[2]) - b[2]);
@@ -669,7 +711,7 @@ __device__ __forceinline__ void solve_particle_t(int manifold, const double *z, 
   for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
   o.sn_fixed = 0.0;
   o.cs_fixed = 1.0;
-  if (KIND == NBP_F_SE2 && solve_b) sincos(other[2], &o.sn_fixed, &o.cs_fixed);
+  if (KIND == NBP_F_SE2 && solve_b) sincos_fast(other[2], &o.sn_fixed, &o.cs_fixed);
   double xc[DN];
 #pragma unroll
   for (int d = 0; d < DN; d++) xc[d] = x[d];

@@ -685,7 +685,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       lr[jk * N + z] = rz;
       if (KC >= 0 && k == KC) {
         double sn, cs_;
-        sincos(cen[j * 3 + k] + mu, &sn, &cs_);
+        sincos_fast(cen[j * 3 + k] + mu, &sn, &cs_);
         lsn[j * N + z] = sn * rz;
         lcs[j * N + z] = cs_ * rz;
       }

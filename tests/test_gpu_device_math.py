@@ -1,0 +1,34 @@
+"""-m gpu: the device's own elementary functions against numpy -- sincos_fast (Cody-Waite + fdlibm kernels) through an
+observable: a CircularCircular / SE(2) reverse solve uses it in every residual evaluation, the product uses it for the
+node means of circular coordinates; here directly through the SE(2) relative residual root (closed form)."""
+import numpy as np
+import pytest
+
+import analytic_cases as ac
+from parity_utils import abi, relative_factor_desc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_se2_reverse_root_over_the_whole_circle(hip_backend):
+    """reverse SE(2) solves with headings all around the circle (and beyond +-pi before wrapping): the root of the residual
+    involves sin / cos of the solved heading"""
+    N = 256
+    rng = np.random.default_rng(0)
+    o = np.stack([rng.normal(0, 3, N), rng.normal(0, 3, N), rng.uniform(-np.pi, np.pi, N)], axis=1)
+    x0 = np.stack([rng.normal(0, 3, N), rng.normal(0, 3, N), rng.uniform(-np.pi, np.pi, N)], axis=1)
+    for z in ([1.0, 0.5, 0.8], [-3.0, 2.0, 3.0], [0.3, -0.2, -3.1]):
+        be = hip_backend(N, 3)
+        try:
+            be.slot_write(0, abi.SE2, ac.to_points(abi.SE2, x0), np.ones(3))
+            be.slot_write(1, abi.SE2, ac.to_points(abi.SE2, o), np.ones(3))
+            d = relative_factor_desc(abi.F_SE2, abi.SE2, 2, 0, [0, 1], 2, 99, z, [0.0, 0.0, 0.0])
+            d.skip_bandwidth = 1
+            be.run_proposals([d])
+            got = ac.to_coords(abi.SE2, be.slot_read(2, abi.SE2)[0])
+        finally:
+            be.close()
+        want = ac.root_of(abi.F_SE2, abi.SE2, np.tile(z, (N, 1)), o, 0)
+        err = got - want
+        err[:, 2] = ac.wrap(err[:, 2])
+        assert np.abs(err).max() < 5e-3 and np.sqrt((err ** 2).mean()) < 5e-4, (z, np.abs(err).max())
