@@ -29,6 +29,11 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
       return fail(NBP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
   } while (0)
 
+// Speculative fits (lcv_bandwidth_1d_spec): used when every workgroup of the launch is resident at once -- the launch,
+// with NBP_SPEC_K workgroups per fit, stays below NBP_SPEC_MAXBLOCKS (the chip has 256 CUs and a fit's workgroup has a CU
+// to itself: 1024 lanes, ~63 KB of LDS).
+#define NBP_SPEC_MAXJOBS 24
+#define NBP_SPEC_MAXBLOCKS 224
 struct nbp_program;
 struct nbp_ctx {
   std::vector<nbp_program *> programs;  // live programs: detached (device blob freed, ctx = null) by nbp_ctx_destroy
@@ -44,6 +49,8 @@ struct nbp_ctx {
   double *lv_dbls = nullptr;
   double *ws = nullptr;  // KD workspace: [products][kdF] x nbp_kd_ws_doubles(N), kdF = largest F of the batch
   size_t ws_doubles = 0;
+  nbp_spec_area *spec = nullptr;  // rendezvous areas of the speculative fits (latency-mode launches), NBP_SPEC_MAXJOBS x 3
+  bool spec_on = true;
   double *gstats = nullptr;  // node statistics of products too large for the LDS
   size_t gstats_doubles = 0;
   // staging for immediate-mode calls
@@ -178,6 +185,8 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipMalloc(&c->counters, sizeof(nbp_counters)));
   HIPCHK(hipMemset(c->counters, 0, sizeof(nbp_counters)));
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&c->spec, sizeof(nbp_spec_area) * 3 * NBP_SPEC_MAXJOBS));
+  c->spec_on = getenv("NBP_NO_SPECULATIVE_FITS") == nullptr;
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
@@ -216,6 +225,7 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (c->stage) hipFree(c->stage);
   if (c->ws) hipFree(c->ws);
   if (c->gstats) hipFree(c->gstats);
+  if (c->spec) hipFree(c->spec);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return NBP_OK;
@@ -455,8 +465,11 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, P);
   (void)hipGetLastError();
   const int kdF = maxFD / 4;
-  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw, dev,
-                     n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
+  // latency mode: a handful of fits, the rest of the chip idle -> NBP_SPEC_K workgroups per fit
+  const bool spec = c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS && 3 * nbw * NBP_SPEC_K + n * kdF <= NBP_SPEC_MAXBLOCKS;
+  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
+  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw * (spec ? NBP_SPEC_K : 1) + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+                     dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
 }
@@ -559,8 +572,10 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
   if (rc) return rc;
   (void)hipGetLastError();
   const int P = lcv_helpers(c, 2 * n);
-  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
-                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters);
+  const bool spec = c->spec_on && n <= NBP_SPEC_MAXJOBS && 3 * n * NBP_SPEC_K <= NBP_SPEC_MAXBLOCKS;
+  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
+  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3, spec ? NBP_SPEC_K : 1), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[3]);
 }

@@ -288,9 +288,23 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
     {
       const double x0 = x[0];
       const double di = (threadIdx.x < N) ? wrap_pi(x[threadIdx.x] - x0) : 0.0;
-      const double dmin = block_min((threadIdx.x < N) ? di : INFINITY, red);
-      const double dmax = block_max((threadIdx.x < N) ? di : -INFINITY, red);
-      if (dmax - dmin < 3.0) {  // block-uniform
+      // min and max in one pass: max(d) and max(-d) ride through the same shuffles and one barrier pair
+      double hi = (threadIdx.x < N) ? di : -INFINITY, lo = (threadIdx.x < N) ? -di : -INFINITY;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        hi = fmax(hi, __shfl_xor(hi, o, 64));
+        lo = fmax(lo, __shfl_xor(lo, o, 64));
+      }
+      {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+        __syncthreads();
+        if (lane == 0) { red[w] = hi; red[16 + w] = lo; }
+        __syncthreads();
+        hi = red[0];
+        lo = red[16];
+        for (int i = 1; i < nw; i++) { hi = fmax(hi, red[i]); lo = fmax(lo, red[16 + i]); }
+      }
+      if (hi + lo < 3.0) {  // max - min, block-uniform
         const double mo = block_sum(di, red) / (double)N;
         return wrap_pi(x0 + mo);
       }
@@ -1024,6 +1038,134 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   }
   if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
   return (f1 < f2 ? x1 : x2) * sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same search for launches that cannot fill the chip (the top of the tree: a handful of fits, each pinned at what
+// ONE CU does for 16-21 dependent likelihood evaluations).  K = 3 workgroups on three CUs serve one fit: in every round
+// they evaluate, concurrently, the point the search needs next (its position follows from values already known) and
+// the two points it would need after that, one per outcome of the comparison the first value decides -- the positions of
+// a golden-section search depend on comparison OUTCOMES only.  One device-scope rendezvous per round then advances the
+// search two iterations.  Every likelihood value is computed by the same code at the same point as in the sequential
+// search, so the selected bandwidth is bit-identical.  A workgroup that waits too long for its peers (they could in
+// principle not be resident) stops waiting and evaluates all three points itself: slower, never stuck.
+// ------------------------------------------------------------------------------------------------
+#define NBP_SPEC_K 3
+#define NBP_SPEC_ROUNDS 24
+struct nbp_spec_area {  // one per (fit job, coordinate); zeroed by the host before the launch
+  unsigned long long f[NBP_SPEC_ROUNDS][4];  // published values (bit patterns), [round][role]
+  unsigned int cnt[NBP_SPEC_ROUNDS];         // arrivals per round
+  unsigned int pad_[8];
+};
+struct golden_state {
+  double x0, x1, x2, x3, f1, f2;
+};
+// the point iteration `it` evaluates given the outcome c = (f2 < f1), and the positional update
+__device__ __forceinline__ double golden_step(golden_state &g, bool c, double R, double C) {
+  if (c) { g.x0 = g.x1; g.x1 = g.x2; g.x2 = R * g.x1 + C * g.x3; g.f1 = g.f2; return g.x2; }
+  g.x3 = g.x2; g.x2 = g.x1; g.x1 = R * g.x2 + C * g.x0; g.f2 = g.f1;
+  return g.x1;
+}
+__device__ __forceinline__ bool golden_done(const golden_state &g, double tol) { return !(fabs(g.x3 - g.x0) > tol * (fabs(g.x1) + fabs(g.x2))); }
+
+__device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, int Npad, bool circ, double *part, double *red, const double *tab,
+                                                        nbp_counters *ctr, nbp_spec_area *area, int role) {
+  const int i = threadIdx.x;
+  double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
+  if (i < N) {
+    lo = hi = x[i];
+    if (i + 1 < N) {
+      double d = x[i] - x[i + 1];
+      if (circ) d = wrap_pi(d);
+      mn = fabs(d);
+    }
+  }
+  {
+    double *acc = part + (blockDim.x / Npad) * Npad;
+    for (int q = threadIdx.x; q < (int)(blockDim.x >> 6) * 2 * N; q += blockDim.x) acc[q] = 0.0;
+    for (int q = threadIdx.x; q < (int)blockDim.x; q += blockDim.x) part[q] = 0.0;
+  }
+  double minm = block_min(mn, red);
+  lo = block_min(lo, red);
+  hi = block_max(hi, red);
+  const double maxm = circ ? NBP_TWO_PI : (hi - lo);
+  if (!(maxm > 0)) return 1.0;
+  if (minm < 1e-6 * maxm) minm = 1e-6 * maxm;
+  const double sc = 0.5 * (minm + maxm);
+  const double ax = minm / sc, bx = 1.0, cx = maxm / sc;
+  const double R = 0.61803399, C = 1.0 - R, tol = 1e-2;
+  const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
+  golden_state g;
+  g.x0 = ax; g.x3 = cx;
+  if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = bx + C * (cx - bx); }
+  else { g.x2 = bx; g.x1 = bx - C * (bx - ax); }
+  auto eval = [&](double xs) { return neg_loo_ll(x, N, Npad, circ, xs * sc, lognorm0, part, red, tab); };
+  bool solo = false;  // gave up on the peers: evaluate everything here
+  int round = 0;
+  // rendezvous of round r: publish `mine` for `role`, collect all K values (or compute them when solo)
+  auto exchange = [&](const double (&pts)[NBP_SPEC_K], int npts, double (&vals)[NBP_SPEC_K]) {
+    if (!solo && round >= NBP_SPEC_ROUNDS) solo = true;
+    if (!solo) {
+      double mine = 0.0;
+      if (role < npts) mine = eval(pts[role]);
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&area->f[round][role], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&area->cnt[round], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int spin = 0; spin < 100000; spin++) {
+          if (__hip_atomic_load(&area->cnt[round], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)NBP_SPEC_K) { ok = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        red[40] = (double)ok;  // broadcast slot of the reduction scratch
+      }
+      __syncthreads();
+      const bool ok_ = red[40] != 0.0;
+      if (ok_) {
+#pragma unroll
+        for (int r = 0; r < NBP_SPEC_K; r++)
+          vals[r] = __longlong_as_double((long long)__hip_atomic_load(&area->f[round][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        round++;
+        return;
+      }
+      solo = true;  // block-uniform (the flag came through LDS)
+      __syncthreads();
+    }
+    for (int r = 0; r < npts; r++) vals[r] = eval(pts[r]);
+    round++;
+  };
+  unsigned int nev = 2;
+  {
+    const double p[NBP_SPEC_K] = {g.x1, g.x2, 0.0};
+    double v[NBP_SPEC_K];
+    exchange(p, 2, v);
+    g.f1 = v[0];
+    g.f2 = v[1];
+  }
+  while (!golden_done(g, tol)) {
+    // iteration A: its point is certain; iteration B: one point per outcome of A's comparison
+    const bool cA = g.f2 < g.f1;
+    golden_state gA = g;
+    const double pA = golden_step(gA, cA, R, C);  // gA: positions after A; the new value goes to (cA ? f2 : f1)
+    golden_state gB1 = gA, gB0 = gA;
+    // outcome "new value is the smaller one of the next comparison" depends on which slot it fills
+    const double pB_true = golden_step(gB1, true, R, C), pB_false = golden_step(gB0, false, R, C);
+    const double p[NBP_SPEC_K] = {pA, pB_true, pB_false};
+    double v[NBP_SPEC_K];
+    exchange(p, NBP_SPEC_K, v);
+    if (cA) gA.f2 = v[0]; else gA.f1 = v[0];
+    g = gA;
+    nev++;
+    if (golden_done(g, tol)) break;
+    const bool cB = g.f2 < g.f1;
+    golden_state gn = g;
+    (void)golden_step(gn, cB, R, C);
+    if (cB) gn.f2 = v[1]; else gn.f1 = v[2];
+    g = gn;
+    nev++;
+  }
+  if (ctr && threadIdx.x == 0 && role == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
+  return (g.f1 < g.f2 ? g.x1 : g.x2) * sc;
 }
 
 // rand(Categorical(p)) by inverse CDF on one uniform
