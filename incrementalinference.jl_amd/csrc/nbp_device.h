@@ -1027,14 +1027,15 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   const double R = 0.61803399, C = 1.0 - R, tol = 1e-2;
   const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   double x0 = ax, x3 = cx, x1, x2;
-  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
-  else { x2 = bx; x1 = bx - C * (bx - ax); }
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = fma(C, cx - bx, bx); }
+  else { x2 = bx; x1 = fma(-C, bx - ax, bx); }
   double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab);
   unsigned int nev = 2;
   while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
     nev++;
-    if (f2 < f1) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab); }
-    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab); }
+    // positions by explicit fma (see golden_step)
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab); }
+    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab); }
   }
   if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
   return (f1 < f2 ? x1 : x2) * sc;
@@ -1062,8 +1063,10 @@ struct golden_state {
 };
 // the point iteration `it` evaluates given the outcome c = (f2 < f1), and the positional update
 __device__ __forceinline__ double golden_step(golden_state &g, bool c, double R, double C) {
-  if (c) { g.x0 = g.x1; g.x1 = g.x2; g.x2 = R * g.x1 + C * g.x3; g.f1 = g.f2; return g.x2; }
-  g.x3 = g.x2; g.x2 = g.x1; g.x1 = R * g.x2 + C * g.x0; g.f2 = g.f1;
+  // one explicit fma per position (hipcc contracts a * b + c wherever it likes, and differently in different
+  // functions): the sequential search and this one then walk through bit-identical positions
+  if (c) { g.x0 = g.x1; g.x1 = g.x2; g.x2 = fma(R, g.x1, C * g.x3); g.f1 = g.f2; return g.x2; }
+  g.x3 = g.x2; g.x2 = g.x1; g.x1 = fma(R, g.x2, C * g.x0); g.f2 = g.f1;
   return g.x1;
 }
 __device__ __forceinline__ bool golden_done(const golden_state &g, double tol) { return !(fabs(g.x3 - g.x0) > tol * (fabs(g.x1) + fabs(g.x2))); }
@@ -1097,8 +1100,8 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   golden_state g;
   g.x0 = ax; g.x3 = cx;
-  if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = bx + C * (cx - bx); }
-  else { g.x2 = bx; g.x1 = bx - C * (bx - ax); }
+  if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = fma(C, cx - bx, bx); }
+  else { g.x2 = bx; g.x1 = fma(-C, bx - ax, bx); }
   auto eval = [&](double xs) { return neg_loo_ll(x, N, Npad, circ, xs * sc, lognorm0, part, red, tab); };
   bool solo = false;  // gave up on the peers: evaluate everything here
   int round = 0;
