@@ -30,7 +30,7 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
   } while (0)
 
 // Speculative fits (lcv_bandwidth_1d_spec): used when every workgroup of the launch is resident at once -- the launch,
-// with NBP_SPEC_K workgroups per fit, stays below NBP_SPEC_MAXBLOCKS (the chip has 256 CUs and a fit's workgroup has a CU
+// with 3 or 7 workgroups per fit, stays below NBP_SPEC_MAXBLOCKS (the chip has 256 CUs and a fit's workgroup has a CU
 // to itself: 1024 lanes, ~63 KB of LDS).
 #define NBP_SPEC_MAXJOBS 24
 #define NBP_SPEC_MAXBLOCKS 224
@@ -51,6 +51,7 @@ struct nbp_ctx {
   size_t ws_doubles = 0;
   nbp_spec_area *spec = nullptr;  // rendezvous areas of the speculative fits (latency-mode launches), NBP_SPEC_MAXJOBS x 3
   bool spec_on = true;
+  bool spec_depth3 = false;  // 7 workgroups per fit: measured no faster than 3 (the rendezvous of 7 costs what the third iteration saves)
   double *gstats = nullptr;  // node statistics of products too large for the LDS
   size_t gstats_doubles = 0;
   // staging for immediate-mode calls
@@ -187,6 +188,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&c->spec, sizeof(nbp_spec_area) * 3 * NBP_SPEC_MAXJOBS));
   c->spec_on = getenv("NBP_NO_SPECULATIVE_FITS") == nullptr;
+  c->spec_depth3 = getenv("NBP_SPEC_DEPTH3") != nullptr;
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
@@ -466,10 +468,17 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   (void)hipGetLastError();
   const int kdF = maxFD / 4;
   // latency mode: a handful of fits, the rest of the chip idle -> NBP_SPEC_K workgroups per fit
-  const bool spec = c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS && 3 * nbw * NBP_SPEC_K + n * kdF <= NBP_SPEC_MAXBLOCKS;
+  // 3 workgroups per fit (two iterations per rendezvous) when the whole launch is resident at once (7 / three on request)
+  int depth = 0;
+  if (c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS) {
+    if (c->spec_depth3 && 3 * nbw * 7 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 3;
+    else if (3 * nbw * 3 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 2;
+  }
+  const bool spec = depth > 0;
+  const int KS = spec ? (1 << depth) - 1 : 1;
   if (spec) HIPCHK(hipMemsetAsync(c->spec, 0, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
-  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw * (spec ? NBP_SPEC_K : 1) + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
-                     dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr);
+  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+                     dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr, depth);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
 }
@@ -572,10 +581,12 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
   if (rc) return rc;
   (void)hipGetLastError();
   const int P = lcv_helpers(c, 2 * n);
-  const bool spec = c->spec_on && n <= NBP_SPEC_MAXJOBS && 3 * n * NBP_SPEC_K <= NBP_SPEC_MAXBLOCKS;
+  int depth = 0;
+  if (c->spec_on && n <= NBP_SPEC_MAXJOBS) depth = (c->spec_depth3 && 3 * n * 7 <= NBP_SPEC_MAXBLOCKS) ? 3 : ((3 * n * 3 <= NBP_SPEC_MAXBLOCKS) ? 2 : 0);
+  const bool spec = depth > 0;
   if (spec) HIPCHK(hipMemsetAsync(c->spec, 0, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
-  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3, spec ? NBP_SPEC_K : 1), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
-                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr);
+  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3, spec ? (1 << depth) - 1 : 1), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr, depth);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[3]);
 }

@@ -1043,25 +1043,26 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
 
 // ------------------------------------------------------------------------------------------------
 // The same search for launches that cannot fill the chip (the top of the tree: a handful of fits, each pinned at what
-// ONE CU does for 16-21 dependent likelihood evaluations).  K = 3 workgroups on three CUs serve one fit: in every round
-// they evaluate, concurrently, the point the search needs next (its position follows from values already known) and
-// the two points it would need after that, one per outcome of the comparison the first value decides -- the positions of
-// a golden-section search depend on comparison OUTCOMES only.  One device-scope rendezvous per round then advances the
-// search two iterations.  Every likelihood value is computed by the same code at the same point as in the sequential
+// ONE CU does for 16-21 dependent likelihood evaluations).  K = 3 or 7 workgroups on as many CUs serve one fit: in every
+// round they evaluate, concurrently, the point the search needs next (its position follows from values already known)
+// and the points it would need in the one or two iterations after that, one per outcome of the comparisons in between --
+// the positions of a golden-section search depend on comparison OUTCOMES only.  One device-scope rendezvous per round
+// then advances the search two or three iterations.  Every likelihood value is computed by the same code at the same point as in the sequential
 // search, so the selected bandwidth is bit-identical.  A workgroup that waits too long for its peers (they could in
 // principle not be resident) stops waiting and evaluates all three points itself: slower, never stuck.
 // ------------------------------------------------------------------------------------------------
-#define NBP_SPEC_K 3
+#define NBP_SPEC_KMAX 7
 #define NBP_SPEC_ROUNDS 24
 struct nbp_spec_area {  // one per (fit job, coordinate); zeroed by the host before the launch
-  unsigned long long f[NBP_SPEC_ROUNDS][4];  // published values (bit patterns), [round][role]
+  unsigned long long f[NBP_SPEC_ROUNDS][8];  // published values (bit patterns), [round][role]
   unsigned int cnt[NBP_SPEC_ROUNDS];         // arrivals per round
   unsigned int pad_[8];
 };
 struct golden_state {
   double x0, x1, x2, x3, f1, f2;
 };
-// the point iteration `it` evaluates given the outcome c = (f2 < f1), and the positional update
+// the positional update of one iteration given the outcome c = (f2 < f1); returns the point the iteration evaluates
+// (its value belongs in f2 when c, in f1 otherwise)
 __device__ __forceinline__ double golden_step(golden_state &g, bool c, double R, double C) {
   // one explicit fma per position (hipcc contracts a * b + c wherever it likes, and differently in different
   // functions): the sequential search and this one then walk through bit-identical positions
@@ -1071,8 +1072,13 @@ __device__ __forceinline__ double golden_step(golden_state &g, bool c, double R,
 }
 __device__ __forceinline__ bool golden_done(const golden_state &g, double tol) { return !(fabs(g.x3 - g.x0) > tol * (fabs(g.x1) + fabs(g.x2))); }
 
+// DEPTH iterations per rendezvous, K = 2^DEPTH - 1 workgroups per fit.  Roles are the nodes of the outcome tree in heap
+// order: node 1 = the iteration whose comparison is already decided by known values; node 2n / 2n+1 = the iteration that
+// follows node n when the comparison after n comes out true / false.
+template <int DEPTH>
 __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, int Npad, bool circ, double *part, double *red, const double *tab,
                                                         nbp_counters *ctr, nbp_spec_area *area, int role) {
+  constexpr int K = (1 << DEPTH) - 1;
   const int i = threadIdx.x;
   double lo = INFINITY, hi = -INFINITY, mn = INFINITY;
   if (i < N) {
@@ -1103,69 +1109,77 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = fma(C, cx - bx, bx); }
   else { g.x2 = bx; g.x1 = fma(-C, bx - ax, bx); }
   auto eval = [&](double xs) { return neg_loo_ll(x, N, Npad, circ, xs * sc, lognorm0, part, red, tab); };
-  bool solo = false;  // gave up on the peers: evaluate everything here
+  bool solo = false;  // gave up on the peers: the sequential search from here on
   int round = 0;
-  // rendezvous of round r: publish `mine` for `role`, collect all K values (or compute them when solo)
-  auto exchange = [&](const double (&pts)[NBP_SPEC_K], int npts, double (&vals)[NBP_SPEC_K]) {
-    if (!solo && round >= NBP_SPEC_ROUNDS) solo = true;
-    if (!solo) {
-      double mine = 0.0;
-      if (role < npts) mine = eval(pts[role]);
-      if (threadIdx.x == 0) {
-        __hip_atomic_store(&area->f[round][role], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&area->cnt[round], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 0;
-        for (int spin = 0; spin < 100000; spin++) {
-          if (__hip_atomic_load(&area->cnt[round], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)NBP_SPEC_K) { ok = 1; break; }
-          __builtin_amdgcn_s_sleep(2);
-        }
-        red[40] = (double)ok;  // broadcast slot of the reduction scratch
-      }
-      __syncthreads();
-      const bool ok_ = red[40] != 0.0;
-      if (ok_) {
-#pragma unroll
-        for (int r = 0; r < NBP_SPEC_K; r++)
-          vals[r] = __longlong_as_double((long long)__hip_atomic_load(&area->f[round][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        __syncthreads();
-        round++;
-        return;
-      }
-      solo = true;  // block-uniform (the flag came through LDS)
-      __syncthreads();
-    }
-    for (int r = 0; r < npts; r++) vals[r] = eval(pts[r]);
-    round++;
-  };
   unsigned int nev = 2;
-  {
-    const double p[NBP_SPEC_K] = {g.x1, g.x2, 0.0};
-    double v[NBP_SPEC_K];
-    exchange(p, 2, v);
-    g.f1 = v[0];
-    g.f2 = v[1];
+  double vals[K + 1];
+  // rendezvous: publish the value of this role's point, collect all K values; false = on our own from now on
+  auto rendezvous = [&](double mine) -> bool {
+    if (round >= NBP_SPEC_ROUNDS) return false;
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&area->f[round][role], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&area->cnt[round], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 0;
+      for (int spin = 0; spin < 100000; spin++) {
+        if (__hip_atomic_load(&area->cnt[round], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)K) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      red[40] = (double)ok;  // broadcast slot of the reduction scratch
+    }
+    __syncthreads();
+    const bool ok_ = red[40] != 0.0;
+    if (ok_) {
+#pragma unroll
+      for (int r = 0; r < K; r++)
+        vals[r + 1] = __longlong_as_double((long long)__hip_atomic_load(&area->f[round][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();
+    round++;
+    return ok_;
+  };
+  {  // the two initial values: roles 0 and 1
+    const double mine = role == 0 ? eval(g.x1) : (role == 1 ? eval(g.x2) : 0.0);
+    if (rendezvous(mine)) { g.f1 = vals[1]; g.f2 = vals[2]; }
+    else { solo = true; g.f1 = eval(g.x1); g.f2 = eval(g.x2); }
   }
   while (!golden_done(g, tol)) {
-    // iteration A: its point is certain; iteration B: one point per outcome of A's comparison
-    const bool cA = g.f2 < g.f1;
-    golden_state gA = g;
-    const double pA = golden_step(gA, cA, R, C);  // gA: positions after A; the new value goes to (cA ? f2 : f1)
-    golden_state gB1 = gA, gB0 = gA;
-    // outcome "new value is the smaller one of the next comparison" depends on which slot it fills
-    const double pB_true = golden_step(gB1, true, R, C), pB_false = golden_step(gB0, false, R, C);
-    const double p[NBP_SPEC_K] = {pA, pB_true, pB_false};
-    double v[NBP_SPEC_K];
-    exchange(p, NBP_SPEC_K, v);
-    if (cA) gA.f2 = v[0]; else gA.f1 = v[0];
-    g = gA;
-    nev++;
-    if (golden_done(g, tol)) break;
-    const bool cB = g.f2 < g.f1;
-    golden_state gn = g;
-    (void)golden_step(gn, cB, R, C);
-    if (cB) gn.f2 = v[1]; else gn.f1 = v[2];
-    g = gn;
-    nev++;
+    if (solo) {
+      const bool c = g.f2 < g.f1;
+      const double p = golden_step(g, c, R, C);
+      const double v = eval(p);
+      if (c) g.f2 = v; else g.f1 = v;
+      nev++;
+      continue;
+    }
+    const bool c0 = g.f2 < g.f1;
+    // this role's point: replay the outcomes on the path from the root of the outcome tree to node role + 1
+    double mine = 0.0;
+    {
+      const int node = role + 1;
+      int depth = 0;
+      while ((node >> (depth + 1)) != 0) depth++;
+      golden_state gs = g;
+      double p = golden_step(gs, c0, R, C);
+      bool dead = false;  // the search stops before it gets to this node
+      for (int lvl = depth - 1; lvl >= 0; lvl--) {
+        if (golden_done(gs, tol)) { dead = true; break; }
+        p = golden_step(gs, ((node >> lvl) & 1) == 0, R, C);
+      }
+      if (!dead) mine = eval(p);  // block-uniform
+    }
+    if (!rendezvous(mine)) { solo = true; continue; }
+    // advance up to DEPTH iterations with the values now known
+    int node = 1;
+    bool c = c0;
+#pragma unroll
+    for (int lvl = 0; lvl < DEPTH; lvl++) {
+      (void)golden_step(g, c, R, C);
+      if (c) g.f2 = vals[node]; else g.f1 = vals[node];
+      nev++;
+      if (lvl == DEPTH - 1 || golden_done(g, tol)) break;
+      c = g.f2 < g.f1;
+      node = 2 * node + (c ? 0 : 1);
+    }
   }
   if (ctr && threadIdx.x == 0 && role == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
   return (g.f1 < g.f2 ? g.x1 : g.x2) * sc;

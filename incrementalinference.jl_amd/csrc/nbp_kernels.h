@@ -338,7 +338,7 @@ static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP
 
 // fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)
 __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int Ncap, int Npad, double *smem, nbp_counters *ctr,
-                                                    nbp_spec_area *area = nullptr, int role = 0) {
+                                                    nbp_spec_area *area = nullptr, int role = 0, int depth = 0) {
   const int D = mani_dim(M), n = threadIdx.x;
   if (k >= D) {
     if (n == 0) s[3 * Ncap + k] = 0.0;
@@ -355,8 +355,9 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
     X[n] = X[n + N] = is_circ(M, k) ? wrap_pi(v) : v;
   }
   __syncthreads();
-  if (area) {  // latency mode: NBP_SPEC_K workgroups per fit (lcv_bandwidth_1d_spec)
-    const double hs = lcv_bandwidth_1d_spec(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role);
+  if (area) {  // latency mode: 2^depth - 1 workgroups per fit (lcv_bandwidth_1d_spec)
+    const double hs = depth == 3 ? lcv_bandwidth_1d_spec<3>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role)
+                                 : lcv_bandwidth_1d_spec<2>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role);
     if (n == 0 && role == 0) s[3 * Ncap + k] = hs;
     return;
   }
@@ -371,10 +372,10 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
 // ================================================================================================
 __global__ void __launch_bounds__(1024)
 nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S,
-                     nbp_counters *ctr, nbp_spec_area *spec) {
-  extern __shared__ double smem[];  // grid (jobs, 3, 1 or NBP_SPEC_K)
+                     nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
+  extern __shared__ double smem[];  // grid (jobs, 3, 1 or 2^spec_depth - 1)
   lcv_slot_coordinate(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr,
-                      spec ? spec + (blockIdx.x * 3 + blockIdx.y) : nullptr, blockIdx.z);
+                      spec ? spec + (blockIdx.x * 3 + blockIdx.y) : nullptr, blockIdx.z, spec_depth);
 }
 
 // X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
@@ -575,13 +576,13 @@ static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
 
 __global__ void __launch_bounds__(1024)
 nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
-                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec) {
+                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
   extern __shared__ double smem[];
   const int b = blockIdx.x;
-  const int KS = spec ? NBP_SPEC_K : 1;  // workgroups per (slot, coordinate)
+  const int KS = spec ? (1 << spec_depth) - 1 : 1;  // workgroups per (slot, coordinate)
   if (b < 3 * nbw * KS) {  // manikde! bandwidth of (slot, coordinate)
     const int job = b / (3 * KS), k = (b % (3 * KS)) / KS, role = b % KS;
-    lcv_slot_coordinate(arena + S * bw_slots[job], bw_manis[job], k, N, Npad, smem, ctr, spec ? spec + (job * 3 + k) : nullptr, role);
+    lcv_slot_coordinate(arena + S * bw_slots[job], bw_manis[job], k, N, Npad, smem, ctr, spec ? spec + (job * 3 + k) : nullptr, role, spec_depth);
     return;
   }
   const int q = b - 3 * nbw * KS, p = q / kdF, j = q % kdF;  // kdF = largest nfactors of the batch
