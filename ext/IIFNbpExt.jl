@@ -36,8 +36,8 @@ const NBP_MAXC = 4
 const NBP_COMP_STRIDE = 13
 
 const NBP_EUCLID1, NBP_EUCLID2, NBP_EUCLID3, NBP_CIRCULAR, NBP_SE2 = Int32(1), Int32(2), Int32(3), Int32(4), Int32(5)
-const NBP_F_PRIOR, NBP_F_MSGPRIOR, NBP_F_LINREL, NBP_F_CIRCULAR, NBP_F_SE2, NBP_F_EUCLIDDIST =
-  Int32(1), Int32(2), Int32(3), Int32(4), Int32(5), Int32(6)
+const NBP_F_PRIOR, NBP_F_MSGPRIOR, NBP_F_LINREL, NBP_F_CIRCULAR, NBP_F_SE2, NBP_F_EUCLIDDIST, NBP_F_PASSTHROUGH =
+  Int32(1), Int32(2), Int32(3), Int32(4), Int32(5), Int32(6), Int32(7)
 const NBP_SOLVER_STORED_MEASUREMENTS, NBP_SOLVER_MSG_LIKELIHOODS = Int32(1), Int32(2)
 
 # ---- structs: byte-for-byte mirrors (checked by tests/test_julia_shim_layout.py) ----------------------------------
@@ -57,7 +57,7 @@ struct NbpProposalDesc
   skip_bandwidth::Int32
   partial_mask::Int32
   meas_kde::Int32
-  reserved_::Int32
+  keep_count::Int32
   multihypo::NTuple{NBP_MAXV, Float64}
   nullhypo::Float64
   inflation::Float64
@@ -154,6 +154,7 @@ struct NbpCliqueDesc
   nmsgs::Int32
   msg_var::Ptr{Int32}
   msg_belief::Ptr{NbpTreeBelief}
+  factor_density::Ptr{NbpTreeBelief}
 end
 
 # ---- error mapping: status < 0 -> error() -> the clique Task fails -> monitorCSMs puts ERROR_STATUS on every
@@ -252,7 +253,7 @@ end
 # ---- factors: the closed set libnbp implements (SURVEY a10) ---------------------------------------------------------
 const NbpRelative = Union{LinearRelative, CircularCircular, EuclidDistance, ManifoldFactor}
 const NbpPrior = Union{Prior, PriorCircular, ManifoldPrior}
-const NbpUser = Union{NbpRelative, NbpPrior, Mixture}
+const NbpUser = Union{NbpRelative, NbpPrior, Mixture, PartialPriorPassThrough}
 
 factorkind(::Union{Prior, PriorCircular, ManifoldPrior}) = NBP_F_PRIOR
 factorkind(::LinearRelative) = NBP_F_LINREL
@@ -260,6 +261,7 @@ factorkind(::CircularCircular) = NBP_F_CIRCULAR
 factorkind(::ManifoldFactor) = NBP_F_SE2
 factorkind(::EuclidDistance) = NBP_F_EUCLIDDIST
 factorkind(m::Mixture) = factorkind(m.mechanics)
+factorkind(::PartialPriorPassThrough) = NBP_F_PASSTHROUGH   # its density travels in nbp_clique_desc.factor_density
 
 "one measurement-model component: weight, mean[3], lower Cholesky factor L[3][3] row-major (NBP_COMP_STRIDE doubles)"
 function component(w::Real, Z)::Vector{Float64}
@@ -284,6 +286,7 @@ function components(fnc)::Vector{Float64}
     flat = reduce(vcat, [component(ws[i], zs[i]) for i in eachindex(zs)])
     return vcat(flat, zeros(Float64, NBP_MAXC * NBP_COMP_STRIDE - length(flat)))
   end
+  fnc isa PartialPriorPassThrough && return vcat([1.0], zeros(Float64, NBP_MAXC * NBP_COMP_STRIDE - 1))  # no measurement model
   return vcat(component(1.0, fnc.Z), zeros(Float64, (NBP_MAXC - 1) * NBP_COMP_STRIDE))
 end
 ncomponents(fnc) = fnc isa Mixture ? length(fnc.components) : 1
@@ -336,6 +339,35 @@ end
 function BeliefBuf(mkd::ManifoldKernelDensity, code::Int32, ipc, N::Int)
   return BeliefBuf(code, getPoints(mkd, false), getBW(mkd)[:, 1], ipc, N)
 end
+"the density of a PartialPriorPassThrough (calcProposalBelief, ApproxConv.jl:196-227) in the variable's point layout:
+ its partial coordinates filled in, the others at the identity (antimarginal), bandwidth zero where it says nothing"
+function BeliefBuf(fnc::PartialPriorPassThrough, vt::InferenceVariable, code::Int32)
+  mkd = fnc.Z.heatmap.densityFnc
+  pts = getPoints(mkd, false)
+  D, P = tangentdim(code), pointdoubles(code)
+  part = Int[fnc.partial...]
+  buf = zeros(Float64, length(pts) * P)
+  bw = zeros(Float64, D)
+  h = getBW(mkd)[:, 1]
+  for (i, k) in enumerate(part)
+    bw[k] = h[i]
+  end
+  for (n, p) in enumerate(pts)
+    c = zeros(Float64, D)
+    for (i, k) in enumerate(part)
+      c[k] = p[i]
+    end
+    o = (n - 1) * P
+    if code == NBP_SE2
+      buf[o + 1] = c[1]; buf[o + 2] = c[2]
+      buf[o + 3] = cos(c[3]); buf[o + 4] = sin(c[3]); buf[o + 5] = -sin(c[3]); buf[o + 6] = cos(c[3])
+    else
+      buf[(o + 1):(o + P)] .= c
+    end
+  end
+  return BeliefBuf(buf, bw, ones(Float64, D), length(pts))
+end
+const _NOBELIEF = NbpTreeBelief(Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Int32(0), Int32(0))
 
 # ---- the clique seam --------------------------------------------------------------------------------------------------
 "everything one nbp_clique_* call needs, with the Julia arrays the C struct points into"
@@ -350,6 +382,8 @@ struct CliquePack
   msgs::Vector{NbpTreeBelief}
   bufs::Vector{BeliefBuf}
   beliefs::Vector{NbpTreeBelief}
+  densbuf::Vector{Union{Nothing, BeliefBuf}}   # per user factor: the density of a PartialPriorPassThrough
+  dens::Vector{NbpTreeBelief}
 end
 
 function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, labels::Vector{Symbol}, factors::Vector{<:DFGFactor})
@@ -366,7 +400,11 @@ function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int
   msgvar = Int32[index[getVariableOrder(f)[1]] for f in msgf]
   msgbuf = BeliefBuf[BeliefBuf(getFactorType(f).Z, codes[index[getVariableOrder(f)[1]] + 1], getFactorType(f).infoPerCoord, N) for f in msgf]
   bufs = BeliefBuf[BeliefBuf(dfg, l, solveKey, N) for l in labels]
-  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs))
+  densbuf = Union{Nothing, BeliefBuf}[
+    (fnc = getFactorType(f); v = getVariableOrder(f)[1];
+     fnc isa PartialPriorPassThrough ? BeliefBuf(fnc, getVariableType(dfg, v), codes[index[v] + 1]) : nothing) for f in user]
+  dens = NbpTreeBelief[b === nothing ? _NOBELIEF : cview(b) for b in densbuf]
+  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs), densbuf, dens)
 end
 
 ptr_or_null(v::Vector{T}) where {T} = isempty(v) ? Ptr{T}(C_NULL) : pointer(v)
@@ -376,7 +414,8 @@ function cliquedesc(cliq::TreeClique, p::CliquePack, nfrontals::Int, nseparators
                        pointer(p.codes), pointer(p.margin), Int32(length(p.specs)), ptr_or_null(p.specs),
                        Int32(length(p.lists[1])), Int32(length(p.lists[2])), Int32(length(p.lists[3])), Int32(length(p.lists[4])),
                        ptr_or_null(p.lists[1]), ptr_or_null(p.lists[2]), ptr_or_null(p.lists[3]), ptr_or_null(p.lists[4]),
-                       Int32(length(p.msgvar)), ptr_or_null(p.msgvar), ptr_or_null(p.msgs))
+                       Int32(length(p.msgvar)), ptr_or_null(p.msgvar), ptr_or_null(p.msgs),
+                       any(b -> b !== nothing, p.densbuf) ? pointer(p.dens) : Ptr{NbpTreeBelief}(C_NULL))
 end
 
 "write the beliefs libnbp returned back into the sub graph: setValKDE!(vnd, pts, bw, setinit, ipc) (FactorGraph.jl:250-297)"

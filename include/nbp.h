@@ -68,7 +68,12 @@ enum nbp_factor {
   NBP_F_LINREL = 3,     /* LinearRelative{D}: r = z - (x2 - x1)       Factors/LinearRelative.jl:42-49 */
   NBP_F_CIRCULAR = 4,   /* CircularCircular                            Factors/Circular.jl:24-28       */
   NBP_F_SE2 = 5,        /* ManifoldFactor(SpecialEuclidean(2))         Factors/GenericFunctions.jl:39-44,98-100 */
-  NBP_F_EUCLIDDIST = 6  /* EuclidDistance: r = z - ||x2 - x1||         Factors/EuclidDistance.jl:20    */
+  NBP_F_EUCLIDDIST = 6, /* EuclidDistance: r = z - ||x2 - x1||         Factors/EuclidDistance.jl:20    */
+  NBP_F_PASSTHROUGH = 7 /* PartialPriorPassThrough(Z, partial): the proposal IS the density Z.heatmap.densityFnc, placed on
+                           the coordinates of `.partial` (calcProposalBelief dispatch, ApproxConv.jl:196-227;
+                           Factors/PartialPriorPassThrough.jl).  var_slot[1] = slot holding that density (points in the
+                           variable's coordinates -- only the partial ones are read --, bandwidth, count); nothing is
+                           sampled, solved or fitted, and no hypothesis machinery applies (evalFactor is bypassed) */
 };
 
 /*
@@ -107,7 +112,14 @@ typedef struct nbp_proposal_desc {
                                  CircularCircular(::MKD) of the useMsgLikelihoods upward messages
                                  (TreeMessageUtils.jl:279-335, Factors/LinearRelative.jl:32,
                                  manifolds/services/ManifoldSampling.jl:13-19); relative factors only */
-  int32_t reserved_;
+  int32_t keep_count;         /* NBP_F_PASSTHROUGH only.  1: the proposal keeps the density's own particle count (the
+                                 density is the only factor of the update: "PassThrough transfers the full point count
+                                 to the graph, unless a product is calculated", test/testSpecialEuclidean2Mani.jl:394);
+                                 0: it is resampled (multinomially, no kernel noise: the bandwidth stays) to the N
+                                 points a product needs from every input;
+                                 2: graph initialisation of a variable from this density alone: "the graph should stay
+                                 restricted to N" (resample(bel, N), GraphInit.jl:174-177) -- the density's points
+                                 stay, the rest up to N are draws from its KDE (random kernel + bw * randn) */
   double multihypo[NBP_MAXV]; /* parsed Categorical p: certain variables carry 0.0
                                  (services/FactorGraph.jl:639-651)                            */
   double nullhypo;            /* max(ccw.nullhypo, nullSurplus)   EvalFactor.jl:352            */

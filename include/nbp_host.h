@@ -81,6 +81,14 @@ int32_t nbp_graph_num_factors(const nbp_graph *g);
  * variable v lives in slot v.  nbp_graph_init_compile makes the resident program (run it once) and marks
  * the planned variables initialised in the graph. */
 int32_t nbp_graph_init_plan(nbp_graph *g, uint64_t seed);
+/* NBP_F_PASSTHROUGH priors (PartialPriorPassThrough, ApproxConv.jl:196-227) carry a density that the caller writes
+ * into a slot of its own with nbp_belief_write before running a program, like an initial belief: density i belongs
+ * to factor nbp_graph_density_factors()[i] and sits in slot (density_slot0 + i) of the plan being run — after
+ * nbp_graph_init_plan for the initialisation program, after nbp_tree_plan_slots for the tree solve. */
+int32_t nbp_graph_num_densities(const nbp_graph *g);
+nbp_status nbp_graph_density_factors(const nbp_graph *g, int32_t *factor_ids_out);
+int32_t nbp_graph_init_density_slot0(const nbp_graph *g);
+int32_t nbp_tree_density_slot0(const nbp_tree *t);
 int32_t nbp_graph_init_num_variables(const nbp_graph *g);
 nbp_status nbp_graph_init_variables(const nbp_graph *g, int32_t *vars_out);
 int32_t nbp_graph_init_num_stages(const nbp_graph *g);
@@ -195,6 +203,10 @@ typedef struct nbp_clique_desc {
   int32_t nmsgs;
   const int32_t *msg_var;            /* [nmsgs] index into the variable list */
   const nbp_tree_belief *msg_belief; /* [nmsgs] */
+  /* [nfactors] or NULL: the density of every NBP_F_PASSTHROUGH factor (PartialPriorPassThrough.Z, a
+   * ManifoldKernelDensity; its points, bandwidth and point count become the proposal as they are,
+   * ApproxConv.jl:196-227); entries of other factors are ignored */
+  const nbp_tree_belief *factor_density;
 } nbp_clique_desc;
 
 /* slots a context needs for this clique (nbp_ctx_create(..., n_slots >= this)) */

@@ -11,7 +11,7 @@ MAXV, MAXF, MAXD, MAXC, MAXN, COMP_STRIDE = 6, 128, 3, 4, 512, 13
 # enum nbp_manifold
 EUCLID1, EUCLID2, EUCLID3, CIRCULAR, SE2 = 1, 2, 3, 4, 5
 # enum nbp_factor
-F_PRIOR, F_MSGPRIOR, F_LINREL, F_CIRCULAR, F_SE2, F_EUCLIDDIST = 1, 2, 3, 4, 5, 6
+F_PRIOR, F_MSGPRIOR, F_LINREL, F_CIRCULAR, F_SE2, F_EUCLIDDIST, F_PASSTHROUGH = 1, 2, 3, 4, 5, 6, 7
 STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES, STAGE_DECONV, STAGE_COPY_POINTS = 1, 2, 3, 4, 5
 OPT_LAZY_BANDWIDTH = 1
 OPT_GRAPH_REPLAY = 2
@@ -36,7 +36,7 @@ class ProposalDesc(C.Structure):
         ("skip_bandwidth", C.c_int32),
         ("partial_mask", C.c_int32),
         ("meas_kde", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("keep_count", C.c_int32),
         ("multihypo", C.c_double * MAXV),
         ("nullhypo", C.c_double),
         ("inflation", C.c_double),

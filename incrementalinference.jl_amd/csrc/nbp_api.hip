@@ -325,7 +325,17 @@ static nbp_status check_proposals(nbp_ctx *c, const nbp_proposal_desc *d, int n)
   for (int i = 0; i < n; i++) {
     const nbp_proposal_desc &p = d[i];
     if (!manifold_ok(p.manifold)) return fail(NBP_ERR_ARG, "proposal: unknown manifold");
-    if (p.factor_kind < NBP_F_PRIOR || p.factor_kind > NBP_F_EUCLIDDIST) return fail(NBP_ERR_ARG, "proposal: unknown factor kind");
+    if (p.factor_kind < NBP_F_PRIOR || p.factor_kind > NBP_F_PASSTHROUGH) return fail(NBP_ERR_ARG, "proposal: unknown factor kind");
+    if (p.factor_kind == NBP_F_PASSTHROUGH) {  // the density is the proposal: a unary factor, two slots, an optional partial mask
+      if (p.nvars != 1 || p.sfidx != 0) return fail(NBP_ERR_ARG, "proposal: a pass-through prior is unary");
+      if (p.out_slot < 0 || p.out_slot >= c->n_slots) return fail(NBP_ERR_RANGE, "proposal: out_slot");
+      for (int k = 0; k < 2; k++)
+        if (p.var_slot[k] < 0 || p.var_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "proposal: var_slot");
+      if (p.partial_mask < 0 || p.partial_mask >= (1 << manifold_dim_h(p.manifold))) return fail(NBP_ERR_RANGE, "proposal: partial_mask");
+      if (p.has_multihypo || p.nullhypo != 0.0) return fail(NBP_ERR_ARG, "proposal: a pass-through prior takes no multihypo / nullhypo (evalFactor is bypassed)");
+      if (p.keep_count < 0 || p.keep_count > 2) return fail(NBP_ERR_RANGE, "proposal: keep_count");
+      continue;
+    }
     if (p.nvars < 1 || p.nvars > NBP_MAXV) return fail(NBP_ERR_RANGE, "proposal: nvars");
     if (p.sfidx < 0 || p.sfidx >= p.nvars) return fail(NBP_ERR_RANGE, "proposal: sfidx");
     if (p.ncomp < 1 || p.ncomp > NBP_MAXC) return fail(NBP_ERR_RANGE, "proposal: ncomp");
@@ -594,7 +604,7 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
 // bandwidth jobs of a batch of proposals / products (host side)
 static void jobs_of_proposals(const nbp_proposal_desc *d, int n, std::vector<int32_t> &slots, std::vector<int32_t> &manis) {
   for (int i = 0; i < n; i++)
-    if (!d[i].skip_bandwidth) { slots.push_back(d[i].out_slot); manis.push_back(d[i].manifold); }
+    if (!d[i].skip_bandwidth && d[i].factor_kind != NBP_F_PASSTHROUGH) { slots.push_back(d[i].out_slot); manis.push_back(d[i].manifold); }
 }
 static void jobs_of_products(const nbp_product_desc *d, int n, std::vector<int32_t> &slots, std::vector<int32_t> &manis) {
   for (int i = 0; i < n; i++)
@@ -759,7 +769,7 @@ nbp_status nbp_conv(nbp_ctx *c, const nbp_proposal_desc *tmpl, const double *con
                     const int32_t *mhidx_in, double *out_pts, double *out_bw, int32_t *out_mhidx) {
   if (!c || !tmpl || !var_pts || !out_pts) return fail(NBP_ERR_ARG, "null argument");
   nbp_proposal_desc d = *tmpl;
-  const int nin = (d.factor_kind == NBP_F_MSGPRIOR) ? 2 : d.nvars;
+  const int nin = (d.factor_kind == NBP_F_MSGPRIOR || d.factor_kind == NBP_F_PASSTHROUGH) ? 2 : d.nvars;
   if (nin < 1 || nin > NBP_MAXV) return fail(NBP_ERR_RANGE, "conv: nvars");
   if (c->n_slots < nin + 1) return fail(NBP_ERR_RANGE, "conv: the context needs nvars + 1 slots");
   if ((mhidx_in || out_mhidx) && c->side_ints < 2 * c->N) return fail(NBP_ERR_RANGE, "conv: the context needs 2N side ints");
@@ -1003,7 +1013,7 @@ static nbp_liveness product_liveness(const nbp_program *p) {
       const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
       L.dead_proposal[s].assign(st.n, 0);
       for (int i = 0; i < st.n; i++) {
-        if (pd[i].factor_kind == NBP_F_MSGPRIOR) read_kde(pd[i].var_slot[1]);  // read: live
+        if (pd[i].factor_kind == NBP_F_MSGPRIOR || pd[i].factor_kind == NBP_F_PASSTHROUGH) read_kde(pd[i].var_slot[1]);  // read: live
         if (pd[i].meas_kde > 0) read_kde(pd[i].meas_kde - 1);
       }
       for (int i = 0; i < st.n; i++) {
@@ -1071,7 +1081,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       // a MsgPrior samples from the KDE in var_slot[1] (points AND bandwidth)
       for (int i = 0; i < st.n && !st.flush_before; i++) {
         const nbp_proposal_desc &pd = ((const nbp_proposal_desc *)d)[i];
-        if (pd.factor_kind == NBP_F_MSGPRIOR)
+        if (pd.factor_kind == NBP_F_MSGPRIOR || pd.factor_kind == NBP_F_PASSTHROUGH)
           for (int32_t ps : pend_s) st.flush_before |= (ps == pd.var_slot[1]);
         if (pd.meas_kde > 0)  // a measurement KDE: points and bandwidth
           for (int32_t ps : pend_s) st.flush_before |= (ps == pd.meas_kde - 1);
@@ -1080,7 +1090,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       if (p->lazy_bw) {
         const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
         for (int i = 0; i < st.n; i++)
-          if (!pd[i].skip_bandwidth && !live.dead_proposal[sidx][i]) { pend_s.push_back(pd[i].out_slot); pend_m.push_back(pd[i].manifold); }
+          if (!pd[i].skip_bandwidth && pd[i].factor_kind != NBP_F_PASSTHROUGH && !live.dead_proposal[sidx][i]) { pend_s.push_back(pd[i].out_slot); pend_m.push_back(pd[i].manifold); }
       } else
         jobs_of_proposals((const nbp_proposal_desc *)d, st.n, pend_s, pend_m);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {

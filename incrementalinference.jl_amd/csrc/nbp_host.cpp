@@ -23,7 +23,7 @@ static nbp_status hfail(nbp_status c, const char *m) { return nbp_internal_fail(
 namespace {
 
 struct HVar { int manifold; bool initialized, ismargin; };
-struct HFac { nbp_factor_spec s; bool is_prior; };
+struct HFac { nbp_factor_spec s; bool is_prior; int dens = -1; /* index among the graph's pass-through densities */ };
 
 inline int mani_dim(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
 inline int mani_P(int m) { return m == NBP_SE2 ? 6 : mani_dim(m); }
@@ -76,6 +76,8 @@ struct nbp_graph {
   std::vector<HVar> vars;
   std::vector<HFac> facs;
   std::vector<std::vector<int>> vfacs;  // variable -> factor ids, insertion order
+  std::vector<int> dens_facs;           // PartialPriorPassThrough factors: each owns a density slot in every plan
+  int init_dens0 = 0;                   // first density slot of the last graph-initialisation plan
   // graph initialisation (initAll!): last plan
   std::vector<int> init_vars;
   std::vector<Stage> init_stages;
@@ -89,7 +91,7 @@ struct nbp_tree {
   std::vector<int> frontal_of;  // variable -> clique id
   std::vector<int> roots;
   // slot plan
-  int snapshot = 0, n_slots = 0;
+  int snapshot = 0, n_slots = 0, dens0 = 0;  // dens0: first of the pass-through density slots (after main / snap)
   std::vector<int> main_slot, snap_slot;
   std::vector<std::map<int, int>> B;  // per clique: variable -> slot
   std::vector<int> scratch;           // per clique: first scratch slot
@@ -612,7 +614,7 @@ std::vector<Entry> joint_entries(const Clique &c, int v, bool down) {
 
 void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, int msg_slot, int target, const std::map<int, int> *Bc,
                    const std::vector<int> *main_slot, const std::set<int> *inclq, int out_slot, uint64_t seed, double nullSurplus,
-                   const std::vector<char> *isinit = nullptr) {
+                   const std::vector<char> *isinit = nullptr, int keep_count = 0) {
   memset(&d, 0, sizeof(d));
   const nbp_solver_params &sp = g->sp;
   auto slot_of = [&](int v) { return Bc == nullptr ? v : ((inclq == nullptr || inclq->count(v)) ? Bc->at(v) : (*main_slot)[v]); };
@@ -635,6 +637,20 @@ void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, in
     return;
   }
   const nbp_factor_spec &s = fac->s;
+  if (s.factor_kind == NBP_F_PASSTHROUGH) {  // the density is the proposal (ApproxConv.jl:196-227); msg_slot = its slot
+    d.factor_kind = NBP_F_PASSTHROUGH;
+    d.partial_mask = s.partial_mask;
+    d.inflation = s.inflation > 0 ? s.inflation : sp.inflation;
+    d.nvars = 1;
+    d.sfidx = 0;
+    d.var_slot[0] = slot_of(target);
+    d.var_slot[1] = msg_slot;
+    d.ncomp = 1;
+    d.comp[0][0] = 1.0;
+    d.skip_bandwidth = 1;
+    d.keep_count = keep_count;  // the only factor of its update: 1 = the belief keeps the density's point count, 2 = graph init
+    return;
+  }
   d.factor_kind = s.factor_kind;
   d.partial_mask = s.partial_mask;
   d.inflation = s.inflation > 0 ? s.inflation : sp.inflation;
@@ -731,10 +747,11 @@ nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &ent
     }
     double ns = 0.0;  // _null_surplus: relative non-multihypo siblings of a multihypo factor
     if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = g->sp.null_surplus_add;
-    const int msg_slot = e.tag == 'm' ? t->msg_slot(e.a, v) : -1;
+    int msg_slot = e.tag == 'm' ? t->msg_slot(e.a, v) : -1;
+    if (fac && fac->s.factor_kind == NBP_F_PASSTHROUGH) msg_slot = t->dens0 + fac->dens;  // the slot of its density
     nbp_proposal_desc d;
     const uint64_t sd = op_seed(seed, passid, cid, step, i + 1);
-    fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, sd, ns);
+    fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, sd, ns, nullptr, F == 1 ? 1 : 0);
     if (e.tag == 'd') d.meas_kde = t->cl[e.a - 1].Dslot[e.b] + 1;
     {  // needFreshMeasurements (SolveTree.jl:119): one stored measurement per factor object
       const std::array<int, 5> key{cid, (int)e.tag, e.a, e.b, e.tag == 'm' ? v : -1};
@@ -796,18 +813,20 @@ int32_t nbp_graph_add_variable(nbp_graph *g, int32_t manifold) {
 }
 int32_t nbp_graph_add_factor(nbp_graph *g, const nbp_factor_spec *s) {
   if (!g || !s) return hfail(NBP_ERR_ARG, "null argument");
-  if (s->factor_kind < NBP_F_PRIOR || s->factor_kind > NBP_F_EUCLIDDIST || s->factor_kind == NBP_F_MSGPRIOR)
+  if (s->factor_kind < NBP_F_PRIOR || s->factor_kind > NBP_F_PASSTHROUGH || s->factor_kind == NBP_F_MSGPRIOR)
     return hfail(NBP_ERR_ARG, "factor: unknown kind");
   if (s->nvars < 1 || s->nvars > NBP_MAXV) return hfail(NBP_ERR_RANGE, "factor: nvars");
   if (s->ncomp < 1 || s->ncomp > NBP_MAXC) return hfail(NBP_ERR_RANGE, "factor: ncomp");
-  const bool prior = s->factor_kind == NBP_F_PRIOR;
+  const bool prior = s->factor_kind == NBP_F_PRIOR || s->factor_kind == NBP_F_PASSTHROUGH;
   if (prior && s->nvars != 1) return hfail(NBP_ERR_ARG, "priors are unary factors");
+  if (s->factor_kind == NBP_F_PASSTHROUGH && s->has_multihypo) return hfail(NBP_ERR_ARG, "a pass-through prior takes no multihypo");
   for (int i = 0; i < s->nvars; i++)
     if (s->vars[i] < 0 || s->vars[i] >= (int)g->vars.size()) return hfail(NBP_ERR_RANGE, "factor: variable id");
   HFac f;
   f.s = *s;
   f.is_prior = prior;
   const int id = (int)g->facs.size();
+  if (s->factor_kind == NBP_F_PASSTHROUGH) { f.dens = (int)g->dens_facs.size(); g->dens_facs.push_back(id); }
   g->facs.push_back(f);
   for (int i = 0; i < s->nvars; i++) g->vfacs[s->vars[i]].push_back(id);
   return id;
@@ -927,6 +946,8 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
     for (int v = 0; v < n; v++) t->snap_slot[v] = nxt + v;
     nxt += n;
   }
+  t->dens0 = nxt;  // one slot per pass-through density, written by the caller like the initial beliefs
+  nxt += (int)g->dens_facs.size();
   t->B.assign(t->cl.size(), {});
   t->ghost.assign(t->cl.size(), {});
   t->scratch.assign(t->cl.size(), 0);
@@ -1385,6 +1406,7 @@ int32_t nbp_graph_init_plan(nbp_graph *g, uint64_t seed) {
   }
   size_t width = 0;
   for (auto &gr : groups) width = std::max(width, gr.size());
+  g->init_dens0 = V + (int)(width * maxF);  // V beliefs | proposal scratch | the pass-through densities
   nbp_tree tmp;  // only for add_stage's container
   tmp.g = g;
   for (auto &gr : groups) {
@@ -1401,7 +1423,8 @@ int32_t nbp_graph_init_plan(nbp_graph *g, uint64_t seed) {
         const HFac &fac = g->facs[p.use[i]];
         const double ns = (anymh && !fac.is_prior && !fac.s.has_multihypo) ? g->sp.null_surplus_add : 0.0;
         nbp_proposal_desc d;
-        fill_proposal(g, d, &fac, -1, p.sym, nullptr, nullptr, nullptr, base + (int)i, op_seed(seed, PASS_INIT, p.sym, 0, i + 1), ns, &p.state);
+        fill_proposal(g, d, &fac, fac.dens >= 0 ? g->init_dens0 + fac.dens : -1, p.sym, nullptr, nullptr, nullptr, base + (int)i,
+                      op_seed(seed, PASS_INIT, p.sym, 0, i + 1), ns, &p.state, p.use.size() == 1 ? 2 : 0);
         props.push_back(d);
         q.in_slot[i] = base + (int)i;
         q.in_partial[i] = (uint8_t)fac.s.partial_mask;
@@ -1422,9 +1445,19 @@ int32_t nbp_graph_init_plan(nbp_graph *g, uint64_t seed) {
   }
   g->init_stages = std::move(tmp.stages);
   for (auto &p : plan) g->init_vars.push_back(p.sym);
-  g->init_slots = V + (int)(width * maxF);
+  g->init_slots = V + (int)(width * maxF) + (int)g->dens_facs.size();
   return g->init_slots;
 }
+
+// pass-through priors: factor ids in density order, and where their slots start in the two slot plans
+int32_t nbp_graph_num_densities(const nbp_graph *g) { return g ? (int32_t)g->dens_facs.size() : 0; }
+nbp_status nbp_graph_density_factors(const nbp_graph *g, int32_t *out) {
+  if (!g || !out) return hfail(NBP_ERR_ARG, "null argument");
+  for (size_t i = 0; i < g->dens_facs.size(); i++) out[i] = g->dens_facs[i];
+  return NBP_OK;
+}
+int32_t nbp_graph_init_density_slot0(const nbp_graph *g) { return g ? g->init_dens0 : hfail(NBP_ERR_ARG, "null argument"); }
+int32_t nbp_tree_density_slot0(const nbp_tree *t) { return t ? t->dens0 : hfail(NBP_ERR_ARG, "null argument"); }
 
 int32_t nbp_graph_init_num_variables(const nbp_graph *g) { return g ? (int32_t)g->init_vars.size() : 0; }
 nbp_status nbp_graph_init_variables(const nbp_graph *g, int32_t *out) {
@@ -1469,7 +1502,12 @@ static nbp_status clique_check(const nbp_solver_params *sp, const nbp_clique_des
     if (q->manifold[v] < NBP_EUCLID1 || q->manifold[v] > NBP_SE2) return hfail(NBP_ERR_ARG, "clique: unknown manifold");
   for (int f = 0; f < q->nfactors; f++) {
     const nbp_factor_spec &s = q->factors[f];
-    if (s.factor_kind < NBP_F_PRIOR || s.factor_kind > NBP_F_EUCLIDDIST || s.factor_kind == NBP_F_MSGPRIOR) return hfail(NBP_ERR_ARG, "clique: factor kind");
+    if (s.factor_kind < NBP_F_PRIOR || s.factor_kind > NBP_F_PASSTHROUGH || s.factor_kind == NBP_F_MSGPRIOR) return hfail(NBP_ERR_ARG, "clique: factor kind");
+    if (s.factor_kind == NBP_F_PASSTHROUGH) {
+      if (s.nvars != 1 || s.has_multihypo) return hfail(NBP_ERR_ARG, "clique: a pass-through prior is unary, without multihypo");
+      if (!q->factor_density || !q->factor_density[f].pts || !q->factor_density[f].bw)
+        return hfail(NBP_ERR_ARG, "clique: a pass-through prior needs its density (factor_density[f])");
+    }
     if (s.nvars < 1 || s.nvars > NBP_MAXV || s.ncomp < 1 || s.ncomp > NBP_MAXC) return hfail(NBP_ERR_RANGE, "clique: factor shape");
     for (int i = 0; i < s.nvars; i++)
       if (s.vars[i] < 0 || s.vars[i] >= q->nvars) return hfail(NBP_ERR_RANGE, "clique: factor variable index");
@@ -1508,7 +1546,9 @@ int32_t nbp_clique_slots(const nbp_clique_desc *q) {
     clique_entries(q, v, true, fa, ms);
     maxf = std::max(maxf, fa.size() + ms.size());
   }
-  return q->nvars + q->nmsgs + (int32_t)maxf;
+  int ndens = 0;
+  for (int f = 0; f < q->nfactors; f++) ndens += q->factors && q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
+  return q->nvars + q->nmsgs + ndens + (int32_t)maxf;
 }
 
 static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
@@ -1521,9 +1561,14 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   g.sp = *sp;
   for (int v = 0; v < q->nvars; v++) g.vars.push_back({q->manifold[v], true, q->ismargin ? q->ismargin[v] != 0 : false});
   std::vector<HFac> facs(q->nfactors);
-  for (int f = 0; f < q->nfactors; f++) { facs[f].s = q->factors[f]; facs[f].is_prior = q->factors[f].factor_kind == NBP_F_PRIOR; }
-  // slot plan: the clique's variables | the message beliefs | proposal scratch
-  const int msg0 = q->nvars, base = q->nvars + q->nmsgs;
+  int ndens = 0;
+  for (int f = 0; f < q->nfactors; f++) {
+    facs[f].s = q->factors[f];
+    facs[f].is_prior = q->factors[f].factor_kind == NBP_F_PRIOR || q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
+    if (q->factors[f].factor_kind == NBP_F_PASSTHROUGH) facs[f].dens = ndens++;
+  }
+  // slot plan: the clique's variables | the message beliefs | the pass-through densities | proposal scratch
+  const int msg0 = q->nvars, dens0 = q->nvars + q->nmsgs, base = dens0 + ndens;
   // ---- schedule ------------------------------------------------------------------------------------------
   std::vector<int> sched, iter;
   std::vector<int> fa, ms;
@@ -1585,6 +1630,12 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
     rc = nbp_belief_write(ctx, msg0 + i, q->manifold[q->msg_var[i]], m.pts, m.n_pts, m.bw, m.ipc);
     if (rc) return rc;
   }
+  for (int f = 0; f < q->nfactors; f++) {
+    if (facs[f].dens < 0) continue;
+    const nbp_tree_belief &m = q->factor_density[f];
+    rc = nbp_belief_write(ctx, dens0 + facs[f].dens, q->manifold[facs[f].s.vars[0]], m.pts, m.n_pts, m.bw, m.ipc);
+    if (rc) return rc;
+  }
   // ---- the schedule as a resident program ------------------------------------------------------------------
   nbp_program *p = nullptr;
   rc = nbp_program_create(ctx, &p);
@@ -1617,7 +1668,8 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
       if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = sp->null_surplus_add;
       nbp_proposal_desc d;
       const uint64_t sd = op_seed(seed, passid, q->clique_id, (uint64_t)k, (uint64_t)(i + 1));
-      fill_proposal(&g, d, fac, ismsg ? msg0 + mi : -1, v, nullptr, nullptr, nullptr, base + i, sd, ns);
+      fill_proposal(&g, d, fac, ismsg ? msg0 + mi : (fac->dens >= 0 ? dens0 + fac->dens : -1), v, nullptr, nullptr, nullptr, base + i, sd, ns,
+                    nullptr, F == 1 ? 1 : 0);
       const std::pair<int, int> key{ismsg ? 1 : 0, ismsg ? mi : fa[i]};
       if (fresh) meas_seed[key] = sd;
       else {

@@ -112,7 +112,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
   NBP_CTICK_INIT();
   if (n == 0) build_recipe(d, &R);
   {
-    const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR) ? 0 : d->sfidx];
+    const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR || kind == NBP_F_PASSTHROUGH) ? 0 : d->sfidx];
     // resize!(target copy, N): entries beyond the belief's own count are the point default (CalcFactor.jl:555-565)
     const int ct = slot_count(src, N);
     if (live)
@@ -134,6 +134,43 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
   }
   __syncthreads();
 
+  if (kind == NBP_F_PASSTHROUGH) {
+    // calcProposalBelief(::PartialPriorPassThrough) (ApproxConv.jl:196-227): the density itself, on the partial coordinates
+    // (antimarginal); the other coordinates of the scratch copy stay the target's
+    const double *den = arena + S * d->var_slot[1];
+    const int cd = slot_count(den, N), pm = d->partial_mask ? d->partial_mask : 7;
+    int idx = n;
+    if (!d->keep_count && cd < N) {  // multinomial resampling to N (a product needs N points from every input)
+      double ua, ub;
+      uniform_pair(d->seed, n, PURP_KDESEL, 0, ua, ub);
+      idx = (int)(ua * cd);
+      if (idx >= cd) idx = cd - 1;
+    }
+    double nz[4] = {0, 0, 0, 0};
+    if (d->keep_count == 2 && cd < N && n >= cd) {  // resample(bel, N) of graph initialisation (GraphInit.jl:174-177):
+      double ua, ub;                                 // the density's points stay, the rest are draws from its KDE
+      uniform_pair(d->seed, n, PURP_OLDSEL, 0, ua, ub);
+      idx = (int)(ua * cd);
+      if (idx >= cd) idx = cd - 1;
+      normal_pair(d->seed, n, PURP_OLDNOISE, 0, nz[0], nz[1]);
+      if (D > 2) normal_pair(d->seed, n, PURP_OLDNOISE, 1, nz[2], nz[3]);
+    }
+    if (live && idx < cd)
+      for (int k = 0; k < D; k++)
+        if ((pm >> k) & 1) {
+          const double v = den[k * N + idx] + den[3 * N + k] * nz[k];
+          X[k * N + n] = (nz[k] != 0.0 && is_circ(M, k)) ? wrap_pi(v) : v;
+        }
+    if (live)
+      for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
+    if (n < 3) {
+      const bool in = n < D && ((pm >> n) & 1);
+      out[3 * N + n] = in ? den[3 * N + n] : 0.0;   // the density's own bandwidth: nothing is fitted
+      out[3 * N + 3 + n] = in ? 1.0 : 0.0;          // infoPerCoord
+    }
+    if (n == 0) out[3 * N + 6] = (d->keep_count == 1 && cd < N) ? (double)cd : 0.0;
+    return;
+  }
   if (kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR) {
     // evalPotentialSpecific(prior), EvalFactor.jl:400-542
     const double spread = d->spread_nh * std_basic_spread(X, N, N, M, red);  // :464, before the overwrite

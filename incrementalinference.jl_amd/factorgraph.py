@@ -209,6 +209,38 @@ class Mixture(_Factor):
         return out
 
 
+class PartialPriorPassThrough(_Factor):
+    """PartialPriorPassThrough(Z, partial): a prior whose density is handed to inference as it is -- no sampling, no
+    solve, no bandwidth fit (Factors/PartialPriorPassThrough.jl; calcProposalBelief dispatch, ApproxConv.jl:196-227).
+    `points` (n x len(partial)) and `bw` (len(partial)) are that density, `Z.heatmap.densityFnc` of the reference's
+    HeatmapGridDensity / LevelSetGridNormal; n need not equal the solver's N."""
+    kind, is_prior = abi.F_PASSTHROUGH, True
+
+    def __init__(self, varType, points, bw, partial=None):
+        self.varType = varType
+        self.partial = tuple(partial) if partial is not None else tuple(range(1, varType.dim + 1))
+        self.partial_mask = _partial_mask(self.partial, varType.dim) if len(self.partial) < varType.dim else 0
+        pts = np.atleast_2d(np.asarray(points, dtype=float))
+        if pts.shape[1] != len(self.partial) or len(np.atleast_1d(bw)) != len(self.partial):
+            raise ValueError("PartialPriorPassThrough: points / bw must have len(partial) columns")
+        self.points, self.bw = pts, np.atleast_1d(np.asarray(bw, dtype=float))
+        self.slot = None  # device slot of the density, set by whoever plans the slots
+
+    def components(self):
+        return [(1.0, np.zeros(1), np.zeros((1, 1)))]
+
+    def density_belief(self):
+        """(points n x P in the variable's point layout, bw D): the partial coordinates filled, the others zero"""
+        D, n = self.varType.dim, self.points.shape[0]
+        c, b = np.zeros((n, D)), np.zeros(D)
+        for i, k in enumerate(self.partial):
+            c[:, k - 1], b[k - 1] = self.points[:, i], self.bw[i]
+        if self.varType.manifold == abi.SE2:
+            th = c[:, 2]
+            c = np.stack([c[:, 0], c[:, 1], np.cos(th), np.sin(th), -np.sin(th), np.cos(th)], axis=1)
+        return c, b
+
+
 class MsgPrior(_Factor):
     """MsgPrior(belief): tree message as a prior (Factors/MsgPrior.jl:10-36,
     services/TreeMessageUtils.jl:86-89).  `slot` holds the TreeBelief (val + bw) on the device."""

@@ -48,7 +48,7 @@ class CliqueDescC(C.Structure):
                 ("n_direct_frtl_msg", i32), ("n_msgskip", i32), ("n_itervar", i32), ("n_direct_prior_msg", i32),
                 ("direct_frtl_msg", C.POINTER(i32)), ("msgskip", C.POINTER(i32)), ("itervar", C.POINTER(i32)),
                 ("direct_prior_msg", C.POINTER(i32)), ("nmsgs", i32), ("msg_var", C.POINTER(i32)),
-                ("msg_belief", C.POINTER(TreeBeliefC))]
+                ("msg_belief", C.POINTER(TreeBeliefC)), ("factor_density", C.POINTER(TreeBeliefC))]
 
 
 CLIQ_UPSOLVED, CLIQ_DOWNSOLVED = 3, 5  # enum nbp_cliq_status
@@ -59,7 +59,8 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
                 "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve",
-                "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment"]
+                "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment",
+                "nbp_graph_num_densities", "nbp_graph_density_factors", "nbp_graph_init_density_slot0", "nbp_tree_density_slot0"]
 
 _declared = False
 
@@ -79,6 +80,10 @@ def _lib():
         lib.nbp_graph_order_nested_dissection.argtypes = [vp, ip]
         lib.nbp_graph_init_plan.argtypes = [vp, C.c_uint64]
         lib.nbp_graph_init_num_variables.argtypes = [vp]
+        lib.nbp_graph_num_densities.argtypes = [vp]
+        lib.nbp_graph_density_factors.argtypes = [vp, ip]
+        lib.nbp_graph_init_density_slot0.argtypes = [vp]
+        lib.nbp_tree_density_slot0.argtypes = [vp]
         lib.nbp_graph_init_variables.argtypes = [vp, ip]
         lib.nbp_graph_init_num_stages.argtypes = [vp]
         lib.nbp_graph_init_stage.argtypes = [vp, i32, ip, ip, vp, i64]
@@ -220,6 +225,17 @@ def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, mani
     mv = (i32 * max(1, len(msgs)))(*[idx[v] for v, _ in msgs])
     mb = (TreeBeliefC * max(1, len(msgs)))(*[b.c() for _, b in msgs])
     q.nmsgs, q.msg_var, q.msg_belief = len(msgs), mv, mb
+    dens = []  # the densities of the pass-through priors ride along with their factors
+    for f in factors:
+        if f.fnc.kind == abi.F_PASSTHROUGH:
+            pts, bw = f.fnc.density_belief()
+            dens.append(Belief(f.fnc.varType.manifold, pts, bw))
+        else:
+            dens.append(None)
+    if any(d is not None for d in dens):
+        fd = (TreeBeliefC * len(factors))(*[d.c() if d is not None else TreeBeliefC() for d in dens])
+        q.factor_density = fd
+        keep += [fd, dens]
     need = _check(lib.nbp_clique_slots(C.byref(q)))
     if need > backend.n_slots:
         raise ValueError(f"the context has {backend.n_slots} slots, this clique needs {need}")
@@ -264,6 +280,21 @@ class NativeGraph:
         out = (i32 * max(1, k))()
         _check(self.lib.nbp_graph_init_variables(self._g, out))
         return n, [self.labels[out[i]] for i in range(k)]
+
+    def density_factors(self):
+        """labels of the pass-through priors, in the order of their density slots"""
+        k = self.lib.nbp_graph_num_densities(self._g)
+        out = (i32 * max(1, k))()
+        _check(self.lib.nbp_graph_density_factors(self._g, out))
+        return [self.flabels[out[i]] for i in range(k)]
+
+    def init_density_slot0(self):
+        return _check(self.lib.nbp_graph_init_density_slot0(self._g))
+
+    def place_densities(self, fg, slot0):
+        """tell the factor objects which slot their density goes to (solver.write_densities writes them)"""
+        for i, fl in enumerate(self.density_factors()):
+            fg.getFactor(fl).fnc.slot = slot0 + i
 
     def init_stages(self):
         return _stages_of(lambda s, kind, n, buf, cap: self.lib.nbp_graph_init_stage(self._g, s, kind, n, buf, cap),
@@ -349,6 +380,9 @@ class NativeTree:
             _check(self.lib.nbp_tree_segment(self._t, i, None, None, None, None, None, sx, rx, cap))
             out.append(("xchg", [(sx[k].peer, sx[k].slot) for k in range(ns.value)], [(rx[k].peer, rx[k].slot) for k in range(nr.value)]))
         return out
+
+    def density_slot0(self):
+        return _check(self.lib.nbp_tree_density_slot0(self._t))
 
     def plan_slots(self, snapshot=False):
         self.n_slots = _check(self.lib.nbp_tree_plan_slots(self._t, int(snapshot)))

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import abi, bayestree, jointmsg
 from .backend import HipBackend
-from .factorgraph import DFGFactor, DifferentialRelative, MsgPrior
+from .factorgraph import DFGFactor, DifferentialRelative, MsgPrior, PartialPriorPassThrough
 from .seeds import op_seed
 
 PASS_INIT, PASS_UP, PASS_DOWN, PASS_UNIT = 0, 1, 2, 3
@@ -32,7 +32,7 @@ PRODUCT_ID = 0xFFFF
 # descriptor builders
 # ------------------------------------------------------------------------------------------------
 def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhidx_in=-1, mhidx_out=-1,
-                  skip_bandwidth=False, inflateCycles=None, isinit=None, meas_seed=0):
+                  skip_bandwidth=False, inflateCycles=None, isinit=None, meas_seed=0, alone=False):
     """One approxConvBelief(dfg, fct, target) as a libnbp descriptor (ApproxConv.jl:4-45 +
     evalFactor kwargs, EvalFactor.jl:571-603)."""
     sp = fg.solverParams
@@ -51,6 +51,14 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     d.nullhypo = max(fct.nullhypo, nullSurplus)  # EvalFactor.jl:352
     d.seed = seed
     d.meas_seed = meas_seed  # needFreshMeasurements = false: reuse the samples of the op with that seed
+    if isinstance(fnc, PartialPriorPassThrough):
+        # the density is the proposal (ApproxConv.jl:196-227): no hypotheses, no fit; alone in its update it keeps its
+        # own particle count (alone = 1; 2 = graph initialisation tops it up to N), in a product it is resampled to N
+        d.nvars, d.sfidx, d.ncomp = 1, 0, 1
+        d.var_slot[0], d.var_slot[1] = slot_of(target), fnc.slot
+        d.comp[0][0] = 1.0
+        d.nullhypo, d.skip_bandwidth, d.keep_count = 0.0, 1, int(alone)
+        return d
     if isinstance(fnc, MsgPrior):
         d.nvars, d.sfidx = 1, 0
         d.var_slot[0] = slot_of(target)
@@ -112,6 +120,26 @@ def product_desc(manifold, in_slots, out_slot, seed, niter=1, labels_out=-1, par
     return d
 
 
+def passthrough_factors(fg, labels=None):
+    """labels of the PartialPriorPassThrough factors (of the whole graph, or among `labels`)"""
+    return [f for f in (fg.lsf() if labels is None else labels) if isinstance(fg.getFactor(f).fnc, PartialPriorPassThrough)]
+
+
+def _plan_densities(fg, labels, first_slot):
+    """give every pass-through factor among `labels` a slot from `first_slot` on; returns the number of slots taken"""
+    pts = passthrough_factors(fg, labels)
+    for i, f in enumerate(pts):
+        fg.getFactor(f).fnc.slot = first_slot + i
+    return len(pts)
+
+
+def write_densities(fg, be, labels=None):
+    for f in passthrough_factors(fg, labels):
+        fnc = fg.getFactor(f).fnc
+        pts, bw = fnc.density_belief()
+        be.belief_write(fnc.slot, fnc.varType.manifold, pts, bw)
+
+
 def _partials(fcts):
     return [getattr(f.fnc, "partial_mask", 0) for f in fcts]
 
@@ -146,19 +174,21 @@ def approxConvBelief(fg, fctlabel, target, backend=None, seed=0, nullSurplus=0.0
     labels = list(fct.variables)
     slot = {v: i for i, v in enumerate(labels)}
     out = len(labels)
-    be, own = _make_backend(backend, N, out + 1, side_ints=2 * N)
+    nd = _plan_densities(fg, [fctlabel], out + 1)
+    be, own = _make_backend(backend, N, out + 1 + nd, side_ints=2 * N)
     try:
         for v in labels:
             var = fg.getVariable(v)
-            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+            be.belief_write(slot[v], var.varType.manifold, var.val, var.bw)
+        write_densities(fg, be, [fctlabel])
         mh_in = -1
         if mhidx is not None:
             be.side_write(0, np.asarray(mhidx, dtype=np.int32))
             mh_in = 0
         d = proposal_desc(fg, fct, target, slot.__getitem__, out, op_seed(seed, PASS_UNIT, 0, 0, 0),
-                          nullSurplus=nullSurplus, mhidx_in=mh_in, mhidx_out=N)
+                          nullSurplus=nullSurplus, mhidx_in=mh_in, mhidx_out=N, alone=True)
         be.run_proposals([d])
-        pts, bw = be.slot_read(out, fg.getVariable(target).varType.manifold)
+        pts, bw, _ = be.belief_read(out, fg.getVariable(target).varType.manifold)  # a pass-through density keeps its count
         used = be.side_read(N, N)
     finally:
         if own:
@@ -213,7 +243,7 @@ def approxConvBeliefPath(fg, frm, target, backend=None, seed=0, path=None):
     try:
         for v in labels:
             var = fg.getVariable(v)
-            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+            be.belief_write(slot[v], var.varType.manifold, var.val, var.bw)
         for k, (l, f) in enumerate(zip(path, isfct)):
             if not f:
                 continue
@@ -259,7 +289,7 @@ def approxDeconv(fg, fctlabel, backend=None, seed=0):
     try:
         for i, v in enumerate(labels):
             var = fg.getVariable(v)
-            be.slot_write(i, var.varType.manifold, var.val, var.bw)
+            be.belief_write(i, var.varType.manifold, var.val, var.bw)
         out, ms = len(labels), len(labels) + 1
         d = proposal_desc(fg, fct, labels[-1], lambda v: labels.index(v), out, op_seed(seed, PASS_UNIT, 0, 0, 0))
         be.run_deconv([d], [ms])
@@ -309,26 +339,28 @@ def propagateBelief(fg, destlbl, factors=None, backend=None, seed=0, return_prop
         labels.append(destlbl)
     slot = {v: i for i, v in enumerate(labels)}
     nv = len(labels)
-    be, own = _make_backend(backend, N, nv + len(fcts) + 1)
+    nd = _plan_densities(fg, flabels, nv + len(fcts) + 1)
+    be, own = _make_backend(backend, N, nv + len(fcts) + 1 + nd)
     man = fg.getVariable(destlbl).varType.manifold
     try:
         for v in labels:
             var = fg.getVariable(v)
-            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+            be.belief_write(slot[v], var.varType.manifold, var.val, var.bw)
+        write_densities(fg, be, flabels)
         ns = _null_surplus(fg, fcts)
         descs = [proposal_desc(fg, f, destlbl, slot.__getitem__, nv + i, op_seed(seed, PASS_UNIT, 0, 0, i + 1),
-                               nullSurplus=ns[i]) for i, f in enumerate(fcts)]
+                               nullSurplus=ns[i], alone=len(fcts) == 1) for i, f in enumerate(fcts)]
         be.run_proposals(descs)
         out = nv + len(fcts)
         be.run_products([product_desc(man, [nv + i for i in range(len(fcts))], out,
                                       op_seed(seed, PASS_UNIT, 0, 0, PRODUCT_ID), sp.productNiter,
                                       partials=_partials(fcts), old_slot=slot[destlbl])])
-        pts, bw = be.slot_read(out, man)
-        props = [be.slot_read(nv + i, man) for i in range(len(fcts))] if return_proposals else None
+        pts, bw, ipc = be.belief_read(out, man)  # the belief may hold a pass-through density's own point count
+        props = [be.belief_read(nv + i, man)[:2] for i in range(len(fcts))] if return_proposals else None
     finally:
         if own:
             be.close()
-    ipc = np.full(fg.getVariable(destlbl).varType.dim, float(len(fcts)))  # ApproxConv.jl:298-303
+    # ipc = the sum over the factors of ones(D) (`fct_ipc = ones(vardim)`, ApproxConv.jl:277,298-303), produced on the device
     if return_proposals:
         return (pts, bw), ipc, props
     return (pts, bw), ipc
@@ -440,6 +472,7 @@ def initStages(fg, seed=0):
     if cur:
         groups.append(cur)
     width = max(len(g) for g in groups)
+    nd = _plan_densities(fg, None, V + width * maxF)  # V beliefs | proposal scratch | the pass-through densities
     stages = []
     for gi, g in enumerate(groups):
         props, prods = [], []
@@ -449,13 +482,14 @@ def initStages(fg, seed=0):
             base = V + ci * maxF
             for i, f in enumerate(fcts):
                 props.append(proposal_desc(fg, f, sym, slot.__getitem__, base + i,
-                                           op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i], isinit=st))
+                                           op_seed(seed, PASS_INIT, slot[sym], 0, i + 1), nullSurplus=ns[i], isinit=st,
+                                           alone=2 if len(fcts) == 1 else 0))  # 2: resample(bel, N), GraphInit.jl:174-177
             prods.append(product_desc(fg.getVariable(sym).varType.manifold, [base + i for i in range(len(fcts))],
                                       slot[sym], op_seed(seed, PASS_INIT, slot[sym], 0, PRODUCT_ID), sp.productNiter,
                                       partials=_partials(fcts), old_slot=slot[sym]))
         stages.append((abi.STAGE_PROPOSALS, props))
         stages.append((abi.STAGE_PRODUCTS, prods))
-    return plan, slot, V + width * maxF, stages
+    return plan, slot, V + width * maxF + nd, stages
 
 
 def initAll(fg, backend=None, seed=0):
@@ -470,14 +504,15 @@ def initAll(fg, backend=None, seed=0):
     try:
         for v in fg.ls():
             var = fg.getVariable(v)
-            be.slot_write(slot[v], var.varType.manifold, var.val, var.bw)
+            be.belief_write(slot[v], var.varType.manifold, var.val, var.bw)
+        write_densities(fg, be)
         prog = None
         try:
             prog = be.program(stages)
             prog.run()
             be.synchronize()
-            for sym, _, _ in plan:
-                pts, bw = be.slot_read(slot[sym], fg.getVariable(sym).varType.manifold)
+            for sym, _, _ in plan:  # a variable initialised from one pass-through density carries that density's point count
+                pts, bw, _ = be.belief_read(slot[sym], fg.getVariable(sym).varType.manifold)
                 setValKDE(fg, sym, pts, bw, True)
         finally:  # the program goes before its context, on the error path too
             if prog is not None:
@@ -530,6 +565,8 @@ class TreeProgram:
         if snapshot:
             self.snap = {v: nxt + i for i, v in enumerate(labels)}
             nxt += len(labels)
+        self.dens0 = nxt  # one slot per pass-through density, written by the caller like the initial beliefs
+        nxt += _plan_densities(fg, None, nxt)
         self.B = {}
         self.ghost = {}
         self.scratch = {}
@@ -658,7 +695,7 @@ class TreeProgram:
             if fresh:  # the factor's ccw.measurement is overwritten (CalcFactor.jl:492-510)
                 self._meas_seed[key] = sd
             props.append(proposal_desc(fg, f, v, slot_of, base + i, sd, nullSurplus=ns[i],
-                                       meas_seed=0 if fresh else self._meas_seed.get(key, 0)))
+                                       meas_seed=0 if fresh else self._meas_seed.get(key, 0), alone=len(fcts) == 1))
         man = fg.getVariable(v).varType.manifold
         prod = product_desc(man, [base + i for i in range(len(fcts))], out_slot,
                             op_seed(self.seed, passid, cid, step, PRODUCT_ID), sp.productNiter,
@@ -974,13 +1011,15 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
         ng = native_host.NativeGraph.from_fg(fg)
         tp = ng.build_tree(tree.eliminationOrder)
         tp.plan_slots(False)
+        ng.place_densities(fg, tp.density_slot0())
     else:
         tp = TreeProgram(fg, tree, seed=seed)
     be, own = _make_backend(backend, sp.N, tp.n_slots)
     try:
         for v in fg.ls():
             var = fg.getVariable(v)
-            be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+            be.belief_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+        write_densities(fg, be)
         prog = None
         try:
             prog = tp.compile(be, seed) if use_native else be.program(tp.stages, lazy_bandwidth=True)
@@ -990,7 +1029,7 @@ def solveTree(fg, tree=None, eliminationOrder=None, backend=None, seed=0, orderi
             t4 = time.perf_counter()
             for v in fg.ls():
                 var = fg.getVariable(v)
-                pts, bw = be.slot_read(tp.main[v], var.varType.manifold)
+                pts, bw, _ = be.belief_read(tp.main[v], var.varType.manifold)
                 setValKDE(fg, v, pts, bw, True)
                 var.solvedCount += 1
         finally:  # the program goes before its context, on the error path too

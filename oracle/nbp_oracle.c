@@ -902,6 +902,50 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     if (d->mhidx_out >= 0) side[d->mhidx_out + n] = mhidx[n];
   }
 
+  if (d->factor_kind == NBP_F_PASSTHROUGH) {
+    /* calcProposalBelief(::PartialPriorPassThrough), ApproxConv.jl:196-227: the proposal is the density itself
+     * (fctFnc.Z.heatmap.densityFnc), placed on the partial coordinates (antimarginal); nothing is sampled or fitted.
+     * keep_count = 0: multinomial resampling to the N points a product needs from every input. */
+    const double *den = arena + S * d->var_slot[1], *cur = arena + S * d->var_slot[0];
+    const int cd = slot_count(den, N), ct = slot_count(cur, N), pm = d->partial_mask ? d->partial_mask : 7;
+    double *X = (double *)malloc(sizeof(double) * 3 * N);
+    for (int n = 0; n < N; n++)
+      for (int k = 0; k < 3; k++) X[k * N + n] = (k < D && n < ct) ? cur[k * N + n] : 0.0;
+    for (int n = 0; n < N; n++) {
+      int idx = n;
+      if (!d->keep_count && cd < N) {
+        double ua, ub;
+        orc_uniform_pair(d->seed, n, PURP_KDESEL, 0, &ua, &ub);
+        idx = (int)(ua * cd);
+        if (idx >= cd) idx = cd - 1;
+      }
+      double nz[4] = {0, 0, 0, 0};
+      if (d->keep_count == 2 && cd < N && n >= cd) { /* resample(bel, N) of graph initialisation, GraphInit.jl:174-177 */
+        double ua, ub;
+        orc_uniform_pair(d->seed, n, PURP_OLDSEL, 0, &ua, &ub);
+        idx = (int)(ua * cd);
+        if (idx >= cd) idx = cd - 1;
+        orc_normal_pair(d->seed, n, PURP_OLDNOISE, 0, &nz[0], &nz[1]);
+        if (D > 2) orc_normal_pair(d->seed, n, PURP_OLDNOISE, 1, &nz[2], &nz[3]);
+      }
+      if (idx < cd)
+        for (int k = 0; k < D; k++)
+          if ((pm >> k) & 1) {
+            const double v = den[k * N + idx] + den[3 * N + k] * nz[k];
+            X[k * N + n] = (nz[k] != 0.0 && is_circ(d->manifold, k)) ? orc_wrap(v) : v;
+          }
+    }
+    memcpy(out, X, sizeof(double) * 3 * N);
+    free(X);
+    free(mhidx);
+    for (int k = 0; k < 3; k++) {
+      const int in = k < D && ((pm >> k) & 1);
+      out[3 * N + k] = in ? den[3 * N + k] : 0.0;
+      out[3 * N + 3 + k] = in ? 1.0 : 0.0;
+    }
+    out[3 * N + 6] = (d->keep_count == 1 && cd < N) ? (double)cd : 0.0;
+    return NBP_OK;
+  }
   if (d->factor_kind == NBP_F_PRIOR || d->factor_kind == NBP_F_MSGPRIOR) {
     /* evalPotentialSpecific(prior), EvalFactor.jl:400-542 */
     const double *cur = arena + S * d->var_slot[0];

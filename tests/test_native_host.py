@@ -45,6 +45,21 @@ def graphs():
         iif.addFactor(fg, [vs[0], vs[1]], iif.LinearRelative(iif.Normal(1, 1)))
         iif.addFactor(fg, [vs[1], vs[2]], iif.LinearRelative(iif.Normal(1, 1)))
     yield "forest", fg
+    # pass-through priors (PartialPriorPassThrough): alone on x0, next to a prior on x2, a partial one on a Euclid(2) variable
+    SE2 = iif.SpecialEuclidean2
+    fg = iif.initfg(iif.SolverParams(N=100))
+    rng = np.random.default_rng(0)
+    for v in ("x0", "x1", "x2"):
+        iif.addVariable(fg, v, SE2)
+    iif.addVariable(fg, "l1", E2)
+    iif.addFactor(fg, ["x0"], iif.PartialPriorPassThrough(SE2, rng.normal(size=(60, 2)), [0.3, 0.3], (1, 2)), nullhypo=0.2)
+    z = iif.MvNormal([1.0, 0.0, 0.1], np.diag([0.01, 0.01, 0.01]))
+    iif.addFactor(fg, ["x0", "x1"], iif.ManifoldFactor(z))
+    iif.addFactor(fg, ["x1", "x2"], iif.ManifoldFactor(z))
+    iif.addFactor(fg, ["x2"], iif.ManifoldPrior(np.zeros(3), iif.MvNormal(np.zeros(3), np.diag([0.01, 0.01, 0.01]))))
+    iif.addFactor(fg, ["x2"], iif.PartialPriorPassThrough(SE2, rng.normal(size=(100, 3)), [0.3, 0.3, 0.1]), inflation=2.0)
+    iif.addFactor(fg, ["l1"], iif.PartialPriorPassThrough(E2, rng.normal(size=(40, 1)), [0.2], (2,)))
+    yield "passthrough", fg
 
 
 GRAPHS = dict(graphs())
