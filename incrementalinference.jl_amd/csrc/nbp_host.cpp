@@ -94,13 +94,17 @@ struct nbp_tree {
   int snapshot = 0, n_slots = 0, dens0 = 0;  // dens0: first of the pass-through density slots (after main / snap)
   std::vector<int> main_slot, snap_slot;
   std::vector<std::map<int, int>> B;  // per clique: variable -> slot
-  std::vector<int> scratch;           // per clique: first scratch slot
+  std::vector<int> scratch, maxf;     // per clique: first scratch slot, widest product (one scratch row per step of a round)
   // compile products
   std::vector<Stage> stages;
   nbp_tree_stats st{};
   bool joint = false;   // NBP_SOLVER_MSG_LIKELIHOODS
   bool stored = false;  // NBP_SOLVER_STORED_MEASUREMENTS
   std::vector<std::vector<int>> jdnsched;  // joint mode: down schedule per clique
+  // the schedules as they run (solver.TreeProgram._plan_symbolic): up = variables with a density, not marginalized;
+  // rounds = the steps of a schedule grouped into sets of commuting steps (solver.TreeProgram._rounds)
+  std::vector<std::vector<int>> usched, uiter, dsched;
+  std::vector<std::vector<std::vector<int>>> urounds, drounds;
   std::map<std::array<int, 5>, uint64_t> meas_seed;  // (clique, tag, a, b, variable of a message) -> seed of the last fresh draw
   // multi-rank compile (solver.TreeProgram(owner=, rank=)): owner[c] = rank of clique c (index c - 1); this rank compiles
   // only its own cliques; tree edges that cross a rank boundary become exchange segments between the stage segments
@@ -713,11 +717,86 @@ void up_edges(const nbp_tree *t, const std::vector<int> &cliques, std::vector<Ed
   }
 }
 
+// the densities of variable v in clique c, up solve: clique potentials touching v + child messages on v
+std::vector<Entry> up_entries(const nbp_tree *t, const Clique &c, int v) {
+  if (t->joint) return joint_entries(c, v, false);
+  const nbp_graph *g = t->g;
+  std::vector<Entry> ent;
+  for (int f : c.potentials) {
+    bool hit = false;
+    for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
+    if (hit) ent.push_back({false, f});
+  }
+  for (int chd : c.children)
+    if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
+  return ent;
+}
+// ... down solve: every factor of the frontal (addDownVariableFactors!)
+std::vector<Entry> down_entries(const nbp_tree *t, const Clique &c, int v) {
+  if (t->joint) return joint_entries(c, v, true);
+  std::vector<Entry> ent;
+  for (int f : t->g->vfacs[v]) ent.push_back({false, f});
+  return ent;
+}
+
+// solver.TreeProgram._rounds: steps whose variables differ and share no factor commute (disjoint beliefs, random
+// streams keyed by the step index); round[j] = 1 + the latest round among the earlier steps j conflicts with
+template <typename EntriesOf>
+std::vector<std::vector<int>> schedule_rounds(const nbp_tree *t, const std::vector<int> &sched, EntriesOf entries_of) {
+  std::map<int, std::set<int>> reads;
+  for (int v : sched) {
+    if (reads.count(v)) continue;
+    std::set<int> &r = reads[v];
+    for (const Entry &e : entries_of(v)) {
+      if (e.tag == 'f')
+        for (int q = 0; q < t->g->facs[e.a].s.nvars; q++) r.insert(t->g->facs[e.a].s.vars[q]);
+      else if (e.tag == 'd') {
+        r.insert(t->cl[e.a - 1].rel[e.b][0]);
+        r.insert(t->cl[e.a - 1].rel[e.b][1]);
+      }
+    }
+    r.erase(v);
+  }
+  std::vector<int> rnd(sched.size(), 0);
+  int top = -1;
+  for (size_t j = 0; j < sched.size(); j++) {
+    const int v = sched[j];
+    for (size_t i = 0; i < j; i++) {
+      const int u = sched[i];
+      if (u == v || reads[v].count(u) || reads[u].count(v)) rnd[j] = std::max(rnd[j], rnd[i] + 1);
+    }
+    top = std::max(top, rnd[j]);
+  }
+  std::vector<std::vector<int>> groups(top + 1);
+  for (size_t j = 0; j < sched.size(); j++) groups[rnd[j]].push_back((int)j);
+  return groups;
+}
+
+void plan_rounds(nbp_tree *t) {
+  const nbp_graph *g = t->g;
+  const size_t nc = t->cl.size();
+  t->usched.assign(nc, {});
+  t->uiter.assign(nc, {});
+  t->dsched.assign(nc, {});
+  t->urounds.assign(nc, {});
+  t->drounds.assign(nc, {});
+  for (const Clique &c : t->cl) {
+    const size_t k0 = c.id - 1;
+    for (size_t k = 0; k < c.upsched.size(); k++) {  // doFMCIteration passes over marginalized variables and variables without a density
+      const int v = c.upsched[k];
+      if (!up_entries(t, c, v).empty() && !g->vars[v].ismargin) { t->usched[k0].push_back(v); t->uiter[k0].push_back(c.upiter[k]); }
+    }
+    t->dsched[k0] = t->joint ? t->jdnsched[k0] : c.dnsched;
+    t->urounds[k0] = schedule_rounds(t, t->usched[k0], [&](int v) { return up_entries(t, c, v); });
+    t->drounds[k0] = schedule_rounds(t, t->dsched[k0], [&](int v) { return down_entries(t, c, v); });
+  }
+}
+
 nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &entries, const std::set<int> *inclq, int out_slot, int passid,
                       int step, uint64_t seed, std::vector<nbp_proposal_desc> &props, std::vector<nbp_product_desc> &prods,
-                      bool fresh = true) {
+                      bool fresh = true, int lane = 0) {
   const nbp_graph *g = t->g;
-  const int base = t->scratch[cid - 1];
+  const int base = t->scratch[cid - 1] + lane * t->maxf[cid - 1];  // `lane`: position of this step within its round
   const std::map<int, int> &Bc = t->B[cid - 1];
   const int F = (int)entries.size();
   if (F > NBP_MAXF) return hfail(NBP_ERR_RANGE, "a product exceeds NBP_MAXF densities");
@@ -889,6 +968,7 @@ nbp_status nbp_tree_build(const nbp_graph *g, const int32_t *order, int32_t n, n
           if (itv.count(v) && !skip(v)) d.push_back(v);
     }
   }
+  plan_rounds(t);
   *out = t;
   return NBP_OK;
 }
@@ -951,6 +1031,13 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
   t->B.assign(t->cl.size(), {});
   t->ghost.assign(t->cl.size(), {});
   t->scratch.assign(t->cl.size(), 0);
+  t->maxf.assign(t->cl.size(), 1);
+  auto conc = [&](const Clique &c) {  // steps of one round run side by side: one scratch row each
+    size_t m = 1;
+    for (const auto &r : t->urounds[c.id - 1]) m = std::max(m, r.size());
+    for (const auto &r : t->drounds[c.id - 1]) m = std::max(m, r.size());
+    return (int)m;
+  };
   for (Clique &c : t->cl) {  // clique ids ascending == Python's iteration over tree.cliques (insertion order)
     if (!t->mine(c.id)) continue;
     for (int v : c.all()) t->B[c.id - 1][v] = nxt++;
@@ -972,7 +1059,8 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
         if (!g->vars[v].ismargin) maxf = std::max(maxf, joint_entries(c, v, false).size());
       for (int v : t->jdnsched[c.id - 1]) maxf = std::max(maxf, joint_entries(c, v, true).size());
       t->scratch[c.id - 1] = nxt;
-      nxt += (int)maxf;
+      t->maxf[c.id - 1] = (int)maxf;
+      nxt += (int)maxf * conc(c);
       continue;
     }
     for (int v : c.upsched) {
@@ -987,7 +1075,8 @@ int32_t nbp_tree_plan_slots(nbp_tree *t, int32_t snapshot) {
     }
     for (int v : c.dnsched) maxf = std::max(maxf, g->vfacs[v].size());
     t->scratch[c.id - 1] = nxt;
-    nxt += (int)maxf;
+    t->maxf[c.id - 1] = (int)maxf;
+    nxt += (int)maxf * conc(c);
   }
   t->n_slots = nxt;
   return nxt;
@@ -1051,20 +1140,6 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
   // CliqueStateMachine, :221-234); stage t batches step t - start[c] of every running clique (solver.TreeProgram)
   if (g->sp.upsolve) {
     const size_t nc = t->cl.size();
-    // up schedule filtered like solver.TreeProgram: variables with at least one density, not marginalized
-    std::vector<std::vector<int>> sched(nc + 1), iters(nc + 1);
-    for (const Clique &c : t->cl)
-      for (size_t k = 0; k < c.upsched.size(); k++) {
-        const int v = c.upsched[k];
-        bool any = false;
-        if (t->joint) any = !joint_entries(c, v, false).empty();
-        else {
-          for (int f : c.potentials)
-            for (int q = 0; q < g->facs[f].s.nvars && !any; q++) any = g->facs[f].s.vars[q] == v;
-          for (int chd : c.children) any |= contains(t->cl[chd - 1].seps, v);
-        }
-        if (any && !g->vars[v].ismargin) { sched[c.id].push_back(v); iters[c.id].push_back(c.upiter[k]); }
-      }
     std::vector<int> ids, start(nc + 1, 0), finish(nc + 1, 0);
     for (const Clique &c : t->cl) ids.push_back(c.id);
     std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return height[a] != height[b] ? height[a] < height[b] : a < b; });
@@ -1073,7 +1148,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       int st = 0;
       for (int chd : t->cl[cid - 1].children) st = std::max(st, finish[chd]);
       start[cid] = st;
-      finish[cid] = st + (int)sched[cid].size();
+      finish[cid] = st + (int)t->urounds[cid - 1].size();
       T = std::max(T, finish[cid]);
     }
     for (int tt = 0; tt < T; tt++) {
@@ -1115,22 +1190,14 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       prods.clear();
       for (const Clique &c : t->cl) {
         if (!(start[c.id] <= tt && tt < finish[c.id]) || !t->mine(c.id)) continue;
-        const int k = tt - start[c.id], v = sched[c.id][k];
-        std::vector<Entry> ent;
-        if (t->joint) ent = joint_entries(c, v, false);
-        else {
-          for (int f : c.potentials) {
-            bool hit = false;
-            for (int q = 0; q < g->facs[f].s.nvars; q++) hit |= g->facs[f].s.vars[q] == v;
-            if (hit) ent.push_back({false, f});
-          }
-          for (int chd : c.children)
-            if (contains(t->cl[chd - 1].seps, v)) ent.push_back({true, chd});
+        const std::vector<int> &round = t->urounds[c.id - 1][tt - start[c.id]];
+        for (size_t lane = 0; lane < round.size(); lane++) {
+          const int k = round[lane], v = t->usched[c.id - 1][k];
+          const bool fresh = t->uiter[c.id - 1][k] == 1 || !t->stored;
+          rc = update_ops(t, c.id, v, up_entries(t, c, v), nullptr, t->B[c.id - 1].at(v), PASS_UP, k, seed, props, prods, fresh, (int)lane);
+          if (rc) return rc;
+          t->st.updates_up++;
         }
-        const bool fresh = iters[c.id][k] == 1 || !t->stored;
-        rc = update_ops(t, c.id, v, ent, nullptr, t->B[c.id - 1].at(v), PASS_UP, k, seed, props, prods, fresh);
-        if (rc) return rc;
-        t->st.updates_up++;
       }
       if (!prods.empty()) {
         add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());
@@ -1159,7 +1226,6 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
     // and starts in the stage after the parent's last update (solver.TreeProgram._compile_down_asap)
     {
       const size_t nc = t->cl.size();
-      auto dsched = [&](const Clique &c) -> const std::vector<int> & { return t->joint ? t->jdnsched[c.id - 1] : c.dnsched; };
       std::vector<int> ids, start(nc + 1, 0), finish(nc + 1, 0);
       for (const Clique &c : t->cl) ids.push_back(c.id);
       std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return depth[a] != depth[b] ? depth[a] < depth[b] : a < b; });
@@ -1167,7 +1233,7 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
       for (int cid : ids) {
         const Clique &c = t->cl[cid - 1];
         start[cid] = c.parent ? finish[c.parent] : 0;
-        finish[cid] = start[cid] + (int)dsched(c).size();
+        finish[cid] = start[cid] + (int)t->drounds[cid - 1].size();
         T = std::max(T, finish[cid]);
       }
       for (int tt = 0; tt <= T; tt++) {
@@ -1204,16 +1270,15 @@ nbp_status nbp_tree_schedule(nbp_tree *t, uint64_t seed) {
         prods.clear();
         for (const Clique &c : t->cl) {
           if (!(start[c.id] <= tt && tt < finish[c.id]) || !t->mine(c.id)) continue;
-          const int k = tt - start[c.id], v = dsched(c)[k];
           const std::vector<int> allv = c.all();
           std::set<int> inclq(allv.begin(), allv.end());
-          std::vector<Entry> ent;
-          if (t->joint) ent = joint_entries(c, v, true);
-          else
-            for (int f : g->vfacs[v]) ent.push_back({false, f});
-          rc = update_ops(t, c.id, v, ent, &inclq, t->B[c.id - 1].at(v), PASS_DOWN, k, seed, props, prods);
-          if (rc) return rc;
-          t->st.updates_down++;
+          const std::vector<int> &round = t->drounds[c.id - 1][tt - start[c.id]];
+          for (size_t lane = 0; lane < round.size(); lane++) {
+            const int k = round[lane], v = t->dsched[c.id - 1][k];
+            rc = update_ops(t, c.id, v, down_entries(t, c, v), &inclq, t->B[c.id - 1].at(v), PASS_DOWN, k, seed, props, prods, true, (int)lane);
+            if (rc) return rc;
+            t->st.updates_down++;
+          }
         }
         if (!prods.empty()) {
           add_stage(t, NBP_STAGE_PROPOSALS, props.data(), sizeof(nbp_proposal_desc), (int)props.size());

@@ -576,6 +576,7 @@ class TreeProgram:
         if getattr(sp, "useMsgLikelihoods", False):
             self.joint = jointmsg.plan_joint_messages(fg, tree)  # the same plan on every rank
         self.upsched, self.dnsched, self.upfacs, self.dnfacs = {}, {}, {}, {}
+        self.uprounds, self.dnrounds = {}, {}  # per clique: the schedule's steps grouped into rounds of commuting steps
         self.upfresh = {}     # per clique: does step k of the up schedule draw fresh measurements?
         self._meas_seed = {}  # (clique, factor entry) -> seed of the op that last drew its measurements
         self.heights, self.depths = tree.heights(), tree.depths()
@@ -605,8 +606,9 @@ class TreeProgram:
             maxf = max([len(upf[v]) for v in sched] + [len(dnf[v]) for v in self.dnsched[cid]] + [1])
             if maxf > abi.MAXF:
                 raise ValueError(f"clique {cid}: {maxf} densities in one product exceeds NBP_MAXF")
+            conc = max([len(g) for g in self.uprounds[cid] + self.dnrounds[cid]] + [1])  # steps of one round run side by side
             self.scratch[cid] = (nxt, maxf)
-            nxt += maxf
+            nxt += maxf * conc
         self.n_slots = nxt
         self.stages = []
         self.stage_pass = []
@@ -658,6 +660,43 @@ class TreeProgram:
                     + [v for v in cl.frontalIDs if v in itv and v not in skip] * 3) if cl.parent >= 0 else []  # MCIters = 3
         self.dnfacs[cid] = dnf
         self.dnsched[cid] = dsch
+        self.uprounds[cid] = self._rounds(sched, upf)
+        self.dnrounds[cid] = self._rounds(dsch, dnf)
+
+    def _entry_variables(self, entry):
+        kind, ref = entry
+        if kind == "f":
+            return self.fg.getFactor(ref).variables
+        if kind == "d":
+            return list(self.joint[ref[0]].relatives[ref[1]][:2])
+        return ()  # a message prior touches its own variable only
+
+    def _rounds(self, sched, facs):
+        """Steps of one clique's Gibbs schedule that can share a stage.  The reference runs the steps one after the other
+        (fmcmc!, SolveTree.jl:97-160); step j only sees step i < j through the belief of i's variable, so two steps whose
+        variables are different and share no factor commute -- they read and write disjoint beliefs, and the random
+        streams are keyed by the step index, not by the execution order.  round[j] = 1 + the latest round among the
+        earlier steps j conflicts with; a round is one PROPOSALS + PRODUCTS stage pair.  A chain clique {f | a, b} with
+        factors (a,f), (f,b) runs f | a b | f | a b | f | a b: six rounds instead of nine."""
+        reads = {}
+        for v in set(sched):
+            r = set()
+            for e in facs[v]:
+                r.update(self._entry_variables(e))
+            r.discard(v)
+            reads[v] = r
+        rnd = []
+        for j, v in enumerate(sched):
+            r = 0
+            for i in range(j):
+                u = sched[i]
+                if u == v or u in reads[v] or v in reads[u]:
+                    r = max(r, rnd[i] + 1)
+            rnd.append(r)
+        groups = [[] for _ in range(max(rnd) + 1)] if rnd else []
+        for j, r in enumerate(rnd):
+            groups[r].append(j)
+        return groups
 
     # -- helpers ------------------------------------------------------------------------------
     def _account(self, man, F_in):
@@ -674,9 +713,10 @@ class TreeProgram:
     def _msg_slot(self, child, v):
         return self.B[(child, v)] if self.owner[child] == self.rank else self.ghost[(child, v)]
 
-    def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step, fresh=True):
+    def _update_ops(self, cid, v, entries, slot_of, out_slot, passid, step, fresh=True, lane=0):
         fg, sp = self.fg, self.fg.solverParams
-        base, _ = self.scratch[cid]
+        base, maxf = self.scratch[cid]
+        base += lane * maxf  # `lane`: position of this step within its round
         fcts = []
         for kind, ref in entries:
             if kind == "f":
@@ -741,7 +781,7 @@ class TreeProgram:
         start, finish = {}, {}
         for c in sorted(tree.cliques, key=lambda c: (self.heights[c], c)):
             start[c] = max([finish[x] for x in tree.cliques[c].children] + [0])
-            finish[c] = start[c] + len(self.upsched[c])
+            finish[c] = start[c] + len(self.uprounds[c])
         for t in range(max(finish.values()) if finish else 0):
             done = [c for c in sorted(tree.cliques) if finish[c] == t and tree.cliques[c].parent >= 0]
             if self.joint is not None:  # the joint messages of the cliques that have just finished
@@ -753,13 +793,13 @@ class TreeProgram:
             for c in self.cliques:
                 if not (start[c] <= t < finish[c]):
                     continue
-                k = t - start[c]
-                v = self.upsched[c][k]
-                p, q = self._update_ops(c, v, self.upfacs[c][v], lambda u, c=c: self.B[(c, u)], self.B[(c, v)], PASS_UP, k,
-                                        fresh=self.upfresh[c][k])
-                props += p
-                prods.append(q)
-                self.n_updates_up += 1
+                for lane, k in enumerate(self.uprounds[c][t - start[c]]):
+                    v = self.upsched[c][k]
+                    p, q = self._update_ops(c, v, self.upfacs[c][v], lambda u, c=c: self.B[(c, u)], self.B[(c, v)], PASS_UP, k,
+                                            fresh=self.upfresh[c][k], lane=lane)
+                    props += p
+                    prods.append(q)
+                    self.n_updates_up += 1
             if prods:
                 self._add(abi.STAGE_PROPOSALS, props, "up")
                 self._add(abi.STAGE_PRODUCTS, prods, "up")
@@ -786,7 +826,7 @@ class TreeProgram:
         for c in sorted(tree.cliques, key=lambda c: (self.depths[c], c)):
             par = tree.cliques[c].parent
             start[c] = finish[par] if par >= 0 else 0
-            finish[c] = start[c] + len(self.dnsched[c])
+            finish[c] = start[c] + len(self.dnrounds[c])
         for t in range(max(finish.values()) + 1 if finish else 0):
             # down messages of the cliques that start now: one round, or one more per link of a chain of cliques
             # without updates of their own, which hand the values on within the same time step
@@ -808,17 +848,17 @@ class TreeProgram:
             for c in self.cliques:
                 if not (start[c] <= t < finish[c]):
                     continue
-                k = t - start[c]
-                v = self.dnsched[c][k]
                 inclq = set(tree.cliques[c].allIDs)
 
                 def slot_of(u, c=c, inclq=inclq):
                     return self.B[(c, u)] if u in inclq else self.main[u]
 
-                p, q = self._update_ops(c, v, self.dnfacs[c][v], slot_of, self.B[(c, v)], PASS_DOWN, k)
-                props += p
-                prods.append(q)
-                self.n_updates_down += 1
+                for lane, k in enumerate(self.dnrounds[c][t - start[c]]):
+                    v = self.dnsched[c][k]
+                    p, q = self._update_ops(c, v, self.dnfacs[c][v], slot_of, self.B[(c, v)], PASS_DOWN, k, lane=lane)
+                    props += p
+                    prods.append(q)
+                    self.n_updates_down += 1
             if prods:
                 self._add(abi.STAGE_PROPOSALS, props, "down")
                 self._add(abi.STAGE_PRODUCTS, prods, "down")

@@ -31,6 +31,11 @@ def run(N, nfits, manifold=abi.EUCLID2):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 3:  # one geometry (for a rocprofv3 --pmc pass): N nfits
+        N, nfits = int(sys.argv[1]), int(sys.argv[2])
+        t, ev, ps, frac = run(N, nfits)
+        print(f"N={N:4d} fits={nfits:5d} x2 coords: {t:9.3f} ms, {ev:9.0f} evals, {ps:7.3f} ps/pair, FP64 frac {frac:.3f}", flush=True)
+        sys.exit(0)
     for N in (192, 200, 256, 128, 100):
         for nfits in (1, 64, 2048, 8192):
             t, ev, ps, frac = run(N, nfits)
