@@ -184,7 +184,7 @@ end
 
 const _POOL = Dict{Int, Vector{NbpCtx}}()      # N => idle contexts
 const _POOL_LOCK = ReentrantLock()
-const _POOL_SLOTS = 512                         # slots per pooled context (a clique needs nvars + nmsgs + maxF)
+const _POOL_SLOTS = 512                         # slots per pooled context (a clique needs nvars + nmsgs + densities + maxF * nvars: nbp_clique_slots)
 
 "borrow a context for N particles and at least `nslots` slots; give it back with `release!`"
 function acquire(N::Int, nslots::Int)

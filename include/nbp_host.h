@@ -209,7 +209,9 @@ typedef struct nbp_clique_desc {
   const nbp_tree_belief *factor_density;
 } nbp_clique_desc;
 
-/* slots a context needs for this clique (nbp_ctx_create(..., n_slots >= this)) */
+/* slots a context needs for this clique (nbp_ctx_create(..., n_slots >= this)): variables + messages + pass-through
+ * densities + one scratch row of the widest product per variable (Gibbs steps that commute -- different variables,
+ * no common factor -- run side by side in one stage; the particles are those of the step-by-step schedule) */
 int32_t nbp_clique_slots(const nbp_clique_desc *cliq);
 /* beliefs_inout[nvars]: in = the beliefs of the clique sub graph (the deep copy the CSM made); out = the belief of
  * every variable the schedule updated (the others are left as they were).  status_out (nullable) = NBP_CLIQ_UPSOLVED /

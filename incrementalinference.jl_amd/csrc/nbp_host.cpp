@@ -1613,7 +1613,17 @@ int32_t nbp_clique_slots(const nbp_clique_desc *q) {
   }
   int ndens = 0;
   for (int f = 0; f < q->nfactors; f++) ndens += q->factors && q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
-  return q->nvars + q->nmsgs + ndens + (int32_t)maxf;
+  // steps that commute run side by side, one scratch row of maxf proposals each: at most one per variable
+  return q->nvars + q->nmsgs + ndens + (int32_t)maxf * q->nvars;
+}
+static size_t clique_maxf(const nbp_clique_desc *q) {
+  size_t maxf = 1;
+  std::vector<int> fa, ms;
+  for (int v = 0; v < q->nvars; v++) {
+    clique_entries(q, v, true, fa, ms);
+    maxf = std::max(maxf, fa.size() + ms.size());
+  }
+  return maxf;
 }
 
 static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
@@ -1712,52 +1722,79 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   std::map<std::pair<int, int>, uint64_t> meas_seed;  // (0 = factor | 1 = message, index) -> seed of its last fresh draw
   const int passid = down ? PASS_DOWN : PASS_UP;
   std::vector<char> updated(q->nvars, 0);
-  for (size_t k = 0; k < sched.size(); k++) {
-    const int v = sched[k];
-    clique_entries(q, v, !down, fa, ms);
-    const int F = (int)(fa.size() + ms.size());
-    if (F == 0) continue;
-    if (F > NBP_MAXF) return hfail(NBP_ERR_RANGE, "a product exceeds NBP_MAXF densities");
-    bool anymh = false;
-    for (int f : fa) anymh |= facs[f].s.has_multihypo != 0;
-    std::vector<nbp_proposal_desc> props;
-    nbp_product_desc pq;
-    memset(&pq, 0, sizeof(pq));
-    bool anypartial = false;
-    const bool fresh = iter[k] == 1 || !stored || down;
-    for (int i = 0; i < F; i++) {
-      const bool ismsg = i >= (int)fa.size();
-      const HFac *fac = ismsg ? nullptr : &facs[fa[i]];
-      const int mi = ismsg ? ms[i - fa.size()] : -1;
-      double ns = 0.0;  // proposalbeliefs!: relative non-multihypo siblings of a multihypo factor (ApproxConv.jl:255-265)
-      if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = sp->null_surplus_add;
-      nbp_proposal_desc d;
-      const uint64_t sd = op_seed(seed, passid, q->clique_id, (uint64_t)k, (uint64_t)(i + 1));
-      fill_proposal(&g, d, fac, ismsg ? msg0 + mi : (fac->dens >= 0 ? dens0 + fac->dens : -1), v, nullptr, nullptr, nullptr, base + i, sd, ns,
-                    nullptr, F == 1 ? 1 : 0);
-      const std::pair<int, int> key{ismsg ? 1 : 0, ismsg ? mi : fa[i]};
-      if (fresh) meas_seed[key] = sd;
-      else {
-        auto it = meas_seed.find(key);
-        d.meas_seed = it == meas_seed.end() ? 0 : it->second;
-      }
-      props.push_back(d);
-      pq.in_slot[i] = base + i;
-      pq.in_partial[i] = (uint8_t)(fac ? fac->s.partial_mask : 0);
-      anypartial |= pq.in_partial[i] != 0;
+  // rounds of commuting steps (solver.TreeProgram._rounds): steps whose variables differ and share no factor read and
+  // write disjoint beliefs, and the random streams are keyed by the step index -- one stage pair per round
+  std::vector<std::vector<int>> rounds;
+  {
+    std::vector<std::set<int>> reads(q->nvars);
+    for (int v = 0; v < q->nvars; v++) {
+      clique_entries(q, v, false, fa, ms);
+      for (int f : fa)
+        for (int i = 0; i < q->factors[f].nvars; i++)
+          if (q->factors[f].vars[i] != v) reads[v].insert(q->factors[f].vars[i]);
     }
-    pq.manifold = q->manifold[v];
-    pq.nfactors = F;
-    pq.niter = sp->product_niter;
-    pq.out_slot = v;
-    pq.labels_out = -1;
-    pq.old_slot = anypartial ? v : -1;
-    if (!anypartial) memset(pq.in_partial, 0, sizeof(pq.in_partial));
-    pq.seed = op_seed(seed, passid, q->clique_id, (uint64_t)k, PRODUCT_ID);
+    std::vector<int> rnd(sched.size(), 0);
+    for (size_t j = 0; j < sched.size(); j++) {
+      for (size_t i = 0; i < j; i++)
+        if (sched[i] == sched[j] || reads[sched[j]].count(sched[i]) || reads[sched[i]].count(sched[j])) rnd[j] = std::max(rnd[j], rnd[i] + 1);
+      if ((int)rounds.size() <= rnd[j]) rounds.resize(rnd[j] + 1);
+      rounds[rnd[j]].push_back((int)j);
+    }
+  }
+  const int maxf = (int)clique_maxf(q);
+  for (const std::vector<int> &round : rounds) {
+    std::vector<nbp_proposal_desc> props;
+    std::vector<nbp_product_desc> prods;
+    for (size_t lane = 0; lane < round.size(); lane++) {
+      const size_t k = (size_t)round[lane];
+      const int v = sched[k];
+      clique_entries(q, v, !down, fa, ms);
+      const int F = (int)(fa.size() + ms.size());
+      if (F == 0) continue;
+      if (F > NBP_MAXF) return hfail(NBP_ERR_RANGE, "a product exceeds NBP_MAXF densities");
+      bool anymh = false;
+      for (int f : fa) anymh |= facs[f].s.has_multihypo != 0;
+      nbp_product_desc pq;
+      memset(&pq, 0, sizeof(pq));
+      bool anypartial = false;
+      const bool fresh = iter[k] == 1 || !stored || down;
+      const int row = base + (int)lane * maxf;
+      for (int i = 0; i < F; i++) {
+        const bool ismsg = i >= (int)fa.size();
+        const HFac *fac = ismsg ? nullptr : &facs[fa[i]];
+        const int mi = ismsg ? ms[i - fa.size()] : -1;
+        double ns = 0.0;  // proposalbeliefs!: relative non-multihypo siblings of a multihypo factor (ApproxConv.jl:255-265)
+        if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = sp->null_surplus_add;
+        nbp_proposal_desc d;
+        const uint64_t sd = op_seed(seed, passid, q->clique_id, (uint64_t)k, (uint64_t)(i + 1));
+        fill_proposal(&g, d, fac, ismsg ? msg0 + mi : (fac->dens >= 0 ? dens0 + fac->dens : -1), v, nullptr, nullptr, nullptr, row + i, sd, ns,
+                      nullptr, F == 1 ? 1 : 0);
+        const std::pair<int, int> key{ismsg ? 1 : 0, ismsg ? mi : fa[i]};
+        if (fresh) meas_seed[key] = sd;
+        else {
+          auto it = meas_seed.find(key);
+          d.meas_seed = it == meas_seed.end() ? 0 : it->second;
+        }
+        props.push_back(d);
+        pq.in_slot[i] = row + i;
+        pq.in_partial[i] = (uint8_t)(fac ? fac->s.partial_mask : 0);
+        anypartial |= pq.in_partial[i] != 0;
+      }
+      pq.manifold = q->manifold[v];
+      pq.nfactors = F;
+      pq.niter = sp->product_niter;
+      pq.out_slot = v;
+      pq.labels_out = -1;
+      pq.old_slot = anypartial ? v : -1;
+      if (!anypartial) memset(pq.in_partial, 0, sizeof(pq.in_partial));
+      pq.seed = op_seed(seed, passid, q->clique_id, (uint64_t)k, PRODUCT_ID);
+      prods.push_back(pq);
+      updated[v] = 1;
+    }
+    if (prods.empty()) continue;
     rc = nbp_program_add_stage(p, NBP_STAGE_PROPOSALS, props.data(), (int)props.size());
-    if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, &pq, 1);
+    if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, prods.data(), (int)prods.size());
     if (rc) return rc;
-    updated[v] = 1;
   }
   rc = nbp_program_finalize(p);
   if (!rc) rc = nbp_program_run(p, 0, -1);
