@@ -51,7 +51,7 @@ struct nbp_ctx {
   size_t ws_doubles = 0;
   nbp_spec_area *spec = nullptr;  // rendezvous areas of the speculative fits (latency-mode launches), NBP_SPEC_MAXJOBS x 3
   bool spec_on = true;
-  bool spec_depth3 = false;  // 7 workgroups per fit: measured no faster than 3 (the rendezvous of 7 costs what the third iteration saves)
+  bool spec_depth3 = true;  // 7 workgroups per fit (three iterations per rendezvous) where the launch still fits the chip; NBP_SPEC_DEPTH3=0: 3 only
   double *gstats = nullptr;  // node statistics of products too large for the LDS
   size_t gstats_doubles = 0;
   // staging for immediate-mode calls
@@ -188,7 +188,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&c->spec, sizeof(nbp_spec_area) * 3 * NBP_SPEC_MAXJOBS));
   c->spec_on = getenv("NBP_NO_SPECULATIVE_FITS") == nullptr;
-  c->spec_depth3 = getenv("NBP_SPEC_DEPTH3") != nullptr;
+  c->spec_depth3 = !(getenv("NBP_SPEC_DEPTH3") && atoi(getenv("NBP_SPEC_DEPTH3")) == 0);
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
@@ -203,6 +203,8 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
     HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel_spec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel_spec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   guard.c = nullptr;
   *out = c;
@@ -486,9 +488,13 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   }
   const bool spec = depth > 0;
   const int KS = spec ? (1 << depth) - 1 : 1;
-  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
-  hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
-                     dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr, depth);
+  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
+  if (spec)
+    hipLaunchKernelGGL(nbp_prep_kernel_spec, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+                       dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec, depth);
+  else
+    hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+                       dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
 }
@@ -594,9 +600,13 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
   int depth = 0;
   if (c->spec_on && n <= NBP_SPEC_MAXJOBS) depth = (c->spec_depth3 && 3 * n * 7 <= NBP_SPEC_MAXBLOCKS) ? 3 : ((3 * n * 3 <= NBP_SPEC_MAXBLOCKS) ? 2 : 0);
   const bool spec = depth > 0;
-  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
-  hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3, spec ? (1 << depth) - 1 : 1), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
-                     dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, spec ? c->spec : (nbp_spec_area *)nullptr, depth);
+  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
+  if (spec)
+    hipLaunchKernelGGL(nbp_bandwidth_kernel_spec, dim3(n, 3, (1 << depth) - 1), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                       dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, c->spec, depth);
+  else
+    hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                       dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[3]);
 }

@@ -39,7 +39,7 @@
 #define NBP_TAG 0x4E4250u
 
 #define NBP_MAXLEVELS 12
-#define NBP_RED 48
+#define NBP_RED 64
 
 // Level tables of the balanced KD-tree over N leaves: data-independent, built once per context.
 struct nbp_levels {
@@ -186,6 +186,9 @@ __device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) {
 // `tab` = the 32-entry 2^(j/32) table staged in LDS (nbp_exp_tab_init).
 __constant__ double NBP_EXP2_TAB[32] = {1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332, 1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
 #define NBP_EXPTAB 32
+// 2^(k/64), k = 0..63 (correctly rounded): the table of the bandwidth fit's exponential (lcv_exp below)
+__constant__ double NBP_EXP2_TAB64[64] = {1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+#define NBP_EXPTAB64 64
 __device__ __forceinline__ void nbp_exp_tab_init(double *tab) {
   if (threadIdx.x < 32) tab[threadIdx.x] = NBP_EXP2_TAB[threadIdx.x];
 }
@@ -863,7 +866,11 @@ __device__ long long nbp_phase_clk[64];
 #endif
 
 typedef __attribute__((address_space(3))) double nbp_lds_double;
+#ifdef NBP_X_NOATOMIC  // timing experiments only (tools/exp): wrong sums
+__device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { if (v == 123.456) *p = v; }
+#else
 __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
+#endif
 
 // squared geodesic distance on the circle for a difference within (-3pi, 3pi): min(|d|, ||d| - 2pi|)^2,
 // two VALU operations instead of a wrap (equal to wrap_pi(d)^2 up to the rounding of one subtraction)
@@ -872,8 +879,92 @@ __device__ __forceinline__ double circ_sq(double d) {
   return a * a;
 }
 
+// exp(-c q), q >= 0, with everything that depends on the bandwidth folded into per-evaluation constants that live in
+// SGPRs: n = round(-c q 64/ln2) by the magic-number trick, z = -c q - n ln2/64 = -c r with r = q + n ln2/(64 c), and
+// exp(z) = 1 + a1 r + ... + a5 r^5 with a_k = (-c)^k / k!  (|z| <= ln2/128: the next term is 3.5e-17), times
+// 2^((n & 63)/64) from the table, times 2^(n >> 6) by an integer add on the exponent field.  17 VALU operations per
+// pair where exp(-(q c)) by the general-purpose exp_nonpos takes 20 (the multiplication by c, one Horner step and one
+// of the integer operations are gone).
+struct lcv_exp_k {
+  double A, negM, B, qmax, a1, a2, a3, a4, a5;
+};
+// a wave-uniform double into an SGPR pair.  Opaque to the compiler on purpose: it folds __builtin_amdgcn_readfirstlane
+// of a value it can prove uniform and then keeps the result of the (vector) arithmetic in VGPRs -- eight constants of the
+// pair loop would cost sixteen VGPRs.
+__device__ __forceinline__ double sgpr_double(double v) {
+  int lo, hi;
+  asm("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
+  asm("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c) {
+  lcv_exp_k K;
+  K.A = sgpr_double(-c * 92.33248261689366);       // 64/ln2
+  K.negM = -6755399441055744.0;
+  K.B = sgpr_double(0.010830424696249145 / c);     // ln2/64
+  K.qmax = sgpr_double(700.0 / c);                  // exp(-700) = 1e-304 is as good as 0 for every sum it enters
+  const double m = -c;
+  K.a1 = sgpr_double(m);
+  K.a2 = sgpr_double(m * m * 0.5);
+  K.a3 = sgpr_double(m * m * m * 1.66666666666666666667e-01);
+  K.a4 = sgpr_double(m * m * m * m * 4.16666666666666666667e-02);
+  K.a5 = m * m * m * m * m * 8.33333333333333333333e-03;  // the leading coefficient stays in a VGPR pair (one scalar operand per VOP3)
+  return K;
+}
+#define NBP_FMA_VVS(dst, a, b, cst) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "s"(cst))
+#define NBP_FMA_VSV(dst, a, cst, c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "s"(cst), "v"(c))
+__device__ __forceinline__ double lcv_exp(double q, const lcv_exp_k &K, const double *tab64) {
+  q = fmin(q, K.qmax);
+  double t, r, p;
+  const double M = 6755399441055744.0;
+  NBP_FMA_VSV(t, q, K.A, M);
+  const int n = __double2loint(t);
+  const double tf = t + K.negM;
+  NBP_FMA_VSV(r, tf, K.B, q);
+  NBP_FMA_VVS(p, K.a5, r, K.a4);
+  NBP_FMA_VVS(p, p, r, K.a3);
+  NBP_FMA_VVS(p, p, r, K.a2);
+  NBP_FMA_VVS(p, p, r, K.a1);
+  p = fma(p, r, 1.0);
+  const double y = tab64[n & 63] * p;
+  int hi;
+  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(hi) : "v"(n & ~63), "v"(__double2hiint(y)));  // 2^(n >> 6) onto the exponent field
+  return __hiloint2double(hi, __double2loint(y));
+}
+
+// four independent chains, written step by step so that the instruction stream keeps them interleaved (the scheduler
+// otherwise runs one Horner chain after the other when registers are tight)
+__device__ __forceinline__ void lcv_exp4(double &q0, double &q1, double &q2, double &q3, const lcv_exp_k &K, const double *tab64) {
+  const double M = 6755399441055744.0;
+  q0 = fmin(q0, K.qmax); q1 = fmin(q1, K.qmax); q2 = fmin(q2, K.qmax); q3 = fmin(q3, K.qmax);
+  double t0, t1, t2, t3;
+  NBP_FMA_VSV(t0, q0, K.A, M); NBP_FMA_VSV(t1, q1, K.A, M); NBP_FMA_VSV(t2, q2, K.A, M); NBP_FMA_VSV(t3, q3, K.A, M);
+  const int n0 = __double2loint(t0), n1 = __double2loint(t1), n2 = __double2loint(t2), n3 = __double2loint(t3);
+#ifdef NBP_X_NOTAB
+  const double w0 = 1.0 + 1e-9 * n0, w1 = 1.0 + 1e-9 * n1, w2 = 1.0, w3 = 1.0;
+#else
+  const double w0 = tab64[n0 & 63], w1 = tab64[n1 & 63], w2 = tab64[n2 & 63], w3 = tab64[n3 & 63];
+#endif
+  t0 += K.negM; t1 += K.negM; t2 += K.negM; t3 += K.negM;
+  double r0, r1, r2, r3, p0, p1, p2, p3;
+  NBP_FMA_VSV(r0, t0, K.B, q0); NBP_FMA_VSV(r1, t1, K.B, q1); NBP_FMA_VSV(r2, t2, K.B, q2); NBP_FMA_VSV(r3, t3, K.B, q3);
+  NBP_FMA_VVS(p0, K.a5, r0, K.a4); NBP_FMA_VVS(p1, K.a5, r1, K.a4); NBP_FMA_VVS(p2, K.a5, r2, K.a4); NBP_FMA_VVS(p3, K.a5, r3, K.a4);
+  NBP_FMA_VVS(p0, p0, r0, K.a3); NBP_FMA_VVS(p1, p1, r1, K.a3); NBP_FMA_VVS(p2, p2, r2, K.a3); NBP_FMA_VVS(p3, p3, r3, K.a3);
+  NBP_FMA_VVS(p0, p0, r0, K.a2); NBP_FMA_VVS(p1, p1, r1, K.a2); NBP_FMA_VVS(p2, p2, r2, K.a2); NBP_FMA_VVS(p3, p3, r3, K.a2);
+  NBP_FMA_VVS(p0, p0, r0, K.a1); NBP_FMA_VVS(p1, p1, r1, K.a1); NBP_FMA_VVS(p2, p2, r2, K.a1); NBP_FMA_VVS(p3, p3, r3, K.a1);
+  p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0); p2 = fma(p2, r2, 1.0); p3 = fma(p3, r3, 1.0);
+  const double y0 = w0 * p0, y1 = w1 * p1, y2 = w2 * p2, y3 = w3 * p3;
+  int h0, h1, h2, h3;
+  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h0) : "v"(n0 & ~63), "v"(__double2hiint(y0)));
+  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h1) : "v"(n1 & ~63), "v"(__double2hiint(y1)));
+  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h2) : "v"(n2 & ~63), "v"(__double2hiint(y2)));
+  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h3) : "v"(n3 & ~63), "v"(__double2hiint(y3)));
+  q0 = __hiloint2double(h0, __double2loint(y0)); q1 = __hiloint2double(h1, __double2loint(y1));
+  q2 = __hiloint2double(h2, __double2loint(y2)); q3 = __hiloint2double(h3, __double2loint(y3));
+}
+
 template <bool CIRC>
-__device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta, int n4, int nt, bool extra, double xi, double c,
+__device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta, int n4, int nt, bool extra, double xi, const lcv_exp_k &K,
                                                 double *accw, const double *tab) {
   // x and the accumulator row are stored twice over ([0,2N)): partner pi+t never wraps, so both
   // addresses are one base register plus an immediate that advances with t.
@@ -885,12 +976,15 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
   const double *xp = x + pi + ta;
   nbp_lds_double *ap = (nbp_lds_double *)(accw + pi + ta);
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  // the coordinates of the next four partners are fetched while the current four are in flight
+  double y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+  if (n4 > 0) { y0 = xp[0]; y1 = xp[1]; y2 = xp[2]; y3 = xp[3]; }
   for (int k = 0; k < n4; k++, xp += 4, ap += 4) {
-    const double d0 = xi - xp[0], d1 = xi - xp[1], d2 = xi - xp[2], d3 = xi - xp[3];
-    const double q0 = CIRC ? circ_sq(d0) : d0 * d0, q1 = CIRC ? circ_sq(d1) : d1 * d1;
-    const double q2 = CIRC ? circ_sq(d2) : d2 * d2, q3 = CIRC ? circ_sq(d3) : d3 * d3;
-    const double e0 = exp_nonpos(-q0 * c, tab), e1 = exp_nonpos(-q1 * c, tab);
-    const double e2 = exp_nonpos(-q2 * c, tab), e3 = exp_nonpos(-q3 * c, tab);
+    const double d0 = xi - y0, d1 = xi - y1, d2 = xi - y2, d3 = xi - y3;
+    if (k + 1 < n4) { y0 = xp[4]; y1 = xp[5]; y2 = xp[6]; y3 = xp[7]; }
+    double e0 = CIRC ? circ_sq(d0) : d0 * d0, e1 = CIRC ? circ_sq(d1) : d1 * d1;
+    double e2 = CIRC ? circ_sq(d2) : d2 * d2, e3 = CIRC ? circ_sq(d3) : d3 * d3;
+    lcv_exp4(e0, e1, e2, e3, K, tab);
     s0 += e0;
     s1 += e1;
     s2 += e2;
@@ -902,13 +996,13 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
   }
   for (int k = 0; k < nt; k++) {
     const double d0 = xi - xp[k];
-    const double e0 = exp_nonpos(-(CIRC ? circ_sq(d0) : d0 * d0) * c, tab);
+    const double e0 = lcv_exp(CIRC ? circ_sq(d0) : d0 * d0, K, tab);
     s0 += e0;
     lds_add(ap + k, e0);
   }
   if (extra) {
     const double d0 = xi - xp[nt];
-    const double e0 = exp_nonpos(-(CIRC ? circ_sq(d0) : d0 * d0) * c, tab);
+    const double e0 = lcv_exp(CIRC ? circ_sq(d0) : d0 * d0, K, tab);
     s1 += e0;
     lds_add(ap + nt, e0);
   }
@@ -925,6 +1019,7 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   // three (every lane of a wave pays for a log whether one lane needs it or all of them do)
   NBP_CTICK_INIT();
   const double inv_h = 1.0 / h, inv2h2 = 0.5 * inv_h * inv_h;
+  const lcv_exp_k K = lcv_exp_consts(inv2h2);
   const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
   const int w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   double *acc = part + P * Npad;
@@ -940,25 +1035,54 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     const int lastbase = (N - 1) & ~63, A = N - lastbase, l = threadIdx.x & 63;
     int A2 = 1;
     while (A2 < A) A2 <<= 1;
-    const bool redeal = (i >= lastbase) && A2 <= 32;  // wave-uniform
+    const bool lastwave = i >= lastbase;            // wave-uniform
+    const bool redeal = lastwave && A2 <= 32;
     const int HH = redeal ? 64 / A2 : 1;
-    const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l / A2 : 0;
-    const int len = t1 - t0, lenmin = len / HH, rem = len - lenmin * HH;
-    const int ta = t0 + hh * lenmin + min(hh, rem);
-    const int n4 = __builtin_amdgcn_readfirstlane(lenmin >> 2), nt = __builtin_amdgcn_readfirstlane(lenmin & 3);
-    if (pi < N) {
-      const double xi = x[pi];
-      double *accw = acc + w * 2 * N;
-      const double s = circ ? loo_symmetric<true>(x, pi, ta, n4, nt, hh < rem, xi, inv2h2, accw, tab)
-                            : loo_symmetric<false>(x, pi, ta, n4, nt, hh < rem, xi, inv2h2, accw, tab);
-      lds_add((nbp_lds_double *)(part + p * Npad + pi), s);
+    const int len = t1 - t0;
+    // Balance between the waves of a row: after its own points (len / HH steps when re-dealt) the last wave takes the
+    // tail steps [t0 + Lw, t1) of every full wave's points, so that all waves of the row leave the pair loop together
+    // (N = 200, P = 1: 78 steps in the full waves, 13 + 3 x 21 in the last one, instead of 99 and 13).  A row sum then
+    // has two contributors -- its owner and the last wave -- each with ONE atomic add into a slot that starts at zero:
+    // a + b = b + a, so the sums do not depend on which comes first.
+    const int nfull = lastbase >> 6, own_ws = (A2 <= 32) ? (len + 64 / A2 - 1) / (64 / A2) : len;
+    int Lw = len;
+    if (A < 64 && nfull > 0) Lw = min(len, (own_ws + nfull * len + nfull) / (nfull + 1));
+    const int hand = len - Lw;
+    double *accw = acc + w * 2 * N;
+    if (!lastwave) {
+      const int n4 = __builtin_amdgcn_readfirstlane(Lw >> 2), nt = __builtin_amdgcn_readfirstlane(Lw & 3);
+      const double xi = x[i];
+      const double s = circ ? loo_symmetric<true>(x, i, t0, n4, nt, false, xi, K, accw, tab)
+                            : loo_symmetric<false>(x, i, t0, n4, nt, false, xi, K, accw, tab);
+      lds_add((nbp_lds_double *)(part + p * Npad + i), s);
+    } else {
+      const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l / A2 : 0;
+      const int lenmin = len / HH, rem = len - lenmin * HH;
+      const int ta = t0 + hh * lenmin + min(hh, rem);
+      const int n4 = __builtin_amdgcn_readfirstlane(lenmin >> 2), nt = __builtin_amdgcn_readfirstlane(lenmin & 3);
+      if (pi < N) {
+        const double xi = x[pi];
+        const double s = circ ? loo_symmetric<true>(x, pi, ta, n4, nt, hh < rem, xi, K, accw, tab)
+                              : loo_symmetric<false>(x, pi, ta, n4, nt, hh < rem, xi, K, accw, tab);
+        lds_add((nbp_lds_double *)(part + p * Npad + pi), s);
+      }
+      if (hand > 0) {
+        const int h4 = __builtin_amdgcn_readfirstlane(hand >> 2), ht = __builtin_amdgcn_readfirstlane(hand & 3);
+        for (int f = 0; f < nfull; f++) {
+          const int pj = 64 * f + l;
+          const double xj = x[pj];
+          const double s = circ ? loo_symmetric<true>(x, pj, t0 + Lw, h4, ht, false, xj, K, accw, tab)
+                                : loo_symmetric<false>(x, pj, t0 + Lw, h4, ht, false, xj, K, accw, tab);
+          lds_add((nbp_lds_double *)(part + p * Npad + pj), s);
+        }
+      }
     }
-    if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair
-      const int j = i + N / 2;
+    if ((N & 1) == 0 && p == P - 1 && i < N / 2) {  // antipodal partner, once per pair; both ends through the per-wave
+      const int j = i + N / 2;                        // accumulators (program order within a wave: deterministic)
       const double d = x[i] - x[j];
-      const double e = exp_nonpos(-(circ ? circ_sq(d) : d * d) * inv2h2, tab);
-      lds_add((nbp_lds_double *)(part + p * Npad + i), e);
-      lds_add((nbp_lds_double *)(acc + w * 2 * N + j), e);
+      const double e = lcv_exp(circ ? circ_sq(d) : d * d, K, tab);
+      lds_add((nbp_lds_double *)(accw + i), e);
+      lds_add((nbp_lds_double *)(accw + j), e);
     }
   }
   NBP_CTICK(20);  // pair loop
@@ -1053,7 +1177,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
 // ------------------------------------------------------------------------------------------------
 #define NBP_SPEC_KMAX 7
 #define NBP_SPEC_ROUNDS 24
-struct nbp_spec_area {  // one per (fit job, coordinate); zeroed by the host before the launch
+struct nbp_spec_area {  // one per (fit job, coordinate); filled with ones (0xFF bytes) by the host before the launch
   unsigned long long f[NBP_SPEC_ROUNDS][8];  // published values (bit patterns), [round][role]
   unsigned int cnt[NBP_SPEC_ROUNDS];         // arrivals per round
   unsigned int pad_[8];
@@ -1116,24 +1240,37 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   // rendezvous: publish the value of this role's point, collect all K values; false = on our own from now on
   auto rendezvous = [&](double mine) -> bool {
     if (round >= NBP_SPEC_ROUNDS) return false;
+    // one lane talks to memory: it publishes this role's value, waits for the K arrivals, fetches the K values and hands
+    // them to the workgroup through the reduction scratch (slots 48 .. 63; its two halves alternate by
+    // round so that one barrier per rendezvous is enough)
+    double *box = red + 48 + (round & 1) * (K + 1);
     if (threadIdx.x == 0) {
+      // Relaxed device-scope atomics only: a release / acquire pair at agent scope costs a write-back and an
+      // invalidation of the XCD's L2 (microseconds -- as much as the evaluation it is meant to save).  The values
+      // themselves are the flags: the host fills the area with ones (a NaN pattern no likelihood takes), a role's slot
+      // turns into its value with one 8-byte atomic store, and the reader polls the K slots until none is blank.
+      const unsigned long long blank = ~0ull;
       __hip_atomic_store(&area->f[round][role], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&area->cnt[round], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       int ok = 0;
-      for (int spin = 0; spin < 100000; spin++) {
-        if (__hip_atomic_load(&area->cnt[round], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)K) { ok = 1; break; }
-        __builtin_amdgcn_s_sleep(2);
+      unsigned long long got[K];
+      for (int spin = 0; spin < 200000 && !ok; spin++) {
+        ok = 1;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+          got[r] = __hip_atomic_load(&area->f[round][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok &= got[r] != blank;
+        }
       }
-      red[40] = (double)ok;  // broadcast slot of the reduction scratch
+      box[0] = (double)ok;
+#pragma unroll
+      for (int r = 0; r < K; r++) box[r + 1] = __longlong_as_double((long long)got[r]);
     }
     __syncthreads();
-    const bool ok_ = red[40] != 0.0;
+    const bool ok_ = box[0] != 0.0;
     if (ok_) {
 #pragma unroll
-      for (int r = 0; r < K; r++)
-        vals[r + 1] = __longlong_as_double((long long)__hip_atomic_load(&area->f[round][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      for (int r = 0; r < K; r++) vals[r + 1] = box[r + 1];
     }
-    __syncthreads();
     round++;
     return ok_;
   };

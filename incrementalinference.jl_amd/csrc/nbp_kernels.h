@@ -374,6 +374,7 @@ nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, dou
 static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
 
 // fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)
+template <bool SPEC>
 __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int Ncap, int Npad, double *smem, nbp_counters *ctr,
                                                     nbp_spec_area *area = nullptr, int role = 0, int depth = 0) {
   const int D = mani_dim(M), n = threadIdx.x;
@@ -384,7 +385,7 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   const int N = slot_count(s, Ncap);  // manikde! of the points the belief holds (Ncap = slot capacity = stride)
   const int P = blockDim.x / Npad;
   double *X = smem, *part = smem + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N, *tab = red + NBP_RED;
-  nbp_exp_tab_init(tab);
+  if (n < NBP_EXPTAB64) tab[n] = NBP_EXP2_TAB64[n];  // the table of lcv_exp
   // circular coordinates are staged wrapped (the identity for stored beliefs): every pair difference of
   // the fit is then within (-2pi, 2pi), which is what circ_sqdist relies on
   if (n < N) {
@@ -392,7 +393,8 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
     X[n] = X[n + N] = is_circ(M, k) ? wrap_pi(v) : v;
   }
   __syncthreads();
-  if (area) {  // latency mode: 2^depth - 1 workgroups per fit (lcv_bandwidth_1d_spec)
+  if (SPEC) {  // latency mode: 2^depth - 1 workgroups per fit (lcv_bandwidth_1d_spec); a kernel of its own, so that the
+               // registers the outcome tree needs do not cost the throughput kernel its occupancy
     const double hs = depth == 3 ? lcv_bandwidth_1d_spec<3>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role)
                                  : lcv_bandwidth_1d_spec<2>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role);
     if (n == 0 && role == 0) s[3 * Ncap + k] = hs;
@@ -408,16 +410,21 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
 // for the rebandwidth of products and for nbp_run_bandwidth.
 // ================================================================================================
 __global__ void __launch_bounds__(1024)
-nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S,
-                     nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
-  extern __shared__ double smem[];  // grid (jobs, 3, 1 or 2^spec_depth - 1)
-  lcv_slot_coordinate(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr,
-                      spec ? spec + (blockIdx.x * 3 + blockIdx.y) : nullptr, blockIdx.z, spec_depth);
+nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S, nbp_counters *ctr) {
+  extern __shared__ double smem[];  // grid (jobs, 3)
+  lcv_slot_coordinate<false>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
+}
+__global__ void __launch_bounds__(1024)
+nbp_bandwidth_kernel_spec(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S,
+                          nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
+  extern __shared__ double smem[];  // grid (jobs, 3, 2^spec_depth - 1)
+  lcv_slot_coordinate<true>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr,
+                            spec + (blockIdx.x * 3 + blockIdx.y), blockIdx.z, spec_depth);
 }
 
 // X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
 static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
-  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_EXPTAB) * 8;
+  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_EXPTAB64) * 8;
 }
 
 __global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S) {
@@ -611,15 +618,15 @@ static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
   return ((size_t)D * N + 3 * Npad + NBP_RED) * 8 + ((size_t)2 * N + (size_t)P * Npad + Npad) * 4;
 }
 
-__global__ void __launch_bounds__(1024)
-nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
-                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
-  extern __shared__ double smem[];
+template <bool SPEC>
+__device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
+                                          double *arena, double *ws, int N, int Npad, int64_t S, const nbp_levels &T, nbp_counters *ctr,
+                                          nbp_spec_area *spec, int spec_depth, double *smem) {
   const int b = blockIdx.x;
-  const int KS = spec ? (1 << spec_depth) - 1 : 1;  // workgroups per (slot, coordinate)
+  const int KS = SPEC ? (1 << spec_depth) - 1 : 1;  // workgroups per (slot, coordinate)
   if (b < 3 * nbw * KS) {  // manikde! bandwidth of (slot, coordinate)
     const int job = b / (3 * KS), k = (b % (3 * KS)) / KS, role = b % KS;
-    lcv_slot_coordinate(arena + S * bw_slots[job], bw_manis[job], k, N, Npad, smem, ctr, spec ? spec + (job * 3 + k) : nullptr, role, spec_depth);
+    lcv_slot_coordinate<SPEC>(arena + S * bw_slots[job], bw_manis[job], k, N, Npad, smem, ctr, SPEC ? spec + (job * 3 + k) : nullptr, role, spec_depth);
     return;
   }
   const int q = b - 3 * nbw * KS, p = q / kdF, j = q % kdF;  // kdF = largest nfactors of the batch
@@ -635,6 +642,19 @@ nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const
   case 2: kd_build<2>(x, wsj, N, Npad, T, smem, mask); break;
   default: kd_build<3>(x, wsj, N, Npad, T, smem, mask); break;
   }
+}
+__global__ void __launch_bounds__(1024)
+nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
+                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr) {
+  extern __shared__ double smem[];
+  prep_body<false>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, nullptr, 0, smem);
+}
+// latency mode: 2^spec_depth - 1 workgroups per fit (lcv_bandwidth_1d_spec)
+__global__ void __launch_bounds__(1024)
+nbp_prep_kernel_spec(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
+                     double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
+  extern __shared__ double smem[];
+  prep_body<true>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, spec, spec_depth, smem);
 }
 
 // Gibbs geometry: HL adjacent lanes of ONE wave serve one output sample (a wave carries 64/HL samples).
