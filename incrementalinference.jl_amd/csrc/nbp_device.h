@@ -888,13 +888,14 @@ __device__ __forceinline__ double circ_sq(double d) {
 struct lcv_exp_k {
   double A, negM, B, qmax, a1, a2, a3, a4, a5;
 };
+
 // a wave-uniform double into an SGPR pair.  Opaque to the compiler on purpose: it folds __builtin_amdgcn_readfirstlane
 // of a value it can prove uniform and then keeps the result of the (vector) arithmetic in VGPRs -- eight constants of the
 // pair loop would cost sixteen VGPRs.
 __device__ __forceinline__ double sgpr_double(double v) {
   int lo, hi;
-  asm("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
-  asm("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
+  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
+  asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(hi) : "v"(__double2hiint(v)));  // the assembler's hazard checks do not see inside
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c) {
@@ -1150,19 +1151,20 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   const double ax = minm / sc, bx = 1.0, cx = maxm / sc;
   const double R = 0.61803399, C = 1.0 - R, tol = 1e-2;
   const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
+  const double scs = sgpr_double(sc), ln0 = sgpr_double(lognorm0);
   double x0 = ax, x3 = cx, x1, x2;
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = fma(C, cx - bx, bx); }
   else { x2 = bx; x1 = fma(-C, bx - ax, bx); }
-  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab);
+  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * scs, ln0, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * scs, ln0, part, red, tab);
   unsigned int nev = 2;
   while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
     nev++;
     // positions by explicit fma (see golden_step)
-    if (f2 < f1) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * sc, lognorm0, part, red, tab); }
-    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * sc, lognorm0, part, red, tab); }
+    if (f2 < f1) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * scs, ln0, part, red, tab); }
+    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * scs, ln0, part, red, tab); }
   }
   if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
-  return (f1 < f2 ? x1 : x2) * sc;
+  return (f1 < f2 ? x1 : x2) * scs;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1232,7 +1234,10 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   g.x0 = ax; g.x3 = cx;
   if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = fma(C, cx - bx, bx); }
   else { g.x2 = bx; g.x1 = fma(-C, bx - ax, bx); }
-  auto eval = [&](double xs) { return neg_loo_ll(x, N, Npad, circ, xs * sc, lognorm0, part, red, tab); };
+  // uniform state in SGPRs across the evaluations (see lcv_bandwidth_1d)
+  const double scs = sgpr_double(sc), ln0 = sgpr_double(lognorm0);
+  g.f1 = g.f2 = 0.0;
+  auto eval = [&](double xs) { return neg_loo_ll(x, N, Npad, circ, xs * scs, ln0, part, red, tab); };
   bool solo = false;  // gave up on the peers: the sequential search from here on
   int round = 0;
   unsigned int nev = 2;
@@ -1319,7 +1324,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
     }
   }
   if (ctr && threadIdx.x == 0 && role == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
-  return (g.f1 < g.f2 ? g.x1 : g.x2) * sc;
+  return (g.f1 < g.f2 ? g.x1 : g.x2) * scs;
 }
 
 // rand(Categorical(p)) by inverse CDF on one uniform

@@ -1,0 +1,20 @@
+#!/bin/bash
+# The round's evidence in one GPU call: plain bench line, kernel trace of the same command (+ timed-region summary +
+# per-kernel stats), three PMC passes (HBM traffic), the other configs.  Output under gpurun_out/$TAG; copy what is
+# to be judged into profiles/.   Usage (on the GPU box): tools/collect_profiles.sh r02
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k > $O/bench_under_rocprof.json 2> $O/trace.err
+python $R/tools/summarize_trace.py $O/trace 5 > $O/bench_timed_region_summary.txt
+python $R/tools/kernel_stats.py $O/trace > $O/bench_kernel_stats.csv
+for p in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $p -d $O/pmc/$p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k --no-profile-pass > /dev/null 2> $O/pmc_$p.err; done
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc/TCC -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k --no-profile-pass > /dev/null 2> $O/pmc_TCC.err
+python $R/tools/pmc_traffic.py $O/pmc 5 200 $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+for c in 3 4 5; do python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; done
+python $R/tools/lcv_bench.py > $O/lcv_microbench.txt 2>/dev/null
+rm -rf $O/trace/*/*.db.tmp
+du -sh $O
