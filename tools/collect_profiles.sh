@@ -16,5 +16,9 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc/TCC -- python $R/bench.py --s
 python $R/tools/pmc_traffic.py $O/pmc 5 200 $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 for c in 3 4 5; do python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; done
 python $R/tools/lcv_bench.py > $O/lcv_microbench.txt 2>/dev/null
+# SQ counters of the chip-filling bandwidth fit (two passes of 8 counters)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU -d $O/sq/p1 -- python $R/tools/lcv_bench.py 200 2048 > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INST_CYCLES_SALU -d $O/sq/p2 -- python $R/tools/lcv_bench.py 200 2048 > /dev/null 2>&1
+python $R/tools/pmc_sq.py $O/sq nbp_bandwidth > $O/lcv_sq_counters.txt 2>&1
 rm -rf $O/trace/*/*.db.tmp
 du -sh $O
