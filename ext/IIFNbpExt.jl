@@ -267,6 +267,13 @@ factorkind(::PartialPriorPassThrough) = NBP_F_PASSTHROUGH   # its density travel
 function component(w::Real, Z)::Vector{Float64}
   row = zeros(Float64, NBP_COMP_STRIDE)
   row[1] = w
+  if Z isa Uniform                                      # enum nbp_dist (include/nbp.h): scalar families ride in the last slot
+    row[2] = minimum(Z); row[5] = maximum(Z) - minimum(Z); row[NBP_COMP_STRIDE] = 1.0
+    return row
+  elseif Z isa Rayleigh
+    row[5] = scale(Z); row[NBP_COMP_STRIDE] = 2.0
+    return row
+  end
   mu = Z isa Normal ? [mean(Z)] : collect(mean(Z))
   L = Z isa Normal ? fill(std(Z), 1, 1) : Matrix(cholesky(Symmetric(Matrix(cov(Z)))).L)
   for i in 1:min(3, length(mu))

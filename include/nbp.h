@@ -41,6 +41,14 @@ extern "C" {
 #define NBP_MAXC 4   /* Mixture components                                                  */
 #define NBP_MAXN 512 /* particles per belief                                                */
 #define NBP_COMP_STRIDE 13 /* per component: weight, mean[3], sqrt-cov L[3][3] row-major    */
+/* Family of a SCALAR measurement component, carried in its last slot (comp[c][12] = L[2][2], which a one-dimensional
+ * measurement does not use; read only when the measurement has one dimension).  Multi-dimensional measurements are
+ * Gaussian (MvNormal).  `rand(Z)` of the reference's Distributions.jl objects (sampleFactor, CalcFactor.jl). */
+enum nbp_dist {
+  NBP_DIST_GAUSSIAN = 0, /* z = mean[0] + L[0][0] * randn                                     */
+  NBP_DIST_UNIFORM = 1,  /* Uniform(a, b): mean[0] = a, L[0][0] = b - a; z = a + (b - a) u   */
+  NBP_DIST_RAYLEIGH = 2  /* Rayleigh(sigma): L[0][0] = sigma; z = sigma sqrt(-2 log(1 - u))   */
+};
 
 typedef int32_t nbp_status;
 #define NBP_OK 0

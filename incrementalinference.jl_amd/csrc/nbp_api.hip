@@ -461,9 +461,11 @@ static nbp_status ensure_gstats(nbp_ctx *c, size_t need) {
 // workgroups share a CU so that the barrier/combine phases of one overlap the pair loop of the
 // others when there are many fits (throughput mode).
 static int lcv_helpers(nbp_ctx *c, int nblocks) {
+  static const int p2_min = getenv("NBP_LCV_P2_MIN") ? atoi(getenv("NBP_LCV_P2_MIN")) : 256;
+  static const int p1_min = getenv("NBP_LCV_P1_MIN") ? atoi(getenv("NBP_LCV_P1_MIN")) : 4 * 256;
   int P = c->P;
-  if (nblocks > 256 && P > 2) P = 2;
-  if (nblocks > 4 * 256) P = 1;
+  if (nblocks > p2_min && P > 2) P = 2;
+  if (nblocks > p1_min) P = 1;
   return P;
 }
 

@@ -48,6 +48,13 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
     if (c < 0) c = last;
   }
   const double *cp = d->comp[c];
+  if (zdim == 1 && cp[12] != 0.0) {  // scalar Uniform / Rayleigh component (enum nbp_dist)
+    double ua, ub;
+    uniform_pair(mseed, n, PURP_MEAS, 0, ua, ub);
+    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(1.0 - ua));
+    z[1] = z[2] = 0.0;
+    return;
+  }
   double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
   normal_pair(mseed, n, PURP_MEAS, 0, n0, n1);
   if (zdim > 2) normal_pair(mseed, n, PURP_MEAS, 1, n2, n3);

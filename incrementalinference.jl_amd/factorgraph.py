@@ -29,6 +29,34 @@ class Normal:
         return np.array([self.mu]), np.array([[self.sigma]])
 
 
+class Uniform:
+    """Uniform(a, b): a scalar measurement drawn uniformly on [a, b] (Distributions.jl; test/testMixturePrior.jl:30,
+    test/testPackingMixtures.jl:20).  In a measurement component: mean slot = a, L[0][0] = b - a, family code 1."""
+    family = abi.DIST_UNIFORM
+
+    def __init__(self, a=0.0, b=1.0):
+        self.a, self.b = float(a), float(b)
+        if not self.b > self.a:
+            raise ValueError("Uniform(a, b) needs a < b")
+
+    def mean_sqrtcov(self):
+        return np.array([self.a]), np.array([[self.b - self.a]])
+
+
+class Rayleigh:
+    """Rayleigh(sigma): z = sigma * sqrt(-2 log u) (test/testCompareVariablesFactors.jl:106 `LinearRelative(Rayleigh())`).
+    In a measurement component: L[0][0] = sigma, family code 2."""
+    family = abi.DIST_RAYLEIGH
+
+    def __init__(self, sigma=1.0):
+        self.sigma = float(sigma)
+        if not self.sigma > 0:
+            raise ValueError("Rayleigh(sigma) needs sigma > 0")
+
+    def mean_sqrtcov(self):
+        return np.array([0.0]), np.array([[self.sigma]])
+
+
 class MvNormal:
     """MvNormal(mu, Sigma).  Like Distributions.jl, a vector second argument is a vector of
     standard deviations (`MvNormal(mu, sigma::Vector)`), a matrix is the covariance."""
@@ -89,9 +117,9 @@ class _Factor:
     zdim = None  # None = dimension of the variable
 
     def components(self):
-        """list of (weight, mean, sqrtcov) measurement components"""
+        """list of (weight, mean, sqrtcov, family) measurement components; family: abi.DIST_* (scalar measurements)"""
         mu, L = self.Z.mean_sqrtcov()
-        return [(1.0, mu, L)]
+        return [(1.0, mu, L, getattr(self.Z, "family", abi.DIST_GAUSSIAN))]
 
 
 class Prior(_Factor):
@@ -205,7 +233,7 @@ class Mixture(_Factor):
             mu, L = z.mean_sqrtcov()
             if isinstance(self.mechanics, ManifoldPrior):
                 mu = self.mechanics.p + mu
-            out.append((float(w), mu, L))
+            out.append((float(w), mu, L, getattr(z, "family", abi.DIST_GAUSSIAN)))
         return out
 
 

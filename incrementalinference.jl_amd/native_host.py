@@ -151,13 +151,16 @@ def factor_spec(f, index):
         s.vars[i] = index[v]
     comps = f.fnc.components()
     s.ncomp = len(comps)
-    for c, (w, mu, L) in enumerate(comps):
+    for c, comp in enumerate(comps):
+        w, mu, L = comp[:3]
         s.comp[c][0] = w
         for i in range(min(3, len(mu))):
             s.comp[c][1 + i] = float(mu[i])
         for i in range(min(3, L.shape[0])):
             for j in range(i + 1):
                 s.comp[c][4 + 3 * i + j] = float(L[i, j])
+        if len(comp) > 3 and comp[3] != abi.DIST_GAUSSIAN:  # scalar Uniform / Rayleigh (enum nbp_dist)
+            s.comp[c][12] = float(comp[3])
     if f.multihypo is not None:
         s.has_multihypo = 1
         for i, p in enumerate(f.multihypo):

@@ -74,7 +74,8 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     if flat is None:
         comps = fnc.components()
         flat = []
-        for (w, mu, L) in comps:
+        for comp in comps:
+            w, mu, L = comp[:3]
             row = [0.0] * abi.COMP_STRIDE
             row[0] = w
             for i in range(min(3, len(mu))):
@@ -82,6 +83,10 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
             for i in range(min(3, L.shape[0])):
                 for j in range(i + 1):
                     row[4 + 3 * i + j] = float(L[i, j])
+            if len(comp) > 3 and comp[3] != abi.DIST_GAUSSIAN:  # scalar Uniform / Rayleigh: the family rides in the last slot
+                if len(mu) != 1:
+                    raise ValueError("Uniform / Rayleigh measurements are scalar")
+                row[12] = float(comp[3])
             flat.append(row)
         try:
             fnc._comp_flat = flat
@@ -316,8 +321,14 @@ def _sample_components(comps, N, seed):
     lbl = rng.choice(len(comps), size=N, p=w / w.sum())
     out = []
     for n in range(N):
-        _, mu, L = comps[lbl[n]]
-        out.append(np.asarray(mu) + np.asarray(L) @ rng.normal(size=len(mu)))
+        comp = comps[lbl[n]]
+        mu, L, fam = comp[1], comp[2], (comp[3] if len(comp) > 3 else abi.DIST_GAUSSIAN)
+        if fam == abi.DIST_UNIFORM:
+            out.append(np.asarray(mu) + np.asarray(L)[0] * rng.uniform())
+        elif fam == abi.DIST_RAYLEIGH:
+            out.append(np.asarray(L)[0] * np.sqrt(-2.0 * np.log(1.0 - rng.uniform())))
+        else:
+            out.append(np.asarray(mu) + np.asarray(L) @ rng.normal(size=len(mu)))
     return np.array(out)
 
 

@@ -835,6 +835,13 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
   }
   if (label) *label = c;
   const double *cp = d->comp[c];
+  if (zdim == 1 && cp[12] != 0.0) { /* rand(Uniform(a, b)) / rand(Rayleigh(sigma)): enum nbp_dist, include/nbp.h */
+    double ua, ub;
+    orc_uniform_pair(mseed, n, PURP_MEAS, 0, &ua, &ub);
+    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(1.0 - ua));
+    z[1] = z[2] = 0;
+    return;
+  }
   double nn[4];
   orc_normal_pair(mseed, n, PURP_MEAS, 0, &nn[0], &nn[1]);
   if (zdim > 2) orc_normal_pair(mseed, n, PURP_MEAS, 1, &nn[2], &nn[3]);
