@@ -86,6 +86,7 @@ class RankSolve:
             t3 = time.perf_counter()
             iif.initAll(fg, backend=mk, seed=0)
             t_init = time.perf_counter() - t3
+            t_ctx = 0.0  # inside graph_init_s on this path (initAll makes its own context)
             ta = time.perf_counter()
             tp = iif.TreeProgram(fg, tree, seed=1, snapshot=True)
             self.be = mk(self.N, tp.n_slots)
@@ -109,7 +110,12 @@ class RankSolve:
             n_slots = nt.plan_slots(True)
             ti = time.perf_counter()
             need, _ = g.init_plan(0)
-            self.be = mk(self.N, max(n_slots, need))
+            t_plan = time.perf_counter() - ti
+            tb = time.perf_counter()
+            self.be = mk(self.N, max(n_slots, need))  # context: arena allocation, code object load -- process setup, not initAll!
+            self.be.synchronize()
+            t_ctx = time.perf_counter() - tb
+            ti = time.perf_counter() - t_plan
             for i, v in enumerate(fg.ls()):  # a fresh arena is all zeros = N points at the identity, what addVariable! leaves
                 var = fg.getVariable(v)
                 if np.any(var.val[:, :var.varType.dim] if var.varType.manifold != iif.abi.SE2 else var.val[:, :2]) or var.initialized:
@@ -130,7 +136,7 @@ class RankSolve:
             self._native = (g, nt)
         self.host_setup = {"host": "python mirror" if self.python_host else "native C++ (nbp_host.h)", "graph_s": t_graph,
                            "graph_mirror_s": mirror, "elimination_order_s": t2 - t1, "tree_build_s": t3 - t2,
-                           "graph_init_s": t_init, "schedule_compile_s": t_comp}
+                           "graph_init_s": t_init, "schedule_compile_s": t_comp, "context_create_s": t_ctx}
         if self.python_host:
             for v in fg.ls():
                 var = fg.getVariable(v)

@@ -47,7 +47,7 @@ extern "C" {
 enum nbp_dist {
   NBP_DIST_GAUSSIAN = 0, /* z = mean[0] + L[0][0] * randn                                     */
   NBP_DIST_UNIFORM = 1,  /* Uniform(a, b): mean[0] = a, L[0][0] = b - a; z = a + (b - a) u   */
-  NBP_DIST_RAYLEIGH = 2  /* Rayleigh(sigma): L[0][0] = sigma; z = sigma sqrt(-2 log(1 - u))   */
+  NBP_DIST_RAYLEIGH = 2  /* Rayleigh(sigma): L[0][0] = sigma; z = sigma sqrt(-2 log u), u in (0, 1] */
 };
 
 typedef int32_t nbp_status;

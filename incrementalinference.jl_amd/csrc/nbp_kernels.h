@@ -51,7 +51,7 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
   if (zdim == 1 && cp[12] != 0.0) {  // scalar Uniform / Rayleigh component (enum nbp_dist)
     double ua, ub;
     uniform_pair(mseed, n, PURP_MEAS, 0, ua, ub);
-    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(1.0 - ua));
+    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
     z[1] = z[2] = 0.0;
     return;
   }

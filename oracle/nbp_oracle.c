@@ -838,7 +838,7 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
   if (zdim == 1 && cp[12] != 0.0) { /* rand(Uniform(a, b)) / rand(Rayleigh(sigma)): enum nbp_dist, include/nbp.h */
     double ua, ub;
     orc_uniform_pair(mseed, n, PURP_MEAS, 0, &ua, &ub);
-    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(1.0 - ua));
+    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
     z[1] = z[2] = 0;
     return;
   }
