@@ -866,11 +866,7 @@ __device__ long long nbp_phase_clk[64];
 #endif
 
 typedef __attribute__((address_space(3))) double nbp_lds_double;
-#ifdef NBP_X_NOATOMIC  // timing experiments only (tools/exp): wrong sums
-__device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { if (v == 123.456) *p = v; }
-#else
 __device__ __forceinline__ void lds_add(nbp_lds_double *p, double v) { (void)__builtin_amdgcn_ds_atomic_fadd_f64(p, v); }
-#endif
 
 // squared geodesic distance on the circle for a difference within (-3pi, 3pi): min(|d|, ||d| - 2pi|)^2,
 // two VALU operations instead of a wrap (equal to wrap_pi(d)^2 up to the rounding of one subtraction)
@@ -941,11 +937,7 @@ __device__ __forceinline__ void lcv_exp4(double &q0, double &q1, double &q2, dou
   double t0, t1, t2, t3;
   NBP_FMA_VSV(t0, q0, K.A, M); NBP_FMA_VSV(t1, q1, K.A, M); NBP_FMA_VSV(t2, q2, K.A, M); NBP_FMA_VSV(t3, q3, K.A, M);
   const int n0 = __double2loint(t0), n1 = __double2loint(t1), n2 = __double2loint(t2), n3 = __double2loint(t3);
-#ifdef NBP_X_NOTAB
-  const double w0 = 1.0 + 1e-9 * n0, w1 = 1.0 + 1e-9 * n1, w2 = 1.0, w3 = 1.0;
-#else
   const double w0 = tab64[n0 & 63], w1 = tab64[n1 & 63], w2 = tab64[n2 & 63], w3 = tab64[n3 & 63];
-#endif
   t0 += K.negM; t1 += K.negM; t2 += K.negM; t3 += K.negM;
   double r0, r1, r2, r3, p0, p1, p2, p3;
   NBP_FMA_VSV(r0, t0, K.B, q0); NBP_FMA_VSV(r1, t1, K.B, q1); NBP_FMA_VSV(r2, t2, K.B, q2); NBP_FMA_VSV(r3, t3, K.B, q3);
@@ -1089,29 +1081,48 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   NBP_CTICK(20);  // pair loop
   __syncthreads();
   NBP_CTICK(21);  // barrier 1
-  // combine: helper p folds the accumulator rows p, p+P, ... of point i (and clears them)
-  if (i < N) {
-    double s = part[p * Npad + i];
-    for (int q = p; q < NW; q += P) {
-      double *a = acc + q * 2 * N + i;
-      s += a[0] + a[N];
-      a[0] = 0.0;
-      a[N] = 0.0;
-    }
-    part[p * Npad + i] = s;
-  }
-  NBP_CTICK(22);  // combine
-  __syncthreads();
-  NBP_CTICK(23);  // barrier 2
   double term = 0;
-  if (p == 0 && i < N) {
-    double s = 0;
-    for (int q = 0; q < P; q++) {  // read-and-clear: the next evaluation accumulates into zeros
-      s += part[q * Npad + i];
-      part[q * Npad + i] = 0.0;
+  if (P == 1) {
+    // one helper row (throughput mode): lane i folds all accumulator rows of its point itself -- no second pass through
+    // `part`, one barrier fewer; the same additions in the same order as the two-pass form
+    if (i < N) {
+      double s = part[i];
+      part[i] = 0.0;
+      for (int q = 0; q < NW; q++) {
+        double *a = acc + q * 2 * N + i;
+        s += a[0] + a[N];
+        a[0] = 0.0;
+        a[N] = 0.0;
+      }
+      if (s < 1e-300) s = 1e-300;
+      term = log(s * inv_h) - lognorm0;
     }
-    if (s < 1e-300) s = 1e-300;
-    term = log(s * inv_h) - lognorm0;
+    NBP_CTICK(22);
+    NBP_CTICK(23);
+  } else {
+    // combine: helper p folds the accumulator rows p, p+P, ... of point i (and clears them)
+    if (i < N) {
+      double s = part[p * Npad + i];
+      for (int q = p; q < NW; q += P) {
+        double *a = acc + q * 2 * N + i;
+        s += a[0] + a[N];
+        a[0] = 0.0;
+        a[N] = 0.0;
+      }
+      part[p * Npad + i] = s;
+    }
+    NBP_CTICK(22);  // combine
+    __syncthreads();
+    NBP_CTICK(23);  // barrier 2
+    if (p == 0 && i < N) {
+      double s = 0;
+      for (int q = 0; q < P; q++) {  // read-and-clear: the next evaluation accumulates into zeros
+        s += part[q * Npad + i];
+        part[q * Npad + i] = 0.0;
+      }
+      if (s < 1e-300) s = 1e-300;
+      term = log(s * inv_h) - lognorm0;
+    }
   }
   // only the first Npad lanes hold terms: reduce their waves
   term = wave_sum(term);
