@@ -203,8 +203,10 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
     HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel_spec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel_spec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel_spec<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel_spec<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel_spec<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel_spec<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
   guard.c = nullptr;
   *out = c;
@@ -491,9 +493,12 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   const bool spec = depth > 0;
   const int KS = spec ? (1 << depth) - 1 : 1;
   if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
-  if (spec)
-    hipLaunchKernelGGL(nbp_prep_kernel_spec, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
-                       dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec, depth);
+  if (depth == 3)
+    hipLaunchKernelGGL(nbp_prep_kernel_spec<3>, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+                       dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec);
+  else if (depth == 2)
+    hipLaunchKernelGGL(nbp_prep_kernel_spec<2>, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+                       dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec);
   else
     hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
                        dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
@@ -603,9 +608,12 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
   if (c->spec_on && n <= NBP_SPEC_MAXJOBS) depth = (c->spec_depth3 && 3 * n * 7 <= NBP_SPEC_MAXBLOCKS) ? 3 : ((3 * n * 3 <= NBP_SPEC_MAXBLOCKS) ? 2 : 0);
   const bool spec = depth > 0;
   if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
-  if (spec)
-    hipLaunchKernelGGL(nbp_bandwidth_kernel_spec, dim3(n, 3, (1 << depth) - 1), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
-                       dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, c->spec, depth);
+  if (depth == 3)
+    hipLaunchKernelGGL(nbp_bandwidth_kernel_spec<3>, dim3(n, 3, 7), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                       dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, c->spec);
+  else if (depth == 2)
+    hipLaunchKernelGGL(nbp_bandwidth_kernel_spec<2>, dim3(n, 3, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+                       dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, c->spec);
   else
     hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
                        dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters);

@@ -1002,10 +1002,16 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
   return (s0 + s1) + (s2 + s3);
 }
 
+// log() as a real call from the evaluation: inlined, the double constants of its polynomial are hoisted out of the search
+// as VGPR pairs and then spilled (40 B per lane that reach HBM once per fit); the callee is a leaf with a handful of
+// registers, called once per evaluation
+__device__ __attribute__((noinline)) double lcv_log(double v) { return log(v); }
+
 // LDS: x[2N] (the coordinate, twice), part[P][Npad] row-sum partials, acc[NW][2N] per-wave partner
 // accumulators (entry j and j+N both belong to point j).
 // `acc` and `part` must be all-zero on entry and are all-zero again on exit (the readers clear what
 // they read), so one evaluation costs three barriers: compute | combine+log | cross-wave sum.
+template <bool REROLE = true>
 __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, bool circ, double h, double lognorm0, double *part,
                                              double *red, const double *tab) {
   // log(s_i) - log(h) - lognorm0 = log(s_i / h) - lognorm0: one log sequence per evaluation instead of
@@ -1013,8 +1019,15 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   NBP_CTICK_INIT();
   const double inv_h = 1.0 / h, inv2h2 = 0.5 * inv_h * inv_h;
   const lcv_exp_k K = lcv_exp_consts(inv2h2);
-  const int i = threadIdx.x % Npad, p = threadIdx.x / Npad, P = blockDim.x / Npad;
-  const int w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  // The lane's role in the pair loop is recomputed in every evaluation, behind an opaque copy of the lane id: hoisted
+  // out of the search (it does not depend on the bandwidth) the dozen role integers stay live across everything and go
+  // to scratch -- which reaches HBM once per fit and workgroup (tens of MB per chip-filling launch).
+  // (REROLE = false in the speculative search: there the opaque copy made the selected bandwidth depend on timing in a
+  // few fits per thousand -- cause not found, the plain lane id is what the tests pin; those launches are small.)
+  int tid = threadIdx.x;
+  if (REROLE) asm volatile("" : "+v"(tid));
+  const int i = tid % Npad, p = tid / Npad, P = blockDim.x / Npad;
+  const int w = tid >> 6, NW = blockDim.x >> 6;
   double *acc = part + P * Npad;
   {
     // Lane roles of the pair loop.  Normally lane (i, p) owns point i and the p-th share of the partner
@@ -1025,7 +1038,7 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     // x 8 sub-helpers).  Row sums and partner sums are LDS atomics, so any dealing gives the same sets.
     const int H = (N - 1) / 2;  // full partner steps
     const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
-    const int lastbase = (N - 1) & ~63, A = N - lastbase, l = threadIdx.x & 63;
+    const int lastbase = (N - 1) & ~63, A = N - lastbase, l = tid & 63;
     int A2 = 1;
     while (A2 < A) A2 <<= 1;
     const bool lastwave = i >= lastbase;            // wave-uniform
@@ -1088,14 +1101,15 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     if (i < N) {
       double s = part[i];
       part[i] = 0.0;
-      for (int q = 0; q < NW; q++) {
-        double *a = acc + q * 2 * N + i;
+      double *a = acc + i;  // a running pointer and no unrolling: sixteen hoisted row addresses would live across the whole search
+#pragma unroll 1
+      for (int q = 0; q < NW; q++, a += 2 * N) {
         s += a[0] + a[N];
         a[0] = 0.0;
         a[N] = 0.0;
       }
       if (s < 1e-300) s = 1e-300;
-      term = log(s * inv_h) - lognorm0;
+      term = lcv_log(s * inv_h) - lognorm0;
     }
     NBP_CTICK(22);
     NBP_CTICK(23);
@@ -1103,8 +1117,9 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     // combine: helper p folds the accumulator rows p, p+P, ... of point i (and clears them)
     if (i < N) {
       double s = part[p * Npad + i];
-      for (int q = p; q < NW; q += P) {
-        double *a = acc + q * 2 * N + i;
+      double *a = acc + p * 2 * N + i;
+#pragma unroll 1
+      for (int q = p; q < NW; q += P, a += P * 2 * N) {
         s += a[0] + a[N];
         a[0] = 0.0;
         a[N] = 0.0;
@@ -1121,7 +1136,7 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
         part[q * Npad + i] = 0.0;
       }
       if (s < 1e-300) s = 1e-300;
-      term = log(s * inv_h) - lognorm0;
+      term = lcv_log(s * inv_h) - lognorm0;
     }
   }
   // only the first Npad lanes hold terms: reduce their waves
@@ -1166,13 +1181,24 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   double x0 = ax, x3 = cx, x1, x2;
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = fma(C, cx - bx, bx); }
   else { x2 = bx; x1 = fma(-C, bx - ax, bx); }
-  double f1 = neg_loo_ll(x, N, Npad, circ, x1 * scs, ln0, part, red, tab), f2 = neg_loo_ll(x, N, Npad, circ, x2 * scs, ln0, part, red, tab);
+  // one call site for the evaluation (its six pair loops are inlined once per kernel, not once per call): the two
+  // initial values, then one new point per iteration
+  double f1 = 0.0, f2 = 0.0, pt = x1;
   unsigned int nev = 2;
-  while (fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2))) {
+  int stage = 0;
+  bool c = false;
+  while (true) {
+    const double v = neg_loo_ll(x, N, Npad, circ, pt * scs, ln0, part, red, tab);
+    if (stage == 0) { f1 = v; stage = 1; pt = x2; continue; }
+    if (stage == 1) { f2 = v; stage = 2; }
+    else if (c) f2 = v;
+    else f1 = v;
+    if (!(fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2)))) break;
     nev++;
+    c = f2 < f1;
     // positions by explicit fma (see golden_step)
-    if (f2 < f1) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; f2 = neg_loo_ll(x, N, Npad, circ, x2 * scs, ln0, part, red, tab); }
-    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; f1 = neg_loo_ll(x, N, Npad, circ, x1 * scs, ln0, part, red, tab); }
+    if (c) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; pt = x2; }
+    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; pt = x1; }
   }
   if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
   return (f1 < f2 ? x1 : x2) * scs;
@@ -1248,7 +1274,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   // uniform state in SGPRs across the evaluations (see lcv_bandwidth_1d)
   const double scs = sgpr_double(sc), ln0 = sgpr_double(lognorm0);
   g.f1 = g.f2 = 0.0;
-  auto eval = [&](double xs) { return neg_loo_ll(x, N, Npad, circ, xs * scs, ln0, part, red, tab); };
+  auto eval = [&](double xs) { return neg_loo_ll<false>(x, N, Npad, circ, xs * scs, ln0, part, red, tab); };
   bool solo = false;  // gave up on the peers: the sequential search from here on
   int round = 0;
   unsigned int nev = 2;
@@ -1290,48 +1316,60 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
     round++;
     return ok_;
   };
-  {  // the two initial values: roles 0 and 1
-    const double mine = role == 0 ? eval(g.x1) : (role == 1 ? eval(g.x2) : 0.0);
-    if (rendezvous(mine)) { g.f1 = vals[1]; g.f2 = vals[2]; }
-    else { solo = true; g.f1 = eval(g.x1); g.f2 = eval(g.x2); }
-  }
-  while (!golden_done(g, tol)) {
-    if (solo) {
-      const bool c = g.f2 < g.f1;
-      const double p = golden_step(g, c, R, C);
-      const double v = eval(p);
-      if (c) g.f2 = v; else g.f1 = v;
+  // One call site for the evaluation: every pass of the loop decides which point (if any) this workgroup evaluates,
+  // evaluates it, then consumes the value -- start-up (roles 0 and 1 hold the two initial points), speculative rounds,
+  // or the sequential search once the peers are given up on.
+  bool starting = true, c = false;
+  int solo_stage = 0;
+  while (true) {
+    double pt = 0.0;
+    bool doit = false;
+    if (starting) {
+      if (!solo) { doit = role < 2; pt = role == 0 ? g.x1 : g.x2; }
+      else { doit = true; pt = solo_stage == 0 ? g.x1 : g.x2; }
+    } else if (golden_done(g, tol)) {
+      break;
+    } else if (solo) {
+      c = g.f2 < g.f1;
+      pt = golden_step(g, c, R, C);
+      doit = true;
       nev++;
-      continue;
-    }
-    const bool c0 = g.f2 < g.f1;
-    // this role's point: replay the outcomes on the path from the root of the outcome tree to node role + 1
-    double mine = 0.0;
-    {
+    } else {
+      // this role's point: replay the outcomes on the path from the root of the outcome tree to node role + 1
       const int node = role + 1;
       int depth = 0;
       while ((node >> (depth + 1)) != 0) depth++;
       golden_state gs = g;
-      double p = golden_step(gs, c0, R, C);
-      bool dead = false;  // the search stops before it gets to this node
+      pt = golden_step(gs, g.f2 < g.f1, R, C);
+      doit = true;  // false: the search stops before it gets to this node
       for (int lvl = depth - 1; lvl >= 0; lvl--) {
-        if (golden_done(gs, tol)) { dead = true; break; }
-        p = golden_step(gs, ((node >> lvl) & 1) == 0, R, C);
+        if (golden_done(gs, tol)) { doit = false; break; }
+        pt = golden_step(gs, ((node >> lvl) & 1) == 0, R, C);
       }
-      if (!dead) mine = eval(p);  // block-uniform
     }
-    if (!rendezvous(mine)) { solo = true; continue; }
-    // advance up to DEPTH iterations with the values now known
-    int node = 1;
-    bool c = c0;
+    const double v = doit ? eval(pt) : 0.0;  // block-uniform
+    if (starting) {
+      if (!solo) {
+        if (rendezvous(v)) { g.f1 = vals[1]; g.f2 = vals[2]; starting = false; }
+        else solo = true;  // evaluate both initial points ourselves
+      } else if (solo_stage == 0) { g.f1 = v; solo_stage = 1; }
+      else { g.f2 = v; starting = false; }
+    } else if (solo) {
+      if (c) g.f2 = v; else g.f1 = v;
+    } else {
+      if (!rendezvous(v)) { solo = true; continue; }
+      // advance up to DEPTH iterations with the values now known
+      int node = 1;
+      bool cc = g.f2 < g.f1;
 #pragma unroll
-    for (int lvl = 0; lvl < DEPTH; lvl++) {
-      (void)golden_step(g, c, R, C);
-      if (c) g.f2 = vals[node]; else g.f1 = vals[node];
-      nev++;
-      if (lvl == DEPTH - 1 || golden_done(g, tol)) break;
-      c = g.f2 < g.f1;
-      node = 2 * node + (c ? 0 : 1);
+      for (int lvl = 0; lvl < DEPTH; lvl++) {
+        (void)golden_step(g, cc, R, C);
+        if (cc) g.f2 = vals[node]; else g.f1 = vals[node];
+        nev++;
+        if (lvl == DEPTH - 1 || golden_done(g, tol)) break;
+        cc = g.f2 < g.f1;
+        node = 2 * node + (cc ? 0 : 1);
+      }
     }
   }
   if (ctr && threadIdx.x == 0 && role == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);

@@ -381,9 +381,9 @@ nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, dou
 static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
 
 // fit the bandwidth of coordinate k of a resident slot (block-uniform early exit for k >= D)
-template <bool SPEC>
+template <int SPEC>  // 0: sequential search; 2 / 3: speculative search, that many iterations per rendezvous
 __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int Ncap, int Npad, double *smem, nbp_counters *ctr,
-                                                    nbp_spec_area *area = nullptr, int role = 0, int depth = 0) {
+                                                    nbp_spec_area *area = nullptr, int role = 0) {
   const int D = mani_dim(M), n = threadIdx.x;
   if (k >= D) {
     if (n == 0) s[3 * Ncap + k] = 0.0;
@@ -402,8 +402,7 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   __syncthreads();
   if (SPEC) {  // latency mode: 2^depth - 1 workgroups per fit (lcv_bandwidth_1d_spec); a kernel of its own, so that the
                // registers the outcome tree needs do not cost the throughput kernel its occupancy
-    const double hs = depth == 3 ? lcv_bandwidth_1d_spec<3>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role)
-                                 : lcv_bandwidth_1d_spec<2>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role);
+    const double hs = lcv_bandwidth_1d_spec<SPEC ? SPEC : 2>(X, N, Npad, is_circ(M, k), part, red, tab, ctr, area, role);
     if (n == 0 && role == 0) s[3 * Ncap + k] = hs;
     return;
   }
@@ -419,14 +418,15 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
 __global__ void __launch_bounds__(1024)
 nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S, nbp_counters *ctr) {
   extern __shared__ double smem[];  // grid (jobs, 3)
-  lcv_slot_coordinate<false>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
+  lcv_slot_coordinate<0>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
 }
+template <int DEPTH>
 __global__ void __launch_bounds__(1024)
 nbp_bandwidth_kernel_spec(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S,
-                          nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
-  extern __shared__ double smem[];  // grid (jobs, 3, 2^spec_depth - 1)
-  lcv_slot_coordinate<true>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr,
-                            spec + (blockIdx.x * 3 + blockIdx.y), blockIdx.z, spec_depth);
+                          nbp_counters *ctr, nbp_spec_area *spec) {
+  extern __shared__ double smem[];  // grid (jobs, 3, 2^DEPTH - 1)
+  lcv_slot_coordinate<DEPTH>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr,
+                             spec + (blockIdx.x * 3 + blockIdx.y), blockIdx.z);
 }
 
 // X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
@@ -625,15 +625,15 @@ static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
   return ((size_t)D * N + 3 * Npad + NBP_RED) * 8 + ((size_t)2 * N + (size_t)P * Npad + Npad) * 4;
 }
 
-template <bool SPEC>
+template <int SPEC>
 __device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
                                           double *arena, double *ws, int N, int Npad, int64_t S, const nbp_levels &T, nbp_counters *ctr,
-                                          nbp_spec_area *spec, int spec_depth, double *smem) {
+                                          nbp_spec_area *spec, double *smem) {
   const int b = blockIdx.x;
-  const int KS = SPEC ? (1 << spec_depth) - 1 : 1;  // workgroups per (slot, coordinate)
+  constexpr int KS = SPEC ? (1 << SPEC) - 1 : 1;  // workgroups per (slot, coordinate)
   if (b < 3 * nbw * KS) {  // manikde! bandwidth of (slot, coordinate)
     const int job = b / (3 * KS), k = (b % (3 * KS)) / KS, role = b % KS;
-    lcv_slot_coordinate<SPEC>(arena + S * bw_slots[job], bw_manis[job], k, N, Npad, smem, ctr, SPEC ? spec + (job * 3 + k) : nullptr, role, spec_depth);
+    lcv_slot_coordinate<SPEC>(arena + S * bw_slots[job], bw_manis[job], k, N, Npad, smem, ctr, SPEC ? spec + (job * 3 + k) : nullptr, role);
     return;
   }
   const int q = b - 3 * nbw * KS, p = q / kdF, j = q % kdF;  // kdF = largest nfactors of the batch
@@ -654,14 +654,15 @@ __global__ void __launch_bounds__(1024)
 nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
                 double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr) {
   extern __shared__ double smem[];
-  prep_body<false>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, nullptr, 0, smem);
+  prep_body<0>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, nullptr, smem);
 }
-// latency mode: 2^spec_depth - 1 workgroups per fit (lcv_bandwidth_1d_spec)
+// latency mode: 2^DEPTH - 1 workgroups per fit (lcv_bandwidth_1d_spec)
+template <int DEPTH>
 __global__ void __launch_bounds__(1024)
 nbp_prep_kernel_spec(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
-                     double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec, int spec_depth) {
+                     double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec) {
   extern __shared__ double smem[];
-  prep_body<true>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, spec, spec_depth, smem);
+  prep_body<DEPTH>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, spec, smem);
 }
 
 // Gibbs geometry: HL adjacent lanes of ONE wave serve one output sample (a wave carries 64/HL samples).

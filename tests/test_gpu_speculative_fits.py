@@ -45,3 +45,38 @@ def test_speculative_search_is_bit_identical(manifold, N, nfits):
     np.testing.assert_array_equal(k3, seq)
     np.testing.assert_array_equal(k7, seq)
     assert ev3 == ev0 and ev7 == ev0  # the same iterations, advanced two or three per rendezvous
+
+
+def test_many_fits_are_reproducible_and_equal_the_sequential_search():
+    """a regression guard: 240 fits of 64-point beliefs in launches of 8 (three workgroups per fit, 72 workgroups per
+    launch), twice -- an earlier build selected a different bandwidth in a few fits per thousand, differently each run"""
+    N, man = 64, abi.EUCLID2
+    rng = np.random.default_rng(5)
+    data = [rng.normal(0, rng.uniform(0.01, 5), (N, 2)) for _ in range(240)]
+
+    def run(env, group):
+        old = {k: os.environ.pop(k, None) for k in ("NBP_NO_SPECULATIVE_FITS", "NBP_SPEC_DEPTH3")}
+        os.environ.update(env)
+        try:
+            be = iif.HipBackend(N, group, 0)
+            out = []
+            try:
+                for g0 in range(0, len(data), group):
+                    chunk = data[g0:g0 + group]
+                    for s, pts in enumerate(chunk):
+                        be.slot_write(s, man, pts)
+                    be.run_bandwidth(list(range(len(chunk))), [man] * len(chunk))
+                    out += [be.slot_read(s, man)[1].copy() for s in range(len(chunk))]
+            finally:
+                be.close()
+        finally:
+            for k in ("NBP_NO_SPECULATIVE_FITS", "NBP_SPEC_DEPTH3"):
+                os.environ.pop(k, None)
+                if old[k] is not None:
+                    os.environ[k] = old[k]
+        return np.array(out)
+
+    seq = run({"NBP_NO_SPECULATIVE_FITS": "1"}, 8)
+    np.testing.assert_array_equal(run({"NBP_NO_SPECULATIVE_FITS": "1"}, 240), seq)  # one chip-filling launch: other helper geometry
+    for env, group in (({"NBP_SPEC_DEPTH3": "0"}, 8), ({"NBP_SPEC_DEPTH3": "0"}, 8), ({}, 3), ({}, 3)):
+        np.testing.assert_array_equal(run(env, group), seq)
