@@ -703,7 +703,10 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
 // density enters the conditionals and the final draw on its own coordinates only; a coordinate that
 // no density informs keeps the old point (GraphProductOperations.jl:39-45).  Separate instantiation so
 // that the all-full path carries no masks.
-template <int MANI, bool PARTIAL, int HL>
+// BIG: the node statistics live in this workgroup's scratch in global memory (products with many densities; only the
+// latency geometries HL = 16 / 8 run them).  A compile-time switch: with a run-time one every access to the statistics
+// goes through a generic 64-bit pointer -- flat loads in the Gibbs loop and register pairs for what is an LDS offset.
+template <int MANI, bool PARTIAL, int HL, bool BIG>
 __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int kdF, double *gstats,
                                              int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
@@ -713,7 +716,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   const int sl = tid / HL, h = tid % HL;   // sample (local), helper index
   const int s = blockIdx.y * SPB + sl;
   const bool live = s < N;
-  const bool big = gstats != nullptr;
+  constexpr bool big = BIG;
   product_lds L;
   product_lds_layout(F, D, N, SPB, big, smem, &L);
   double *cen = L.cen, *h2 = L.h2;
@@ -1017,6 +1020,11 @@ __device__ __forceinline__ void product_write_ipc(const nbp_product_desc *d, dou
 }
 
 
+#define NBP_PRODUCT_BODY(M_, P_)                                                                              \
+  do {                                                                                                        \
+    if (HL >= 8 && gstats) product_body<M_, P_, HL, (HL >= 8)>(d, arena, ws, kdF, gstats, N, S, side, T, smem); \
+    else product_body<M_, P_, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);                     \
+  } while (0)
 template <int HL>
 __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
                                                     double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
@@ -1027,18 +1035,18 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
   for (int j = 0; j < d->nfactors; j++) partial |= (d->in_partial[j] != 0);
   if (partial) {  // validated on the host: D >= 2
     switch (d->manifold) {
-    case NBP_EUCLID2: product_body<NBP_EUCLID2, true, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
-    case NBP_EUCLID3: product_body<NBP_EUCLID3, true, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
-    default: product_body<NBP_SE2, true, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+    case NBP_EUCLID2: NBP_PRODUCT_BODY(NBP_EUCLID2, true); break;
+    case NBP_EUCLID3: NBP_PRODUCT_BODY(NBP_EUCLID3, true); break;
+    default: NBP_PRODUCT_BODY(NBP_SE2, true); break;
     }
     return;
   }
   switch (d->manifold) {
-  case NBP_EUCLID1: product_body<NBP_EUCLID1, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
-  case NBP_EUCLID2: product_body<NBP_EUCLID2, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
-  case NBP_EUCLID3: product_body<NBP_EUCLID3, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
-  case NBP_CIRCULAR: product_body<NBP_CIRCULAR, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
-  default: product_body<NBP_SE2, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem); break;
+  case NBP_EUCLID1: NBP_PRODUCT_BODY(NBP_EUCLID1, false); break;
+  case NBP_EUCLID2: NBP_PRODUCT_BODY(NBP_EUCLID2, false); break;
+  case NBP_EUCLID3: NBP_PRODUCT_BODY(NBP_EUCLID3, false); break;
+  case NBP_CIRCULAR: NBP_PRODUCT_BODY(NBP_CIRCULAR, false); break;
+  default: NBP_PRODUCT_BODY(NBP_SE2, false); break;
   }
 }
 
@@ -1052,7 +1060,7 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
   const nbp_product_desc *d = descs + blockIdx.x;
   if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
   product_write_ipc(d, arena, N, S);
-  product_body<MANI, false, HL>(d, arena, ws, kdF, gstats, N, S, side, T, smem);
+  product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);  // HL = 4 / 2: never BIG (launch_products)
 }
 
 // Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in

@@ -5,7 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from rocpd import counter_rows
+from rocpd import counter_rows, short_name
 
 
 def main(root, prefix="nbp_"):
@@ -16,7 +16,7 @@ def main(root, prefix="nbp_"):
         if not os.path.isdir(d):
             continue
         for r in counter_rows(d):
-            k = r["Kernel_Name"].split("(")[0]
+            k = short_name(r["Kernel_Name"])
             if k.startswith(prefix):
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 n[k][r["Counter_Name"]] += 1

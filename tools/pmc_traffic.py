@@ -9,13 +9,17 @@ import csv
 import glob
 import gzip
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocpd import short_name  # noqa: E402
 
 
 def load(d):
     import os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from rocpd import counter_rows
+    from rocpd import counter_rows, short_name
     return counter_rows(d)
 
 
@@ -29,7 +33,7 @@ def per_kernel(rows, counter, steps, lps=60):
     for r in rows:
         if int(r["Dispatch_Id"]) < d0 and not r["Kernel_Name"].startswith("nbp_copy_kernel"):
             continue
-        name = r["Kernel_Name"].split("(")[0]
+        name = short_name(r["Kernel_Name"])
         if name.startswith("nbp_"):
             by[name].append((float(r["Counter_Value"]), int(r["Grid_Size"]) // int(r["Workgroup_Size"])))
     out = {}

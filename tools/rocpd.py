@@ -37,3 +37,9 @@ def counter_rows(path):
     q = "select dispatch_id, kernel_name, counter_name, value, grid_size, workgroup_size from counters_collection order by dispatch_id"
     return [{"Dispatch_Id": r[0], "Kernel_Name": r[1], "Counter_Name": r[2], "Counter_Value": r[3], "Grid_Size": r[4], "Workgroup_Size": r[5]}
             for r in c.execute(q)]
+
+
+def short_name(kernel_name):
+    """`void nbp_prep_kernel_spec<3>(int const*, ...)` -> `nbp_prep_kernel_spec<3>`"""
+    n = kernel_name.split("(")[0].strip()
+    return n[5:] if n.startswith("void ") else n

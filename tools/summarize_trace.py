@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main(path, steps, lps=60):
-    from rocpd import kernel_rows
+    from rocpd import kernel_rows, short_name
     rows = kernel_rows(path)
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # every step of bench.py starts with one nbp_reseed_kernel launch: the timed region begins at the `steps`-th from last
@@ -23,7 +23,7 @@ def main(path, steps, lps=60):
     rows = region
     by = collections.defaultdict(list)
     for r in rows:
-        name = r["Kernel_Name"].split("(")[0]
+        name = short_name(r["Kernel_Name"])
         if name.startswith("nbp_product_kernel"):
             name = "nbp_product_kernel(x16|l8|m4|t2)"  # one launch per stage, three geometries
         if name.startswith("nbp_"):
