@@ -1085,7 +1085,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) n
 // waves per SIMD of the single-manifold kernels, measured (profiles/r02_product_waves.txt): Euclid(1/2) are faster at 4
 // (Euclid(2) then spills 76 B per lane; at 3 it is spill-free but 16 % slower on the 10 000-variable chain), Euclid(3),
 // Circular and SE(2) at 3 (140-168 VGPRs: no scratch on Euclid(3), 36 / 120 B on the circular ones; 1-3 % faster)
-#define NBP_PRODUCT_UNIFORM(NAME, MANI, HL) NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, ((MANI) <= NBP_EUCLID2 ? 4 : 3))
+#ifndef NBP_W_E2
+#define NBP_W_E2 4
+#endif
+#ifndef NBP_W_SE
+#define NBP_W_SE 2
+#endif
+#define NBP_PRODUCT_UNIFORM(NAME, MANI, HL) NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, ((MANI) == NBP_EUCLID1 ? 4 : (MANI) == NBP_EUCLID2 ? NBP_W_E2 : (MANI) == NBP_SE2 ? NBP_W_SE : 3))
 #define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES)                                                                        \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME(NBP_PRODUCT_ARGS) { \
     extern __shared__ double smem[];                                                                               \
