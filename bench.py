@@ -107,6 +107,10 @@ def main():
     dist = None
     if world > 1 or a.force_dist:
         import torch.distributed as dist
+        if "RANK" not in os.environ:  # --force-dist outside a launcher: a world of one on the loopback
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
