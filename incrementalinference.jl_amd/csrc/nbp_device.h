@@ -890,16 +890,19 @@ struct lcv_exp_k {
 // pair loop would cost sixteen VGPRs.
 __device__ __forceinline__ double sgpr_double(double v) {
   int lo, hi;
-  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
-  asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(hi) : "v"(__double2hiint(v)));  // the assembler's hazard checks do not see inside
+  // wait states on both sides: the compiler's hazard recognizer does not look inside inline asm, so neither the VALU
+  // instruction that has just written the source VGPR nor the one that is about to read the SGPR gets its distance
+  asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(lo) : "v"(__double2loint(v)));
+  asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(hi) : "v"(__double2hiint(v)));
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c) {
+__device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c, double h) {  // c = 1/(2 h^2): 1/c = 2 h^2 without a division
   lcv_exp_k K;
+  const double rc = 2.0 * h * h;
   K.A = sgpr_double(-c * 92.33248261689366);       // 64/ln2
   K.negM = -6755399441055744.0;
-  K.B = sgpr_double(0.010830424696249145 / c);     // ln2/64
-  K.qmax = sgpr_double(700.0 / c);                  // exp(-700) = 1e-304 is as good as 0 for every sum it enters
+  K.B = sgpr_double(0.010830424696249145 * rc);    // ln2/64
+  K.qmax = sgpr_double(700.0 * rc);                 // exp(-700) = 1e-304 is as good as 0 for every sum it enters
   const double m = -c;
   K.a1 = sgpr_double(m);
   K.a2 = sgpr_double(m * m * 0.5);
@@ -1018,15 +1021,16 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   // three (every lane of a wave pays for a log whether one lane needs it or all of them do)
   NBP_CTICK_INIT();
   const double inv_h = 1.0 / h, inv2h2 = 0.5 * inv_h * inv_h;
-  const lcv_exp_k K = lcv_exp_consts(inv2h2);
+  const lcv_exp_k K = lcv_exp_consts(inv2h2, h);
   // The lane's role in the pair loop is recomputed in every evaluation, behind an opaque copy of the lane id: hoisted
   // out of the search (it does not depend on the bandwidth) the dozen role integers stay live across everything and go
   // to scratch -- which reaches HBM once per fit and workgroup (tens of MB per chip-filling launch).
-  // (REROLE = false in the speculative search: there the opaque copy made the selected bandwidth depend on timing in a
-  // few fits per thousand -- cause not found, the plain lane id is what the tests pin; those launches are small.)
+  // (REROLE = false in the speculative search: its launches are small, the spill does not matter there.)
   int tid = threadIdx.x;
   if (REROLE) asm volatile("" : "+v"(tid));
-  const int i = tid % Npad, p = tid / Npad, P = blockDim.x / Npad;
+  // throughput mode has one helper row (workgroup = Npad lanes): no divisions by run-time values for the lane's place
+  const int P = ((int)blockDim.x == Npad) ? 1 : (int)blockDim.x / Npad;
+  const int p = (P == 1) ? 0 : tid / Npad, i = (P == 1) ? tid : tid - p * Npad;
   const int w = tid >> 6, NW = blockDim.x >> 6;
   double *acc = part + P * Npad;
   {
@@ -1037,20 +1041,20 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     // 1/HH of the steps instead of idling most of its lanes through all of them (N = 200: 8 points
     // x 8 sub-helpers).  Row sums and partner sums are LDS atomics, so any dealing gives the same sets.
     const int H = (N - 1) / 2;  // full partner steps
-    const int t0 = 1 + (p * H) / P, t1 = 1 + ((p + 1) * H) / P;
+    const int t0 = (P == 1) ? 1 : 1 + (p * H) / P, t1 = (P == 1) ? 1 + H : 1 + ((p + 1) * H) / P;
     const int lastbase = (N - 1) & ~63, A = N - lastbase, l = tid & 63;
-    int A2 = 1;
-    while (A2 < A) A2 <<= 1;
+    int A2 = 1, lg2 = 0;  // powers of two: every division by A2 or HH below is a shift
+    while (A2 < A) { A2 <<= 1; lg2++; }
     const bool lastwave = i >= lastbase;            // wave-uniform
     const bool redeal = lastwave && A2 <= 32;
-    const int HH = redeal ? 64 / A2 : 1;
+    const int lgH = redeal ? 6 - lg2 : 0, HH = 1 << lgH;
     const int len = t1 - t0;
     // Balance between the waves of a row: after its own points (len / HH steps when re-dealt) the last wave takes the
     // tail steps [t0 + Lw, t1) of every full wave's points, so that all waves of the row leave the pair loop together
     // (N = 200, P = 1: 78 steps in the full waves, 13 + 3 x 21 in the last one, instead of 99 and 13).  A row sum then
     // has two contributors -- its owner and the last wave -- each with ONE atomic add into a slot that starts at zero:
     // a + b = b + a, so the sums do not depend on which comes first.
-    const int nfull = lastbase >> 6, own_ws = (A2 <= 32) ? (len + 64 / A2 - 1) / (64 / A2) : len;
+    const int nfull = lastbase >> 6, own_ws = (A2 <= 32) ? (len + (64 >> lg2) - 1) >> (6 - lg2) : len;
     int Lw = len;
     if (A < 64 && nfull > 0) Lw = min(len, (own_ws + nfull * len + nfull) / (nfull + 1));
     const int hand = len - Lw;
@@ -1062,8 +1066,8 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
                             : loo_symmetric<false>(x, i, t0, n4, nt, false, xi, K, accw, tab);
       lds_add((nbp_lds_double *)(part + p * Npad + i), s);
     } else {
-      const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l / A2 : 0;
-      const int lenmin = len / HH, rem = len - lenmin * HH;
+      const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l >> lg2 : 0;
+      const int lenmin = len >> lgH, rem = len - (lenmin << lgH);
       const int ta = t0 + hh * lenmin + min(hh, rem);
       const int n4 = __builtin_amdgcn_readfirstlane(lenmin >> 2), nt = __builtin_amdgcn_readfirstlane(lenmin & 3);
       if (pi < N) {
