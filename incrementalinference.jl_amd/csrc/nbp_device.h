@@ -274,6 +274,41 @@ __device__ __forceinline__ double block_max(double v, double *red) {
   return t;
 }
 
+// a double through one DPP pattern (lanes without a source, or masked out, receive 0)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over a wave64 in lane order, the DPP way: three row shifts of the input, shifts by 4 and 8 of the
+// partial sums inside each row of 16, then the row totals broadcast to the rows behind (row_bcast:15 / :31)
+__device__ __forceinline__ double wave_inclusive_scan(double x) {
+  double s = x + dpp_f64<0x111, 0xf, 0xf>(x);   // row_shr:1
+  s += dpp_f64<0x112, 0xf, 0xf>(x);             // row_shr:2
+  s += dpp_f64<0x113, 0xf, 0xf>(x);             // row_shr:3
+  s += dpp_f64<0x114, 0xf, 0xe>(s);             // row_shr:4, lanes 4..15 of every row
+  s += dpp_f64<0x118, 0xf, 0xc>(s);             // row_shr:8, lanes 8..15
+  s += dpp_f64<0x142, 0xa, 0xf>(s);             // row_bcast:15 into rows 1 and 3
+  s += dpp_f64<0x143, 0xc, 0xf>(s);             // row_bcast:31 into rows 2 and 3
+  return s;
+}
+// exclusive prefix sum over the workgroup in lane order (wave scans, wave totals through `red`); *total = the sum
+__device__ __forceinline__ double block_exclusive_scan(double v, double *red, double *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const double inc = wave_inclusive_scan(v);
+  __syncthreads();
+  if (lane == 63) red[w] = inc;
+  __syncthreads();
+  double off = 0, tot = 0;
+  for (int q = 0; q < nw; q++) {
+    if (q < w) off += red[q];
+    tot += red[q];
+  }
+  *total = tot;
+  return off + inc - v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // statistics: mean(M, pts, GeodesicInterpolation()) and calcStdBasicSpread
 // (services/VariableStatistics.jl:22-36).  x = LDS or global SoA [d*stride + n].
@@ -311,6 +346,58 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
         const double mo = block_sum(di, red) / (double)N;
         return wrap_pi(x0 + mo);
       }
+    }
+    // Spread around the circle: the running mean m_i = m_{i-1} + wrap(x_i - m_{i-1}) / (i + 1) is the running ARITHMETIC mean
+    // of the lifted points X_i = x_i + 2 pi k_i, where k_i puts X_i within pi of m_{i-1}.  The lifts depend on the
+    // trajectory, the trajectory is a prefix mean of the lifts: iterate (prefix sums -> lifts) to the fixed point, which
+    // by induction on i is the sequential walk's own assignment (every sweep fixes at least one more leading lift; on
+    // beliefs spread over the circle 5-15 sweeps of a workgroup-wide scan instead of N dependent steps; equal to the walk
+    // up to the rounding of the sums).  A belief that needs more sweeps is walked as before.
+    {
+      // One barrier per sweep: the wave totals and the "a lift changed in the previous sweep" flags go through
+      // alternating halves of `red`, and the loop ends one sweep after the last change (that sweep's sums are the final ones).
+      const int i = threadIdx.x, lane = i & 63, w = i >> 6, nw = (blockDim.x + 63) >> 6;
+      const double xi = (i < N) ? x[i] : 0.0;
+      double ki = 0.0, tot = 0.0;
+      bool changed = true, fixed = false;  // `changed`: this lane's lift moved in the previous sweep
+      if (i < 64) {
+        // the head of the trajectory, where the weights 1/(i+1) are large and the lifts take most sweeps to settle, is
+        // iterated by wave 0 alone: no barriers, no LDS -- the workgroup-wide sweeps below then start from a settled head
+        for (int sweep = 0; sweep < 24; sweep++) {
+          const double Xi = (i < N) ? fma(NBP_TWO_PI, ki, xi) : 0.0;
+          const double before = wave_inclusive_scan(Xi) - Xi;
+          double kn = ki;
+          if (i >= 1 && i < N) kn = ki + rint((before / (double)i - Xi) * (1.0 / NBP_TWO_PI));
+          const bool moved = __builtin_amdgcn_ballot_w64(kn != ki) != 0;
+          ki = kn;
+          if (!moved) break;
+        }
+      }
+      __syncthreads();                      // the reductions above are done with `red`
+      for (int sweep = 0; sweep < 32; sweep++) {
+        double *buf = red + (sweep & 1) * 32;
+        const double Xi = (i < N) ? fma(NBP_TWO_PI, ki, xi) : 0.0;
+        const double inc = wave_inclusive_scan(Xi);
+        const bool wave_changed = __builtin_amdgcn_ballot_w64(changed) != 0;
+        if (lane == 63) buf[w] = inc;
+        if (lane == 0) buf[16 + w] = wave_changed ? 1.0 : 0.0;
+        __syncthreads();
+        double off = 0.0, any = 0.0;
+        tot = 0.0;
+        for (int q = 0; q < nw; q++) {
+          if (q < w) off += buf[q];
+          tot += buf[q];
+          any += buf[16 + q];
+        }
+        if (sweep > 0 && any == 0.0) { fixed = true; break; }  // nothing moved last time: these are the sums of the fixed point
+        const double before = off + inc - Xi;
+        double kn = ki;
+        if (i >= 1 && i < N) kn = ki + rint((before / (double)i - Xi) * (1.0 / NBP_TWO_PI));
+        changed = kn != ki;
+        ki = kn;
+      }
+      __syncthreads();  // `red` is free again
+      if (fixed) return wrap_pi(tot / (double)N);
     }
     __syncthreads();
     if (threadIdx.x < 64) {

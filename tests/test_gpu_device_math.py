@@ -32,3 +32,30 @@ def test_se2_reverse_root_over_the_whole_circle(hip_backend):
         err = got - want
         err[:, 2] = ac.wrap(err[:, 2])
         assert np.abs(err).max() < 5e-3 and np.sqrt((err ** 2).mean()) < 5e-4, (z, np.abs(err).max())
+
+
+@pytest.mark.parametrize("N", [37, 100, 200, 256, 300])
+@pytest.mark.parametrize("shape", ["uniform", "doors", "near_pi", "one_mode"])
+def test_geodesic_mean_of_beliefs_spread_over_the_circle(hip_backend, oracle_backend, N, shape):
+    """calcStdBasicSpread of a circular belief: the oracle walks the running geodesic mean point by point (what
+    Manifolds.jl does); the kernel iterates lifts and prefix means to the same trajectory.  Observable: a prior proposal
+    with nullhypo -- the null particles get entropy scaled by spreadNH * that spread (EvalFactor.jl:464-476)"""
+    rng = np.random.default_rng(N)
+    x = {"uniform": rng.uniform(-np.pi, np.pi, N),
+         "doors": rng.choice([-2.5, -0.8, 0.9, 2.6], N) + rng.normal(0, 0.1, N),
+         "near_pi": rng.normal(3.1, 0.4, N),
+         "one_mode": rng.normal(0.4, 0.3, N)}[shape]
+    x = ((x + np.pi) % (2 * np.pi) - np.pi).reshape(N, 1)
+    out = []
+    for fac in (hip_backend, oracle_backend):
+        be = fac(N, 2)
+        try:
+            be.slot_write(0, abi.CIRCULAR, x, np.ones(1))
+            d = relative_factor_desc(abi.F_PRIOR, abi.CIRCULAR, 1, 0, [0], 1, 321, [0.3], [0.05], nullhypo=0.5)
+            d.skip_bandwidth = 1
+            be.run_proposals([d])
+            out.append(be.slot_read(1, abi.CIRCULAR)[0])
+        finally:
+            be.close()
+    d = (out[0] - out[1] + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() < 1e-9
