@@ -316,6 +316,61 @@ __device__ __forceinline__ double block_exclusive_scan(double v, double *red, do
 // rounding).  Circular coordinates: the running geodesic interpolation is order dependent, so lane
 // 0 walks it sequentially exactly like Manifolds.jl does.
 // ------------------------------------------------------------------------------------------------
+// Spread around the circle: the running mean m_i = m_{i-1} + wrap(x_i - m_{i-1}) / (i + 1) is the running ARITHMETIC mean
+// of the lifted points X_i = x_i + 2 pi k_i, where k_i puts X_i within pi of m_{i-1}.  The lifts depend on the
+// trajectory, the trajectory is a prefix mean of the lifts: iterate (prefix sums -> lifts) to the fixed point, which
+// by induction on i is the sequential walk's own assignment (every sweep fixes at least one more leading lift; on
+// beliefs spread over the circle 5-15 sweeps of a workgroup-wide scan instead of N dependent steps; equal to the walk
+// up to the rounding of the sums).  A belief that needs more sweeps is walked as before.
+// A real call: inlined into the proposal kernel the sweeps cost that kernel 13 VGPRs and 48 B of scratch per lane.
+__device__ __attribute__((noinline)) bool mean_geodesic_lifts(const double *x, int N, double *red, double *mean_out) {
+  // One barrier per sweep: the wave totals and the "a lift changed in the previous sweep" flags go through
+  // alternating halves of `red`, and the loop ends one sweep after the last change (that sweep's sums are the final ones).
+  const int i = threadIdx.x, lane = i & 63, w = i >> 6, nw = (blockDim.x + 63) >> 6;
+  const double xi = (i < N) ? x[i] : 0.0;
+  double ki = 0.0, tot = 0.0;
+  bool changed = true, fixed = false;  // `changed`: this lane's lift moved in the previous sweep
+  if (i < 64) {
+    // the head of the trajectory, where the weights 1/(i+1) are large and the lifts take most sweeps to settle, is
+    // iterated by wave 0 alone: no barriers, no LDS -- the workgroup-wide sweeps below then start from a settled head
+    for (int sweep = 0; sweep < 24; sweep++) {
+      const double Xi = (i < N) ? fma(NBP_TWO_PI, ki, xi) : 0.0;
+      const double before = wave_inclusive_scan(Xi) - Xi;
+      double kn = ki;
+      if (i >= 1 && i < N) kn = ki + rint((before / (double)i - Xi) * (1.0 / NBP_TWO_PI));
+      const bool moved = __builtin_amdgcn_ballot_w64(kn != ki) != 0;
+      ki = kn;
+      if (!moved) break;
+    }
+  }
+  __syncthreads();                      // the reductions above are done with `red`
+  for (int sweep = 0; sweep < 32; sweep++) {
+    double *buf = red + (sweep & 1) * 32;
+    const double Xi = (i < N) ? fma(NBP_TWO_PI, ki, xi) : 0.0;
+    const double inc = wave_inclusive_scan(Xi);
+    const bool wave_changed = __builtin_amdgcn_ballot_w64(changed) != 0;
+    if (lane == 63) buf[w] = inc;
+    if (lane == 0) buf[16 + w] = wave_changed ? 1.0 : 0.0;
+    __syncthreads();
+    double off = 0.0, any = 0.0;
+    tot = 0.0;
+    for (int q = 0; q < nw; q++) {
+      if (q < w) off += buf[q];
+      tot += buf[q];
+      any += buf[16 + q];
+    }
+    if (sweep > 0 && any == 0.0) { fixed = true; break; }  // nothing moved last time: these are the sums of the fixed point
+    const double before = off + inc - Xi;
+    double kn = ki;
+    if (i >= 1 && i < N) kn = ki + rint((before / (double)i - Xi) * (1.0 / NBP_TWO_PI));
+    changed = kn != ki;
+    ki = kn;
+  }
+  __syncthreads();  // `red` is free again
+  *mean_out = wrap_pi(tot / (double)N);
+  return fixed;
+}
+
 __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, int manifold, int d, double *red) {
   double mu;
   if (is_circ(manifold, d)) {
@@ -347,57 +402,9 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
         return wrap_pi(x0 + mo);
       }
     }
-    // Spread around the circle: the running mean m_i = m_{i-1} + wrap(x_i - m_{i-1}) / (i + 1) is the running ARITHMETIC mean
-    // of the lifted points X_i = x_i + 2 pi k_i, where k_i puts X_i within pi of m_{i-1}.  The lifts depend on the
-    // trajectory, the trajectory is a prefix mean of the lifts: iterate (prefix sums -> lifts) to the fixed point, which
-    // by induction on i is the sequential walk's own assignment (every sweep fixes at least one more leading lift; on
-    // beliefs spread over the circle 5-15 sweeps of a workgroup-wide scan instead of N dependent steps; equal to the walk
-    // up to the rounding of the sums).  A belief that needs more sweeps is walked as before.
-    {
-      // One barrier per sweep: the wave totals and the "a lift changed in the previous sweep" flags go through
-      // alternating halves of `red`, and the loop ends one sweep after the last change (that sweep's sums are the final ones).
-      const int i = threadIdx.x, lane = i & 63, w = i >> 6, nw = (blockDim.x + 63) >> 6;
-      const double xi = (i < N) ? x[i] : 0.0;
-      double ki = 0.0, tot = 0.0;
-      bool changed = true, fixed = false;  // `changed`: this lane's lift moved in the previous sweep
-      if (i < 64) {
-        // the head of the trajectory, where the weights 1/(i+1) are large and the lifts take most sweeps to settle, is
-        // iterated by wave 0 alone: no barriers, no LDS -- the workgroup-wide sweeps below then start from a settled head
-        for (int sweep = 0; sweep < 24; sweep++) {
-          const double Xi = (i < N) ? fma(NBP_TWO_PI, ki, xi) : 0.0;
-          const double before = wave_inclusive_scan(Xi) - Xi;
-          double kn = ki;
-          if (i >= 1 && i < N) kn = ki + rint((before / (double)i - Xi) * (1.0 / NBP_TWO_PI));
-          const bool moved = __builtin_amdgcn_ballot_w64(kn != ki) != 0;
-          ki = kn;
-          if (!moved) break;
-        }
-      }
-      __syncthreads();                      // the reductions above are done with `red`
-      for (int sweep = 0; sweep < 32; sweep++) {
-        double *buf = red + (sweep & 1) * 32;
-        const double Xi = (i < N) ? fma(NBP_TWO_PI, ki, xi) : 0.0;
-        const double inc = wave_inclusive_scan(Xi);
-        const bool wave_changed = __builtin_amdgcn_ballot_w64(changed) != 0;
-        if (lane == 63) buf[w] = inc;
-        if (lane == 0) buf[16 + w] = wave_changed ? 1.0 : 0.0;
-        __syncthreads();
-        double off = 0.0, any = 0.0;
-        tot = 0.0;
-        for (int q = 0; q < nw; q++) {
-          if (q < w) off += buf[q];
-          tot += buf[q];
-          any += buf[16 + q];
-        }
-        if (sweep > 0 && any == 0.0) { fixed = true; break; }  // nothing moved last time: these are the sums of the fixed point
-        const double before = off + inc - Xi;
-        double kn = ki;
-        if (i >= 1 && i < N) kn = ki + rint((before / (double)i - Xi) * (1.0 / NBP_TWO_PI));
-        changed = kn != ki;
-        ki = kn;
-      }
-      __syncthreads();  // `red` is free again
-      if (fixed) return wrap_pi(tot / (double)N);
+    {  // spread around the circle: lifts and prefix means iterated to the walk's fixed point (mean_geodesic_lifts)
+      double mlift;
+      if (mean_geodesic_lifts(x, N, red, &mlift)) return mlift;
     }
     __syncthreads();
     if (threadIdx.x < 64) {
