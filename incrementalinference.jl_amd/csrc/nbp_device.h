@@ -1393,7 +1393,10 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
       __hip_atomic_store(&area->f[round][role], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int ok = 0;
       unsigned long long got[K];
-      for (int spin = 0; spin < 200000 && !ok; spin++) {
+      // Patience: a few hundred polls (a poll is a round trip to memory, ~1 us) = many evaluations.  Peers that have not
+      // published by then are not running (other contexts' kernels hold the CUs): going on alone costs this fit its
+      // speed-up, waiting longer would cost the whole solve its latency.
+      for (int spin = 0; spin < 512 && !ok; spin++) {
         ok = 1;
 #pragma unroll
         for (int r = 0; r < K; r++) {
