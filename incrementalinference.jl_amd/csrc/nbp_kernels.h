@@ -493,6 +493,7 @@ __host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return nbp_kd_stats
 
 // KD-tree permutation of one density: median split of the widest coordinate, by rank counting
 // inside each segment (P helper lanes per position, no sort network).
+#define NBP_KD_PARTS 512
 template <int D>
 __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, int Npad, const nbp_levels &T, double *smem,
                                          int mask /* coordinates the density informs */) {
@@ -503,7 +504,8 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
   int *tmpA = (int *)(red + NBP_RED);   // [N]
   int *tmpB = tmpA + N;                 // [N]
   int *prk = tmpB + N;                  // [P*Npad]
-  int *bdim = prk + P * Npad;           // [Npad]
+  double *pmn = (double *)(prk + P * Npad + (P * Npad & 1));  // [NBP_KD_PARTS] partial minima of the extent pass
+  double *pmx = pmn + NBP_KD_PARTS;     // [NBP_KD_PARTS]
   if (tid < N) {
 #pragma unroll
     for (int k = 0; k < D; k++) raw[k * N + tid] = x[k * N + tid];
@@ -514,26 +516,47 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
   for (int l = 0; l < T.L; l++) {
     const int cnt = T.cnt[l], off = T.off[l];
     if (D > 1) {
-      // extent of every segment in every coordinate: item = (node, coordinate, quarter), then argmax
-      for (int item = tid; item < cnt * D; item += TB) {
-        const int z = item / D, k = item % D;
-        const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
-        double mn = INFINITY, mx = -INFINITY;
-        for (int p = lo; p < hi; p++) {
-          const double v = raw[k * N + pa[p]];
-          mn = fmin(mn, v);
-          mx = fmax(mx, v);
+      // extent of every segment in every coordinate.  Long segments (the top levels) are cut into parts of about
+      // four positions, one thread each, and a second pass combines the parts: min/max do not care about the order
+      const int len0 = T.node_hi[off] - T.node_lo[off];
+      int Q = (len0 + 3) / 4;
+      if (Q > NBP_KD_PARTS / (cnt * D)) Q = NBP_KD_PARTS / (cnt * D);
+      if (Q > 1) {
+        for (int item = tid; item < cnt * D * Q; item += TB) {
+          const int zk = item / Q, part = item % Q, z = zk / D, k = zk % D;
+          const int lo = T.node_lo[off + z], len = T.node_hi[off + z] - lo;
+          const int a = lo + (part * len) / Q, b = lo + ((part + 1) * len) / Q;
+          double mn = INFINITY, mx = -INFINITY;
+#pragma unroll 4
+          for (int p = a; p < b; p++) {
+            const double v = raw[k * N + pa[p]];
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+          }
+          pmn[item] = mn;
+          pmx[item] = mx;
         }
-        ext[item] = mx - mn;
-      }
-      __syncthreads();
-      for (int z = tid; z < cnt; z += TB) {
-        int best = 0;
-        double bext = -1.0;
-#pragma unroll
-        for (int k = 0; k < D; k++)
-          if (((mask >> k) & 1) && ext[z * D + k] > bext) { bext = ext[z * D + k]; best = k; }
-        bdim[z] = best;
+        __syncthreads();
+        for (int item = tid; item < cnt * D; item += TB) {
+          double mn = INFINITY, mx = -INFINITY;
+          for (int q = 0; q < Q; q++) {
+            mn = fmin(mn, pmn[item * Q + q]);
+            mx = fmax(mx, pmx[item * Q + q]);
+          }
+          ext[item] = mx - mn;
+        }
+      } else {
+        for (int item = tid; item < cnt * D; item += TB) {
+          const int z = item / D, k = item % D;
+          const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
+          double mn = INFINITY, mx = -INFINITY;
+          for (int p = lo; p < hi; p++) {
+            const double v = raw[k * N + pa[p]];
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+          }
+          ext[item] = mx - mn;
+        }
       }
       __syncthreads();
     }
@@ -545,9 +568,16 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
       me = pa[s];
       int rank = 0;
       if (hi - lo > 1) {
-        const int best = (D > 1) ? bdim[node] : 0;
+        int best = 0;
+        if (D > 1) {  // widest informed coordinate of the segment (first one on ties)
+          double bext = -1.0;
+#pragma unroll
+          for (int k = 0; k < D; k++)
+            if (((mask >> k) & 1) && ext[node * D + k] > bext) { bext = ext[node * D + k]; best = k; }
+        }
         const double v = raw[best * N + me];
         const int len = hi - lo, a = lo + (sub * len) / P, b = lo + ((sub + 1) * len) / P;
+#pragma unroll 4
         for (int p = a; p < b; p++) {
           const int ip = pa[p];
           const double vp = raw[best * N + ip];
@@ -622,7 +652,7 @@ __global__ void nbp_resample_kernel(const int32_t *slots, const int32_t *manifol
 }
 
 static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
-  return ((size_t)D * N + 3 * Npad + NBP_RED) * 8 + ((size_t)2 * N + (size_t)P * Npad + Npad) * 4;
+  return ((size_t)D * N + 3 * Npad + NBP_RED + 2 * NBP_KD_PARTS) * 8 + ((size_t)2 * N + (size_t)P * Npad + 2) * 4;
 }
 
 template <int SPEC>
