@@ -426,13 +426,33 @@ static nbp_status toc(nbp_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>>
   return NBP_OK;
 }
 
-static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int n) {
+// 0, or the class of a batch whose relative factors are all full (non-partial) factors of one kind on one manifold, with
+// everything else in it (priors, message priors, pass-through densities) on that manifold as well:
+// 1 LinearRelative / Euclid(2), 3 LinearRelative / Euclid(3)
+static int proposals_uniform_class(const nbp_proposal_desc *d, int n) {
+  if (n <= 0) return 0;
+  const int M = d[0].manifold;
+  const int cls = M == NBP_EUCLID2 ? 1 : (M == NBP_EUCLID3 ? 3 : 0);
+  const int want = NBP_F_LINREL;
+  if (!cls) return 0;
+  bool any = false;
+  for (int i = 0; i < n; i++) {
+    if (d[i].manifold != M) return 0;
+    const int k = d[i].factor_kind;
+    if (k == NBP_F_PRIOR || k == NBP_F_MSGPRIOR || k == NBP_F_PASSTHROUGH) continue;
+    if (k != want || d[i].partial_mask) return 0;
+    any = true;
+  }
+  return any ? cls : 0;
+}
+static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int n, int cls = 0) {
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev[0]);
   if (rc) return rc;
   (void)hipGetLastError();  // clear stale, unrelated errors
-  hipLaunchKernelGGL(nbp_proposal_kernel, dim3(n), dim3(c->Npad), nbp_proposal_lds_bytes(c->N), c->stream, dev, c->arena,
-                     c->N, c->Npad, c->S, c->side, c->counters);
+  auto *kern = cls == 1 ? nbp_proposal_kernel_lin2 : (cls == 3 ? nbp_proposal_kernel_lin3 : nbp_proposal_kernel);
+  hipLaunchKernelGGL(kern, dim3(n), dim3(c->Npad), nbp_proposal_lds_bytes(c->N), c->stream, dev, c->arena, c->N, c->Npad, c->S, c->side,
+                     c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[0]);
 }
@@ -697,7 +717,7 @@ nbp_status nbp_run_proposals(nbp_ctx *c, const nbp_proposal_desc *descs, int32_t
   const int32_t *ds, *dm;
   rc = stage_with_jobs(c, descs, sizeof(nbp_proposal_desc) * (size_t)n, js, jm, &ds, &dm);
   if (rc) return rc;
-  rc = launch_proposals(c, (const nbp_proposal_desc *)c->stage, n);
+  rc = launch_proposals(c, (const nbp_proposal_desc *)c->stage, n, proposals_uniform_class(descs, n));
   if (rc) return rc;
   rc = launch_bandwidth(c, ds, dm, (int)js.size());  // manikde!(M, pts), ApproxConv.jl:36-42
   if (rc) return rc;
@@ -915,7 +935,7 @@ nbp_status nbp_run_resample(nbp_ctx *c, const int32_t *slots, const int32_t *man
 // proposal sampling from it, or a copy stage moving whole slots.  Per update the critical path is
 // proposal -> prep (LCV || KD) -> product.
 struct nbp_stage {
-  int kind = 0, n = 0, maxfd = 0, mani = 0;  // mani: products_uniform_manifold
+  int kind = 0, n = 0, maxfd = 0, mani = 0;  // mani: products_uniform_manifold / proposals_uniform_class
   size_t offset = 0;            // byte offset of the descriptors in the program blob
   std::vector<int32_t> ent_s, ent_m;  // fits pending at ENTRY of the stage
   size_t ent_off = 0;
@@ -965,7 +985,11 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
   nbp_status rc = NBP_OK;
   nbp_stage st;
   switch (kind) {
-  case NBP_STAGE_PROPOSALS: esz = sizeof(nbp_proposal_desc); rc = check_proposals(p->ctx, (const nbp_proposal_desc *)descs, n); break;
+  case NBP_STAGE_PROPOSALS:
+    esz = sizeof(nbp_proposal_desc);
+    rc = check_proposals(p->ctx, (const nbp_proposal_desc *)descs, n);
+    st.mani = proposals_uniform_class((const nbp_proposal_desc *)descs, n);
+    break;
   case NBP_STAGE_PRODUCTS:
     esz = sizeof(nbp_product_desc);
     rc = check_products(p->ctx, (const nbp_product_desc *)descs, n);
@@ -1214,7 +1238,7 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
     if (st.flush_before) rc = launch_bandwidth(c, ent_s(st), ent_s(st) + nent, nent);
     if (rc) return rc;
     if (st.kind == NBP_STAGE_PROPOSALS) {
-      rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n);
+      rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
       if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);

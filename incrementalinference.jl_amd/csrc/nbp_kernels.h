@@ -102,16 +102,18 @@ __device__ __forceinline__ double var_distance_expected_fractional(const nbp_pro
   return kappa * best;
 }
 
-__global__ void __launch_bounds__(512)
-nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side,
-                    nbp_counters *ctr) {
-  extern __shared__ double smem[];
+// FIXK / FIXM: a batch whose relative factors are all of kind FIXK on the manifold FIXM, none of them partial (priors,
+// message priors and pass-through densities of that manifold may ride along): the solver dispatch and the partial
+// branches fold away, and with them the registers of the largest solver (the generic kernel holds the SE(2) simplex)
+template <int FIXK, int FIXM>
+__device__ __forceinline__ void proposal_body(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side,
+                                              nbp_counters *ctr, double *smem) {
   double *X = smem;                 // [3][N]
   double *red = X + 3 * N;          // [NBP_RED]
   int *mh = (int *)(red + NBP_RED); // [N]
   __shared__ recipe_t R;
   const nbp_proposal_desc *d = descs + blockIdx.x;
-  const int n = threadIdx.x, M = d->manifold, D = mani_dim(M), kind = d->factor_kind;
+  const int n = threadIdx.x, M = FIXK ? FIXM : d->manifold, D = mani_dim(M), kind = d->factor_kind;
   const bool live = n < N;  // lanes (i < N, p == 0) own a particle
   double *out = arena + S * d->out_slot;
   unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
@@ -230,10 +232,11 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     // and solves that coordinate only (EvalFactor.jl:184-198, NumericalCalculations.jl:424)
     // a partial relative factor measures, inflates and solves its `.partial` coordinates only (validated on the host:
     // LinearRelative, one or two of the variable's coordinates)
-    const int pmask = d->partial_mask, npd = __popc(pmask & 7);
+    const int pmask = FIXK ? 0 : d->partial_mask, npd = __popc(pmask & 7);
     const int pdim = pmask ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;                  // first partial coordinate
     const int pdim2 = (npd > 1) ? ((pmask & 1) && (pmask & 2) ? 1 : 2) : -1;              // second one
-    const int zdim = pmask ? npd : ((kind == NBP_F_LINREL) ? D : (kind == NBP_F_SE2 ? 3 : 1));
+    const int rkind = FIXK ? FIXK : kind;
+    const int zdim = pmask ? npd : ((rkind == NBP_F_LINREL) ? D : (rkind == NBP_F_SE2 ? 3 : 1));
     double z[3] = {0, 0, 0};
     if (live) sample_measurement(d, n, zdim, z, arena, S, N);  // sampleFactor!, CalcFactor.jl:578
     const int sf1 = d->sfidx + 1;
@@ -280,7 +283,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
               else if (pdim == 1) x[1] = x1[0];
               else x[2] = x1[0];
             } else
-              solve_particle(kind, M, z, oth, solve_b, x, n_solves, n_nonconv, n_nan, n_evals);  // approxConvOnElements!
+              solve_particle(rkind, M, z, oth, solve_b, x, n_solves, n_nonconv, n_nan, n_evals);  // approxConvOnElements!
             X[n] = x[0];
             if (D > 1) X[N + n] = x[1];
             if (D > 2) X[2 * N + n] = x[2];
@@ -328,6 +331,24 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     }
   }
 }
+
+__global__ void __launch_bounds__(512)
+nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side,
+                    nbp_counters *ctr) {
+  extern __shared__ double smem[];
+  proposal_body<0, 0>(descs, arena, N, Npad, S, side, ctr, smem);
+}
+// one relative-factor kind on one manifold (the odometry chains of the BASELINE configs): lin2 = LinearRelative on
+// Euclid(2) (configs 2 / 2p: -10 % proposal time), lin3 = LinearRelative on Euclid(3) (config 5: -7 %).  The circle
+// (config 3) gains nothing from its own instance: the registers there are the spread statistics', not the solver's
+#define NBP_PROPOSAL_UNIFORM(NAME, K_, M_, WAVES)                                                                          \
+  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES)))                                       \
+  NAME(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side, nbp_counters *ctr) {     \
+    extern __shared__ double smem[];                                                                                       \
+    proposal_body<K_, M_>(descs, arena, N, Npad, S, side, ctr, smem);                                                      \
+  }
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, 4)
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
 
 // ================================================================================================
 // Deconvolution kernel: one workgroup = one approxDeconv(dfg, fct) (DeconvUtils.jl:32-160), one lane

@@ -26,6 +26,8 @@ def main(path, steps, lps=60):
         name = short_name(r["Kernel_Name"])
         if name.startswith("nbp_product_kernel"):
             name = "nbp_product_kernel(x16|l8|m4|t2)"  # one launch per stage, three geometries
+        if name.startswith("nbp_proposal_kernel"):
+            name = "nbp_proposal_kernel(generic|lin2|lin3)"  # one launch per stage
         if name.startswith("nbp_"):
             by[name].append(r)
     print(f"{'kernel':34s} {'launches':>8s} {'avg_us':>10s} {'total_ms':>9s} | avg_us by grid size (blocks): <=8, <=64, <=300, >300")
