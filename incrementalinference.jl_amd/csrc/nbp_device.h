@@ -187,8 +187,7 @@ __device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) {
 __constant__ double NBP_EXP2_TAB[32] = {1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332, 1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
 #define NBP_EXPTAB 32
 // 2^(k/64), k = 0..63 (correctly rounded): the table of the bandwidth fit's exponential (lcv_exp below)
-__constant__ double NBP_EXP2_TAB64[64] = {1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199, 1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812, 1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783, 1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303, 1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112, 1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647, 1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384, 1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267, 1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364, 1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062, 1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989, 1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656, 1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
-#define NBP_EXPTAB64 64
+#include "nbp_lcv_table.h"
 __device__ __forceinline__ void nbp_exp_tab_init(double *tab) {
   if (threadIdx.x < 32) tab[threadIdx.x] = NBP_EXP2_TAB[threadIdx.x];
 }
@@ -970,13 +969,13 @@ __device__ __forceinline__ double circ_sq(double d) {
 }
 
 // exp(-c q), q >= 0, with everything that depends on the bandwidth folded into per-evaluation constants that live in
-// SGPRs: n = round(-c q 64/ln2) by the magic-number trick, z = -c q - n ln2/64 = -c r with r = q + n ln2/(64 c), and
-// exp(z) = 1 + a1 r + ... + a5 r^5 with a_k = (-c)^k / k!  (|z| <= ln2/128: the next term is 3.5e-17), times
-// 2^((n & 63)/64) from the table, times 2^(n >> 6) by an integer add on the exponent field.  17 VALU operations per
-// pair where exp(-(q c)) by the general-purpose exp_nonpos takes 20 (the multiplication by c, one Horner step and one
-// of the integer operations are gone).
+// SGPRs: n = round(-c q 256/ln2) by the magic-number trick, z = -c q - n ln2/256 = -c r with r = q + n ln2/(256 c), and
+// exp(z) = 1 + a1 r + ... + a4 r^4 with a_k = (-c)^k / k!  (|z| <= ln2/512: the next term is 3.8e-17), times
+// 2^((n & 255)/256) * 2^(n >> 8), which is ONE table read and ONE integer add (lcv_tab_scaled).  15 VALU operations per
+// pair where exp(-(q c)) by the general-purpose exp_nonpos takes 20 (the multiplication by c, two Horner steps and the
+// masking of n are gone).
 struct lcv_exp_k {
-  double A, negM, B, qmax, a1, a2, a3, a4, a5;
+  double A, negM, B, qmax, a1, a2, a3, a4;
 };
 
 // a wave-uniform double into an SGPR pair.  Opaque to the compiler on purpose: it folds __builtin_amdgcn_readfirstlane
@@ -993,21 +992,28 @@ __device__ __forceinline__ double sgpr_double(double v) {
 __device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c, double h) {  // c = 1/(2 h^2): 1/c = 2 h^2 without a division
   lcv_exp_k K;
   const double rc = 2.0 * h * h;
-  K.A = sgpr_double(-c * 92.33248261689366);       // 64/ln2
+  K.A = sgpr_double(-c * 369.3299304675746);       // 256/ln2
   K.negM = -6755399441055744.0;
-  K.B = sgpr_double(0.010830424696249145 * rc);    // ln2/64
+  K.B = sgpr_double(0.0027076061740622863 * rc);   // ln2/256
   K.qmax = sgpr_double(700.0 * rc);                 // exp(-700) = 1e-304 is as good as 0 for every sum it enters
   const double m = -c;
   K.a1 = sgpr_double(m);
   K.a2 = sgpr_double(m * m * 0.5);
   K.a3 = sgpr_double(m * m * m * 1.66666666666666666667e-01);
-  K.a4 = sgpr_double(m * m * m * m * 4.16666666666666666667e-02);
-  K.a5 = m * m * m * m * m * 8.33333333333333333333e-03;  // the leading coefficient stays in a VGPR pair (one scalar operand per VOP3)
+  K.a4 = m * m * m * m * 4.16666666666666666667e-02;  // the leading coefficient stays in a VGPR pair (one scalar operand per VOP3)
   return K;
 }
 #define NBP_FMA_VVS(dst, a, b, cst) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "s"(cst))
 #define NBP_FMA_VSV(dst, a, cst, c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "s"(cst), "v"(c))
-__device__ __forceinline__ double lcv_exp(double q, const lcv_exp_k &K, const double *tab64) {
+// the table entry of n with 2^(n >> 8) already on it: entry k = n & 255 holds the bits of 2^(k/256) with k << 12 taken off
+// the high word (tools/gen_lcv_table.py), so adding n << 12 = (e << 20) + (k << 12) leaves e on the exponent field
+__device__ __forceinline__ double lcv_tab_scaled(const double *tab, int n) {
+  const double w = tab[n & (NBP_LCVTAB - 1)];
+  int hi;
+  asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(w)));
+  return __hiloint2double(hi, __double2loint(w));
+}
+__device__ __forceinline__ double lcv_exp(double q, const lcv_exp_k &K, const double *tab) {
   q = fmin(q, K.qmax);
   double t, r, p;
   const double M = 6755399441055744.0;
@@ -1015,42 +1021,30 @@ __device__ __forceinline__ double lcv_exp(double q, const lcv_exp_k &K, const do
   const int n = __double2loint(t);
   const double tf = t + K.negM;
   NBP_FMA_VSV(r, tf, K.B, q);
-  NBP_FMA_VVS(p, K.a5, r, K.a4);
-  NBP_FMA_VVS(p, p, r, K.a3);
+  NBP_FMA_VVS(p, K.a4, r, K.a3);
   NBP_FMA_VVS(p, p, r, K.a2);
   NBP_FMA_VVS(p, p, r, K.a1);
   p = fma(p, r, 1.0);
-  const double y = tab64[n & 63] * p;
-  int hi;
-  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(hi) : "v"(n & ~63), "v"(__double2hiint(y)));  // 2^(n >> 6) onto the exponent field
-  return __hiloint2double(hi, __double2loint(y));
+  return lcv_tab_scaled(tab, n) * p;
 }
 
 // four independent chains, written step by step so that the instruction stream keeps them interleaved (the scheduler
 // otherwise runs one Horner chain after the other when registers are tight)
-__device__ __forceinline__ void lcv_exp4(double &q0, double &q1, double &q2, double &q3, const lcv_exp_k &K, const double *tab64) {
+__device__ __forceinline__ void lcv_exp4(double &q0, double &q1, double &q2, double &q3, const lcv_exp_k &K, const double *tab) {
   const double M = 6755399441055744.0;
   q0 = fmin(q0, K.qmax); q1 = fmin(q1, K.qmax); q2 = fmin(q2, K.qmax); q3 = fmin(q3, K.qmax);
   double t0, t1, t2, t3;
   NBP_FMA_VSV(t0, q0, K.A, M); NBP_FMA_VSV(t1, q1, K.A, M); NBP_FMA_VSV(t2, q2, K.A, M); NBP_FMA_VSV(t3, q3, K.A, M);
-  const int n0 = __double2loint(t0), n1 = __double2loint(t1), n2 = __double2loint(t2), n3 = __double2loint(t3);
-  const double w0 = tab64[n0 & 63], w1 = tab64[n1 & 63], w2 = tab64[n2 & 63], w3 = tab64[n3 & 63];
+  const double w0 = lcv_tab_scaled(tab, __double2loint(t0)), w1 = lcv_tab_scaled(tab, __double2loint(t1));
+  const double w2 = lcv_tab_scaled(tab, __double2loint(t2)), w3 = lcv_tab_scaled(tab, __double2loint(t3));
   t0 += K.negM; t1 += K.negM; t2 += K.negM; t3 += K.negM;
   double r0, r1, r2, r3, p0, p1, p2, p3;
   NBP_FMA_VSV(r0, t0, K.B, q0); NBP_FMA_VSV(r1, t1, K.B, q1); NBP_FMA_VSV(r2, t2, K.B, q2); NBP_FMA_VSV(r3, t3, K.B, q3);
-  NBP_FMA_VVS(p0, K.a5, r0, K.a4); NBP_FMA_VVS(p1, K.a5, r1, K.a4); NBP_FMA_VVS(p2, K.a5, r2, K.a4); NBP_FMA_VVS(p3, K.a5, r3, K.a4);
-  NBP_FMA_VVS(p0, p0, r0, K.a3); NBP_FMA_VVS(p1, p1, r1, K.a3); NBP_FMA_VVS(p2, p2, r2, K.a3); NBP_FMA_VVS(p3, p3, r3, K.a3);
+  NBP_FMA_VVS(p0, K.a4, r0, K.a3); NBP_FMA_VVS(p1, K.a4, r1, K.a3); NBP_FMA_VVS(p2, K.a4, r2, K.a3); NBP_FMA_VVS(p3, K.a4, r3, K.a3);
   NBP_FMA_VVS(p0, p0, r0, K.a2); NBP_FMA_VVS(p1, p1, r1, K.a2); NBP_FMA_VVS(p2, p2, r2, K.a2); NBP_FMA_VVS(p3, p3, r3, K.a2);
   NBP_FMA_VVS(p0, p0, r0, K.a1); NBP_FMA_VVS(p1, p1, r1, K.a1); NBP_FMA_VVS(p2, p2, r2, K.a1); NBP_FMA_VVS(p3, p3, r3, K.a1);
   p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0); p2 = fma(p2, r2, 1.0); p3 = fma(p3, r3, 1.0);
-  const double y0 = w0 * p0, y1 = w1 * p1, y2 = w2 * p2, y3 = w3 * p3;
-  int h0, h1, h2, h3;
-  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h0) : "v"(n0 & ~63), "v"(__double2hiint(y0)));
-  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h1) : "v"(n1 & ~63), "v"(__double2hiint(y1)));
-  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h2) : "v"(n2 & ~63), "v"(__double2hiint(y2)));
-  asm("v_lshl_add_u32 %0, %1, 14, %2" : "=v"(h3) : "v"(n3 & ~63), "v"(__double2hiint(y3)));
-  q0 = __hiloint2double(h0, __double2loint(y0)); q1 = __hiloint2double(h1, __double2loint(y1));
-  q2 = __hiloint2double(h2, __double2loint(y2)); q3 = __hiloint2double(h3, __double2loint(y3));
+  q0 = w0 * p0; q1 = w1 * p1; q2 = w2 * p2; q3 = w3 * p3;
 }
 
 template <bool CIRC>

@@ -413,7 +413,7 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   const int N = slot_count(s, Ncap);  // manikde! of the points the belief holds (Ncap = slot capacity = stride)
   const int P = blockDim.x / Npad;
   double *X = smem, *part = smem + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N, *tab = red + NBP_RED;
-  if (n < NBP_EXPTAB64) tab[n] = NBP_EXP2_TAB64[n];  // the table of lcv_exp
+  for (int q = n; q < NBP_LCVTAB; q += blockDim.x) tab[q] = __longlong_as_double((long long)NBP_LCV_TAB[q]);  // the table of lcv_exp
   // circular coordinates are staged wrapped (the identity for stored beliefs): every pair difference of
   // the fit is then within (-2pi, 2pi), which is what circ_sqdist relies on
   if (n < N) {
@@ -452,7 +452,7 @@ nbp_bandwidth_kernel_spec(const int32_t *slots, const int32_t *manifolds, double
 
 // X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
 static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
-  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_EXPTAB64) * 8;
+  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_LCVTAB) * 8;
 }
 
 __global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S) {
