@@ -347,7 +347,7 @@ nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Np
     extern __shared__ double smem[];                                                                                       \
     proposal_body<K_, M_>(descs, arena, N, Npad, S, side, ctr, smem);                                                      \
   }
-NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, 4)
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, 3)
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
 
 // ================================================================================================
