@@ -1497,6 +1497,11 @@ nbp_status nbp_debug_phase_read(long long *out, int n, int reset) {
   }
   return NBP_OK;
 }
+nbp_status nbp_debug_block_read(long long *out, int nblocks) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nbp_block_clk), sizeof(long long) * 3 * (size_t)(nblocks < 8192 ? nblocks : 8192)));
+  return NBP_OK;
+}
 #endif
 
 }  // extern "C"

@@ -522,6 +522,19 @@ struct objective_t {
   }
   __device__ __forceinline__ double operator()(const double (&x)[DN]) {
     evals++;
+    if (KIND == NBP_F_LINREL) {
+      // z - (x - other) when x is the second variable, z - (other - x) = z + (x - other) when it is the first: the same
+      // values as normsq() either way (a negation is exact), without a wave-uniform branch on solve_b in front of every
+      // evaluation -- a lone wave (the slowest search of a workgroup) pays a taken branch with its instruction fetch
+      const double sg = solve_b ? -1.0 : 1.0;
+      double acc = 0;
+#pragma unroll
+      for (int d = 0; d < DN; d++) {
+        const double r = fma(sg, x[d] - other[d], z[d]);
+        acc += r * r;
+      }
+      return acc;
+    }
     double xo[DN];
 #pragma unroll
     for (int d = 0; d < DN; d++) xo[d] = other[d];
@@ -612,30 +625,23 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
     const double f_reflect = o(xr);
     const bool do_expand = f_reflect < f_lowest;
     const bool accept_reflect = !do_expand && f_reflect < f_second;
-    bool shrink = false;
-    if (!accept_reflect) {
-      const bool outside = f_reflect < f_highest;
-      const double coef = do_expand ? beta : (outside ? gamma : -gamma);
+    // straight-line: the second point of the iteration (expansion, outside or inside contraction) is always computed
+    // and dropped by the lanes that accept the reflection -- the lanes of a wave take different branches in almost
+    // every iteration anyway, and one copy of the insertion below serves all of them
+    const bool outside = f_reflect < f_highest;
+    const double coef = do_expand ? beta : (outside ? gamma : -gamma);
 #pragma unroll
-      for (int d = 0; d < DN; d++) xcache[d] = xc[d] + coef * (xr[d] - xc[d]);
-      const double f2 = o(xcache);
-      // expansion: the better of (expand, reflect) replaces the worst; contraction: accepted only
-      // if it improves on min(reflect, highest)
-      const bool take2 = do_expand ? (f2 < f_reflect) : (f2 < (outside ? f_reflect : f_highest));
-      const bool taker = do_expand && !take2;
-      shrink = !do_expand && !take2;
-      if (take2 || taker) {
+    for (int d = 0; d < DN; d++) xcache[d] = xc[d] + coef * (xr[d] - xc[d]);
+    const double f2 = o(xcache);
+    o.evals -= accept_reflect ? 1 : 0;  // Optim does not evaluate it
+    // expansion: the better of (expand, reflect) replaces the worst; contraction: accepted only
+    // if it improves on min(reflect, highest)
+    const bool take2 = !accept_reflect && (do_expand ? (f2 < f_reflect) : (f2 < (outside ? f_reflect : f_highest)));
+    const bool shrink = !accept_reflect && !do_expand && !take2;
 #pragma unroll
-        for (int d = 0; d < DN; d++) sx[DN][d] = take2 ? xcache[d] : xr[d];
-        f[DN] = take2 ? f2 : f_reflect;
-        nm_sift_last<DN>(sx, f);
-      }
-    } else {
-#pragma unroll
-      for (int d = 0; d < DN; d++) sx[DN][d] = xr[d];
-      f[DN] = f_reflect;
-      nm_sift_last<DN>(sx, f);
-    }
+    for (int d = 0; d < DN; d++) sx[DN][d] = shrink ? sx[DN][d] : (take2 ? xcache[d] : xr[d]);
+    f[DN] = shrink ? f[DN] : (take2 ? f2 : f_reflect);
+    nm_sift_last<DN>(sx, f);  // leaves a sorted simplex (the shrinking lanes') as it is
     if (shrink) {
 #pragma unroll
       for (int q = 1; q < M; q++) {
@@ -951,7 +957,13 @@ __device__ long long nbp_phase_clk[64];
 // of the launch (so that a chip-filling batch is in flight around it)
 #define NBP_CTICK(k) do { if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0) nbp_phase_clk[k] += (long long)__builtin_readcyclecounter() - c_last_; c_last_ = __builtin_readcyclecounter(); } while (0)
 #define NBP_CTICK_INIT() long long c_last_ = __builtin_readcyclecounter()
+// begin / end (100 MHz wall clock) and hardware id of every workgroup of the last launch (tools/exp/block_timeline.py)
+__device__ long long nbp_block_clk[8192][3];
+#define NBP_BLOCK_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { nbp_block_clk[blockIdx.x][0] = (long long)wall_clock64(); nbp_block_clk[blockIdx.x][2] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); } } while (0)
+#define NBP_BLOCK_END() do { if (threadIdx.x == 0 && blockIdx.x < 8192) nbp_block_clk[blockIdx.x][1] = (long long)wall_clock64(); } while (0)
 #else
+#define NBP_BLOCK_BEGIN()
+#define NBP_BLOCK_END()
 #define NBP_TICK(k)
 #define NBP_TICK_INIT()
 #define NBP_CTICK(k)

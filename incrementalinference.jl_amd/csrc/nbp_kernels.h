@@ -119,6 +119,7 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *descs, do
   unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
 
   NBP_CTICK_INIT();
+  NBP_BLOCK_BEGIN();
   if (n == 0) build_recipe(d, &R);
   {
     const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR || kind == NBP_F_PASSTHROUGH) ? 0 : d->sfidx];
@@ -314,6 +315,7 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *descs, do
   // infoPerCoord of the proposal: ones(D), zeroed outside the factor's `.partial` (EvalFactor.jl:383-391, :534-540)
   if (n < 3) out[3 * N + 3 + n] = (n < D && (!d->partial_mask || ((d->partial_mask >> n) & 1))) ? 1.0 : 0.0;
   if (n == 0) out[3 * N + 6] = 0.0;  // a proposal always holds N points
+  NBP_BLOCK_END();
   // diagnostics: one atomic per wave
   {
     unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
