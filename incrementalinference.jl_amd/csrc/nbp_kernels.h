@@ -5,6 +5,7 @@
 // helper index, all lanes of a wave share p); the product kernel runs HL adjacent lanes per output
 // sample.  The host picks P / HL per launch from the batch size (latency vs throughput mode).
 #pragma once
+#include <type_traits>
 #include "nbp_device.h"
 
 // ================================================================================================
@@ -836,7 +837,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     __syncthreads();
     NBP_CTICK(41);  // node statistics + levelDown
     const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range
-    const bool leaf = (l == T.L);
+    // the sweep is instantiated for the leaf level and for the levels above it: `leaf` as a run-time flag is a
+    // wave-uniform branch in front of every node weight (two taken branches per node in the pass-1 loop)
+    auto sweep = [&](auto leaf_c) {
+    constexpr bool leaf = decltype(leaf_c)::value;
     for (int it = 0; it < d->niter; it++) {
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
         // Draw l_j ~ p(l_j | others) by inverse CDF over the nodes of this level.
@@ -1011,6 +1015,9 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         NBP_CTICK(46);  // pass 2: rescan of the chosen chunk + broadcast of the choice
       }
     }
+    };
+    if (l == T.L) sweep(std::true_type{});
+    else sweep(std::false_type{});
   }
   NBP_CTICK(40);
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
