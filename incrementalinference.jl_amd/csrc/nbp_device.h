@@ -183,42 +183,39 @@ __device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) {
 // with a degree-6 polynomial; the integer n = 32k + j is taken from the low mantissa bits after
 // adding 1.5*2^52 and 2^k is applied by an integer add on the exponent field, so every operation is
 // a full-rate FP64/INT32 VALU op (no v_rndne/v_cvt/v_ldexp quarter-rate ops).  <= 2 ulp.
-// `tab` = the 32-entry 2^(j/32) table staged in LDS (nbp_exp_tab_init).
-__constant__ double NBP_EXP2_TAB[32] = {1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332, 1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228, 1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965, 1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
-#define NBP_EXPTAB 32
-// 2^(k/64), k = 0..63 (correctly rounded): the table of the bandwidth fit's exponential (lcv_exp below)
+// `tab` = the 256-entry table of nbp_lcv_table.h staged in LDS (nbp_exp_tab_init): entry k holds the bits of 2^(k/256)
+// with k << 12 taken off the high word, so adding n << 12 puts 2^(n >> 8) on without masking (tools/gen_lcv_table.py)
 #include "nbp_lcv_table.h"
+#define NBP_EXPTAB NBP_LCVTAB
 __device__ __forceinline__ void nbp_exp_tab_init(double *tab) {
-  if (threadIdx.x < 32) tab[threadIdx.x] = NBP_EXP2_TAB[threadIdx.x];
+  for (int q = threadIdx.x; q < NBP_LCVTAB; q += blockDim.x) tab[q] = __longlong_as_double((long long)NBP_LCV_TAB[q]);
 }
 __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
   // clamp instead of branching: exp(-700) = 1e-304 is as good as 0 for every sum it enters
   x = fmax(x, -700.0);
-  const double t = fma(x, 46.16624130844683, 6755399441055744.0);
+  const double t = fma(x, 369.3299304675746, 6755399441055744.0);  // 256/ln2
   const int n = __double2loint(t);
   const double tf = t - 6755399441055744.0;
-  // one-constant reduction: |tf| <= 3.3e4, so the rounding of ln2/32 (<= 1.8e-18) moves r by <= 6e-14
+  // one-constant reduction: |tf| <= 2.6e5, so the rounding of ln2/256 (<= 2.2e-19) moves r by <= 6e-14
   // at the clamp and by < 1e-15 where the result still matters to a sum
-  const double r = fma(tf, -2.1660849392498290e-02, x);
-  // Horner with the coefficients pinned in SGPRs: one v_fma_f64 per step (hipcc otherwise keeps them
-  // in VGPRs and pays a v_mov_b64 + v_fmac_f64 per step)
+  const double r = fma(tf, -2.7076061740622863e-03, x);
+  // |r| <= ln2/512: degree 4 (next term 3.8e-17).  Horner with the coefficients pinned in SGPRs: one v_fma_f64 per step
+  // (hipcc otherwise keeps them in VGPRs and pays a v_mov_b64 + v_fmac_f64 per step)
   double p;
 #define NBP_FMA_S(dst, a, b, cst) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "s"(cst))
   {
-    const double c6 = 1.38888888888888888889e-03, c5 = 8.33333333333333333333e-03, c4 = 4.16666666666666666667e-02,
-                 c3 = 1.66666666666666666667e-01;
+    const double c4 = 4.16666666666666666667e-02, c3 = 1.66666666666666666667e-01;
     double q;
-    NBP_FMA_S(q, c6, r, c5);
-    NBP_FMA_S(q, q, r, c4);
-    NBP_FMA_S(q, q, r, c3);
+    NBP_FMA_S(q, c4, r, c3);
     p = fma(q, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
   }
 #undef NBP_FMA_S
-  const double y = tab[n & 31] * p;
-  // 2^(n>>5): add (n>>5)<<20 to the high word == ((n & ~31) << 15), one v_and + one v_lshl_add
-  return __hiloint2double(__double2hiint(y) + ((n & ~31) << 15), __double2loint(y));
+  const double w = tab[n & (NBP_LCVTAB - 1)];
+  int hi;
+  asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(w)));  // 2^(n >> 8) onto the exponent field
+  return __hiloint2double(hi, __double2loint(w)) * p;
 }
 
 // ------------------------------------------------------------------------------------------------
