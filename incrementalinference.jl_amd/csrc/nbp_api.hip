@@ -1502,6 +1502,15 @@ nbp_status nbp_debug_block_read(long long *out, int nblocks) {
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nbp_block_clk), sizeof(long long) * 3 * (size_t)(nblocks < 8192 ? nblocks : 8192)));
   return NBP_OK;
 }
+nbp_status nbp_debug_block_hist(unsigned int *out, int reset) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nbp_block_hist), sizeof(unsigned int) * 4 * 64));
+  if (reset) {
+    unsigned int z[4 * 64] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nbp_block_hist), z, sizeof(z)));
+  }
+  return NBP_OK;
+}
 #endif
 
 }  // extern "C"

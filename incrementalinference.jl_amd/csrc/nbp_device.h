@@ -956,8 +956,13 @@ __device__ long long nbp_phase_clk[64];
 #define NBP_CTICK_INIT() long long c_last_ = __builtin_readcyclecounter()
 // begin / end (100 MHz wall clock) and hardware id of every workgroup of the last launch (tools/exp/block_timeline.py)
 __device__ long long nbp_block_clk[8192][3];
-#define NBP_BLOCK_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { nbp_block_clk[blockIdx.x][0] = (long long)wall_clock64(); nbp_block_clk[blockIdx.x][2] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); } } while (0)
-#define NBP_BLOCK_END() do { if (threadIdx.x == 0 && blockIdx.x < 8192) nbp_block_clk[blockIdx.x][1] = (long long)wall_clock64(); } while (0)
+#define NBP_BLOCK_BEGIN() const long long blk_t0_ = (long long)wall_clock64(); do { if (threadIdx.x == 0 && blockIdx.x < 8192) { nbp_block_clk[blockIdx.x][0] = (long long)wall_clock64(); nbp_block_clk[blockIdx.x][2] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); } } while (0)
+// histogram of workgroup durations over all launches since the last read, by grid-size class (<= 8, <= 64, <= 300, more
+// workgroups) in bins of 16 us
+__device__ unsigned int nbp_block_hist[4][64];
+#define NBP_BLOCK_END() do { if (threadIdx.x == 0) { const long long e_ = (long long)wall_clock64(); if (blockIdx.x < 8192) nbp_block_clk[blockIdx.x][1] = e_; \
+  const int g_ = gridDim.x <= 8 ? 0 : (gridDim.x <= 64 ? 1 : (gridDim.x <= 300 ? 2 : 3)); long long b_ = (e_ - blk_t0_) / 1600; if (b_ > 63) b_ = 63; \
+  atomicAdd(&nbp_block_hist[g_][b_], 1u); } } while (0)
 #else
 #define NBP_BLOCK_BEGIN()
 #define NBP_BLOCK_END()
