@@ -30,9 +30,10 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
   } while (0)
 
 // Speculative fits (lcv_bandwidth_1d_spec): used when every workgroup of the launch is resident at once -- the launch,
-// with 3 or 7 workgroups per fit, stays below NBP_SPEC_MAXBLOCKS (the chip has 256 CUs and a fit's workgroup has a CU
-// to itself: 1024 lanes, ~63 KB of LDS).
-#define NBP_SPEC_MAXJOBS 24
+// with 3 or 7 workgroups per fitted coordinate, stays below NBP_SPEC_MAXBLOCKS (the chip has 256 CUs and a fit's
+// workgroup has a CU to itself: 1024 lanes, ~63 KB of LDS).  Counted are the workgroups that stay: those of a
+// coordinate the manifold does not have leave at once (`coords` = sum of the manifold dimensions of the jobs).
+#define NBP_SPEC_MAXJOBS 40
 #define NBP_SPEC_MAXBLOCKS 224
 struct nbp_program;
 struct nbp_ctx {
@@ -492,8 +493,14 @@ static int lcv_helpers(nbp_ctx *c, int nblocks) {
 }
 
 // nbp_prep_kernel: pending bandwidth fits + KD builds of this product batch, one launch
+static int coords_of(const int32_t *manis, size_t n) {
+  int cds = 0;
+  for (size_t i = 0; i < n; i++) cds += manifold_dim_h(manis[i]);
+  return cds;
+}
 static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
-                              const nbp_product_desc *dev, int n, int maxFD) {
+                              const nbp_product_desc *dev, int n, int maxFD, int coords = -1) {
+  if (coords < 0) coords = 3 * nbw;
   nbp_status rc = ensure_ws(c, n, maxFD / 4);
   if (rc) return rc;
   rc = tic(c, c->ev[1]);
@@ -507,8 +514,8 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   // 3 workgroups per fit (two iterations per rendezvous) when the whole launch is resident at once (7 / three on request)
   int depth = 0;
   if (c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS) {
-    if (c->spec_depth3 && 3 * nbw * 7 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 3;
-    else if (3 * nbw * 3 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 2;
+    if (c->spec_depth3 && coords * 7 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 3;
+    else if (coords * 3 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 2;
   }
   const bool spec = depth > 0;
   const int KS = spec ? (1 << depth) - 1 : 1;
@@ -618,14 +625,15 @@ static nbp_status presize_products(nbp_ctx *c, int n, int maxFD) {
   return rc;
 }
 
-static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const int32_t *dev_manis, int n) {
+static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const int32_t *dev_manis, int n, int coords = -1) {
   if (n <= 0) return NBP_OK;
+  if (coords < 0) coords = 3 * n;
   nbp_status rc = tic(c, c->ev[3]);
   if (rc) return rc;
   (void)hipGetLastError();
   const int P = lcv_helpers(c, 2 * n);
   int depth = 0;
-  if (c->spec_on && n <= NBP_SPEC_MAXJOBS) depth = (c->spec_depth3 && 3 * n * 7 <= NBP_SPEC_MAXBLOCKS) ? 3 : ((3 * n * 3 <= NBP_SPEC_MAXBLOCKS) ? 2 : 0);
+  if (c->spec_on && n <= NBP_SPEC_MAXJOBS) depth = (c->spec_depth3 && coords * 7 <= NBP_SPEC_MAXBLOCKS) ? 3 : ((coords * 3 <= NBP_SPEC_MAXBLOCKS) ? 2 : 0);
   const bool spec = depth > 0;
   if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
   if (depth == 3)
@@ -719,7 +727,7 @@ nbp_status nbp_run_proposals(nbp_ctx *c, const nbp_proposal_desc *descs, int32_t
   if (rc) return rc;
   rc = launch_proposals(c, (const nbp_proposal_desc *)c->stage, n, proposals_uniform_class(descs, n));
   if (rc) return rc;
-  rc = launch_bandwidth(c, ds, dm, (int)js.size());  // manikde!(M, pts), ApproxConv.jl:36-42
+  rc = launch_bandwidth(c, ds, dm, (int)js.size(), coords_of(jm.data(), jm.size()));  // manikde!(M, pts), ApproxConv.jl:36-42
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
@@ -740,7 +748,7 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   if (rc) return rc;
   rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n), products_uniform_manifold(descs, n));
   if (rc) return rc;
-  rc = launch_bandwidth(c, ds, dm, (int)js.size());  // rebandwidth of the product
+  rc = launch_bandwidth(c, ds, dm, (int)js.size(), coords_of(jm.data(), jm.size()));  // rebandwidth of the product
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
@@ -900,7 +908,7 @@ nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *ma
   nbp_status rc = stage_upload(c, both.data(), both.size() * 4);
   if (rc) return rc;
   const int32_t *ds = (const int32_t *)c->stage;
-  rc = launch_bandwidth(c, ds, ds + n, n);
+  rc = launch_bandwidth(c, ds, ds + n, n, coords_of(manifolds, (size_t)n));
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
   return NBP_OK;
@@ -1235,13 +1243,13 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
     const nbp_stage &st = p->stages[s];
     const int nent = (int)st.ent_s.size();
     nbp_status rc = NBP_OK;
-    if (st.flush_before) rc = launch_bandwidth(c, ent_s(st), ent_s(st) + nent, nent);
+    if (st.flush_before) rc = launch_bandwidth(c, ent_s(st), ent_s(st) + nent, nent, coords_of(st.ent_m.data(), st.ent_m.size()));
     if (rc) return rc;
     if (st.kind == NBP_STAGE_PROPOSALS) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
-      if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd);
+      if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd, coords_of(st.ent_m.data(), st.ent_m.size()));
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd, st.mani);
     } else if (st.kind == NBP_STAGE_DECONV) {
       rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);
@@ -1254,7 +1262,7 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
   }
   // leave every slot consistent: run whatever is still pending at the end of the range
   const nbp_stage &nx = p->stages[last];
-  return launch_bandwidth(c, ent_s(nx), ent_s(nx) + nx.ent_s.size(), (int)nx.ent_s.size());
+  return launch_bandwidth(c, ent_s(nx), ent_s(nx) + nx.ent_s.size(), (int)nx.ent_s.size(), coords_of(nx.ent_m.data(), nx.ent_m.size()));
 }
 
 nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
