@@ -13,6 +13,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the entry points are resolved with dlsym (see rccl_api)
 
+#ifndef NBP_TU
+#define NBP_TU 0  // host code: the kernels live in the nbp_k_*.hip files (-DNBP_TU=0xFFFF: single-file build with every kernel)
+#endif
 #include "nbp_kernels.h"
 
 static thread_local std::string g_err;

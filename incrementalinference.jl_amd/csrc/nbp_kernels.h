@@ -8,6 +8,20 @@
 #include <type_traits>
 #include "nbp_device.h"
 
+// Translation units: libnbp is built from several .hip files in parallel (tools/build_lib.py), each defining one group of
+// kernels (NBP_TU = the groups this file defines; everything else is declared only, so that the host code in nbp_api.hip
+// can launch it).  A file that does not set NBP_TU defines every kernel (single-file build).
+#define NBP_TU_PROPOSAL 1   // proposal / deconv kernels + the small copy / reseed / resample kernels
+#define NBP_TU_PREP 2       // bandwidth fits + KD builds, sequential search
+#define NBP_TU_PREPSPEC 4   // the same with the speculative search
+#define NBP_TU_PRODLAT 8    // product kernels, latency geometries (x16, l8)
+#define NBP_TU_PRODTHR 16   // product kernels, throughput geometries, generic (m4, t2)
+#define NBP_TU_PRODUNI 32   // product kernels, throughput geometries, one manifold per instance
+#define NBP_TU_FUSED 64     // the fused variable-update kernels
+#ifndef NBP_TU
+#define NBP_TU 0xFFFF
+#endif
+
 // ================================================================================================
 // Proposal kernel: one workgroup = one approxConvBelief (ApproxConv.jl:4-45)
 //   evalFactor -> evalPotentialSpecific (EvalFactor.jl:321-395 relative, :400-542 prior)
@@ -335,21 +349,29 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *descs, do
   }
 }
 
+#define NBP_PROPOSAL_ARGS const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side, nbp_counters *ctr
+#if NBP_TU & NBP_TU_PROPOSAL
 __global__ void __launch_bounds__(512)
-nbp_proposal_kernel(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side,
-                    nbp_counters *ctr) {
+nbp_proposal_kernel(NBP_PROPOSAL_ARGS) {
   extern __shared__ double smem[];
   proposal_body<0, 0>(descs, arena, N, Npad, S, side, ctr, smem);
 }
+#else
+__global__ void nbp_proposal_kernel(NBP_PROPOSAL_ARGS);
+#endif
 // one relative-factor kind on one manifold (the odometry chains of the BASELINE configs): lin2 = LinearRelative on
 // Euclid(2) (configs 2 / 2p: -10 % proposal time), lin3 = LinearRelative on Euclid(3) (config 5: -7 %).  The circle
 // (config 3) gains nothing from its own instance: the registers there are the spread statistics', not the solver's
+#if NBP_TU & NBP_TU_PROPOSAL
 #define NBP_PROPOSAL_UNIFORM(NAME, K_, M_, WAVES)                                                                          \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES)))                                       \
-  NAME(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side, nbp_counters *ctr) {     \
+  NAME(NBP_PROPOSAL_ARGS) {                                                                                                \
     extern __shared__ double smem[];                                                                                       \
     proposal_body<K_, M_>(descs, arena, N, Npad, S, side, ctr, smem);                                                      \
   }
+#else
+#define NBP_PROPOSAL_UNIFORM(NAME, K_, M_, WAVES) __global__ void NAME(NBP_PROPOSAL_ARGS);
+#endif
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, 3)
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
 
@@ -358,6 +380,8 @@ NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
 // per particle: sample a measurement (the search start, returned as "measured"), then find the
 // measurement that zeroes the residual between the two stored variable points ("predicted").
 // ================================================================================================
+#define NBP_DECONV_ARGS const nbp_proposal_desc *descs, const int32_t *meas_slots, double *arena, int N, int64_t S, nbp_counters *ctr
+#if NBP_TU & NBP_TU_PROPOSAL
 __global__ void __launch_bounds__(512)
 nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, double *arena, int N, int64_t S, nbp_counters *ctr) {
   const nbp_proposal_desc *d = descs + blockIdx.x;
@@ -401,6 +425,9 @@ nbp_deconv_kernel(const nbp_proposal_desc *descs, const int32_t *meas_slots, dou
     atomicAdd(&ctr->residual_evals, (unsigned long long)v[3]);
   }
 }
+#else
+__global__ void nbp_deconv_kernel(NBP_DECONV_ARGS);
+#endif
 
 static inline size_t nbp_proposal_lds_bytes(int N) { return ((size_t)3 * N + NBP_RED) * 8 + (size_t)N * 4; }
 
@@ -439,25 +466,36 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
 // the D per-coordinate fits of a KDE are independent.  Used for proposals (ApproxConv.jl:36-42),
 // for the rebandwidth of products and for nbp_run_bandwidth.
 // ================================================================================================
+#define NBP_BANDWIDTH_ARGS const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S, nbp_counters *ctr
+#if NBP_TU & NBP_TU_PREP
 __global__ void __launch_bounds__(1024)
-nbp_bandwidth_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S, nbp_counters *ctr) {
+nbp_bandwidth_kernel(NBP_BANDWIDTH_ARGS) {
   extern __shared__ double smem[];  // grid (jobs, 3)
   lcv_slot_coordinate<0>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
 }
+#else
+__global__ void nbp_bandwidth_kernel(NBP_BANDWIDTH_ARGS);
+#endif
+#if NBP_TU & NBP_TU_PREPSPEC
 template <int DEPTH>
 __global__ void __launch_bounds__(1024)
-nbp_bandwidth_kernel_spec(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S,
-                          nbp_counters *ctr, nbp_spec_area *spec) {
+nbp_bandwidth_kernel_spec(NBP_BANDWIDTH_ARGS, nbp_spec_area *spec) {
   extern __shared__ double smem[];  // grid (jobs, 3, 2^DEPTH - 1)
   lcv_slot_coordinate<DEPTH>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr,
                              spec + (blockIdx.x * 3 + blockIdx.y), blockIdx.z);
 }
+template __global__ void nbp_bandwidth_kernel_spec<2>(NBP_BANDWIDTH_ARGS, nbp_spec_area *spec);
+template __global__ void nbp_bandwidth_kernel_spec<3>(NBP_BANDWIDTH_ARGS, nbp_spec_area *spec);
+#else
+template <int DEPTH> __global__ void nbp_bandwidth_kernel_spec(NBP_BANDWIDTH_ARGS, nbp_spec_area *spec);
+#endif
 
 // X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
 static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
   return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_LCVTAB) * 8;
 }
 
+#if NBP_TU & NBP_TU_PROPOSAL
 __global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S) {
   const double *src = arena + S * c[blockIdx.x].src_slot;
   double *dst = arena + S * c[blockIdx.x].dst_slot;
@@ -471,6 +509,10 @@ __global__ void nbp_copy_points_kernel(const nbp_copy_desc *c, double *arena, in
   for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) dst[i] = src[i];
   if (threadIdx.x == 0) dst[3 * N + 6] = src[3 * N + 6];  // the particle count belongs to the points
 }
+#else
+__global__ void nbp_copy_kernel(const nbp_copy_desc *c, double *arena, int64_t S);
+__global__ void nbp_copy_points_kernel(const nbp_copy_desc *c, double *arena, int64_t S, int N);
+#endif
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -479,6 +521,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+#if NBP_TU & NBP_TU_PROPOSAL
 // re-key every op of a resident program: seed <- splitmix64(seed ^ splitmix64(salt)) (seeds.py mix_seed)
 __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, uint64_t salt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -487,6 +530,9 @@ __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, ui
     *s = splitmix64(*s ^ splitmix64(salt));
   }
 }
+#else
+__global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, uint64_t salt);
+#endif
 
 // ================================================================================================
 // AMP.manifoldProduct(dens, M; Niter, N) + setBelief!  (GraphProductOperations.jl:53-60,
@@ -671,9 +717,13 @@ __device__ __forceinline__ void topup_slot(double *s, int N, int manifold, uint6
   __syncthreads();
   if (threadIdx.x == 0) s[3 * N + 6] = 0.0;
 }
+#if NBP_TU & NBP_TU_PROPOSAL
 __global__ void nbp_resample_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int64_t S, uint64_t seed) {
   topup_slot(arena + S * slots[blockIdx.x], N, manifolds[blockIdx.x], seed + 0x9E3779B97F4A7C15ull * (uint64_t)(blockIdx.x + 1));
 }
+#else
+__global__ void nbp_resample_kernel(const int32_t *slots, const int32_t *manifolds, double *arena, int N, int64_t S, uint64_t seed);
+#endif
 
 static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
   return ((size_t)D * N + 3 * Npad + NBP_RED + 2 * NBP_KD_PARTS) * 8 + ((size_t)2 * N + (size_t)P * Npad + 2) * 4;
@@ -704,20 +754,30 @@ __device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t
   default: kd_build<3>(x, wsj, N, Npad, T, smem, mask); break;
   }
 }
+#define NBP_PREP_ARGS const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF, \
+                      double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr
+#if NBP_TU & NBP_TU_PREP
 __global__ void __launch_bounds__(1024)
-nbp_prep_kernel(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
-                double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr) {
+nbp_prep_kernel(NBP_PREP_ARGS) {
   extern __shared__ double smem[];
   prep_body<0>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, nullptr, smem);
 }
+#else
+__global__ void nbp_prep_kernel(NBP_PREP_ARGS);
+#endif
 // latency mode: 2^DEPTH - 1 workgroups per fit (lcv_bandwidth_1d_spec)
+#if NBP_TU & NBP_TU_PREPSPEC
 template <int DEPTH>
 __global__ void __launch_bounds__(1024)
-nbp_prep_kernel_spec(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
-                     double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr, nbp_spec_area *spec) {
+nbp_prep_kernel_spec(NBP_PREP_ARGS, nbp_spec_area *spec) {
   extern __shared__ double smem[];
   prep_body<DEPTH>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, spec, smem);
 }
+template __global__ void nbp_prep_kernel_spec<2>(NBP_PREP_ARGS, nbp_spec_area *spec);
+template __global__ void nbp_prep_kernel_spec<3>(NBP_PREP_ARGS, nbp_spec_area *spec);
+#else
+template <int DEPTH> __global__ void nbp_prep_kernel_spec(NBP_PREP_ARGS, nbp_spec_area *spec);
+#endif
 
 // Gibbs geometry: HL adjacent lanes of ONE wave serve one output sample (a wave carries 64/HL samples).
 // The helpers of a sample split the nodes of a level into contiguous ranges and combine their shares
@@ -1126,6 +1186,7 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
 // Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in
 // flight) keep everything in registers (236 VGPRs); the throughput variants trade a few spills for 4-5 waves per SIMD.
 #define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
+#if NBP_TU & NBP_TU_PRODLAT
 __global__ void __launch_bounds__(512) nbp_product_kernel_x16(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<16>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
@@ -1134,6 +1195,11 @@ __global__ void __launch_bounds__(512) nbp_product_kernel_l8(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<8>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
+#else
+__global__ void nbp_product_kernel_x16(NBP_PRODUCT_ARGS);
+__global__ void nbp_product_kernel_l8(NBP_PRODUCT_ARGS);
+#endif
+#if NBP_TU & NBP_TU_PRODTHR
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) nbp_product_kernel_m4(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<4>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
@@ -1142,6 +1208,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) n
   extern __shared__ double smem[];
   product_kernel_body<2>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
+#else
+__global__ void nbp_product_kernel_m4(NBP_PRODUCT_ARGS);
+__global__ void nbp_product_kernel_t2(NBP_PRODUCT_ARGS);
+#endif
 // waves per SIMD of the single-manifold kernels, measured (profiles/r02_product_waves.txt): Euclid(1/2) are faster at 4
 // (Euclid(2) then spills 76 B per lane; at 3 it is spill-free but 16 % slower on the 10 000-variable chain), Euclid(3),
 // Circular and SE(2) at 3 (140-168 VGPRs: no scratch on Euclid(3), 36 / 120 B on the circular ones; 1-3 % faster)
@@ -1152,11 +1222,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) n
 #define NBP_W_SE 2
 #endif
 #define NBP_PRODUCT_UNIFORM(NAME, MANI, HL) NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, ((MANI) == NBP_EUCLID1 ? 4 : (MANI) == NBP_EUCLID2 ? NBP_W_E2 : (MANI) == NBP_SE2 ? NBP_W_SE : 3))
+#if NBP_TU & NBP_TU_PRODUNI
 #define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES)                                                                        \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME(NBP_PRODUCT_ARGS) { \
     extern __shared__ double smem[];                                                                               \
     product_kernel_uniform<MANI, HL>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                           \
   }
+#else
+#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) __global__ void NAME(NBP_PRODUCT_ARGS);
+#endif
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e1, NBP_EUCLID1, 2)
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e2, NBP_EUCLID2, 2)
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e3, NBP_EUCLID3, 2)
