@@ -314,7 +314,9 @@ function factorspec(fct::DFGFactor, index::Dict{Symbol, Int})::NbpFactorSpec
                        Float64(ccw.nullhypo), Float64(ccw.inflation), Tuple(components(fnc)))
 end
 
-solverparams(sp, N::Int) = NbpSolverParams(Int32(N), Int32(sp.gibbsIters), Int32(sp.inflateCycles), Int32(1),
+# `iters`: the Gibbs iterations of the iterated variables -- upGibbsCliqueDensity's own argument (SolveTree.jl:171,216-227),
+# MCIters of the down solve; SolverParams.gibbsIters where the caller has neither
+solverparams(sp, N::Int, iters::Int = sp.gibbsIters) = NbpSolverParams(Int32(N), Int32(iters), Int32(sp.inflateCycles), Int32(1),
                                            Int32(sp.upsolve), Int32(sp.downsolve), Int32(sp.limitfixeddown),
                                            sp.alwaysFreshMeasurements ? Int32(0) : NBP_SOLVER_STORED_MEASUREMENTS,
                                            Float64(sp.spreadNH), Float64(sp.inflation), Float64(sp.nullSurplusAdd))
@@ -431,14 +433,19 @@ function unpack!(dfg::AbstractDFG, p::CliquePack, solveKey::Symbol, N::Int, whic
     l in which || continue
     vt = getVariableType(dfg, l)
     b = p.bufs[i]
-    setValKDE!(getSolverData(getVariable(dfg, l), solveKey), wrappoints(vt, p.codes[i], b.pts, N), reshape(b.bw, :, 1), true, b.ipc)
+    # the count libnbp wrote back: N for a solved belief, the density's own count when the variable's only factor is a
+    # PartialPriorPassThrough ("PassThrough transfers the full point count to the graph", testSpecialEuclidean2Mani.jl:394)
+    n = Int(p.beliefs[i].n_pts)
+    (1 <= n <= N) || error("libnbp: belief $(l) came back with $(n) points")
+    setValKDE!(getSolverData(getVariable(dfg, l), solveKey), wrappoints(vt, p.codes[i], b.pts, n), reshape(b.bw, :, 1), true, b.ipc)
   end
   return nothing
 end
 
-function runclique(sym::Symbol, dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, p::CliquePack, nfr::Int, nsep::Int, seed::UInt64)
+function runclique(sym::Symbol, dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, p::CliquePack, nfr::Int, nsep::Int, seed::UInt64,
+                   iters::Int = getSolverParams(dfg).gibbsIters)
   q = cliquedesc(cliq, p, nfr, nsep)
-  sp = solverparams(getSolverParams(dfg), N)
+  sp = solverparams(getSolverParams(dfg), N, iters)
   status = Ref{Int32}(0)
   GC.@preserve p begin
     need = chk(ccall((:nbp_clique_slots, libnbp), Int32, (Ref{NbpCliqueDesc},), q))
@@ -473,10 +480,13 @@ function upGibbsCliqueDensity(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symb
   all(supported, factors) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
                                            dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)      # generic CPU path
   p = packclique(dfg, cliq, solveKey, N, labels, factors)
-  runclique(:up, dfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64))
-  unpack!(dfg, p, solveKey, N, labels)
+  runclique(:up, dfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64), iters)
+  # what the four fmcmc! calls of the reference touch (SolveTree.jl:193-235): marginalized variables are skipped inside
+  # fmcmc! (:61) but still reported by compileFMCMessages (:32-45), so the lists decide, not the margin flags
+  touched = Symbol[l for l in labels if l in cd.directFrtlMsgIDs || l in cd.msgskipIDs || l in cd.itervarIDs || l in cd.directPriorMsgIDs]
+  unpack!(dfg, p, solveKey, N, [l for (i, l) in enumerate(labels) if l in touched && p.margin[i] == 0])
   d = Dict{Symbol, TreeBelief}()
-  for l in labels                                            # compileFMCMessages, SolveTree.jl:32-45
+  for l in touched                                           # compileFMCMessages, SolveTree.jl:32-45
     d[l] = TreeBelief(getVariable(dfg, l), solveKey)
   end
   return d

@@ -209,7 +209,8 @@ nbp_status nbp_slot_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *p
  * (CalcFactor.jl:555-565), a MsgPrior / KDE measurement samples among the points it has, the oldPoints of a product are
  * topped up with sample(oldBel, N - Npts) (GraphProductOperations.jl:39-45), manikde! fits the points there are; every
  * kernel output holds N points.  More than N: the first N are kept (`_pts[1:N]`, GraphProductOperations.jl:44).
- * nbp_belief_read returns the count in *n_pts and fills the first *n_pts points. */
+ * nbp_belief_read returns the count in *n_pts and fills the first *n_pts points (at most N rows: size `pts` for the N of the
+ * context unless the count is known); with n_pts = NULL (nbp_slot_read) all N rows of the slot are written. */
 nbp_status nbp_belief_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP, int32_t n_pts,
                             const double *bw_D /* nullable */, const double *ipc_D /* nullable: zeros */);
 nbp_status nbp_belief_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP, int32_t *n_pts /* nullable */,

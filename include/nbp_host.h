@@ -168,10 +168,12 @@ nbp_status nbp_tree_get_stats(const nbp_tree *t, nbp_tree_stats *out);
 
 /* TreeBelief (entities/BeliefTypes.jl:47-57): val, bw, infoPerCoord; host buffers owned by the caller */
 typedef struct nbp_tree_belief {
-  double *pts;      /* n_pts x P doubles, packed AoS like nbp_slot_write                          */
+  double *pts;      /* room for N x P doubles (N of the context), packed AoS like nbp_slot_write: in, the first
+                       n_pts rows are read; out, n_pts rows are written (a solved belief holds N points, a belief
+                       whose only factor is a pass-through density keeps that density's count)              */
   double *bw;       /* D                                                                          */
   double *ipc;      /* D: infoPerCoord (in: may be NULL = zeros; out: written when not NULL)      */
-  int32_t n_pts;    /* in: particles held (this version: == N); out: N                            */
+  int32_t n_pts;    /* in: particles held (<= N; fewer than N needs bw); out: particles written             */
   int32_t reserved_;
 } nbp_tree_belief;
 

@@ -39,8 +39,11 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
 #define NBP_SPEC_MAXJOBS 40
 #define NBP_SPEC_MAXBLOCKS 224
 struct nbp_program;
+struct nbp_comm;
 struct nbp_ctx {
   std::vector<nbp_program *> programs;  // live programs: detached (device blob freed, ctx = null) by nbp_ctx_destroy
+  std::vector<nbp_comm *> comms;        // live communicators: shut down (and detached) by nbp_ctx_destroy
+  uint64_t ws_gen = 0;  // bumped whenever a workspace a captured launch sequence holds by value (ws, gstats) is re-allocated
   int device = 0, N = 0, n_slots = 0, side_ints = 0, threads = 0, Npad = 0, P = 1;
   int64_t S = 0;
   double *arena = nullptr;
@@ -218,6 +221,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
 }
 
 static void program_detach(nbp_program *p);
+static void ctx_detach_comms(nbp_ctx *c);
 
 nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (!c) return NBP_OK;
@@ -225,6 +229,7 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   for (nbp_program *p : c->programs) program_detach(p);  // a program outliving its context must not touch it
   c->programs.clear();
+  ctx_detach_comms(c);  // likewise a communicator: shut down now, its handle stays valid for nbp_comm_destroy
   for (auto &v : c->ev)
     for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   if (c->own_arena) hipFree(c->arena);
@@ -295,7 +300,11 @@ nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *p
   std::vector<double> s(c->S);
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipMemcpy(s.data(), c->arena + c->S * slot, c->S * 8, hipMemcpyDeviceToHost));
-  for (int n = 0; n < N; n++) {
+  // with n_pts: the rows the belief holds (the caller sized `pts` by the count it expects back, at most N); without
+  // (nbp_slot_read): all N rows of the slot
+  const int cnt_held = (s[3 * N + 6] > 0.0 && s[3 * N + 6] < (double)N) ? (int)s[3 * N + 6] : N;
+  const int rows = n_pts ? cnt_held : N;
+  for (int n = 0; n < rows; n++) {
     double *p = pts + (size_t)n * P;
     if (manifold == NBP_SE2) {
       double th = s[2 * N + n];
@@ -309,7 +318,7 @@ nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *p
     for (int d = 0; d < D; d++) bw[d] = s[3 * N + d];
   if (ipc)
     for (int d = 0; d < D; d++) ipc[d] = s[3 * N + 3 + d];
-  if (n_pts) *n_pts = (s[3 * N + 6] > 0.0 && s[3 * N + 6] < (double)N) ? (int)s[3 * N + 6] : N;
+  if (n_pts) *n_pts = cnt_held;
   return NBP_OK;
 }
 
@@ -466,6 +475,7 @@ static nbp_status ensure_ws(nbp_ctx *c, int nprod, int kdF) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->ws) HIPCHK(hipFree(c->ws));
   c->ws = nullptr;
+  c->ws_gen++;  // captured graphs hold the old pointer as a kernel argument: they are re-captured before their next replay
   c->ws_doubles = need + need / 4 + 16 * nbp_kd_ws_doubles(c->N);
   HIPCHK(hipMalloc(&c->ws, c->ws_doubles * 8));
   return NBP_OK;
@@ -475,6 +485,7 @@ static nbp_status ensure_gstats(nbp_ctx *c, size_t need) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->gstats) HIPCHK(hipFree(c->gstats));
   c->gstats = nullptr;
+  c->ws_gen++;
   c->gstats_doubles = need + need / 4;
   HIPCHK(hipMalloc(&c->gstats, c->gstats_doubles * 8));
   return NBP_OK;
@@ -963,7 +974,8 @@ struct nbp_program {
   bool use_graph = true; // NBP_OPT_GRAPH_REPLAY
   int n_user_stages = 0;
   // captured launch sequences of nbp_program_run(first, last): key = first * 2^32 + last
-  std::unordered_map<uint64_t, hipGraphExec_t> graphs;
+  struct captured { hipGraphExec_t exec; uint64_t ws_gen; };  // ws_gen: the context's workspace generation at capture time
+  std::unordered_map<uint64_t, captured> graphs;
   std::unordered_map<uint64_t, int> runs;
   size_t seed_off = 0;  // table of the blob offsets of every descriptor's seed field (one reseed launch)
   int n_seeds = 0;
@@ -979,7 +991,7 @@ nbp_status nbp_program_create(nbp_ctx *c, nbp_program **out) {
 }
 // the context is going away: free the device blob while the context's device is still current
 static void program_detach(nbp_program *p) {
-  for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second);
+  for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second.exec);
   p->graphs.clear();
   if (p->dev) hipFree(p->dev);
   p->dev = nullptr;
@@ -1152,6 +1164,13 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       const nbp_product_desc *qd0 = (const nbp_product_desc *)d;
       st.need_prep = false;
       for (int i = 0; i < st.n; i++) st.need_prep |= qd0[i].nfactors > 1;
+      // the prep launch tops up the oldPoints of a partial product in place (topup_slot: reads the slot's bandwidth and
+      // count, writes points and count) beside the fits of the same launch: a fit still pending for that very slot would
+      // race with it, so such fits run first, in a launch of their own
+      for (int i = 0; i < st.n && !st.flush_before; i++)
+        if (qd0[i].nfactors > 1 && qd0[i].old_slot >= 0)
+          for (int32_t ps : pend_s) st.flush_before |= (ps == qd0[i].old_slot);
+      if (st.flush_before) { pend_s.clear(); pend_m.clear(); }
       if (st.need_prep) {
         pend_s.clear(); pend_m.clear();  // the entry fits run inside this stage's prep launch
       } else {
@@ -1283,6 +1302,14 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   if (c->timing || !p->use_graph || last - first < 4) return run_range(p, first, last);
   const uint64_t key = ((uint64_t)(uint32_t)first << 32) | (uint32_t)last;
   auto it = p->graphs.find(key);
+  if (it != p->graphs.end() && it->second.ws_gen != c->ws_gen) {
+    // a workspace was re-allocated since the capture (another program finalized on this context, an immediate-mode
+    // call with a larger batch, a clique call): the graph's kernel nodes hold the freed pointer -- capture again
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipGraphExecDestroy(it->second.exec);
+    p->graphs.erase(it);
+    it = p->graphs.end();
+  }
   if (it == p->graphs.end() && p->runs[key]++ == 0) return run_range(p, first, last);  // a program that runs once never pays for a capture
   if (it == p->graphs.end()) {
     hipGraph_t g = nullptr;
@@ -1303,9 +1330,9 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
       p->use_graph = false;
       return run_range(p, first, last);
     }
-    it = p->graphs.emplace(key, ge).first;
+    it = p->graphs.emplace(key, nbp_program::captured{ge, c->ws_gen}).first;
   }
-  HIPCHK(hipGraphLaunch(it->second, c->stream));
+  HIPCHK(hipGraphLaunch(it->second.exec, c->stream));
   return NBP_OK;
   // asynchronous: nbp_synchronize / nbp_slot_read wait for completion
 }
@@ -1335,7 +1362,7 @@ nbp_status nbp_program_destroy(nbp_program *p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     if (p->dev) hipFree(p->dev);
-    for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second);
+    for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second.exec);
     auto &v = p->ctx->programs;
     for (size_t i = 0; i < v.size(); i++)
       if (v[i] == p) { v.erase(v.begin() + i); break; }
@@ -1393,9 +1420,23 @@ static nbp_status rccl_load() {
 
 struct nbp_comm {
   ncclComm_t comm = nullptr;
-  nbp_ctx *ctx = nullptr;
+  nbp_ctx *ctx = nullptr;  // null once the context is gone (nbp_ctx_destroy shuts the communicator down first)
   int world = 0, rank = 0;
 };
+static void comm_shutdown(nbp_comm *m) {
+  if (m->comm && m->ctx && g_rccl.CommDestroy) {
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    g_rccl.CommDestroy(m->comm);
+  }
+  m->comm = nullptr;
+  m->ctx = nullptr;
+}
+// called by nbp_ctx_destroy while the stream still exists
+static void ctx_detach_comms(nbp_ctx *c) {
+  for (nbp_comm *m : c->comms) comm_shutdown(m);
+  c->comms.clear();
+}
 
 nbp_status nbp_comm_unique_id(void *id_out) {
   if (!id_out) return fail(NBP_ERR_ARG, "null argument");
@@ -1420,23 +1461,26 @@ nbp_status nbp_comm_create(nbp_ctx *c, int32_t world, int32_t rank, const void *
   m->ctx = c; m->world = world; m->rank = rank;
   ncclResult_t r = g_rccl.CommInitRank(&m->comm, world, uid, rank);
   if (r != ncclSuccess) { delete m; return fail(NBP_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+  c->comms.push_back(m);
   *out = m;
   return NBP_OK;
 }
 
 nbp_status nbp_comm_destroy(nbp_comm *m) {
   if (!m) return NBP_OK;
-  if (m->comm && g_rccl.CommDestroy) {
-    hipSetDevice(m->ctx->device);
-    hipStreamSynchronize(m->ctx->stream);
-    g_rccl.CommDestroy(m->comm);
+  if (m->ctx) {
+    auto &v = m->ctx->comms;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i] == m) { v.erase(v.begin() + i); break; }
   }
+  comm_shutdown(m);  // nothing left to do when the context went first
   delete m;
   return NBP_OK;
 }
 
 nbp_status nbp_exchange(nbp_ctx *c, nbp_comm *m, const nbp_xfer *sends, int32_t ns, const nbp_xfer *recvs, int32_t nr) {
   if (!c || !m || (ns > 0 && !sends) || (nr > 0 && !recvs)) return fail(NBP_ERR_ARG, "null argument");
+  if (!m->ctx || !m->comm) return fail(NBP_ERR_ARG, "exchange: the communicator's context was destroyed");
   if (m->ctx != c) return fail(NBP_ERR_ARG, "exchange: the communicator belongs to another context");
   for (int i = 0; i < ns; i++)
     if (sends[i].peer < 0 || sends[i].peer >= m->world || sends[i].slot < 0 || sends[i].slot >= c->n_slots) return fail(NBP_ERR_RANGE, "exchange: send");
@@ -1445,9 +1489,20 @@ nbp_status nbp_exchange(nbp_ctx *c, nbp_comm *m, const nbp_xfer *sends, int32_t 
   if (ns + nr == 0) return NBP_OK;
   HIPCHK(hipSetDevice(c->device));
   RCCLCHK(g_rccl.GroupStart());
-  for (int i = 0; i < ns; i++) RCCLCHK(g_rccl.Send(c->arena + c->S * sends[i].slot, (size_t)c->S, ncclDouble, sends[i].peer, m->comm, c->stream));
-  for (int i = 0; i < nr; i++) RCCLCHK(g_rccl.Recv(c->arena + c->S * recvs[i].slot, (size_t)c->S, ncclDouble, recvs[i].peer, m->comm, c->stream));
-  RCCLCHK(g_rccl.GroupEnd());
+  // a failing Send / Recv must not leave the group open for the rest of the process: close it, then report the first error
+  ncclResult_t bad = ncclSuccess;
+  const char *what = "";
+  for (int i = 0; i < ns && bad == ncclSuccess; i++) {
+    bad = g_rccl.Send(c->arena + c->S * sends[i].slot, (size_t)c->S, ncclDouble, sends[i].peer, m->comm, c->stream);
+    what = "ncclSend";
+  }
+  for (int i = 0; i < nr && bad == ncclSuccess; i++) {
+    bad = g_rccl.Recv(c->arena + c->S * recvs[i].slot, (size_t)c->S, ncclDouble, recvs[i].peer, m->comm, c->stream);
+    what = "ncclRecv";
+  }
+  const ncclResult_t ge = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) return fail(NBP_ERR_HIP, std::string(what) + ": " + g_rccl.GetErrorString(bad));
+  if (ge != ncclSuccess) return fail(NBP_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
   return NBP_OK;  // stream-ordered: the next launch on the library stream sees the received slots
 }
 

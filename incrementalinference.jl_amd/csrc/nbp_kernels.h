@@ -121,16 +121,16 @@ __device__ __forceinline__ double var_distance_expected_fractional(const nbp_pro
 // message priors and pass-through densities of that manifold may ride along): the solver dispatch and the partial
 // branches fold away, and with them the registers of the largest solver (the generic kernel holds the SE(2) simplex)
 template <int FIXK, int FIXM>
-__device__ __forceinline__ void proposal_body(const nbp_proposal_desc *descs, double *arena, int N, int Npad, int64_t S, int32_t *side,
+// `d`: the op; `out`: where the proposal goes -- the slot d->out_slot of the arena, or (fused update kernel) a slot-shaped
+// area of the workgroup's LDS
+__device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double *out, double *arena, int N, int Npad, int64_t S, int32_t *side,
                                               nbp_counters *ctr, double *smem) {
   double *X = smem;                 // [3][N]
   double *red = X + 3 * N;          // [NBP_RED]
   int *mh = (int *)(red + NBP_RED); // [N]
   __shared__ recipe_t R;
-  const nbp_proposal_desc *d = descs + blockIdx.x;
   const int n = threadIdx.x, M = FIXK ? FIXM : d->manifold, D = mani_dim(M), kind = d->factor_kind;
   const bool live = n < N;  // lanes (i < N, p == 0) own a particle
-  double *out = arena + S * d->out_slot;
   unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
 
   NBP_CTICK_INIT();
@@ -354,7 +354,7 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *descs, do
 __global__ void __launch_bounds__(512)
 nbp_proposal_kernel(NBP_PROPOSAL_ARGS) {
   extern __shared__ double smem[];
-  proposal_body<0, 0>(descs, arena, N, Npad, S, side, ctr, smem);
+  proposal_body<0, 0>(descs + blockIdx.x, arena + S * descs[blockIdx.x].out_slot, arena, N, Npad, S, side, ctr, smem);
 }
 #else
 __global__ void nbp_proposal_kernel(NBP_PROPOSAL_ARGS);
@@ -367,7 +367,7 @@ __global__ void nbp_proposal_kernel(NBP_PROPOSAL_ARGS);
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES)))                                       \
   NAME(NBP_PROPOSAL_ARGS) {                                                                                                \
     extern __shared__ double smem[];                                                                                       \
-    proposal_body<K_, M_>(descs, arena, N, Npad, S, side, ctr, smem);                                                      \
+    proposal_body<K_, M_>(descs + blockIdx.x, arena + S * descs[blockIdx.x].out_slot, arena, N, Npad, S, side, ctr, smem);  \
   }
 #else
 #define NBP_PROPOSAL_UNIFORM(NAME, K_, M_, WAVES) __global__ void NAME(NBP_PROPOSAL_ARGS);
@@ -565,8 +565,11 @@ __host__ __device__ inline size_t nbp_kd_ws_doubles(int N) { return nbp_kd_stats
 // inside each segment (P helper lanes per position, no sort network).
 #define NBP_KD_PARTS 512
 template <int D>
-__device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, int Npad, const nbp_levels &T, double *smem,
-                                         int mask /* coordinates the density informs */) {
+// Outputs: xs[D][N] the sorted, centred coordinates (may be `x` itself: the points are staged before anything is
+// written), cen[D] the centres, widx[N] the permutation, st = the node sums of every level (null: the caller takes them
+// from xs itself -- the fused update kernel keeps the tree in LDS).
+__device__ __forceinline__ void kd_build(const double *x, double *xs, double *cen_out, int *widx, double *st, int N, int Npad, const nbp_levels &T,
+                                         double *smem, int mask /* coordinates the density informs */) {
   const int tid = threadIdx.x, TB = blockDim.x, P = TB / Npad, s = tid % Npad, sub = tid / Npad;
   double *raw = smem;                   // [D][N]
   double *ext = raw + (size_t)D * N;    // [3*Npad]
@@ -665,15 +668,14 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
     __syncthreads();
     int *t = pa; pa = pb; pb = t;
   }
-  int *widx = (int *)(wsj + 3 * N + 4);
   double *srt = ext;  // [D][Npad] sorted, centred coordinates (the extent scratch is free now)
 #pragma unroll
   for (int k = 0; k < D; k++) {
     double c = block_sum(tid < N ? raw[k * N + tid] : 0.0, red) / (double)N;
-    if (tid == 0) wsj[3 * N + k] = c;
+    if (tid == 0) cen_out[k] = c;
     if (tid < N) {
       const double v = raw[k * N + pa[tid]] - c;
-      wsj[k * N + tid] = v;
+      xs[k * N + tid] = v;
       srt[k * Npad + tid] = v;
     }
   }
@@ -681,9 +683,8 @@ __device__ __forceinline__ void kd_build(const double *x, double *wsj, int N, in
   __syncthreads();
   // node sums of every level (the moment-matched Gaussians of the product's multiscale sampler): done here,
   // beside the bandwidth fits of the same launch, so that the product kernel only reads them
-  {
+  if (st) {
     const int g0 = T.off[1], TOT = T.off[T.L] + T.cnt[T.L];
-    double *st = wsj + nbp_kd_stats_offset(N);
     const size_t cap = nbp_kd_nodes_cap(N);
     for (int item = tid; item < (TOT - g0) * D; item += TB) {
       const int g = g0 + item % (TOT - g0), k = item / (TOT - g0);
@@ -748,10 +749,12 @@ __device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t
   double *wsj = ws + (size_t)(p * kdF + j) * nbp_kd_ws_doubles(N);
   const int mask = d->in_partial[j] ? d->in_partial[j] : 7;
   if (j == 0 && d->old_slot >= 0) topup_slot(arena + S * d->old_slot, N, d->manifold, d->seed);  // oldPoints of the product
+  double *cenj = wsj + 3 * N, *stj = wsj + nbp_kd_stats_offset(N);
+  int *idxj = (int *)(wsj + 3 * N + 4);
   switch (mani_dim(d->manifold)) {
-  case 1: kd_build<1>(x, wsj, N, Npad, T, smem, 1); break;
-  case 2: kd_build<2>(x, wsj, N, Npad, T, smem, mask); break;
-  default: kd_build<3>(x, wsj, N, Npad, T, smem, mask); break;
+  case 1: kd_build<1>(x, wsj, cenj, idxj, stj, N, Npad, T, smem, 1); break;
+  case 2: kd_build<2>(x, wsj, cenj, idxj, stj, N, Npad, T, smem, mask); break;
+  default: kd_build<3>(x, wsj, cenj, idxj, stj, N, Npad, T, smem, mask); break;
   }
 }
 #define NBP_PREP_ARGS const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF, \
@@ -820,9 +823,22 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
 // BIG: the node statistics live in this workgroup's scratch in global memory (products with many densities; only the
 // latency geometries HL = 16 / 8 run them).  A compile-time switch: with a run-time one every access to the statistics
 // goes through a generic 64-bit pointer -- flat loads in the Gibbs loop and register pairs for what is an LDS offset.
-template <int MANI, bool PARTIAL, int HL, bool BIG>
+// FUSED (the fused update kernel, nbp_fused.h): the densities are the proposals this workgroup has just made -- sorted,
+// centred coordinates, centres, permutations and bandwidths in LDS (`fio`), node sums taken from the sorted coordinates
+// level by level (the same leaf-order sums kd_build leaves in the HBM workspace), the result into an LDS slot.
+#define NBP_FUSED_MAXF 4
+struct nbp_fused_io {
+  product_lds L;                      // the product's own LDS areas
+  const double *xs[NBP_FUSED_MAXF];   // [D][N] sorted, centred coordinates of density j
+  const int *idx[NBP_FUSED_MAXF];     // [N] permutation
+  const double *cen;                  // [F][3]
+  const double *bw;                   // [F][3]
+  double *out;                        // slot-shaped LDS area that receives the product's points
+};
+template <int MANI, bool PARTIAL, int HL, bool BIG, bool FUSED = false>
 __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int kdF, double *gstats,
-                                             int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
+                                             int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem,
+                                             const nbp_fused_io *fio = nullptr) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
   const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
@@ -832,11 +848,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   const bool live = s < N;
   constexpr bool big = BIG;
   product_lds L;
-  product_lds_layout(F, D, N, SPB, big, smem, &L);
+  if constexpr (FUSED) L = fio->L;
+  else product_lds_layout(F, D, N, SPB, big, smem, &L);
   double *cen = L.cen, *h2 = L.h2;
   int *ind = L.ind;
-  double *out = arena + S * d->out_slot;
-  const double *wsp = ws + (size_t)blockIdx.x * kdF * nbp_kd_ws_doubles(N);
+  double *out = FUSED ? fio->out : arena + S * d->out_slot;
+  const double *wsp = FUSED ? nullptr : ws + (size_t)blockIdx.x * kdF * nbp_kd_ws_doubles(N);
   // node statistics: LDS, or (big) this workgroup's private scratch in global memory
   double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * nbp_product_gstats_doubles(F, D, N) : nullptr;
   double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv, *lr = big ? gs + 2 * (size_t)F * D * N : L.lr;
@@ -848,9 +865,9 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   const size_t stcap = nbp_kd_nodes_cap(N);
   for (int t = tid; t < F * 3; t += TB) {
     const int j = t / 3, k = t % 3;
-    const double bw = arena[S * d->in_slot[j] + 3 * N + k];
+    const double bw = FUSED ? fio->bw[t] : arena[S * d->in_slot[j] + 3 * N + k];
     h2[t] = (k < D) ? bw * bw : 0.0;
-    cen[t] = wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
+    cen[t] = FUSED ? ((k < D) ? fio->cen[t] : 0.0) : wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
   }
   int *nxt = ind + F * SPB;  // the child each selected node hands its label to on the next level
   if (h == 0)
@@ -864,9 +881,17 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       const int z = item % cnt, jk = item / cnt;
       const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
       const int j = jk / D, k = jk % D;
-      // the node sums were left by the KD build of this density (nbp_prep_kernel)
-      const double *st = wsp + (size_t)j * nbp_kd_ws_doubles(N) + nbp_kd_stats_offset(N) + (size_t)(k * 2) * stcap + off + z;
-      const double s1 = st[0], s2 = st[stcap];
+      double s1, s2;
+      if constexpr (FUSED) {  // the same sums in the same (leaf) order as kd_build's, from the tree in LDS
+        const double *srt = fio->xs[j] + k * N;
+        s1 = 0;
+        s2 = 0;
+        for (int p = lo; p < hi; p++) { const double v = srt[p]; s1 += v; s2 += v * v; }
+      } else {  // the node sums were left by the KD build of this density (nbp_prep_kernel)
+        const double *st = wsp + (size_t)j * nbp_kd_ws_doubles(N) + nbp_kd_stats_offset(N) + (size_t)(k * 2) * stcap + off + z;
+        s1 = st[0];
+        s2 = st[stcap];
+      }
       const double nn = (double)(hi - lo), mu = s1 / nn;
       double var = s2 / nn - mu * mu;
       if (var < 0) var = 0;
@@ -1080,6 +1105,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     else sweep(std::false_type{});
   }
   NBP_CTICK(40);
+  if constexpr (FUSED) __syncthreads();  // the result slot shares LDS with statistics the slower waves still read
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
   if (h == 0 && live) {
     double res[D];
@@ -1111,7 +1137,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     }
     if (d->labels_out >= 0)
       for (int j = 0; j < F; j++) {
-        const int *widx = (const int *)(wsp + (size_t)j * nbp_kd_ws_doubles(N) + 3 * N + 4);
+        const int *widx = FUSED ? fio->idx[j] : (const int *)(wsp + (size_t)j * nbp_kd_ws_doubles(N) + 3 * N + 4);
         side[d->labels_out + s * F + j] = widx[T.node_lo[T.off[T.L] + ind[j * SPB + sl]]];
       }
     // setBelief!: the rebandwidth rides with the next nbp_prep_kernel / nbp_bandwidth_kernel launch

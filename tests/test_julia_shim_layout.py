@@ -112,3 +112,103 @@ def test_shim_ccalls_name_exported_symbols():
     assert called and called <= set(abi.EXPORTS) | set(native_host.HOST_EXPORTS), called - set(abi.EXPORTS) - set(native_host.HOST_EXPORTS)
     for need in ("nbp_clique_upsolve", "nbp_clique_downsolve", "nbp_conv", "nbp_manifold_product", "nbp_kde_bandwidth", "nbp_ctx_create"):
         assert need in called
+
+
+# ---- every ccall's (return type, argument types) against the prototype in the headers -------------------------------
+# C type -> the set of Julia ccall argument types that pass it correctly (by value 4/8-byte scalars, pointers of any
+# pointee the header names: Ptr{T} / Ref{T} / Ptr{Cvoid}; a Julia Vector passed to Ptr{T} is its data pointer)
+_JL_STRUCT = {v: k for k, v in C_NAME.items()}
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def c_prototypes():
+    hdr = open(os.path.join(ROOT, "include", "nbp.h")).read() + open(os.path.join(ROOT, "include", "nbp_host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^\s*([\w ]+?[\w\*])\s*\b(nbp_\w+)\(([^;{]*?)\)\s*;", hdr, re.M | re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3)
+        if ret.startswith("typedef") or ret.startswith("#"):
+            continue
+        al = [] if args.strip() in ("", "void") else _split_top(" ".join(args.split()))
+        types = []
+        for a in al:
+            a = re.sub(r"\b(\w+)\s*(\[[^\]]*\])?$", "", a.strip()).strip() if not a.strip().endswith("*") else a.strip()  # drop the parameter name
+            types.append(a.replace("const ", "").replace(" const", "").replace(" ", ""))
+        protos[name] = (ret.replace("const ", "").replace(" ", ""), types)
+    return protos
+
+
+def _ok(ctype, jtype):
+    scal = {"int32_t": {"Int32", "Cint"}, "nbp_status": {"Int32", "Cint"}, "int64_t": {"Int64"}, "uint64_t": {"UInt64"},
+            "double": {"Float64", "Cdouble"}}
+    if ctype in scal:
+        return jtype in scal[ctype]
+    if ctype.endswith("**"):  # array of pointers
+        base = ctype[:-2]
+        return jtype in ("Ptr{Ptr{%s}}" % _jl_scalar(base), "Ptr{Ptr{Cvoid}}", "Ref{Ptr{Cvoid}}")
+    if ctype.endswith("*"):
+        base = ctype[:-1]
+        if base in ("void", "nbp_ctx", "nbp_program", "nbp_comm", "nbp_graph", "nbp_tree"):  # opaque handles
+            return jtype in ("Ptr{Cvoid}",)
+        if base == "char":
+            return jtype in ("Cstring", "Ptr{UInt8}", "Ptr{Cchar}")
+        j = _jl_scalar(base)
+        return jtype in ("Ptr{%s}" % j, "Ref{%s}" % j)
+    return False
+
+
+def _jl_scalar(base):
+    return {"int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint8_t": "UInt8", "double": "Float64"}.get(base, _JL_STRUCT.get(base, base))
+
+
+def shim_ccalls():
+    src = open(SHIM).read()
+    out = []
+    for m in re.finditer(r"ccall\(\(:(\w+), libnbp\),\s*([\w\{\}]+),\s*\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        args = src[m.end():i - 1]
+        out.append((m.group(1), m.group(2), [a for a in _split_top(" ".join(args.split())) if a]))
+    return out
+
+
+def test_shim_ccall_signatures_match_the_prototypes():
+    protos = c_prototypes()
+    calls = shim_ccalls()
+    assert len(calls) >= 8
+    for name, jret, jargs in calls:
+        assert name in protos, f"{name}: no prototype in include/"
+        cret, cargs = protos[name]
+        if cret.endswith("*"):
+            assert jret in ("Ptr{Cvoid}", "Cstring", "Ptr{UInt8}"), (name, cret, jret)
+        else:
+            assert _ok(cret, jret), (name, "return type", cret, jret)
+        assert len(jargs) == len(cargs), (name, "argument count", cargs, jargs)
+        for k, (ct, jt) in enumerate(zip(cargs, jargs)):
+            assert _ok(ct, jt), (name, f"argument {k}", ct, jt)
+
+
+def test_shim_forwards_iters_and_reports_only_touched_labels():
+    src = open(SHIM).read()
+    up = src[src.index("function upGibbsCliqueDensity"):src.index("function solveCliqDownFrontalProducts!")]
+    assert re.search(r"runclique\(:up,.*iters\)", up), "upGibbsCliqueDensity must forward its `iters` (SolveTree.jl:171,216-227)"
+    assert "for l in touched" in up and "directFrtlMsgIDs" in up and "directPriorMsgIDs" in up
+    assert "p.beliefs[i].n_pts" in src  # the count written back by libnbp, not N
