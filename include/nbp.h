@@ -287,13 +287,22 @@ nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *de
  * on, the bandwidth of such an intermediate belief is undefined between stages.
  * NBP_OPT_GRAPH_REPLAY (default 1): nbp_program_run captures the launch sequence of a stage range into a hipGraph the
  * second time it runs and replays the graph afterwards (one submission instead of ~3 launches per variable update).
- * Ignored while per-kernel timing is enabled. */
-enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2 };
+ * Ignored while per-kernel timing is enabled.
+ * NBP_OPT_FUSED_UPDATES (default 1): a PROPOSALS stage followed by the PRODUCTS stage that multiplies exactly its proposals
+ * (one round of Gibbs steps) may run as ONE launch of the fused update kernel -- proposals, their bandwidth fits, the KD
+ * trees, the product and the fit of the result in one workgroup per variable, with nothing but the operand beliefs and
+ * the new belief touching HBM -- when the round has at least NBP_FUSED_MIN updates (environment, read at nbp_ctx_create;
+ * unset = never: the fused form trades time for traffic) and its factors are of a class the kernel is built
+ * for; same particles and bandwidths as the three-launch form up to the rounding of sums taken in another order.
+ * nbp_program_run refuses a stage range that ends between the two stages of a fused pair. */
+enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2, NBP_OPT_FUSED_UPDATES = 3 };
 nbp_status nbp_program_set_option(nbp_program *prog, int32_t option, int32_t value);
 nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
 nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);
 nbp_status nbp_program_reseed(nbp_program *prog, uint64_t salt); /* xor-mix all op seeds on device */
 nbp_status nbp_program_num_stages(nbp_program *prog, int32_t *out);
+/* rounds of a finalized program that run as one launch of the fused update kernel (NBP_OPT_FUSED_UPDATES) */
+nbp_status nbp_program_num_fused(nbp_program *prog, int32_t *out);
 nbp_status nbp_program_destroy(nbp_program *prog);
 
 /* ---- separator exchange between ranks (one process per GPU) -------------------------------------------------------
@@ -319,6 +328,8 @@ nbp_status nbp_timing_enable(nbp_ctx *ctx, int32_t on);
 /* ms[4] / launches[4] per kernel: 0 = proposal kernel, 1 = prep kernel = bandwidth fits + KD-tree builds,
  *                      2 = product kernel, 3 = plain bandwidth kernel = early flushes; reset by the call */
 nbp_status nbp_timing_read(nbp_ctx *ctx, double *ms, int64_t *launches);
+/* the same with n <= 5 entries: 4 = the fused update kernel (NBP_OPT_FUSED_UPDATES); all five are reset by either call */
+nbp_status nbp_timing_read_n(nbp_ctx *ctx, double *ms, int64_t *launches, int32_t n);
 nbp_status nbp_diag_read(nbp_ctx *ctx, nbp_diag *out, int32_t reset);
 
 #ifdef __cplusplus

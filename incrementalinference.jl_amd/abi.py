@@ -16,6 +16,7 @@ DIST_GAUSSIAN, DIST_UNIFORM, DIST_RAYLEIGH = 0, 1, 2  # enum nbp_dist: family of
 STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES, STAGE_DECONV, STAGE_COPY_POINTS = 1, 2, 3, 4, 5
 OPT_LAZY_BANDWIDTH = 1
 OPT_GRAPH_REPLAY = 2
+OPT_FUSED_UPDATES = 3
 
 MANIFOLD_DIM = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 3}
 MANIFOLD_P = {EUCLID1: 1, EUCLID2: 2, EUCLID3: 3, CIRCULAR: 1, SE2: 6}
@@ -97,8 +98,8 @@ EXPORTS = [
     "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
     "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
-    "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_destroy",
-    "nbp_timing_enable", "nbp_timing_read", "nbp_diag_read",
+    "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_num_fused", "nbp_program_destroy",
+    "nbp_timing_enable", "nbp_timing_read", "nbp_timing_read_n", "nbp_diag_read",
     "nbp_comm_unique_id", "nbp_comm_create", "nbp_comm_destroy", "nbp_exchange",
 ]
 
@@ -171,6 +172,8 @@ def load_library(path=None):
     lib.nbp_exchange.argtypes = [vp, vp, C.POINTER(Xfer), i32, C.POINTER(Xfer), i32]
     lib.nbp_timing_enable.argtypes = [vp, i32]
     lib.nbp_timing_read.argtypes = [vp, dp, C.POINTER(i64)]
+    lib.nbp_timing_read_n.argtypes = [vp, dp, C.POINTER(i64), i32]
+    lib.nbp_program_num_fused.argtypes = [vp, C.POINTER(i32)]
     lib.nbp_diag_read.argtypes = [vp, C.POINTER(Diag), i32]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -206,19 +206,19 @@ class HipBackend:
         self._check(self.lib.nbp_exchange(self._ctx, self._comm, sx, len(sends), rx, len(recvs)))
 
     # ---- resident programs (clique seam) -----------------------------------------------------
-    def program(self, stages, lazy_bandwidth=False):
-        return HipProgram(self, stages, lazy_bandwidth)
+    def program(self, stages, lazy_bandwidth=False, fused_updates=True):
+        return HipProgram(self, stages, lazy_bandwidth, fused_updates)
 
     def timing_enable(self, on=True):
         self._check(self.lib.nbp_timing_enable(self._ctx, int(on)))
 
-    KERNELS = ("nbp_proposal_kernel", "nbp_prep_kernel", "nbp_product_kernel", "nbp_bandwidth_kernel")
+    KERNELS = ("nbp_proposal_kernel", "nbp_prep_kernel", "nbp_product_kernel", "nbp_bandwidth_kernel", "nbp_update_kernel")
 
     def timing_read(self):
         """{kernel: (total ms, launches)} measured with HIP events on the library stream"""
-        ms = (C.c_double * 4)()
-        nl = (C.c_int64 * 4)()
-        self._check(self.lib.nbp_timing_read(self._ctx, ms, nl))
+        ms = (C.c_double * 5)()
+        nl = (C.c_int64 * 5)()
+        self._check(self.lib.nbp_timing_read_n(self._ctx, ms, nl, 5))
         return {k: (ms[i], nl[i]) for i, k in enumerate(self.KERNELS)}
 
     def diag(self, reset=False):
@@ -241,18 +241,26 @@ _STAGE_CTYPE = {abi.STAGE_PROPOSALS: abi.ProposalDesc, abi.STAGE_PRODUCTS: abi.P
 class HipProgram:
     """A device-resident schedule: list of (kind, descriptor-array) stages uploaded once."""
 
-    def __init__(self, backend, stages, lazy_bandwidth=False):
+    def __init__(self, backend, stages, lazy_bandwidth=False, fused_updates=True):
         self.backend, lib = backend, backend.lib
         self._p = C.c_void_p()
         backend._check(lib.nbp_program_create(backend._ctx, C.byref(self._p)))
         backend._programs.add(self)
         if lazy_bandwidth:  # whole-solve programs: intermediate bandwidths nobody reads are not fitted
             backend._check(lib.nbp_program_set_option(self._p, abi.OPT_LAZY_BANDWIDTH, 1))
+        if not fused_updates:  # every round as three launches (proposal, prep, product)
+            backend._check(lib.nbp_program_set_option(self._p, abi.OPT_FUSED_UPDATES, 0))
         for kind, descs in stages:
             arr, n = _as_array(descs, _STAGE_CTYPE[kind])
             backend._check(lib.nbp_program_add_stage(self._p, kind, C.cast(arr, C.c_void_p), n))
         backend._check(lib.nbp_program_finalize(self._p))
         self.n_stages = len(stages)
+
+    def num_fused(self):
+        """rounds (PROPOSALS + PRODUCTS stage pairs) that run as one launch of the fused update kernel"""
+        n = C.c_int32(0)
+        self.backend._check(self.backend.lib.nbp_program_num_fused(self._p, C.byref(n)))
+        return n.value
 
     def run(self, first=0, last=-1):
         self.backend._check(self.backend.lib.nbp_program_run(self._p, first, last))

@@ -17,6 +17,7 @@
 #define NBP_TU 0  // host code: the kernels live in the nbp_k_*.hip files (-DNBP_TU=0xFFFF: single-file build with every kernel)
 #endif
 #include "nbp_kernels.h"
+#include "nbp_fused.h"
 
 static thread_local std::string g_err;
 static nbp_status fail(nbp_status code, const std::string &msg) {
@@ -64,11 +65,20 @@ struct nbp_ctx {
   // staging for immediate-mode calls
   void *stage = nullptr;
   size_t stage_bytes = 0;
-  // timing
+  // fused variable updates (nbp_fused.h) for the stages that fill the chip: NBP_NO_FUSED_UPDATE=1 turns them off,
+  // NBP_FUSED_MIN = smallest stage (updates) that runs fused
+  // Off unless NBP_FUSED_MIN is set: measured on config 2 and on the 10 000-variable chain the fused form moves a ninth of
+  // the bytes and takes 10-35 % longer (one workgroup serialises the six fits of an update that the
+  // three-launch form spreads over the chip).
+  bool fused_on = true;
+  int fused_min = 1 << 30;
+  int fused_p1_min = 2048;  // rounds with at least this many updates run one lane per particle (NBP_FUSED_P1_MIN); smaller
+                            // ones two helper rows per update, so that they fill the chip with twice the lanes each
+  // timing: 0 proposal, 1 prep, 2 product, 3 plain bandwidth, 4 fused update kernel
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
-  double ms[4] = {0, 0, 0, 0};
-  int64_t nl[4] = {0, 0, 0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+  double ms[5] = {0, 0, 0, 0, 0};
+  int64_t nl[5] = {0, 0, 0, 0, 0};
 };
 
 static int manifold_dim_h(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
@@ -196,6 +206,9 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipMalloc(&c->spec, sizeof(nbp_spec_area) * 3 * NBP_SPEC_MAXJOBS));
   c->spec_on = getenv("NBP_NO_SPECULATIVE_FITS") == nullptr;
   c->spec_depth3 = !(getenv("NBP_SPEC_DEPTH3") && atoi(getenv("NBP_SPEC_DEPTH3")) == 0);
+  c->fused_on = getenv("NBP_NO_FUSED_UPDATE") == nullptr;
+  if (getenv("NBP_FUSED_MIN")) c->fused_min = atoi(getenv("NBP_FUSED_MIN"));
+  if (getenv("NBP_FUSED_P1_MIN")) c->fused_p1_min = atoi(getenv("NBP_FUSED_P1_MIN"));
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
@@ -214,6 +227,9 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel_spec<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel_spec<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel_spec<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // (the kernel has 608 B of static LDS, the hypothesis recipe: static + dynamic must stay within the 160 KiB)
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_update_kernel_lin2_p1, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_update_kernel_lin2_p2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
 
   guard.c = nullptr;
   *out = c;
@@ -445,25 +461,29 @@ static nbp_status toc(nbp_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>>
 static int proposals_uniform_class(const nbp_proposal_desc *d, int n) {
   if (n <= 0) return 0;
   const int M = d[0].manifold;
-  const int cls = M == NBP_EUCLID2 ? 1 : (M == NBP_EUCLID3 ? 3 : 0);
-  const int want = NBP_F_LINREL;
+  // class = the manifold code: LinearRelative on Euclid(2) / Euclid(3), CircularCircular on the circle, ManifoldFactor on SE(2)
+  const int cls = M == NBP_EUCLID2 ? 1 : (M == NBP_EUCLID3 ? 3 : (M == NBP_CIRCULAR ? 4 : (M == NBP_SE2 ? 5 : 0)));
+  const int want = M == NBP_CIRCULAR ? NBP_F_CIRCULAR : (M == NBP_SE2 ? NBP_F_SE2 : NBP_F_LINREL);
   if (!cls) return 0;
   bool any = false;
   for (int i = 0; i < n; i++) {
     if (d[i].manifold != M) return 0;
     const int k = d[i].factor_kind;
+    if (d[i].partial_mask) return 0;  // partial priors and partial relatives run the generic kernel
     if (k == NBP_F_PRIOR || k == NBP_F_MSGPRIOR || k == NBP_F_PASSTHROUGH) continue;
-    if (k != want || d[i].partial_mask) return 0;
+    if (k != want) return 0;
     any = true;
   }
-  return any ? cls : 0;
+  (void)any;  // a batch of priors / message priors alone runs its manifold's instance as well
+  return cls;
 }
 static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int n, int cls = 0) {
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev[0]);
   if (rc) return rc;
   (void)hipGetLastError();  // clear stale, unrelated errors
-  auto *kern = cls == 1 ? nbp_proposal_kernel_lin2 : (cls == 3 ? nbp_proposal_kernel_lin3 : nbp_proposal_kernel);
+  auto *kern = cls == 1 ? nbp_proposal_kernel_lin2 : (cls == 3 ? nbp_proposal_kernel_lin3 : (cls == 4 ? nbp_proposal_kernel_circ :
+               (cls == 5 ? nbp_proposal_kernel_se2 : nbp_proposal_kernel)));
   hipLaunchKernelGGL(kern, dim3(n), dim3(c->Npad), nbp_proposal_lds_bytes(c->N), c->stream, dev, c->arena, c->N, c->Npad, c->S, c->side,
                      c->counters);
   HIPCHK(hipGetLastError());
@@ -963,6 +983,12 @@ struct nbp_stage {
   size_t ent_off = 0;
   bool flush_before = false;    // run the pending fits in a plain bandwidth launch before the stage
   bool need_prep = true;        // products: some product multiplies > 1 densities (KD builds; the entry fits run beside them)
+  // fused variable updates: this PROPOSALS stage and the PRODUCTS stage behind it run as ONE nbp_update_kernel launch
+  // (fused_second marks that PRODUCTS stage); upd = one nbp_update_desc per product
+  bool fused = false, fused_second = false;
+  int upd_F = 0, upd_cls = 0;
+  std::vector<nbp_update_desc> upd;
+  size_t upd_off = 0;
 };
 struct nbp_program {
   nbp_ctx *ctx = nullptr;
@@ -972,6 +998,7 @@ struct nbp_program {
   bool finalized = false;
   bool lazy_bw = false;  // NBP_OPT_LAZY_BANDWIDTH
   bool use_graph = true; // NBP_OPT_GRAPH_REPLAY
+  bool use_fused = true; // NBP_OPT_FUSED_UPDATES
   int n_user_stages = 0;
   // captured launch sequences of nbp_program_run(first, last): key = first * 2^32 + last
   struct captured { hipGraphExec_t exec; uint64_t ws_gen; };  // ws_gen: the context's workspace generation at capture time
@@ -1038,6 +1065,7 @@ nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value)
   if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
   if (option == NBP_OPT_LAZY_BANDWIDTH) { p->lazy_bw = value != 0; return NBP_OK; }
   if (option == NBP_OPT_GRAPH_REPLAY) { p->use_graph = value != 0; return NBP_OK; }
+  if (option == NBP_OPT_FUSED_UPDATES) { p->use_fused = value != 0; return NBP_OK; }
   return fail(NBP_ERR_ARG, "unknown program option");
 }
 
@@ -1126,6 +1154,118 @@ static nbp_liveness product_liveness(const nbp_program *p) {
   return L;  // whatever is still open is flushed at the end of the program: live
 }
 
+// ---- fused variable updates ---------------------------------------------------------------------------------------------
+// A PROPOSALS stage followed by the PRODUCTS stage that multiplies exactly its proposals -- one round of Gibbs steps, as
+// both hosts emit it -- runs as one launch of the fused update kernel when the round fills the chip and is of a class the
+// kernel is built for.  What must hold (checked here, so that any program a caller assembles stays correct):
+//   * every input of every product is the output of exactly one proposal of the stage in front, and every proposal feeds
+//     exactly one product (the proposals never reach HBM; one that a later stage reads from its slot is written there too);
+//   * no proposal reads a slot another update of the round writes (the three-launch form runs all proposals before any
+//     product; fused, the updates of a round run in any order) -- rounds of commuting Gibbs steps satisfy this by construction;
+//   * class: LinearRelative / priors / message priors on Euclid(2), full (non-partial) densities, no label output.
+static bool fused_plan(const nbp_program *p, int s, std::vector<nbp_update_desc> &upd, int &Fmax, int &cls) {
+  const nbp_ctx *c = p->ctx;
+  if (!c->fused_on || !p->use_fused || s + 1 >= p->n_user_stages || c->Npad > 256) return false;
+  const nbp_stage &A = p->stages[s], &B = p->stages[s + 1];
+  if (A.kind != NBP_STAGE_PROPOSALS || B.kind != NBP_STAGE_PRODUCTS || B.n < c->fused_min || A.n < B.n) return false;
+  if (A.mani != 1) return false;  // proposals_uniform_class: 1 = LinearRelative on Euclid(2)
+  const int M = NBP_EUCLID2;
+  const nbp_proposal_desc *pd = (const nbp_proposal_desc *)(p->blob.data() + A.offset);
+  const nbp_product_desc *qd = (const nbp_product_desc *)(p->blob.data() + B.offset);
+  std::unordered_map<int32_t, int> prop_of, prod_of;  // slot -> proposal / product writing it
+  for (int i = 0; i < A.n; i++) {
+    if (pd[i].manifold != M) return false;
+    if (!prop_of.emplace(pd[i].out_slot, i).second) return false;
+  }
+  for (int i = 0; i < B.n; i++) {
+    if (qd[i].manifold != M || qd[i].nfactors > NBP_FUSED_MAXF || qd[i].labels_out >= 0 || qd[i].old_slot >= 0) return false;
+    if (!prod_of.emplace(qd[i].out_slot, i).second) return false;
+  }
+  upd.assign(B.n, nbp_update_desc{});
+  std::vector<char> used(A.n, 0);
+  int nused = 0;
+  Fmax = 2;
+  for (int i = 0; i < B.n; i++) {
+    nbp_update_desc &u = upd[i];
+    u.prod = i;
+    if (qd[i].nfactors > Fmax) Fmax = qd[i].nfactors;
+    for (int j = 0; j < qd[i].nfactors; j++) {
+      if (qd[i].in_partial[j]) return false;
+      auto it = prop_of.find(qd[i].in_slot[j]);
+      if (it == prop_of.end() || used[it->second]) return false;
+      const nbp_proposal_desc &q = pd[it->second];
+      if (qd[i].nfactors > 1 && q.skip_bandwidth && q.factor_kind != NBP_F_PASSTHROUGH) return false;  // the product would read a stale bandwidth
+      if (q.factor_kind == NBP_F_PASSTHROUGH && qd[i].nfactors == 1 && q.keep_count) return false;
+      used[it->second] = 1;
+      nused++;
+      u.prop[j] = it->second;
+      // what the proposal reads: never a slot that another update of this launch writes, nor another proposal's slot
+      const int nv = (q.factor_kind == NBP_F_MSGPRIOR || q.factor_kind == NBP_F_PASSTHROUGH) ? 2 : q.nvars;
+      for (int k = 0; k <= nv; k++) {
+        const int32_t r = k < nv ? q.var_slot[k] : (q.meas_kde > 0 ? q.meas_kde - 1 : -1);
+        if (r < 0) continue;
+        auto w = prod_of.find(r);
+        if (w != prod_of.end() && w->second != i) return false;
+        if (prop_of.count(r)) return false;
+      }
+    }
+  }
+  if (nused != A.n) return false;
+  // proposals a later stage reads from their arena slots before anything overwrites them (or that are still there when the
+  // program ends): those are written as well
+  std::unordered_map<int32_t, std::pair<int, int>> watch;  // slot -> (update, input)
+  for (int i = 0; i < B.n; i++)
+    for (int j = 0; j < qd[i].nfactors; j++) watch[qd[i].in_slot[j]] = {i, j};
+  auto rd = [&](int32_t slot) {
+    auto it = watch.find(slot);
+    if (it == watch.end()) return;
+    upd[it->second.first].flags |= 2 << it->second.second;
+    watch.erase(it);
+  };
+  for (int i = 0; i < B.n; i++) watch.erase(qd[i].out_slot);  // (a product writing a proposal slot: overwritten at once)
+  for (int t = s + 2; t < p->n_user_stages && !watch.empty(); t++) {
+    const nbp_stage &st = p->stages[t];
+    const char *d = p->blob.data() + st.offset;
+    if (st.kind == NBP_STAGE_PROPOSALS || st.kind == NBP_STAGE_DECONV) {
+      const nbp_proposal_desc *x = (const nbp_proposal_desc *)d;
+      for (int i = 0; i < st.n; i++) {
+        const int nv = (x[i].factor_kind == NBP_F_MSGPRIOR || x[i].factor_kind == NBP_F_PASSTHROUGH) ? 2 : x[i].nvars;
+        for (int k = 0; k < nv; k++) rd(x[i].var_slot[k]);
+        if (x[i].meas_kde > 0) rd(x[i].meas_kde - 1);
+      }
+      for (int i = 0; i < st.n; i++) watch.erase(x[i].out_slot);
+    } else if (st.kind == NBP_STAGE_PRODUCTS) {
+      const nbp_product_desc *x = (const nbp_product_desc *)d;
+      for (int i = 0; i < st.n; i++) {
+        for (int j = 0; j < x[i].nfactors; j++) rd(x[i].in_slot[j]);
+        if (x[i].old_slot >= 0) rd(x[i].old_slot);
+      }
+      for (int i = 0; i < st.n; i++) watch.erase(x[i].out_slot);
+    } else {
+      const nbp_copy_desc *x = (const nbp_copy_desc *)d;
+      if (st.n == 0) break;  // barrier: slots leave the device -- whatever is still watched is written (below)
+      for (int i = 0; i < st.n; i++) rd(x[i].src_slot);
+      for (int i = 0; i < st.n; i++) watch.erase(x[i].dst_slot);
+    }
+  }
+  for (auto &w : watch) upd[w.second.first].flags |= 2 << w.second.second;
+  cls = A.mani;
+  return true;
+}
+
+static nbp_status launch_update(nbp_ctx *c, const nbp_stage &st, const nbp_update_desc *uds, const nbp_proposal_desc *props,
+                                const nbp_product_desc *prods, int n) {
+  nbp_status rc = tic(c, c->ev[4]);
+  if (rc) return rc;
+  (void)hipGetLastError();
+  const int P = n >= c->fused_p1_min ? 1 : 2;
+  const size_t lds = nbp_update_lds_bytes(st.upd_F, 2, c->N, c->Npad, P, false);
+  hipLaunchKernelGGL(P == 1 ? nbp_update_kernel_lin2_p1 : nbp_update_kernel_lin2_p2, dim3(n), dim3(P * c->Npad), lds, c->stream, uds, props, prods,
+                     c->arena, c->N, c->Npad, c->S, c->side, c->T, c->counters, st.upd_F);
+  HIPCHK(hipGetLastError());
+  return toc(c, c->ev[4]);
+}
+
 nbp_status nbp_program_finalize(nbp_program *p) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
   PROG_ALIVE(p);
@@ -1144,6 +1284,39 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     const char *d = p->blob.data() + st.offset;
     st.ent_s = pend_s;
     st.ent_m = pend_m;
+    if (st.kind == NBP_STAGE_PROPOSALS && sidx + 1 < p->n_user_stages && !st.fused) {
+      std::vector<nbp_update_desc> upd;
+      int Fm = 0, cls = 0;
+      if (fused_plan(p, sidx, upd, Fm, cls) && nbp_update_lds_bytes(Fm, 2, p->ctx->N, p->ctx->Npad, 2, false) <= 158 * 1024) {
+        // every fit of the round happens inside the launch: what is pending runs first, nothing is queued behind it
+        nbp_stage &nx = p->stages[sidx + 1];
+        const nbp_proposal_desc *pd = (const nbp_proposal_desc *)d;
+        const nbp_product_desc *qd = (const nbp_product_desc *)(p->blob.data() + nx.offset);
+        for (int i = 0; i < nx.n; i++) {
+          bool fit;
+          if (qd[i].nfactors > 1) fit = !p->lazy_bw || !live.dead_product[sidx + 1][i];
+          else {
+            const nbp_proposal_desc &q = pd[upd[i].prop[0]];
+            fit = !q.skip_bandwidth && q.factor_kind != NBP_F_PASSTHROUGH && (!p->lazy_bw || !live.dead_proposal[sidx][upd[i].prop[0]]);
+          }
+          if (fit) upd[i].flags |= NBP_UPD_FIT_OUT;
+        }
+        st.fused = true;
+        st.upd = std::move(upd);
+        st.upd_F = Fm;
+        st.upd_cls = cls;
+        nx.fused_second = true;
+        st.flush_before = !pend_s.empty();
+        pend_s.clear(); pend_m.clear();
+        continue;
+      }
+    }
+    if (st.kind == NBP_STAGE_PRODUCTS && st.fused_second) {  // ran inside the launch of the stage in front
+      st.ent_s.clear(); st.ent_m.clear();
+      st.need_prep = false;
+      // an output slot whose old points still had a fit queued cannot be: the launch in front flushed everything
+      continue;
+    }
     if (st.kind == NBP_STAGE_PROPOSALS) {
       // a MsgPrior samples from the KDE in var_slot[1] (points AND bandwidth)
       for (int i = 0; i < st.n && !st.flush_before; i++) {
@@ -1225,6 +1398,13 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     }
     st.ent_off = off;
   }
+  for (nbp_stage &st : p->stages)
+    if (st.fused) {
+      size_t off = (p->blob.size() + 63) & ~(size_t)63;
+      p->blob.resize(off + st.upd.size() * sizeof(nbp_update_desc));
+      memcpy(p->blob.data() + off, st.upd.data(), st.upd.size() * sizeof(nbp_update_desc));
+      st.upd_off = off;
+    }
   {
     std::vector<int64_t> so;
     for (int s = 0; s < p->n_user_stages; s++) {
@@ -1247,7 +1427,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   // size the workspaces now: nothing may allocate once a launch sequence is being captured
   nbp_status rc = NBP_OK;
   for (const nbp_stage &st : p->stages)
-    if (st.kind == NBP_STAGE_PRODUCTS && st.n > 0) {
+    if (st.kind == NBP_STAGE_PRODUCTS && st.n > 0 && !st.fused_second) {
       rc = presize_products(p->ctx, st.n, st.maxfd);
       if (rc) return rc;
     }
@@ -1267,7 +1447,12 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
     nbp_status rc = NBP_OK;
     if (st.flush_before) rc = launch_bandwidth(c, ent_s(st), ent_s(st) + nent, nent, coords_of(st.ent_m.data(), st.ent_m.size()));
     if (rc) return rc;
-    if (st.kind == NBP_STAGE_PROPOSALS) {
+    if (st.kind == NBP_STAGE_PROPOSALS && st.fused) {
+      const nbp_stage &nx = p->stages[s + 1];
+      rc = launch_update(c, st, (const nbp_update_desc *)(p->dev + st.upd_off), (const nbp_proposal_desc *)(p->dev + st.offset),
+                         (const nbp_product_desc *)(p->dev + nx.offset), nx.n);
+      s++;  // the products ran inside
+    } else if (st.kind == NBP_STAGE_PROPOSALS) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
@@ -1296,6 +1481,9 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   const int nuser = p->n_user_stages;
   if (last < 0 || last > nuser) last = nuser;
   if (first < 0) first = 0;
+  if (first < last && (p->stages[first].fused_second || p->stages[last - 1].fused))
+    return fail(NBP_ERR_ARG, "program_run: the range splits a fused variable update (a PROPOSALS stage and the PRODUCTS stage behind it); "
+                             "cut the range around the pair or set NBP_OPT_FUSED_UPDATES to 0");
   // Replay: the launch sequence of a range is captured into a hipGraph the second time it runs and launched as one
   // graph from then on (the descriptors live in device memory, so nbp_program_reseed still takes effect).  Per-kernel
   // event timing (nbp_timing_enable) and programs of a handful of launches take the plain path.
@@ -1353,6 +1541,14 @@ nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
 nbp_status nbp_program_num_stages(nbp_program *p, int32_t *out) {
   if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
   *out = p->finalized ? p->n_user_stages : (int32_t)p->stages.size();
+  return NBP_OK;
+}
+
+nbp_status nbp_program_num_fused(nbp_program *p, int32_t *out) {
+  if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
+  int n = 0;
+  for (const nbp_stage &st : p->stages) n += st.fused ? 1 : 0;
+  *out = n;
   return NBP_OK;
 }
 
@@ -1525,13 +1721,17 @@ static nbp_status drain(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, doubl
   return NBP_OK;
 }
 nbp_status nbp_timing_read(nbp_ctx *c, double *ms, int64_t *launches) {
+  return nbp_timing_read_n(c, ms, launches, 4);
+}
+nbp_status nbp_timing_read_n(nbp_ctx *c, double *ms, int64_t *launches, int32_t n) {
   if (!c) return fail(NBP_ERR_ARG, "null argument");
+  if (n < 0 || n > 5) return fail(NBP_ERR_RANGE, "timing: n in [0, 5]");
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 5; k++) {
     nbp_status rc = drain(c->ev[k], c->ms[k], c->nl[k]);
     if (rc) return rc;
-    if (ms) ms[k] = c->ms[k];
-    if (launches) launches[k] = c->nl[k];
+    if (k < n && ms) ms[k] = c->ms[k];
+    if (k < n && launches) launches[k] = c->nl[k];
     c->ms[k] = 0;
     c->nl[k] = 0;
   }

@@ -88,6 +88,7 @@ __device__ __forceinline__ void uniform_pair(uint64_t seed, uint32_t n, uint32_t
   ub = u01_from(o[2], o[3]);
 }
 
+__device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs);
 __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k,
                                             double &na, double &nb) {
   double ua, ub;
@@ -95,7 +96,11 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t 
   double r = sqrt(-2.0 * log(ua));
   double th = NBP_TWO_PI * ub;
   double s, c;
+#ifdef NBP_X_FASTSINCOS
+  sincos_fast(th, &s, &c);
+#else
   sincos(th, &s, &c);
+#endif
   na = r * c;
   nb = r * s;
 }
@@ -319,7 +324,9 @@ __device__ __forceinline__ double block_exclusive_scan(double v, double *red, do
 // beliefs spread over the circle 5-15 sweeps of a workgroup-wide scan instead of N dependent steps; equal to the walk
 // up to the rounding of the sums).  A belief that needs more sweeps is walked as before.
 // A real call: inlined into the proposal kernel the sweeps cost that kernel 13 VGPRs and 48 B of scratch per lane.
-__device__ __attribute__((noinline)) bool mean_geodesic_lifts(const double *x, int N, double *red, double *mean_out) {
+// Returns the mean, or NaN when the lifts have not settled after 32 sweeps (by value: a result handed back through a
+// pointer to a local of the caller costs every kernel that inlines the caller a stack slot in scratch).
+__device__ __attribute__((noinline)) double mean_geodesic_lifts(const double *x, int N, double *red) {
   // One barrier per sweep: the wave totals and the "a lift changed in the previous sweep" flags go through
   // alternating halves of `red`, and the loop ends one sweep after the last change (that sweep's sums are the final ones).
   const int i = threadIdx.x, lane = i & 63, w = i >> 6, nw = (blockDim.x + 63) >> 6;
@@ -363,8 +370,7 @@ __device__ __attribute__((noinline)) bool mean_geodesic_lifts(const double *x, i
     ki = kn;
   }
   __syncthreads();  // `red` is free again
-  *mean_out = wrap_pi(tot / (double)N);
-  return fixed;
+  return fixed ? wrap_pi(tot / (double)N) : __longlong_as_double(0x7ff8000000000000ll);
 }
 
 __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, int manifold, int d, double *red) {
@@ -399,8 +405,8 @@ __device__ __forceinline__ double mean_geodesic_coord(const double *x, int N, in
       }
     }
     {  // spread around the circle: lifts and prefix means iterated to the walk's fixed point (mean_geodesic_lifts)
-      double mlift;
-      if (mean_geodesic_lifts(x, N, red, &mlift)) return mlift;
+      const double mlift = mean_geodesic_lifts(x, N, red);
+      if (mlift == mlift) return mlift;  // (block-uniform: every lane computes the same sums)
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -532,10 +538,15 @@ struct objective_t {
       }
       return acc;
     }
-    double xo[DN];
+    // which end is searched is chosen value by value (wave-uniform selects): two array arguments picked at run time
+    // would have to live in memory, i.e. in scratch
+    double a[DN], b[DN];
 #pragma unroll
-    for (int d = 0; d < DN; d++) xo[d] = other[d];
-    return solve_b ? normsq(xo, x) : normsq(x, xo);
+    for (int d = 0; d < DN; d++) {
+      a[d] = solve_b ? other[d] : x[d];
+      b[d] = solve_b ? x[d] : other[d];
+    }
+    return normsq(a, b);
   }
 };
 
@@ -606,6 +617,9 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   nm_sort_all<DN>(sx, f);
   bool converged = nm_converged<DN>(f);
   int it = 0;
+#ifdef NBP_X_NMNOUNROLL
+#pragma clang loop unroll(disable)
+#endif
   while (!converged && it < 1000) {
     it++;
     double xc[DN], xr[DN], xcache[DN];
@@ -813,8 +827,13 @@ __device__ __forceinline__ bool bfgs_nd(OBJ &o, double (&x)[DN]) {
 }
 
 // _solveCCWNumeric! for one particle (NumericalCalculations.jl:413-452, :90-133)
+#ifdef NBP_SOLVE_NOINLINE
+#define NBP_SOLVE_ATTR __attribute__((noinline))
+#else
+#define NBP_SOLVE_ATTR __forceinline__
+#endif
 template <int KIND, int DN, bool PARTIAL_BFGS = false>
-__device__ __forceinline__ void solve_particle_t(int manifold, const double *z, const double *other, int solve_b, double *x,
+__device__ NBP_SOLVE_ATTR void solve_particle_t(int manifold, const double *z, const double *other, int solve_b, double *x,
                                                  unsigned int &n_solves, unsigned int &n_nonconv, unsigned int &n_nan,
                                                  unsigned int &n_evals) {
   objective_t<KIND, DN> o;

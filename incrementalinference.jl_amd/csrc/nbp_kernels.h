@@ -96,9 +96,10 @@ __device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int 
 }
 
 // calcVariableDistanceExpectedFractional, EvalFactor.jl:40-92 (block-uniform result)
+// `M`: the manifold (a compile-time constant in the single-class kernels: the circular-mean paths then fold away)
 __device__ __forceinline__ double var_distance_expected_fractional(const nbp_proposal_desc *d, const recipe_t *R, const double *arena,
-                                                   int64_t S, int N, const double *X, double kappa, double *red) {
-  const int sf1 = d->sfidx + 1, M = d->manifold, D = mani_dim(M);
+                                                   int64_t S, int N, const double *X, double kappa, double *red, const int M) {
+  const int sf1 = d->sfidx + 1, D = mani_dim(M);
   if (in_list(R->certain, R->ncertain, sf1)) return kappa * std_basic_spread(X, N, N, M, red);
   double ref[3] = {0, 0, 0};
   for (int k = 0; k < D; k++) ref[k] = mean_default_coord(X + k * N, N, M, k, red);
@@ -171,20 +172,21 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
       idx = (int)(ua * cd);
       if (idx >= cd) idx = cd - 1;
     }
-    double nz[4] = {0, 0, 0, 0};
+    double nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;  // (scalars: an array indexed by the loop below lives in scratch)
     if (d->keep_count == 2 && cd < N && n >= cd) {  // resample(bel, N) of graph initialisation (GraphInit.jl:174-177):
       double ua, ub;                                 // the density's points stay, the rest are draws from its KDE
       uniform_pair(d->seed, n, PURP_OLDSEL, 0, ua, ub);
       idx = (int)(ua * cd);
       if (idx >= cd) idx = cd - 1;
-      normal_pair(d->seed, n, PURP_OLDNOISE, 0, nz[0], nz[1]);
-      if (D > 2) normal_pair(d->seed, n, PURP_OLDNOISE, 1, nz[2], nz[3]);
+      normal_pair(d->seed, n, PURP_OLDNOISE, 0, nz0, nz1);
+      if (D > 2) normal_pair(d->seed, n, PURP_OLDNOISE, 1, nz2, nz3);
     }
     if (live && idx < cd)
       for (int k = 0; k < D; k++)
         if ((pm >> k) & 1) {
-          const double v = den[k * N + idx] + den[3 * N + k] * nz[k];
-          X[k * N + n] = (nz[k] != 0.0 && is_circ(M, k)) ? wrap_pi(v) : v;
+          const double nzk = k == 0 ? nz0 : (k == 1 ? nz1 : nz2);
+          const double v = den[k * N + idx] + den[3 * N + k] * nzk;
+          X[k * N + n] = (nzk != 0.0 && is_circ(M, k)) ? wrap_pi(v) : v;
         }
     if (live)
       for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
@@ -203,14 +205,14 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
     if (live) {
       double x[3] = {X[n], X[N + n], X[2 * N + n]};
       if (mh[n] == 1) {
-        if (kind == NBP_F_PRIOR && d->partial_mask) {
+        if (!FIXK && kind == NBP_F_PRIOR && d->partial_mask) {  // (a uniform batch holds no partial priors: proposals_uniform_class)
           // partial prior: setPointPartial! on the partial coordinates only (:457-538)
           const int pmk = d->partial_mask;
           double z[3];
           sample_measurement(d, n, __popc(pmk & 7), z, arena, S, N);
           int pk = 0;
           if (pmk & 1) { x[0] = is_circ(M, 0) ? wrap_pi(z[0]) : z[0]; pk = 1; }
-          if (pmk & 2) { x[1] = z[pk]; pk++; }
+          if (pmk & 2) { x[1] = pk ? z[1] : z[0]; pk++; }  // (z[pk] would put the array in scratch)
           if (pmk & 4) { const double v = (pk == 0) ? z[0] : (pk == 1 ? z[1] : z[2]); x[2] = is_circ(M, 2) ? wrap_pi(v) : v; }
         } else if (kind == NBP_F_PRIOR) {
           double z[3];
@@ -258,13 +260,17 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
     const int sf1 = d->sfidx + 1;
     const int myh = live ? mh[n] : -1000;
     // computeAcrossHypothesis!, EvalFactor.jl:145-237
-    for (int g = 0; g < R.ngroups; g++) {
-      if (R.empty[g]) continue;
-      const int hyp = R.hypo[g];
+    // the recipe lives in LDS: what is read from it is wave-uniform but arrives in vector registers -- moved to scalar
+    // ones, so that the group / cycle loops branch on SGPRs and keep no VGPRs live across the per-particle searches
+    const int ngroups = __builtin_amdgcn_readfirstlane(R.ngroups);
+    for (int g = 0; g < ngroups; g++) {
+      if (__builtin_amdgcn_readfirstlane(R.empty[g])) continue;
+      const int hyp = __builtin_amdgcn_readfirstlane(R.hypo[g]);
       if (!__syncthreads_or(myh == hyp)) continue;  // empty allelements[g]: nothing to do
-      const bool solve_case = (in_list(R.certain, R.ncertain, sf1) && hyp != 0) || in_list(R.certain, R.ncertain, hyp) || hyp == sf1;
+      const bool solve_case = __builtin_amdgcn_readfirstlane(
+          (int)((in_list(R.certain, R.ncertain, sf1) && hyp != 0) || in_list(R.certain, R.ncertain, hyp) || hyp == sf1)) != 0;
       if (solve_case) {
-        const int va = R.act[g][0], vb = R.act[g][1];
+        const int va = __builtin_amdgcn_readfirstlane(R.act[g][0]), vb = __builtin_amdgcn_readfirstlane(R.act[g][1]);
         const int solve_b = (vb == sf1);
         const int vother = solve_b ? va : vb;
         const double *O = arena + S * d->var_slot[vother - 1];
@@ -277,7 +283,7 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
         }
         for (int c = 0; c < d->inflate_cycles; c++) {  // :184-207
           NBP_CTICK(30);  // everything before / between cycles
-          const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->inflation, red);
+          const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->inflation, red, M);
           __syncthreads();
           NBP_CTICK(31);  // spread statistics (workgroup reductions)
           if (myh == hyp) {
@@ -309,7 +315,7 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
           NBP_CTICK(33);  // waiting for the slowest lane / wave
         }
       } else {  // other-hypothesis (:208-220) / nullhypo (:222-231): entropy only
-        const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->spread_nh, red);
+        const double spread = var_distance_expected_fractional(d, &R, arena, S, N, X, d->spread_nh, red, M);
         __syncthreads();
         if (myh == hyp) {
           double x[3] = {X[n], X[N + n], X[2 * N + n]};
@@ -372,8 +378,14 @@ __global__ void nbp_proposal_kernel(NBP_PROPOSAL_ARGS);
 #else
 #define NBP_PROPOSAL_UNIFORM(NAME, K_, M_, WAVES) __global__ void NAME(NBP_PROPOSAL_ARGS);
 #endif
-NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, 3)
+#ifndef NBP_W_LIN2
+#define NBP_W_LIN2 3
+#endif
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, NBP_W_LIN2)
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
+// CircularCircular on the circle (config 3, incl. its multihypo sightings) and ManifoldFactor on SE(2) (config 4)
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_circ, NBP_F_CIRCULAR, NBP_CIRCULAR, 3)
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_se2, NBP_F_SE2, NBP_SE2, 2)
 
 // ================================================================================================
 // Deconvolution kernel: one workgroup = one approxDeconv(dfg, fct) (DeconvUtils.jl:32-160), one lane
@@ -829,8 +841,10 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
 #define NBP_FUSED_MAXF 4
 struct nbp_fused_io {
   product_lds L;                      // the product's own LDS areas
-  const double *xs[NBP_FUSED_MAXF];   // [D][N] sorted, centred coordinates of density j
-  const int *idx[NBP_FUSED_MAXF];     // [N] permutation
+  const double *xs;                   // sorted, centred coordinates of density j: [D][N] at xs + j * xs_stride
+  size_t xs_stride;
+  const int *idx;                     // [N] permutation of density j at idx + j * idx_stride (only for label output)
+  size_t idx_stride;
   const double *cen;                  // [F][3]
   const double *bw;                   // [F][3]
   double *out;                        // slot-shaped LDS area that receives the product's points
@@ -883,7 +897,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       const int j = jk / D, k = jk % D;
       double s1, s2;
       if constexpr (FUSED) {  // the same sums in the same (leaf) order as kd_build's, from the tree in LDS
-        const double *srt = fio->xs[j] + k * N;
+        const double *srt = fio->xs + j * fio->xs_stride + k * N;
         s1 = 0;
         s2 = 0;
         for (int p = lo; p < hi; p++) { const double v = srt[p]; s1 += v; s2 += v * v; }
@@ -1137,7 +1151,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     }
     if (d->labels_out >= 0)
       for (int j = 0; j < F; j++) {
-        const int *widx = FUSED ? fio->idx[j] : (const int *)(wsp + (size_t)j * nbp_kd_ws_doubles(N) + 3 * N + 4);
+        const int *widx = FUSED ? fio->idx + j * fio->idx_stride : (const int *)(wsp + (size_t)j * nbp_kd_ws_doubles(N) + 3 * N + 4);
         side[d->labels_out + s * F + j] = widx[T.node_lo[T.off[T.L] + ind[j * SPB + sl]]];
       }
     // setBelief!: the rebandwidth rides with the next nbp_prep_kernel / nbp_bandwidth_kernel launch

@@ -73,7 +73,11 @@ def main():
         want_res = args.resources and src.endswith(".hip") and "nbp_k_" in src
         if not args.force and os.path.exists(obj) and os.path.getmtime(obj) >= dep_m and (not want_res or os.path.exists(log)):
             continue
-        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+        own = []  # per-file flags: a `// hipcc-flags: ...` line in the source
+        for line in open(src):
+            if line.startswith("// hipcc-flags:"):
+                own += line.split(":", 1)[1].split()
+        cmd = [HIPCC] + FLAGS + own + extra + ["-c", src, "-o", obj]
         if src.endswith(".hip"):
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), log))
