@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--config", default="2", choices=["2", "2p", "3", "4", "5"], help="BASELINE.json configuration (default 2: the metric's)")
     ap.add_argument("--nvars", type=int, default=None, help="override the per-GPU size of the configuration (variables / poses / lattice rows)")
     ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="several GPUs: strong = the configuration's graph as BASELINE.json defines it, its cliques sharded over the ranks "
+                         "(auto: configs 4 and 5, which BASELINE quotes on 8 GPUs); weak = the graph grows with the ranks (auto: 2, 2p, 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vars", type=int, default=1000, help="variables of the CPU baseline's chain (default: the whole config-2 graph)")
     ap.add_argument("--no-10k", action="store_true", help="skip the secondary 10 000-variable north-star measurement")
@@ -121,7 +124,8 @@ def main():
     wl = workloads(iif)[a.config]
     N = a.particles or wl.N
     size = a.nvars or wl.size
-    rs = RankSolve(iif, wl, size, N, rank, world, local, dist, python_host=a.python_host)
+    scaling = a.scaling if a.scaling != "auto" else ("strong" if a.config in ("4", "5") else "weak")
+    rs = RankSolve(iif, wl, size, N, rank, world, local, dist, python_host=a.python_host, scaling=scaling)
     rs.prepare()
 
     def barrier():
@@ -158,10 +162,10 @@ def main():
     peak, peak_src = hbm_peak_gbps(local)
     out = {
         "metric": "clique-messages/sec", "value": value, "unit": "messages/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": wl.name.format(size=size * world) + f", N={N} particles, nested-dissection order, full up+down solveTree",
-                   "baseline_config": a.config, f"{wl.unit_name}_per_gpu": size, "variables_per_gpu": len(rs.fg.ls()) // world,
+        "config": {"workload": wl.name.format(size=rs.size_total) + f", N={N} particles, nested-dissection order, full up+down solveTree",
+                   "baseline_config": a.config, f"{wl.unit_name}_per_gpu": rs.size_total / world, "variables_per_gpu": len(rs.fg.ls()) // world,
                    "particles": N, "cliques": st["cliques_global"], "messages_per_step": msgs_total,
                    "variable_updates_per_step": st["updates_global"],
                    "launch": "staged program replayed as a hipGraph; per-kernel events only in the separate profiling pass",

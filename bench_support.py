@@ -2,7 +2,9 @@
 
 One rank: ordering, Bayes tree, Gibbs schedules and stage descriptors come from the native C++ host
 (include/nbp_host.h).  Several ranks: the cliques are sharded (dist_solver.ShardedTreeSolve) and every rank compiles
-its share.  Weak scaling: the graph grows with the number of ranks (`scale` = per-GPU size x world)."""
+its share.  Scaling: BASELINE.json's configurations 4 and 5 are fixed graphs on 8 GPUs -- strong scaling, the default for
+them; configurations 2 / 2p / 3 are single-GPU configurations -- with several ranks the graph grows with the ranks (weak
+scaling: `size` per GPU), unless --scaling says otherwise."""
 import time
 
 import numpy as np
@@ -55,11 +57,13 @@ def workloads(iif):
 
 
 class RankSolve:
-    def __init__(self, iif, wl, size, N, rank, world, local, dist, python_host=False):
+    def __init__(self, iif, wl, size, N, rank, world, local, dist, python_host=False, scaling="weak"):
         self.iif, self.wl, self.size, self.N = iif, wl, size, N
         self.rank, self.world, self.local, self.dist = rank, world, local, dist
         self.python_host = python_host
-        self.size_total = size * world
+        # weak: the graph grows with the ranks (`size` per GPU); strong: BASELINE's graph as it is, its cliques sharded
+        self.scaling = scaling
+        self.size_total = size * world if scaling == "weak" else size
 
     def prepare(self):
         iif = self.iif

@@ -147,6 +147,16 @@ int32_t nbp_tree_num_segments(const nbp_tree *t);
 nbp_status nbp_tree_segment(const nbp_tree *t, int32_t i, int32_t *kind, int32_t *first, int32_t *last, int32_t *nsend, int32_t *nrecv,
                             nbp_xfer *sends, nbp_xfer *recvs, int32_t cap);
 
+/* One solve of this rank's share from C: run the stage segments of the last nbp_tree_compile and, between them, the
+ * separator exchanges -- nbp_exchange on `comm` (grouped RCCL send / recv on the library's stream: stream-ordered with
+ * the kernels on both sides, no host synchronisation, no host code between the launches), or the caller's transport
+ * (`xchg`: e.g. host-staged point-to-point in the CPU tests).  The counterpart of the reference's task graph -- one Task
+ * per clique, blocked on the Channels of its tree edges (taskSolveTree!, src/services/SolverAPI.jl:50-100;
+ * CliqueStateMachine.jl:221-234, 617-629) -- with the cliques of a rank compiled into stage ranges. */
+typedef nbp_status (*nbp_exchange_fn)(void *user, const nbp_xfer *sends, int32_t n_sends, const nbp_xfer *recvs, int32_t n_recvs);
+nbp_status nbp_tree_run_sharded(const nbp_tree *t, nbp_program *prog, nbp_ctx *ctx, nbp_comm *comm);
+nbp_status nbp_tree_run_sharded_cb(const nbp_tree *t, nbp_program *prog, nbp_exchange_fn xchg, void *user);
+
 typedef struct nbp_tree_stats {
   int64_t stages, proposals, products, updates_up, updates_down, messages, slots;
   int64_t alg_bytes;          /* sum of B_upd over all updates, SURVEY 8(d) */

@@ -1338,7 +1338,8 @@ nbp_status nbp_tree_set_owner(nbp_tree *t, const int32_t *owner, int32_t rank) {
 }
 
 // dist_solver.partition_cliques: cut the tree into >= world subtrees by repeatedly splitting the heaviest one, place the
-// subtrees largest-first on the least loaded rank, give every clique above the cut to the rank of its heaviest child.
+// subtrees largest-first on the least loaded rank, give every clique above the cut to the rank of one of its children
+// (level by level, siblings of a level on different ranks where possible).
 // weight of a clique = 1 + the variable updates of its up schedule.
 nbp_status nbp_tree_partition(const nbp_tree *t, int32_t world, int32_t *owner_out) {
   if (!t || !owner_out || world < 1) return hfail(NBP_ERR_ARG, "bad argument");
@@ -1378,16 +1379,75 @@ nbp_status nbp_tree_partition(const nbp_tree *t, int32_t world, int32_t *owner_o
       for (int chd : t->cl[c - 1].children) st.push_back(chd);
     }
   }
-  for (auto it = top.rbegin(); it != top.rend(); ++it) {  // children before parents
-    const Clique &c = t->cl[*it - 1];
-    int best = c.children[0];
-    for (int chd : c.children)
-      if (sub[chd] > sub[best]) best = chd;
-    owner[*it] = owner[best];
-    load[owner[*it]] += w[*it];
+  // The cliques above the cut, level by level (a clique's level = the longest chain of such cliques below it): each goes
+  // to the rank of one of its children -- one of its edges stays local -- and the cliques of one level, which can run side
+  // by side, go to different ranks where their children allow it: the heaviest child whose rank has no clique of this
+  // level yet, else the heaviest child.
+  {
+    std::map<int, int> level;
+    int maxlevel = 0;
+    for (auto it = top.rbegin(); it != top.rend(); ++it) {  // children before parents
+      int lv = 0;
+      for (int chd : t->cl[*it - 1].children)
+        if (level.count(chd)) lv = std::max(lv, level[chd] + 1);
+      level[*it] = lv;
+      maxlevel = std::max(maxlevel, lv);
+    }
+    for (int lv = 0; lv <= maxlevel; lv++) {
+      std::vector<char> used(world, 0);
+      for (auto it = top.rbegin(); it != top.rend(); ++it) {
+        if (level[*it] != lv) continue;
+        std::vector<int> kids(t->cl[*it - 1].children.begin(), t->cl[*it - 1].children.end());
+        std::stable_sort(kids.begin(), kids.end(), [&](int a, int b) { return sub[a] > sub[b]; });
+        int pick = owner[kids[0]];
+        for (int chd : kids)
+          if (!used[owner[chd]]) { pick = owner[chd]; break; }
+        owner[*it] = pick;
+        used[pick] = 1;
+        load[pick] += w[*it];
+      }
+    }
   }
   for (size_t k = 1; k <= nc; k++) owner_out[k - 1] = owner[k];
   return NBP_OK;
+}
+
+// One solve of this rank's share: the stage segments of the last compile with the separator exchanges between them, all
+// issued from here on the library's stream -- no host code between a segment and the exchange behind it, no host
+// synchronisation (the reference: one Task per clique blocking on its Channels, SolverAPI.jl:50-100).
+nbp_status nbp_tree_run_sharded_cb(const nbp_tree *t, nbp_program *prog, nbp_exchange_fn xchg, void *user) {
+  if (!t || !prog) return hfail(NBP_ERR_ARG, "null argument");
+  std::vector<nbp_xfer> sx, rx;
+  for (const nbp_tree::Segment &x : t->segments) {
+    if (x.kind == 0) {
+      if (x.last > x.first) {
+        nbp_status rc = nbp_program_run(prog, x.first, x.last);
+        if (rc) return rc;
+      }
+      continue;
+    }
+    if (x.sends.empty() && x.recvs.empty()) continue;
+    if (!xchg) return hfail(NBP_ERR_ARG, "run_sharded: the compile has exchange segments but no transport was given");
+    sx.clear();
+    rx.clear();
+    for (const auto &s : x.sends) sx.push_back({s[0], s[1]});
+    for (const auto &r : x.recvs) rx.push_back({r[0], r[1]});
+    nbp_status rc = xchg(user, sx.data(), (int32_t)sx.size(), rx.data(), (int32_t)rx.size());
+    if (rc) return rc;
+  }
+  return NBP_OK;
+}
+namespace {
+struct rccl_transport { nbp_ctx *ctx; nbp_comm *comm; };
+nbp_status rccl_xchg(void *user, const nbp_xfer *sends, int32_t ns, const nbp_xfer *recvs, int32_t nr) {
+  rccl_transport *r = (rccl_transport *)user;
+  return nbp_exchange(r->ctx, r->comm, sends, ns, recvs, nr);
+}
+}  // namespace
+nbp_status nbp_tree_run_sharded(const nbp_tree *t, nbp_program *prog, nbp_ctx *ctx, nbp_comm *comm) {
+  if (!t || !prog) return hfail(NBP_ERR_ARG, "null argument");
+  rccl_transport r{ctx, comm};
+  return nbp_tree_run_sharded_cb(t, prog, (ctx && comm) ? rccl_xchg : nullptr, &r);
 }
 
 int32_t nbp_tree_num_segments(const nbp_tree *t) { return t ? (int32_t)t->segments.size() : 0; }

@@ -20,7 +20,8 @@ from .solver import TreeProgram
 def partition_cliques(tree, world, weight=None):
     """Assign every clique to a rank: cut the tree into >= world subtrees by repeatedly splitting
     the heaviest one, place subtrees largest-first on the least loaded rank, then give every
-    clique above the cut to the rank of its heaviest child (one of its edges stays local)."""
+    clique above the cut to the rank of one of its children, level by level (siblings of a level on
+    different ranks where their children allow it)."""
     cl = tree.cliques
     w = {c: (1.0 if weight is None else float(weight(c))) for c in cl}
     sub = {}
@@ -48,10 +49,22 @@ def partition_cliques(tree, world, weight=None):
             c = stack.pop()
             owner[c] = k
             stack.extend(cl[c].children)
+    # the cliques above the cut, level by level (level = the longest chain of such cliques below): each goes to the rank
+    # of one of its children (one of its edges stays local), and the cliques of one level -- which can run side by side --
+    # go to different ranks where their children allow it
+    level = {}
     for c in reversed(top):  # children before parents
-        best = max(cl[c].children, key=lambda ch: sub[ch])
-        owner[c] = owner[best]
-        load[owner[c]] += w[c]
+        level[c] = max([level[ch] + 1 for ch in cl[c].children if ch in level], default=0)
+    for lv in range(max(level.values(), default=-1) + 1):
+        used = set()
+        for c in reversed(top):
+            if level[c] != lv:
+                continue
+            kids = sorted(cl[c].children, key=lambda ch: -sub[ch])  # stable: first maximum first
+            pick = next((owner[ch] for ch in kids if owner[ch] not in used), owner[kids[0]])
+            owner[c] = pick
+            used.add(pick)
+            load[pick] += w[c]
     return owner
 
 
@@ -91,8 +104,9 @@ def choose_transport(dist, device, log=None):
 class ShardedRunner:
     """Runs one rank's share of a TreeProgram: stage segments interleaved with slot exchanges."""
 
-    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None, transport="rccl", group=None, prog=None):
+    def __init__(self, tp, backend, dist=None, slot_tensor=None, sync_device=None, transport="rccl", group=None, prog=None, native_tree=None):
         self.tp, self.be, self.dist = tp, backend, dist
+        self.native_tree = native_tree  # native_host.NativeTree: the segment loop runs in C (nbp_tree_run_sharded)
         self.slot_tensor = slot_tensor
         self.sync_device = sync_device or (lambda: None)
         self.transport, self.group = transport, group
@@ -102,6 +116,14 @@ class ShardedRunner:
     def run(self, salt=None):
         if salt is not None:
             self.prog.reseed(salt)
+        if self.native_tree is not None:
+            # the whole solve is one C call: stage ranges and exchanges issued back to back on the library stream (RCCL
+            # from C), or the C loop calling back into this object's transport
+            if self.transport == "rccl-native":
+                self.native_tree.run_sharded(self.prog, self.be)
+            else:
+                self.native_tree.run_sharded(self.prog, exchange=self._exchange)
+            return
         for seg in self.tp.segments:
             if seg[0] == "run":
                 if seg[2] > seg[1]:
@@ -231,7 +253,7 @@ class ShardedTreeSolve:
             else:
                 self.transport, group = choose_transport(self.dist, dev, log=log)
         self.runner = ShardedRunner(self.tp, self.be, self.dist, lambda s: self.arena[s * stride:(s + 1) * stride],
-                                    torch.cuda.synchronize, transport=self.transport, group=group, prog=prog)
+                                    torch.cuda.synchronize, transport=self.transport, group=group, prog=prog, native_tree=nt)
         self.host_setup = {"host": "native C++ (nbp_host.h), sharded compile", "graph_s": None, "graph_mirror_s": mirror,
                            "elimination_order_s": t1 - t0, "tree_build_s": t2 - t1, "graph_init_s": t3 - t2,
                            "schedule_compile_s": t4 - t3}

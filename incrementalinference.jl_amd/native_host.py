@@ -35,6 +35,7 @@ class TreeStats(C.Structure):
 
 
 Xfer = abi.Xfer
+XCHG_FN = C.CFUNCTYPE(i32, C.c_void_p, C.POINTER(Xfer), i32, C.POINTER(Xfer), i32)  # nbp_exchange_fn
 
 
 class TreeBeliefC(C.Structure):
@@ -60,6 +61,7 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
                 "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve",
                 "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment",
+                "nbp_tree_run_sharded", "nbp_tree_run_sharded_cb",
                 "nbp_graph_num_densities", "nbp_graph_density_factors", "nbp_graph_init_density_slot0", "nbp_tree_density_slot0"]
 
 _declared = False
@@ -105,6 +107,8 @@ def _lib():
         lib.nbp_tree_set_owner.argtypes = [vp, ip, i32]
         lib.nbp_tree_num_segments.argtypes = [vp]
         lib.nbp_tree_segment.argtypes = [vp, i32, ip, ip, ip, ip, ip, C.POINTER(Xfer), C.POINTER(Xfer), i32]
+        lib.nbp_tree_run_sharded.argtypes = [vp, vp, vp, vp]
+        lib.nbp_tree_run_sharded_cb.argtypes = [vp, vp, XCHG_FN, vp]
         lib.nbp_clique_slots.argtypes = [C.POINTER(CliqueDescC)]
         for fn in (lib.nbp_clique_upsolve, lib.nbp_clique_downsolve):
             fn.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC), ip]
@@ -383,6 +387,29 @@ class NativeTree:
             _check(self.lib.nbp_tree_segment(self._t, i, None, None, None, None, None, sx, rx, cap))
             out.append(("xchg", [(sx[k].peer, sx[k].slot) for k in range(ns.value)], [(rx[k].peer, rx[k].slot) for k in range(nr.value)]))
         return out
+
+    def run_sharded(self, prog, backend=None, exchange=None):
+        """one solve of this rank's share from C (nbp_tree_run_sharded): the stage segments of the last compile and the
+        separator exchanges between them.  `backend` with a communicator (HipBackend.comm_create): grouped RCCL send /
+        recv on the library stream; `exchange(sends, recvs)`: the caller's transport, called back from the C loop."""
+        if exchange is None:
+            comm = getattr(backend, "_comm", None) if backend is not None else None
+            _check(self.lib.nbp_tree_run_sharded(self._t, prog._p, backend._ctx if comm else None, comm))
+            return
+        err = []
+
+        def cb(_user, sx, ns, rx, nr):
+            try:
+                exchange([(sx[k].peer, sx[k].slot) for k in range(ns)], [(rx[k].peer, rx[k].slot) for k in range(nr)])
+                return 0
+            except Exception as e:  # noqa: BLE001 -- reported after the C loop returns
+                err.append(e)
+                return -2
+        fn = XCHG_FN(cb)
+        rc = self.lib.nbp_tree_run_sharded_cb(self._t, prog._p, fn, None)
+        if err:
+            raise err[0]
+        _check(rc)
 
     def density_slot0(self):
         return _check(self.lib.nbp_tree_density_slot0(self._t))

@@ -26,13 +26,47 @@ def build(joint=False):
     return fg, iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
 
 
+class NativeShare:
+    """this rank's share as the NATIVE host compiles it (nbp_tree_partition / nbp_tree_set_owner / nbp_tree_schedule:
+    descriptors, slot plan and exchange segments from libnbp's C++ host, no device needed), in the shape ShardedRunner
+    and this worker read from a solver.TreeProgram"""
+
+    def __init__(self, fg, world, rank, seed):
+        import ctypes as C
+        from iif_amd import abi, native_host
+        g = native_host.NativeGraph.from_fg(fg)
+        nt = g.build_tree(g.order_nested_dissection())
+        self.owner = nt.partition(world)
+        nt.set_owner(self.owner, rank)
+        self.n_slots = nt.plan_slots(False)
+        nt.schedule(seed)
+        ctype = {abi.STAGE_PROPOSALS: abi.ProposalDesc, abi.STAGE_PRODUCTS: abi.ProductDesc, abi.STAGE_COPIES: abi.CopyDesc,
+                 abi.STAGE_DECONV: abi.ProposalDesc, abi.STAGE_COPY_POINTS: abi.CopyDesc}
+        self.stages = []
+        for kind, raw in nt.stages():
+            n = len(raw) // C.sizeof(ctype[kind])
+            self.stages.append((kind, list((ctype[kind] * n).from_buffer_copy(raw)) if n else []))
+        self.segments = nt.segments()
+        self.main = nt.main
+        self.n_messages = nt.stats()["messages"]
+        self.cliques = [k for k in range(1, nt.n_cliques + 1) if self.owner[k] == rank]
+        self.frontals = {k: nt.clique(k)["frontals"] for k in self.cliques}
+        self._keep = (g, nt)
+
+
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "priors"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    fg, tree = build(len(sys.argv) > 5 and sys.argv[5] == "joint")
-    owner = partition_cliques(tree, world)
-    tp = iif.TreeProgram(fg, tree, seed=7, owner=owner, rank=rank)
+    fg, tree = build(mode == "joint")
+    if mode == "native":
+        tp = NativeShare(fg, world, rank, 7)
+        frontals = tp.frontals
+    else:
+        owner = partition_cliques(tree, world)
+        tp = iif.TreeProgram(fg, tree, seed=7, owner=owner, rank=rank)
+        frontals = {c: tree.cliques[c].frontalIDs for c in tp.cliques}
     be = OracleBackend(100, tp.n_slots, 0, threads=2)
     for v in fg.ls():
         var = fg.getVariable(v)
@@ -45,7 +79,7 @@ def main():
     runner.run()
     res = {}
     for c in tp.cliques:
-        for v in tree.cliques[c].frontalIDs:
+        for v in frontals[c]:
             pts, bw = be.slot_read(tp.main[v], fg.getVariable(v).varType.manifold)
             res[v] = pts
             res[v + "_bw"] = bw

@@ -26,10 +26,10 @@ def test_partition_covers_tree_and_balances():
         counts = np.bincount(list(owner.values()), minlength=world)
         assert counts.min() > 0 and counts.max() <= 2.0 * len(tree.cliques) / world
         cross = sum(1 for c, cl in tree.cliques.items() if cl.parent >= 0 and owner[c] != owner[cl.parent])
-        assert cross <= 2 * world  # only the top of the tree crosses ranks
+        assert cross <= 3 * world  # only the top of the tree crosses ranks (siblings of a level spread over ranks: a few more edges)
 
 
-@pytest.mark.parametrize("mode", ["priors", "joint"])
+@pytest.mark.parametrize("mode", ["priors", "joint", "native"])  # native: this rank's share compiled by libnbp's C++ host
 def test_two_rank_gloo_matches_single_process(tmp_path, mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
