@@ -103,6 +103,16 @@ def timed_steps(rs, steps, warmup, barrier):
 
 
 def main():
+    # stdout carries ONE JSON line: whatever libraries print there (RCCL's version banner, for one) goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _main(real_stdout)
+    finally:
+        os.dup2(real_stdout, 1)
+
+
+def _main(real_stdout):
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,7 +267,7 @@ def main():
                                  if "cpu_baseline" in out else None, "target_vs_cpu_baseline": 20.0}
         rs10.close()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

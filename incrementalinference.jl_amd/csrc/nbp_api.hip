@@ -219,7 +219,10 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   for (const void *k : {(const void *)nbp_product_kernel_t2_e1, (const void *)nbp_product_kernel_t2_e2, (const void *)nbp_product_kernel_t2_e3,
                         (const void *)nbp_product_kernel_t2_ci, (const void *)nbp_product_kernel_t2_se, (const void *)nbp_product_kernel_m4_e1,
                         (const void *)nbp_product_kernel_m4_e2, (const void *)nbp_product_kernel_m4_e3, (const void *)nbp_product_kernel_m4_ci,
-                        (const void *)nbp_product_kernel_m4_se})
+                        (const void *)nbp_product_kernel_m4_se, (const void *)nbp_product_kernel_t2_e1_xs, (const void *)nbp_product_kernel_t2_e2_xs,
+                        (const void *)nbp_product_kernel_t2_e3_xs, (const void *)nbp_product_kernel_t2_ci_xs, (const void *)nbp_product_kernel_t2_se_xs,
+                        (const void *)nbp_product_kernel_m4_e1_xs, (const void *)nbp_product_kernel_m4_e2_xs, (const void *)nbp_product_kernel_m4_e3_xs,
+                        (const void *)nbp_product_kernel_m4_ci_xs, (const void *)nbp_product_kernel_m4_se_xs})
     HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_bandwidth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -532,8 +535,21 @@ static int coords_of(const int32_t *manis, size_t n) {
   for (size_t i = 0; i < n; i++) cds += manifold_dim_h(manis[i]);
   return cds;
 }
+static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G);
+// The product launch of a batch takes the node sums from the sorted coordinates itself (the _xs kernels: 4 KB instead of
+// 33 KB of KD workspace per density through HBM) when the batch runs a single-manifold throughput kernel and every
+// product has at most NBP_FUSED_MAXF densities; the prep launch in front then leaves the node sums out.
+static bool products_use_xs(nbp_ctx *c, int n, int maxFD, int mani) {
+  static const bool off = getenv("NBP_NO_XS_PRODUCTS") != nullptr;
+  if (off || mani == 0 || n <= 0) return false;
+  int HL, wpb, G;
+  product_geometry(c, n, &HL, &wpb, &G);
+  const int F = maxFD / 4, D = maxFD % 4;
+  if (HL > 4 || F > NBP_FUSED_MAXF) return false;
+  return nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) + 8 + nbp_product_xs_doubles(F, D, c->N) * 8 <= 150 * 1024;
+}
 static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
-                              const nbp_product_desc *dev, int n, int maxFD, int coords = -1) {
+                              const nbp_product_desc *dev, int n, int maxFD, int coords = -1, int mani = 0) {
   if (coords < 0) coords = 3 * nbw;
   nbp_status rc = ensure_ws(c, n, maxFD / 4);
   if (rc) return rc;
@@ -543,25 +559,26 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   size_t lds = nbp_kd_lds_bytes(3, c->N, c->Npad, P);
   if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, P);
   (void)hipGetLastError();
-  const int kdF = maxFD / 4;
+  const int kdF = (maxFD / 4) | (products_use_xs(c, n, maxFD, mani) ? NBP_KD_NOSTATS : 0);
+  const int nkd = n * (maxFD / 4);  // KD-build workgroups
   // latency mode: a handful of fits, the rest of the chip idle -> NBP_SPEC_K workgroups per fit
   // 3 workgroups per fit (two iterations per rendezvous) when the whole launch is resident at once (7 / three on request)
   int depth = 0;
   if (c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS) {
-    if (c->spec_depth3 && coords * 7 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 3;
-    else if (coords * 3 + n * kdF <= NBP_SPEC_MAXBLOCKS) depth = 2;
+    if (c->spec_depth3 && coords * 7 + nkd <= NBP_SPEC_MAXBLOCKS) depth = 3;
+    else if (coords * 3 + nkd <= NBP_SPEC_MAXBLOCKS) depth = 2;
   }
   const bool spec = depth > 0;
   const int KS = spec ? (1 << depth) - 1 : 1;
   if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
   if (depth == 3)
-    hipLaunchKernelGGL(nbp_prep_kernel_spec<3>, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+    hipLaunchKernelGGL(nbp_prep_kernel_spec<3>, dim3(3 * nbw * KS + nkd), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
                        dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec);
   else if (depth == 2)
-    hipLaunchKernelGGL(nbp_prep_kernel_spec<2>, dim3(3 * nbw * KS + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+    hipLaunchKernelGGL(nbp_prep_kernel_spec<2>, dim3(3 * nbw * KS + nkd), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
                        dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec);
   else
-    hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + n * kdF), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
+    hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + nkd), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
                        dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
@@ -583,9 +600,23 @@ static const size_t NBP_PRODUCT_LDS_CAP = 150 * 1024;
 typedef void (*nbp_product_fn)(const nbp_product_desc *, double *, const double *, int, double *, int, int64_t, int32_t *, nbp_levels);
 // the kernel of a product launch: HL helper lanes per sample; `mani` != 0: every multi-density product of the batch lives
 // on that manifold and has only full inputs (the throughput variants then run the single-instantiation kernels)
-static nbp_product_fn product_kernel_for(int HL, int mani) {
+static nbp_product_fn product_kernel_for(int HL, int mani, bool xs = false) {
   if (HL == 16) return nbp_product_kernel_x16;
   if (HL == 8) return nbp_product_kernel_l8;
+  if (xs) {
+    switch (mani * 8 + HL) {
+    case NBP_EUCLID1 * 8 + 4: return nbp_product_kernel_m4_e1_xs;
+    case NBP_EUCLID2 * 8 + 4: return nbp_product_kernel_m4_e2_xs;
+    case NBP_EUCLID3 * 8 + 4: return nbp_product_kernel_m4_e3_xs;
+    case NBP_CIRCULAR * 8 + 4: return nbp_product_kernel_m4_ci_xs;
+    case NBP_SE2 * 8 + 4: return nbp_product_kernel_m4_se_xs;
+    case NBP_EUCLID1 * 8 + 2: return nbp_product_kernel_t2_e1_xs;
+    case NBP_EUCLID2 * 8 + 2: return nbp_product_kernel_t2_e2_xs;
+    case NBP_EUCLID3 * 8 + 2: return nbp_product_kernel_t2_e3_xs;
+    case NBP_CIRCULAR * 8 + 2: return nbp_product_kernel_t2_ci_xs;
+    default: return nbp_product_kernel_t2_se_xs;
+    }
+  }
   if (HL == 4) {
     switch (mani) {
     case NBP_EUCLID1: return nbp_product_kernel_m4_e1;
@@ -628,7 +659,8 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
     product_geometry(c, 16, &HL, &wpb, &G);
   }
   const int TB = wpb * 64, SPB = TB / HL;
-  const size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big);
+  const bool xs = !big && products_use_xs(c, n, maxFD, mani);
+  const size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
   if (lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: too many densities for the LDS label table");
   nbp_status rc = NBP_OK;
   double *gs = nullptr;
@@ -640,7 +672,7 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(product_kernel_for(HL, mani), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
+  hipLaunchKernelGGL(product_kernel_for(HL, mani, xs), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }
@@ -778,7 +810,7 @@ nbp_status nbp_run_products(nbp_ctx *c, const nbp_product_desc *descs, int32_t n
   const int32_t *ds, *dm;
   rc = stage_with_jobs(c, descs, sizeof(nbp_product_desc) * (size_t)n, js, jm, &ds, &dm);
   if (rc) return rc;
-  rc = launch_prep(c, nullptr, nullptr, 0, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n));  // KD trees
+  rc = launch_prep(c, nullptr, nullptr, 0, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n), -1, products_uniform_manifold(descs, n));  // KD trees
   if (rc) return rc;
   rc = launch_products(c, (const nbp_product_desc *)c->stage, n, products_maxfd(descs, n), products_uniform_manifold(descs, n));
   if (rc) return rc;
@@ -1456,7 +1488,7 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
-      if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd, coords_of(st.ent_m.data(), st.ent_m.size()));
+      if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd, coords_of(st.ent_m.data(), st.ent_m.size()), st.mani);
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd, st.mani);
     } else if (st.kind == NBP_STAGE_DECONV) {
       rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);

@@ -1354,9 +1354,14 @@ struct golden_state {
 __device__ __forceinline__ double golden_step(golden_state &g, bool c, double R, double C) {
   // one explicit fma per position (hipcc contracts a * b + c wherever it likes, and differently in different
   // functions): the sequential search and this one then walk through bit-identical positions
-  if (c) { g.x0 = g.x1; g.x1 = g.x2; g.x2 = fma(R, g.x1, C * g.x3); g.f1 = g.f2; return g.x2; }
-  g.x3 = g.x2; g.x2 = g.x1; g.x1 = fma(R, g.x2, C * g.x0); g.f2 = g.f1;
-  return g.x1;
+  // Both outcomes as selects (the values of `if (c) {x0 = x1; x1 = x2; x2 = fma(R, x1, C x3); f1 = f2} else {x3 = x2; x2 = x1;
+  // x1 = fma(R, x2, C x0); f2 = f1}`): with branches the compiler merges the conditional stores into "store to field f1 or
+  // f2" and the whole state goes to scratch (48 B per lane in the speculative kernels)
+  const double up = fma(R, g.x2, C * g.x3), dn = fma(R, g.x1, C * g.x0);
+  const double x0 = c ? g.x1 : g.x0, x1 = c ? g.x2 : dn, x2 = c ? up : g.x1, x3 = c ? g.x3 : g.x2;
+  const double f1 = c ? g.f2 : g.f1, f2 = c ? g.f2 : g.f1;
+  g.x0 = x0; g.x1 = x1; g.x2 = x2; g.x3 = x3; g.f1 = f1; g.f2 = f2;
+  return c ? x2 : x1;
 }
 __device__ __forceinline__ bool golden_done(const golden_state &g, double tol) { return !(fabs(g.x3 - g.x0) > tol * (fabs(g.x1) + fabs(g.x2))); }
 
@@ -1403,7 +1408,9 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   bool solo = false;  // gave up on the peers: the sequential search from here on
   int round = 0;
   unsigned int nev = 2;
-  double vals[K + 1];
+  // the values of a round stay where the rendezvous put them (LDS): picked by a run-time node index below, a register
+  // array would live in scratch (112 B per lane, written back to HBM once per launch)
+  const double *vals = red + 48;
   // rendezvous: publish the value of this role's point, collect all K values; false = on our own from now on
   auto rendezvous = [&](double mine) -> bool {
     if (round >= NBP_SPEC_ROUNDS) return false;
@@ -1437,10 +1444,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
     }
     __syncthreads();
     const bool ok_ = box[0] != 0.0;
-    if (ok_) {
-#pragma unroll
-      for (int r = 0; r < K; r++) vals[r + 1] = box[r + 1];
-    }
+    vals = box;  // vals[r + 1] = the value of role r
     round++;
     return ok_;
   };
@@ -1483,7 +1487,9 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
       } else if (solo_stage == 0) { g.f1 = v; solo_stage = 1; }
       else { g.f2 = v; starting = false; }
     } else if (solo) {
-      if (c) g.f2 = v; else g.f1 = v;
+      // (selects, not a store to "f1 or f2": a field picked at run time puts the whole state into scratch)
+      g.f2 = c ? v : g.f2;
+      g.f1 = c ? g.f1 : v;
     } else {
       if (!rendezvous(v)) { solo = true; continue; }
       // advance up to DEPTH iterations with the values now known
@@ -1492,7 +1498,9 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
 #pragma unroll
       for (int lvl = 0; lvl < DEPTH; lvl++) {
         (void)golden_step(g, cc, R, C);
-        if (cc) g.f2 = vals[node]; else g.f1 = vals[node];
+        const double vn = vals[node];
+        g.f2 = cc ? vn : g.f2;
+        g.f1 = cc ? g.f1 : vn;
         nev++;
         if (lvl == DEPTH - 1 || golden_done(g, tol)) break;
         cc = g.f2 < g.f1;

@@ -742,10 +742,15 @@ static inline size_t nbp_kd_lds_bytes(int D, int N, int Npad, int P) {
   return ((size_t)D * N + 3 * Npad + NBP_RED + 2 * NBP_KD_PARTS) * 8 + ((size_t)2 * N + (size_t)P * Npad + 2) * 4;
 }
 
+// kdF: the largest nfactors of the batch in its low 16 bits; bit 16 = the product launch behind this one takes the node
+// sums from the sorted coordinates itself (product_kernel_uniform<.., XS = true>): the KD builds leave them out
+#define NBP_KD_NOSTATS 0x10000
 template <int SPEC>
-__device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF,
+__device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF_,
                                           double *arena, double *ws, int N, int Npad, int64_t S, const nbp_levels &T, nbp_counters *ctr,
                                           nbp_spec_area *spec, double *smem) {
+  const int kdF = kdF_ & 0xFFFF;
+  const bool nostats = (kdF_ & NBP_KD_NOSTATS) != 0;
   const int b = blockIdx.x;
   constexpr int KS = SPEC ? (1 << SPEC) - 1 : 1;  // workgroups per (slot, coordinate)
   if (b < 3 * nbw * KS) {  // manikde! bandwidth of (slot, coordinate)
@@ -761,7 +766,7 @@ __device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t
   double *wsj = ws + (size_t)(p * kdF + j) * nbp_kd_ws_doubles(N);
   const int mask = d->in_partial[j] ? d->in_partial[j] : 7;
   if (j == 0 && d->old_slot >= 0) topup_slot(arena + S * d->old_slot, N, d->manifold, d->seed);  // oldPoints of the product
-  double *cenj = wsj + 3 * N, *stj = wsj + nbp_kd_stats_offset(N);
+  double *cenj = wsj + 3 * N, *stj = nostats ? nullptr : wsj + nbp_kd_stats_offset(N);
   int *idxj = (int *)(wsj + 3 * N + 4);
   switch (mani_dim(d->manifold)) {
   case 1: kd_build<1>(x, wsj, cenj, idxj, stj, N, Npad, T, smem, 1); break;
@@ -1214,13 +1219,45 @@ __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *desc
 // homogeneous graph) runs a kernel that holds that one instantiation: the register allocation of the throughput
 // variants is then the body's own need instead of the maximum over all manifolds (scratch per lane at 4 waves per
 // SIMD: generic 308-328 B, Euclid(1) 0, Euclid(2) 64 B, Euclid(3) 52 B).
-template <int MANI, int HL>
+// XS: the workgroup stages the sorted, centred coordinates of its F <= NBP_FUSED_MAXF densities in LDS (F x D x N doubles
+// behind the product's own areas) and takes the node sums of every level from there -- the same leaf-order sums kd_build
+// would have left in the workspace -- so that a KD workspace carries 4 KB per density (coordinates, centres, permutation)
+// through HBM instead of 33 KB (the 2 x D x ~2N node sums written by the prep launch and read back here).
+__host__ __device__ inline size_t nbp_product_xs_doubles(int F, int D, int N) { return (size_t)F * D * N + 6 * (size_t)F; }
+template <int MANI, int HL, bool XS>
 __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
                                                        double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
   if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
   product_write_ipc(d, arena, N, S);
-  product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);  // HL = 4 / 2: never BIG (launch_products)
+  if constexpr (XS) {
+    constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
+    const int F = d->nfactors, TB = blockDim.x, tid = threadIdx.x;
+    nbp_fused_io fio;
+    const size_t own = (product_lds_layout(F, D, N, TB / HL, false, smem, &fio.L) + 7) / 8;
+    double *xs = smem + own, *cen = xs + (size_t)F * D * N, *bw = cen + 3 * F;
+    const size_t wsd = nbp_kd_ws_doubles(N);
+    const double *wsp = ws + (size_t)blockIdx.x * kdF * wsd;
+    for (int t = tid; t < F * D * N; t += TB) {
+      const int j = t / (D * N), r = t - j * (D * N);
+      xs[t] = wsp[(size_t)j * wsd + r];
+    }
+    for (int t = tid; t < F * 3; t += TB) {
+      const int j = t / 3, k = t % 3;
+      cen[t] = wsp[(size_t)j * wsd + 3 * N + k];
+      bw[t] = arena[S * d->in_slot[j] + 3 * N + k];
+    }
+    fio.xs = xs;
+    fio.xs_stride = (size_t)D * N;
+    fio.idx = (const int *)(wsp + 3 * N + 4);
+    fio.idx_stride = wsd * 2;  // in ints
+    fio.cen = cen;
+    fio.bw = bw;
+    fio.out = arena + S * d->out_slot;
+    __syncthreads();
+    product_body<MANI, false, HL, false, true>(d, arena, ws, kdF, gstats, N, S, side, T, smem, &fio);
+  } else
+    product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);  // HL = 4 / 2: never BIG (launch_products)
 }
 
 // Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in
@@ -1266,10 +1303,14 @@ __global__ void nbp_product_kernel_t2(NBP_PRODUCT_ARGS);
 #define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES)                                                                        \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME(NBP_PRODUCT_ARGS) { \
     extern __shared__ double smem[];                                                                               \
-    product_kernel_uniform<MANI, HL>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                           \
+    product_kernel_uniform<MANI, HL, false>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                    \
+  }                                                                                                                \
+  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME##_xs(NBP_PRODUCT_ARGS) { \
+    extern __shared__ double smem[];                                                                               \
+    product_kernel_uniform<MANI, HL, true>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                     \
   }
 #else
-#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) __global__ void NAME(NBP_PRODUCT_ARGS);
+#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) __global__ void NAME(NBP_PRODUCT_ARGS); __global__ void NAME##_xs(NBP_PRODUCT_ARGS);
 #endif
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e1, NBP_EUCLID1, 2)
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e2, NBP_EUCLID2, 2)
