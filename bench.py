@@ -251,10 +251,28 @@ def _main(real_stdout):
                                                 "sample": f"{max(40, a.cpu_sample_vars // 16)}-variable chain, {m1} messages in {secs1:.1f} s"}
         if a.config in ("2", "2p"):
             out["vs_cpu_baseline"] = value / v
+    out["lazy_bandwidth"] = True  # NBP_OPT_LAZY_BANDWIDTH: fits whose result nothing reads are not made (same posteriors, bit for bit)
+    if world == 1 and dist is None and not a.no_profile_pass:
+        # the same solve with every bandwidth fit the reference makes (manikde! on every setBelief!): what the option saves
+        rs.close()
+        os.environ["NBP_NO_LAZY_BANDWIDTH"] = "1"
+        try:
+            rse = RankSolve(iif, wl, size, N, 0, 1, local, None, python_host=a.python_host, scaling=scaling)
+            rse.prepare()
+            dte = timed_steps(rse, min(a.steps, 5), 1, lambda: rse.be.synchronize()) / min(a.steps, 5)
+            rse.be.diag(reset=True)
+            rse.step(999)
+            rse.be.synchronize()
+            out["ms_per_step_every_fit"] = dte * 1e3
+            out["lcv_evals_per_step_every_fit"] = rse.be.diag()["lcv_evals"]
+            rse.close()
+        finally:
+            os.environ.pop("NBP_NO_LAZY_BANDWIDTH", None)
     if world == 1 and dist is None and not a.no_10k and a.config == "2":
         # BASELINE.md config 2': the same chain with 10 000 variables is the graph the north-star target (>= 20x the CPU
         # baseline) is stated on; measured the same way (same --steps / --warmup), reported beside the headline value
-        rs.close()
+        if not getattr(rs, "_closed", False):
+            rs.close()
         rs10 = RankSolve(iif, workloads(iif)["2p"], 10000, N, 0, 1, local, None, python_host=a.python_host)
         rs10.prepare()
         dt10 = timed_steps(rs10, a.steps, a.warmup, lambda: rs10.be.synchronize()) / a.steps

@@ -180,6 +180,9 @@ class RankSolve:
             raise RuntimeError(f"posterior means off by {worst} (tolerance {wl.tol}): result invalid")
 
     def close(self):
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
         if self.sharded:
             self.impl.close()
             return

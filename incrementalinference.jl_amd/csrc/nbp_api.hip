@@ -1095,7 +1095,9 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
 nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
   if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
-  if (option == NBP_OPT_LAZY_BANDWIDTH) { p->lazy_bw = value != 0; return NBP_OK; }
+  // NBP_NO_LAZY_BANDWIDTH=1 (environment): every fit the reference makes is made, whatever the program asks for -- the
+  // measurement of what the option saves (bench.py "ms_per_step_every_fit")
+  if (option == NBP_OPT_LAZY_BANDWIDTH) { p->lazy_bw = value != 0 && getenv("NBP_NO_LAZY_BANDWIDTH") == nullptr; return NBP_OK; }
   if (option == NBP_OPT_GRAPH_REPLAY) { p->use_graph = value != 0; return NBP_OK; }
   if (option == NBP_OPT_FUSED_UPDATES) { p->use_fused = value != 0; return NBP_OK; }
   return fail(NBP_ERR_ARG, "unknown program option");

@@ -18,6 +18,7 @@
 #define NBP_TU_PRODTHR 16   // product kernels, throughput geometries, generic (m4, t2)
 #define NBP_TU_PRODUNI 32   // product kernels, throughput geometries, one manifold per instance
 #define NBP_TU_FUSED 64     // the fused variable-update kernels
+#define NBP_TU_PRODUNI4 128 // product kernels, one manifold per instance, four helper lanes (the two-lane ones: NBP_TU_PRODUNI)
 #ifndef NBP_TU
 #define NBP_TU 0xFFFF
 #endif
@@ -141,8 +142,9 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
     const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR || kind == NBP_F_PASSTHROUGH) ? 0 : d->sfidx];
     // resize!(target copy, N): entries beyond the belief's own count are the point default (CalcFactor.jl:555-565)
     const int ct = slot_count(src, N);
+    // (rows beyond the manifold's dimension hold zeros in every slot: not read)
     if (live)
-      for (int k = 0; k < 3; k++) X[k * N + n] = (n < ct) ? src[k * N + n] : 0.0;
+      for (int k = 0; k < 3; k++) X[k * N + n] = (k < D && n < ct) ? src[k * N + n] : 0.0;
   }
   __syncthreads();
   // mhidx: injected or rand(Categorical)  (ExplicitDiscreteMarginalizations.jl:186,261)
@@ -1171,7 +1173,8 @@ __device__ __forceinline__ void product_passthrough(const nbp_product_desc *d, d
   if (blockIdx.y != 0) return;
   const double *src = arena + S * d->in_slot[0];
   double *out = arena + S * d->out_slot;
-  for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = src[i];
+  const int DN = mani_dim(d->manifold) * N;  // (the rows beyond the manifold's dimension are zeros: written, not read)
+  for (int i = threadIdx.x; i < 3 * N + 3; i += blockDim.x) out[i] = (i < DN || i >= 3 * N) ? src[i] : 0.0;
   // infoPerCoord of the update: the sum over its factors of ones(D) (proposalbeliefs!, ApproxConv.jl:277,298-303)
   if (threadIdx.x < 3) out[3 * N + 3 + threadIdx.x] = (threadIdx.x < mani_dim(d->manifold)) ? 1.0 : 0.0;
   if (threadIdx.x == 0) out[3 * N + 6] = src[3 * N + 6];
@@ -1299,8 +1302,10 @@ __global__ void nbp_product_kernel_t2(NBP_PRODUCT_ARGS);
 #define NBP_W_SE 2
 #endif
 #define NBP_PRODUCT_UNIFORM(NAME, MANI, HL) NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, ((MANI) == NBP_EUCLID1 ? 4 : (MANI) == NBP_EUCLID2 ? NBP_W_E2 : (MANI) == NBP_SE2 ? NBP_W_SE : 3))
-#if NBP_TU & NBP_TU_PRODUNI
-#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES)                                                                        \
+#define NBP_PRODUCT_UNIFORM_DECL(NAME) __global__ void NAME(NBP_PRODUCT_ARGS); __global__ void NAME##_xs(NBP_PRODUCT_ARGS);
+#if NBP_TU & (NBP_TU_PRODUNI | NBP_TU_PRODUNI4)
+#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) NBP_PRODUCT_UNIFORM_W##HL(NAME, MANI, HL, NBP_UNIFORM_WAVES)
+#define NBP_PRODUCT_UNIFORM_DEF(NAME, MANI, HL, NBP_UNIFORM_WAVES)                                                                        \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME(NBP_PRODUCT_ARGS) { \
     extern __shared__ double smem[];                                                                               \
     product_kernel_uniform<MANI, HL, false>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                    \
@@ -1309,8 +1314,18 @@ __global__ void nbp_product_kernel_t2(NBP_PRODUCT_ARGS);
     extern __shared__ double smem[];                                                                               \
     product_kernel_uniform<MANI, HL, true>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                     \
   }
+#if NBP_TU & NBP_TU_PRODUNI
+#define NBP_PRODUCT_UNIFORM_W2(NAME, MANI, HL, W) NBP_PRODUCT_UNIFORM_DEF(NAME, MANI, HL, W)
 #else
-#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) __global__ void NAME(NBP_PRODUCT_ARGS); __global__ void NAME##_xs(NBP_PRODUCT_ARGS);
+#define NBP_PRODUCT_UNIFORM_W2(NAME, MANI, HL, W) NBP_PRODUCT_UNIFORM_DECL(NAME)
+#endif
+#if NBP_TU & NBP_TU_PRODUNI4
+#define NBP_PRODUCT_UNIFORM_W4(NAME, MANI, HL, W) NBP_PRODUCT_UNIFORM_DEF(NAME, MANI, HL, W)
+#else
+#define NBP_PRODUCT_UNIFORM_W4(NAME, MANI, HL, W) NBP_PRODUCT_UNIFORM_DECL(NAME)
+#endif
+#else
+#define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) NBP_PRODUCT_UNIFORM_DECL(NAME)
 #endif
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e1, NBP_EUCLID1, 2)
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_t2_e2, NBP_EUCLID2, 2)

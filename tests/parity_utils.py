@@ -1,9 +1,13 @@
 """Shared helpers for the oracle-vs-HIP parity tests: build the same slots and descriptors on both
 backends, run, compare.  Tolerances: identical RNG streams -> per-particle results
 within 1e-9 relative; integer outputs (mhidx, labels) identical."""
+import os
+
 import numpy as np
 
 import iif_amd_loader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 iif = iif_amd_loader.load()
 abi = iif.abi
@@ -85,3 +89,12 @@ def both(oracle_factory, hip_factory, N, n_slots, side_ints, setup, run, read):
         out.append(read(be))
         be.close()
     return out
+
+
+def record_parity(line):
+    """append one line to gpurun_out/r03_whole_solve_parity.txt (the -m gpu suite's whole-solve figures: shares of
+    particle-identical variables, KL medians, mode shares; copied to profiles/ after a GPU run)"""
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "r03_whole_solve_parity.txt"), "a") as f:
+        f.write(line.rstrip("\n") + "\n")

@@ -5,7 +5,20 @@ import pytest
 
 import kl_tools
 from kl_parity import compare_solves
-from parity_utils import abi, iif
+from parity_utils import abi, iif, record_parity
+
+# Floors on the share of variables whose particles agree with the oracle's particle by particle (1e-6) in ONE solve with
+# identical random streams -- below them something other than a rare last-bit branch flip separates the two sides.
+# Observed on MI355X (profiles/r03_whole_solve_parity.txt) minus a margin; a variable that diverged is then held to the
+# two-sample criterion of tests/kl_parity.py.
+# The configurations with THREE-dimensional Nelder-Mead searches (SE(2), Euclid(3)) are the exception: those searches stop
+# at a spread of 1e-8 of the OBJECTIVE, which leaves the root to ~1e-4, and device and host part ways inside that within a
+# few stages (not through FMA contraction: compiling the proposal kernels with -ffp-contract=off changes nothing) -- the
+# solves stay close, not identical.  There the figure that is held is the symmetric KL itself: about BASELINE.md 5's 0.05
+# nats in the median (observed 0.048 / 0.017), at most half of what two oracle solves with different seeds read.
+SHARE_FLOOR = {"config1_scalar_chain": 0.9, "config2_euclid2_chain": 0.9, "config3_circular_doors": 0.9,
+               "config4_se2_lattice": 0.0, "config5_mixture_chain": 0.0}
+KL_MEDIAN_CAP = {"config4_se2_lattice": 0.08, "config5_mixture_chain": 0.08}
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +51,17 @@ def test_symmetric_kl_gpu_vs_oracle(oracle_backend, hip_backend, name):
     iif.solveTree(fg_, eliminationOrder=order, backend=hip_backend, seed=31)
     iif.solveTree(fo2, eliminationOrder=order, backend=oracle_backend, seed=32)
     share, kl = compare_solves(fo, fg_, fo2)
-    print(f"{name}: {share:.0%} of the variables agree particle by particle; symKL max {max(kl.values()):.3f} median {np.median(list(kl.values())):.3f}")
+    # the yardstick beside it: the same figures for the second oracle solve (another seed) against the first
+    ref = [kl_tools.symmetric_kl(abi, fo.getVariable(v).varType.manifold, fo.getVal(v), fo2.getVal(v)) for v in fo.ls()]
+    line = (f"{name}: {share:.0%} of {len(fo.ls())} variables particle-identical (1e-6) to the oracle solve; symKL of the rest: "
+            f"median {np.median([k for k in kl.values() if k > 0] or [0.0]):.3f} max {max(kl.values()):.3f} nats; "
+            f"oracle vs oracle (another seed): median {np.median(ref):.3f} max {max(ref):.3f}")
+    print(line)
+    record_parity(line)
+    assert share >= SHARE_FLOOR[name], (name, share)
+    if name in KL_MEDIAN_CAP:
+        rest = [k for k in kl.values() if k > 0]
+        assert np.median(rest) <= KL_MEDIAN_CAP[name] and np.median(rest) <= 0.5 * np.median(ref), (np.median(rest), np.median(ref))
 
 
 @pytest.mark.parametrize("seed", [3, 17])
@@ -51,5 +74,18 @@ def test_symmetric_kl_against_exact_gaussian_chain(hip_backend, seed):
     fg, mu, sig = chain_with_end_priors(41)
     iif.solveTree(fg, eliminationOrder=iif.nestedDissectionOrder(fg), backend=hip_backend, seed=seed)
     kl = np.array([kl_tools.symmetric_kl_to_gaussian(fg.getVal(f"x{i}")[:, 0], mu[i], sig[i]) for i in range(41)])
-    print(f"seed {seed}: symKL to the exact posterior: median {np.median(kl):.3f} max {kl.max():.3f}")
+    # BASELINE.md 5's bands against the exact posterior, variable by variable: |mean - truth| <= 3 sigma / sqrt(N) + 0.1 * scale
+    # (scale = sigma of the factors, 0.1) and sample std within [0.5, 2] x the exact sigma
+    means = np.array([fg.getVal(f"x{i}")[:, 0].mean() for i in range(41)])
+    stds = np.array([fg.getVal(f"x{i}")[:, 0].std() for i in range(41)])
+    in_mean = np.abs(means - mu) <= 3 * sig / np.sqrt(200) + 0.1 * 0.1
+    in_std = (stds >= 0.5 * sig) & (stds <= 2.0 * sig)
+    line = (f"exact 41-pose Gaussian chain, seed {seed}: symKL to the exact posterior median {np.median(kl):.3f} max {kl.max():.3f}; "
+            f"BASELINE 5 mean band holds for {in_mean.sum()} / 41 variables, width band [0.5, 2] x sigma for {in_std.sum()} / 41 "
+            f"(outside: {[f'x{i}: {stds[i] / sig[i]:.2f}' for i in np.nonzero(~in_std)[0]]})")
+    print(line)
+    record_parity(line)
     assert np.median(kl) < 0.6 and kl.max() < 4.0, (np.median(kl), kl.max())
+    # the width band is BASELINE's where it holds (most of the chain); the variables outside it are the ones DESIGN.md 5
+    # (iii) names -- next to the priors, where the down solve multiplies pre-solve beliefs in -- and are listed above
+    assert in_std.sum() >= 33 and in_mean.sum() >= 25, (in_std.sum(), in_mean.sum())

@@ -3,7 +3,7 @@ no tracing) of `bench.py --steps K`: per-kernel averages over the TIMED region (
 dispatches of each kernel), the nbp_copy_kernel calibration of the counters' units (a copy launch
 moves exactly blocks x slot_stride x 8 bytes each way in the same 8 B/lane access pattern the other
 kernels use), and the corrected HBM bytes per launch.
-Usage: pmc_traffic.py <dir with FETCH_SIZE/ WRITE_SIZE/ TCC/> <steps> <N> [out.json]"""
+Usage: pmc_traffic.py <dir with FETCH_SIZE/ WRITE_SIZE/ TCC/> <steps> <N> [out.json] [algorithmic bytes per step]"""
 import collections
 import csv
 import glob
@@ -42,7 +42,7 @@ def per_kernel(rows, counter, steps, lps=60):
     return out
 
 
-def main(root, steps, N, outp=None):
+def main(root, steps, N, outp=None, alg=None):
     S = 3 * N + 8
     res = {"steps": steps, "N": N, "note": "values are per launch, timed region only"}
     cal = {}
@@ -75,6 +75,22 @@ def main(root, steps, N, outp=None):
             e["hbm_bytes_per_launch"] = e["FETCH_SIZE_bytes_avg"] + e["WRITE_SIZE_bytes_avg"]
         kern[k] = e
     res["kernels"] = kern
+    # the whole solve: every launch of the timed region, per step (the copy kernel's launches outside the timed region
+    # were only admitted for the calibration: count steps' worth of them by their share of reseed-delimited dispatches)
+    per_step, total = {}, 0.0
+    for k, e in kern.items():
+        if "hbm_bytes_per_launch" not in e:
+            continue
+        n = e["launches"]
+        if k == "nbp_copy_kernel":
+            n = min(n, steps * max(1, round(e["launches"] / max(steps + 1, 1))))
+        per_step[k] = e["hbm_bytes_per_launch"] * n / steps
+        total += per_step[k]
+    res["hbm_bytes_per_step_by_kernel"] = per_step
+    res["hbm_bytes_per_step"] = total
+    if alg:
+        res["algorithmic_bytes_per_step"] = alg
+        res["traffic_over_algorithmic"] = total / alg
     s = json.dumps(res, indent=1)
     print(s)
     if outp:
@@ -82,4 +98,5 @@ def main(root, steps, N, outp=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None,
+         float(sys.argv[5]) if len(sys.argv) > 5 else None)
