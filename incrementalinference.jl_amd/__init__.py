@@ -12,7 +12,7 @@ from .canonical import (generateChainEuclid, generateCircularDoors, generateGrap
                         generateGraph_LineStep, generateMixtureChain, generateSE2Lattice)
 from .factorgraph import (Circular, CircularCircular, ContinuousEuclid, ContinuousScalar,  # noqa: F401
                           EuclidDistance, LinearRelative, ManifoldFactor, ManifoldPrior, Mixture,
-                          MsgPrior, MvNormal, Normal, PartialLinearRelative, PartialPrior, PartialPriorPassThrough, Prior, Rayleigh, Uniform, PriorCircular, SolverParams,
+                          MsgPrior, MvNormal, Normal, PartialLinearRelative, PartialManifoldFactor, PartialPrior, PartialPriorPassThrough, Prior, Rayleigh, Uniform, PriorCircular, SolverParams,
                           SpecialEuclidean2, addFactor, addVariable, deleteFactor, getSolverParams, initfg, isPartial)
 from .solver import (TreeProgram, approxConv, approxConvBelief, approxConvBeliefPath, approxDeconv, findShortestPath,  # noqa: F401
                      product_desc, proposal_desc,

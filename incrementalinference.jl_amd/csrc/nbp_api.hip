@@ -395,8 +395,8 @@ static nbp_status check_proposals(nbp_ctx *c, const nbp_proposal_desc *d, int n)
       if (p.partial_mask < 0 || p.partial_mask >= (1 << D)) return fail(NBP_ERR_RANGE, "proposal: partial_mask");
       if (p.factor_kind == NBP_F_LINREL) {
         if (__builtin_popcount(p.partial_mask) > 2) return fail(NBP_ERR_ARG, "partial LinearRelative: one or two partial coordinates");
-      } else if (p.factor_kind != NBP_F_PRIOR)
-        return fail(NBP_ERR_ARG, "proposal: partial_mask is supported for Prior and LinearRelative factors");
+      } else if (p.factor_kind != NBP_F_PRIOR && p.factor_kind != NBP_F_SE2)
+        return fail(NBP_ERR_ARG, "proposal: partial_mask is supported for Prior, LinearRelative and SE(2) ManifoldFactor factors");
     }
     if (p.meas_kde) {
       if (p.meas_kde < 0 || p.meas_kde > c->n_slots) return fail(NBP_ERR_RANGE, "proposal: meas_kde");
@@ -639,6 +639,11 @@ static nbp_product_fn product_kernel_for(int HL, int mani, bool xs = false) {
 // 0 unless all products with more than one density share a manifold and none has a partial input
 static int products_uniform_manifold(const nbp_product_desc *d, int n) {
   int mani = -1;
+  // a batch of pass-through products only (single densities: AMP returns them) runs the copy path of whichever instance:
+  // the first product's manifold picks a single-manifold kernel instead of the all-manifold one (308 B of scratch per lane)
+  bool multi = false;
+  for (int i = 0; i < n; i++) multi |= d[i].nfactors > 1;
+  if (!multi && n > 0) return d[0].manifold;
   for (int i = 0; i < n; i++) {
     if (d[i].nfactors <= 1) continue;
     for (int j = 0; j < d[i].nfactors; j++)

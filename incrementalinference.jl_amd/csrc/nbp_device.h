@@ -494,6 +494,7 @@ struct objective_t {
   double z[3], other[3];
   double sn_fixed, cs_fixed;  // SE(2), solve_b: sin/cos of the fixed pose's heading (hoisted out of the search)
   int solve_b;
+  int rmask = 7;  // SE(2): the residual components that count (a partial ManifoldFactor: its `.partial` coordinates)
   unsigned int evals;
   __device__ __forceinline__ double normsq(const double *a, const double *b) const {
     double acc = 0;
@@ -513,7 +514,13 @@ struct objective_t {
       double r0 = (a[0] + c * z[0] - s * z[1]) - b[0];
       double r1 = (a[1] + s * z[0] + c * z[1]) - b[1];
       double r2 = wrap_pi((a[2] + z[2]) - b[2]);
-      acc = r0 * r0 + r1 * r1 + r2 * r2;
+      if (rmask == 7) acc = r0 * r0 + r1 * r1 + r2 * r2;
+      else {  // the same order of additions as the full sum, components outside the mask left out
+        acc = 0;
+        if (rmask & 1) acc += r0 * r0;
+        if (rmask & 2) acc += r1 * r1;
+        if (rmask & 4) acc += r2 * r2;
+      }
     } else {  // NBP_F_EUCLIDDIST, Factors/EuclidDistance.jl:20
       double q = 0;
 #pragma unroll
@@ -682,28 +689,34 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
 
 // Optim.BFGS for a 1-D decision variable (islen1 branch), central finite differences,
 // Armijo / quadratic-interpolation line search (documented deviation from HagerZhang).
+// (the decision variable travels as a scalar and becomes a one-element array only inside the call of the objective:
+//  arrays that live across the line-search loop end up in scratch)
+template <class OBJ>
+__device__ __forceinline__ double eval1(OBJ &o, double x) {
+  const double t[1] = {x};
+  return o(t);
+}
 template <class OBJ>
 __device__ __forceinline__ double fd_grad1(OBJ &o, double x) {
   double h = 6.0554544523933395e-06 * fmax(1.0, fabs(x));
-  double xp[1] = {x + h}, xm[1] = {x - h};
-  return (o(xp) - o(xm)) / (2.0 * h);
+  return (eval1(o, x + h) - eval1(o, x - h)) / (2.0 * h);
 }
 
 template <class OBJ>
 __device__ __forceinline__ bool bfgs_1d(OBJ &o, double (&x)[1]) {
-  double xc[1] = {x[0]};
-  double fx = o(xc), g = fd_grad1(o, xc[0]), H = 1.0;
+  double xc = x[0];
+  double fx = eval1(o, xc), g = fd_grad1(o, xc), H = 1.0;
   bool converged = false;
   for (int it = 0; it < 1000; it++) {
     if (fabs(g) <= 1e-8) { converged = true; break; }
     double s = -H * g;
     if (s * g >= 0) { H = 1.0; s = -g; }
     double al = 1.0, dphi0 = g * s, fn = fx;
-    double xn[1] = {xc[0]};
+    double xn = xc;
     bool ok = false;
     for (int ls = 0; ls < 50; ls++) {
-      xn[0] = xc[0] + al * s;
-      fn = o(xn);
+      xn = xc + al * s;
+      fn = eval1(o, xn);
       if (fn <= fx + 1e-4 * al * dphi0) { ok = true; break; }
       double aq = -dphi0 * al * al / (2.0 * (fn - fx - dphi0 * al));
       if (!(aq >= 0.1 * al)) aq = 0.1 * al;
@@ -711,12 +724,12 @@ __device__ __forceinline__ bool bfgs_1d(OBJ &o, double (&x)[1]) {
       al = aq;
     }
     if (!ok) break;
-    double gn = fd_grad1(o, xn[0]), dx = xn[0] - xc[0], dg = gn - g;
+    double gn = fd_grad1(o, xn), dx = xn - xc, dg = gn - g;
     if (dx == 0.0) { converged = fabs(gn) <= 1e-8; break; }
     if (dx * dg > 0) H = dx / dg;
-    xc[0] = xn[0]; fx = fn; g = gn;
+    xc = xn; fx = fn; g = gn;
   }
-  x[0] = xc[0];
+  x[0] = xc;
   return converged;
 }
 
@@ -835,10 +848,11 @@ __device__ __forceinline__ bool bfgs_nd(OBJ &o, double (&x)[DN]) {
 template <int KIND, int DN, bool PARTIAL_BFGS = false>
 __device__ NBP_SOLVE_ATTR void solve_particle_t(int manifold, const double *z, const double *other, int solve_b, double *x,
                                                  unsigned int &n_solves, unsigned int &n_nonconv, unsigned int &n_nan,
-                                                 unsigned int &n_evals) {
+                                                 unsigned int &n_evals, int rmask = 7) {
   objective_t<KIND, DN> o;
   o.solve_b = solve_b;
   o.evals = 0;
+  o.rmask = PARTIAL_BFGS ? rmask : 7;
 #pragma unroll
   for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
   o.sn_fixed = 0.0;
@@ -865,6 +879,13 @@ __device__ NBP_SOLVE_ATTR void solve_particle_t(int manifold, const double *z, c
 __device__ __forceinline__ void solve_particle_partial2(const double *z, const double *other, int solve_b, double *x, unsigned int &a,
                                                         unsigned int &b, unsigned int &c, unsigned int &e) {
   solve_particle_t<NBP_F_LINREL, 2, true>(NBP_EUCLID2, z, other, solve_b, x, a, b, c, e);
+}
+
+// a partial ManifoldFactor on SE(2): the residual counts the components of `.partial` only, the search is BFGS over the
+// whole point (NumericalCalculations.jl:424-446: `islen1 = ... || ccwl.partial`, the decision variable is the full u0)
+__device__ __forceinline__ void solve_particle_partial_se2(const double *z, const double *other, int solve_b, double *x, int rmask, unsigned int &a,
+                                                           unsigned int &b, unsigned int &c, unsigned int &e) {
+  solve_particle_t<NBP_F_SE2, 3, true>(NBP_SE2, z, other, solve_b, x, a, b, c, e, rmask);
 }
 
 // wave-uniform dispatch on (factor kind, tangent dimension)

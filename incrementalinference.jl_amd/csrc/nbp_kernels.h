@@ -32,7 +32,10 @@
 // ================================================================================================
 __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, const double *arena,
                                                    int64_t S, int N) {
+  // (one exit, the three coordinates as scalars until then: with a return per measurement family the array the caller
+  //  hands in ends up in scratch)
   const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;  // stored measurement of an earlier op, or fresh
+  double z0, z1 = 0.0, z2 = 0.0;
   if (d->meas_kde > 0) {
     // the measurement is a KDE (differential message factor): sample(belief) = random kernel + bw*randn
     // (manifolds/services/ManifoldSampling.jl:13-19), like the MsgPrior draw below
@@ -44,39 +47,41 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
     if (i >= cm) i = cm - 1;
     normal_pair(mseed, n, PURP_KDENOISE, 0, n0, n1);
     if (zdim > 2) normal_pair(mseed, n, PURP_KDENOISE, 1, n2, n3);
-    z[0] = msg[i] + msg[3 * N] * n0;
-    z[1] = (zdim > 1) ? msg[N + i] + msg[3 * N + 1] * n1 : 0.0;
-    z[2] = (zdim > 2) ? msg[2 * N + i] + msg[3 * N + 2] * n2 : 0.0;
-    return;
-  }
-  int c = 0;
-  if (d->ncomp > 1) {  // Mixture.sampleFactor, Factors/Mixture.jl:114-155
-    double ua, ub, cum = 0;
-    uniform_pair(mseed, n, PURP_MIXLBL, 0, ua, ub);
-    int last = 0;
-    c = -1;
-    for (int i = 0; i < d->ncomp; i++) {
-      const double w = d->comp[i][0];
-      if (w > 0) last = i;
-      cum += w;
-      if (c < 0 && ua < cum) c = i;
+    z0 = msg[i] + msg[3 * N] * n0;
+    z1 = (zdim > 1) ? msg[N + i] + msg[3 * N + 1] * n1 : 0.0;
+    z2 = (zdim > 2) ? msg[2 * N + i] + msg[3 * N + 2] * n2 : 0.0;
+  } else {
+    int c = 0;
+    if (d->ncomp > 1) {  // Mixture.sampleFactor, Factors/Mixture.jl:114-155
+      double ua, ub, cum = 0;
+      uniform_pair(mseed, n, PURP_MIXLBL, 0, ua, ub);
+      int last = 0;
+      c = -1;
+      for (int i = 0; i < d->ncomp; i++) {
+        const double w = d->comp[i][0];
+        if (w > 0) last = i;
+        cum += w;
+        if (c < 0 && ua < cum) c = i;
+      }
+      if (c < 0) c = last;
     }
-    if (c < 0) c = last;
+    const double *cp = d->comp[c];
+    if (zdim == 1 && cp[12] != 0.0) {  // scalar Uniform / Rayleigh component (enum nbp_dist)
+      double ua, ub;
+      uniform_pair(mseed, n, PURP_MEAS, 0, ua, ub);
+      z0 = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
+    } else {
+      double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+      normal_pair(mseed, n, PURP_MEAS, 0, n0, n1);
+      if (zdim > 2) normal_pair(mseed, n, PURP_MEAS, 1, n2, n3);
+      z0 = cp[1] + cp[4] * n0;
+      z1 = (zdim > 1) ? cp[2] + cp[7] * n0 + cp[8] * n1 : 0.0;
+      z2 = (zdim > 2) ? cp[3] + cp[10] * n0 + cp[11] * n1 + cp[12] * n2 : 0.0;
+    }
   }
-  const double *cp = d->comp[c];
-  if (zdim == 1 && cp[12] != 0.0) {  // scalar Uniform / Rayleigh component (enum nbp_dist)
-    double ua, ub;
-    uniform_pair(mseed, n, PURP_MEAS, 0, ua, ub);
-    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
-    z[1] = z[2] = 0.0;
-    return;
-  }
-  double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-  normal_pair(mseed, n, PURP_MEAS, 0, n0, n1);
-  if (zdim > 2) normal_pair(mseed, n, PURP_MEAS, 1, n2, n3);
-  z[0] = cp[1] + cp[4] * n0;
-  z[1] = (zdim > 1) ? cp[2] + cp[7] * n0 + cp[8] * n1 : 0.0;
-  z[2] = (zdim > 2) ? cp[3] + cp[10] * n0 + cp[11] * n1 + cp[12] * n2 : 0.0;
+  z[0] = z0;
+  z[1] = z1;
+  z[2] = z2;
 }
 
 // addEntropyOnManifold!, EvalFactor.jl:95-132
@@ -87,13 +92,12 @@ __device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int 
   uniform_pair(seed, n, PURP_ENTROPY, kbase, u0, u1);
   if (D > 2) uniform_pair(seed, n, PURP_ENTROPY, kbase + 1, u2, u3);
   if (mask == 0) mask = 7;
-  double v0 = x[0] + spread * (u0 - 0.5);
-  if (mask & 1) x[0] = is_circ(manifold, 0) ? wrap_pi(v0) : v0;
-  if (D > 1 && (mask & 2)) x[1] = x[1] + spread * (u1 - 0.5);
-  if (D > 2 && (mask & 4)) {
-    double v2 = x[2] + spread * (u2 - 0.5);
-    x[2] = is_circ(manifold, 2) ? wrap_pi(v2) : v2;
-  }
+  // (selects, not conditional stores: the compiler merges those into stores through a selected address, and the caller's
+  //  point then lives in scratch)
+  const double v0 = x[0] + spread * (u0 - 0.5), v1 = x[1] + spread * (u1 - 0.5), v2 = x[2] + spread * (u2 - 0.5);
+  x[0] = (mask & 1) ? (is_circ(manifold, 0) ? wrap_pi(v0) : v0) : x[0];
+  x[1] = (D > 1 && (mask & 2)) ? v1 : x[1];
+  x[2] = (D > 2 && (mask & 4)) ? (is_circ(manifold, 2) ? wrap_pi(v2) : v2) : x[2];
 }
 
 // calcVariableDistanceExpectedFractional, EvalFactor.jl:40-92 (block-uniform result)
@@ -253,10 +257,13 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
     // a partial relative factor measures, inflates and solves its `.partial` coordinates only (validated on the host:
     // LinearRelative, one or two of the variable's coordinates)
     const int pmask = FIXK ? 0 : d->partial_mask, npd = __popc(pmask & 7);
-    const int pdim = pmask ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;                  // first partial coordinate
-    const int pdim2 = (npd > 1) ? ((pmask & 1) && (pmask & 2) ? 1 : 2) : -1;              // second one
     const int rkind = FIXK ? FIXK : kind;
-    const int zdim = pmask ? npd : ((rkind == NBP_F_LINREL) ? D : (rkind == NBP_F_SE2 ? 3 : 1));
+    // a partial ManifoldFactor on SE(2) keeps its full measurement and searches over the whole point (its residual counts
+    // the partial components only); a partial LinearRelative measures and searches its partial coordinates
+    const bool pse2 = !FIXK && pmask && rkind == NBP_F_SE2;
+    const int pdim = (pmask && !pse2) ? (pmask & 1 ? 0 : (pmask & 2 ? 1 : 2)) : -1;       // first partial coordinate
+    const int pdim2 = (npd > 1 && !pse2) ? ((pmask & 1) && (pmask & 2) ? 1 : 2) : -1;     // second one
+    const int zdim = (pmask && !pse2) ? npd : ((rkind == NBP_F_LINREL) ? D : (rkind == NBP_F_SE2 ? 3 : 1));
     double z[3] = {0, 0, 0};
     if (live) sample_measurement(d, n, zdim, z, arena, S, N);  // sampleFactor!, CalcFactor.jl:578
     const int sf1 = d->sfidx + 1;
@@ -291,7 +298,9 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
           if (myh == hyp) {
             double x[3] = {X[n], X[N + n], X[2 * N + n]};
             add_entropy(M, D, x, n, spread, d->seed, (g * 8 + c) * 2, pmask);
-            if (pdim2 >= 0) {  // two partial coordinates: BFGS on the pair (NumericalCalculations.jl:108,424)
+            if (pse2) {
+              solve_particle_partial_se2(z, oth, solve_b, x, pmask, n_solves, n_nonconv, n_nan, n_evals);
+            } else if (pdim2 >= 0) {  // two partial coordinates: BFGS on the pair (NumericalCalculations.jl:108,424)
               double x2[3] = {pdim == 0 ? x[0] : x[1], pdim2 == 1 ? x[1] : x[2], 0};
               const double o2[3] = {pdim == 0 ? oth[0] : oth[1], pdim2 == 1 ? oth[1] : oth[2], 0};
               solve_particle_partial2(z, o2, solve_b, x2, n_solves, n_nonconv, n_nan, n_evals);
@@ -339,6 +348,18 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
   if (n < 3) out[3 * N + 3 + n] = (n < D && (!d->partial_mask || ((d->partial_mask >> n) & 1))) ? 1.0 : 0.0;
   if (n == 0) out[3 * N + 6] = 0.0;  // a proposal always holds N points
   NBP_BLOCK_END();
+#ifdef NBP_PHASE_TIMING
+  {  // lane utilisation of the per-particle searches: residual evaluations summed over the lanes vs 64 x the wave's slowest lane
+    unsigned int mx = n_evals;
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
+    unsigned long long sm = n_evals;
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if ((threadIdx.x & 63) == 0 && mx) {
+      atomicAdd((unsigned long long *)&nbp_phase_clk[60], sm);
+      atomicAdd((unsigned long long *)&nbp_phase_clk[61], 64ull * mx);
+    }
+  }
+#endif
   // diagnostics: one atomic per wave
   {
     unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
@@ -1280,11 +1301,11 @@ __global__ void nbp_product_kernel_x16(NBP_PRODUCT_ARGS);
 __global__ void nbp_product_kernel_l8(NBP_PRODUCT_ARGS);
 #endif
 #if NBP_TU & NBP_TU_PRODTHR
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) nbp_product_kernel_m4(NBP_PRODUCT_ARGS) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) nbp_product_kernel_m4(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<4>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) nbp_product_kernel_t2(NBP_PRODUCT_ARGS) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) nbp_product_kernel_t2(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<2>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
@@ -1301,7 +1322,10 @@ __global__ void nbp_product_kernel_t2(NBP_PRODUCT_ARGS);
 #ifndef NBP_W_SE
 #define NBP_W_SE 2
 #endif
-#define NBP_PRODUCT_UNIFORM(NAME, MANI, HL) NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, ((MANI) == NBP_EUCLID1 ? 4 : (MANI) == NBP_EUCLID2 ? NBP_W_E2 : (MANI) == NBP_SE2 ? NBP_W_SE : 3))
+#ifndef NBP_W_CI
+#define NBP_W_CI 2  // (two waves: no spill -- three spilled 12 B per lane -- and 2 % faster on config 3)
+#endif
+#define NBP_PRODUCT_UNIFORM(NAME, MANI, HL) NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, ((MANI) == NBP_EUCLID1 ? 4 : (MANI) == NBP_EUCLID2 ? NBP_W_E2 : (MANI) == NBP_SE2 ? NBP_W_SE : (MANI) == NBP_CIRCULAR ? NBP_W_CI : 3))
 #define NBP_PRODUCT_UNIFORM_DECL(NAME) __global__ void NAME(NBP_PRODUCT_ARGS); __global__ void NAME##_xs(NBP_PRODUCT_ARGS);
 #if NBP_TU & (NBP_TU_PRODUNI | NBP_TU_PRODUNI4)
 #define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) NBP_PRODUCT_UNIFORM_W##HL(NAME, MANI, HL, NBP_UNIFORM_WAVES)

@@ -207,6 +207,21 @@ class ManifoldFactor(_Factor):
         self.Z = Z
 
 
+class PartialManifoldFactor(ManifoldFactor):
+    """A relative factor on SE(2) that constrains only the residual components in `partial` (1-based: 1, 2 = the
+    translation in the frame of the first pose, 3 = the heading): the reference's `.partial` mechanism applied to
+    ManifoldFactor's residual -- the residual "must deal with the partial" itself and gets the full points, entropy goes
+    on the partial coordinates only, the search is BFGS over the whole point (EvalFactor.jl:184-198,
+    NumericalCalculations.jl:424-446).  Z stays on the full Lie algebra (dx, dy, dtheta); components outside `partial`
+    are sampled and ignored."""
+
+    def __init__(self, varType, Z, partial):
+        self.Z, self.partial = Z, tuple(partial)
+        if varType.manifold != abi.SE2 or not 1 <= len(self.partial) <= 2:
+            raise ValueError("PartialManifoldFactor: an SE(2) variable and one or two partial components")
+        self.partial_mask = _partial_mask(partial, varType.dim)
+
+
 class EuclidDistance(_Factor):
     """EuclidDistance(Z): r = z - ||x2 - x1||   (Factors/EuclidDistance.jl:20)"""
     kind, zdim = abi.F_EUCLIDDIST, 1

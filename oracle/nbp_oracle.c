@@ -326,6 +326,8 @@ int32_t orc_residual(int32_t kind, int32_t manifold, const double *z, const doub
 typedef struct {
   int kind, manifold, D, solve_b; /* solve_b == 2: the measurement is the decision variable (deconv) */
   double z[3], other[3];          /* deconv: z = first variable's point, other = second variable's point */
+  int rmask;                      /* 0: every residual component; else bit k = component k counts (a partial relative
+                                     factor whose residual "deals with the partial" itself, NumericalCalculations.jl:429) */
 } objective_t;
 
 static double objective(const objective_t *o, const double *x) {
@@ -334,7 +336,8 @@ static double objective(const objective_t *o, const double *x) {
            : o->solve_b    ? orc_residual(o->kind, o->manifold, o->z, o->other, x, r)
                            : orc_residual(o->kind, o->manifold, o->z, x, o->other, r);
   double acc = 0;
-  for (int i = 0; i < nr; i++) acc += r[i] * r[i];
+  for (int i = 0; i < nr; i++)
+    if (!o->rmask || ((o->rmask >> i) & 1)) acc += r[i] * r[i];
   return acc;
 }
 
@@ -576,7 +579,7 @@ int orc_bfgs_nd(const objective_t *o, int n, double *x, int *iters) {
 /* _solveCCWNumeric! for one particle, NumericalCalculations.jl:413-452 + :90-133 */
 static void solve_particle(int kind, int manifold, const double *z, const double *other, int solve_b, double *x) {
   objective_t o;
-  o.kind = kind; o.manifold = manifold; o.D = mani_dim(manifold); o.solve_b = solve_b;
+  o.kind = kind; o.manifold = manifold; o.D = mani_dim(manifold); o.solve_b = solve_b; o.rmask = 0;
   for (int i = 0; i < 3; i++) { o.z[i] = z[i]; o.other[i] = other[i]; }
   double xc[3];
   int D = o.D;
@@ -1003,8 +1006,15 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
     if (d->partial_mask) {
       int cnt = 0;
       for (int k = 0; k < D; k++) if ((d->partial_mask >> k) & 1) { if (cnt == 0) pdim = k; else pdim2 = k; cnt++; }
-      if (d->factor_kind != NBP_F_LINREL || cnt < 1 || cnt > 2) { free(mhidx); return NBP_ERR_ARG; }
-      zdim = cnt;
+      if (d->factor_kind == NBP_F_SE2) {
+        /* a partial ManifoldFactor on SE(2): the measurement stays the full group element; the residual counts only the
+         * components in `.partial` (it "must deal with the partial" itself), entropy goes on those coordinates only, and
+         * the search is BFGS over the WHOLE point (`islen1 = ... || ccwl.partial`, NumericalCalculations.jl:424-446) */
+        pdim = pdim2 = -1;
+      } else {
+        if (d->factor_kind != NBP_F_LINREL || cnt < 1 || cnt > 2) { free(mhidx); return NBP_ERR_ARG; }
+        zdim = cnt;
+      }
     }
     double *X = out; /* ccwl.varValsAll[sfidx] = deepcopy(target), CalcFactor.jl:543-548 */
     {
@@ -1040,9 +1050,18 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
             double x[3], oth[3];
             const int io = anyn_index(n, slot_count(O, N), d->seed, vother); /* _getindex_anyn */
             for (int k = 0; k < D; k++) { x[k] = X[k * N + n]; oth[k] = O[k * N + io]; }
-            if (pdim2 >= 0) { /* two partial coordinates: n-D BFGS on the pair */
+            if (d->partial_mask && d->factor_kind == NBP_F_SE2) { /* partial SE(2) factor: BFGS over the whole point */
+              objective_t o3;
+              o3.kind = NBP_F_SE2; o3.manifold = NBP_SE2; o3.D = 3; o3.solve_b = solve_b; o3.rmask = d->partial_mask;
+              for (int k = 0; k < 3; k++) { o3.z[k] = Z[3 * n + k]; o3.other[k] = oth[k]; }
+              double x3[3] = {x[0], x[1], x[2]};
+              t_diag.solves++;
+              if (!orc_bfgs_nd(&o3, 3, x3, 0)) t_diag.nonconverged++;
+              if (isnan(x3[0]) || isnan(x3[1]) || isnan(x3[2])) t_diag.nan_results++;
+              else { x[0] = x3[0]; x[1] = x3[1]; x[2] = orc_wrap(x3[2]); }
+            } else if (pdim2 >= 0) { /* two partial coordinates: n-D BFGS on the pair */
               objective_t o2;
-              o2.kind = NBP_F_LINREL; o2.manifold = NBP_EUCLID2; o2.D = 2; o2.solve_b = solve_b;
+              o2.kind = NBP_F_LINREL; o2.manifold = NBP_EUCLID2; o2.D = 2; o2.solve_b = solve_b; o2.rmask = 0;
               for (int k = 0; k < 3; k++) { o2.z[k] = Z[3 * n + k]; o2.other[k] = 0.0; }
               o2.other[0] = oth[pdim]; o2.other[1] = oth[pdim2];
               double x2[3] = {x[pdim], x[pdim2], 0};
@@ -1345,7 +1364,7 @@ int32_t orc_run_deconv(double *arena, int32_t N, const nbp_proposal_desc *d, int
     sample_measurement(d, n, zdim, z, 0, arena, N);
     if (ms) for (int k = 0; k < 3; k++) ms[k * N + n] = k < zdim ? z[k] : 0.0;
     objective_t o;
-    o.kind = d->factor_kind; o.manifold = d->manifold; o.D = D; o.solve_b = 2;
+    o.kind = d->factor_kind; o.manifold = d->manifold; o.D = D; o.solve_b = 2; o.rmask = 0;
     const int ia = anyn_index(n, slot_count(A, N), d->seed, 1), ib = anyn_index(n, slot_count(B, N), d->seed, 2);
     for (int k = 0; k < 3; k++) { o.z[k] = k < D ? A[k * N + ia] : 0.0; o.other[k] = k < D ? B[k * N + ib] : 0.0; }
     double zc[3] = {z[0], z[1], z[2]};

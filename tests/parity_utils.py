@@ -50,8 +50,12 @@ def assert_points_close(manifold, a, b, rtol=RTOL, max_bad=0, what=""):
 
 
 def relative_factor_desc(kind, manifold, nvars, sfidx, var_slots, out_slot, seed, mean, sig, *, multihypo=None,
-                         nullhypo=0.0, ncomp=1, comps=None, mhidx_in=-1, mhidx_out=-1, cycles=3, inflation=5.0):
+                         nullhypo=0.0, ncomp=1, comps=None, mhidx_in=-1, mhidx_out=-1, cycles=3, inflation=5.0, partial_mask=0,
+                         inflate_cycles=None):
     d = abi.ProposalDesc()
+    d.partial_mask = partial_mask
+    if inflate_cycles is not None:
+        cycles = inflate_cycles
     d.factor_kind, d.manifold, d.nvars, d.sfidx = kind, manifold, nvars, sfidx
     for i, s in enumerate(var_slots):
         d.var_slot[i] = s

@@ -1,0 +1,27 @@
+"""-m gpu: partial relative factors on SE(2): the known answers on the device, and device against oracle with identical
+random streams (BFGS searches: 1e-8)."""
+import numpy as np
+import pytest
+
+import partial_se2_cases as cases
+from parity_utils import abi, assert_points_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", cases.CASES, ids=lambda c: c.__name__)
+def test_partial_se2_known_answers_and_parity(oracle_backend, hip_backend, case):
+    (po, bo), (pg, bg) = case(oracle_backend), case(hip_backend)
+    if case is cases.case_first_pose_translation:
+        # two residual components, three decision variables: the roots form a curve, and where on it a BFGS search ends
+        # depends on the last bits of its first gradients (sincos on the device is not libm's) -- both sides satisfy the
+        # known answer (asserted inside the case); most particles still agree
+        d = np.abs(pg - po).max(axis=1)
+        assert (d < 1e-6).mean() > 0.6, (d < 1e-6).mean()
+        return
+    assert_points_close(abi.SE2, po, pg, rtol=1e-7, what=case.__name__)
+    np.testing.assert_allclose(bg, bo, rtol=1e-6)
+
+
+def test_partial_se2_in_a_graph(hip_backend):
+    cases.case_in_a_graph(hip_backend)
