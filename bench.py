@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="several GPUs: strong = the configuration's graph as BASELINE.json defines it, its cliques sharded over the ranks "
                          "(auto: configs 4 and 5, which BASELINE quotes on 8 GPUs); weak = the graph grows with the ranks (auto: 2, 2p, 3)")
+    ap.add_argument("--fused-min", type=int, default=None,
+                    help="rounds with at least this many variable updates run as ONE launch of the fused update kernel "
+                         "(NBP_FUSED_MIN; default: never -- the fused form moves a ninth of the bytes and is slower, DESIGN.md 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vars", type=int, default=1000, help="variables of the CPU baseline's chain (default: the whole config-2 graph)")
     ap.add_argument("--no-10k", action="store_true", help="skip the secondary 10 000-variable north-star measurement")
@@ -134,6 +137,8 @@ def _main(real_stdout):
     wl = workloads(iif)[a.config]
     N = a.particles or wl.N
     size = a.nvars or wl.size
+    if a.fused_min is not None:
+        os.environ["NBP_FUSED_MIN"] = str(a.fused_min)
     scaling = a.scaling if a.scaling != "auto" else ("strong" if a.config in ("4", "5") else "weak")
     rs = RankSolve(iif, wl, size, N, rank, world, local, dist, python_host=a.python_host, scaling=scaling)
     rs.prepare()
@@ -179,6 +184,7 @@ def _main(real_stdout):
                    "particles": N, "cliques": st["cliques_global"], "messages_per_step": msgs_total,
                    "variable_updates_per_step": st["updates_global"],
                    "launch": "staged program replayed as a hipGraph; per-kernel events only in the separate profiling pass",
+                   "fused_update_min": int(os.environ["NBP_FUSED_MIN"]) if os.environ.get("NBP_FUSED_MIN") else None,
                    "parallelism": (f"cliques sharded over {world} GPU(s), separator exchange: "
                                    f"{getattr(getattr(rs, 'impl', None), 'transport', 'none')}") if world > 1 else "single GPU"},
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": rs.posterior_max_mean_err,
@@ -201,22 +207,31 @@ def _main(real_stdout):
         alg_rank = float(sum(st["alg_bytes"].values()))
         bytes_per_launch = alg_rank / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        # HBM traffic cannot be counted from inside this process (PMC passes need rocprofv3 around it): the figures of the
+        # committed PMC run of this very command (tools/pmc_quick.sh -> profiles/r03_pmc_traffic.json) are quoted, for the
+        # configuration they were taken on only
+        traffic, traffic_src, traffic_step, traffic_ratio = None, None, None, None
+        fused_on = os.environ.get("NBP_FUSED_MIN") is not None and os.environ.get("NBP_NO_FUSED_UPDATE") is None
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic_fused.json" if fused_on else "r03_pmc_traffic.json")
         if world == 1 and a.config == "2" and size == 1000 and N == 200 and os.path.exists(pmc):
             try:
-                k = json.load(open(pmc))["kernels"][dominant]
-                traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json"
+                pj = json.load(open(pmc))
+                traffic_src = os.path.relpath(pmc, ROOT)
+                traffic_step, traffic_ratio = pj.get("hbm_bytes_per_step"), pj.get("traffic_over_algorithmic")
+                traffic = next(v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items() if k.startswith(dominant))
             except Exception:  # noqa: BLE001
                 pass
         kern_s = sum(per_step.values()) * 1e-3
         pairs = N * (N - 1) / 2
         lcv_flop = diag["lcv_evals"] * pairs * 25.0
-        prep_s = (tim["nbp_prep_kernel"][0] + tim["nbp_bandwidth_kernel"][0]) * 1e-3
+        # (with fused rounds some of the fits run inside nbp_update_kernel: its time is counted in full, so the figure is a
+        #  lower bound then)
+        prep_s = (tim["nbp_prep_kernel"][0] + tim["nbp_bandwidth_kernel"][0] + tim.get("nbp_update_kernel", (0.0, 0))[0]) * 1e-3
         valu = lcv_flop / prep_s / 1e12 if prep_s > 0 else 0.0
         out["roofline"] = {
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "traffic": traffic, "traffic_source": traffic_src, "peak_source": peak_src,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_per_step": traffic_step,
+            "traffic_over_algorithmic": traffic_ratio, "peak_source": peak_src,
             "alg_bytes_per_launch": bytes_per_launch, "alg_bytes_per_step": alg_rank, "avg_launch_ms": avg_ms,
             "launches_per_step": launches, "whole_solve_GBps": alg_rank / (dt / a.steps) / 1e9,
             "kernel_ms_per_step": per_step, "profiling_pass_ms_per_step": tprof / psteps * 1e3,

@@ -1,19 +1,27 @@
 #!/bin/bash
-# The round's evidence in one GPU call: plain bench line, kernel trace of the same command (+ timed-region summary +
-# per-kernel stats), three PMC passes (HBM traffic), the other configs.  Output under gpurun_out/$TAG; copy what is
-# to be judged into profiles/.   Usage (on the GPU box): tools/collect_profiles.sh r02
-TAG=${1:-r02}
+# The round's evidence in one GPU call: plain bench line, kernel trace of the same command (+ timed-region summary,
+# per-kernel stats, the launches of one solve and of graph initialisation in order), PMC passes (HBM traffic) for the
+# default launch form and for the fused update kernel, the other configs, micro-benchmarks and SQ counters.
+# Output under gpurun_out/$TAG; copy what is to be judged into profiles/.   Usage (on the GPU box): tools/collect_profiles.sh r03
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
-rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k > $O/bench_under_rocprof.json 2> $O/trace.err
+python $R/bench.py --fused-min 256 --no-cpu-baseline --no-10k > $O/bench_fused.json 2> $O/bench_fused.err
+rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k --no-profile-pass > $O/bench_under_rocprof.json 2> $O/trace.err
 python $R/tools/summarize_trace.py $O/trace 5 > $O/bench_timed_region_summary.txt
 python $R/tools/kernel_stats.py $O/trace > $O/bench_kernel_stats.csv
-for p in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $p -d $O/pmc/$p -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k --no-profile-pass > /dev/null 2> $O/pmc_$p.err; done
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc/TCC -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-10k --no-profile-pass > /dev/null 2> $O/pmc_TCC.err
-python $R/tools/pmc_traffic.py $O/pmc 5 200 $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+python $R/tools/stage_timeline.py $O/trace > $O/solve_launches_in_order.txt
+python $R/tools/init_timeline.py $O/trace > $O/graph_init_launches.txt
+rocprofv3 --kernel-trace -d $O/trace4 -- python $R/bench.py --config 4 --steps 1 --warmup 0 --no-cpu-baseline --no-profile-pass > /dev/null 2> $O/trace4.err
+python $R/tools/init_timeline.py $O/trace4 >> $O/graph_init_launches.txt
+rm -rf $O/trace4
+cd $R
+tools/pmc_quick.sh $TAG/pmc_default NBP_X=1 > $O/pmc_traffic.txt 2>&1
+tools/pmc_quick.sh $TAG/pmc_fused NBP_FUSED_MIN=256 > $O/pmc_traffic_fused.txt 2>&1
+cd /tmp
 for c in 3 4 5; do python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; done
 python $R/tools/lcv_bench.py > $O/lcv_microbench.txt 2>/dev/null
 # SQ counters of the chip-filling bandwidth fit (two passes of 8 counters)
@@ -27,8 +35,12 @@ for k in prop prod; do
 done
 { python $R/tools/exp/prop_batch.py 975; python $R/tools/exp/prop_batch.py 1; python $R/tools/pmc_sq.py $O/sq_prop nbp_proposal; } > $O/proposal_sq_counters.txt 2>/dev/null
 { python $R/tools/exp/prod_batch.py 975 2; python $R/tools/exp/prod_batch.py 1 2; python $R/tools/pmc_sq.py $O/sq_prod nbp_product; } > $O/product_sq_counters.txt 2>/dev/null
-# what a stream of independent v_fma_f64 reaches on this part (built here if the binary did not travel)
-[ -x $R/tools/exp/dp_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/exp/dp_rate.hip -o $R/tools/exp/dp_rate 2>/dev/null
-$R/tools/exp/dp_rate > $O/dp_rate.txt 2>&1
-rm -rf $O/trace/*/*.db.tmp
+# debug build (tools/libnbp_dbg.so, -DNBP_PHASE_TIMING): where one evaluation of a fit and one fused workgroup spend their
+# time, and how busy the lanes of the per-particle searches are
+if [ -f $R/tools/libnbp_dbg.so ]; then
+  NBP_NO_SPECULATIVE_FITS=1 python $R/tools/lcv_phase_timing.py > $O/lcv_phase_timing.txt 2>/dev/null
+  python $R/tools/exp/nm_lane_util.py > $O/search_lane_utilisation.txt 2>/dev/null
+  for a in "488 2" "975 2" "4000 2"; do python $R/tools/exp/fused_phase.py $a 2>/dev/null; done > $O/fused_phase_timing.txt
+fi
+rm -rf $O/trace/*/*.db.tmp $O/sq $O/sq_prop $O/sq_prod
 du -sh $O
