@@ -107,12 +107,10 @@ def timed_steps(rs, steps, warmup, barrier):
 
 def main():
     # stdout carries ONE JSON line: whatever libraries print there (RCCL's version banner, for one) goes to stderr
+    # (fd 1 stays redirected until the process ends: RCCL prints its banner from a destructor, after main returns)
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    try:
-        _main(real_stdout)
-    finally:
-        os.dup2(real_stdout, 1)
+    _main(real_stdout)
 
 
 def _main(real_stdout):
