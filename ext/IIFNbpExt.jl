@@ -155,6 +155,12 @@ struct NbpCliqueDesc
   msg_var::Ptr{Int32}
   msg_belief::Ptr{NbpTreeBelief}
   factor_density::Ptr{NbpTreeBelief}
+  factor_meas_kde::Ptr{NbpTreeBelief}
+  n_diff::Int32
+  reserved_::Int32
+  diff_a::Ptr{Int32}
+  diff_b::Ptr{Int32}
+  diff_kind::Ptr{Int32}
 end
 
 # ---- error mapping: status < 0 -> error() -> the clique Task fails -> monitorCSMs puts ERROR_STATUS on every
@@ -424,7 +430,10 @@ function cliquedesc(cliq::TreeClique, p::CliquePack, nfrontals::Int, nseparators
                        Int32(length(p.lists[1])), Int32(length(p.lists[2])), Int32(length(p.lists[3])), Int32(length(p.lists[4])),
                        ptr_or_null(p.lists[1]), ptr_or_null(p.lists[2]), ptr_or_null(p.lists[3]), ptr_or_null(p.lists[4]),
                        Int32(length(p.msgvar)), ptr_or_null(p.msgvar), ptr_or_null(p.msgs),
-                       any(b -> b !== nothing, p.densbuf) ? pointer(p.dens) : Ptr{NbpTreeBelief}(C_NULL))
+                       any(b -> b !== nothing, p.densbuf) ? pointer(p.dens) : Ptr{NbpTreeBelief}(C_NULL),
+                       # joint messages (useMsgLikelihoods): the differential factors of a child's message arrive as
+                       # LinearRelative(::MKD) & co. -- not in this shim's closed set yet, such cliques take the generic path
+                       Ptr{NbpTreeBelief}(C_NULL), Int32(0), Int32(0), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
 end
 
 "write the beliefs libnbp returned back into the sub graph: setValKDE!(vnd, pts, bw, setinit, ipc) (FactorGraph.jl:250-297)"

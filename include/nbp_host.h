@@ -219,6 +219,20 @@ typedef struct nbp_clique_desc {
    * ManifoldKernelDensity; its points, bandwidth and point count become the proposal as they are,
    * ApproxConv.jl:196-227); entries of other factors are ignored */
   const nbp_tree_belief *factor_density;
+  /* Joint upward messages (SolverParams.useMsgLikelihoods; TreeMessageUtils.jl:279-456), the numeric half.  WHICH
+   * differential factors and common priors a clique sends up and which of them its parent keeps is symbolic work that
+   * stays with the caller (addLikelihoodsDifferentialCHILD!, _generateMsgJointRelativesPriors, addMsgFactors!).
+   *   receiving: a differential factor of a child's message -- LinearRelative(::MKD), CircularCircular(::MKD), an SE(2)
+   *     ManifoldFactor over a KDE -- is an entry of `factors` (kind, the two separator variables) with its measurement
+   *     density in factor_meas_kde[f]: points = the measurement's tangent coordinates (zdim doubles per point, packed like
+   *     an Euclid(zdim) belief) + bandwidth.  [nfactors] or NULL; entries with pts == NULL use the factor's own model.
+   *   sending (up solve, nbp_clique_upsolve_joint): for every pair (diff_a[i], diff_b[i]) of separator variables the
+   *     approxDeconv of a default-constructed factor of kind diff_kind[i] between the solved beliefs, and manikde! of
+   *     the predicted measurements (TreeMessageUtils.jl:279-335) -> diff_out[i] (zdim doubles per point, N points). */
+  const nbp_tree_belief *factor_meas_kde;
+  int32_t n_diff;
+  int32_t reserved_;
+  const int32_t *diff_a, *diff_b, *diff_kind;
 } nbp_clique_desc;
 
 /* slots a context needs for this clique (nbp_ctx_create(..., n_slots >= this)): variables + messages + pass-through
@@ -232,6 +246,10 @@ nbp_status nbp_clique_upsolve(nbp_ctx *ctx, const nbp_solver_params *params, con
                               nbp_tree_belief *beliefs_inout, int32_t *status_out);
 nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,
                                 nbp_tree_belief *beliefs_inout, int32_t *status_out);
+/* the up solve of a clique that sends a joint message: diff_out[cliq->n_diff] receives the differential KDEs (the caller
+ * provides pts with room for N x zdim doubles and bw[zdim] each); nbp_clique_upsolve is this call with n_diff == 0 */
+nbp_status nbp_clique_upsolve_joint(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,
+                                    nbp_tree_belief *beliefs_inout, nbp_tree_belief *diff_out, int32_t *status_out);
 
 /* test access: the descriptors of stage s of the last compile (kind = NBP_STAGE_*; bytes copied <= cap) */
 int32_t nbp_tree_num_stages(const nbp_tree *t);

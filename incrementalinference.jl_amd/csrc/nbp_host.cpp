@@ -606,13 +606,17 @@ void plan_joint(nbp_tree *t) {
 
 // the densities of variable v in clique c: up solve (with the common message priors) or down solve (without)
 std::vector<Entry> joint_entries(const Clique &c, int v, bool down) {
+  // potentials and differentials in sub-graph order, the common message priors last (the reference iterates a Dict; with
+  // this order a clique call -- factors, then messages -- numbers the densities of a variable the same way)
   std::vector<Entry> e;
   for (const auto &f : c.jf) {
-    if (!contains(f.vars, v) || (down && f.tag == 'p')) continue;
+    if (!contains(f.vars, v) || f.tag == 'p') continue;
     if (f.tag == 'f') e.push_back(Entry('f', f.a, 0));
-    else if (f.tag == 'd') e.push_back(Entry('d', f.a, f.b));
-    else e.push_back(Entry('m', f.a, 0));
+    else e.push_back(Entry('d', f.a, f.b));
   }
+  if (!down)
+    for (const auto &f : c.jf)
+      if (contains(f.vars, v) && f.tag == 'p') e.push_back(Entry('m', f.a, 0));
   return e;
 }
 
@@ -1618,7 +1622,13 @@ nbp_status nbp_graph_init_compile(nbp_graph *g, nbp_ctx *ctx, nbp_program **out)
 // ---- the clique seam, one clique at a time (upGibbsCliqueDensity / solveCliqDownFrontalProducts!) ---------
 static nbp_status clique_check(const nbp_solver_params *sp, const nbp_clique_desc *q) {
   if (!sp || !q) return hfail(NBP_ERR_ARG, "null argument");
-  if (sp->flags & NBP_SOLVER_MSG_LIKELIHOODS) return hfail(NBP_ERR_ARG, "clique entry: useMsgLikelihoods needs the whole-tree compile");
+  if (q->n_diff < 0 || (q->n_diff > 0 && (!q->diff_a || !q->diff_b || !q->diff_kind))) return hfail(NBP_ERR_ARG, "clique: differential lists");
+  for (int i = 0; i < q->n_diff; i++) {
+    if (q->diff_a[i] < 0 || q->diff_a[i] >= q->nvars || q->diff_b[i] < 0 || q->diff_b[i] >= q->nvars || q->diff_a[i] == q->diff_b[i])
+      return hfail(NBP_ERR_RANGE, "clique: differential variable index");
+    if (q->diff_kind[i] != NBP_F_LINREL && q->diff_kind[i] != NBP_F_CIRCULAR && q->diff_kind[i] != NBP_F_SE2)
+      return hfail(NBP_ERR_ARG, "clique: a differential factor is LinearRelative, CircularCircular or an SE(2) ManifoldFactor");
+  }
   if (q->nvars < 1 || q->nfrontals < 1 || q->nseparators < 0 || q->nfrontals + q->nseparators > q->nvars)
     return hfail(NBP_ERR_RANGE, "clique: variable counts");
   if (!q->manifold || (q->nfactors > 0 && !q->factors) || (q->nmsgs > 0 && (!q->msg_var || !q->msg_belief)))
@@ -1671,10 +1681,13 @@ int32_t nbp_clique_slots(const nbp_clique_desc *q) {
     clique_entries(q, v, true, fa, ms);
     maxf = std::max(maxf, fa.size() + ms.size());
   }
-  int ndens = 0;
-  for (int f = 0; f < q->nfactors; f++) ndens += q->factors && q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
+  int ndens = 0, nkde = 0;
+  for (int f = 0; f < q->nfactors; f++) {
+    ndens += q->factors && q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
+    nkde += q->factor_meas_kde && q->factor_meas_kde[f].pts != nullptr;
+  }
   // steps that commute run side by side, one scratch row of maxf proposals each: at most one per variable
-  return q->nvars + q->nmsgs + ndens + (int32_t)maxf * q->nvars;
+  return q->nvars + q->nmsgs + ndens + nkde + (q->n_diff > 0 ? q->n_diff : 0) + (int32_t)maxf * q->nvars;
 }
 static size_t clique_maxf(const nbp_clique_desc *q) {
   size_t maxf = 1;
@@ -1686,11 +1699,15 @@ static size_t clique_maxf(const nbp_clique_desc *q) {
   return maxf;
 }
 
+// measurement dimension of a relative factor kind on a variable's manifold
+static int clique_zdim(int kind, int manifold) { return kind == NBP_F_LINREL ? mani_dim(manifold) : (kind == NBP_F_SE2 ? 3 : 1); }
+
 static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
-                               nbp_tree_belief *bel, int32_t *status_out, bool down) {
+                               nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
   nbp_status rc = clique_check(sp, q);
   if (rc) return rc;
   if (!ctx || !bel) return hfail(NBP_ERR_ARG, "null argument");
+  if (!down && q->n_diff > 0 && !diff_out) return hfail(NBP_ERR_ARG, "clique: differential factors are asked for, diff_out is null (nbp_clique_upsolve_joint)");
   // a throw-away graph object carries the solver parameters and the variables for fill_proposal
   nbp_graph g;
   g.sp = *sp;
@@ -1702,8 +1719,19 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
     facs[f].is_prior = q->factors[f].factor_kind == NBP_F_PRIOR || q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
     if (q->factors[f].factor_kind == NBP_F_PASSTHROUGH) facs[f].dens = ndens++;
   }
-  // slot plan: the clique's variables | the message beliefs | the pass-through densities | proposal scratch
-  const int msg0 = q->nvars, dens0 = q->nvars + q->nmsgs, base = dens0 + ndens;
+  // slot plan: the clique's variables | the message beliefs | the pass-through densities | the measurement KDEs of
+  // differential factors received from children | the differential KDEs this clique sends up | proposal scratch
+  std::vector<int> kde_of(q->nfactors, -1);
+  int nkde = 0;
+  for (int f = 0; f < q->nfactors; f++)
+    if (q->factor_meas_kde && q->factor_meas_kde[f].pts) {
+      const int k = q->factors[f].factor_kind;
+      if ((k != NBP_F_LINREL && k != NBP_F_CIRCULAR && k != NBP_F_SE2) || q->factors[f].nvars != 2 || !q->factor_meas_kde[f].bw)
+        return hfail(NBP_ERR_ARG, "clique: a measurement KDE (points + bandwidth) belongs to a binary LinearRelative / CircularCircular / SE(2) factor");
+      kde_of[f] = nkde++;
+    }
+  const int ndiff = down ? 0 : std::max(0, (int)q->n_diff);
+  const int msg0 = q->nvars, dens0 = q->nvars + q->nmsgs, kde0 = dens0 + ndens, diff0 = kde0 + nkde, base = diff0 + ndiff;
   // ---- schedule ------------------------------------------------------------------------------------------
   std::vector<int> sched, iter;
   std::vector<int> fa, ms;
@@ -1771,6 +1799,13 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
     rc = nbp_belief_write(ctx, dens0 + facs[f].dens, q->manifold[facs[f].s.vars[0]], m.pts, m.n_pts, m.bw, m.ipc);
     if (rc) return rc;
   }
+  for (int f = 0; f < q->nfactors; f++) {  // LinearRelative(::MKD) & co.: the measurement is the child's KDE, in measurement coordinates
+    if (kde_of[f] < 0) continue;
+    const nbp_tree_belief &m = q->factor_meas_kde[f];
+    const int zd = clique_zdim(q->factors[f].factor_kind, q->manifold[q->factors[f].vars[0]]);
+    rc = nbp_belief_write(ctx, kde0 + kde_of[f], zd /* Euclid(zd) */, m.pts, m.n_pts, m.bw, nullptr);
+    if (rc) return rc;
+  }
   // ---- the schedule as a resident program ------------------------------------------------------------------
   nbp_program *p = nullptr;
   rc = nbp_program_create(ctx, &p);
@@ -1829,6 +1864,7 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
         const uint64_t sd = op_seed(seed, passid, q->clique_id, (uint64_t)k, (uint64_t)(i + 1));
         fill_proposal(&g, d, fac, ismsg ? msg0 + mi : (fac->dens >= 0 ? dens0 + fac->dens : -1), v, nullptr, nullptr, nullptr, row + i, sd, ns,
                       nullptr, F == 1 ? 1 : 0);
+        if (!ismsg && kde_of[fa[i]] >= 0) d.meas_kde = kde0 + kde_of[fa[i]] + 1;
         const std::pair<int, int> key{ismsg ? 1 : 0, ismsg ? mi : fa[i]};
         if (fresh) meas_seed[key] = sd;
         else {
@@ -1856,10 +1892,38 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
     if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, prods.data(), (int)prods.size());
     if (rc) return rc;
   }
+  if (ndiff > 0) {
+    // prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD! (TreeMessageUtils.jl:279-335): approxDeconv between the solved
+    // beliefs of every pair, searched from samples of the default-constructed factor, manikde! of the result -- the same
+    // ops, with the same seeds, as the whole-tree compile emits when the clique finishes
+    std::vector<nbp_proposal_desc> props;
+    for (int i = 0; i < ndiff; i++) {
+      HFac dflt;
+      memset(&dflt, 0, sizeof(dflt));
+      dflt.s.factor_kind = q->diff_kind[i];
+      dflt.s.nvars = 2;
+      dflt.s.vars[0] = q->diff_a[i];
+      dflt.s.vars[1] = q->diff_b[i];
+      dflt.s.ncomp = 1;
+      dflt.s.comp[0][0] = 1.0;
+      const int zd = clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]);
+      for (int k = 0; k < zd; k++) dflt.s.comp[0][4 + 4 * k] = 1.0;  // identity square-root covariance
+      nbp_proposal_desc d;
+      fill_proposal(&g, d, &dflt, -1, q->diff_b[i], nullptr, nullptr, nullptr, diff0 + i, op_seed(seed, PASS_UP, q->clique_id, 0x4000 + i, 0), 0.0);
+      props.push_back(d);
+    }
+    rc = nbp_program_add_stage(p, NBP_STAGE_DECONV, props.data(), (int)props.size());
+    if (rc) return rc;
+  }
   rc = nbp_program_finalize(p);
   if (!rc) rc = nbp_program_run(p, 0, -1);
   if (!rc) rc = nbp_synchronize(ctx);
   if (rc) return rc;
+  for (int i = 0; i < ndiff; i++) {  // the differential KDEs: points in measurement coordinates + fitted bandwidth
+    if (!diff_out[i].pts || !diff_out[i].bw) return hfail(NBP_ERR_ARG, "clique: diff_out entries need pts and bw");
+    rc = nbp_belief_read(ctx, diff0 + i, clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]), diff_out[i].pts, &diff_out[i].n_pts, diff_out[i].bw, nullptr);
+    if (rc) return rc;
+  }
   // ---- beliefs out: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the schedule touched
   for (int v = 0; v < q->nvars; v++) {
     if (!updated[v]) continue;
@@ -1873,6 +1937,10 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
 nbp_status nbp_clique_upsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
                               nbp_tree_belief *bel, int32_t *status_out) {
   return clique_solve(ctx, sp, q, seed, bel, status_out, false);
+}
+nbp_status nbp_clique_upsolve_joint(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
+                                    nbp_tree_belief *bel, nbp_tree_belief *diff_out, int32_t *status_out) {
+  return clique_solve(ctx, sp, q, seed, bel, status_out, false, diff_out);
 }
 nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
                                 nbp_tree_belief *bel, int32_t *status_out) {

@@ -49,7 +49,9 @@ class CliqueDescC(C.Structure):
                 ("n_direct_frtl_msg", i32), ("n_msgskip", i32), ("n_itervar", i32), ("n_direct_prior_msg", i32),
                 ("direct_frtl_msg", C.POINTER(i32)), ("msgskip", C.POINTER(i32)), ("itervar", C.POINTER(i32)),
                 ("direct_prior_msg", C.POINTER(i32)), ("nmsgs", i32), ("msg_var", C.POINTER(i32)),
-                ("msg_belief", C.POINTER(TreeBeliefC)), ("factor_density", C.POINTER(TreeBeliefC))]
+                ("msg_belief", C.POINTER(TreeBeliefC)), ("factor_density", C.POINTER(TreeBeliefC)),
+                ("factor_meas_kde", C.POINTER(TreeBeliefC)), ("n_diff", i32), ("reserved_", i32),
+                ("diff_a", C.POINTER(i32)), ("diff_b", C.POINTER(i32)), ("diff_kind", C.POINTER(i32))]
 
 
 CLIQ_UPSOLVED, CLIQ_DOWNSOLVED = 3, 5  # enum nbp_cliq_status
@@ -59,7 +61,7 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_graph_order_nested_dissection", "nbp_graph_init_plan", "nbp_graph_init_num_variables", "nbp_graph_init_variables",
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
-                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_downsolve",
+                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_upsolve_joint", "nbp_clique_downsolve",
                 "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment",
                 "nbp_tree_run_sharded", "nbp_tree_run_sharded_cb",
                 "nbp_graph_num_densities", "nbp_graph_density_factors", "nbp_graph_init_density_slot0", "nbp_tree_density_slot0"]
@@ -112,6 +114,8 @@ def _lib():
         lib.nbp_clique_slots.argtypes = [C.POINTER(CliqueDescC)]
         for fn in (lib.nbp_clique_upsolve, lib.nbp_clique_downsolve):
             fn.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC), ip]
+        lib.nbp_clique_upsolve_joint.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC),
+                                                 C.POINTER(TreeBeliefC), ip]
         for n in HOST_EXPORTS:
             getattr(lib, n).restype = i32
         _declared = True
@@ -205,13 +209,16 @@ class Belief:
 
 
 def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, manifolds, factors, beliefs, seed, down=False,
-                 ismargin=None, lists=None, msgs=()):
+                 ismargin=None, lists=None, msgs=(), meas_kdes=None, diffs=()):
     """nbp_clique_upsolve / nbp_clique_downsolve (include/nbp_host.h) -- the per-clique seam of the CliqueStateMachine:
     upGibbsCliqueDensity (SolveTree.jl:164-239) / solveCliqDownFrontalProducts! (CliqStateMachineUtils.jl:479-571).
 
     variables: labels, frontals first, then separators, then (down) the others; factors: DFGFactor list; beliefs:
     {label: Belief} (updated in place); lists: {"directFrtlMsg", "msgskip", "itervar", "directPriorMsg"} of labels;
-    msgs: [(label, Belief)] the children's up messages.  Returns the CliqStatus code."""
+    msgs: [(label, Belief)] the children's up messages.  Joint messages (useMsgLikelihoods): meas_kdes = per factor None or
+    the Belief (Euclid(zdim), measurement coordinates) of a differential factor received from a child; diffs =
+    [(label_a, label_b, kind)] the differential factors to send up -- then the call returns (status, [Belief]).
+    Returns the CliqStatus code otherwise."""
     lib = _lib()
     idx = {v: i for i, v in enumerate(variables)}
     q = CliqueDescC()
@@ -243,17 +250,37 @@ def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, mani
         fd = (TreeBeliefC * len(factors))(*[d.c() if d is not None else TreeBeliefC() for d in dens])
         q.factor_density = fd
         keep += [fd, dens]
+    if meas_kdes is not None and any(m is not None for m in meas_kdes):
+        mk = (TreeBeliefC * len(factors))(*[m.c() if m is not None else TreeBeliefC() for m in meas_kdes])
+        q.factor_meas_kde = mk
+        keep += [mk, meas_kdes]
+    diff_out = []
+    if diffs:
+        da = (i32 * len(diffs))(*[idx[a] for a, _, _ in diffs])
+        db = (i32 * len(diffs))(*[idx[b] for _, b, _ in diffs])
+        dk = (i32 * len(diffs))(*[k for _, _, k in diffs])
+        q.n_diff, q.diff_a, q.diff_b, q.diff_kind = len(diffs), da, db, dk
+        keep += [da, db, dk]
+        for a, _, k in diffs:
+            zd = abi.MANIFOLD_DIM[manifolds[idx[a]]] if k == abi.F_LINREL else (3 if k == abi.F_SE2 else 1)
+            diff_out.append(Belief(zd, np.zeros((sp.N, zd)), np.zeros(zd)))  # Euclid(zd): the manifold code is the dimension
     need = _check(lib.nbp_clique_slots(C.byref(q)))
     if need > backend.n_slots:
         raise ValueError(f"the context has {backend.n_slots} slots, this clique needs {need}")
     bel = (TreeBeliefC * len(variables))(*[beliefs[v].c(capacity=sp.N) for v in variables])
     status = i32(0)
     p = solver_params_c(sp)
-    fn = lib.nbp_clique_downsolve if down else lib.nbp_clique_upsolve
-    _check(fn(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, C.byref(status)))
+    if diffs and not down:
+        dout = (TreeBeliefC * len(diffs))(*[b.c() for b in diff_out])
+        _check(lib.nbp_clique_upsolve_joint(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, dout, C.byref(status)))
+        for i, b in enumerate(diff_out):
+            b.take(dout[i])
+    else:
+        fn = lib.nbp_clique_downsolve if down else lib.nbp_clique_upsolve
+        _check(fn(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, C.byref(status)))
     for i, v in enumerate(variables):
         beliefs[v].take(bel[i])
-    return status.value
+    return (status.value, diff_out) if diffs and not down else status.value
 
 
 class NativeGraph:

@@ -641,7 +641,10 @@ class TreeProgram:
         upf = {}
         for v in cl.allIDs:
             if self.joint is not None:  # potentials + the children's differentials + their common priors
-                lst = [(f.tag, f.ref) if f.tag != "p" else ("m", f.ref[0]) for f in self.joint[cid].factors if v in f.variables]
+                # (the common message priors last: the reference iterates a Dict here, and with this order a clique call
+                #  -- factors first, then messages, nbp_clique_upsolve -- numbers the densities of a variable the same way)
+                lst = [(f.tag, f.ref) for f in self.joint[cid].factors if v in f.variables and f.tag != "p"] + \
+                      [("m", f.ref[0]) for f in self.joint[cid].factors if v in f.variables and f.tag == "p"]
             else:
                 lst = [("f", f) for f in cl.potentials if v in fg.getFactor(f).variables]
                 for ch in cl.children:

@@ -62,3 +62,73 @@ def solve_tree_by_clique_calls(fg, tree, backend, seed):
         for v in cl.frontalIDs:
             post[v] = bel[v]
     return post, status
+
+
+def solve_tree_by_clique_calls_joint(fg, tree, backend, seed):
+    """the same walk with joint upward messages (SolverParams.useMsgLikelihoods): the symbolic half -- which differential
+    factors and common priors a clique sends up, which of them its parent keeps (addLikelihoodsDifferentialCHILD!,
+    addMsgFactors!; iif_amd.jointmsg) -- is done here, as the Julia CSM does it; the numeric half goes through
+    nbp_clique_upsolve_joint (approxDeconv + manikde! of every differential pair on the way up) and the measurement KDEs
+    of nbp_clique_desc.factor_meas_kde (on the way in).  -> ({label: Belief}, {clique: status})"""
+    from iif_amd import jointmsg
+    from iif_amd.factorgraph import DFGFactor, DifferentialRelative
+    sp = fg.solverParams
+    plan = jointmsg.plan_joint_messages(fg, tree)
+    man = {v: fg.getVariable(v).varType.manifold for v in fg.ls()}
+    marg = {v: fg.getVariable(v).ismargin for v in fg.ls()}
+    main = {v: Belief(man[v], fg.getVariable(v).val, fg.getVariable(v).bw) for v in fg.ls()}
+    sub, status, dkde = {}, {}, {}   # dkde[(clique, i)]: the KDE of differential factor i of that clique's message
+
+    def subgraph(cid):
+        """(factors, measurement KDEs, message priors) of the clique sub graph, in the order of the plan"""
+        facs, kdes, msgs = [], [], []
+        for f in plan[cid].factors:
+            if f.tag == "f":
+                facs.append(fg.getFactor(f.ref))
+                kdes.append(None)
+            elif f.tag == "d":
+                a, b, _, kind = plan[f.ref[0]].relatives[f.ref[1]]
+                facs.append(DFGFactor(f"diff{f.ref[0]}_{f.ref[1]}", [a, b], DifferentialRelative(kind, -1), None, 0.0, sp.inflation))
+                kdes.append(dkde[f.ref])
+            else:
+                msgs.append((f.ref[1], sub[f.ref[0]][f.ref[1]]))
+        return facs, kdes, msgs
+
+    for cid in tree.postorder():
+        cl = tree.cliques[cid]
+        labels = list(cl.frontalIDs) + list(cl.separatorIDs)
+        bel = {v: main[v].copy() for v in labels}
+        facs, kdes, msgs = subgraph(cid)
+        lists = {"directFrtlMsg": cl.directFrtlMsgIDs, "msgskip": cl.msgskipIDs, "itervar": cl.itervarIDs,
+                 "directPriorMsg": cl.directPriorMsgIDs}
+        diffs = [(a, b, kind) for (a, b, _, kind) in plan[cid].relatives] if cl.parent >= 0 else []
+        r = clique_solve(backend, sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels], facs, bel, seed,
+                         down=False, ismargin=[marg[v] for v in labels], lists=lists, msgs=msgs, meas_kdes=kdes, diffs=diffs)
+        if diffs:
+            status[cid], out = r
+            for i, b in enumerate(out):
+                dkde[(cid, i)] = b
+        else:
+            status[cid] = r
+        sub[cid] = bel
+    post = {}
+    for r in tree.roots:
+        for v in tree.cliques[r].frontalIDs:
+            main[v] = sub[r][v].copy()
+            post[v] = main[v]
+    depths = tree.depths()
+    for cid in sorted(tree.cliques, key=lambda c: (depths[c], c)):
+        cl = tree.cliques[cid]
+        if cl.parent < 0:
+            continue
+        for s in cl.separatorIDs:
+            sub[cid][s].pts[:] = sub[cl.parent][s].pts
+        # no addDownVariableFactors! in this mode: the down solve works on the clique sub graph as the up solve left it,
+        # minus the common priors (CliqueStateMachine.jl:558)
+        facs, kdes, _ = subgraph(cid)
+        labels = list(cl.frontalIDs) + list(cl.separatorIDs)
+        status[cid] = clique_solve(backend, sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels], facs,
+                                   sub[cid], seed, down=True, ismargin=[marg[v] for v in labels], meas_kdes=kdes)
+        for v in cl.frontalIDs:
+            post[v] = sub[cid][v]
+    return post, status

@@ -5,7 +5,7 @@ launch geometries coincide (trees with fewer than 16 concurrent updates), to rou
 import numpy as np
 import pytest
 
-from clique_csm import solve_tree_by_clique_calls
+from clique_csm import solve_tree_by_clique_calls, solve_tree_by_clique_calls_joint
 from parity_utils import abi, assert_points_close, iif
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +58,36 @@ def test_clique_calls_equal_whole_tree_program(hip_backend, name):
     # atan2 is not a bitwise round trip, so the clique-by-clique solve agrees to rounding (1e-9 above) there
     if name != "se2_lattice":
         assert nbit == len(fa.ls()), f"{nbit} of {len(fa.ls())} variables bit-identical"
+
+
+@pytest.mark.parametrize("name", ["euclid2_chain", "kaess", "circular_chain"])
+def test_joint_messages_through_the_clique_entry(hip_backend, name):
+    """SolverParams.useMsgLikelihoods: the differential factors of the children's messages arrive as measurement KDEs
+    (nbp_clique_desc.factor_meas_kde), the clique's own are made by nbp_clique_upsolve_joint (approxDeconv + manikde!) --
+    clique call by clique call the posteriors are those of the whole-tree program of the same mode, bit for bit"""
+    build = {"euclid2_chain": lambda: iif.generateChainEuclid(14, vardims=2, priorEvery=6, N=128),
+             "kaess": lambda: iif.generateGraph_Kaess(iif.SolverParams(N=100)),
+             "circular_chain": lambda: iif.generateCircularDoors(nposes=10, N=128, sightEvery=100)}[name]
+    fa, fb = build(), build()
+    for f in (fa, fb):
+        f.solverParams.useMsgLikelihoods = True
+        iif.initAll(f, backend=hip_backend, seed=0)
+        f.solverParams.graphinit = False
+    order = iif.nestedDissectionOrder(fa)
+    tree = iif.buildTreeReset(fa, order)
+    iif.solveTree(fa, tree=iif.buildTreeReset(fa, order), backend=hip_backend, seed=91)
+    be = hip_backend(fb.solverParams.N, 96)
+    try:
+        post, status = solve_tree_by_clique_calls_joint(fb, tree, be, 91)
+    finally:
+        be.close()
+    assert set(post) == set(fb.ls())
+    from iif_amd import jointmsg
+    ndiff = sum(len(j.relatives) for j in jointmsg.plan_joint_messages(fb, tree).values())
+    assert ndiff > 0 or name == "kaess"  # differentials did travel (the Kaess graph's tree sends common priors only)
+    for v in fa.ls():
+        np.testing.assert_array_equal(fa.getVal(v), post[v].pts, err_msg=f"{name}:{v}")
+        np.testing.assert_allclose(post[v].bw, fa.getVariable(v).bw, rtol=1e-12)
 
 
 def test_clique_entry_rejects_bad_input(hip_backend):
