@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--fused-min", type=int, default=None,
                     help="rounds with at least this many variable updates run as ONE launch of the fused update kernel "
                          "(NBP_FUSED_MIN; default: never -- the fused form moves a ninth of the bytes and is slower, DESIGN.md 3)")
+    ap.add_argument("--pipeline-min", type=int, default=None,
+                    help="rounds with at least this many variable updates run as two halves on two streams, one launch apart "
+                         "(NBP_PIPELINE_MIN; same posteriors bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-vars", type=int, default=1000, help="variables of the CPU baseline's chain (default: the whole config-2 graph)")
     ap.add_argument("--no-10k", action="store_true", help="skip the secondary 10 000-variable north-star measurement")
@@ -52,6 +55,9 @@ def parse():
     ap.add_argument("--python-host", action="store_true", help="build tree and schedule with the Python mirror instead of the native host")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: take the sharded multi-GPU code path (process group, torch-owned arena) even with one rank")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="testing: process-group backend.  gloo lets several ranks SHARE one GPU (RCCL refuses two ranks on one "
+                         "device), separator slots then travel host-staged: every line of the sharded path but the RCCL calls")
     return ap.parse_args()
 
 
@@ -128,7 +134,11 @@ def _main(real_stdout):
             os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.dist_backend == "gloo":
+            local %= torch.cuda.device_count()
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
     from bench_support import RankSolve, workloads
@@ -137,6 +147,8 @@ def _main(real_stdout):
     size = a.nvars or wl.size
     if a.fused_min is not None:
         os.environ["NBP_FUSED_MIN"] = str(a.fused_min)
+    if a.pipeline_min is not None:
+        os.environ["NBP_PIPELINE_MIN"] = str(a.pipeline_min)
     scaling = a.scaling if a.scaling != "auto" else ("strong" if a.config in ("4", "5") else "weak")
     rs = RankSolve(iif, wl, size, N, rank, world, local, dist, python_host=a.python_host, scaling=scaling)
     rs.prepare()
@@ -151,7 +163,7 @@ def _main(real_stdout):
     rs.be.timing_enable(False)
     dt = timed_steps(rs, a.steps, a.warmup, barrier)
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rs.check_posteriors()
@@ -183,6 +195,7 @@ def _main(real_stdout):
                    "variable_updates_per_step": st["updates_global"],
                    "launch": "staged program replayed as a hipGraph; per-kernel events only in the separate profiling pass",
                    "fused_update_min": int(os.environ["NBP_FUSED_MIN"]) if os.environ.get("NBP_FUSED_MIN") else None,
+                   "two_stream_round_min": int(os.environ["NBP_PIPELINE_MIN"]) if os.environ.get("NBP_PIPELINE_MIN") else None,
                    "parallelism": (f"cliques sharded over {world} GPU(s), separator exchange: "
                                    f"{getattr(getattr(rs, 'impl', None), 'transport', 'none')}") if world > 1 else "single GPU"},
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": rs.posterior_max_mean_err,

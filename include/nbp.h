@@ -303,6 +303,9 @@ nbp_status nbp_program_reseed(nbp_program *prog, uint64_t salt); /* xor-mix all 
 nbp_status nbp_program_num_stages(nbp_program *prog, int32_t *out);
 /* rounds of a finalized program that run as one launch of the fused update kernel (NBP_OPT_FUSED_UPDATES) */
 nbp_status nbp_program_num_fused(nbp_program *prog, int32_t *out);
+/* rounds of a finalized program whose two halves run on two streams, one launch apart (environment NBP_PIPELINE_MIN =
+ * smallest product batch that is split; same particles and bandwidths as the single-stream order, bit for bit) */
+nbp_status nbp_program_num_two_stream(nbp_program *prog, int32_t *out);
 nbp_status nbp_program_destroy(nbp_program *prog);
 
 /* ---- separator exchange between ranks (one process per GPU) -------------------------------------------------------

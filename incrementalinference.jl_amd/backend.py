@@ -262,6 +262,12 @@ class HipProgram:
         self.backend._check(self.backend.lib.nbp_program_num_fused(self._p, C.byref(n)))
         return n.value
 
+    def num_two_stream(self):
+        """rounds whose two halves run on two streams one launch apart (NBP_PIPELINE_MIN)"""
+        n = C.c_int32(0)
+        self.backend._check(self.backend.lib.nbp_program_num_two_stream(self._p, C.byref(n)))
+        return n.value
+
     def run(self, first=0, last=-1):
         self.backend._check(self.backend.lib.nbp_program_run(self._p, first, last))
 

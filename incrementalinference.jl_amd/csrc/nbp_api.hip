@@ -74,6 +74,12 @@ struct nbp_ctx {
   int fused_min = 1 << 30;
   int fused_p1_min = 2048;  // rounds with at least this many updates run one lane per particle (NBP_FUSED_P1_MIN); smaller
                             // ones two helper rows per update, so that they fill the chip with twice the lanes each
+  // two-stream rounds (NBP_PIPELINE_MIN = smallest product batch; see plan_pipeline): the second stream, the fork / join
+  // events, and the geometry of the WHOLE batch that both halves launch with (so that no result depends on the split)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};
+  int pipe_min = 1 << 30;
+  int geom_n = 0, geom_blocks = 0;
   // timing: 0 proposal, 1 prep, 2 product, 3 plain bandwidth, 4 fused update kernel
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
@@ -208,6 +214,9 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   c->spec_depth3 = !(getenv("NBP_SPEC_DEPTH3") && atoi(getenv("NBP_SPEC_DEPTH3")) == 0);
   c->fused_on = getenv("NBP_NO_FUSED_UPDATE") == nullptr;
   if (getenv("NBP_FUSED_MIN")) c->fused_min = atoi(getenv("NBP_FUSED_MIN"));
+  if (getenv("NBP_PIPELINE_MIN")) c->pipe_min = atoi(getenv("NBP_PIPELINE_MIN"));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->pipe_ev[i], hipEventDisableTiming));
   if (getenv("NBP_FUSED_P1_MIN")) c->fused_p1_min = atoi(getenv("NBP_FUSED_P1_MIN"));
   nbp_status rc = build_levels(c);
   if (rc != NBP_OK) return rc;
@@ -260,6 +269,8 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (c->ws) hipFree(c->ws);
   if (c->gstats) hipFree(c->gstats);
   if (c->spec) hipFree(c->spec);
+  if (c->stream2) hipStreamDestroy(c->stream2);
+  for (int i = 0; i < 2; i++) if (c->pipe_ev[i]) hipEventDestroy(c->pipe_ev[i]);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return NBP_OK;
@@ -555,7 +566,7 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   if (rc) return rc;
   rc = tic(c, c->ev[1]);
   if (rc) return rc;
-  const int P = lcv_helpers(c, 2 * nbw + 2 * n);
+  const int P = lcv_helpers(c, c->geom_blocks ? c->geom_blocks : 2 * nbw + 2 * n);
   size_t lds = nbp_kd_lds_bytes(3, c->N, c->Npad, P);
   if (nbw > 0 && nbp_bandwidth_lds_bytes(c->N, c->Npad, P) > lds) lds = nbp_bandwidth_lds_bytes(c->N, c->Npad, P);
   (void)hipGetLastError();
@@ -564,7 +575,7 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   // latency mode: a handful of fits, the rest of the chip idle -> NBP_SPEC_K workgroups per fit
   // 3 workgroups per fit (two iterations per rendezvous) when the whole launch is resident at once (7 / three on request)
   int depth = 0;
-  if (c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS) {
+  if (c->spec_on && nbw > 0 && nbw <= NBP_SPEC_MAXJOBS && !c->geom_n) {
     if (c->spec_depth3 && coords * 7 + nkd <= NBP_SPEC_MAXBLOCKS) depth = 3;
     else if (coords * 3 + nkd <= NBP_SPEC_MAXBLOCKS) depth = 2;
   }
@@ -589,7 +600,9 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
 // several small workgroups per product; throughput mode: HL = 2 so that one workgroup covers all
 // samples and the node statistics of a product are computed once.
 static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
-  *HL = n >= 192 ? 2 : (n >= 48 ? 4 : (n >= 16 ? 8 : 16));
+  if (c->geom_n) n = c->geom_n;  // one half of a two-stream round: the geometry of the whole batch
+  static const int hl2_min = getenv("NBP_PRODUCT_HL2_MIN") ? atoi(getenv("NBP_PRODUCT_HL2_MIN")) : 192;
+  *HL = n >= hl2_min ? 2 : (n >= 48 ? 4 : (n >= 16 ? 8 : 16));
   const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL >= 8) ? 6 : 8;
   int g = (waves + cap - 1) / cap;
   *wpb = (waves + g - 1) / g;
@@ -1026,6 +1039,10 @@ struct nbp_stage {
   int upd_F = 0, upd_cls = 0;
   std::vector<nbp_update_desc> upd;
   size_t upd_off = 0;
+  // two-stream round (plan_pipeline): descriptors [0, pipe_split) are the first half; on the PRODUCTS stage pipe_ent splits
+  // the entry fits the same way.  `pipe` on the PROPOSALS stage = the pair runs that way.
+  bool pipe = false;
+  int pipe_split = -1, pipe_ent = 0;
 };
 struct nbp_program {
   nbp_ctx *ctx = nullptr;
@@ -1305,6 +1322,79 @@ static nbp_status launch_update(nbp_ctx *c, const nbp_stage &st, const nbp_updat
   return toc(c, c->ev[4]);
 }
 
+
+// ---- two-stream rounds --------------------------------------------------------------------------------------------------
+// A round of many variable updates is three chip-filling launches with different bottlenecks: the proposal launch waits
+// (barriers of the inflation cycles, divergent per-particle searches), the fit launch issues FP64 back to back, and every
+// launch ends in a tail of partly filled CUs.  The updates of a round are independent of each other, so the round is cut
+// in two halves that run the same three launches on two streams, the second half one launch behind the first:
+//     stream 1:  proposals(a)  fits + KD(a)   products(a)                 join
+//     stream 2:                proposals(b)   fits + KD(b)   products(b)
+// What must hold for that to compute what the single-stream order computes: a product of half a must not write a slot a
+// proposal of half b still has to read.  plan_pipeline() puts such updates into the same half (union-find over the
+// products of the stage), balances the halves, and reorders the descriptors of both stages so that each half is a
+// contiguous range.  Every launch of a half uses the geometry of the whole batch (helper rows per fit, lanes per sample),
+// so no particle depends on the split: tests/test_gpu_pipelined_rounds.py compares every slot, bit for bit.
+static void plan_pipeline(nbp_program *p, int s) {
+  nbp_stage &ps = p->stages[s], &qs = p->stages[s + 1];
+  if (ps.kind != NBP_STAGE_PROPOSALS || qs.kind != NBP_STAGE_PRODUCTS || qs.n < p->ctx->pipe_min || qs.n < 128) return;
+  nbp_proposal_desc *pd = (nbp_proposal_desc *)(p->blob.data() + ps.offset);
+  nbp_product_desc *qd = (nbp_product_desc *)(p->blob.data() + qs.offset);
+  std::unordered_map<int32_t, int> prop_of, prod_of, reader_of;
+  for (int i = 0; i < ps.n; i++) prop_of[pd[i].out_slot] = i;
+  for (int i = 0; i < qs.n; i++) prod_of[qd[i].out_slot] = i;
+  std::vector<int> uf(qs.n), owner(ps.n, -1);
+  for (int i = 0; i < qs.n; i++) uf[i] = i;
+  auto find = [&](int a) { while (uf[a] != a) a = uf[a] = uf[uf[a]]; return a; };
+  auto unite = [&](int a, int b) { a = find(a); b = find(b); if (a != b) uf[a] = b; };
+  for (int i = 0; i < qs.n; i++) {
+    if (qd[i].old_slot >= 0) return;  // partial products top their old points up inside the fit launch: left alone
+    for (int j = 0; j < qd[i].nfactors; j++) {
+      // two products reading one density (a proposal, or a message whose fit is still pending) stay together: the fit of
+      // that density runs in one half only
+      auto rd = reader_of.find(qd[i].in_slot[j]);
+      if (rd == reader_of.end()) reader_of[qd[i].in_slot[j]] = i; else unite(rd->second, i);
+      auto it = prop_of.find(qd[i].in_slot[j]);
+      if (it != prop_of.end() && owner[it->second] < 0) owner[it->second] = i;
+    }
+  }
+  for (int k = 0; k < ps.n; k++) {
+    if (owner[k] < 0) continue;  // feeds no product of this round: first half, done before any product starts
+    auto reads = [&](int32_t slot) { auto it = prod_of.find(slot); if (it != prod_of.end()) unite(owner[k], it->second); };
+    for (int v = 0; v < pd[k].nvars && v < NBP_MAXV; v++) reads(pd[k].var_slot[v]);
+    if (pd[k].factor_kind == NBP_F_MSGPRIOR || pd[k].factor_kind == NBP_F_PASSTHROUGH) reads(pd[k].var_slot[1]);
+    if (pd[k].meas_kde > 0) reads(pd[k].meas_kde - 1);
+  }
+  // components, largest first, each to the lighter half (weight: densities, the unit of the fit and KD work)
+  std::unordered_map<int, std::pair<int, std::vector<int>>> comp;
+  for (int i = 0; i < qs.n; i++) { auto &c = comp[find(i)]; c.first += qd[i].nfactors; c.second.push_back(i); }
+  std::vector<std::pair<int, std::vector<int>>> cs;
+  for (auto &kv : comp) cs.push_back(std::move(kv.second));
+  std::sort(cs.begin(), cs.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second[0] < b.second[0]; });
+  std::vector<char> half(qs.n, 0);
+  int w[2] = {0, 0}, cnt[2] = {0, 0};
+  for (auto &c : cs) {
+    const int h = w[1] < w[0] ? 1 : 0;
+    w[h] += c.first;
+    for (int i : c.second) { half[i] = (char)h; cnt[h]++; }
+  }
+  if (cnt[0] < qs.n / 3 || cnt[1] < qs.n / 3) return;  // one big component: nothing to run side by side
+  std::vector<nbp_product_desc> q2;
+  for (int h = 0; h < 2; h++)
+    for (int i = 0; i < qs.n; i++) if (half[i] == h) q2.push_back(qd[i]);
+  std::vector<nbp_proposal_desc> p2;
+  int np0 = 0;
+  for (int h = 0; h < 2; h++)
+    for (int k = 0; k < ps.n; k++) {
+      const int hk = owner[k] < 0 ? 0 : half[owner[k]];
+      if (hk == h) { p2.push_back(pd[k]); np0 += h == 0; }
+    }
+  memcpy(qd, q2.data(), q2.size() * sizeof(nbp_product_desc));
+  memcpy(pd, p2.data(), p2.size() * sizeof(nbp_proposal_desc));
+  ps.pipe_split = np0;
+  qs.pipe_split = cnt[0];
+}
+
 nbp_status nbp_program_finalize(nbp_program *p) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
   PROG_ALIVE(p);
@@ -1315,6 +1405,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   p->stages.back().kind = 0;
   std::vector<int32_t> pend_s, pend_m;
   int maxprod = 0;
+  for (int s0 = 0; s0 + 1 < p->n_user_stages; s0++) plan_pipeline(p, s0);  // reorders descriptors: before anything indexes them
   nbp_liveness live;
   if (p->lazy_bw) live = product_liveness(p);
   int sidx = -1;
@@ -1428,6 +1519,27 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       pend_s.clear(); pend_m.clear();
     }
   }
+  for (int s0 = 0; s0 + 1 < p->n_user_stages; s0++) {
+    nbp_stage &ps = p->stages[s0], &qs = p->stages[s0 + 1];
+    if (ps.kind != NBP_STAGE_PROPOSALS || qs.kind != NBP_STAGE_PRODUCTS || ps.pipe_split < 0 || qs.pipe_split < 0) continue;
+    if (ps.fused || !qs.need_prep || qs.flush_before) continue;
+    {  // products too large for the LDS share one node-statistics workspace: single stream
+      int HL, wpb, G;
+      product_geometry(p->ctx, qs.n, &HL, &wpb, &G);
+      if (nbp_product_lds_bytes(qs.maxfd / 4, qs.maxfd % 4, p->ctx->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) continue;
+    }
+    const nbp_product_desc *qd = (const nbp_product_desc *)(p->blob.data() + qs.offset);
+    std::unordered_map<int32_t, int> second;  // slots the second half's products read
+    for (int i = qs.pipe_split; i < qs.n; i++)
+      for (int j = 0; j < qd[i].nfactors; j++) second[qd[i].in_slot[j]] = 1;
+    std::vector<int32_t> es, em;
+    for (int h = 0; h < 2; h++)
+      for (size_t q = 0; q < qs.ent_s.size(); q++)
+        if ((int)second.count(qs.ent_s[q]) == h) { es.push_back(qs.ent_s[q]); em.push_back(qs.ent_m[q]); if (!h) qs.pipe_ent++; }
+    qs.ent_s = es;
+    qs.ent_m = em;
+    ps.pipe = true;
+  }
   for (nbp_stage &st : p->stages) {
     size_t off = (p->blob.size() + 63) & ~(size_t)63;
     p->blob.resize(off + (st.ent_s.size() + st.ent_m.size()) * 4);
@@ -1491,6 +1603,45 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
       rc = launch_update(c, st, (const nbp_update_desc *)(p->dev + st.upd_off), (const nbp_proposal_desc *)(p->dev + st.offset),
                          (const nbp_product_desc *)(p->dev + nx.offset), nx.n);
       s++;  // the products ran inside
+    } else if (st.kind == NBP_STAGE_PROPOSALS && st.pipe && !c->timing && s + 1 < last) {
+      // two-stream round (plan_pipeline): the second half runs one launch behind the first
+      const nbp_stage &nx = p->stages[s + 1];
+      const nbp_proposal_desc *pd = (const nbp_proposal_desc *)(p->dev + st.offset);
+      const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + nx.offset);
+      const int ne = (int)nx.ent_s.size(), ea = nx.pipe_ent, qa = nx.pipe_split, pa = st.pipe_split;
+      const int32_t *es = ent_s(nx), *em = ent_s(nx) + ne;
+      c->geom_n = nx.n;
+      c->geom_blocks = 2 * ne + 2 * nx.n;
+      hipStream_t s1 = c->stream;
+      double *ws1 = c->ws;
+      const size_t wsd1 = c->ws_doubles, wsa = (size_t)qa * (size_t)(nx.maxfd / 4) * nbp_kd_ws_doubles(c->N);
+      auto half = [&](int h) -> nbp_status {
+        const nbp_product_desc *dh = dd + (h ? qa : 0);
+        const int nq = h ? nx.n - qa : qa, nf = h ? ne - ea : ea;
+        nbp_status r = launch_prep(c, es + (h ? ea : 0), em + (h ? ea : 0), nf, dh, nq, nx.maxfd, coords_of(nx.ent_m.data() + (h ? ea : 0), nf), nx.mani);
+        if (!r) r = launch_products(c, dh, nq, nx.maxfd, nx.mani);
+        return r;
+      };
+      rc = launch_proposals(c, pd, pa, st.mani);
+      hipError_t he = hipSuccess;
+      if (!rc) he = hipEventRecord(c->pipe_ev[0], s1);
+      if (!rc && he == hipSuccess) he = hipStreamWaitEvent(c->stream2, c->pipe_ev[0], 0);
+      if (!rc && he == hipSuccess) {
+        c->stream = c->stream2;
+        c->ws = ws1 + wsa;
+        c->ws_doubles = wsd1 - wsa;
+        rc = launch_proposals(c, pd + pa, st.n - pa, st.mani);
+        if (!rc) rc = half(1);
+        c->stream = s1;
+        c->ws = ws1;
+        c->ws_doubles = wsd1;
+        if (!rc) he = hipEventRecord(c->pipe_ev[1], c->stream2);
+      }
+      if (!rc && he == hipSuccess) rc = half(0);
+      if (!rc && he == hipSuccess) he = hipStreamWaitEvent(s1, c->pipe_ev[1], 0);
+      c->geom_n = c->geom_blocks = 0;
+      if (he != hipSuccess) return fail(NBP_ERR_HIP, std::string("two-stream round: ") + hipGetErrorString(he));
+      s++;  // the products ran here
     } else if (st.kind == NBP_STAGE_PROPOSALS) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
@@ -1587,6 +1738,14 @@ nbp_status nbp_program_num_fused(nbp_program *p, int32_t *out) {
   if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
   int n = 0;
   for (const nbp_stage &st : p->stages) n += st.fused ? 1 : 0;
+  *out = n;
+  return NBP_OK;
+}
+
+nbp_status nbp_program_num_two_stream(nbp_program *p, int32_t *out) {
+  if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
+  int n = 0;
+  for (const nbp_stage &st : p->stages) n += st.pipe ? 1 : 0;
   *out = n;
   return NBP_OK;
 }

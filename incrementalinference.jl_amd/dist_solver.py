@@ -261,7 +261,8 @@ class ShardedTreeSolve:
         self.global_messages = st["messages"]
         alg = {"nbp_proposal_kernel": st["alg_bytes_proposal"], "nbp_prep_kernel": st["alg_bytes_prep"],
                "nbp_product_kernel": st["alg_bytes_product"], "nbp_bandwidth_kernel": 0}
-        t = torch.tensor([float(st["updates_up"] + st["updates_down"]), float(st["alg_bytes"])], device=dev, dtype=torch.float64)
+        cdev = dev if (self.dist is None or self.dist.get_backend() == "nccl") else "cpu"  # gloo (tests): host tensors
+        t = torch.tensor([float(st["updates_up"] + st["updates_down"]), float(st["alg_bytes"])], device=cdev, dtype=torch.float64)
         if self.dist is not None:
             self.dist.all_reduce(t)
         self.stats = {"cliques_global": nt.n_cliques, "updates_global": int(t[0].item()), "alg_bytes_total": float(t[1].item()), "alg_bytes": alg}
