@@ -6,14 +6,20 @@
  * with message assembly (separator beliefs up, parent values down) done on the host.  The result is compared, byte
  * for byte, with the whole-tree resident program (nbp_tree_compile) run from the same initial beliefs and seed.
  *
- *   gcc -O2 -Iinclude examples/solve_by_clique_calls.c -o /tmp/clique_calls \
+ *   gcc -O2 -fopenmp -Iinclude examples/solve_by_clique_calls.c -o /tmp/clique_calls \
  *       -Lincrementalinference.jl_amd/csrc -lnbp -Wl,-rpath,$PWD/incrementalinference.jl_amd/csrc -lm
- *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5]
+ *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5] [concurrent callers=1]
+ *
+ * With several concurrent callers the cliques of one tree level are solved side by side, one context per caller -- the
+ * C equivalent of the reference's one-task-per-clique state machines.  Same posteriors: nothing depends on which context
+ * ran a clique.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): set it to the number of
+ * concurrent callers (up to 16), or their launches queue up behind each other.
  *
  * It also times both: the resident program (beliefs stay in HBM) and the clique-by-clique walk, where every call takes its
  * beliefs from host memory and returns them there (the PCIe-inclusive rate of the seam).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,10 +56,92 @@ static void gaussian_factor(nbp_factor_spec *f, int kind, int nvars, int a, int 
 }
 static int find(const int32_t *l, int n, int v) { for (int i = 0; i < n; i++) if (l[i] == v) return i; return -1; }
 
+/* ---- the host side of the clique seam: what the CliqueStateMachine keeps -------------------------------------------- */
+typedef struct {
+  int nvars, nfac, ncl;
+  const nbp_factor_spec *fac;
+  nbp_tree *tree;
+  nbp_clique_info *info;
+  int32_t **fr, **se, **ch, **po, *depth;
+  belief **sub;          /* sub[c][i]: belief of the i-th variable (frontals, then separators) of clique c's sub graph */
+  belief *graph, *post;  /* the graph's beliefs (read-only during the passes, but for the roots' frontals) and the posteriors */
+  const nbp_solver_params *sp;
+  uint64_t seed;
+} host;
+typedef struct { /* one concurrent caller: its context and its scratch */
+  nbp_ctx *ctx;
+  int32_t *vars, *mani, *lists[4], *msgv;
+  nbp_factor_spec *cf;
+  nbp_tree_belief *bel, *msgb;
+} worker;
+
+static int up_clique(host *H, worker *w, int c) {
+  const nbp_clique_info *info = H->info;
+  const int nf = info[c].nfrontals, ns = info[c].nseparators, nv = nf + ns;
+  int32_t *vars = w->vars, counts[4], status = 0;
+  memcpy(vars, H->fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, H->se[c], sizeof(int32_t) * ns);
+  H->sub[c] = malloc(sizeof(belief) * nv);
+  for (int i = 0; i < nv; i++) { H->sub[c][i] = belief_new(); belief_copy(&H->sub[c][i], &H->graph[vars[i]]); w->bel[i] = view(&H->sub[c][i]); } /* deep copy */
+  nbp_clique_desc q;
+  memset(&q, 0, sizeof(q));
+  q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = w->mani;
+  for (int i = 0; i < info[c].npotentials; i++) { /* the clique's potentials, variable ids -> positions in `vars` */
+    w->cf[i] = H->fac[H->po[c][i]];
+    for (int k = 0; k < w->cf[i].nvars; k++) w->cf[i].vars[k] = find(vars, nv, w->cf[i].vars[k]);
+  }
+  q.nfactors = info[c].npotentials; q.factors = w->cf;
+  CHK(nbp_tree_clique_idlists(H->tree, c, counts, w->lists[0], w->lists[1], w->lists[2], w->lists[3]));
+  for (int k = 0; k < 4; k++) for (int i = 0; i < counts[k]; i++) w->lists[k][i] = find(vars, nv, w->lists[k][i]);
+  q.n_direct_frtl_msg = counts[0]; q.n_msgskip = counts[1]; q.n_itervar = counts[2]; q.n_direct_prior_msg = counts[3];
+  q.direct_frtl_msg = w->lists[0]; q.msgskip = w->lists[1]; q.itervar = w->lists[2]; q.direct_prior_msg = w->lists[3];
+  int nm = 0; /* the children's upward messages: their separator beliefs */
+  for (int j = 0; j < info[c].nchildren; j++) {
+    const int cc = H->ch[c][j];
+    for (int i = 0; i < info[cc].nseparators; i++) { w->msgv[nm] = find(vars, nv, H->se[cc][i]); w->msgb[nm++] = view(&H->sub[cc][info[cc].nfrontals + i]); }
+  }
+  q.nmsgs = nm; q.msg_var = w->msgv; q.msg_belief = w->msgb;
+  CHK(nbp_clique_upsolve(w->ctx, H->sp, &q, H->seed, w->bel, &status));
+  if (status != NBP_CLIQ_UPSOLVED) return 1;
+  if (info[c].parent == 0) for (int i = 0; i < nf; i++) { belief_copy(&H->post[vars[i]], &H->sub[c][i]); belief_copy(&H->graph[vars[i]], &H->sub[c][i]); } /* root */
+  return 0;
+}
+
+static int down_clique(host *H, worker *w, int c) {
+  const nbp_clique_info *info = H->info;
+  const int p = info[c].parent, nf = info[c].nfrontals, ns = info[c].nseparators;
+  int nv = nf + ns;
+  int32_t *vars = w->vars, status = 0;
+  memcpy(vars, H->fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, H->se[c], sizeof(int32_t) * ns);
+  for (int i = 0; i < ns; i++) { /* the down message: the parent's values of the separators */
+    int pi = find(H->fr[p], info[p].nfrontals, H->se[c][i]);
+    pi = pi >= 0 ? pi : info[p].nfrontals + find(H->se[p], info[p].nseparators, H->se[c][i]);
+    memcpy(H->sub[c][nf + i].pts, H->sub[p][pi].pts, sizeof(double) * N * D);
+  }
+  int ncf = 0; /* every factor of the frontals, in graph order; their other variables come from the graph */
+  for (int f = 0; f < H->nfac; f++) {
+    int hit = 0;
+    for (int k = 0; k < H->fac[f].nvars; k++) hit |= find(H->fr[c], nf, H->fac[f].vars[k]) >= 0;
+    if (!hit) continue;
+    w->cf[ncf] = H->fac[f];
+    for (int k = 0; k < H->fac[f].nvars; k++) if (find(vars, nv, H->fac[f].vars[k]) < 0) vars[nv++] = H->fac[f].vars[k];
+    ncf++;
+  }
+  for (int i = 0; i < ncf; i++) for (int k = 0; k < w->cf[i].nvars; k++) w->cf[i].vars[k] = find(vars, nv, w->cf[i].vars[k]);
+  for (int i = 0; i < nv; i++) w->bel[i] = i < nf + ns ? view(&H->sub[c][i]) : view(&H->graph[vars[i]]);
+  nbp_clique_desc q;
+  memset(&q, 0, sizeof(q));
+  q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = w->mani; q.nfactors = ncf; q.factors = w->cf;
+  CHK(nbp_clique_downsolve(w->ctx, H->sp, &q, H->seed, w->bel, &status));
+  if (status != NBP_CLIQ_DOWNSOLVED) return 1;
+  for (int i = 0; i < nf; i++) belief_copy(&H->post[vars[i]], &H->sub[c][i]);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int nvars = argc > 1 ? atoi(argv[1]) : 12;
   N = argc > 2 ? atoi(argv[2]) : 128;
   const int every = argc > 3 ? atoi(argv[3]) : 5;
+  const int threads = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : 1;
   const uint64_t seed = 2024;
   nbp_solver_params sp;
   memset(&sp, 0, sizeof(sp));
@@ -97,99 +185,71 @@ int main(int argc, char **argv) {
   CHK(nbp_synchronize(ctx));
   const double t_resident = now_s() - ta;
   for (int v = 0; v < nvars; v++) CHK(nbp_belief_read(ctx, mainslot[v], NBP_EUCLID2, whole[v].pts, NULL, whole[v].bw, whole[v].ipc));
+  int32_t *io_m = malloc(sizeof(int32_t) * nvars), *io_n = malloc(sizeof(int32_t) * nvars);
+  double **io_p = malloc(sizeof(double *) * nvars), **io_b = malloc(sizeof(double *) * nvars), **io_i = malloc(sizeof(double *) * nvars);
   double t_replay = 0, t_io = 0; /* the same program again from the same beliefs: the third run replays the captured hipGraph */
   for (int r = 0; r < 2; r++) {
     const double tw = now_s();
-    for (int v = 0; v < nvars; v++) CHK(nbp_belief_write(ctx, mainslot[v], NBP_EUCLID2, graph[v].pts, N, graph[v].bw, graph[v].ipc));
+    for (int v = 0; v < nvars; v++) { io_m[v] = NBP_EUCLID2; io_n[v] = N; io_p[v] = graph[v].pts; io_b[v] = graph[v].bw; io_i[v] = graph[v].ipc; }
+    CHK(nbp_belief_write_batch(ctx, nvars, mainslot, io_m, (const double *const *)io_p, io_n, (const double *const *)io_b, (const double *const *)io_i));
     CHK(nbp_synchronize(ctx));
     const double t0 = now_s();
     CHK(nbp_program_run(prog, 0, -1));
     CHK(nbp_synchronize(ctx));
     const double t1 = now_s();
-    for (int v = 0; v < nvars; v++) CHK(nbp_belief_read(ctx, mainslot[v], NBP_EUCLID2, post[v].pts, NULL, post[v].bw, post[v].ipc));
+    for (int v = 0; v < nvars; v++) { io_p[v] = post[v].pts; io_b[v] = post[v].bw; io_i[v] = post[v].ipc; }
+    CHK(nbp_belief_read_batch(ctx, nvars, mainslot, io_m, io_p, io_n, io_b, io_i));
     t_replay = t1 - t0;
-    t_io = (t0 - tw) + (now_s() - t1); /* every belief of the graph written to and read from the device, one call each */
+    t_io = (t0 - tw) + (now_s() - t1); /* every belief of the graph written to and read from the device: one call each way */
   }
   CHK(nbp_program_destroy(prog));
   /* ---- (B) one C call per clique ----------------------------------------------------------------------------- */
-  nbp_clique_info *info = calloc((size_t)ncl + 1, sizeof(*info));
-  int32_t **fr = calloc((size_t)ncl + 1, sizeof(*fr)), **se = calloc((size_t)ncl + 1, sizeof(*se)), **ch = calloc((size_t)ncl + 1, sizeof(*ch)),
-          **po = calloc((size_t)ncl + 1, sizeof(*po)), *depth = calloc((size_t)ncl + 1, sizeof(*depth));
-  belief **sub = calloc((size_t)ncl + 1, sizeof(*sub)); /* sub[c][i]: belief of the i-th variable (frontals, then separators) of clique c's sub graph */
+  host H;
+  memset(&H, 0, sizeof(H));
+  H.nvars = nvars; H.nfac = nfac; H.ncl = ncl; H.fac = fac; H.graph = graph; H.post = post; H.seed = seed; H.sp = &sp;
+  H.info = calloc((size_t)ncl + 1, sizeof(*H.info));
+  H.fr = calloc((size_t)ncl + 1, sizeof(*H.fr)); H.se = calloc((size_t)ncl + 1, sizeof(*H.se));
+  H.ch = calloc((size_t)ncl + 1, sizeof(*H.ch)); H.po = calloc((size_t)ncl + 1, sizeof(*H.po));
+  H.depth = calloc((size_t)ncl + 1, sizeof(*H.depth));
+  H.sub = calloc((size_t)ncl + 1, sizeof(*H.sub));
+  H.tree = tree;
   int maxdepth = 0;
   for (int c = 1; c <= ncl; c++) {
-    fr[c] = malloc(sizeof(int32_t) * nvars); se[c] = malloc(sizeof(int32_t) * nvars);
-    ch[c] = malloc(sizeof(int32_t) * ncl); po[c] = malloc(sizeof(int32_t) * (nfac + 1));
-    CHK(nbp_tree_clique(tree, c, &info[c], fr[c], se[c], ch[c], po[c], NULL, NULL));
+    nbp_clique_info ci;
+    CHK(nbp_tree_clique(tree, c, &ci, NULL, NULL, NULL, NULL, NULL, NULL)); /* sizes first */
+    H.fr[c] = malloc(sizeof(int32_t) * (ci.nfrontals + 1)); H.se[c] = malloc(sizeof(int32_t) * (ci.nseparators + 1));
+    H.ch[c] = malloc(sizeof(int32_t) * (ci.nchildren + 1)); H.po[c] = malloc(sizeof(int32_t) * (ci.npotentials + 1));
+    CHK(nbp_tree_clique(tree, c, &H.info[c], H.fr[c], H.se[c], H.ch[c], H.po[c], NULL, NULL));
   }
-  for (int c = 1; c <= ncl; c++) { int d = 0; for (int p = info[c].parent; p; p = info[p].parent) d++; depth[c] = d; if (d > maxdepth) maxdepth = d; }
-  int32_t *vars = malloc(sizeof(int32_t) * nvars), *mani = malloc(sizeof(int32_t) * nvars), *lists[4], counts[4];
-  for (int k = 0; k < 4; k++) lists[k] = malloc(sizeof(int32_t) * nvars);
-  nbp_factor_spec *cf = calloc((size_t)nfac + 1, sizeof(*cf));
-  nbp_tree_belief *bel = malloc(sizeof(nbp_tree_belief) * nvars), *msgb = malloc(sizeof(nbp_tree_belief) * nvars);
-  int32_t *msgv = malloc(sizeof(int32_t) * nvars);
-  for (int v = 0; v < nvars; v++) mani[v] = NBP_EUCLID2;
-  int32_t status = 0;
+  for (int c = 1; c <= ncl; c++) { int d = 0; for (int p = H.info[c].parent; p; p = H.info[p].parent) d++; H.depth[c] = d; if (d > maxdepth) maxdepth = d; }
+  /* one context per concurrent caller: the cliques of a tree level are independent of each other (the reference runs them
+   * as concurrent tasks, CliqueStateMachine.jl), and contexts share nothing */
+  worker *W = calloc((size_t)threads, sizeof(*W));
+  for (int t = 0; t < threads; t++) {
+    W[t].ctx = t == 0 ? ctx : NULL;
+    if (t > 0) CHK(nbp_ctx_create(0, N, 256, NULL, 0, 0, &W[t].ctx));
+    W[t].vars = malloc(sizeof(int32_t) * nvars); W[t].mani = malloc(sizeof(int32_t) * nvars);
+    for (int k = 0; k < 4; k++) W[t].lists[k] = malloc(sizeof(int32_t) * nvars);
+    W[t].cf = calloc((size_t)nfac + 1, sizeof(*W[t].cf));
+    W[t].bel = malloc(sizeof(nbp_tree_belief) * nvars); W[t].msgb = malloc(sizeof(nbp_tree_belief) * nvars);
+    W[t].msgv = malloc(sizeof(int32_t) * nvars);
+    for (int v = 0; v < nvars; v++) W[t].mani[v] = NBP_EUCLID2;
+  }
+  int failed = 0;
   const double tb = now_s();
-  for (int d = maxdepth; d >= 0; d--)  /* up pass: children before parents */
-    for (int c = 1; c <= ncl; c++) {
-      if (depth[c] != d) continue;
-      const int nf = info[c].nfrontals, ns = info[c].nseparators, nv = nf + ns;
-      memcpy(vars, fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, se[c], sizeof(int32_t) * ns);
-      sub[c] = malloc(sizeof(belief) * nv);
-      for (int i = 0; i < nv; i++) { sub[c][i] = belief_new(); belief_copy(&sub[c][i], &graph[vars[i]]); bel[i] = view(&sub[c][i]); } /* deep copy */
-      nbp_clique_desc q;
-      memset(&q, 0, sizeof(q));
-      q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = mani;
-      for (int i = 0; i < info[c].npotentials; i++) { /* the clique's potentials, variable ids -> positions in `vars` */
-        cf[i] = fac[po[c][i]];
-        for (int k = 0; k < cf[i].nvars; k++) cf[i].vars[k] = find(vars, nv, cf[i].vars[k]);
-      }
-      q.nfactors = info[c].npotentials; q.factors = cf;
-      CHK(nbp_tree_clique_idlists(tree, c, counts, lists[0], lists[1], lists[2], lists[3]));
-      for (int k = 0; k < 4; k++) for (int i = 0; i < counts[k]; i++) lists[k][i] = find(vars, nv, lists[k][i]);
-      q.n_direct_frtl_msg = counts[0]; q.n_msgskip = counts[1]; q.n_itervar = counts[2]; q.n_direct_prior_msg = counts[3];
-      q.direct_frtl_msg = lists[0]; q.msgskip = lists[1]; q.itervar = lists[2]; q.direct_prior_msg = lists[3];
-      int nm = 0; /* the children's upward messages: their separator beliefs */
-      for (int j = 0; j < info[c].nchildren; j++) {
-        const int cc = ch[c][j];
-        for (int i = 0; i < info[cc].nseparators; i++) { msgv[nm] = find(vars, nv, se[cc][i]); msgb[nm++] = view(&sub[cc][info[cc].nfrontals + i]); }
-      }
-      q.nmsgs = nm; q.msg_var = msgv; q.msg_belief = msgb;
-      CHK(nbp_clique_upsolve(ctx, &sp, &q, seed, bel, &status));
-      if (status != NBP_CLIQ_UPSOLVED) return 4;
-      if (info[c].parent == 0) for (int i = 0; i < nf; i++) { belief_copy(&post[vars[i]], &sub[c][i]); belief_copy(&graph[vars[i]], &sub[c][i]); } /* root */
-    }
-  for (int d = 1; d <= maxdepth; d++)  /* down pass: parents before children */
-    for (int c = 1; c <= ncl; c++) {
-      if (depth[c] != d) continue;
-      const int p = info[c].parent, nf = info[c].nfrontals, ns = info[c].nseparators;
-      int nv = nf + ns;
-      memcpy(vars, fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, se[c], sizeof(int32_t) * ns);
-      for (int i = 0; i < ns; i++) { /* the down message: the parent's values of the separators */
-        int pi = find(fr[p], info[p].nfrontals, se[c][i]);
-        pi = pi >= 0 ? pi : info[p].nfrontals + find(se[p], info[p].nseparators, se[c][i]);
-        memcpy(sub[c][nf + i].pts, sub[p][pi].pts, sizeof(double) * N * D);
-      }
-      int ncf = 0; /* every factor of the frontals, in graph order; their other variables come from the graph */
-      for (int f = 0; f < nfac; f++) {
-        int hit = 0;
-        for (int k = 0; k < fac[f].nvars; k++) hit |= find(fr[c], nf, fac[f].vars[k]) >= 0;
-        if (!hit) continue;
-        cf[ncf] = fac[f];
-        for (int k = 0; k < fac[f].nvars; k++) if (find(vars, nv, fac[f].vars[k]) < 0) vars[nv++] = fac[f].vars[k];
-        ncf++;
-      }
-      for (int i = 0; i < ncf; i++) for (int k = 0; k < cf[i].nvars; k++) cf[i].vars[k] = find(vars, nv, cf[i].vars[k]);
-      for (int i = 0; i < nv; i++) bel[i] = i < nf + ns ? view(&sub[c][i]) : view(&graph[vars[i]]);
-      nbp_clique_desc q;
-      memset(&q, 0, sizeof(q));
-      q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = mani; q.nfactors = ncf; q.factors = cf;
-      CHK(nbp_clique_downsolve(ctx, &sp, &q, seed, bel, &status));
-      if (status != NBP_CLIQ_DOWNSOLVED) return 4;
-      for (int i = 0; i < nf; i++) belief_copy(&post[vars[i]], &sub[c][i]);
-    }
+  for (int d = maxdepth; d >= 0 && !failed; d--) { /* up pass: children before parents, the cliques of a level side by side */
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(| : failed)
+    for (int c = 1; c <= ncl; c++)
+      if (H.depth[c] == d) failed |= up_clique(&H, &W[omp_get_thread_num()], c);
+  }
+  for (int d = 1; d <= maxdepth && !failed; d++) { /* down pass: parents before children */
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(| : failed)
+    for (int c = 1; c <= ncl; c++)
+      if (H.depth[c] == d) failed |= down_clique(&H, &W[omp_get_thread_num()], c);
+  }
+  if (failed) return 4;
   const double t_calls = now_s() - tb;
+  for (int t = 1; t < threads; t++) nbp_ctx_destroy(W[t].ctx);
   /* ---- compare -------------------------------------------------------------------------------------------------- */
   int same = 0;
   double worst = 0;
@@ -200,10 +260,11 @@ int main(int argc, char **argv) {
     if (fabs(mx / N - v) > worst) worst = fabs(mx / N - v);
   }
   printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program; "
-         "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f\n", nvars, ncl, same, nvars, post[0].ipc[0], post[0].ipc[1], worst);
+         "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
+         post[0].ipc[0], post[0].ipc[1], worst, threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
-         "of the graph over PCIe: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s\n",
+         "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s\n",
          t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls);
   nbp_ctx_destroy(ctx);
   nbp_tree_destroy(tree);

@@ -215,6 +215,15 @@ nbp_status nbp_belief_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const 
                             const double *bw_D /* nullable */, const double *ipc_D /* nullable: zeros */);
 nbp_status nbp_belief_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP, int32_t *n_pts /* nullable */,
                            double *bw_D /* nullable */, double *ipc_D /* nullable */);
+/* Many beliefs in one call: packed into a pinned staging buffer and moved with one asynchronous copy per run of consecutive
+ * slots on the library's stream (a clique call moves all its beliefs in one or two copies; a caller loading a whole graph
+ * moves it in one).  Arrays of n entries; n_pts / bw / ipc may be NULL as a whole (N points, no bandwidth, infoPerCoord 0)
+ * or per entry (bw, ipc).  _write_batch returns once the copies are queued: they are ordered before whatever is launched
+ * next.  _read_batch returns the rows each belief holds in n_pts[i] (pts[i] sized for N rows), like nbp_belief_read. */
+nbp_status nbp_belief_write_batch(nbp_ctx *ctx, int32_t n, const int32_t *slots, const int32_t *manifolds, const double *const *pts,
+                                  const int32_t *n_pts, const double *const *bw, const double *const *ipc);
+nbp_status nbp_belief_read_batch(nbp_ctx *ctx, int32_t n, const int32_t *slots, const int32_t *manifolds, double *const *pts,
+                                 int32_t *n_pts, double *const *bw, double *const *ipc);
 /* sample(oldBel, N - Npts) in place: beliefs with fewer than N points are topped up to N with draws from their own KDE
  * (random kernel + bw * randn); the points they hold stay.  Multinomial resampling of a belief to the solver's N. */
 nbp_status nbp_run_resample(nbp_ctx *ctx, const int32_t *slots, const int32_t *manifolds, int32_t n, uint64_t seed);

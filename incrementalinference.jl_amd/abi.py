@@ -95,7 +95,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libnbp.so")
 EXPORTS = [
     "nbp_arena_bytes", "nbp_slot_stride_doubles", "nbp_ctx_create", "nbp_ctx_destroy",
     "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr",
-    "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
+    "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_belief_write_batch", "nbp_belief_read_batch", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
     "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
     "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_num_fused", "nbp_program_num_two_stream", "nbp_program_destroy",
@@ -146,6 +146,8 @@ def load_library(path=None):
     lib.nbp_slot_read.argtypes = [vp, i32, i32, dp, dp]
     lib.nbp_belief_write.argtypes = [vp, i32, i32, dp, i32, dp, dp]
     lib.nbp_belief_read.argtypes = [vp, i32, i32, dp, ip, dp, dp]
+    lib.nbp_belief_write_batch.argtypes = [vp, i32, ip, ip, C.POINTER(dp), ip, C.POINTER(dp), C.POINTER(dp)]
+    lib.nbp_belief_read_batch.argtypes = [vp, i32, ip, ip, C.POINTER(dp), ip, C.POINTER(dp), C.POINTER(dp)]
     lib.nbp_run_resample.argtypes = [vp, ip, ip, i32, C.c_uint64]
     lib.nbp_side_write.argtypes = [vp, i32, ip, i32]
     lib.nbp_side_read.argtypes = [vp, i32, ip, i32]

@@ -93,6 +93,34 @@ class HipBackend:
                                              bw.ctypes.data_as(dp), ipc.ctypes.data_as(dp)))
         return pts[:n.value], bw, ipc
 
+    def beliefs_write(self, slots, manifolds, beliefs):
+        """many TreeBeliefs in one call (nbp_belief_write_batch): beliefs = [(pts, bw or None, ipc or None), ...]"""
+        dp, n = C.POINTER(C.c_double), len(slots)
+        keep, P, B, I, cnt = [], (dp * n)(), (dp * n)(), (dp * n)(), (C.c_int32 * n)()
+        for i, (pts, bw, ipc) in enumerate(beliefs):
+            pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, abi.MANIFOLD_P[manifolds[i]])
+            keep.append(pts)
+            P[i], cnt[i] = pts.ctypes.data_as(dp), pts.shape[0]
+            for arr, tab in ((bw, B), (ipc, I)):
+                if arr is not None:
+                    arr = np.ascontiguousarray(arr, dtype=np.float64)
+                    keep.append(arr)
+                    tab[i] = arr.ctypes.data_as(dp)
+        self._check(self.lib.nbp_belief_write_batch(self._ctx, n, (C.c_int32 * n)(*slots), (C.c_int32 * n)(*manifolds), P, cnt, B, I))
+        # (packed into the staging buffer before the call returns: `keep` may go)
+
+    def beliefs_read(self, slots, manifolds):
+        """-> [(pts, bw, ipc), ...] (nbp_belief_read_batch)"""
+        dp, n = C.POINTER(C.c_double), len(slots)
+        P, B, I, cnt = (dp * n)(), (dp * n)(), (dp * n)(), (C.c_int32 * n)()
+        out = []
+        for i, m in enumerate(manifolds):
+            pts, bw, ipc = np.empty((self.N, abi.MANIFOLD_P[m])), np.empty(abi.MANIFOLD_DIM[m]), np.empty(abi.MANIFOLD_DIM[m])
+            out.append((pts, bw, ipc))
+            P[i], B[i], I[i] = pts.ctypes.data_as(dp), bw.ctypes.data_as(dp), ipc.ctypes.data_as(dp)
+        self._check(self.lib.nbp_belief_read_batch(self._ctx, n, (C.c_int32 * n)(*slots), (C.c_int32 * n)(*manifolds), P, cnt, B, I))
+        return [(p[:cnt[i]], b, q) for i, (p, b, q) in enumerate(out)]
+
     def side_write(self, offset, ints):
         a = np.ascontiguousarray(ints, dtype=np.int32)
         self._check(self.lib.nbp_side_write(self._ctx, offset, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))

@@ -65,6 +65,13 @@ struct nbp_ctx {
   // staging for immediate-mode calls
   void *stage = nullptr;
   size_t stage_bytes = 0;
+  // pinned host staging of the batched belief transfers (nbp_belief_write_batch / _read_batch): one copy per run of
+  // consecutive slots, asynchronous on the library stream
+  double *pin = nullptr;
+  size_t pin_doubles = 0;
+  // device blobs of destroyed programs, kept for the next short-lived one (a clique call compiles, runs and drops a
+  // program: hipMalloc / hipFree per call would synchronise the whole device each time)
+  std::vector<std::pair<char *, size_t>> blob_cache;
   // fused variable updates (nbp_fused.h) for the stages that fill the chip: NBP_NO_FUSED_UPDATE=1 turns them off,
   // NBP_FUSED_MIN = smallest stage (updates) that runs fused
   // Off unless NBP_FUSED_MIN is set: measured on config 2 and on the 10 000-variable chain the fused form moves a ninth of
@@ -266,6 +273,9 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (c->lv_ints) hipFree(c->lv_ints);
   if (c->lv_dbls) hipFree(c->lv_dbls);
   if (c->stage) hipFree(c->stage);
+  if (c->pin) hipHostFree(c->pin);
+  for (auto &b : c->blob_cache) hipFree(b.first);
+  c->blob_cache.clear();
   if (c->ws) hipFree(c->ws);
   if (c->gstats) hipFree(c->gstats);
   if (c->spec) hipFree(c->spec);
@@ -292,15 +302,10 @@ nbp_status nbp_slot_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts
   return nbp_belief_read(c, slot, manifold, pts, nullptr, bw, nullptr);
 }
 
-nbp_status nbp_belief_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, int32_t n_pts, const double *bw,
-                            const double *ipc) {
-  if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
-  if (n_pts < 1) return fail(NBP_ERR_RANGE, "belief: n_pts < 1");
-  if (n_pts < c->N && !bw) return fail(NBP_ERR_ARG, "belief: a belief with fewer than N points needs its bandwidth (it is a density, not a point set)");
-  if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
-  if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
+// a belief as its slot holds it: coordinates SoA over N rows, then bandwidth (3), infoPerCoord (3), count
+static void pack_belief(const nbp_ctx *c, int32_t manifold, const double *pts, int32_t n_pts, const double *bw, const double *ipc, double *s) {
   const int N = c->N, D = manifold_dim_h(manifold), P = manifold_P_h(manifold);
-  std::vector<double> s(c->S, 0.0);
+  memset(s, 0, sizeof(double) * (size_t)c->S);
   const int cnt = n_pts < N ? n_pts : N;  // more than N points: the first N (GraphProductOperations.jl:44, `_pts[1:N]`)
   s[3 * N + 6] = cnt < N ? (double)cnt : 0.0;
   for (int n = 0; n < cnt; n++) {
@@ -317,21 +322,11 @@ nbp_status nbp_belief_write(nbp_ctx *c, int32_t slot, int32_t manifold, const do
   }
   for (int d = 0; d < D; d++) s[3 * N + d] = bw ? bw[d] : 0.0;
   for (int d = 0; d < D; d++) s[3 * N + 3 + d] = ipc ? ipc[d] : 0.0;  // a fresh VariableNodeData carries infoPerCoord = 0
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(c->arena + c->S * slot, s.data(), c->S * 8, hipMemcpyHostToDevice));
-  return NBP_OK;
 }
-
-nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts, int32_t *n_pts, double *bw, double *ipc) {
-  if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
-  if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
-  if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
+// with n_pts: the rows the belief holds (the caller sized `pts` by the count it expects back, at most N); without
+// (nbp_slot_read): all N rows of the slot
+static void unpack_belief(const nbp_ctx *c, int32_t manifold, const double *s, double *pts, int32_t *n_pts, double *bw, double *ipc) {
   const int N = c->N, D = manifold_dim_h(manifold), P = manifold_P_h(manifold);
-  std::vector<double> s(c->S);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(s.data(), c->arena + c->S * slot, c->S * 8, hipMemcpyDeviceToHost));
-  // with n_pts: the rows the belief holds (the caller sized `pts` by the count it expects back, at most N); without
-  // (nbp_slot_read): all N rows of the slot
   const int cnt_held = (s[3 * N + 6] > 0.0 && s[3 * N + 6] < (double)N) ? (int)s[3 * N + 6] : N;
   const int rows = n_pts ? cnt_held : N;
   for (int n = 0; n < rows; n++) {
@@ -349,6 +344,96 @@ nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *p
   if (ipc)
     for (int d = 0; d < D; d++) ipc[d] = s[3 * N + 3 + d];
   if (n_pts) *n_pts = cnt_held;
+}
+static nbp_status belief_args(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts) {
+  if (!c || !pts) return fail(NBP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
+  if (!manifold_ok(manifold)) return fail(NBP_ERR_ARG, "unknown manifold");
+  return NBP_OK;
+}
+
+nbp_status nbp_belief_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, int32_t n_pts, const double *bw,
+                            const double *ipc) {
+  nbp_status rc = belief_args(c, slot, manifold, pts);
+  if (rc) return rc;
+  if (n_pts < 1) return fail(NBP_ERR_RANGE, "belief: n_pts < 1");
+  if (n_pts < c->N && !bw) return fail(NBP_ERR_ARG, "belief: a belief with fewer than N points needs its bandwidth (it is a density, not a point set)");
+  std::vector<double> s(c->S);
+  pack_belief(c, manifold, pts, n_pts, bw, ipc, s.data());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->arena + c->S * slot, s.data(), c->S * 8, hipMemcpyHostToDevice));
+  return NBP_OK;
+}
+
+nbp_status nbp_belief_read(nbp_ctx *c, int32_t slot, int32_t manifold, double *pts, int32_t *n_pts, double *bw, double *ipc) {
+  nbp_status rc = belief_args(c, slot, manifold, pts);
+  if (rc) return rc;
+  std::vector<double> s(c->S);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(s.data(), c->arena + c->S * slot, c->S * 8, hipMemcpyDeviceToHost));
+  unpack_belief(c, manifold, s.data(), pts, n_pts, bw, ipc);
+  return NBP_OK;
+}
+
+// ---- many beliefs in one call ---------------------------------------------------------------------------------------------
+// The beliefs are packed into (unpacked from) a pinned staging buffer and moved with ONE asynchronous copy per run of
+// consecutive slots on the library stream: a clique call moves its 3-10 beliefs in one or two copies instead of one
+// synchronous copy each, a caller that loads a whole graph moves it in one.
+static nbp_status ensure_pin(nbp_ctx *c, size_t doubles) {
+  if (doubles <= c->pin_doubles) return NBP_OK;
+  if (c->pin) HIPCHK(hipHostFree(c->pin));
+  c->pin = nullptr;
+  c->pin_doubles = 0;
+  HIPCHK(hipHostMalloc((void **)&c->pin, (doubles + doubles / 2) * 8, hipHostMallocDefault));
+  c->pin_doubles = doubles + doubles / 2;
+  return NBP_OK;
+}
+nbp_status nbp_belief_write_batch(nbp_ctx *c, int32_t n, const int32_t *slots, const int32_t *manifolds, const double *const *pts,
+                                  const int32_t *n_pts, const double *const *bw, const double *const *ipc) {
+  if (!c || (n > 0 && (!slots || !manifolds || !pts))) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; i++) {
+    nbp_status rc = belief_args(c, slots[i], manifolds[i], pts[i]);
+    if (rc) return rc;
+    const int np = n_pts ? n_pts[i] : c->N;
+    if (np < 1) return fail(NBP_ERR_RANGE, "belief: n_pts < 1");
+    if (np < c->N && !(bw && bw[i])) return fail(NBP_ERR_ARG, "belief: a belief with fewer than N points needs its bandwidth (it is a density, not a point set)");
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));  // the staging buffer is free again (and so is every slot about to be replaced)
+  nbp_status rc = ensure_pin(c, (size_t)n * (size_t)c->S);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++)
+    pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, c->pin + (size_t)i * c->S);
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && slots[j] == slots[j - 1] + 1) j++;
+    HIPCHK(hipMemcpyAsync(c->arena + c->S * slots[i], c->pin + (size_t)i * c->S, (size_t)(j - i) * c->S * 8, hipMemcpyHostToDevice, c->stream));
+    i = j;
+  }
+  return NBP_OK;  // stream-ordered: whatever is launched next sees the beliefs; the next use of the staging buffer waits for the copies
+}
+nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, const int32_t *manifolds, double *const *pts,
+                                 int32_t *n_pts, double *const *bw, double *const *ipc) {
+  if (!c || (n > 0 && (!slots || !manifolds || !pts))) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; i++) {
+    nbp_status rc = belief_args(c, slots[i], manifolds[i], pts[i]);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  nbp_status rc = ensure_pin(c, (size_t)n * (size_t)c->S);
+  if (rc) return rc;
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && slots[j] == slots[j - 1] + 1) j++;
+    HIPCHK(hipMemcpyAsync(c->pin + (size_t)i * c->S, c->arena + c->S * slots[i], (size_t)(j - i) * c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    i = j;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++)
+    unpack_belief(c, manifolds[i], c->pin + (size_t)i * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
   return NBP_OK;
 }
 
@@ -1049,6 +1134,7 @@ struct nbp_program {
   std::vector<nbp_stage> stages;  // + one trailing pseudo stage holding the fits pending at exit
   std::vector<char> blob;
   char *dev = nullptr;
+  size_t dev_bytes = 0;
   bool finalized = false;
   bool lazy_bw = false;  // NBP_OPT_LAZY_BANDWIDTH
   bool use_graph = true; // NBP_OPT_GRAPH_REPLAY
@@ -1583,7 +1669,21 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       if (rc) return rc;
     }
   size_t bytes = p->blob.size() ? p->blob.size() : 64;
-  HIPCHK(hipMalloc(&p->dev, bytes));
+  {  // a blob a destroyed program left behind, if one is large enough (the smallest such)
+    auto &bc = p->ctx->blob_cache;
+    int best = -1;
+    for (size_t i = 0; i < bc.size(); i++)
+      if (bc[i].second >= bytes && (best < 0 || bc[i].second < bc[(size_t)best].second)) best = (int)i;
+    if (best >= 0) {
+      p->dev = bc[(size_t)best].first;
+      p->dev_bytes = bc[(size_t)best].second;
+      bc.erase(bc.begin() + best);
+    }
+  }
+  if (!p->dev) {
+    p->dev_bytes = bytes < 65536 ? 65536 : bytes;
+    HIPCHK(hipMalloc(&p->dev, p->dev_bytes));
+  }
   if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
   p->finalized = true;
   return NBP_OK;
@@ -1755,7 +1855,12 @@ nbp_status nbp_program_destroy(nbp_program *p) {
   if (p->ctx) {  // (a program whose context is gone was detached by nbp_ctx_destroy: nothing left on the device)
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    if (p->dev) hipFree(p->dev);
+    if (p->dev) {
+      // small blobs are kept for the next program of this context (hipFree synchronises the whole device)
+      auto &bc = p->ctx->blob_cache;
+      if (p->dev_bytes <= (1u << 20) && bc.size() < 8) bc.emplace_back(p->dev, p->dev_bytes);
+      else hipFree(p->dev);
+    }
     for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second.exec);
     auto &v = p->ctx->programs;
     for (size_t i = 0; i < v.size(); i++)

@@ -1781,29 +1781,27 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
     for (int k = 0; k < NBP_DOWN_MCITERS; k++)
       for (int v : itf) { sched.push_back(v); iter.push_back(k + 1); }
   }
-  // ---- beliefs in ----------------------------------------------------------------------------------------
-  for (int v = 0; v < q->nvars; v++) {
-    if (!bel[v].pts) return hfail(NBP_ERR_ARG, "clique: null belief");
-    rc = nbp_belief_write(ctx, v, q->manifold[v], bel[v].pts, bel[v].n_pts, bel[v].bw, bel[v].ipc);
-    if (rc) return rc;
-  }
-  for (int i = 0; i < (down ? 0 : q->nmsgs); i++) {
-    const nbp_tree_belief &m = q->msg_belief[i];
-    if (!m.pts || !m.bw) return hfail(NBP_ERR_ARG, "clique: a message needs points and bandwidth");
-    rc = nbp_belief_write(ctx, msg0 + i, q->manifold[q->msg_var[i]], m.pts, m.n_pts, m.bw, m.ipc);
-    if (rc) return rc;
-  }
-  for (int f = 0; f < q->nfactors; f++) {
-    if (facs[f].dens < 0) continue;
-    const nbp_tree_belief &m = q->factor_density[f];
-    rc = nbp_belief_write(ctx, dens0 + facs[f].dens, q->manifold[facs[f].s.vars[0]], m.pts, m.n_pts, m.bw, m.ipc);
-    if (rc) return rc;
-  }
-  for (int f = 0; f < q->nfactors; f++) {  // LinearRelative(::MKD) & co.: the measurement is the child's KDE, in measurement coordinates
-    if (kde_of[f] < 0) continue;
-    const nbp_tree_belief &m = q->factor_meas_kde[f];
-    const int zd = clique_zdim(q->factors[f].factor_kind, q->manifold[q->factors[f].vars[0]]);
-    rc = nbp_belief_write(ctx, kde0 + kde_of[f], zd /* Euclid(zd) */, m.pts, m.n_pts, m.bw, nullptr);
+  // ---- beliefs in: one batched transfer (the slots are consecutive: one copy) -------------------------------------
+  {
+    std::vector<int32_t> bs, bm, bn;
+    std::vector<const double *> bp, bb, bi;
+    auto put = [&](int slot, int mani, const nbp_tree_belief &m, bool with_ipc) {
+      bs.push_back(slot); bm.push_back(mani); bn.push_back(m.n_pts); bp.push_back(m.pts); bb.push_back(m.bw); bi.push_back(with_ipc ? m.ipc : nullptr);
+    };
+    for (int v = 0; v < q->nvars; v++) {
+      if (!bel[v].pts) return hfail(NBP_ERR_ARG, "clique: null belief");
+      put(v, q->manifold[v], bel[v], true);
+    }
+    for (int i = 0; i < (down ? 0 : q->nmsgs); i++) {
+      const nbp_tree_belief &m = q->msg_belief[i];
+      if (!m.pts || !m.bw) return hfail(NBP_ERR_ARG, "clique: a message needs points and bandwidth");
+      put(msg0 + i, q->manifold[q->msg_var[i]], m, true);
+    }
+    for (int f = 0; f < q->nfactors; f++)
+      if (facs[f].dens >= 0) put(dens0 + facs[f].dens, q->manifold[facs[f].s.vars[0]], q->factor_density[f], true);
+    for (int f = 0; f < q->nfactors; f++)  // LinearRelative(::MKD) & co.: the measurement is the child's KDE, in measurement coordinates
+      if (kde_of[f] >= 0) put(kde0 + kde_of[f], clique_zdim(q->factors[f].factor_kind, q->manifold[q->factors[f].vars[0]]) /* Euclid(zd) */, q->factor_meas_kde[f], false);
+    rc = nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
     if (rc) return rc;
   }
   // ---- the schedule as a resident program ------------------------------------------------------------------
@@ -1919,16 +1917,25 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   if (!rc) rc = nbp_program_run(p, 0, -1);
   if (!rc) rc = nbp_synchronize(ctx);
   if (rc) return rc;
-  for (int i = 0; i < ndiff; i++) {  // the differential KDEs: points in measurement coordinates + fitted bandwidth
-    if (!diff_out[i].pts || !diff_out[i].bw) return hfail(NBP_ERR_ARG, "clique: diff_out entries need pts and bw");
-    rc = nbp_belief_read(ctx, diff0 + i, clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]), diff_out[i].pts, &diff_out[i].n_pts, diff_out[i].bw, nullptr);
+  // ---- beliefs out, one batched transfer: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the
+  // schedule touched, then the differential KDEs (points in measurement coordinates + fitted bandwidth)
+  {
+    std::vector<int32_t> bs, bm, bn;
+    std::vector<double *> bp, bb, bi;
+    std::vector<int32_t *> cnt;
+    for (int v = 0; v < q->nvars; v++) {
+      if (!updated[v]) continue;
+      bs.push_back(v); bm.push_back(q->manifold[v]); bp.push_back(bel[v].pts); bb.push_back(bel[v].bw); bi.push_back(bel[v].ipc); cnt.push_back(&bel[v].n_pts);
+    }
+    for (int i = 0; i < ndiff; i++) {
+      if (!diff_out[i].pts || !diff_out[i].bw) return hfail(NBP_ERR_ARG, "clique: diff_out entries need pts and bw");
+      bs.push_back(diff0 + i); bm.push_back(clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]));
+      bp.push_back(diff_out[i].pts); bb.push_back(diff_out[i].bw); bi.push_back(nullptr); cnt.push_back(&diff_out[i].n_pts);
+    }
+    bn.resize(bs.size());
+    rc = nbp_belief_read_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
     if (rc) return rc;
-  }
-  // ---- beliefs out: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the schedule touched
-  for (int v = 0; v < q->nvars; v++) {
-    if (!updated[v]) continue;
-    rc = nbp_belief_read(ctx, v, q->manifold[v], bel[v].pts, &bel[v].n_pts, bel[v].bw, bel[v].ipc);
-    if (rc) return rc;
+    for (size_t i = 0; i < bs.size(); i++) *cnt[i] = bn[i];
   }
   if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
   return NBP_OK;

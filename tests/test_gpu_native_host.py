@@ -71,11 +71,15 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "incrementalinference.jl_amd", "csrc")
     exe = str(tmp_path / "clique_calls")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "solve_by_clique_calls.c"),
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-fopenmp", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "solve_by_clique_calls.c"),
                            "-o", exe, "-L", lib, "-lnbp", f"-Wl,-rpath,{lib}", "-lm"])
     out = subprocess.run([exe, "12", "128"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "12 of 12 posteriors byte-identical" in out.stdout, out.stdout
+    # the cliques of a tree level solved by four concurrent callers, one context each: the same bytes
+    out = subprocess.run([exe, "60", "100", "10", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "60 of 60 posteriors byte-identical" in out.stdout and "4 concurrent caller(s)" in out.stdout, out.stdout
 
 
 def test_native_graph_init_equals_python_init_all(hip_backend):
