@@ -8,7 +8,7 @@
  *
  *   gcc -O2 -fopenmp -Iinclude examples/solve_by_clique_calls.c -o /tmp/clique_calls \
  *       -Lincrementalinference.jl_amd/csrc -lnbp -Wl,-rpath,$PWD/incrementalinference.jl_amd/csrc -lm
- *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5] [concurrent callers=1]
+ *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5] [concurrent callers=1; 0 = one batched call per tree level]
  *
  * With several concurrent callers the cliques of one tree level are solved side by side, one context per caller -- the
  * C equivalent of the reference's one-task-per-clique state machines.  Same posteriors: nothing depends on which context
@@ -68,17 +68,18 @@ typedef struct {
   const nbp_solver_params *sp;
   uint64_t seed;
 } host;
-typedef struct { /* one concurrent caller: its context and its scratch */
+typedef struct { /* one concurrent caller: its context and its scratch; `q` = the clique call it has prepared */
   nbp_ctx *ctx;
+  nbp_clique_desc q;
   int32_t *vars, *mani, *lists[4], *msgv;
   nbp_factor_spec *cf;
   nbp_tree_belief *bel, *msgb;
 } worker;
 
-static int up_clique(host *H, worker *w, int c) {
+static int up_prepare(host *H, worker *w, int c) {
   const nbp_clique_info *info = H->info;
   const int nf = info[c].nfrontals, ns = info[c].nseparators, nv = nf + ns;
-  int32_t *vars = w->vars, counts[4], status = 0;
+  int32_t *vars = w->vars, counts[4];
   memcpy(vars, H->fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, H->se[c], sizeof(int32_t) * ns);
   H->sub[c] = malloc(sizeof(belief) * nv);
   for (int i = 0; i < nv; i++) { H->sub[c][i] = belief_new(); belief_copy(&H->sub[c][i], &H->graph[vars[i]]); w->bel[i] = view(&H->sub[c][i]); } /* deep copy */
@@ -100,17 +101,28 @@ static int up_clique(host *H, worker *w, int c) {
     for (int i = 0; i < info[cc].nseparators; i++) { w->msgv[nm] = find(vars, nv, H->se[cc][i]); w->msgb[nm++] = view(&H->sub[cc][info[cc].nfrontals + i]); }
   }
   q.nmsgs = nm; q.msg_var = w->msgv; q.msg_belief = w->msgb;
-  CHK(nbp_clique_upsolve(w->ctx, H->sp, &q, H->seed, w->bel, &status));
+  w->q = q;
+  return 0;
+}
+static void up_finish(host *H, int c) {
+  const int nf = H->info[c].nfrontals;
+  if (H->info[c].parent == 0) /* root: the up-solved frontals are the posterior and go back to the graph */
+    for (int i = 0; i < nf; i++) { belief_copy(&H->post[H->fr[c][i]], &H->sub[c][i]); belief_copy(&H->graph[H->fr[c][i]], &H->sub[c][i]); }
+}
+static int up_clique(host *H, worker *w, int c) {
+  int32_t status = 0;
+  if (up_prepare(H, w, c)) return 1;
+  CHK(nbp_clique_upsolve(w->ctx, H->sp, &w->q, H->seed, w->bel, &status));
   if (status != NBP_CLIQ_UPSOLVED) return 1;
-  if (info[c].parent == 0) for (int i = 0; i < nf; i++) { belief_copy(&H->post[vars[i]], &H->sub[c][i]); belief_copy(&H->graph[vars[i]], &H->sub[c][i]); } /* root */
+  up_finish(H, c);
   return 0;
 }
 
-static int down_clique(host *H, worker *w, int c) {
+static int down_prepare(host *H, worker *w, int c) {
   const nbp_clique_info *info = H->info;
   const int p = info[c].parent, nf = info[c].nfrontals, ns = info[c].nseparators;
   int nv = nf + ns;
-  int32_t *vars = w->vars, status = 0;
+  int32_t *vars = w->vars;
   memcpy(vars, H->fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, H->se[c], sizeof(int32_t) * ns);
   for (int i = 0; i < ns; i++) { /* the down message: the parent's values of the separators */
     int pi = find(H->fr[p], info[p].nfrontals, H->se[c][i]);
@@ -131,9 +143,69 @@ static int down_clique(host *H, worker *w, int c) {
   nbp_clique_desc q;
   memset(&q, 0, sizeof(q));
   q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = w->mani; q.nfactors = ncf; q.factors = w->cf;
-  CHK(nbp_clique_downsolve(w->ctx, H->sp, &q, H->seed, w->bel, &status));
+  w->q = q;
+  return 0;
+}
+static void down_finish(host *H, int c) {
+  for (int i = 0; i < H->info[c].nfrontals; i++) belief_copy(&H->post[H->fr[c][i]], &H->sub[c][i]);
+}
+static int down_clique(host *H, worker *w, int c) {
+  int32_t status = 0;
+  if (down_prepare(H, w, c)) return 1;
+  CHK(nbp_clique_downsolve(w->ctx, H->sp, &w->q, H->seed, w->bel, &status));
   if (status != NBP_CLIQ_DOWNSOLVED) return 1;
-  for (int i = 0; i < nf; i++) belief_copy(&H->post[vars[i]], &H->sub[c][i]);
+  down_finish(H, c);
+  return 0;
+}
+
+/* the cliques of one tree level in ONE call (nbp_clique_solve_batch): the host still assembles every clique's sub graph and
+ * messages; the library plans them side by side, moves the beliefs in one transfer each way and shares the launches */
+static worker worker_new(int nvars, int nfac) {
+  worker w;
+  memset(&w, 0, sizeof(w));
+  w.vars = malloc(sizeof(int32_t) * nvars); w.mani = malloc(sizeof(int32_t) * nvars);
+  for (int k = 0; k < 4; k++) w.lists[k] = malloc(sizeof(int32_t) * nvars);
+  w.cf = calloc((size_t)nfac + 1, sizeof(*w.cf));
+  w.bel = malloc(sizeof(nbp_tree_belief) * nvars); w.msgb = malloc(sizeof(nbp_tree_belief) * nvars);
+  w.msgv = malloc(sizeof(int32_t) * nvars);
+  for (int v = 0; v < nvars; v++) w.mani[v] = NBP_EUCLID2;
+  return w;
+}
+static void worker_free(worker *w) {
+  free(w->vars); free(w->mani); free(w->cf); free(w->bel); free(w->msgb); free(w->msgv);
+  for (int k = 0; k < 4; k++) free(w->lists[k]);
+}
+static int level_batched(host *H, nbp_ctx *ctx, int d, int down) {
+  int n = 0;
+  for (int c = 1; c <= H->ncl; c++) n += H->depth[c] == d;
+  worker *W = calloc((size_t)n, sizeof(*W));
+  nbp_clique_request *R = calloc((size_t)n, sizeof(*R));
+  int *id = malloc(sizeof(int) * n), k = 0;
+  for (int c = 1; c <= H->ncl; c++) {
+    if (H->depth[c] != d) continue;
+    int ncf = H->info[c].npotentials; /* scratch sized by the clique: its potentials (up), every factor of its frontals (down) */
+    if (down) {
+      ncf = 0;
+      for (int f = 0; f < H->nfac; f++) {
+        int hit = 0;
+        for (int i = 0; i < H->fac[f].nvars; i++) hit |= find(H->fr[c], H->info[c].nfrontals, H->fac[f].vars[i]) >= 0;
+        ncf += hit;
+      }
+    }
+    int nmsg = 0;
+    for (int j = 0; j < H->info[c].nchildren; j++) nmsg += H->info[H->ch[c][j]].nseparators;
+    W[k] = worker_new(H->info[c].nfrontals + H->info[c].nseparators + 2 * ncf + nmsg + 1, ncf);
+    if (down ? down_prepare(H, &W[k], c) : up_prepare(H, &W[k], c)) return 1;
+    R[k].params = H->sp; R[k].clique = &W[k].q; R[k].seed = H->seed; R[k].beliefs = W[k].bel; R[k].down = down;
+    id[k++] = c;
+  }
+  CHK(nbp_clique_solve_batch(ctx, R, n));
+  for (int i = 0; i < n; i++) {
+    if (R[i].status != (down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED)) return 1;
+    if (down) down_finish(H, id[i]); else up_finish(H, id[i]);
+    worker_free(&W[i]);
+  }
+  free(W); free(R); free(id);
   return 0;
 }
 
@@ -141,6 +213,7 @@ int main(int argc, char **argv) {
   const int nvars = argc > 1 ? atoi(argv[1]) : 12;
   N = argc > 2 ? atoi(argv[2]) : 128;
   const int every = argc > 3 ? atoi(argv[3]) : 5;
+  const int batched = argc > 4 && atoi(argv[4]) == 0; /* callers = 0: the cliques of a level in one batched call */
   const int threads = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : 1;
   const uint64_t seed = 2024;
   nbp_solver_params sp;
@@ -226,23 +299,30 @@ int main(int argc, char **argv) {
    * as concurrent tasks, CliqueStateMachine.jl), and contexts share nothing */
   worker *W = calloc((size_t)threads, sizeof(*W));
   for (int t = 0; t < threads; t++) {
+    W[t] = worker_new(nvars, nfac);
     W[t].ctx = t == 0 ? ctx : NULL;
     if (t > 0) CHK(nbp_ctx_create(0, N, 256, NULL, 0, 0, &W[t].ctx));
-    W[t].vars = malloc(sizeof(int32_t) * nvars); W[t].mani = malloc(sizeof(int32_t) * nvars);
-    for (int k = 0; k < 4; k++) W[t].lists[k] = malloc(sizeof(int32_t) * nvars);
-    W[t].cf = calloc((size_t)nfac + 1, sizeof(*W[t].cf));
-    W[t].bel = malloc(sizeof(nbp_tree_belief) * nvars); W[t].msgb = malloc(sizeof(nbp_tree_belief) * nvars);
-    W[t].msgv = malloc(sizeof(int32_t) * nvars);
-    for (int v = 0; v < nvars; v++) W[t].mani[v] = NBP_EUCLID2;
+  }
+  nbp_ctx *bctx = NULL; /* batched mode: a context with room for the widest level */
+  if (batched) {
+    int widest = 0;
+    for (int d = 0; d <= maxdepth; d++) {
+      int cnt = 0;
+      for (int c = 1; c <= ncl; c++) cnt += H.depth[c] == d;
+      if (cnt > widest) widest = cnt;
+    }
+    CHK(nbp_ctx_create(0, N, widest * 40 + 64, NULL, 0, 0, &bctx)); /* generous: nbp_clique_slots(desc) is the exact need of a clique */
   }
   int failed = 0;
   const double tb = now_s();
-  for (int d = maxdepth; d >= 0 && !failed; d--) { /* up pass: children before parents, the cliques of a level side by side */
+  for (int d = maxdepth; d >= 0 && !failed && batched; d--) failed |= level_batched(&H, bctx, d, 0);
+  for (int d = 1; d <= maxdepth && !failed && batched; d++) failed |= level_batched(&H, bctx, d, 1);
+  for (int d = maxdepth; d >= 0 && !failed && !batched; d--) { /* up pass: children before parents, the cliques of a level side by side */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(| : failed)
     for (int c = 1; c <= ncl; c++)
       if (H.depth[c] == d) failed |= up_clique(&H, &W[omp_get_thread_num()], c);
   }
-  for (int d = 1; d <= maxdepth && !failed; d++) { /* down pass: parents before children */
+  for (int d = 1; d <= maxdepth && !failed && !batched; d++) { /* down pass: parents before children */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(| : failed)
     for (int c = 1; c <= ncl; c++)
       if (H.depth[c] == d) failed |= down_clique(&H, &W[omp_get_thread_num()], c);
@@ -260,8 +340,8 @@ int main(int argc, char **argv) {
     if (fabs(mx / N - v) > worst) worst = fabs(mx / N - v);
   }
   printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program; "
-         "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
-         post[0].ipc[0], post[0].ipc[1], worst, threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
+         "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %s%d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
+         post[0].ipc[0], post[0].ipc[1], worst, batched ? "one batched call per tree level, " : "", threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s\n",

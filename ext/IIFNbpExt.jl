@@ -163,6 +163,17 @@ struct NbpCliqueDesc
   diff_kind::Ptr{Int32}
 end
 
+# nbp_clique_request (include/nbp_host.h): one entry of nbp_clique_solve_batch
+struct NbpCliqueRequest
+  params::Ptr{NbpSolverParams}
+  clique::Ptr{NbpCliqueDesc}
+  seed::UInt64
+  beliefs::Ptr{NbpTreeBelief}
+  diff_out::Ptr{NbpTreeBelief}
+  down::Int32
+  status::Int32
+end
+
 # ---- error mapping: status < 0 -> error() -> the clique Task fails -> monitorCSMs puts ERROR_STATUS on every
 #      channel -> solveTree! throws CompositeException (CliqStateMachineUtils.jl:184-246, test/testCSMMonitor.jl:51)
 function chk(rc::Integer)
@@ -451,11 +462,69 @@ function unpack!(dfg::AbstractDFG, p::CliquePack, solveKey::Symbol, N::Int, whic
   return nothing
 end
 
+# ---- gathering the clique calls that are ready (opt-in: IIFNbpExt.BATCH_CLIQUES[] = true) ------------------------------------
+# The state machines run as one task per clique and reach their solve step independently; cliques of one tree level do not
+# depend on each other.  With BATCH_CLIQUES the calls are queued, and a dispatcher task hands everything that is waiting to
+# ONE nbp_clique_solve_batch: one transfer of beliefs each way and shared launches (DESIGN.md 6: 926 ms -> 60 ms per solve
+# of the config-2 graph when whole levels arrive together).  The state machines stay as they are: each waits for its own
+# result.  Same posteriors either way (the random streams are keyed by clique, not by batch).
+const BATCH_CLIQUES = Ref(false)
+struct PendingClique
+  N::Int
+  need::Int
+  sp::Base.RefValue{NbpSolverParams}
+  q::Base.RefValue{NbpCliqueDesc}
+  seed::UInt64
+  p::CliquePack
+  down::Bool
+  done::Channel{Any}   # the status (Int32) or the exception
+end
+const _PENDING = Channel{PendingClique}(Inf)
+const _DISPATCHER = Ref{Union{Nothing, Task}}(nothing)
+
+function dispatchcliques()
+  while true
+    batch = PendingClique[take!(_PENDING)]
+    yield()                                         # the other clique tasks that are ready get to queue up
+    while isready(_PENDING)
+      push!(batch, take!(_PENDING))
+    end
+    for N in unique(b.N for b in batch)             # one context per particle count
+      group = [b for b in batch if b.N == N]
+      try
+        reqs = NbpCliqueRequest[NbpCliqueRequest(Base.unsafe_convert(Ptr{NbpSolverParams}, b.sp), Base.unsafe_convert(Ptr{NbpCliqueDesc}, b.q),
+                                                 b.seed, pointer(b.p.beliefs), C_NULL, b.down ? 1 : 0, 0) for b in group]
+        GC.@preserve group reqs withctx(N, sum(b.need for b in group)) do ctx
+          chk(ccall((:nbp_clique_solve_batch, libnbp), Int32, (Ptr{Cvoid}, Ptr{NbpCliqueRequest}, Int32), ctx.ptr, reqs, length(reqs)))
+        end
+        foreach((b, r) -> put!(b.done, r.status), group, reqs)
+      catch err
+        foreach(b -> put!(b.done, err), group)      # every waiting clique task fails: monitorCSMs takes it from there
+      end
+    end
+  end
+end
+
+function runclique_batched(q::NbpCliqueDesc, sp::NbpSolverParams, N::Int, need::Int, seed::UInt64, p::CliquePack, down::Bool)
+  lock(_POOL_LOCK) do
+    (_DISPATCHER[] === nothing || istaskdone(_DISPATCHER[])) && (_DISPATCHER[] = errormonitor(@async dispatchcliques()))
+  end
+  pc = PendingClique(N, need, Ref(sp), Ref(q), seed, p, down, Channel{Any}(1))
+  put!(_PENDING, pc)
+  r = take!(pc.done)
+  r isa Exception && throw(r)
+  return r::Int32
+end
+
 function runclique(sym::Symbol, dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, p::CliquePack, nfr::Int, nsep::Int, seed::UInt64,
                    iters::Int = getSolverParams(dfg).gibbsIters)
   q = cliquedesc(cliq, p, nfr, nsep)
   sp = solverparams(getSolverParams(dfg), N, iters)
   status = Ref{Int32}(0)
+  if BATCH_CLIQUES[]
+    need = GC.@preserve p chk(ccall((:nbp_clique_slots, libnbp), Int32, (Ref{NbpCliqueDesc},), q))
+    return runclique_batched(q, sp, N, Int(need), seed, p, sym !== :up)
+  end
   GC.@preserve p begin
     need = chk(ccall((:nbp_clique_slots, libnbp), Int32, (Ref{NbpCliqueDesc},), q))
     withctx(N, need) do ctx

@@ -251,6 +251,26 @@ nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *params, c
 nbp_status nbp_clique_upsolve_joint(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,
                                     nbp_tree_belief *beliefs_inout, nbp_tree_belief *diff_out, int32_t *status_out);
 
+/* Several clique calls in ONE: cliques that do not depend on each other -- the cliques of one tree level on the way up or
+ * down, which the reference runs as concurrent tasks (CliqueStateMachine.jl) -- planned side by side in one context, with
+ * one transfer of beliefs each way and one program whose k-th launches serve the k-th round of every clique.  Up and down
+ * requests may be mixed.  Each request is what the single calls take (diff_out: NULL, or clique->n_diff entries as in
+ * nbp_clique_upsolve_joint); `status` is written on success.  The random streams are keyed by (seed, pass, clique_id, step,
+ * factor), so every belief comes out as the single calls deliver it, bit for bit.  The context needs the sum of
+ * nbp_clique_slots over the requests.  This is the entry for a host that keeps the control flow of the state machines but
+ * gathers the cliques that are ready (the per-clique seam is bound by the latency of each clique's own
+ * launches; batched, the cliques of a level share them). */
+typedef struct nbp_clique_request {
+  const nbp_solver_params *params;
+  const nbp_clique_desc *clique;
+  uint64_t seed;
+  nbp_tree_belief *beliefs;  /* in / out, clique->nvars entries */
+  nbp_tree_belief *diff_out; /* NULL or clique->n_diff entries */
+  int32_t down;              /* 0: upGibbsCliqueDensity; 1: solveCliqDownFrontalProducts! */
+  int32_t status;            /* out: NBP_CLIQ_UPSOLVED / NBP_CLIQ_DOWNSOLVED */
+} nbp_clique_request;
+nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *requests, int32_t n);
+
 /* test access: the descriptors of stage s of the last compile (kind = NBP_STAGE_*; bytes copied <= cap) */
 int32_t nbp_tree_num_stages(const nbp_tree *t);
 nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *descs_out, int64_t cap_bytes);

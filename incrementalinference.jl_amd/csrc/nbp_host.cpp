@@ -1702,11 +1702,31 @@ static size_t clique_maxf(const nbp_clique_desc *q) {
 // measurement dimension of a relative factor kind on a variable's manifold
 static int clique_zdim(int kind, int manifold) { return kind == NBP_F_LINREL ? mani_dim(manifold) : (kind == NBP_F_SE2 ? 3 : 1); }
 
-static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
-                               nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
+// One clique call, planned: the beliefs to move in, the rounds of (proposals, products), the differential stage, the
+// beliefs to move out -- with every slot number shifted by `off`, so that several cliques can share one context, one
+// transfer each way and one program whose stage pair r holds round r of every clique (nbp_clique_solve_batch).
+struct clique_io { int32_t slot, mani; const nbp_tree_belief *src; nbp_tree_belief *dst; bool with_ipc; };
+struct clique_plan {
+  int nslots = 0;  // slots this clique occupies, from `off`
+  std::vector<clique_io> in, out;
+  std::vector<std::pair<std::vector<nbp_proposal_desc>, std::vector<nbp_product_desc>>> rounds;
+  std::vector<nbp_proposal_desc> deconv;
+};
+static void shift_slots(nbp_proposal_desc &d, int off) {
+  for (int i = 0; i < NBP_MAXV; i++) d.var_slot[i] += off;  // (entries beyond nvars are never read)
+  d.out_slot += off;
+  if (d.meas_kde > 0) d.meas_kde += off;
+}
+static void shift_slots(nbp_product_desc &d, int off) {
+  for (int i = 0; i < d.nfactors; i++) d.in_slot[i] += off;
+  d.out_slot += off;
+  if (d.old_slot >= 0) d.old_slot += off;
+}
+static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed, nbp_tree_belief *bel, bool down,
+                                    nbp_tree_belief *diff_out, int off, clique_plan &P) {
   nbp_status rc = clique_check(sp, q);
   if (rc) return rc;
-  if (!ctx || !bel) return hfail(NBP_ERR_ARG, "null argument");
+  if (!bel) return hfail(NBP_ERR_ARG, "null argument");
   if (!down && q->n_diff > 0 && !diff_out) return hfail(NBP_ERR_ARG, "clique: differential factors are asked for, diff_out is null (nbp_clique_upsolve_joint)");
   // a throw-away graph object carries the solver parameters and the variables for fill_proposal
   nbp_graph g;
@@ -1781,13 +1801,9 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
     for (int k = 0; k < NBP_DOWN_MCITERS; k++)
       for (int v : itf) { sched.push_back(v); iter.push_back(k + 1); }
   }
-  // ---- beliefs in: one batched transfer (the slots are consecutive: one copy) -------------------------------------
+  // ---- beliefs in --------------------------------------------------------------------------------------------------
   {
-    std::vector<int32_t> bs, bm, bn;
-    std::vector<const double *> bp, bb, bi;
-    auto put = [&](int slot, int mani, const nbp_tree_belief &m, bool with_ipc) {
-      bs.push_back(slot); bm.push_back(mani); bn.push_back(m.n_pts); bp.push_back(m.pts); bb.push_back(m.bw); bi.push_back(with_ipc ? m.ipc : nullptr);
-    };
+    auto put = [&](int slot, int mani, const nbp_tree_belief &m, bool with_ipc) { P.in.push_back({off + slot, mani, &m, nullptr, with_ipc}); };
     for (int v = 0; v < q->nvars; v++) {
       if (!bel[v].pts) return hfail(NBP_ERR_ARG, "clique: null belief");
       put(v, q->manifold[v], bel[v], true);
@@ -1801,16 +1817,8 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
       if (facs[f].dens >= 0) put(dens0 + facs[f].dens, q->manifold[facs[f].s.vars[0]], q->factor_density[f], true);
     for (int f = 0; f < q->nfactors; f++)  // LinearRelative(::MKD) & co.: the measurement is the child's KDE, in measurement coordinates
       if (kde_of[f] >= 0) put(kde0 + kde_of[f], clique_zdim(q->factors[f].factor_kind, q->manifold[q->factors[f].vars[0]]) /* Euclid(zd) */, q->factor_meas_kde[f], false);
-    rc = nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
-    if (rc) return rc;
   }
-  // ---- the schedule as a resident program ------------------------------------------------------------------
-  nbp_program *p = nullptr;
-  rc = nbp_program_create(ctx, &p);
-  if (rc) return rc;
-  struct prog_guard { nbp_program *p; ~prog_guard() { nbp_program_destroy(p); } } guard{p};
-  rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
-  if (rc) return rc;
+  // ---- the schedule -------------------------------------------------------------------------------------------------
   const bool stored = (sp->flags & NBP_SOLVER_STORED_MEASUREMENTS) != 0;
   std::map<std::pair<int, int>, uint64_t> meas_seed;  // (0 = factor | 1 = message, index) -> seed of its last fresh draw
   const int passid = down ? PASS_DOWN : PASS_UP;
@@ -1886,10 +1894,13 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
       updated[v] = 1;
     }
     if (prods.empty()) continue;
-    rc = nbp_program_add_stage(p, NBP_STAGE_PROPOSALS, props.data(), (int)props.size());
-    if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, prods.data(), (int)prods.size());
-    if (rc) return rc;
+    for (nbp_proposal_desc &d : props) shift_slots(d, off);
+    for (nbp_product_desc &d : prods) shift_slots(d, off);
+    P.rounds.emplace_back(std::move(props), std::move(prods));
   }
+  int lanes = 1;
+  for (const std::vector<int> &round : rounds) lanes = std::max(lanes, (int)round.size());
+  P.nslots = base + lanes * maxf;
   if (ndiff > 0) {
     // prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD! (TreeMessageUtils.jl:279-335): approxDeconv between the solved
     // beliefs of every pair, searched from samples of the default-constructed factor, manikde! of the result -- the same
@@ -1910,34 +1921,102 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
       fill_proposal(&g, d, &dflt, -1, q->diff_b[i], nullptr, nullptr, nullptr, diff0 + i, op_seed(seed, PASS_UP, q->clique_id, 0x4000 + i, 0), 0.0);
       props.push_back(d);
     }
+    for (nbp_proposal_desc &d : props) shift_slots(d, off);
+    P.deconv = std::move(props);
+  }
+  // ---- beliefs out: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the schedule touched, then
+  // the differential KDEs (points in measurement coordinates + fitted bandwidth)
+  for (int v = 0; v < q->nvars; v++)
+    if (updated[v]) P.out.push_back({off + v, q->manifold[v], nullptr, &bel[v], true});
+  for (int i = 0; i < ndiff; i++) {
+    if (!diff_out[i].pts || !diff_out[i].bw) return hfail(NBP_ERR_ARG, "clique: diff_out entries need pts and bw");
+    P.out.push_back({off + diff0 + i, clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]), nullptr, &diff_out[i], false});
+  }
+  return NBP_OK;
+}
+
+// the plans of one or several cliques on one context: one transfer in, one program (stage pair r = round r of every
+// clique; the differential stages of all of them behind the last round), one transfer out
+static nbp_status clique_plans_run(nbp_ctx *ctx, const std::vector<clique_plan> &plans) {
+  std::vector<int32_t> bs, bm, bn;
+  std::vector<const double *> bp, bb, bi;
+  for (const clique_plan &P : plans)
+    for (const clique_io &e : P.in) {
+      bs.push_back(e.slot); bm.push_back(e.mani); bn.push_back(e.src->n_pts); bp.push_back(e.src->pts); bb.push_back(e.src->bw);
+      bi.push_back(e.with_ipc ? e.src->ipc : nullptr);
+    }
+  nbp_status rc = nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
+  if (rc) return rc;
+  nbp_program *p = nullptr;
+  rc = nbp_program_create(ctx, &p);
+  if (rc) return rc;
+  struct prog_guard { nbp_program *p; ~prog_guard() { nbp_program_destroy(p); } } guard{p};
+  rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
+  if (rc) return rc;
+  size_t nr = 0;
+  for (const clique_plan &P : plans) nr = std::max(nr, P.rounds.size());
+  std::vector<nbp_proposal_desc> props;
+  std::vector<nbp_product_desc> prods;
+  for (size_t r = 0; r < nr; r++) {
+    props.clear(); prods.clear();
+    for (const clique_plan &P : plans)
+      if (r < P.rounds.size()) {
+        props.insert(props.end(), P.rounds[r].first.begin(), P.rounds[r].first.end());
+        prods.insert(prods.end(), P.rounds[r].second.begin(), P.rounds[r].second.end());
+      }
+    rc = nbp_program_add_stage(p, NBP_STAGE_PROPOSALS, props.data(), (int)props.size());
+    if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, prods.data(), (int)prods.size());
+    if (rc) return rc;
+  }
+  props.clear();
+  for (const clique_plan &P : plans) props.insert(props.end(), P.deconv.begin(), P.deconv.end());
+  if (!props.empty()) {
     rc = nbp_program_add_stage(p, NBP_STAGE_DECONV, props.data(), (int)props.size());
     if (rc) return rc;
   }
   rc = nbp_program_finalize(p);
   if (!rc) rc = nbp_program_run(p, 0, -1);
-  if (!rc) rc = nbp_synchronize(ctx);
   if (rc) return rc;
-  // ---- beliefs out, one batched transfer: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the
-  // schedule touched, then the differential KDEs (points in measurement coordinates + fitted bandwidth)
-  {
-    std::vector<int32_t> bs, bm, bn;
-    std::vector<double *> bp, bb, bi;
-    std::vector<int32_t *> cnt;
-    for (int v = 0; v < q->nvars; v++) {
-      if (!updated[v]) continue;
-      bs.push_back(v); bm.push_back(q->manifold[v]); bp.push_back(bel[v].pts); bb.push_back(bel[v].bw); bi.push_back(bel[v].ipc); cnt.push_back(&bel[v].n_pts);
+  std::vector<int32_t> os, om, on;
+  std::vector<double *> op, ob, oi;
+  std::vector<nbp_tree_belief *> dst;
+  for (const clique_plan &P : plans)
+    for (const clique_io &e : P.out) {
+      os.push_back(e.slot); om.push_back(e.mani); op.push_back(e.dst->pts); ob.push_back(e.dst->bw); oi.push_back(e.with_ipc ? e.dst->ipc : nullptr);
+      dst.push_back(e.dst);
     }
-    for (int i = 0; i < ndiff; i++) {
-      if (!diff_out[i].pts || !diff_out[i].bw) return hfail(NBP_ERR_ARG, "clique: diff_out entries need pts and bw");
-      bs.push_back(diff0 + i); bm.push_back(clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]));
-      bp.push_back(diff_out[i].pts); bb.push_back(diff_out[i].bw); bi.push_back(nullptr); cnt.push_back(&diff_out[i].n_pts);
-    }
-    bn.resize(bs.size());
-    rc = nbp_belief_read_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
-    if (rc) return rc;
-    for (size_t i = 0; i < bs.size(); i++) *cnt[i] = bn[i];
-  }
+  on.resize(os.size());
+  rc = nbp_belief_read_batch(ctx, (int32_t)os.size(), os.data(), om.data(), op.data(), on.data(), ob.data(), oi.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < dst.size(); i++) dst[i]->n_pts = on[i];
+  return NBP_OK;
+}
+
+static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
+                               nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
+  if (!ctx) return hfail(NBP_ERR_ARG, "null argument");
+  std::vector<clique_plan> plans(1);
+  nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, 0, plans[0]);
+  if (!rc) rc = clique_plans_run(ctx, plans);
+  if (rc) return rc;
   if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
+  return NBP_OK;
+}
+
+nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t n) {
+  if (!ctx || (n > 0 && !req)) return hfail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  std::vector<clique_plan> plans((size_t)n);
+  int off = 0;
+  for (int i = 0; i < n; i++) {
+    if (!req[i].params || !req[i].clique) return hfail(NBP_ERR_ARG, "clique batch: null params / clique");
+    nbp_status rc = clique_plan_build(req[i].params, req[i].clique, req[i].seed, req[i].beliefs, req[i].down != 0, req[i].diff_out, off, plans[(size_t)i]);
+    if (rc) return rc;
+    off += plans[(size_t)i].nslots;
+  }
+  nbp_status rc = clique_plans_run(ctx, plans);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) req[i].status = req[i].down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
   return NBP_OK;
 }
 

@@ -61,7 +61,7 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_graph_order_nested_dissection", "nbp_graph_init_plan", "nbp_graph_init_num_variables", "nbp_graph_init_variables",
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
-                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_upsolve_joint", "nbp_clique_downsolve",
+                "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_upsolve_joint", "nbp_clique_downsolve", "nbp_clique_solve_batch",
                 "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment",
                 "nbp_tree_run_sharded", "nbp_tree_run_sharded_cb",
                 "nbp_graph_num_densities", "nbp_graph_density_factors", "nbp_graph_init_density_slot0", "nbp_tree_density_slot0"]
@@ -116,6 +116,7 @@ def _lib():
             fn.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC), ip]
         lib.nbp_clique_upsolve_joint.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC),
                                                  C.POINTER(TreeBeliefC), ip]
+        lib.nbp_clique_solve_batch.argtypes = [vp, C.POINTER(CliqueRequestC), i32]
         for n in HOST_EXPORTS:
             getattr(lib, n).restype = i32
         _declared = True
@@ -208,8 +209,12 @@ class Belief:
         self.pts = self._buf[:cview.n_pts]
 
 
-def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, manifolds, factors, beliefs, seed, down=False,
-                 ismargin=None, lists=None, msgs=(), meas_kdes=None, diffs=()):
+class _CliqueCall:
+    """one prepared clique call: the C structures (kept alive here) and where the results go"""
+
+
+def _clique_prepare(backend, sp, clique_id, variables, nfrontals, nseparators, manifolds, factors, beliefs, seed, down=False,
+                    ismargin=None, lists=None, msgs=(), meas_kdes=None, diffs=()):
     """nbp_clique_upsolve / nbp_clique_downsolve (include/nbp_host.h) -- the per-clique seam of the CliqueStateMachine:
     upGibbsCliqueDensity (SolveTree.jl:164-239) / solveCliqDownFrontalProducts! (CliqStateMachineUtils.jl:479-571).
 
@@ -264,23 +269,64 @@ def clique_solve(backend, sp, clique_id, variables, nfrontals, nseparators, mani
         for a, _, k in diffs:
             zd = abi.MANIFOLD_DIM[manifolds[idx[a]]] if k == abi.F_LINREL else (3 if k == abi.F_SE2 else 1)
             diff_out.append(Belief(zd, np.zeros((sp.N, zd)), np.zeros(zd)))  # Euclid(zd): the manifold code is the dimension
-    need = _check(lib.nbp_clique_slots(C.byref(q)))
-    if need > backend.n_slots:
-        raise ValueError(f"the context has {backend.n_slots} slots, this clique needs {need}")
-    bel = (TreeBeliefC * len(variables))(*[beliefs[v].c(capacity=sp.N) for v in variables])
+    k = _CliqueCall()
+    k.need = _check(lib.nbp_clique_slots(C.byref(q)))
+    k.q, k.keep, k.variables, k.beliefs, k.seed, k.down = q, keep, variables, beliefs, seed, bool(down)
+    k.bel = (TreeBeliefC * len(variables))(*[beliefs[v].c(capacity=sp.N) for v in variables])
+    k.p = solver_params_c(sp)
+    k.joint = bool(diffs) and not down
+    k.diff_out = diff_out
+    k.dout = (TreeBeliefC * len(diffs))(*[b.c() for b in diff_out]) if k.joint else None
+    return k
+
+
+def _clique_finish(k, status):
+    if k.joint:
+        for i, b in enumerate(k.diff_out):
+            b.take(k.dout[i])
+    for i, v in enumerate(k.variables):
+        k.beliefs[v].take(k.bel[i])
+    return (status, k.diff_out) if k.joint else status
+
+
+def clique_solve(backend, *args, **kwargs):
+    """one clique call; arguments and return value: see _clique_prepare"""
+    lib = _lib()
+    k = _clique_prepare(backend, *args, **kwargs)
+    if k.need > backend.n_slots:
+        raise ValueError(f"the context has {backend.n_slots} slots, this clique needs {k.need}")
     status = i32(0)
-    p = solver_params_c(sp)
-    if diffs and not down:
-        dout = (TreeBeliefC * len(diffs))(*[b.c() for b in diff_out])
-        _check(lib.nbp_clique_upsolve_joint(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, dout, C.byref(status)))
-        for i, b in enumerate(diff_out):
-            b.take(dout[i])
+    if k.joint:
+        _check(lib.nbp_clique_upsolve_joint(backend._ctx, C.byref(k.p), C.byref(k.q), C.c_uint64(k.seed), k.bel, k.dout, C.byref(status)))
     else:
-        fn = lib.nbp_clique_downsolve if down else lib.nbp_clique_upsolve
-        _check(fn(backend._ctx, C.byref(p), C.byref(q), C.c_uint64(seed), bel, C.byref(status)))
-    for i, v in enumerate(variables):
-        beliefs[v].take(bel[i])
-    return (status.value, diff_out) if diffs and not down else status.value
+        fn = lib.nbp_clique_downsolve if k.down else lib.nbp_clique_upsolve
+        _check(fn(backend._ctx, C.byref(k.p), C.byref(k.q), C.c_uint64(k.seed), k.bel, C.byref(status)))
+    return _clique_finish(k, status.value)
+
+
+class CliqueRequestC(C.Structure):
+    """nbp_clique_request (include/nbp_host.h)"""
+    _fields_ = [("params", C.POINTER(SolverParamsC)), ("clique", C.POINTER(CliqueDescC)), ("seed", C.c_uint64),
+                ("beliefs", C.POINTER(TreeBeliefC)), ("diff_out", C.POINTER(TreeBeliefC)), ("down", i32), ("status", i32)]
+
+
+def clique_solve_batch(backend, calls):
+    """nbp_clique_solve_batch: cliques that do not depend on each other (a tree level) in ONE call.  calls = [(args, kwargs)]
+    of clique_solve without the backend; -> the list of what clique_solve returns for each."""
+    lib = _lib()
+    ks = [_clique_prepare(backend, *a, **kw) for a, kw in calls]
+    need = sum(k.need for k in ks)
+    if need > backend.n_slots:
+        raise ValueError(f"the context has {backend.n_slots} slots, these cliques need {need}")
+    req = (CliqueRequestC * max(1, len(ks)))()
+    for r, k in zip(req, ks):
+        r.params, r.clique, r.seed, r.beliefs, r.down = C.pointer(k.p), C.pointer(k.q), k.seed, k.bel, int(k.down)
+        if k.joint:
+            r.diff_out = k.dout
+    _check(lib.nbp_clique_solve_batch(backend._ctx, req, len(ks)))
+    return [_clique_finish(k, r.status) for r, k in zip(req, ks)]
+
+
 
 
 class NativeGraph:

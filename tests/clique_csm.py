@@ -5,7 +5,7 @@ per-clique C entry points nbp_clique_upsolve / nbp_clique_downsolve.  Message as
 values down, frontals back to the graph) is done here in numpy, as the Julia CSM does it in Julia."""
 from parity_utils import iif
 
-from iif_amd.native_host import Belief, clique_solve
+from iif_amd.native_host import Belief, clique_solve, clique_solve_batch
 
 
 def solve_tree_by_clique_calls(fg, tree, backend, seed):
@@ -131,4 +131,67 @@ def solve_tree_by_clique_calls_joint(fg, tree, backend, seed):
                                    sub[cid], seed, down=True, ismargin=[marg[v] for v in labels], meas_kdes=kdes)
         for v in cl.frontalIDs:
             post[v] = sub[cid][v]
+    return post, status
+
+
+def solve_tree_by_level_batches(fg, tree, backend, seed):
+    """the walk of solve_tree_by_clique_calls with the cliques of one tree level in ONE nbp_clique_solve_batch call (they do
+    not depend on each other: the reference runs them as concurrent tasks).  Message assembly stays here, on the host.
+    -> ({label: Belief}, {clique: status})"""
+    sp = fg.solverParams
+    man = {v: fg.getVariable(v).varType.manifold for v in fg.ls()}
+    marg = {v: fg.getVariable(v).ismargin for v in fg.ls()}
+    main = {v: Belief(man[v], fg.getVariable(v).val, fg.getVariable(v).bw) for v in fg.ls()}
+    depths = tree.depths()
+    levels = sorted(set(depths.values()))
+    sub, status, post = {}, {}, {}
+    for d in reversed(levels):  # up pass: the deepest level first
+        ids = sorted(c for c in tree.cliques if depths[c] == d)
+        calls = []
+        for cid in ids:
+            cl = tree.cliques[cid]
+            labels = list(cl.frontalIDs) + list(cl.separatorIDs)
+            sub[cid] = {v: main[v].copy() for v in labels}
+            msgs = [(v, sub[ch][v]) for ch in cl.children for v in tree.cliques[ch].separatorIDs]
+            lists = {"directFrtlMsg": cl.directFrtlMsgIDs, "msgskip": cl.msgskipIDs, "itervar": cl.itervarIDs,
+                     "directPriorMsg": cl.directPriorMsgIDs}
+            calls.append(((sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels],
+                           [fg.getFactor(f) for f in cl.potentials], sub[cid], seed),
+                          dict(down=False, ismargin=[marg[v] for v in labels], lists=lists, msgs=msgs)))
+        for cid, st in zip(ids, clique_solve_batch(backend, calls)):
+            status[cid] = st
+    for r in tree.roots:
+        for v in tree.cliques[r].frontalIDs:
+            main[v] = sub[r][v].copy()
+            post[v] = main[v]
+    for d in levels:  # down pass: parents before children
+        ids = sorted(c for c in tree.cliques if depths[c] == d and tree.cliques[c].parent >= 0)
+        calls = []
+        for cid in ids:
+            cl = tree.cliques[cid]
+            for s in cl.separatorIDs:
+                sub[cid][s].pts[:] = sub[cl.parent][s].pts
+            factors = []
+            for v in cl.frontalIDs:
+                for f in fg.ls(v):
+                    if f not in factors:
+                        factors.append(f)
+            inclq = list(cl.frontalIDs) + list(cl.separatorIDs)
+            others = []
+            for f in factors:
+                for u in fg.getFactor(f).variables:
+                    if u not in inclq and u not in others:
+                        others.append(u)
+            labels = inclq + others
+            bel = {v: (sub[cid][v] if v in sub[cid] else main[v].copy()) for v in labels}
+            sub[cid] = bel
+            order = [f for f in fg.lsf() if f in factors]
+            calls.append(((sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels],
+                           [fg.getFactor(f) for f in order], bel, seed), dict(down=True, ismargin=[marg[v] for v in labels])))
+        if not calls:
+            continue
+        for cid, st in zip(ids, clique_solve_batch(backend, calls)):
+            status[cid] = st
+            for v in tree.cliques[cid].frontalIDs:
+                post[v] = sub[cid][v]
     return post, status

@@ -5,7 +5,7 @@ launch geometries coincide (trees with fewer than 16 concurrent updates), to rou
 import numpy as np
 import pytest
 
-from clique_csm import solve_tree_by_clique_calls, solve_tree_by_clique_calls_joint
+from clique_csm import solve_tree_by_clique_calls, solve_tree_by_clique_calls_joint, solve_tree_by_level_batches
 from parity_utils import abi, assert_points_close, iif
 
 pytestmark = pytest.mark.gpu
@@ -58,6 +58,30 @@ def test_clique_calls_equal_whole_tree_program(hip_backend, name):
     # atan2 is not a bitwise round trip, so the clique-by-clique solve agrees to rounding (1e-9 above) there
     if name != "se2_lattice":
         assert nbit == len(fa.ls()), f"{nbit} of {len(fa.ls())} variables bit-identical"
+
+
+@pytest.mark.parametrize("name", list(_graphs()) + ["euclid2_chain_60"])
+def test_level_batches_equal_single_clique_calls(hip_backend, name):
+    """nbp_clique_solve_batch: the cliques of a tree level in one call -- one transfer each way, one program -- deliver what
+    one call per clique delivers.  Same ops, same seeds; only the size of the launches differs."""
+    build = _graphs().get(name) or (lambda: iif.generateChainEuclid(60, vardims=2, priorEvery=10, N=100))
+    fa = build()
+    iif.initAll(fa, backend=hip_backend, seed=0)
+    tree = iif.buildTreeReset(fa, iif.nestedDissectionOrder(fa))
+    be = hip_backend(fa.solverParams.N, 1024)
+    try:
+        one, st1 = solve_tree_by_clique_calls(fa, tree, be, 55)
+        many, st2 = solve_tree_by_level_batches(fa, tree, be, 55)
+    finally:
+        be.close()
+    assert st1 == st2 and set(one) == set(many) == set(fa.ls())
+    for v in fa.ls():
+        man = fa.getVariable(v).varType.manifold
+        assert_points_close(man, one[v].pts, many[v].pts, rtol=1e-9, what=f"{name}:{v}")
+        np.testing.assert_allclose(one[v].bw, many[v].bw, rtol=1e-9)
+        np.testing.assert_array_equal(one[v].ipc, many[v].ipc)
+        if name != "se2_lattice":
+            np.testing.assert_array_equal(one[v].pts, many[v].pts)
 
 
 @pytest.mark.parametrize("name", ["euclid2_chain", "kaess", "circular_chain"])

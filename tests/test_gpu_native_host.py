@@ -80,6 +80,10 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
     out = subprocess.run([exe, "60", "100", "10", "4"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "60 of 60 posteriors byte-identical" in out.stdout and "4 concurrent caller(s)" in out.stdout, out.stdout
+    # the cliques of a tree level in one nbp_clique_solve_batch call
+    out = subprocess.run([exe, "60", "100", "10", "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "60 of 60 posteriors byte-identical" in out.stdout and "one batched call per tree level" in out.stdout, out.stdout
 
 
 def test_native_graph_init_equals_python_init_all(hip_backend):

@@ -12,7 +12,7 @@ SHIM = os.path.join(ROOT, "ext", "IIFNbpExt.jl")
 
 C_NAME = {"NbpProposalDesc": "nbp_proposal_desc", "NbpProductDesc": "nbp_product_desc", "NbpCopyDesc": "nbp_copy_desc",
           "NbpDiag": "nbp_diag", "NbpSolverParams": "nbp_solver_params", "NbpFactorSpec": "nbp_factor_spec",
-          "NbpTreeBelief": "nbp_tree_belief", "NbpCliqueDesc": "nbp_clique_desc"}
+          "NbpTreeBelief": "nbp_tree_belief", "NbpCliqueDesc": "nbp_clique_desc", "NbpCliqueRequest": "nbp_clique_request"}
 PRIM = {"Int32": 4, "UInt32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "UInt8": 1, "Int8": 1}
 
 
