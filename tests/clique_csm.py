@@ -64,12 +64,13 @@ def solve_tree_by_clique_calls(fg, tree, backend, seed):
     return post, status
 
 
-def solve_tree_by_clique_calls_joint(fg, tree, backend, seed):
+def solve_tree_by_clique_calls_joint(fg, tree, backend, seed, batched=False):
     """the same walk with joint upward messages (SolverParams.useMsgLikelihoods): the symbolic half -- which differential
     factors and common priors a clique sends up, which of them its parent keeps (addLikelihoodsDifferentialCHILD!,
     addMsgFactors!; iif_amd.jointmsg) -- is done here, as the Julia CSM does it; the numeric half goes through
     nbp_clique_upsolve_joint (approxDeconv + manikde! of every differential pair on the way up) and the measurement KDEs
-    of nbp_clique_desc.factor_meas_kde (on the way in).  -> ({label: Belief}, {clique: status})"""
+    of nbp_clique_desc.factor_meas_kde (on the way in).  batched: the cliques of a tree level in one
+    nbp_clique_solve_batch call (diff_out of every request).  -> ({label: Belief}, {clique: status})"""
     from iif_amd import jointmsg
     from iif_amd.factorgraph import DFGFactor, DifferentialRelative
     sp = fg.solverParams
@@ -94,43 +95,55 @@ def solve_tree_by_clique_calls_joint(fg, tree, backend, seed):
                 msgs.append((f.ref[1], sub[f.ref[0]][f.ref[1]]))
         return facs, kdes, msgs
 
-    for cid in tree.postorder():
-        cl = tree.cliques[cid]
-        labels = list(cl.frontalIDs) + list(cl.separatorIDs)
-        bel = {v: main[v].copy() for v in labels}
-        facs, kdes, msgs = subgraph(cid)
-        lists = {"directFrtlMsg": cl.directFrtlMsgIDs, "msgskip": cl.msgskipIDs, "itervar": cl.itervarIDs,
-                 "directPriorMsg": cl.directPriorMsgIDs}
-        diffs = [(a, b, kind) for (a, b, _, kind) in plan[cid].relatives] if cl.parent >= 0 else []
-        r = clique_solve(backend, sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels], facs, bel, seed,
-                         down=False, ismargin=[marg[v] for v in labels], lists=lists, msgs=msgs, meas_kdes=kdes, diffs=diffs)
-        if diffs:
-            status[cid], out = r
-            for i, b in enumerate(out):
-                dkde[(cid, i)] = b
-        else:
-            status[cid] = r
-        sub[cid] = bel
+    def run(calls):
+        return clique_solve_batch(backend, calls) if batched else [clique_solve(backend, *a, **kw) for a, kw in calls]
+
+    depths = tree.depths()
+    levels = sorted(set(depths.values()))
+    for d in reversed(levels):
+        ids = sorted(c for c in tree.cliques if depths[c] == d)
+        calls = []
+        for cid in ids:
+            cl = tree.cliques[cid]
+            labels = list(cl.frontalIDs) + list(cl.separatorIDs)
+            sub[cid] = {v: main[v].copy() for v in labels}
+            facs, kdes, msgs = subgraph(cid)
+            lists = {"directFrtlMsg": cl.directFrtlMsgIDs, "msgskip": cl.msgskipIDs, "itervar": cl.itervarIDs,
+                     "directPriorMsg": cl.directPriorMsgIDs}
+            diffs = [(a, b, kind) for (a, b, _, kind) in plan[cid].relatives] if cl.parent >= 0 else []
+            calls.append(((sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels], facs, sub[cid], seed),
+                          dict(down=False, ismargin=[marg[v] for v in labels], lists=lists, msgs=msgs, meas_kdes=kdes, diffs=diffs)))
+        for cid, r in zip(ids, run(calls)):
+            if isinstance(r, tuple):
+                status[cid], out = r
+                for i, b in enumerate(out):
+                    dkde[(cid, i)] = b
+            else:
+                status[cid] = r
     post = {}
     for r in tree.roots:
         for v in tree.cliques[r].frontalIDs:
             main[v] = sub[r][v].copy()
             post[v] = main[v]
-    depths = tree.depths()
-    for cid in sorted(tree.cliques, key=lambda c: (depths[c], c)):
-        cl = tree.cliques[cid]
-        if cl.parent < 0:
+    for d in levels:
+        ids = sorted(c for c in tree.cliques if depths[c] == d and tree.cliques[c].parent >= 0)
+        calls = []
+        for cid in ids:
+            cl = tree.cliques[cid]
+            for s in cl.separatorIDs:
+                sub[cid][s].pts[:] = sub[cl.parent][s].pts
+            # no addDownVariableFactors! in this mode: the down solve works on the clique sub graph as the up solve left it,
+            # minus the common priors (CliqueStateMachine.jl:558)
+            facs, kdes, _ = subgraph(cid)
+            labels = list(cl.frontalIDs) + list(cl.separatorIDs)
+            calls.append(((sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels], facs, sub[cid], seed),
+                          dict(down=True, ismargin=[marg[v] for v in labels], meas_kdes=kdes)))
+        if not calls:
             continue
-        for s in cl.separatorIDs:
-            sub[cid][s].pts[:] = sub[cl.parent][s].pts
-        # no addDownVariableFactors! in this mode: the down solve works on the clique sub graph as the up solve left it,
-        # minus the common priors (CliqueStateMachine.jl:558)
-        facs, kdes, _ = subgraph(cid)
-        labels = list(cl.frontalIDs) + list(cl.separatorIDs)
-        status[cid] = clique_solve(backend, sp, cid, labels, len(cl.frontalIDs), len(cl.separatorIDs), [man[v] for v in labels], facs,
-                                   sub[cid], seed, down=True, ismargin=[marg[v] for v in labels], meas_kdes=kdes)
-        for v in cl.frontalIDs:
-            post[v] = sub[cid][v]
+        for cid, st in zip(ids, run(calls)):
+            status[cid] = st
+            for v in tree.cliques[cid].frontalIDs:
+                post[v] = sub[cid][v]
     return post, status
 
 

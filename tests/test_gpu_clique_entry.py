@@ -100,12 +100,17 @@ def test_joint_messages_through_the_clique_entry(hip_backend, name):
     order = iif.nestedDissectionOrder(fa)
     tree = iif.buildTreeReset(fa, order)
     iif.solveTree(fa, tree=iif.buildTreeReset(fa, order), backend=hip_backend, seed=91)
-    be = hip_backend(fb.solverParams.N, 96)
+    be = hip_backend(fb.solverParams.N, 512)
     try:
         post, status = solve_tree_by_clique_calls_joint(fb, tree, be, 91)
+        # ... and with the cliques of a level in one nbp_clique_solve_batch call (diff_out of every request)
+        post2, status2 = solve_tree_by_clique_calls_joint(fb, tree, be, 91, batched=True)
     finally:
         be.close()
-    assert set(post) == set(fb.ls())
+    assert set(post) == set(fb.ls()) and status2 == status
+    for v in fb.ls():
+        np.testing.assert_array_equal(post[v].pts, post2[v].pts, err_msg=f"batched {name}:{v}")
+        np.testing.assert_array_equal(post[v].bw, post2[v].bw)
     from iif_amd import jointmsg
     ndiff = sum(len(j.relatives) for j in jointmsg.plan_joint_messages(fb, tree).values())
     assert ndiff > 0 or name == "kaess"  # differentials did travel (the Kaess graph's tree sends common priors only)
