@@ -314,6 +314,13 @@ int main(int argc, char **argv) {
     CHK(nbp_ctx_create(0, N, widest * 40 + 64, NULL, 0, 0, &bctx)); /* generous: nbp_clique_slots(desc) is the exact need of a clique */
   }
   int failed = 0;
+  double t_calls = 0;
+  belief *graph0 = malloc(sizeof(belief) * nvars); /* the walk writes the roots' frontals back to the graph: keep the start */
+  for (int v = 0; v < nvars; v++) { graph0[v] = belief_new(); belief_copy(&graph0[v], &graph[v]); }
+  double t_first = 0;
+  for (int pass = 0; pass < 2 && !failed; pass++) { /* the second walk runs with every buffer of the library at its final size */
+  for (int v = 0; v < nvars; v++) belief_copy(&graph[v], &graph0[v]);
+  for (int c = 1; c <= ncl && pass; c++) { for (int i = 0; i < H.info[c].nfrontals + H.info[c].nseparators; i++) free(H.sub[c][i].pts); free(H.sub[c]); }
   const double tb = now_s();
   for (int d = maxdepth; d >= 0 && !failed && batched; d--) failed |= level_batched(&H, bctx, d, 0);
   for (int d = 1; d <= maxdepth && !failed && batched; d++) failed |= level_batched(&H, bctx, d, 1);
@@ -327,8 +334,9 @@ int main(int argc, char **argv) {
     for (int c = 1; c <= ncl; c++)
       if (H.depth[c] == d) failed |= down_clique(&H, &W[omp_get_thread_num()], c);
   }
+  if (!pass) t_first = now_s() - tb; else t_calls = now_s() - tb;
+  }
   if (failed) return 4;
-  const double t_calls = now_s() - tb;
   for (int t = 1; t < threads; t++) nbp_ctx_destroy(W[t].ctx);
   /* ---- compare -------------------------------------------------------------------------------------------------- */
   int same = 0;
@@ -344,8 +352,9 @@ int main(int argc, char **argv) {
          post[0].ipc[0], post[0].ipc[1], worst, batched ? "one batched call per tree level, " : "", threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
-         "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s\n",
-         t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls);
+         "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "
+         "(the second walk; the first, while the library's buffers grow: %.1f ms)\n",
+         t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls, t_first * 1e3);
   nbp_ctx_destroy(ctx);
   nbp_tree_destroy(tree);
   nbp_graph_destroy(g);

@@ -465,7 +465,7 @@ end
 # ---- gathering the clique calls that are ready (opt-in: IIFNbpExt.BATCH_CLIQUES[] = true) ------------------------------------
 # The state machines run as one task per clique and reach their solve step independently; cliques of one tree level do not
 # depend on each other.  With BATCH_CLIQUES the calls are queued, and a dispatcher task hands everything that is waiting to
-# ONE nbp_clique_solve_batch: one transfer of beliefs each way and shared launches (DESIGN.md 6: 926 ms -> 60 ms per solve
+# ONE nbp_clique_solve_batch: one transfer of beliefs each way and shared launches (DESIGN.md 6: 926 ms -> 41 ms per solve
 # of the config-2 graph when whole levels arrive together).  The state machines stay as they are: each waits for its own
 # result.  Same posteriors either way (the random streams are keyed by clique, not by batch).
 const BATCH_CLIQUES = Ref(false)

@@ -384,8 +384,10 @@ static nbp_status ensure_pin(nbp_ctx *c, size_t doubles) {
   if (c->pin) HIPCHK(hipHostFree(c->pin));
   c->pin = nullptr;
   c->pin_doubles = 0;
-  HIPCHK(hipHostMalloc((void **)&c->pin, (doubles + doubles / 2) * 8, hipHostMallocDefault));
-  c->pin_doubles = doubles + doubles / 2;
+  const size_t cap = doubles * 2;
+  static const bool noncoh = getenv("NBP_PIN_NONCOHERENT") != nullptr;
+  HIPCHK(hipHostMalloc((void **)&c->pin, cap * 8, noncoh ? hipHostMallocNonCoherent : hipHostMallocDefault));
+  c->pin_doubles = cap;
   return NBP_OK;
 }
 nbp_status nbp_belief_write_batch(nbp_ctx *c, int32_t n, const int32_t *slots, const int32_t *manifolds, const double *const *pts,
@@ -423,6 +425,21 @@ nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, co
     if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
+  // ascending slots with small gaps (the updated variables of many cliques): reading the gaps along costs less than a copy
+  // per run -- one copy of the whole span while it stays under four times the bytes asked for
+  bool ascending = true;
+  for (int i = 1; i < n; i++) ascending &= slots[i] > slots[i - 1];
+  const size_t span = ascending ? (size_t)(slots[n - 1] - slots[0] + 1) : 0;
+  if (ascending && span > (size_t)n && span <= 4 * (size_t)n) {
+    nbp_status rc = ensure_pin(c, span * (size_t)c->S);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->pin, c->arena + c->S * slots[0], span * c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++)
+      unpack_belief(c, manifolds[i], c->pin + (size_t)(slots[i] - slots[0]) * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr,
+                    ipc ? ipc[i] : nullptr);
+    return NBP_OK;
+  }
   nbp_status rc = ensure_pin(c, (size_t)n * (size_t)c->S);
   if (rc) return rc;
   for (int i = 0; i < n;) {
@@ -1858,7 +1875,7 @@ nbp_status nbp_program_destroy(nbp_program *p) {
     if (p->dev) {
       // small blobs are kept for the next program of this context (hipFree synchronises the whole device)
       auto &bc = p->ctx->blob_cache;
-      if (p->dev_bytes <= (1u << 20) && bc.size() < 8) bc.emplace_back(p->dev, p->dev_bytes);
+      if (p->dev_bytes <= (16u << 20) && bc.size() < 8) bc.emplace_back(p->dev, p->dev_bytes);
       else hipFree(p->dev);
     }
     for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second.exec);

@@ -1707,23 +1707,31 @@ static int clique_zdim(int kind, int manifold) { return kind == NBP_F_LINREL ? m
 // transfer each way and one program whose stage pair r holds round r of every clique (nbp_clique_solve_batch).
 struct clique_io { int32_t slot, mani; const nbp_tree_belief *src; nbp_tree_belief *dst; bool with_ipc; };
 struct clique_plan {
-  int nslots = 0;  // slots this clique occupies, from `off`
+  int nslots = 0;  // slots this clique occupies: [0, base) beliefs that cross the boundary, [base, nslots) proposal scratch
+  int base = 0;
   std::vector<clique_io> in, out;
   std::vector<std::pair<std::vector<nbp_proposal_desc>, std::vector<nbp_product_desc>>> rounds;
   std::vector<nbp_proposal_desc> deconv;
 };
-static void shift_slots(nbp_proposal_desc &d, int off) {
-  for (int i = 0; i < NBP_MAXV; i++) d.var_slot[i] += off;  // (entries beyond nvars are never read)
-  d.out_slot += off;
-  if (d.meas_kde > 0) d.meas_kde += off;
+// Several cliques in one context: the beliefs that cross the boundary (variables, messages, densities, measurement KDEs,
+// differentials: local slots [0, base)) of ALL cliques lie one behind the other from offA on, the scratch rows of all of
+// them behind that (from offB on) -- so the beliefs of a whole batch travel in one copy each way.
+struct slot_map {
+  int base, offA, offB;
+  int operator()(int s) const { return s < base ? s + offA : s - base + offB; }
+};
+static void relocate(nbp_proposal_desc &d, const slot_map &m) {
+  for (int i = 0; i < NBP_MAXV; i++) d.var_slot[i] = m(d.var_slot[i]);  // (entries beyond nvars are never read)
+  d.out_slot = m(d.out_slot);
+  if (d.meas_kde > 0) d.meas_kde = m(d.meas_kde - 1) + 1;
 }
-static void shift_slots(nbp_product_desc &d, int off) {
-  for (int i = 0; i < d.nfactors; i++) d.in_slot[i] += off;
-  d.out_slot += off;
-  if (d.old_slot >= 0) d.old_slot += off;
+static void relocate(nbp_product_desc &d, const slot_map &m) {
+  for (int i = 0; i < d.nfactors; i++) d.in_slot[i] = m(d.in_slot[i]);
+  d.out_slot = m(d.out_slot);
+  if (d.old_slot >= 0) d.old_slot = m(d.old_slot);
 }
 static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed, nbp_tree_belief *bel, bool down,
-                                    nbp_tree_belief *diff_out, int off, clique_plan &P) {
+                                    nbp_tree_belief *diff_out, clique_plan &P) {
   nbp_status rc = clique_check(sp, q);
   if (rc) return rc;
   if (!bel) return hfail(NBP_ERR_ARG, "null argument");
@@ -1803,7 +1811,7 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
   }
   // ---- beliefs in --------------------------------------------------------------------------------------------------
   {
-    auto put = [&](int slot, int mani, const nbp_tree_belief &m, bool with_ipc) { P.in.push_back({off + slot, mani, &m, nullptr, with_ipc}); };
+    auto put = [&](int slot, int mani, const nbp_tree_belief &m, bool with_ipc) { P.in.push_back({slot, mani, &m, nullptr, with_ipc}); };
     for (int v = 0; v < q->nvars; v++) {
       if (!bel[v].pts) return hfail(NBP_ERR_ARG, "clique: null belief");
       put(v, q->manifold[v], bel[v], true);
@@ -1894,12 +1902,11 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
       updated[v] = 1;
     }
     if (prods.empty()) continue;
-    for (nbp_proposal_desc &d : props) shift_slots(d, off);
-    for (nbp_product_desc &d : prods) shift_slots(d, off);
     P.rounds.emplace_back(std::move(props), std::move(prods));
   }
   int lanes = 1;
   for (const std::vector<int> &round : rounds) lanes = std::max(lanes, (int)round.size());
+  P.base = base;
   P.nslots = base + lanes * maxf;
   if (ndiff > 0) {
     // prepCliqueMsgUp -> addLikelihoodsDifferentialCHILD! (TreeMessageUtils.jl:279-335): approxDeconv between the solved
@@ -1921,23 +1928,38 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
       fill_proposal(&g, d, &dflt, -1, q->diff_b[i], nullptr, nullptr, nullptr, diff0 + i, op_seed(seed, PASS_UP, q->clique_id, 0x4000 + i, 0), 0.0);
       props.push_back(d);
     }
-    for (nbp_proposal_desc &d : props) shift_slots(d, off);
     P.deconv = std::move(props);
   }
   // ---- beliefs out: setValKDE!(vnd, mkd, setinit, ipc) (FactorGraph.jl:250-263) for everything the schedule touched, then
   // the differential KDEs (points in measurement coordinates + fitted bandwidth)
   for (int v = 0; v < q->nvars; v++)
-    if (updated[v]) P.out.push_back({off + v, q->manifold[v], nullptr, &bel[v], true});
+    if (updated[v]) P.out.push_back({v, q->manifold[v], nullptr, &bel[v], true});
   for (int i = 0; i < ndiff; i++) {
     if (!diff_out[i].pts || !diff_out[i].bw) return hfail(NBP_ERR_ARG, "clique: diff_out entries need pts and bw");
-    P.out.push_back({off + diff0 + i, clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]), nullptr, &diff_out[i], false});
+    P.out.push_back({diff0 + i, clique_zdim(q->diff_kind[i], q->manifold[q->diff_a[i]]), nullptr, &diff_out[i], false});
   }
   return NBP_OK;
 }
 
 // the plans of one or several cliques on one context: one transfer in, one program (stage pair r = round r of every
 // clique; the differential stages of all of them behind the last round), one transfer out
-static nbp_status clique_plans_run(nbp_ctx *ctx, const std::vector<clique_plan> &plans) {
+static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans) {
+  {
+    int offA = 0, offB = 0;
+    for (const clique_plan &P : plans) offB += P.base;
+    for (clique_plan &P : plans) {
+      const slot_map m{P.base, offA, offB};
+      for (auto &r : P.rounds) {
+        for (nbp_proposal_desc &d : r.first) relocate(d, m);
+        for (nbp_product_desc &d : r.second) relocate(d, m);
+      }
+      for (nbp_proposal_desc &d : P.deconv) relocate(d, m);
+      for (clique_io &e : P.in) e.slot = m(e.slot);
+      for (clique_io &e : P.out) e.slot = m(e.slot);
+      offA += P.base;
+      offB += P.nslots - P.base;
+    }
+  }
   std::vector<int32_t> bs, bm, bn;
   std::vector<const double *> bp, bb, bi;
   for (const clique_plan &P : plans)
@@ -1996,7 +2018,7 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
                                nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
   if (!ctx) return hfail(NBP_ERR_ARG, "null argument");
   std::vector<clique_plan> plans(1);
-  nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, 0, plans[0]);
+  nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, plans[0]);
   if (!rc) rc = clique_plans_run(ctx, plans);
   if (rc) return rc;
   if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
@@ -2007,12 +2029,10 @@ nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t
   if (!ctx || (n > 0 && !req)) return hfail(NBP_ERR_ARG, "null argument");
   if (n <= 0) return NBP_OK;
   std::vector<clique_plan> plans((size_t)n);
-  int off = 0;
   for (int i = 0; i < n; i++) {
     if (!req[i].params || !req[i].clique) return hfail(NBP_ERR_ARG, "clique batch: null params / clique");
-    nbp_status rc = clique_plan_build(req[i].params, req[i].clique, req[i].seed, req[i].beliefs, req[i].down != 0, req[i].diff_out, off, plans[(size_t)i]);
+    nbp_status rc = clique_plan_build(req[i].params, req[i].clique, req[i].seed, req[i].beliefs, req[i].down != 0, req[i].diff_out, plans[(size_t)i]);
     if (rc) return rc;
-    off += plans[(size_t)i].nslots;
   }
   nbp_status rc = clique_plans_run(ctx, plans);
   if (rc) return rc;
