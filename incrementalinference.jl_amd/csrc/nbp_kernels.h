@@ -1284,8 +1284,9 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
     product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);  // HL = 4 / 2: never BIG (launch_products)
 }
 
-// Four entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in
-// flight) keep everything in registers (236 VGPRs); the throughput variants trade a few spills for 4-5 waves per SIMD.
+// Entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in flight) and the
+// throughput variants (one workgroup per product, per-manifold instances); none of them uses scratch
+// (profiles/r03_kernel_resources.txt).
 #define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
 #if NBP_TU & NBP_TU_PRODLAT
 __global__ void __launch_bounds__(512) nbp_product_kernel_x16(NBP_PRODUCT_ARGS) {

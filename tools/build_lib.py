@@ -63,13 +63,20 @@ def main():
         return
     os.makedirs(args.objdir, exist_ok=True)
     tag = ("_" + re.sub(r"\W", "", "".join(extra))) if extra else ""
-    hdr_m = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
+    # what a translation unit includes: the kernel groups everything but the host header, nbp_host.cpp only the two ABI headers
+    def hdr_m(src):
+        hs = [h for h in HEADERS if os.path.exists(h)]
+        if src.endswith("nbp_host.cpp"):
+            hs = [h for h in hs if os.path.basename(h) in ("nbp.h", "nbp_host.h")]
+        elif os.path.basename(src).startswith("nbp_k_"):
+            hs = [h for h in hs if os.path.basename(h) != "nbp_host.h"]
+        return max(os.path.getmtime(h) for h in hs)
     jobs, objs = [], []
     for src in sources():
         obj = os.path.join(args.objdir, os.path.basename(src).rsplit(".", 1)[0] + tag + ".o")
         log = obj + ".log"
         objs.append((src, obj, log))
-        dep_m = os.path.getmtime(src) if src.endswith("nbp_host.cpp") and False else max(os.path.getmtime(src), hdr_m)
+        dep_m = max(os.path.getmtime(src), hdr_m(src))
         want_res = args.resources and src.endswith(".hip") and "nbp_k_" in src
         if not args.force and os.path.exists(obj) and os.path.getmtime(obj) >= dep_m and (not want_res or os.path.exists(log)):
             continue
