@@ -138,3 +138,32 @@ def test_clique_entry_rejects_bad_input(hip_backend):
                 small.close()
     finally:
         be.close()
+
+
+def test_clique_batch_rejects_bad_input_and_takes_an_empty_batch(hip_backend):
+    """nbp_clique_solve_batch: a bad request fails the call (no partial results, nothing crashes), a context that cannot hold
+    the sum of the requests is refused, and a batch of zero requests is a no-op"""
+    import ctypes as C
+    from iif_amd import native_host
+    from iif_amd.native_host import Belief, clique_solve_batch
+    fg = iif.generateChainEuclid(4, vardims=2, priorEvery=2, N=64)
+    be = hip_backend(64, 24)
+    try:
+        f = fg.getFactor(fg.ls("x0")[0])
+        mk = lambda: {v: Belief(abi.EUCLID2, np.random.default_rng(1).normal(size=(64, 2)), np.ones(2)) for v in ("x0", "x1")}
+        good = ((fg.solverParams, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [f], mk(), 1), dict(lists={"itervar": ["x0"]}))
+        bad = ((fg.solverParams, 2, ["x0", "x1"], 2, 1, [abi.EUCLID2] * 2, [f], mk(), 1), dict(lists={"itervar": ["x0"]}))
+        assert clique_solve_batch(be, []) == []
+        assert clique_solve_batch(be, [good]) == [3]  # NBP_CLIQ_UPSOLVED
+        with pytest.raises(ValueError):
+            clique_solve_batch(be, [good, bad])
+        with pytest.raises(ValueError):  # 24 slots hold one of these cliques, not eight
+            clique_solve_batch(be, [((fg.solverParams, k, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [f], mk(), 1),
+                                     dict(lists={"itervar": ["x0"]})) for k in range(1, 9)])
+        lib = native_host._lib()
+        req = (native_host.CliqueRequestC * 1)()  # null params / clique
+        assert lib.nbp_clique_solve_batch(be._ctx, req, 1) < 0
+        assert lib.nbp_clique_solve_batch(None, req, 1) < 0
+        assert lib.nbp_clique_solve_batch(be._ctx, None, 0) == 0
+    finally:
+        be.close()
