@@ -280,6 +280,12 @@ factorkind(::EuclidDistance) = NBP_F_EUCLIDDIST
 factorkind(m::Mixture) = factorkind(m.mechanics)
 factorkind(::PartialPriorPassThrough) = NBP_F_PASSTHROUGH   # its density travels in nbp_clique_desc.factor_density
 
+"the measurement of a differential factor of a joint upward message (useMsgLikelihoods): `_sft(newBel)` with newBel a
+ ManifoldKernelDensity on the factor's manifold (addLikelihoodsDifferentialCHILD!, TreeMessageUtils.jl:279-335); nothing
+ for every factor with a parametric measurement"
+measkde(fnc) = (fnc isa Union{LinearRelative, CircularCircular, ManifoldFactor} && fnc.Z isa ManifoldKernelDensity) ? fnc.Z : nothing
+measkde(::Union{Mixture, PartialPriorPassThrough}) = nothing
+
 "one measurement-model component: weight, mean[3], lower Cholesky factor L[3][3] row-major (NBP_COMP_STRIDE doubles)"
 function component(w::Real, Z)::Vector{Float64}
   row = zeros(Float64, NBP_COMP_STRIDE)
@@ -311,6 +317,11 @@ function components(fnc)::Vector{Float64}
     return vcat(flat, zeros(Float64, NBP_MAXC * NBP_COMP_STRIDE - length(flat)))
   end
   fnc isa PartialPriorPassThrough && return vcat([1.0], zeros(Float64, NBP_MAXC * NBP_COMP_STRIDE - 1))  # no measurement model
+  if measkde(fnc) !== nothing                          # LinearRelative(::MKD) & co.: the measurement is the KDE in factor_meas_kde
+    row = zeros(Float64, NBP_COMP_STRIDE)
+    row[1] = 1.0; row[5] = 1.0; row[9] = 1.0; row[13] = 1.0      # weight, identity square-root covariance (unused)
+    return vcat(row, zeros(Float64, (NBP_MAXC - 1) * NBP_COMP_STRIDE))
+  end
   return vcat(component(1.0, fnc.Z), zeros(Float64, (NBP_MAXC - 1) * NBP_COMP_STRIDE))
 end
 ncomponents(fnc) = fnc isa Mixture ? length(fnc.components) : 1
@@ -393,6 +404,15 @@ function BeliefBuf(fnc::PartialPriorPassThrough, vt::InferenceVariable, code::In
   end
   return BeliefBuf(buf, bw, ones(Float64, D), length(pts))
 end
+"the measurement KDE of a differential factor as nbp_clique_desc.factor_meas_kde takes it: the tangent coordinates of its
+ points at the identity of the factor's manifold (zdim doubles per point, packed like an Euclid(zdim) belief) + bandwidth"
+function BeliefBuf(fnc, mkd::ManifoldKernelDensity, N::Int)
+  M = getManifold(fnc)
+  e0 = getPointIdentity(M)
+  coords = [collect(Float64, vee(M, e0, log(M, e0, p))) for p in getPoints(mkd, false)]
+  zd = length(coords[1])
+  return BeliefBuf(Int32(zd), coords, getBW(mkd)[:, 1], zeros(Float64, zd), N)    # manifold code of Euclid(zd) = zd
+end
 const _NOBELIEF = NbpTreeBelief(Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Int32(0), Int32(0))
 
 # ---- the clique seam --------------------------------------------------------------------------------------------------
@@ -410,6 +430,8 @@ struct CliquePack
   beliefs::Vector{NbpTreeBelief}
   densbuf::Vector{Union{Nothing, BeliefBuf}}   # per user factor: the density of a PartialPriorPassThrough
   dens::Vector{NbpTreeBelief}
+  kdebuf::Vector{Union{Nothing, BeliefBuf}}    # per user factor: the measurement KDE of a differential factor (joint messages)
+  kdes::Vector{NbpTreeBelief}
 end
 
 function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, labels::Vector{Symbol}, factors::Vector{<:DFGFactor})
@@ -430,7 +452,10 @@ function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int
     (fnc = getFactorType(f); v = getVariableOrder(f)[1];
      fnc isa PartialPriorPassThrough ? BeliefBuf(fnc, getVariableType(dfg, v), codes[index[v] + 1]) : nothing) for f in user]
   dens = NbpTreeBelief[b === nothing ? _NOBELIEF : cview(b) for b in densbuf]
-  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs), densbuf, dens)
+  kdebuf = Union{Nothing, BeliefBuf}[
+    (fnc = getFactorType(f); z = measkde(fnc); z === nothing ? nothing : BeliefBuf(fnc, z, N)) for f in user]
+  kdes = NbpTreeBelief[b === nothing ? _NOBELIEF : cview(b) for b in kdebuf]
+  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs), densbuf, dens, kdebuf, kdes)
 end
 
 ptr_or_null(v::Vector{T}) where {T} = isempty(v) ? Ptr{T}(C_NULL) : pointer(v)
@@ -442,9 +467,11 @@ function cliquedesc(cliq::TreeClique, p::CliquePack, nfrontals::Int, nseparators
                        ptr_or_null(p.lists[1]), ptr_or_null(p.lists[2]), ptr_or_null(p.lists[3]), ptr_or_null(p.lists[4]),
                        Int32(length(p.msgvar)), ptr_or_null(p.msgvar), ptr_or_null(p.msgs),
                        any(b -> b !== nothing, p.densbuf) ? pointer(p.dens) : Ptr{NbpTreeBelief}(C_NULL),
-                       # joint messages (useMsgLikelihoods): the differential factors of a child's message arrive as
-                       # LinearRelative(::MKD) & co. -- not in this shim's closed set yet, such cliques take the generic path
-                       Ptr{NbpTreeBelief}(C_NULL), Int32(0), Int32(0), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
+                       # joint messages (useMsgLikelihoods), receiving side: the differential factors of a child's message are
+                       # entries of `factors` whose measurement is a KDE.  The sending side (approxDeconv + manikde! of the
+                       # clique's own differentials) stays with prepCliqueMsgUp in Julia: n_diff = 0
+                       any(b -> b !== nothing, p.kdebuf) ? pointer(p.kdes) : Ptr{NbpTreeBelief}(C_NULL),
+                       Int32(0), Int32(0), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
 end
 
 "write the beliefs libnbp returned back into the sub graph: setValKDE!(vnd, pts, bw, setinit, ipc) (FactorGraph.jl:250-297)"
