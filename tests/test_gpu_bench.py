@@ -46,22 +46,22 @@ def test_bench_sharded_path_one_rank():
     _check(out.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("config,size,scaling", [("2", "300", "weak"), ("4", "6", "strong")])
-def test_bench_two_ranks_sharing_one_gpu(config, size, scaling):
-    """the driver's multi-GPU command line with TWO ranks on a 1-GPU box: both ranks open cuda:0, the process group is gloo
+@pytest.mark.parametrize("config,size,scaling,world", [("2", "300", "weak", 2), ("4", "6", "strong", 2), ("4", "8", "strong", 8), ("5", "400", "strong", 4)])
+def test_bench_ranks_sharing_one_gpu(config, size, scaling, world):
+    """the driver's multi-GPU command line with 2 / 4 / 8 ranks on a 1-GPU box: every rank opens cuda:0, the process group is gloo
     (RCCL refuses two ranks on one device) and separator slots travel host-staged.  Everything of the sharded leg but the
     RCCL calls themselves runs: partition, per-rank compile, exchange segments, barriers, max-over-ranks timing, one JSON
     line from rank 0 only."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29555", "bench.py", "--gpus", "2", "--steps", "2",
-                          "--warmup", "1", "--config", config, "--nvars", size, "--dist-backend", "gloo"],
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29555 + world), "bench.py", "--gpus", str(world), "--steps", "2",
+                          "--warmup", "1", "--config", config, "--nvars", size, "--dist-backend", "gloo", "--no-cpu-baseline"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = _check(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == scaling and "staged" in d["config"]["parallelism"]
+    assert d["n_gpus"] == world and d["scaling"] == scaling and "staged" in d["config"]["parallelism"]
     if config == "2":
         assert d["config"]["variables_per_gpu"] == 300 and d["posterior_max_mean_err"] < 1.5
 
