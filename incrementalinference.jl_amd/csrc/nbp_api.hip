@@ -229,6 +229,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   if (rc != NBP_OK) return rc;
   // allow the full 160 KiB LDS for the product kernel
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_x16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_y32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_l8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_m4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_t2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -698,13 +699,14 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
 }
 
 // product launch geometry: HL helper lanes per sample (64/HL samples per wave), workgroups of `wpb` <= 8
-// waves, grid.y = G workgroups per product.  Latency mode (the launch cannot fill the chip): HL = 8 and
-// several small workgroups per product; throughput mode: HL = 2 so that one workgroup covers all
-// samples and the node statistics of a product are computed once.
+// waves, grid.y = G workgroups per product.  Latency mode (the launch cannot fill the chip): HL = 32 (fewer than 16
+// products; NBP_PRODUCT_HL32_MAX) or 8 and several small workgroups per product; throughput mode: HL = 2 so that one
+// workgroup covers all samples and the node statistics of a product are computed once.
 static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
   if (c->geom_n) n = c->geom_n;  // one half of a two-stream round: the geometry of the whole batch
   static const int hl2_min = getenv("NBP_PRODUCT_HL2_MIN") ? atoi(getenv("NBP_PRODUCT_HL2_MIN")) : 192;
-  *HL = n >= hl2_min ? 2 : (n >= 48 ? 4 : (n >= 16 ? 8 : 16));
+  static const int hl32_max = getenv("NBP_PRODUCT_HL32_MAX") ? atoi(getenv("NBP_PRODUCT_HL32_MAX")) : 15;
+  *HL = n >= hl2_min ? 2 : (n >= 48 ? 4 : (n >= 16 ? 8 : (n > hl32_max ? 16 : 32)));
   const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL >= 8) ? 6 : 8;
   int g = (waves + cap - 1) / cap;
   *wpb = (waves + g - 1) / g;
@@ -716,6 +718,7 @@ typedef void (*nbp_product_fn)(const nbp_product_desc *, double *, const double 
 // the kernel of a product launch: HL helper lanes per sample; `mani` != 0: every multi-density product of the batch lives
 // on that manifold and has only full inputs (the throughput variants then run the single-instantiation kernels)
 static nbp_product_fn product_kernel_for(int HL, int mani, bool xs = false) {
+  if (HL == 32) return nbp_product_kernel_y32;
   if (HL == 16) return nbp_product_kernel_x16;
   if (HL == 8) return nbp_product_kernel_l8;
   if (xs) {

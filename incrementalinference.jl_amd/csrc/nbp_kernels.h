@@ -14,7 +14,7 @@
 #define NBP_TU_PROPOSAL 1   // proposal / deconv kernels + the small copy / reseed / resample kernels
 #define NBP_TU_PREP 2       // bandwidth fits + KD builds, sequential search
 #define NBP_TU_PREPSPEC 4   // the same with the speculative search
-#define NBP_TU_PRODLAT 8    // product kernels, latency geometries (x16, l8)
+#define NBP_TU_PRODLAT 8    // product kernels, latency geometries (y32, x16, l8)
 #define NBP_TU_PRODTHR 16   // product kernels, throughput geometries, generic (m4, t2)
 #define NBP_TU_PRODUNI 32   // product kernels, throughput geometries, one manifold per instance
 #define NBP_TU_FUSED 64     // the fused variable-update kernels
@@ -1284,7 +1284,7 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
     product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);  // HL = 4 / 2: never BIG (launch_products)
 }
 
-// Entry points: the latency variants (HL = 16 for a handful of products, HL = 8; few workgroups in flight) and the
+// Entry points: the latency variants (HL = 32 for fewer than 16 products, 16 on request, HL = 8; few workgroups in flight) and the
 // throughput variants (one workgroup per product, per-manifold instances); none of them uses scratch
 // (profiles/r03_kernel_resources.txt).
 #define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
@@ -1297,7 +1297,14 @@ __global__ void __launch_bounds__(512) nbp_product_kernel_l8(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];
   product_kernel_body<8>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
 }
+// fewer than 16 products alone on the chip: 32 helper lanes per sample halve the node range of every lane once more
+// (a lone F = 2 product: 87 -> 77 us; 64 lanes per sample gain nothing more and cost twelve F = 3 products 209 instead of 109 us)
+__global__ void __launch_bounds__(512) nbp_product_kernel_y32(NBP_PRODUCT_ARGS) {
+  extern __shared__ double smem[];
+  product_kernel_body<32>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
+}
 #else
+__global__ void nbp_product_kernel_y32(NBP_PRODUCT_ARGS);
 __global__ void nbp_product_kernel_x16(NBP_PRODUCT_ARGS);
 __global__ void nbp_product_kernel_l8(NBP_PRODUCT_ARGS);
 #endif
