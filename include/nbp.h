@@ -191,6 +191,8 @@ const char *nbp_last_error(void);
 nbp_status nbp_synchronize(nbp_ctx *ctx);
 void *nbp_arena_ptr(nbp_ctx *ctx);
 void *nbp_stream_ptr(nbp_ctx *ctx); /* hipStream_t the library launches on */
+int32_t nbp_ctx_particles(const nbp_ctx *ctx); /* N the context was created for (0: null) */
+int32_t nbp_ctx_slots(const nbp_ctx *ctx);     /* belief slots of its arena (0: null) */
 
 /* ---- belief I/O: setValKDE!/getVal at the boundary (FactorGraph.jl:250-297) --------------- */
 nbp_status nbp_slot_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP,

@@ -94,7 +94,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libnbp.so")
 # every symbol include/nbp.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "nbp_arena_bytes", "nbp_slot_stride_doubles", "nbp_ctx_create", "nbp_ctx_destroy",
-    "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr",
+    "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr", "nbp_ctx_particles", "nbp_ctx_slots",
     "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_belief_write_batch", "nbp_belief_read_batch", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
     "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
@@ -142,6 +142,8 @@ def load_library(path=None):
     lib.nbp_arena_ptr.argtypes = [vp]
     lib.nbp_stream_ptr.restype = vp
     lib.nbp_stream_ptr.argtypes = [vp]
+    lib.nbp_ctx_particles.argtypes = [vp]
+    lib.nbp_ctx_slots.argtypes = [vp]
     lib.nbp_slot_write.argtypes = [vp, i32, i32, dp, dp]
     lib.nbp_slot_read.argtypes = [vp, i32, i32, dp, dp]
     lib.nbp_belief_write.argtypes = [vp, i32, i32, dp, i32, dp, dp]

@@ -294,6 +294,8 @@ nbp_status nbp_synchronize(nbp_ctx *c) {
 }
 void *nbp_arena_ptr(nbp_ctx *c) { return c ? c->arena : nullptr; }
 void *nbp_stream_ptr(nbp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int32_t nbp_ctx_particles(const nbp_ctx *c) { return c ? c->N : 0; }
+int32_t nbp_ctx_slots(const nbp_ctx *c) { return c ? c->n_slots : 0; }
 
 // ---- belief I/O --------------------------------------------------------------------------------
 nbp_status nbp_slot_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, const double *bw) {

@@ -1945,6 +1945,13 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
 // clique; the differential stages of all of them behind the last round), one transfer out
 static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans) {
   {
+    int need = 0;
+    for (const clique_plan &P : plans) need += P.nslots;
+    if (need > nbp_ctx_slots(ctx))
+      return hfail(NBP_ERR_RANGE, ("clique: the context has " + std::to_string(nbp_ctx_slots(ctx)) + " belief slots, the call needs " + std::to_string(need) +
+                                   " (nbp_clique_slots gives the bound per clique)").c_str());
+  }
+  {
     int offA = 0, offB = 0;
     for (const clique_plan &P : plans) offB += P.base;
     for (clique_plan &P : plans) {
@@ -2014,9 +2021,16 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
   return NBP_OK;
 }
 
+static nbp_status clique_particles_ok(nbp_ctx *ctx, const nbp_solver_params *sp) {
+  if (sp && sp->N != nbp_ctx_particles(ctx))
+    return hfail(NBP_ERR_ARG, ("clique: params.N = " + std::to_string(sp->N) + ", the context was created for N = " +
+                               std::to_string(nbp_ctx_particles(ctx))).c_str());
+  return NBP_OK;
+}
 static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
                                nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
   if (!ctx) return hfail(NBP_ERR_ARG, "null argument");
+  if (nbp_status rn = clique_particles_ok(ctx, sp)) return rn;
   std::vector<clique_plan> plans(1);
   nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, plans[0]);
   if (!rc) rc = clique_plans_run(ctx, plans);
@@ -2031,6 +2045,7 @@ nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t
   std::vector<clique_plan> plans((size_t)n);
   for (int i = 0; i < n; i++) {
     if (!req[i].params || !req[i].clique) return hfail(NBP_ERR_ARG, "clique batch: null params / clique");
+    if (nbp_status rn = clique_particles_ok(ctx, req[i].params)) return rn;
     nbp_status rc = clique_plan_build(req[i].params, req[i].clique, req[i].seed, req[i].beliefs, req[i].down != 0, req[i].diff_out, plans[(size_t)i]);
     if (rc) return rc;
   }

@@ -130,6 +130,9 @@ def test_clique_entry_rejects_bad_input(hip_backend):
             clique_solve(be, fg.solverParams, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2, 9], [f], bel, 1, lists={"itervar": ["x0"]})
         with pytest.raises(ValueError):  # more frontals + separators than variables
             clique_solve(be, fg.solverParams, 1, ["x0", "x1"], 2, 1, [abi.EUCLID2] * 2, [f], bel, 1, lists={"itervar": ["x0"]})
+        with pytest.raises(ValueError, match="created for N"):  # solver parameters for another particle count than the context's
+            other = iif.SolverParams(N=32)
+            clique_solve(be, other, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [f], bel, 1, lists={"itervar": ["x0"]})
         with pytest.raises(ValueError):  # a context with too few slots for the clique
             small = hip_backend(64, 2)
             try:
