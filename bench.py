@@ -116,7 +116,17 @@ def main():
     # (fd 1 stays redirected until the process ends: RCCL prints its banner from a destructor, after main returns)
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    _main(real_stdout)
+    rank = os.environ.get("RANK", "0")
+    try:
+        _main(real_stdout)
+    except BaseException as e:  # noqa: BLE001 -- every rank says what killed it before the launcher's table buries it
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+        for line in traceback.format_exc().rstrip().splitlines():
+            sys.stderr.write(f"[bench rank {rank}] {line}\n")
+        sys.stderr.flush()
+        os._exit(1)  # no destructors: a rank that failed must not sit in a collective the others never reach
 
 
 def _main(real_stdout):
@@ -166,7 +176,12 @@ def _main(real_stdout):
         t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    rs.check_posteriors()
+    try:
+        rs.check_posteriors()
+    finally:
+        if world > 1 or os.environ.get("NBP_BENCH_SHA"):
+            print(f"[bench rank {rank}] posterior_max_mean_err={rs.posterior_max_mean_err} mode_share={rs.posterior_mode_share} "
+                  f"sha={rs.posterior_sha()} ({len(rs.mine)} variables of this rank)", file=sys.stderr, flush=True)
     msgs_total = rs.global_messages
     value = msgs_total * a.steps / dt
     st = rs.stats

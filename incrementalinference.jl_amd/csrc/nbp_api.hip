@@ -664,6 +664,16 @@ static bool products_use_xs(nbp_ctx *c, int n, int maxFD, int mani) {
   if (HL > 4 || F > NBP_FUSED_MAXF) return false;
   return nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) + 8 + nbp_product_xs_doubles(F, D, c->N) * 8 <= 150 * 1024;
 }
+// the rendezvous areas of the next launch of speculative fits, blanked on the library's stream (nbp_spec_blank_kernel)
+static void blank_spec_areas(nbp_ctx *c, int jobs) {
+#ifdef NBP_SPEC_BLANK_MEMSET  // experiment (tools/exp/concurrency_probe3.sh): the hipMemsetAsync this kernel replaced
+  (void)hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)jobs, c->stream);
+#else
+  const int words = (int)(sizeof(nbp_spec_area) / 8) * 3 * jobs;
+  hipLaunchKernelGGL(nbp_spec_blank_kernel, dim3((words + 255) / 256), dim3(256), 0, c->stream, (unsigned long long *)c->spec, words);
+#endif
+}
+
 static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t *bw_manis, int nbw,
                               const nbp_product_desc *dev, int n, int maxFD, int coords = -1, int mani = 0) {
   if (coords < 0) coords = 3 * nbw;
@@ -686,7 +696,7 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
   }
   const bool spec = depth > 0;
   const int KS = spec ? (1 << depth) - 1 : 1;
-  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)nbw, c->stream));
+  if (spec) blank_spec_areas(c, nbw);
   if (depth == 3)
     hipLaunchKernelGGL(nbp_prep_kernel_spec<3>, dim3(3 * nbw * KS + nkd), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
                        dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec);
@@ -826,7 +836,7 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
   int depth = 0;
   if (c->spec_on && n <= NBP_SPEC_MAXJOBS) depth = (c->spec_depth3 && coords * 7 <= NBP_SPEC_MAXBLOCKS) ? 3 : ((coords * 3 <= NBP_SPEC_MAXBLOCKS) ? 2 : 0);
   const bool spec = depth > 0;
-  if (spec) HIPCHK(hipMemsetAsync(c->spec, 0xFF, sizeof(nbp_spec_area) * 3 * (size_t)n, c->stream));
+  if (spec) blank_spec_areas(c, n);
   if (depth == 3)
     hipLaunchKernelGGL(nbp_bandwidth_kernel_spec<3>, dim3(n, 3, 7), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
                        dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, c->spec);

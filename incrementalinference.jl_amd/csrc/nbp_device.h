@@ -1389,6 +1389,9 @@ __device__ __forceinline__ bool golden_done(const golden_state &g, double tol) {
 // DEPTH iterations per rendezvous, K = 2^DEPTH - 1 workgroups per fit.  Roles are the nodes of the outcome tree in heap
 // order: node 1 = the iteration whose comparison is already decided by known values; node 2n / 2n+1 = the iteration that
 // follows node n when the comparison after n comes out true / false.
+#ifndef NBP_SPEC_PATIENCE
+#define NBP_SPEC_PATIENCE 512  // polls before a role gives up on its peers (experiments: tools/exp/concurrency_probe.sh)
+#endif
 template <int DEPTH>
 __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, int Npad, bool circ, double *part, double *red, const double *tab,
                                                         nbp_counters *ctr, nbp_spec_area *area, int role) {
@@ -1451,7 +1454,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
       // Patience: a few hundred polls (a poll is a round trip to memory, ~1 us) = many evaluations.  Peers that have not
       // published by then are not running (other contexts' kernels hold the CUs): going on alone costs this fit its
       // speed-up, waiting longer would cost the whole solve its latency.
-      for (int spin = 0; spin < 512 && !ok; spin++) {
+      for (int spin = 0; spin < NBP_SPEC_PATIENCE && !ok; spin++) {
         ok = 1;
 #pragma unroll
         for (int r = 0; r < K; r++) {

@@ -565,8 +565,16 @@ __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, ui
     *s = splitmix64(*s ^ splitmix64(salt));
   }
 }
+// blanks the rendezvous areas of a launch of speculative fits (all ones: the bit pattern no likelihood takes).  A kernel of
+// the library's own in front of the fit kernel, not hipMemsetAsync: kernel -> kernel is the one ordering every path (plain
+// stream, captured graph, several processes on the device) is known to keep
+__global__ void nbp_spec_blank_kernel(unsigned long long *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = ~0ull;
+}
 #else
 __global__ void nbp_reseed_kernel(char *blob, const int64_t *seed_off, int n, uint64_t salt);
+__global__ void nbp_spec_blank_kernel(unsigned long long *p, int n);
 #endif
 
 // ================================================================================================

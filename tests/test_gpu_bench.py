@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _why(out):
+    """what the ranks themselves said (bench.py prefixes every line of a rank's traceback), then the launcher's tail"""
+    said = [l for l in out.stderr.splitlines() if "[bench rank" in l]
+    return "\n".join(said[-80:]) + "\n---- launcher tail ----\n" + out.stderr[-1500:]
+
+
 def _check(line):
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -28,7 +34,7 @@ def _check(line):
 def test_bench_single_process():
     out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--nvars", "200", "--cpu-sample-vars", "40"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, _why(out)
     d = _check(out.stdout.strip().splitlines()[-1])
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
@@ -42,7 +48,7 @@ def test_bench_sharded_path_one_rank():
                           "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "1", "--steps", "2",
                           "--warmup", "1", "--nvars", "200", "--force-dist", "--no-cpu-baseline"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, _why(out)
     _check(out.stdout.strip().splitlines()[-1])
 
 
@@ -57,7 +63,7 @@ def test_bench_ranks_sharing_one_gpu(config, size, scaling, world):
                           "--master-addr", "127.0.0.1", "--master-port", str(29555 + world), "bench.py", "--gpus", str(world), "--steps", "2",
                           "--warmup", "1", "--config", config, "--nvars", size, "--dist-backend", "gloo", "--no-cpu-baseline"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == 0, _why(out)
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = _check(lines[0])
@@ -77,7 +83,7 @@ def test_bench_two_ranks_if_two_gpus():
                           "--master-addr", "127.0.0.1", "--master-port", "29544", "bench.py", "--gpus", "2", "--steps", "2",
                           "--warmup", "1", "--nvars", "300"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == 0, _why(out)
     d = _check([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["variables_per_gpu"] == 300
     assert d["posterior_max_mean_err"] < 1.5
