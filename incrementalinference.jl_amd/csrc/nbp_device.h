@@ -36,6 +36,7 @@
 #define PURP_ANYN 11      // _getindex_anyn: the element a particle beyond the end of a shorter operand reads
 #define PURP_OLDSEL 12    // sample(oldBel, nn): kernel pick / noise of the top-up of a belief with fewer than N points
 #define PURP_OLDNOISE 13
+#define PURP_PLEVEL 14    // samplePoint! between the levels of the product sampler (k = 2 l, 2 l + 1)
 #define NBP_TAG 0x4E4250u
 
 #define NBP_MAXLEVELS 12
@@ -103,6 +104,14 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t 
 #endif
   na = r * c;
   nb = r * s;
+}
+
+// the same as a leaf call (the product sampler draws a point per tree level: inlined, the constants of log and sincos are
+// hoisted out of the level loop and kept live through the Gibbs sweeps -- 40-50 registers spilled at four waves per SIMD)
+__device__ __attribute__((noinline)) double2 normal_pair_call(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k) {
+  double a, b;
+  normal_pair(seed, n, purpose, k, a, b);
+  return make_double2(a, b);
 }
 
 // ------------------------------------------------------------------------------------------------

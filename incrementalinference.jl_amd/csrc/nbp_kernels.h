@@ -919,11 +919,36 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     h2[t] = (k < D) ? bw * bw : 0.0;
     cen[t] = FUSED ? ((k < D) ? fio->cen[t] : 0.0) : wsp[(size_t)j * nbp_kd_ws_doubles(N) + 3 * N + k];
   }
-  int *nxt = ind + F * SPB;  // the child each selected node hands its label to on the next level
   if (h == 0)
-    for (int j = 0; j < F; j++) ind[j * SPB + sl] = 0;  // levelInit!: root
-  // ---- multiscale Gibbs ---------------------------------------------------------------------
-  for (int l = 1; l <= T.L; l++) {
+    for (int j = 0; j < F; j++) ind[j * SPB + sl] = 0;  // levelInit! / initIndices!: root
+  // samplePoint!: a draw from the product of the Gaussians the labels select -- between the levels the point x the labels
+  // of the next level are drawn on, after the last level the output sample.  Its mean and precision are taken at the end of
+  // a level (the statistics of that level are still in place), the normals at the top of the next: one site each.  Every
+  // helper lane of a sample carries them.
+  double xp[D], xmu[D], xpr[D];  // the point drawn on the level above; mean and precision of the next one
+#pragma unroll
+  for (int k = 0; k < D; k++) { xp[k] = 0.0; xmu[k] = 0.0; xpr[k] = 0.0; }
+  // ---- multiscale Gibbs (Ihler, Sudderth, Freeman, Willsky, NIPS 2003, sec. 4; the gibbs1 loop of KernelDensityEstimate.jl):
+  //      per level  samplePoint! (x from the labels of the level above) -> levelDown! (the candidates of every density
+  //      are ALL nodes of this level) -> sampleIndices! (every label given x, independently) -> Niter sweeps of sampleIndex
+  for (int l = 0; l <= T.L + 1; l++) {
+    if (l > 0 && live) {  // samplePoint!
+      double n0, n1, n2 = 0, n3 = 0;
+      const uint32_t purpose = (l <= T.L) ? PURP_PLEVEL : PURP_PFINAL, k0 = (l <= T.L) ? (uint32_t)(2 * l) : 0u;
+      const double2 na = normal_pair_call(d->seed, (uint32_t)s, purpose, k0);
+      n0 = na.x;
+      n1 = na.y;
+      if (D > 2) { const double2 nb = normal_pair_call(d->seed, (uint32_t)s, purpose, k0 + 1); n2 = nb.x; n3 = nb.y; }
+      (void)n3;
+      const double nn[3] = {n0, n1, n2};
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        // (xpr = 0, PARTIAL only: a coordinate no density informs -- it enters no weight and keeps the old point)
+        const double v = (PARTIAL && !(xpr[k] > 0)) ? 0.0 : xmu[k] + sqrt(1.0 / xpr[k]) * nn[k];
+        xp[k] = circ[k] ? wrap_pi(v) : v;
+      }
+    }
+    if (l > T.L) break;
     const int cnt = T.cnt[l], off = T.off[l];
     __syncthreads();
     NBP_CTICK(40);  // staging (first level) / Gibbs draws of the previous level
@@ -934,13 +959,27 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       double s1, s2;
       if constexpr (FUSED) {  // the same sums in the same (leaf) order as kd_build's, from the tree in LDS
         const double *srt = fio->xs + j * fio->xs_stride + k * N;
+        // (the root: the sums of its two children added, as below)
+        const int mid = (l == 0 && T.L > 0) ? T.node_hi[T.off[1]] : hi;
         s1 = 0;
         s2 = 0;
-        for (int p = lo; p < hi; p++) { const double v = srt[p]; s1 += v; s2 += v * v; }
+        for (int p = lo; p < mid; p++) { const double v = srt[p]; s1 += v; s2 += v * v; }
+        if (mid < hi) {
+          double t1 = 0, t2 = 0;
+          for (int p = mid; p < hi; p++) { const double v = srt[p]; t1 += v; t2 += v * v; }
+          s1 += t1;
+          s2 += t2;
+        }
       } else {  // the node sums were left by the KD build of this density (nbp_prep_kernel)
-        const double *st = wsp + (size_t)j * nbp_kd_ws_doubles(N) + nbp_kd_stats_offset(N) + (size_t)(k * 2) * stcap + off + z;
-        s1 = st[0];
-        s2 = st[stcap];
+        const double *st = wsp + (size_t)j * nbp_kd_ws_doubles(N) + nbp_kd_stats_offset(N) + (size_t)(k * 2) * stcap;
+        if (l == 0 && T.L > 0) {  // the root: the sums of its two children (the KD build leaves the levels below the root)
+          const int c0 = T.off[1];
+          s1 = st[c0] + st[c0 + 1];
+          s2 = st[stcap + c0] + st[stcap + c0 + 1];
+        } else {
+          s1 = st[off + z];
+          s2 = st[stcap + off + z];
+        }
       }
       const double nn = (double)(hi - lo), mu = s1 / nn;
       double var = s2 / nn - mu * mu;
@@ -958,25 +997,34 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       }
     }
     for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
-    // levelDown!: the label moves to a child of the selected node drawn by its share of the leaves (always
-    // taking the same child biases the product towards that side of every split); the coin is the spare
-    // uniform of the density's last draw on the level above, or a draw of its own below the root
-    if (h == 0 && live)
-      for (int j = 0; j < F; j++) {
-        if (l > 1) { ind[j * SPB + sl] = nxt[j * SPB + sl]; continue; }
-        double ua, ub;
-        uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)j, ua, ub);
-        const int len = T.node_hi[0] - T.node_lo[0], last = T.node_child[0];
-        ind[j * SPB + sl] = (len <= 1 || !(ua * (double)len < (double)((len + 1) / 2))) ? last : last - 1;
-      }
     __syncthreads();
-    NBP_CTICK(41);  // node statistics + levelDown
-    const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range
+    NBP_CTICK(41);  // node statistics
+    // mean and precision of the product of the selected Gaussians (for the samplePoint! at the top of the next pass)
+    auto point_moments = [&]() {
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        double prec = 0, acc = 0, ss = 0, sc = 0;
+        for (int q = 0; q < F; q++) {
+          if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
+          const int iq = ind[q * SPB + sl];
+          const double rq = lr[(q * D + k) * N + iq];
+          prec += rq;
+          if (circ[k]) {
+            ss += lsn[q * N + iq];
+            sc += lcs[q * N + iq];
+          } else
+            acc += lm[(q * D + k) * N + iq] * rq;
+        }
+        xpr[k] = prec;
+        xmu[k] = (PARTIAL && !(prec > 0)) ? 0.0 : (circ[k] ? atan2(ss, sc) : acc / prec);
+      }
+    };
+    const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range (the root, l = 0: nothing to draw)
     // the sweep is instantiated for the leaf level and for the levels above it: `leaf` as a run-time flag is a
     // wave-uniform branch in front of every node weight (two taken branches per node in the pass-1 loop)
     auto sweep = [&](auto leaf_c) {
     constexpr bool leaf = decltype(leaf_c)::value;
-    for (int it = 0; it < d->niter; it++) {
+    for (int it = -1; l > 0 && it < d->niter; it++) {  // it = -1: sampleIndices! (every label given the point x of the level above)
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
         // Draw l_j ~ p(l_j | others) by inverse CDF over the nodes of this level.
         //   weight_z = w_z * N(mean_z; mn, var_z + vn)  =  exp(a_z) * g_z,
@@ -1026,6 +1074,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         if (live) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
+            if (it < 0) {  // sampleIndices!: p(z) ~ w_z N(x; mean_z, var_z)
+              mn[k] = xp[k];
+              vn[k] = 0.0;
+              if (PARTIAL) use[k] = ((pmj >> k) & 1) && xpr[k] > 0;
+              continue;
+            }
             double prec = 0, acc = 0, ss = 0, sc = 0;
             for (int q = 0; q < F; q++) {
               if (q == j) continue;
@@ -1050,7 +1104,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
             for (int k = 0; k < D; k++) linv[k] = (PARTIAL && !use[k]) ? 0.0 : 1.0 / (h2[j * 3 + k] + vn[k]);
           }
-          uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), ua, ub);
+          uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + (it < 0 ? 7 : it)) * NBP_MAXF + j), ua, ub);
           NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
 #pragma unroll
           for (int c = 0; c < NCH; c++) {
@@ -1140,50 +1194,25 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
         for (int o = 1; o < HL; o <<= 1) choice = max(choice, __shfl_xor(choice, o, HL));
         if (choice < 0) choice = cnt - 1;  // rounding left u * total beyond the last share
-        if (h == 0 && live) {
-          ind[j * SPB + sl] = choice;
-          if (!leaf) {
-            const int len = T.node_hi[off + choice] - T.node_lo[off + choice], last = T.node_child[off + choice];
-            nxt[j * SPB + sl] = (len <= 1 || !(ub * (double)len < (double)((len + 1) / 2))) ? last : last - 1;
-          }
-        }
+        if (h == 0 && live) ind[j * SPB + sl] = choice;
         NBP_CTICK(46);  // pass 2: rescan of the chosen chunk + broadcast of the choice
       }
     }
     };
     if (l == T.L) sweep(std::true_type{});
     else sweep(std::false_type{});
+    if (live) point_moments();
   }
   NBP_CTICK(40);
   if constexpr (FUSED) __syncthreads();  // the result slot shares LDS with statistics the slower waves still read
   // ---- samplePoint!: draw from the product of the F selected leaf kernels -----------------------
   if (h == 0 && live) {
     double res[D];
-    double n0, n1, n2 = 0, n3 = 0;
-    normal_pair(d->seed, s, PURP_PFINAL, 0, n0, n1);
-    if (D > 2) normal_pair(d->seed, s, PURP_PFINAL, 1, n2, n3);
-    const double nn[3] = {n0, n1, n2};
 #pragma unroll
     for (int k = 0; k < D; k++) {
-      double prec = 0, acc = 0, ss = 0, sc = 0;
-      for (int q = 0; q < F; q++) {
-        if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
-        const int iq = ind[q * SPB + sl];
-        const double rq = lr[(q * D + k) * N + iq];
-        prec += rq;
-        if (circ[k]) {
-          ss += lsn[q * N + iq];
-          sc += lcs[q * N + iq];
-        } else
-          acc += lm[(q * D + k) * N + iq] * rq;
-      }
-      if (PARTIAL && !(prec > 0)) {  // uninformed coordinate: oldPoints (topped up to N by the prep launch of this stage)
+      res[k] = xp[k];
+      if (PARTIAL && !(xpr[k] > 0))  // uninformed coordinate: oldPoints (topped up to N by the prep launch of this stage)
         res[k] = (d->old_slot >= 0) ? arena[S * d->old_slot + k * N + s] : 0.0;
-        continue;
-      }
-      const double mu = circ[k] ? atan2(ss, sc) : acc / prec;
-      const double v = mu + sqrt(1.0 / prec) * nn[k];
-      res[k] = circ[k] ? wrap_pi(v) : v;
     }
     if (d->labels_out >= 0)
       for (int j = 0; j < F; j++) {

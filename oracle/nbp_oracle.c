@@ -48,6 +48,7 @@
 #define PURP_KDENOISE 6
 #define PURP_PGIBBS 9
 #define PURP_PFINAL 10
+#define PURP_PLEVEL 14 /* samplePoint! between the levels of the product sampler */
 #define PURP_ANYN 11
 #define PURP_OLDSEL 12
 #define PURP_OLDNOISE 13
@@ -1234,7 +1235,14 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
         int lo = T.lo[l][z], hi = T.hi[l][z], n = hi - lo;
         for (int k = 0; k < D; k++) {
           double s1 = 0, s2 = 0;
-          for (int i = lo; i < hi; i++) { double v = xs[j][k * N + i]; s1 += v; s2 += v * v; }
+          /* (the root: the sums of its two children added -- the order the device takes them in) */
+          int mid = (l == 0 && T.L > 0) ? T.hi[1][0] : hi;
+          for (int i = lo; i < mid; i++) { double v = xs[j][k * N + i]; s1 += v; s2 += v * v; }
+          if (mid < hi) {
+            double t1 = 0, t2 = 0;
+            for (int i = mid; i < hi; i++) { double v = xs[j][k * N + i]; t1 += v; t2 += v * v; }
+            s1 += t1; s2 += t2;
+          }
           double mu = s1 / n, var = s2 / n - mu * mu;
           if (var < 0) var = 0;
           nmean[j][l][k * T.cnt[l] + z] = ctr[j][k] + mu;
@@ -1247,19 +1255,58 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   double *res = (double *)malloc(sizeof(double) * 3 * N);
   for (int s = 0; s < N; s++) {
     int ind[NBP_MAXF];
-    double coin[NBP_MAXF];
-    for (int j = 0; j < F; j++) { ind[j] = 0; coin[j] = 0.0; } /* levelInit!: root */
+    for (int j = 0; j < F; j++) ind[j] = 0; /* levelInit! / initIndices!: root */
     for (int l = 1; l <= T.L; l++) {
-      for (int j = 0; j < F; j++) { /* levelDown!: a child of the selected node, drawn by its share of the leaves */
-        const int z = ind[j], len = T.hi[l - 1][z] - T.lo[l - 1][z], last = T.child[l - 1][z];
-        if (len <= 1) { ind[j] = last; continue; } /* a leaf is carried down as its own only child */
-        double ua, ub;
-        if (l == 1) orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)j, &ua, &ub); /* level 0 has no draw of its own */
-        else ua = coin[j]; /* the spare uniform of this density's last draw on the level above */
-        const int nleft = (len + 1) / 2;
-        ind[j] = (ua * (double)len < (double)nleft) ? last - 1 : last;
+      /* One level of the multiscale sampler as published (Ihler, Sudderth, Freeman, Willsky, "Efficient multiscale
+         sampling from products of Gaussian mixtures", NIPS 2003, sec. 4; KernelDensityEstimate.jl's gibbs1 loop follows
+         it: samplePoint!, levelDown!, sampleIndices!, then Niter sweeps of sampleIndex):
+           samplePoint!:    x ~ the product of the Gaussians selected on the level above,
+           levelDown!:      the candidates of every density become ALL nodes of this level,
+           sampleIndices!:  every density draws its label given x, independently:  p(z) ~ w_z N(x; mean_z, var_z). */
+      const int cp = T.cnt[l - 1], cnt = T.cnt[l];
+      double xp[3];
+      int xinf[3];
+      {
+        double nn[4] = {0, 0, 0, 0};
+        orc_normal_pair(d->seed, s, PURP_PLEVEL, (uint32_t)(2 * l), &nn[0], &nn[1]);
+        if (D > 2) orc_normal_pair(d->seed, s, PURP_PLEVEL, (uint32_t)(2 * l + 1), &nn[2], &nn[3]);
+        for (int k = 0; k < D; k++) {
+          double prec = 0, acc = 0, ss = 0, sc = 0;
+          for (int q = 0; q < F; q++) {
+            if (!((pm[q] >> k) & 1)) continue;
+            double mq = nmean[q][l - 1][k * cp + ind[q]], rq = nprec[q][l - 1][k * cp + ind[q]];
+            prec += rq;
+            if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
+            else acc += mq * rq;
+          }
+          xinf[k] = prec > 0;
+          if (!xinf[k]) { xp[k] = 0.0; continue; } /* no density informs this coordinate: it enters no weight */
+          double mu = is_circ(M, k) ? atan2(ss, sc) : acc / prec;
+          double v = mu + sqrt(1.0 / prec) * nn[k];
+          xp[k] = is_circ(M, k) ? orc_wrap(v) : v;
+        }
       }
-      const int cnt = T.cnt[l];
+      for (int j = 0; j < F; j++) {
+        double ua, ub;
+        orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + 7) * NBP_MAXF + j), &ua, &ub);
+        double ev[NBP_MAXN]; double m = -INFINITY;
+        for (int z = 0; z < cnt; z++) {
+          double e = 0;
+          for (int k = 0; k < D; k++) {
+            if (!((pm[j] >> k) & 1) || !xinf[k]) continue;
+            double tmp = nmean[j][l][k * cnt + z] - xp[k];
+            if (is_circ(M, k)) tmp = orc_wrap(tmp);
+            double v = nvar[j][l][k * cnt + z];
+            e += tmp * tmp / v + log(v);
+          }
+          e = -0.5 * e + log((double)(T.hi[l][z] - T.lo[l][z]) / N);
+          ev[z] = e; if (e > m) m = e;
+        }
+        double tot = 0; for (int z = 0; z < cnt; z++) { ev[z] = exp(ev[z] - m); tot += ev[z]; }
+        double target = ua * tot, c = 0; int choice = -1;
+        for (int z = 0; z < cnt; z++) { c += ev[z]; if (target < c) { choice = z; break; } }
+        ind[j] = choice < 0 ? cnt - 1 : choice;
+      }
       for (int it = 0; it < d->niter; it++) {
         for (int j = 0; j < F; j++) { /* sequential Gibbs sweep: sampleIndex(j) */
           double mn[3], vn[3];
@@ -1301,7 +1348,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             if (choice < 0) choice = cnt - 1;
           }
           if (choice >= 0) ind[j] = choice;
-          coin[j] = ub;
+          (void)ub;
         }
       }
     }

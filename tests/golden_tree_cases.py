@@ -1,0 +1,84 @@
+"""Tree-level golden cases: one small graph per BASELINE.json configuration, runnable on any backend.
+
+A fixture (tests/golden/tree_*.npz, written by tests/golden/make_golden_trees.py from the oracle) holds, per variable,
+the belief graph initialisation leaves (initAll!, GraphInit.jl:61-199) and the posterior after one solveTree with the
+nested-dissection order (SolveTree.jl:164-239, CliqStateMachineUtils.jl:479-571).  The GPU tests start from the fixture's
+initial beliefs and must arrive at its posteriors two ways through the C ABI: the whole-tree program (nbp_tree_compile)
+and one clique call at a time (nbp_clique_upsolve / nbp_clique_downsolve, tests/clique_csm.py)."""
+import os
+
+import numpy as np
+
+from parity_utils import abi, coord_diff, coords, iif
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INIT_SEED, SOLVE_SEED = 11, 77
+
+
+def _config1():
+    return iif.generateGraph_LineStep(5, poseEvery=1, landmarkEvery=0, posePriorsAt=(0,), vardims=1, sigma_pose_prior=1.0,
+                                      sigma_pose_pose=0.1, solverParams=iif.SolverParams(N=100))
+
+
+TREE_CASES = {
+    # name -> (builder, share of the variables that must be particle-identical on the device, note)
+    "tree_config1_chain6": (_config1, 1.0),
+    "tree_config2_euclid2_chain24": (lambda: iif.generateChainEuclid(24, vardims=2, priorEvery=8, N=200), 1.0),
+    "tree_config3_circular_doors24": (lambda: iif.generateCircularDoors(nposes=20, N=200, sightEvery=5), 1.0),
+    "tree_config4_se2_lattice8": (lambda: iif.generateSE2Lattice(rows=2, cols=4, N=128, closeEvery=2), 0.0),
+    "tree_config5_mixture_chain10": (lambda: iif.generateMixtureChain(nvars=10, N=300, priorEvery=5), 0.0),
+}
+
+
+def build(name):
+    fg = TREE_CASES[name][0]()
+    fg.solverParams.graphinit = False
+    return fg
+
+
+def load(name):
+    return np.load(os.path.join(HERE, f"{name}.npz"))
+
+
+def set_beliefs(fg, ref, prefix):
+    for v in fg.ls():
+        iif.setValKDE(fg, v, ref[f"{prefix}_pts_{v}"].copy(), ref[f"{prefix}_bw_{v}"].copy(), True)
+
+
+def beliefs_of(fg, prefix):
+    out = {}
+    for v in fg.ls():
+        out[f"{prefix}_pts_{v}"] = np.array(fg.getVal(v))
+        out[f"{prefix}_bw_{v}"] = np.array(fg.getVariable(v).bw)
+    return out
+
+
+def run_init(name, backend):
+    fg = build(name)
+    iif.initAll(fg, backend=backend, seed=INIT_SEED)
+    return fg
+
+
+def run_solve(name, backend, ref):
+    """one solveTree from the fixture's initial beliefs (whole-tree program of the backend)"""
+    fg = build(name)
+    set_beliefs(fg, ref, "init")
+    iif.solveTree(fg, eliminationOrder=iif.nestedDissectionOrder(fg), backend=backend, seed=SOLVE_SEED)
+    return fg
+
+
+def compare(fg, got, ref, prefix, rtol):
+    """-> (labels whose particles and bandwidth agree to rtol, labels that do not, worst mean offset of those in sigmas)"""
+    same, other, worst = [], [], 0.0
+    for v in fg.ls():
+        man = fg.getVariable(v).varType.manifold
+        a, b = ref[f"{prefix}_pts_{v}"], got[f"{prefix}_pts_{v}"]
+        d = np.abs(coord_diff(man, a, b))
+        scale = np.maximum(1.0, np.abs(coords(man, a)))
+        ok = not (d > rtol * scale).any() and np.allclose(got[f"{prefix}_bw_{v}"], ref[f"{prefix}_bw_{v}"], rtol=max(rtol, 1e-9))
+        (same if ok else other).append(v)
+        if not ok:
+            ca = coords(man, a)
+            sd = np.maximum(ca.std(axis=0), 1e-3)
+            worst = max(worst, float(np.abs(coord_diff(man, a, b).mean(axis=0) / sd).max()))
+    return same, other, worst

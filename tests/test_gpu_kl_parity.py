@@ -15,7 +15,9 @@ from parity_utils import abi, iif, record_parity
 # at a spread of 1e-8 of the OBJECTIVE, which leaves the root to ~1e-4, and device and host part ways inside that within a
 # few stages (not through FMA contraction: compiling the proposal kernels with -ffp-contract=off changes nothing) -- the
 # solves stay close, not identical.  There the figure that is held is the symmetric KL itself: about BASELINE.md 5's 0.05
-# nats in the median (observed 0.048 / 0.017), at most half of what two oracle solves with different seeds read.
+# nats in the median (observed 0.048 / 0.017 in round 3, 0.039 for config 5 with the round-4 product sampler), and no more than
+# 1.5 x what two oracle solves with different seeds read: once the two sides have parted they are independent draws of one
+# algorithm (round 3 asked for half -- the round-3 sampler's seed-to-seed spread was three times larger).
 SHARE_FLOOR = {"config1_scalar_chain": 0.9, "config2_euclid2_chain": 0.9, "config3_circular_doors": 0.9,
                "config4_se2_lattice": 0.0, "config5_mixture_chain": 0.0}
 KL_MEDIAN_CAP = {"config4_se2_lattice": 0.08, "config5_mixture_chain": 0.08}
@@ -61,7 +63,7 @@ def test_symmetric_kl_gpu_vs_oracle(oracle_backend, hip_backend, name):
     assert share >= SHARE_FLOOR[name], (name, share)
     if name in KL_MEDIAN_CAP:
         rest = [k for k in kl.values() if k > 0]
-        assert np.median(rest) <= KL_MEDIAN_CAP[name] and np.median(rest) <= 0.5 * np.median(ref), (np.median(rest), np.median(ref))
+        assert np.median(rest) <= KL_MEDIAN_CAP[name] and np.median(rest) <= 1.5 * np.median(ref), (np.median(rest), np.median(ref))
 
 
 @pytest.mark.parametrize("seed", [3, 17])
