@@ -795,8 +795,17 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   }
   const int TB = wpb * 64, SPB = TB / HL;
   const bool xs = !big && products_use_xs(c, n, maxFD, mani);
-  const size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
+  size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
   if (lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: too many densities for the LDS label table");
+  // resident levels (NBP_PROD_ALL_LEVELS): the statistics of every tree level staged once, no barrier between the levels
+  // of the Gibbs walk -- where two workgroups of the launch still fit a CU's 160 KB
+  static const size_t all_cap = getenv("NBP_PRODUCT_ALL_LEVELS_KB") ? (size_t)atoi(getenv("NBP_PRODUCT_ALL_LEVELS_KB")) * 1024 : 0;  // measured: no gain, off
+  int flagsF = F;
+  if (!big) {
+    const int TOT = c->T.off[c->T.L] + c->T.cnt[c->T.L];
+    const size_t lds_all = product_lds_layout(F, D, c->N, SPB, false, nullptr, nullptr, TOT) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
+    if (lds_all <= all_cap) { lds = lds_all; flagsF |= NBP_PROD_ALL_LEVELS; }
+  }
   nbp_status rc = NBP_OK;
   double *gs = nullptr;
   if (big) {
@@ -807,7 +816,7 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(product_kernel_for(HL, mani, xs), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, F, gs, c->N, c->S, c->side, c->T);
+  hipLaunchKernelGGL(product_kernel_for(HL, mani, xs), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, flagsF, gs, c->N, c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }

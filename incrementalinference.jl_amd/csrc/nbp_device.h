@@ -108,10 +108,14 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t 
 
 // the same as a leaf call (the product sampler draws a point per tree level: inlined, the constants of log and sincos are
 // hoisted out of the level loop and kept live through the Gibbs sweeps -- 40-50 registers spilled at four waves per SIMD)
+// (sincos_fast: the angle is within [0, 2 pi); libm's sincos carries its large-argument reduction along -- a product draws
+//  a point per tree level and sample, the normals were a fifth of its time)
 __device__ __attribute__((noinline)) double2 normal_pair_call(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k) {
-  double a, b;
-  normal_pair(seed, n, purpose, k, a, b);
-  return make_double2(a, b);
+  double ua, ub, s, c;
+  uniform_pair(seed, n, purpose, k, ua, ub);
+  const double r = sqrt(-2.0 * log(ua));
+  sincos_fast(NBP_TWO_PI * ub, &s, &c);
+  return make_double2(r * c, r * s);
 }
 
 // ------------------------------------------------------------------------------------------------

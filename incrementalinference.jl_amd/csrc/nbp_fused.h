@@ -55,7 +55,7 @@ __host__ __device__ inline size_t nbp_update_lds_layout(int Fmax, int D, int N, 
   const size_t fit = 2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_LCVTAB;
   const size_t kd = nbp_update_kd_doubles(D, N, Npad, P) + ((size_t)N + 1) / 2 /* idx */;
   const size_t bulk = (size_t)Fmax * D * N;
-  const size_t prodL = 3 * bulk + (circ ? 2 * (size_t)Fmax * N : 0) + 6 * (size_t)Fmax + N + ((size_t)Fmax * Npad * 2 + 1) / 2 /* ind | nxt */;
+  const size_t prodL = 3 * bulk + (circ ? 2 * (size_t)Fmax * N : 0) + (size_t)Fmax * N /* lg */ + 6 * (size_t)Fmax + N + ((size_t)Fmax * Npad * 2 + 1) / 2 /* ind | nxt */;
   size_t t = prop;
   if (fit > t) t = fit;
   if (kd > t) t = kd;
@@ -170,11 +170,13 @@ __device__ __forceinline__ void update_body(const nbp_update_desc *uds, const nb
     fio.L.lr = b; b += bulk;
     fio.L.ls = b; if (CIRC) b += (size_t)F * N;
     fio.L.lc = b; if (CIRC) b += (size_t)F * N;
+    fio.L.lg = b; b += (size_t)F * N;
     fio.L.cen = b; b += (size_t)F * 3;
     fio.L.h2 = b; b += (size_t)F * 3;
     fio.L.nw = b; b += N;
     fio.L.tab = FL.tab;
     fio.L.ind = (int *)b;
+    fio.L.ns = N;
     fio.xs = FL.slot;
     fio.xs_stride = SL;
     fio.idx = idx_tmp;

@@ -837,29 +837,39 @@ template <int DEPTH> __global__ void nbp_prep_kernel_spec(NBP_PREP_ARGS, nbp_spe
 // launch: 8 when the launch cannot fill the chip (latency: short ranges, several small workgroups per
 // product), 4 or 2 when it can (throughput: one workgroup per product computes the node statistics once).
 struct product_lds {
-  double *lm, *lv, *lr, *ls, *lc, *cen, *h2, *nw, *tab;
+  double *lm, *lv, *lr, *ls, *lc, *lg, *cen, *h2, *nw, *tab;
   int *ind;
+  int ns;  // nodes a (density, coordinate) row holds: N (one level at a time) or the node count of the whole tree
 };
+// RESIDENT LEVELS (bit 17 of a product kernel's F argument): the node statistics of EVERY level are staged once, at node
+// index = position, and the workgroup's waves then walk the levels without a barrier between them (2.3 N nodes per row
+// instead of N: taken where the LDS of two workgroups per CU allows it, launch_products)
+#define NBP_PROD_ALL_LEVELS 0x20000
 
 // `big` = the per-level node statistics (3 x F x D x N doubles) do not fit the LDS: they go to a scratch
 // area private to the workgroup in global memory and are served by L1/L2; LDS then holds only the small
 // per-product items.
-__host__ __device__ inline size_t nbp_product_gstats_doubles(int F, int D, int N) { return (3 * (size_t)F * D + 2 * (size_t)F) * N; }
-__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L) {
+__host__ __device__ inline size_t nbp_product_gstats_doubles(int F, int D, int N) { return (3 * (size_t)F * D + 3 * (size_t)F) * N; }
+__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L, int NS = 0) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
-  const size_t bulk = big ? 0 : (size_t)F * D * N;
+  if (NS <= 0) NS = N;
+  const size_t bulk = big ? 0 : (size_t)F * D * NS;
   size_t lm = dbl(bulk), lv = dbl(bulk), lr = dbl(bulk);
   // circular coordinate (one per manifold at most): sin / cos of every node mean times its precision, so that the
   // conditional mean of a draw is two sums and one atan2 instead of a sincos per density
-  size_t ls = dbl(big ? 0 : (size_t)F * N), lc = dbl(big ? 0 : (size_t)F * N);
+  size_t ls = dbl(big ? 0 : (size_t)F * NS), lc = dbl(big ? 0 : (size_t)F * NS);
+  // g_z = w_z / sqrt(prod_k var_zk): the weight of node z beside its exponential when the label is drawn on a POINT
+  // (sampleIndices!: nothing is added to the node's own variance), once per node instead of once per draw
+  size_t lg = dbl(big ? 0 : (size_t)F * NS);
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
-  size_t nw = dbl((size_t)N), tab = dbl(NBP_EXPTAB);
+  size_t nw = dbl((size_t)NS), tab = dbl(NBP_EXPTAB);
   size_t ints0 = o;
   if (L) {
-    L->lm = base + lm; L->lv = base + lv; L->lr = base + lr; L->ls = base + ls; L->lc = base + lc; L->cen = base + cen; L->h2 = base + h2;
+    L->lm = base + lm; L->lv = base + lv; L->lr = base + lr; L->ls = base + ls; L->lc = base + lc; L->lg = base + lg; L->cen = base + cen; L->h2 = base + h2;
     L->nw = base + nw; L->tab = base + tab;
     L->ind = (int *)(base + ints0);
+    L->ns = NS;
   }
   return ints0 * 8 + (size_t)F * SPB * 4 * 2;  // ind[F][SPB] | nxt[F][SPB]
 }
@@ -888,7 +898,7 @@ struct nbp_fused_io {
 template <int MANI, bool PARTIAL, int HL, bool BIG, bool FUSED = false>
 __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int kdF, double *gstats,
                                              int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem,
-                                             const nbp_fused_io *fio = nullptr) {
+                                             const nbp_fused_io *fio = nullptr, bool all_levels = false) {
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
   const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
@@ -898,8 +908,11 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   const bool live = s < N;
   constexpr bool big = BIG;
   product_lds L;
+  const int TOT = T.off[T.L] + T.cnt[T.L];
   if constexpr (FUSED) L = fio->L;
-  else product_lds_layout(F, D, N, SPB, big, smem, &L);
+  else product_lds_layout(F, D, N, SPB, big, smem, &L, (all_levels && !big) ? TOT : N);
+  const int NS = big ? N : L.ns;   // row length of the statistics
+  const bool all = NS != N;        // every level resident
   double *cen = L.cen, *h2 = L.h2;
   int *ind = L.ind;
   double *out = FUSED ? fio->out : arena + S * d->out_slot;
@@ -908,6 +921,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * nbp_product_gstats_doubles(F, D, N) : nullptr;
   double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv, *lr = big ? gs + 2 * (size_t)F * D * N : L.lr;
   double *lsn = big ? gs + 3 * (size_t)F * D * N : L.ls, *lcs = big ? gs + (3 * (size_t)F * D + F) * N : L.lc;
+  double *lgw = big ? gs + (3 * (size_t)F * D + 2 * (size_t)F) * N : L.lg;
   constexpr int KC = (MANI == NBP_CIRCULAR) ? 0 : (MANI == NBP_SE2 ? 2 : -1);  // the circular coordinate, if any
   nbp_exp_tab_init(L.tab);
   NBP_CTICK_INIT();
@@ -948,19 +962,25 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         xp[k] = circ[k] ? wrap_pi(v) : v;
       }
     }
+    NBP_CTICK(47);  // samplePoint!: the normals
     if (l > T.L) break;
     const int cnt = T.cnt[l], off = T.off[l];
+    const int lb = all ? off : 0;  // where this level's nodes start in a row of the statistics
+    if (!all || l == 0) {
     __syncthreads();
     NBP_CTICK(40);  // staging (first level) / Gibbs draws of the previous level
-    for (int item = tid; item < F * D * cnt; item += TB) {  // node statistics of this level
-      const int z = item % cnt, jk = item / cnt;
-      const int lo = T.node_lo[off + z], hi = T.node_hi[off + z];
+    // node statistics: of this level, or (resident levels) of every level at once -- node g of the tree at row position
+    // g - g0 + (all ? 0 : 0): a level's nodes are contiguous in the tree's node arrays
+    const int g0 = all ? 0 : off, gn = all ? TOT : cnt;
+    for (int item = tid; item < F * D * gn; item += TB) {
+      const int z = item % gn, jk = item / gn, g = g0 + z;
+      const int lo = T.node_lo[g], hi = T.node_hi[g];
       const int j = jk / D, k = jk % D;
+      const bool root = (g == 0 && T.L > 0);  // the root: the sums of its two children added (the KD build leaves the levels below it)
       double s1, s2;
       if constexpr (FUSED) {  // the same sums in the same (leaf) order as kd_build's, from the tree in LDS
         const double *srt = fio->xs + j * fio->xs_stride + k * N;
-        // (the root: the sums of its two children added, as below)
-        const int mid = (l == 0 && T.L > 0) ? T.node_hi[T.off[1]] : hi;
+        const int mid = root ? T.node_hi[T.off[1]] : hi;
         s1 = 0;
         s2 = 0;
         for (int p = lo; p < mid; p++) { const double v = srt[p]; s1 += v; s2 += v * v; }
@@ -972,33 +992,44 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         }
       } else {  // the node sums were left by the KD build of this density (nbp_prep_kernel)
         const double *st = wsp + (size_t)j * nbp_kd_ws_doubles(N) + nbp_kd_stats_offset(N) + (size_t)(k * 2) * stcap;
-        if (l == 0 && T.L > 0) {  // the root: the sums of its two children (the KD build leaves the levels below the root)
+        if (root) {
           const int c0 = T.off[1];
           s1 = st[c0] + st[c0 + 1];
           s2 = st[stcap + c0] + st[stcap + c0 + 1];
         } else {
-          s1 = st[off + z];
-          s2 = st[stcap + off + z];
+          s1 = st[g];
+          s2 = st[stcap + g];
         }
       }
       const double nn = (double)(hi - lo), mu = s1 / nn;
       double var = s2 / nn - mu * mu;
       if (var < 0) var = 0;
-      lm[jk * N + z] = cen[j * 3 + k] + mu;
+      lm[jk * NS + z] = cen[j * 3 + k] + mu;
       const double vz = var + h2[j * 3 + k];
-      lv[jk * N + z] = vz;
+      lv[jk * NS + z] = vz;
       const double rz = 1.0 / vz;  // the precision, once per node: the draws below only multiply
-      lr[jk * N + z] = rz;
+      lr[jk * NS + z] = rz;
       if (KC >= 0 && k == KC) {
         double sn, cs_;
         sincos_fast(cen[j * 3 + k] + mu, &sn, &cs_);
-        lsn[j * N + z] = sn * rz;
-        lcs[j * N + z] = cs_ * rz;
+        lsn[j * NS + z] = sn * rz;
+        lcs[j * NS + z] = cs_ * rz;
       }
     }
-    for (int z = tid; z < cnt; z += TB) L.nw[z] = (double)(T.node_hi[off + z] - T.node_lo[off + z]) / (double)N;
+    for (int z = tid; z < gn; z += TB) L.nw[z] = (double)(T.node_hi[g0 + z] - T.node_lo[g0 + z]) / (double)N;
+    __syncthreads();
+    for (int item = tid; item < F * gn; item += TB) {  // g_z of every node (over the coordinates the density informs)
+      const int z = item % gn, j = item / gn;
+      const int pmz = PARTIAL ? (d->in_partial[j] ? d->in_partial[j] : 7) : 7;
+      double pv = 1.0;
+#pragma unroll
+      for (int k = 0; k < D; k++)
+        if (!PARTIAL || ((pmz >> k) & 1)) pv *= lv[(j * D + k) * NS + z];
+      lgw[j * NS + z] = rsqrt(pv) * L.nw[z];
+    }
     __syncthreads();
     NBP_CTICK(41);  // node statistics
+    }
     // mean and precision of the product of the selected Gaussians (for the samplePoint! at the top of the next pass)
     auto point_moments = [&]() {
 #pragma unroll
@@ -1007,13 +1038,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         for (int q = 0; q < F; q++) {
           if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
           const int iq = ind[q * SPB + sl];
-          const double rq = lr[(q * D + k) * N + iq];
+          const double rq = lr[(q * D + k) * NS + lb + iq];
           prec += rq;
           if (circ[k]) {
-            ss += lsn[q * N + iq];
-            sc += lcs[q * N + iq];
+            ss += lsn[q * NS + lb + iq];
+            sc += lcs[q * NS + lb + iq];
           } else
-            acc += lm[(q * D + k) * N + iq] * rq;
+            acc += lm[(q * D + k) * NS + lb + iq] * rq;
         }
         xpr[k] = prec;
         xmu[k] = (PARTIAL && !(prec > 0)) ? 0.0 : (circ[k] ? atan2(ss, sc) : acc / prec);
@@ -1034,10 +1065,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         // are the same for every node, so g_z cancels and the reciprocals are hoisted.
         // Pass 1 (all helpers, NCH chunks each): rescaled totals -> shuffle max / prefix sum.
         // Pass 2 (the helper whose share holds u * total): locate the chunk, re-evaluate just that chunk.
+        auto draw = [&](auto xp_c) {
+        constexpr bool XP = decltype(xp_c)::value;  // sampleIndices!: the label given the POINT x (nothing added to a node's variance)
         constexpr int NCH = 4;
         double mn[D], vn[D], ua = 0, ub = 0, m = -INFINITY, tot = 0;
         double cs[NCH], ms[NCH];
-        const double *mj = lm + j * D * N, *vj = lv + j * D * N;
+        const double *mj = lm + j * D * NS + lb, *vj = lv + j * D * NS + lb, *rj = lr + j * D * NS + lb, *gj = lgw + j * NS + lb;
         double linv[D];
         bool use[D];  // PARTIAL: coordinates informed by density j and by at least one other
 #pragma unroll
@@ -1047,9 +1080,9 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           double t[D], v[D];
 #pragma unroll
           for (int k = 0; k < D; k++) {
-            const double tmp = mj[k * N + z] - mn[k];  // node mean in [-2pi, 2pi), mn in [-pi, pi]
+            const double tmp = mj[k * NS + z] - mn[k];  // node mean in [-2pi, 2pi), mn in [-pi, pi]
             t[k] = circ[k] ? circ_sq(tmp) : tmp * tmp;
-            v[k] = vj[k * N + z] + vn[k];
+            v[k] = vj[k * NS + z] + vn[k];
             if (PARTIAL && !use[k]) { t[k] = 0.0; v[k] = 1.0; }
           }
           if (leaf) {
@@ -1058,6 +1091,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             for (int k = 0; k < D; k++) q = fma(t[k], linv[k], q);
             a = -0.5 * q;
             g = 1.0;
+          } else if constexpr (XP) {  // the node's own precisions and its g_z from the staging
+            double q = 0;
+#pragma unroll
+            for (int k = 0; k < D; k++) q = fma(t[k], (PARTIAL && !use[k]) ? 0.0 : rj[k * NS + z], q);
+            a = -0.5 * q;
+            g = gj[z];
           } else {
             double pv, num;
             if constexpr (D == 1) { pv = v[0]; num = t[0]; }
@@ -1065,7 +1104,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             else { const double v01 = v[0] * v[1]; pv = v01 * v[2]; num = t[0] * (v[1] * v[2]) + t[1] * (v[0] * v[2]) + t[2] * v01; }
             const double r = rsqrt(pv);
             a = -0.5 * num * (r * r);
-            g = r * L.nw[z];
+            g = r * L.nw[lb + z];
           }
         };
         // chunk size of this helper's range: a multiple of 4, the pass-1 loop takes the nodes four at a time
@@ -1074,10 +1113,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         if (live) {
 #pragma unroll
           for (int k = 0; k < D; k++) {  // product of all but the jth selected Gaussians
-            if (it < 0) {  // sampleIndices!: p(z) ~ w_z N(x; mean_z, var_z)
+            if (XP || it < 0) {  // sampleIndices!: p(z) ~ w_z N(x; mean_z, var_z)
               mn[k] = xp[k];
               vn[k] = 0.0;
-              if (PARTIAL) use[k] = ((pmj >> k) & 1) && xpr[k] > 0;
+              if (PARTIAL) use[k] = ((pmj >> k) & 1) != 0;  // (a coordinate the density informs has a point: xpr > 0)
               continue;
             }
             double prec = 0, acc = 0, ss = 0, sc = 0;
@@ -1085,13 +1124,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               if (q == j) continue;
               if (PARTIAL && d->in_partial[q] && !((d->in_partial[q] >> k) & 1)) continue;
               const int iq = ind[q * SPB + sl];
-              const double rq = lr[(q * D + k) * N + iq];
+              const double rq = lr[(q * D + k) * NS + lb + iq];
               prec += rq;
               if (circ[k]) {
-                ss += lsn[q * N + iq];
-                sc += lcs[q * N + iq];
+                ss += lsn[q * NS + lb + iq];
+                sc += lcs[q * NS + lb + iq];
               } else
-                acc += lm[(q * D + k) * N + iq] * rq;
+                acc += lm[(q * D + k) * NS + lb + iq] * rq;
             }
             if (PARTIAL) {
               use[k] = ((pmj >> k) & 1) && prec > 0;
@@ -1149,7 +1188,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             ms[c] = m;
           }
         }
-        NBP_CTICK(44);  // pass 1: node weights of this helper's range
+        NBP_CTICK(56 + (leaf ? 2 : 0) + (XP ? 1 : 0));  // pass 1: node weights of this helper's range (56 sweep, 57 on the point; 58 / 59 leaf level)
         // combine over the HL helper lanes of the sample (adjacent lanes of this wave): common max,
         // shares rescaled to it, inclusive prefix sum -> the one helper whose interval holds u * total
         double Mx = m;
@@ -1195,13 +1234,21 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         for (int o = 1; o < HL; o <<= 1) choice = max(choice, __shfl_xor(choice, o, HL));
         if (choice < 0) choice = cnt - 1;  // rounding left u * total beyond the last share
         if (h == 0 && live) ind[j * SPB + sl] = choice;
-        NBP_CTICK(46);  // pass 2: rescan of the chosen chunk + broadcast of the choice
+        NBP_CTICK(60 + (leaf ? 2 : 0) + (XP ? 1 : 0));  // pass 2: rescan of the chosen chunk + broadcast of the choice
+        };
+        // (the throughput geometries instantiate the draw on the point separately: g_z and the precisions from the staging,
+        //  no rsqrt per node; in the latency kernels -- five manifolds x partial x big in one kernel -- the second copy costs
+        //  300 spilled registers and goes through the general form)
+        if (HL <= 4 && it < 0) draw(std::true_type{});
+        else draw(std::false_type{});
       }
     }
     };
     if (l == T.L) sweep(std::true_type{});
     else sweep(std::false_type{});
+    NBP_CTICK(40);
     if (live) point_moments();
+    NBP_CTICK(48);  // moments of the next point
   }
   NBP_CTICK(40);
   if constexpr (FUSED) __syncthreads();  // the result slot shares LDS with statistics the slower waves still read
@@ -1249,12 +1296,14 @@ __device__ __forceinline__ void product_write_ipc(const nbp_product_desc *d, dou
 #define NBP_PRODUCT_BODY(M_, P_)                                                                              \
   do {                                                                                                        \
     if (HL >= 8 && gstats) product_body<M_, P_, HL, (HL >= 8)>(d, arena, ws, kdF, gstats, N, S, side, T, smem); \
-    else product_body<M_, P_, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);                     \
+    else product_body<M_, P_, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem, nullptr, all_levels);  \
   } while (0)
 template <int HL>
 __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
                                                     double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
+  const bool all_levels = (kdF & NBP_PROD_ALL_LEVELS) != 0;
+  kdF &= 0xFFFF;
   if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
   product_write_ipc(d, arena, N, S);
   bool partial = false;
@@ -1289,13 +1338,15 @@ template <int MANI, int HL, bool XS>
 __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
                                                        double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
+  const bool all_levels = (kdF & NBP_PROD_ALL_LEVELS) != 0;
+  kdF &= 0xFFFF;
   if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
   product_write_ipc(d, arena, N, S);
   if constexpr (XS) {
     constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
     const int F = d->nfactors, TB = blockDim.x, tid = threadIdx.x;
     nbp_fused_io fio;
-    const size_t own = (product_lds_layout(F, D, N, TB / HL, false, smem, &fio.L) + 7) / 8;
+    const size_t own = (product_lds_layout(F, D, N, TB / HL, false, smem, &fio.L, all_levels ? T.off[T.L] + T.cnt[T.L] : N) + 7) / 8;
     double *xs = smem + own, *cen = xs + (size_t)F * D * N, *bw = cen + 3 * F;
     const size_t wsd = nbp_kd_ws_doubles(N);
     const double *wsp = ws + (size_t)blockIdx.x * kdF * wsd;
@@ -1318,7 +1369,7 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
     __syncthreads();
     product_body<MANI, false, HL, false, true>(d, arena, ws, kdF, gstats, N, S, side, T, smem, &fio);
   } else
-    product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem);  // HL = 4 / 2: never BIG (launch_products)
+    product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem, nullptr, all_levels);  // HL = 4 / 2: never BIG (launch_products)
 }
 
 // Entry points: the latency variants (HL = 32 for fewer than 16 products, 16 on request, HL = 8; few workgroups in flight) and the

@@ -28,6 +28,9 @@ for man, F in ((abi.EUCLID2, 2), (abi.EUCLID2, 3), (abi.SE2, 3)):
         lib.nbp_debug_phase_read(out, 64, 1)
         be.run_products(descs)
         lib.nbp_debug_phase_read(out, 64, 1)
-        tot = sum(out[40:47])
-        print(f"manifold {man} F={F} batch {nops}: {tot} cycles | " + ", ".join(f"{n} {out[40 + i]}" for i, n in enumerate(names)))
+        extra = {47: "samplePoint normals", 48: "point moments", 56: "pass 1 sweep", 57: "pass 1 on the point", 58: "pass 1 sweep (leaf)",
+                 59: "pass 1 on the point (leaf)", 60: "pass 2 sweep", 61: "pass 2 on the point", 62: "pass 2 sweep (leaf)", 63: "pass 2 on the point (leaf)"}
+        tot = sum(out[40:49]) + sum(out[56:64])
+        print(f"manifold {man} F={F} batch {nops}: {tot} cycles | " + ", ".join(f"{n} {out[40 + i]}" for i, n in enumerate(names))
+              + " | " + ", ".join(f"{n} {out[i]}" for i, n in extra.items()))
         be.close()
