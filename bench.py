@@ -214,7 +214,8 @@ def _main(real_stdout):
                    "parallelism": (f"cliques sharded over {world} GPU(s), separator exchange: "
                                    f"{getattr(getattr(rs, 'impl', None), 'transport', 'none')}") if world > 1 else "single GPU"},
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": rs.posterior_max_mean_err,
-        "posterior_mode_share_min_median": rs.posterior_mode_share, "host_setup": rs.host_setup,
+        "posterior_mode_share_min_median": rs.posterior_mode_share,
+        "posterior_alias_share_min_median": getattr(rs, "posterior_alias_share", None), "host_setup": rs.host_setup,
     }
     hs = out["host_setup"]
     if hs:

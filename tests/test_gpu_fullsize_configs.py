@@ -34,12 +34,14 @@ def test_full_size_configuration(key):
             rs.step(seed)
             rs.be.synchronize()
             rs.check_posteriors()
-            res.append((rs.posterior_max_mean_err, rs.posterior_mode_share))
+            res.append((rs.posterior_max_mean_err, rs.posterior_mode_share, getattr(rs, 'posterior_alias_share', None)))
         d = rs.be.diag()
         assert d["nan_results"] == 0 and d["solves"] > 0
         assert d["nonconverged"] <= 2e-3 * d["solves"]  # the degenerate-simplex starts of Optim's AffineSimplexer
         if key == "3":
-            assert all(r[1][1] > 0.1 for r in res), res  # median share of particles within 0.35 rad of the true pose
+            # check_posteriors held the real criteria: >= 0.6 (median >= 0.9) of every pose's particles on the four
+            # positions its latest sighting allows, >= 0.6 at the TRUE one for the poses the x0 prior reaches within a solve
+            assert all(r[2][0] >= 0.6 and r[2][1] >= 0.9 for r in res), res
         print(f"config {key}: {nvars} variables, {rs.stats['cliques_global']} cliques, {rs.stats['updates_global']} updates; "
               f"posterior figures over three seeds: {res}")
     finally:
