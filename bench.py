@@ -61,6 +61,17 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_sources_sha():
+    """sha1 over the device-code sources of libnbp: what a committed PMC profile must have been taken on to be quoted"""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "incrementalinference.jl_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hbm_peak_gbps(device):
     """peak HBM bandwidth from the device properties (memory clock x bus width, double data rate); the datasheet
     figure of MI355X_MICROARCH.md when the runtime does not report them"""
@@ -239,13 +250,18 @@ def _main(real_stdout):
         # configuration they were taken on only
         traffic, traffic_src, traffic_step, traffic_ratio = None, None, None, None
         fused_on = os.environ.get("NBP_FUSED_MIN") is not None and os.environ.get("NBP_NO_FUSED_UPDATE") is None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic_fused.json" if fused_on else "r03_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_fused.json" if fused_on else "r04_pmc_traffic.json")
+        traffic_stale = None
         if world == 1 and a.config == "2" and size == 1000 and N == 200 and os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 traffic_src = os.path.relpath(pmc, ROOT)
-                traffic_step, traffic_ratio = pj.get("hbm_bytes_per_step"), pj.get("traffic_over_algorithmic")
-                traffic = next(v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items() if k.startswith(dominant))
+                # the counters were taken on ONE build of the kernels: quoted only while the kernel sources are the ones
+                # that build had (tools/pmc_quick.sh stamps the file with kernel_sources_sha())
+                traffic_stale = pj.get("kernel_sources_sha") != kernel_sources_sha()
+                if not traffic_stale:
+                    traffic_step, traffic_ratio = pj.get("hbm_bytes_per_step"), pj.get("traffic_over_algorithmic")
+                    traffic = next(v["hbm_bytes_per_launch"] for k, v in pj["kernels"].items() if k.startswith(dominant))
             except Exception:  # noqa: BLE001
                 pass
         kern_s = sum(per_step.values()) * 1e-3
@@ -257,7 +273,7 @@ def _main(real_stdout):
         valu = lcv_flop / prep_s / 1e12 if prep_s > 0 else 0.0
         out["roofline"] = {
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "traffic": traffic, "traffic_source": traffic_src, "traffic_per_step": traffic_step,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_source_is_stale": traffic_stale, "traffic_per_step": traffic_step,
             "traffic_over_algorithmic": traffic_ratio, "peak_source": peak_src,
             "alg_bytes_per_launch": bytes_per_launch, "alg_bytes_per_step": alg_rank, "avg_launch_ms": avg_ms,
             "launches_per_step": launches, "whole_solve_GBps": alg_rank / (dt / a.steps) / 1e9,
@@ -282,17 +298,24 @@ def _main(real_stdout):
         # (measured on the MI355X host: 16-32 threads is the sweet spot), so the baseline is the best of a few thread counts
         # and `cores` is the count actually used
         ncpu = os.cpu_count() or 1
-        v, secs, m, threads = max(cpu_baseline(iif, a.cpu_sample_vars, 200, sorted({min(ncpu, t) for t in (16, 32, 64)})))
-        out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port",
+        # the port is compiled for THIS host before it is timed (-O3 -march=native; the stock test library is -O2 generic);
+        # -ffp-contract=off stays, so its results are the oracle's
+        from oracle import oracle_backend as _ob
+        flags = _ob.use_native_build(f"/tmp/liboracle_native_{os.getpid()}.so") or "-O2 (stock test library: the native build failed)"
+        sweep = cpu_baseline(iif, a.cpu_sample_vars, 200, sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128)}))
+        v, secs, m, threads = max(sweep)
+        out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port", "build": flags,
+                               "thread_sweep": {str(t): round(val, 1) for val, _, _, t in sweep},
                                "sample": f"the config-2 chain with {a.cpu_sample_vars} variables, N=200, one full up+down solve "
-                                         f"({m} messages) in {secs:.1f} s, OpenMP over stage ops, best of 16/32/64 threads on a "
-                                         f"{ncpu}-thread host; the restatement baseline, not the Julia package (no Julia on the box)"}
+                                         f"({m} messages) in {secs:.1f} s, OpenMP over stage ops, best of the thread sweep on a "
+                                         f"{ncpu}-thread host, every bandwidth fit made (the port has no dead-fit elimination); "
+                                         f"the restatement baseline, not the Julia package (no Julia on the box)"}
         # also the single-thread rate of the same restatement (smaller sample: it is slow)
         v1, secs1, m1, _ = cpu_baseline(iif, max(40, a.cpu_sample_vars // 16), 200, [1])[0]
         out["cpu_baseline"]["single_thread"] = {"value": v1, "unit": "messages/s", "cores": 1,
                                                 "sample": f"{max(40, a.cpu_sample_vars // 16)}-variable chain, {m1} messages in {secs1:.1f} s"}
         if a.config in ("2", "2p"):
-            out["vs_cpu_baseline"] = value / v
+            out["vs_cpu_baseline_lazy_fits"] = value / v  # (the device leaves out the fits nothing reads; like for like below)
     out["lazy_bandwidth"] = True  # NBP_OPT_LAZY_BANDWIDTH: fits whose result nothing reads are not made (same posteriors, bit for bit)
     if world == 1 and dist is None and not a.no_profile_pass:
         # the same solve with every bandwidth fit the reference makes (manikde! on every setBelief!): what the option saves
@@ -306,7 +329,11 @@ def _main(real_stdout):
             rse.step(999)
             rse.be.synchronize()
             out["ms_per_step_every_fit"] = dte * 1e3
+            out["value_every_fit"] = msgs_total / dte
             out["lcv_evals_per_step_every_fit"] = rse.be.diag()["lcv_evals"]
+            if "cpu_baseline" in out and a.config in ("2", "2p"):
+                # like for like: both sides make every bandwidth fit the reference makes (FactorGraph.jl:250-263)
+                out["vs_cpu_baseline"] = out["value_every_fit"] / out["cpu_baseline"]["value"]
             rse.close()
         finally:
             os.environ.pop("NBP_NO_LAZY_BANDWIDTH", None)
@@ -319,13 +346,36 @@ def _main(real_stdout):
         rs10.prepare()
         dt10 = timed_steps(rs10, a.steps, a.warmup, lambda: rs10.be.synchronize()) / a.steps
         rs10.check_posteriors()
+        valu10 = None
+        if not a.no_profile_pass:  # FP64 vector rate of the leave-one-out evaluations over the prep kernel's time, as above
+            rs10.be.timing_enable(True)
+            rs10.be.timing_read()
+            rs10.be.diag(reset=True)
+            timed_steps(rs10, 2, 0, lambda: rs10.be.synchronize())
+            tim10, diag10 = rs10.be.timing_read(), rs10.be.diag()
+            rs10.be.timing_enable(False)
+            prep10 = (tim10["nbp_prep_kernel"][0] + tim10["nbp_bandwidth_kernel"][0]) * 1e-3
+            tf10 = diag10["lcv_evals"] * (N * (N - 1) / 2) * 25.0 / prep10 / 1e12 if prep10 > 0 else 0.0
+            valu10 = {"bound": "fp64_valu", "kernel": "nbp_prep_kernel", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
+                      "achieved": tf10, "frac": tf10 / FP64_VALU_PEAK_TFLOPS,
+                      "kernel_ms_per_step": {k: v[0] / 2 for k, v in tim10.items()}}
+        rs10.close()
+        os.environ["NBP_NO_LAZY_BANDWIDTH"] = "1"
+        try:  # the same graph with every fit the reference makes: the like-for-like figure against the CPU port
+            rs10e = RankSolve(iif, workloads(iif)["2p"], 10000, N, 0, 1, local, None, python_host=a.python_host)
+            rs10e.prepare()
+            dt10e = timed_steps(rs10e, min(a.steps, 3), 1, lambda: rs10e.be.synchronize()) / min(a.steps, 3)
+            rs10e.close()
+        finally:
+            os.environ.pop("NBP_NO_LAZY_BANDWIDTH", None)
         out["north_star_10k"] = {"workload": f"ContinuousEuclid(2) 10000-variable chain, N={N}", "value": rs10.global_messages / dt10,
                                  "unit": "messages/s", "ms_per_step": dt10 * 1e3, "messages_per_step": rs10.global_messages,
                                  "steps": a.steps, "warmup": a.warmup, "posterior_max_mean_err": rs10.posterior_max_mean_err,
                                  "graph_init_s": rs10.host_setup["graph_init_s"],
-                                 "vs_cpu_baseline": (rs10.global_messages / dt10) / out["cpu_baseline"]["value"]
-                                 if "cpu_baseline" in out else None, "target_vs_cpu_baseline": 20.0}
-        rs10.close()
+                                 "ms_per_step_every_fit": dt10e * 1e3, "value_every_fit": rs10.global_messages / dt10e,
+                                 "vs_cpu_baseline": (rs10.global_messages / dt10e) / out["cpu_baseline"]["value"]
+                                 if "cpu_baseline" in out else None, "target_vs_cpu_baseline": 20.0,
+                                 "roofline_valu": valu10}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -20,10 +20,22 @@ def build():
     subprocess.check_call(["make", "-C", _DIR, "-s"])
 
 
+def use_native_build(out):
+    """bench.py's cpu_baseline leg: the same source compiled for the timing host (-O3 -march=native) into `out`, loaded
+    in place of the stock library.  -> the flags used, or None when the build failed (the stock -O2 library stays)"""
+    global _SO, _lib
+    try:
+        subprocess.check_call(["make", "-C", _DIR, "-s", "native", f"OUT={out}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:  # noqa: BLE001
+        return None
+    _SO, _lib = out, None
+    return "-O3 -march=native -ffp-contract=off -fopenmp"
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_DIR, "nbp_oracle.c")):
+        if _SO.startswith(_DIR) and (not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_DIR, "nbp_oracle.c"))):
             build()
         L = C.CDLL(_SO)
         dp, ip, i32 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32

@@ -13,8 +13,12 @@ ALG=$(env "$@" python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-10
 python $R/tools/pmc_traffic.py $O/pmc 5 200 $O/pmc_traffic.json $ALG > /dev/null 2> $O/pmc_traffic.err
 rm -rf $O/pmc
 python - <<EOF
-import json
+import json, sys
+sys.path.insert(0, "$R")
+import bench
 d = json.load(open("$O/pmc_traffic.json"))
+d["kernel_sources_sha"] = bench.kernel_sources_sha()
+json.dump(d, open("$O/pmc_traffic.json", "w"), indent=1)
 print("$TAG", "$@", ": %.1f MB per solve = %.2f x algorithmic (%.1f MB)" % (d["hbm_bytes_per_step"] / 1e6, d.get("traffic_over_algorithmic", 0), d.get("algorithmic_bytes_per_step", 0) / 1e6))
 for k, v in sorted(d["hbm_bytes_per_step_by_kernel"].items(), key=lambda kv: -kv[1]):
     print("   %-34s %7.1f MB  (%d launches, %.2f MB each)" % (k, v / 1e6, d["kernels"][k]["launches"], d["kernels"][k]["hbm_bytes_per_launch"] / 1e6))
