@@ -16,13 +16,30 @@ from iif_amd.dist_solver import ShardedRunner, choose_transport, partition_cliqu
 from oracle.oracle_backend import OracleBackend  # noqa: E402
 
 
-def build(joint=False):
-    fg = iif.generateChainEuclid(24, vardims=2, priorEvery=8, N=100)
+def build(joint=False, kind="chain"):
+    """kind: "chain" (config 2 shape), "lattice" (config 4: SE(2) boustrophedon lattice with loop closures), "mixture"
+    (config 5: Euclid(3) chain of Mixture factors); deterministic synthetic "initialised" beliefs (no initAll needed)"""
+    if kind == "chain":
+        fg = iif.generateChainEuclid(24, vardims=2, priorEvery=8, N=100)
+    elif kind == "lattice":
+        fg = iif.generateSE2Lattice(rows=3, cols=8, N=100, closeEvery=3)
+    else:
+        fg = iif.generateMixtureChain(nvars=40, N=100, priorEvery=10)
     fg.solverParams.useMsgLikelihoods = joint
-    for v in fg.ls():  # deterministic synthetic "initialised" beliefs (no initAll needed here)
+    for v in fg.ls():
         i = int(v[1:])
         rng = np.random.default_rng(i)
-        iif.setValKDE(fg, v, rng.normal(size=(100, 2)) * 0.3 + i, np.array([0.1, 0.1]))
+        if kind == "chain":
+            iif.setValKDE(fg, v, rng.normal(size=(100, 2)) * 0.3 + i, np.array([0.1, 0.1]))
+        elif kind == "lattice":
+            r, c = divmod(i, 8)
+            c = c if r % 2 == 0 else 7 - c
+            th = (0.0 if r % 2 == 0 else np.pi) + rng.normal(size=100) * 0.05
+            xy = rng.normal(size=(100, 2)) * 0.2 + np.array([c, r], dtype=float)
+            iif.setValKDE(fg, v, np.stack([xy[:, 0], xy[:, 1], np.cos(th), np.sin(th), -np.sin(th), np.cos(th)], axis=1),
+                          np.array([0.1, 0.1, 0.03]))
+        else:
+            iif.setValKDE(fg, v, rng.normal(size=(100, 3)) * 0.4 + np.array([float(i), 0.0, 0.0]), np.array([0.15, 0.15, 0.15]))
     return fg, iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
 
 
@@ -57,9 +74,10 @@ class NativeShare:
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     mode = sys.argv[5] if len(sys.argv) > 5 else "priors"
+    kind = sys.argv[6] if len(sys.argv) > 6 else "chain"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    fg, tree = build(mode == "joint")
+    fg, tree = build(mode == "joint", kind)
     if mode == "native":
         tp = NativeShare(fg, world, rank, 7)
         frontals = tp.frontals
@@ -84,7 +102,9 @@ def main():
             res[v] = pts
             res[v + "_bw"] = bw
     nx = sum(1 for s in tp.segments if s[0] == "xchg")
-    np.savez(out, n_exchanges=nx, n_messages=tp.n_messages, **res)
+    # every exchange point of the solve as this rank sees it: (slots sent, slots received), empty ones included
+    xc = np.array([(len(s[1]), len(s[2])) for s in tp.segments if s[0] == "xchg"], dtype=np.int64).reshape(-1, 2)
+    np.savez(out, n_exchanges=nx, n_messages=tp.n_messages, exchange_counts=xc, **res)
     dist.barrier()
     dist.destroy_process_group()
 
