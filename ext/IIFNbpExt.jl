@@ -23,7 +23,7 @@ using RecursiveArrayTools: ArrayPartition
 using Distributions
 using LinearAlgebra
 
-import IncrementalInference: upGibbsCliqueDensity, solveCliqDownFrontalProducts!, approxConvBelief,
+import IncrementalInference: upGibbsCliqueDensity, solveCliqDownFrontalProducts!, approxConvBelief, addLikelihoodsDifferentialCHILD!,
                              getSolverParams, getVariableType, getFactorType, getCliqueData, _getCCW,
                              TreeBelief, TreeClique, MsgPrior, setValKDE!
 
@@ -415,6 +415,88 @@ function BeliefBuf(fnc, mkd::ManifoldKernelDensity, N::Int)
 end
 const _NOBELIEF = NbpTreeBelief(Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL), Int32(0), Int32(0))
 
+# ---- joint upward messages, sending side (useMsgLikelihoods) ----------------------------------------------------------------
+# WHICH separator pairs get a differential factor is symbolic and stays the reference's: the selection of
+# addLikelihoodsDifferentialCHILD! (TreeMessageUtils.jl:296-317: separators by decreasing dimension, every later one as
+# partner, the path between them homogeneous and of the default relative type).  The numeric half of that function --
+# approxDeconv of the dummy factor between the solved beliefs and manikde! of the predicted measurements -- is what
+# nbp_clique_upsolve_joint does on the device, in the same call as the up solve (diff_a / diff_b / diff_kind -> diff_out).
+"pairs (0-based indices into the clique's variable list), factor kinds, default factor types and the buffers of their KDEs"
+struct DiffPlan
+  a::Vector{Int32}
+  b::Vector{Int32}
+  kind::Vector{Int32}
+  syms::Vector{Tuple{Symbol, Symbol}}
+  ftype::Vector{Any}                           # selectFactorType(...) of the pair: LinearRelative{N}, CircularCircular, ...
+  bufs::Vector{BeliefBuf}                      # zdim doubles per point, N points, + bandwidth: what diff_out[i] points into
+  out::Vector{NbpTreeBelief}
+end
+DiffPlan() = DiffPlan(Int32[], Int32[], Int32[], Tuple{Symbol, Symbol}[], Any[], BeliefBuf[], NbpTreeBelief[])
+
+function diffplan(dfg::AbstractDFG, seps::Vector{Symbol}, index::Dict{Symbol, Int}, N::Int)
+  plan = DiffPlan()
+  (getSolverParams(dfg).useMsgLikelihoods && length(seps) > 1) || return plan
+  per = sortperm(getDimension.(getVariable.(dfg, seps)); rev = true)
+  dec = seps[per]
+  acc = reverse(dec)
+  already = Symbol[]
+  for s1 in dec
+    push!(already, s1)
+    for s2 in setdiff(acc, already)
+      isHom, ftyps = isPathFactorsHomogeneous(dfg, s1, s2)
+      isHom || continue
+      _sft = selectFactorType(dfg, s1, s2)
+      sft = _sft()
+      (typeof(sft).name == ftyps[1] && sft isa Union{LinearRelative, CircularCircular, ManifoldFactor}) || continue
+      zd = manifold_dimension(getManifold(sft))
+      push!(plan.a, Int32(index[s1])); push!(plan.b, Int32(index[s2])); push!(plan.kind, factorkind(sft))
+      push!(plan.syms, (s1, s2)); push!(plan.ftype, _sft)
+      push!(plan.bufs, BeliefBuf(Int32(zd), [zeros(Float64, zd) for _ in 1:N], ones(Float64, zd), zeros(Float64, zd), N))
+    end
+  end
+  append!(plan.out, cview.(plan.bufs))
+  return plan
+end
+
+"the KDEs nbp_clique_upsolve_joint left for the clique sub graph `subfg`, until prepCliqueMsgUp asks for them"
+const _DIFFS = Dict{UInt, Vector{NamedTuple}}()
+const _DIFFS_LOCK = ReentrantLock()
+
+"`_sft(newBel)` per pair from what the device wrote: tangent coordinates at the identity -> points of the factor's manifold"
+function stashdiffs!(subfg::AbstractDFG, plan::DiffPlan, N::Int)
+  ret = NamedTuple[]
+  for (i, (s1, s2)) in enumerate(plan.syms)
+    _sft = plan.ftype[i]
+    M = getManifold(_sft())
+    e0 = getPointIdentity(M)
+    b = plan.bufs[i]
+    zd = length(b.bw)
+    pts = [exp(M, e0, hat(M, e0, b.pts[((n - 1) * zd + 1):(n * zd)])) for n in 1:N]
+    push!(ret, (; variables = [s1; s2], likelihood = _sft(manikde!(M, pts; bw = b.bw))))
+  end
+  lock(_DIFFS_LOCK) do
+    _DIFFS[objectid(subfg)] = ret
+  end
+  return nothing
+end
+
+"""
+    addLikelihoodsDifferentialCHILD!(cliqSubFG, seps, tfg; solveKey)
+
+TreeMessageUtils.jl:279-335 for a clique whose up solve ran on the device: the differential factors were computed by
+nbp_clique_upsolve_joint in that call (same pairs, same order) and are handed over here; a clique that was solved by the
+generic path (unsupported factor) takes the generic method.
+"""
+function addLikelihoodsDifferentialCHILD!(cliqSubFG::AbstractDFG, seps::Vector{Symbol}, tfg::AbstractDFG; solveKey::Symbol = :default)
+  ret = lock(_DIFFS_LOCK) do
+    pop!(_DIFFS, objectid(cliqSubFG), nothing)
+  end
+  ret === nothing && return invoke(addLikelihoodsDifferentialCHILD!, Tuple{AbstractDFG, Vector{Symbol}, AbstractDFG}, cliqSubFG, seps, tfg; solveKey)
+  out = IncrementalInference.MsgRelativeType()
+  foreach(r -> push!(out, r), ret)
+  return out
+end
+
 # ---- the clique seam --------------------------------------------------------------------------------------------------
 "everything one nbp_clique_* call needs, with the Julia arrays the C struct points into"
 struct CliquePack
@@ -432,9 +514,11 @@ struct CliquePack
   dens::Vector{NbpTreeBelief}
   kdebuf::Vector{Union{Nothing, BeliefBuf}}    # per user factor: the measurement KDE of a differential factor (joint messages)
   kdes::Vector{NbpTreeBelief}
+  diff::DiffPlan                               # the differential factors this clique sends up (joint messages, sending side)
 end
 
-function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, labels::Vector{Symbol}, factors::Vector{<:DFGFactor})
+function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int, labels::Vector{Symbol}, factors::Vector{<:DFGFactor};
+                    senddiffs::Bool = false)
   cd = getCliqueData(cliq)
   index = Dict{Symbol, Int}(l => i - 1 for (i, l) in enumerate(labels))
   all(supported, factors) || error("libnbp: unsupported factor type in clique $(cliq.id)")
@@ -455,7 +539,8 @@ function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int
   kdebuf = Union{Nothing, BeliefBuf}[
     (fnc = getFactorType(f); z = measkde(fnc); z === nothing ? nothing : BeliefBuf(fnc, z, N)) for f in user]
   kdes = NbpTreeBelief[b === nothing ? _NOBELIEF : cview(b) for b in kdebuf]
-  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs), densbuf, dens, kdebuf, kdes)
+  return CliquePack(labels, codes, margin, specs, lists, msgvar, msgbuf, cview.(msgbuf), bufs, cview.(bufs), densbuf, dens, kdebuf, kdes,
+                    senddiffs ? diffplan(dfg, Symbol[cd.separatorIDs...], index, N) : DiffPlan())
 end
 
 ptr_or_null(v::Vector{T}) where {T} = isempty(v) ? Ptr{T}(C_NULL) : pointer(v)
@@ -468,10 +553,9 @@ function cliquedesc(cliq::TreeClique, p::CliquePack, nfrontals::Int, nseparators
                        Int32(length(p.msgvar)), ptr_or_null(p.msgvar), ptr_or_null(p.msgs),
                        any(b -> b !== nothing, p.densbuf) ? pointer(p.dens) : Ptr{NbpTreeBelief}(C_NULL),
                        # joint messages (useMsgLikelihoods), receiving side: the differential factors of a child's message are
-                       # entries of `factors` whose measurement is a KDE.  The sending side (approxDeconv + manikde! of the
-                       # clique's own differentials) stays with prepCliqueMsgUp in Julia: n_diff = 0
+                       # entries of `factors` whose measurement is a KDE; sending side: the pairs of diffplan (up solve only)
                        any(b -> b !== nothing, p.kdebuf) ? pointer(p.kdes) : Ptr{NbpTreeBelief}(C_NULL),
-                       Int32(0), Int32(0), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL), Ptr{Int32}(C_NULL))
+                       Int32(length(p.diff.a)), Int32(0), ptr_or_null(p.diff.a), ptr_or_null(p.diff.b), ptr_or_null(p.diff.kind))
 end
 
 "write the beliefs libnbp returned back into the sub graph: setValKDE!(vnd, pts, bw, setinit, ipc) (FactorGraph.jl:250-297)"
@@ -520,13 +604,27 @@ function dispatchcliques()
       group = [b for b in batch if b.N == N]
       try
         reqs = NbpCliqueRequest[NbpCliqueRequest(Base.unsafe_convert(Ptr{NbpSolverParams}, b.sp), Base.unsafe_convert(Ptr{NbpCliqueDesc}, b.q),
-                                                 b.seed, pointer(b.p.beliefs), C_NULL, b.down ? 1 : 0, 0) for b in group]
+                                                 b.seed, pointer(b.p.beliefs), ptr_or_null(b.p.diff.out), b.down ? 1 : 0, 0) for b in group]
         GC.@preserve group reqs withctx(N, sum(b.need for b in group)) do ctx
           chk(ccall((:nbp_clique_solve_batch, libnbp), Int32, (Ptr{Cvoid}, Ptr{NbpCliqueRequest}, Int32), ctx.ptr, reqs, length(reqs)))
         end
         foreach((b, r) -> put!(b.done, r.status), group, reqs)
-      catch err
-        foreach(b -> put!(b.done, err), group)      # every waiting clique task fails: monitorCSMs takes it from there
+      catch
+        # one request of the batch is at fault (unsupported input, slot overflow): the others must not fail with it -- each
+        # request again on its own, so that only the offending clique task sees the error (monitorCSMs takes it from there).
+        # Which calls share a batch depends on task timing; the results do not (the random streams are keyed per clique).
+        for b in group
+          try
+            req = NbpCliqueRequest[NbpCliqueRequest(Base.unsafe_convert(Ptr{NbpSolverParams}, b.sp), Base.unsafe_convert(Ptr{NbpCliqueDesc}, b.q),
+                                                    b.seed, pointer(b.p.beliefs), ptr_or_null(b.p.diff.out), b.down ? 1 : 0, 0)]
+            GC.@preserve b req withctx(N, b.need) do ctx
+              chk(ccall((:nbp_clique_solve_batch, libnbp), Int32, (Ptr{Cvoid}, Ptr{NbpCliqueRequest}, Int32), ctx.ptr, req, 1))
+            end
+            put!(b.done, req[1].status)
+          catch err
+            put!(b.done, err)
+          end
+        end
       end
     end
   end
@@ -555,7 +653,11 @@ function runclique(sym::Symbol, dfg::AbstractDFG, cliq::TreeClique, solveKey::Sy
   GC.@preserve p begin
     need = chk(ccall((:nbp_clique_slots, libnbp), Int32, (Ref{NbpCliqueDesc},), q))
     withctx(N, need) do ctx
-      if sym === :up
+      if sym === :up && !isempty(p.diff.a)      # the up solve and the clique's differential factors in one call
+        chk(ccall((:nbp_clique_upsolve_joint, libnbp), Int32,
+                  (Ptr{Cvoid}, Ref{NbpSolverParams}, Ref{NbpCliqueDesc}, UInt64, Ptr{NbpTreeBelief}, Ptr{NbpTreeBelief}, Ref{Int32}),
+                  ctx.ptr, sp, q, seed, p.beliefs, p.diff.out, status))
+      elseif sym === :up
         chk(ccall((:nbp_clique_upsolve, libnbp), Int32,
                   (Ptr{Cvoid}, Ref{NbpSolverParams}, Ref{NbpCliqueDesc}, UInt64, Ptr{NbpTreeBelief}, Ref{Int32}),
                   ctx.ptr, sp, q, seed, p.beliefs, status))
@@ -584,8 +686,9 @@ function upGibbsCliqueDensity(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symb
   factors = DFGFactor[getFactor(dfg, f) for f in lsf(dfg)]
   all(supported, factors) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
                                            dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)      # generic CPU path
-  p = packclique(dfg, cliq, solveKey, N, labels, factors)
+  p = packclique(dfg, cliq, solveKey, N, labels, factors; senddiffs = true)
   runclique(:up, dfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64), iters)
+  isempty(p.diff.a) || stashdiffs!(dfg, p.diff, N)     # handed to prepCliqueMsgUp through addLikelihoodsDifferentialCHILD!
   # what the four fmcmc! calls of the reference touch (SolveTree.jl:193-235): marginalized variables are skipped inside
   # fmcmc! (:61) but still reported by compileFMCMessages (:32-45), so the lists decide, not the margin flags
   touched = Symbol[l for l in labels if l in cd.directFrtlMsgIDs || l in cd.msgskipIDs || l in cd.itervarIDs || l in cd.directPriorMsgIDs]
