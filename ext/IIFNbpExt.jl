@@ -296,6 +296,9 @@ function component(w::Real, Z)::Vector{Float64}
   elseif Z isa Rayleigh
     row[5] = scale(Z); row[NBP_COMP_STRIDE] = 2.0
     return row
+  elseif Z isa AliasingScalarSampler                    # NBP_DIST_TABLE: the table travels in factor_density[f] (tablebuf)
+    row[NBP_COMP_STRIDE] = 3.0
+    return row
   end
   mu = Z isa Normal ? [mean(Z)] : collect(mean(Z))
   L = Z isa Normal ? fill(std(Z), 1, 1) : Matrix(cholesky(Symmetric(Matrix(cov(Z)))).L)
@@ -326,6 +329,20 @@ function components(fnc)::Vector{Float64}
 end
 ncomponents(fnc) = fnc isa Mixture ? length(fnc.components) : 1
 
+"the AliasingScalarSampler among a factor's measurement models (entities/AliasScalarSampling.jl:13), or nothing"
+function tablesampler(fnc)
+  fnc isa PartialPriorPassThrough && return nothing
+  zs = fnc isa Mixture ? collect(values(fnc.components)) : (hasfield(typeof(fnc), :Z) ? [fnc.Z] : [])
+  i = findfirst(z -> z isa AliasingScalarSampler, zs)
+  return i === nothing ? nothing : zs[i]
+end
+"the sampler's table as libnbp holds it: a belief on Euclid(2), row 0 the domain, row 1 the cumulative weights (enum nbp_dist)"
+function tablebuf(z::AliasingScalarSampler)
+  cum = cumsum(collect(Float64, z.weights))
+  cum[end] = 1.0
+  return BeliefBuf(NBP_EUCLID2, [[z.domain[i], cum[i]] for i in eachindex(cum)], ones(Float64, 2), zeros(Float64, 2), length(cum))
+end
+
 partialmask(fnc) = hasfield(typeof(fnc), :partial) ? Int32(sum(1 << (k - 1) for k in fnc.partial)) : Int32(0)
 
 pad(v::AbstractVector{T}, n::Int, z::T) where {T} = ntuple(i -> i <= length(v) ? v[i] : z, n)
@@ -349,7 +366,13 @@ solverparams(sp, N::Int, iters::Int = sp.gibbsIters) = NbpSolverParams(Int32(N),
                                            sp.alwaysFreshMeasurements ? Int32(0) : NBP_SOLVER_STORED_MEASUREMENTS,
                                            Float64(sp.spreadNH), Float64(sp.inflation), Float64(sp.nullSurplusAdd))
 
-supported(fct::DFGFactor) = getFactorType(fct) isa Union{NbpUser, MsgPrior{<:ManifoldKernelDensity}}
+# the measurement models libnbp samples (enum nbp_dist + MvNormal): anything else -- the reference accepts every samplable
+# belief (ManifoldSampling.jl:121-145) -- sends its clique down the generic path, factor by factor (INTEGRATION.md 1)
+const NbpMeas = Union{Normal, MvNormal, Uniform, Rayleigh, AliasingScalarSampler}
+measok(fnc::Mixture) = all(z -> z isa NbpMeas, values(fnc.components)) && measok(fnc.mechanics, true)
+measok(::Union{PartialPriorPassThrough, MsgPrior}) = true
+measok(fnc, mechanicsonly::Bool = false) = mechanicsonly || (hasfield(typeof(fnc), :Z) && fnc.Z isa Union{NbpMeas, ManifoldKernelDensity})
+supported(fct::DFGFactor) = getFactorType(fct) isa Union{NbpUser, MsgPrior{<:ManifoldKernelDensity}} && measok(getFactorType(fct))
 
 # ---- beliefs at the boundary ------------------------------------------------------------------------------------------
 "host buffers of one TreeBelief; keeps them alive next to the C view"
@@ -534,7 +557,8 @@ function packclique(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, N::Int
   bufs = BeliefBuf[BeliefBuf(dfg, l, solveKey, N) for l in labels]
   densbuf = Union{Nothing, BeliefBuf}[
     (fnc = getFactorType(f); v = getVariableOrder(f)[1];
-     fnc isa PartialPriorPassThrough ? BeliefBuf(fnc, getVariableType(dfg, v), codes[index[v] + 1]) : nothing) for f in user]
+     fnc isa PartialPriorPassThrough ? BeliefBuf(fnc, getVariableType(dfg, v), codes[index[v] + 1]) :
+     (tablesampler(fnc) === nothing ? nothing : tablebuf(tablesampler(fnc)))) for f in user]
   dens = NbpTreeBelief[b === nothing ? _NOBELIEF : cview(b) for b in densbuf]
   kdebuf = Union{Nothing, BeliefBuf}[
     (fnc = getFactorType(f); z = measkde(fnc); z === nothing ? nothing : BeliefBuf(fnc, z, N)) for f in user]

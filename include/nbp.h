@@ -47,7 +47,13 @@ extern "C" {
 enum nbp_dist {
   NBP_DIST_GAUSSIAN = 0, /* z = mean[0] + L[0][0] * randn                                     */
   NBP_DIST_UNIFORM = 1,  /* Uniform(a, b): mean[0] = a, L[0][0] = b - a; z = a + (b - a) u   */
-  NBP_DIST_RAYLEIGH = 2  /* Rayleigh(sigma): L[0][0] = sigma; z = sigma sqrt(-2 log u), u in (0, 1] */
+  NBP_DIST_RAYLEIGH = 2, /* Rayleigh(sigma): L[0][0] = sigma; z = sigma sqrt(-2 log u), u in (0, 1] */
+  NBP_DIST_TABLE = 3     /* AliasingScalarSampler(domain, weights) (entities/AliasScalarSampling.jl:13-74): z = domain[i],
+                            i ~ Categorical(weights) -- StatsBase.alias_sample! draws from that categorical, here by inverse
+                            CDF on one uniform.  The table lives in a slot: row 0 = the domain, row 1 = the CUMULATIVE
+                            normalised weights, count = its length (<= N); written like a belief on NBP_EUCLID2
+                            (nbp_belief_write; clique calls: factor_density[f]).  nbp_proposal_desc.var_slot[NBP_MAXV - 1]
+                            names the slot (factors with a table have at most NBP_MAXV - 1 variables); one table per factor */
 };
 
 typedef int32_t nbp_status;

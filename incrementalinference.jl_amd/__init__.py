@@ -10,7 +10,7 @@ from .bayestree import (buildTreeFromOrdering, buildTreeReset, getEliminationOrd
                         nestedDissectionOrder)
 from .canonical import (generateChainEuclid, generateCircularDoors, generateGraph_Kaess,  # noqa: F401
                         generateGraph_LineStep, generateMixtureChain, generateSE2Lattice)
-from .factorgraph import (Circular, CircularCircular, ContinuousEuclid, ContinuousScalar,  # noqa: F401
+from .factorgraph import (AliasingScalarSampler, Circular, CircularCircular, ContinuousEuclid, ContinuousScalar,  # noqa: F401
                           EuclidDistance, LinearRelative, ManifoldFactor, ManifoldPrior, Mixture,
                           MsgPrior, MvNormal, Normal, PartialLinearRelative, PartialManifoldFactor, PartialPrior, PartialPriorPassThrough, Prior, Rayleigh, Uniform, PriorCircular, SolverParams,
                           SpecialEuclidean2, addFactor, addVariable, deleteFactor, getSolverParams, initfg, isPartial)

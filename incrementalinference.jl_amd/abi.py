@@ -12,7 +12,7 @@ MAXV, MAXF, MAXD, MAXC, MAXN, COMP_STRIDE = 6, 128, 3, 4, 512, 13
 EUCLID1, EUCLID2, EUCLID3, CIRCULAR, SE2 = 1, 2, 3, 4, 5
 # enum nbp_factor
 F_PRIOR, F_MSGPRIOR, F_LINREL, F_CIRCULAR, F_SE2, F_EUCLIDDIST, F_PASSTHROUGH = 1, 2, 3, 4, 5, 6, 7
-DIST_GAUSSIAN, DIST_UNIFORM, DIST_RAYLEIGH = 0, 1, 2  # enum nbp_dist: family of a scalar measurement component (comp[c][12])
+DIST_GAUSSIAN, DIST_UNIFORM, DIST_RAYLEIGH, DIST_TABLE = 0, 1, 2, 3  # enum nbp_dist: family of a scalar measurement component (comp[c][12])
 STAGE_PROPOSALS, STAGE_PRODUCTS, STAGE_COPIES, STAGE_DECONV, STAGE_COPY_POINTS = 1, 2, 3, 4, 5
 OPT_LAZY_BANDWIDTH = 1
 OPT_GRAPH_REPLAY = 2

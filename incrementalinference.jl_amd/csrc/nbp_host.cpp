@@ -23,7 +23,15 @@ static nbp_status hfail(nbp_status c, const char *m) { return nbp_internal_fail(
 namespace {
 
 struct HVar { int manifold; bool initialized, ismargin; };
-struct HFac { nbp_factor_spec s; bool is_prior; int dens = -1; /* index among the graph's pass-through densities */ };
+struct HFac { nbp_factor_spec s; bool is_prior; int dens = -1; /* index among the graph's density slots: pass-through densities and sampler tables */ };
+// a measurement component that is an AliasingScalarSampler (enum nbp_dist NBP_DIST_TABLE): its table lives in a slot of the
+// factor's own, planned and written like the density of a pass-through prior
+static inline bool spec_has_table(const nbp_factor_spec &s) {
+  if (s.factor_kind == NBP_F_PASSTHROUGH) return false;
+  for (int c = 0; c < s.ncomp && c < NBP_MAXC; c++)
+    if (s.comp[c][12] == (double)NBP_DIST_TABLE) return true;
+  return false;
+}
 
 inline int mani_dim(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
 inline int mani_P(int m) { return m == NBP_SE2 ? 6 : mani_dim(m); }
@@ -668,6 +676,7 @@ void fill_proposal(const nbp_graph *g, nbp_proposal_desc &d, const HFac *fac, in
     if (s.vars[i] == target) d.sfidx = i;
     d.var_slot[i] = slot_of(s.vars[i]);
   }
+  if (spec_has_table(s)) d.var_slot[NBP_MAXV - 1] = msg_slot;  // the slot of the sampler's table (callers pass it like a density slot)
   d.ncomp = s.ncomp;
   memcpy(d.comp, s.comp, sizeof(d.comp));
   if (s.has_multihypo) {
@@ -831,7 +840,7 @@ nbp_status update_ops(nbp_tree *t, int cid, int v, const std::vector<Entry> &ent
     double ns = 0.0;  // _null_surplus: relative non-multihypo siblings of a multihypo factor
     if (anymh && fac && !fac->is_prior && !fac->s.has_multihypo) ns = g->sp.null_surplus_add;
     int msg_slot = e.tag == 'm' ? t->msg_slot(e.a, v) : -1;
-    if (fac && fac->s.factor_kind == NBP_F_PASSTHROUGH) msg_slot = t->dens0 + fac->dens;  // the slot of its density
+    if (fac && fac->dens >= 0 && e.tag != 'm') msg_slot = t->dens0 + fac->dens;  // the slot of its density / sampler table
     nbp_proposal_desc d;
     const uint64_t sd = op_seed(seed, passid, cid, step, i + 1);
     fill_proposal(g, d, fac, msg_slot, v, &Bc, &t->main_slot, inclq, base + i, sd, ns, nullptr, F == 1 ? 1 : 0);
@@ -909,7 +918,8 @@ int32_t nbp_graph_add_factor(nbp_graph *g, const nbp_factor_spec *s) {
   f.s = *s;
   f.is_prior = prior;
   const int id = (int)g->facs.size();
-  if (s->factor_kind == NBP_F_PASSTHROUGH) { f.dens = (int)g->dens_facs.size(); g->dens_facs.push_back(id); }
+  if (spec_has_table(*s) && s->nvars >= NBP_MAXV) return hfail(NBP_ERR_RANGE, "a factor with a sampler table takes at most NBP_MAXV - 1 variables");
+  if (s->factor_kind == NBP_F_PASSTHROUGH || spec_has_table(*s)) { f.dens = (int)g->dens_facs.size(); g->dens_facs.push_back(id); }
   g->facs.push_back(f);
   for (int i = 0; i < s->nvars; i++) g->vfacs[s->vars[i]].push_back(id);
   return id;
@@ -1644,6 +1654,11 @@ static nbp_status clique_check(const nbp_solver_params *sp, const nbp_clique_des
         return hfail(NBP_ERR_ARG, "clique: a pass-through prior needs its density (factor_density[f])");
     }
     if (s.nvars < 1 || s.nvars > NBP_MAXV || s.ncomp < 1 || s.ncomp > NBP_MAXC) return hfail(NBP_ERR_RANGE, "clique: factor shape");
+    if (spec_has_table(s)) {
+      if (s.nvars >= NBP_MAXV) return hfail(NBP_ERR_RANGE, "clique: a factor with a sampler table takes at most NBP_MAXV - 1 variables");
+      if (!q->factor_density || !q->factor_density[f].pts || !q->factor_density[f].bw || q->factor_density[f].n_pts < 1)
+        return hfail(NBP_ERR_ARG, "clique: an AliasingScalarSampler measurement needs its table (factor_density[f])");
+    }
     for (int i = 0; i < s.nvars; i++)
       if (s.vars[i] < 0 || s.vars[i] >= q->nvars) return hfail(NBP_ERR_RANGE, "clique: factor variable index");
   }
@@ -1683,7 +1698,7 @@ int32_t nbp_clique_slots(const nbp_clique_desc *q) {
   }
   int ndens = 0, nkde = 0;
   for (int f = 0; f < q->nfactors; f++) {
-    ndens += q->factors && q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
+    ndens += q->factors && (q->factors[f].factor_kind == NBP_F_PASSTHROUGH || spec_has_table(q->factors[f]));
     nkde += q->factor_meas_kde && q->factor_meas_kde[f].pts != nullptr;
   }
   // steps that commute run side by side, one scratch row of maxf proposals each: at most one per variable
@@ -1745,7 +1760,7 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
   for (int f = 0; f < q->nfactors; f++) {
     facs[f].s = q->factors[f];
     facs[f].is_prior = q->factors[f].factor_kind == NBP_F_PRIOR || q->factors[f].factor_kind == NBP_F_PASSTHROUGH;
-    if (q->factors[f].factor_kind == NBP_F_PASSTHROUGH) facs[f].dens = ndens++;
+    if (q->factors[f].factor_kind == NBP_F_PASSTHROUGH || spec_has_table(q->factors[f])) facs[f].dens = ndens++;
   }
   // slot plan: the clique's variables | the message beliefs | the pass-through densities | the measurement KDEs of
   // differential factors received from children | the differential KDEs this clique sends up | proposal scratch
@@ -1822,7 +1837,9 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
       put(msg0 + i, q->manifold[q->msg_var[i]], m, true);
     }
     for (int f = 0; f < q->nfactors; f++)
-      if (facs[f].dens >= 0) put(dens0 + facs[f].dens, q->manifold[facs[f].s.vars[0]], q->factor_density[f], true);
+      if (facs[f].dens >= 0)  // a density in the variable's layout, or a sampler table (two rows: domain, cumulative weights)
+        put(dens0 + facs[f].dens, facs[f].s.factor_kind == NBP_F_PASSTHROUGH ? q->manifold[facs[f].s.vars[0]] : (int32_t)NBP_EUCLID2,
+            q->factor_density[f], true);
     for (int f = 0; f < q->nfactors; f++)  // LinearRelative(::MKD) & co.: the measurement is the child's KDE, in measurement coordinates
       if (kde_of[f] >= 0) put(kde0 + kde_of[f], clique_zdim(q->factors[f].factor_kind, q->manifold[q->factors[f].vars[0]]) /* Euclid(zd) */, q->factor_meas_kde[f], false);
   }

@@ -69,7 +69,14 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
     if (zdim == 1 && cp[12] != 0.0) {  // scalar Uniform / Rayleigh component (enum nbp_dist)
       double ua, ub;
       uniform_pair(mseed, n, PURP_MEAS, 0, ua, ub);
-      z0 = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
+      if (cp[12] == (double)NBP_DIST_TABLE) {  // rand(::AliasingScalarSampler): a domain value by its weight (inverse CDF)
+        const double *tb = arena + S * d->var_slot[NBP_MAXV - 1];
+        const int K = slot_count(tb, N);
+        int i = 0;
+        while (i < K - 1 && !(ua < tb[N + i])) i++;
+        z0 = tb[i];
+      } else
+        z0 = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
     } else {
       double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
       normal_pair(mseed, n, PURP_MEAS, 0, n0, n1);

@@ -57,6 +57,38 @@ class Rayleigh:
         return np.array([0.0]), np.array([[self.sigma]])
 
 
+class AliasingScalarSampler:
+    """AliasingScalarSampler(domain, weights; SNRfloor = 0) (entities/AliasScalarSampling.jl:13-55): a scalar measurement
+    that takes the value domain[i] with probability weights[i].  The constructor's conditioning of the weights is the
+    reference's: negative weights to zero, normalise, subtract the SNRfloor quantile, clip, (keep the unfloored pmf when
+    nothing is left), normalise.  On the device: a table in a slot (enum nbp_dist NBP_DIST_TABLE), family code 3."""
+    family = abi.DIST_TABLE
+
+    def __init__(self, domain, weights, SNRfloor=0.0):
+        x, p = np.asarray(domain, dtype=float).ravel(), np.asarray(weights, dtype=float).ravel().copy()
+        if x.size != p.size or x.size == 0:
+            raise ValueError("AliasingScalarSampler: domain and weights must have the same, non-zero length")
+        p[p < 0.0] = 0.0
+        p /= p.sum()
+        p2 = p - np.quantile(p, SNRfloor)
+        p2[p2 < 0.0] = 0.0
+        if p2.sum() > 1e-10:
+            p = p2
+        p = p / p.sum()
+        if np.isnan(p).any():
+            raise ValueError("AliasingScalarSampler got NaN because of particular values in p_x")
+        self.domain, self.weights = x, p
+
+    def mean_sqrtcov(self):
+        return np.zeros(1), np.zeros((1, 1))
+
+    def table_belief(self):
+        """the table as the device holds it: a belief on Euclid(2), row 0 the domain, row 1 the cumulative weights"""
+        cum = np.cumsum(self.weights)
+        cum[-1] = 1.0
+        return np.stack([self.domain, cum], axis=1), np.ones(2)
+
+
 class MvNormal:
     """MvNormal(mu, Sigma).  Like Distributions.jl, a vector second argument is a vector of
     standard deviations (`MvNormal(mu, sigma::Vector)`), a matrix is the covariance."""
@@ -120,6 +152,23 @@ class _Factor:
         """list of (weight, mean, sqrtcov, family) measurement components; family: abi.DIST_* (scalar measurements)"""
         mu, L = self.Z.mean_sqrtcov()
         return [(1.0, mu, L, getattr(self.Z, "family", abi.DIST_GAUSSIAN))]
+
+    # a factor whose measurement model (or one component of it) is an AliasingScalarSampler keeps the sampler's table in a
+    # device slot of its own, planned and written like the density of a PartialPriorPassThrough: `slot`, `density_belief()`
+    # and `density_manifold` are what the slot planners (solver._plan_densities, native_host.place_densities) read
+    slot = None
+    density_manifold = abi.EUCLID2
+
+    @property
+    def table(self):
+        zs = getattr(self, "comps", None) or [getattr(self, "Z", None)]
+        tb = [z for z in zs if isinstance(z, AliasingScalarSampler)]
+        if len(tb) > 1:
+            raise ValueError("one AliasingScalarSampler per factor")
+        return tb[0] if tb else None
+
+    def density_belief(self):
+        return self.table.table_belief()
 
 
 class Prior(_Factor):

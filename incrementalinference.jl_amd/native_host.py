@@ -249,6 +249,9 @@ def _clique_prepare(backend, sp, clique_id, variables, nfrontals, nseparators, m
         if f.fnc.kind == abi.F_PASSTHROUGH:
             pts, bw = f.fnc.density_belief()
             dens.append(Belief(f.fnc.varType.manifold, pts, bw))
+        elif getattr(f.fnc, "table", None) is not None:  # the table of an AliasingScalarSampler measurement
+            pts, bw = f.fnc.density_belief()
+            dens.append(Belief(f.fnc.density_manifold, pts, bw))
         else:
             dens.append(None)
     if any(d is not None for d in dens):

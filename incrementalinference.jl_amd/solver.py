@@ -83,9 +83,9 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
             for i in range(min(3, L.shape[0])):
                 for j in range(i + 1):
                     row[4 + 3 * i + j] = float(L[i, j])
-            if len(comp) > 3 and comp[3] != abi.DIST_GAUSSIAN:  # scalar Uniform / Rayleigh: the family rides in the last slot
+            if len(comp) > 3 and comp[3] != abi.DIST_GAUSSIAN:  # scalar Uniform / Rayleigh / table: the family rides in the last slot
                 if len(mu) != 1:
-                    raise ValueError("Uniform / Rayleigh measurements are scalar")
+                    raise ValueError("Uniform / Rayleigh / AliasingScalarSampler measurements are scalar")
                 row[12] = float(comp[3])
             flat.append(row)
         try:
@@ -95,6 +95,10 @@ def proposal_desc(fg, fct, target, slot_of, out_slot, seed, nullSurplus=0.0, mhi
     d.ncomp = len(flat)
     for c, row in enumerate(flat):
         d.comp[c][:] = row
+    if getattr(fnc, "table", None) is not None:  # AliasingScalarSampler: its table lives in the factor's own slot
+        if len(fct.variables) >= abi.MAXV:
+            raise ValueError("a factor with an AliasingScalarSampler takes at most MAXV - 1 variables")
+        d.var_slot[abi.MAXV - 1] = fnc.slot
     if getattr(fnc, "meas_slot", None) is not None:  # measurement = the KDE in that slot
         d.meas_kde = fnc.meas_slot + 1
     if fct.multihypo is not None:
@@ -125,9 +129,15 @@ def product_desc(manifold, in_slots, out_slot, seed, niter=1, labels_out=-1, par
     return d
 
 
+def has_density(fnc):
+    """a factor that keeps something in a device slot of its own: the density of a PartialPriorPassThrough, or the table of
+    an AliasingScalarSampler measurement"""
+    return isinstance(fnc, PartialPriorPassThrough) or getattr(fnc, "table", None) is not None
+
+
 def passthrough_factors(fg, labels=None):
-    """labels of the PartialPriorPassThrough factors (of the whole graph, or among `labels`)"""
-    return [f for f in (fg.lsf() if labels is None else labels) if isinstance(fg.getFactor(f).fnc, PartialPriorPassThrough)]
+    """labels of the factors with a density slot (of the whole graph, or among `labels`)"""
+    return [f for f in (fg.lsf() if labels is None else labels) if has_density(fg.getFactor(f).fnc)]
 
 
 def _plan_densities(fg, labels, first_slot):
@@ -142,7 +152,7 @@ def write_densities(fg, be, labels=None):
     for f in passthrough_factors(fg, labels):
         fnc = fg.getFactor(f).fnc
         pts, bw = fnc.density_belief()
-        be.belief_write(fnc.slot, fnc.varType.manifold, pts, bw)
+        be.belief_write(fnc.slot, fnc.varType.manifold if isinstance(fnc, PartialPriorPassThrough) else fnc.density_manifold, pts, bw)
 
 
 def _partials(fcts):
@@ -323,6 +333,8 @@ def _sample_components(comps, N, seed):
     for n in range(N):
         comp = comps[lbl[n]]
         mu, L, fam = comp[1], comp[2], (comp[3] if len(comp) > 3 else abi.DIST_GAUSSIAN)
+        if fam == abi.DIST_TABLE:
+            raise NotImplementedError("approxDeconv of a prior with an AliasingScalarSampler")
         if fam == abi.DIST_UNIFORM:
             out.append(np.asarray(mu) + np.asarray(L)[0] * rng.uniform())
         elif fam == abi.DIST_RAYLEIGH:

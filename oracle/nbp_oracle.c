@@ -810,6 +810,13 @@ void orc_run_bandwidth(double *arena, int32_t N, int32_t slot, int32_t manifold)
 /* ------------------------------------------------------------------------------------------ */
 /* Proposal = approxConvBelief (ApproxConv.jl:4-45)                                            */
 /* ------------------------------------------------------------------------------------------ */
+/* rand(::AliasingScalarSampler) (entities/AliasScalarSampling.jl:57-66): a domain value drawn by its weight */
+static double table_draw(const double *tb, int N, double u) {
+  const int K = slot_count(tb, N);
+  int i = 0;
+  while (i < K - 1 && !(u < tb[N + i])) i++; /* row 1: cumulative weights */
+  return tb[i];
+}
 static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, double *z, int *label, const double *arena, int N) {
   /* needFreshMeasurements = false (SolveTree.jl:119): the samples are the ones an earlier op drew */
   const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
@@ -842,7 +849,8 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
   if (zdim == 1 && cp[12] != 0.0) { /* rand(Uniform(a, b)) / rand(Rayleigh(sigma)): enum nbp_dist, include/nbp.h */
     double ua, ub;
     orc_uniform_pair(mseed, n, PURP_MEAS, 0, &ua, &ub);
-    z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
+    if (cp[12] == (double)NBP_DIST_TABLE) z[0] = table_draw(arena + orc_slot_stride(N) * d->var_slot[NBP_MAXV - 1], N, ua);
+    else z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
     z[1] = z[2] = 0;
     return;
   }

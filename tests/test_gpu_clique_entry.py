@@ -24,7 +24,19 @@ def _graphs():
     def lattice():
         return iif.generateSE2Lattice(rows=2, cols=4, N=128, closeEvery=2)
 
-    return {"kaess": kaess, "euclid2_chain": chain, "circular_doors_multihypo": doors, "se2_lattice": lattice}
+    def alias():
+        # tabulated measurements (AliasingScalarSampler: the table rides in nbp_clique_desc.factor_density[f])
+        fg = iif.initfg(iif.SolverParams(N=128))
+        bss = iif.AliasingScalarSampler([1.0, 1.5, 2.0, 6.0], [0.05, 0.4, 0.4, 0.15])
+        for i in range(5):
+            iif.addVariable(fg, f"x{i}", iif.ContinuousScalar)
+        iif.addFactor(fg, ["x0"], iif.Prior(iif.Normal(0.0, 0.1)))
+        iif.addFactor(fg, ["x4"], iif.Mixture(iif.Prior, (iif.Normal(7.0, 0.5), iif.AliasingScalarSampler([6.0, 7.0, 8.0, 30.0], [1.0, 3.0, 2.0, 1.5])), [0.5, 0.5]))
+        for i in range(4):
+            iif.addFactor(fg, [f"x{i}", f"x{i + 1}"], iif.LinearRelative(bss if i % 2 == 0 else iif.Normal(1.5, 0.2)))
+        return fg
+
+    return {"kaess": kaess, "euclid2_chain": chain, "circular_doors_multihypo": doors, "se2_lattice": lattice, "alias_sampler_tables": alias}
 
 
 @pytest.mark.parametrize("name", list(_graphs()))

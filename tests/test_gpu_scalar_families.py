@@ -23,3 +23,16 @@ def test_mixture_with_a_uniform_component(hip_backend, oracle_backend):
 
 def test_rayleigh_relative(hip_backend, oracle_backend):
     np.testing.assert_allclose(sc.case_rayleigh_relative(hip_backend), sc.case_rayleigh_relative(oracle_backend), rtol=1e-7, atol=1e-7)
+
+
+def test_alias_sampler_prior(hip_backend, oracle_backend):
+    np.testing.assert_array_equal(sc.case_alias_sampler_prior(hip_backend), sc.case_alias_sampler_prior(oracle_backend))
+
+
+def test_mixture_with_an_alias_sampler(hip_backend, oracle_backend):
+    np.testing.assert_allclose(sc.case_mixture_with_an_alias_sampler(hip_backend), sc.case_mixture_with_an_alias_sampler(oracle_backend),
+                               rtol=1e-12, atol=1e-12)
+
+
+def test_alias_sampler_relative(hip_backend, oracle_backend):
+    np.testing.assert_allclose(sc.case_alias_sampler_relative(hip_backend), sc.case_alias_sampler_relative(oracle_backend), rtol=1e-7, atol=1e-7)

@@ -22,6 +22,18 @@ def test_rayleigh_relative(oracle_backend):
     sc.case_rayleigh_relative(oracle_backend)
 
 
+def test_alias_sampler_prior(oracle_backend):
+    sc.case_alias_sampler_prior(oracle_backend)
+
+
+def test_mixture_with_an_alias_sampler(oracle_backend):
+    sc.case_mixture_with_an_alias_sampler(oracle_backend)
+
+
+def test_alias_sampler_relative(oracle_backend):
+    sc.case_alias_sampler_relative(oracle_backend)
+
+
 def test_families_are_scalar_only():
     with pytest.raises(ValueError):
         iif.Uniform(1.0, 1.0)
