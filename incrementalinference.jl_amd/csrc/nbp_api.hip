@@ -799,9 +799,12 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   if (lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: too many densities for the LDS label table");
   // resident levels (NBP_PROD_ALL_LEVELS): the statistics of every tree level staged once, no barrier between the levels
   // of the Gibbs walk -- where two workgroups of the launch still fit a CU's 160 KB
-  static const size_t all_cap = getenv("NBP_PRODUCT_ALL_LEVELS_KB") ? (size_t)atoi(getenv("NBP_PRODUCT_ALL_LEVELS_KB")) * 1024 : 0;  // measured: no gain, off
+  static const size_t all_cap = getenv("NBP_PRODUCT_ALL_LEVELS_KB") ? (size_t)atoi(getenv("NBP_PRODUCT_ALL_LEVELS_KB")) * 1024 : 76 * 1024;
   int flagsF = F;
-  if (!big) {
+  // (the latency geometries only: a lone product saves nine round trips to the KD workspace and eighteen barriers, 126 -> 116 us;
+  //  a chip-filling launch gains nothing -- NBP_PRODUCT_ALL_LEVELS_HL = 2 switches it on there too)
+  static const int all_hl = getenv("NBP_PRODUCT_ALL_LEVELS_HL") ? atoi(getenv("NBP_PRODUCT_ALL_LEVELS_HL")) : 8;
+  if (!big && HL >= all_hl) {
     const int TOT = c->T.off[c->T.L] + c->T.cnt[c->T.L];
     const size_t lds_all = product_lds_layout(F, D, c->N, SPB, false, nullptr, nullptr, TOT) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
     if (lds_all <= all_cap) { lds = lds_all; flagsF |= NBP_PROD_ALL_LEVELS; }

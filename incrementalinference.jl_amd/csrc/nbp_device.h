@@ -307,6 +307,49 @@ __device__ __forceinline__ double wave_inclusive_scan(double x) {
   s += dpp_f64<0x143, 0xc, 0xf>(s);             // row_bcast:31 into rows 2 and 3
   return s;
 }
+// ---- reductions over an aligned group of HL adjacent lanes (HL = 2 .. 32: the helper lanes of one product sample) --------
+// Data moves through DPP (quad permutes, row mirrors, row shifts, row_bcast:15) instead of ds_bpermute: a dependent chain of
+// five bpermute steps is ~600 cycles of LDS-crossbar latency, the same steps on the VALU ~150 -- what a lone product's draws
+// are made of.  Only the step across the two rows of a 32-lane group, and the broadcast of a group's last lane for HL >= 8,
+// still take a bpermute.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int HL>
+__device__ __forceinline__ double group_max(double v) {  // every lane of the group receives the maximum
+  if (HL >= 2) v = fmax(v, dpp_f64<0xB1, 0xf, 0xf>(v));    // quad_perm [1,0,3,2]
+  if (HL >= 4) v = fmax(v, dpp_f64<0x4E, 0xf, 0xf>(v));    // quad_perm [2,3,0,1]
+  if (HL >= 8) v = fmax(v, dpp_f64<0x141, 0xf, 0xf>(v));   // row_half_mirror: the other quad of the 8
+  if (HL >= 16) v = fmax(v, dpp_f64<0x140, 0xf, 0xf>(v));  // row_mirror: the other half of the row
+  if (HL >= 32) v = fmax(v, __shfl_xor(v, 16, 32));
+  return v;
+}
+template <int HL>
+__device__ __forceinline__ int group_max(int v) {
+  if (HL >= 2) v = max(v, dpp_i32<0xB1, 0xf, 0xf>(v));
+  if (HL >= 4) v = max(v, dpp_i32<0x4E, 0xf, 0xf>(v));
+  if (HL >= 8) v = max(v, dpp_i32<0x141, 0xf, 0xf>(v));
+  if (HL >= 16) v = max(v, dpp_i32<0x140, 0xf, 0xf>(v));
+  if (HL >= 32) v = max(v, __shfl_xor(v, 16, 32));
+  return v;
+}
+// inclusive prefix sum in lane order inside the group; h = the lane's place in its group; *total = the group's sum
+template <int HL>
+__device__ __forceinline__ double group_inclusive_scan(double x, int h, double *total) {
+  const int r = h & 15;  // place in the row of 16 (groups are aligned: up to 16 lanes share a row)
+  double s = x, v;
+  if (HL >= 2) { v = dpp_f64<0x111, 0xf, 0xf>(s); if (r >= 1 && (HL >= 16 || h >= 1)) s += v; }  // row_shr:1
+  if (HL >= 4) { v = dpp_f64<0x112, 0xf, 0xf>(s); if (r >= 2 && (HL >= 16 || h >= 2)) s += v; }  // row_shr:2
+  if (HL >= 8) { v = dpp_f64<0x114, 0xf, 0xf>(s); if (r >= 4 && (HL >= 16 || h >= 4)) s += v; }  // row_shr:4
+  if (HL >= 16) { v = dpp_f64<0x118, 0xf, 0xf>(s); if (r >= 8) s += v; }                        // row_shr:8
+  if (HL >= 32) s += dpp_f64<0x142, 0xa, 0xf>(s);  // row_bcast:15: the first row's total into the second row of the group
+  if (HL == 2) *total = dpp_f64<0xF5, 0xf, 0xf>(s);       // quad_perm [1,1,3,3]
+  else if (HL == 4) *total = dpp_f64<0xFF, 0xf, 0xf>(s);  // quad_perm [3,3,3,3]
+  else *total = __shfl(s, HL - 1, HL);
+  return s;
+}
+
 // exclusive prefix sum over the workgroup in lane order (wave scans, wave totals through `red`); *total = the sum
 __device__ __forceinline__ double block_exclusive_scan(double v, double *red, double *total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -1116,6 +1116,11 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         };
         // chunk size of this helper's range: a multiple of 4, the pass-1 loop takes the nodes four at a time
         const int zr = z1 - z0, csz = (((zr + NCH - 1) / NCH) + 3) & ~3;
+        // latency geometries (many helpers per sample): a level with at most SR nodes per helper -- every level of a
+        // 200-particle tree at 32 helpers -- keeps the weights in registers: no chunks, no rescan, one exponential per node
+        constexpr int SR = (HL >= 8) ? 8 : 1;
+        const bool shortr = (HL >= 8) && (cnt + HL - 1) / HL <= SR;
+        double wr[SR], gr[SR];
         NBP_CTICK(40);
         if (live) {
 #pragma unroll
@@ -1152,6 +1157,21 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           }
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + (it < 0 ? 7 : it)) * NBP_MAXF + j), ua, ub);
           NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
+          if (shortr) {  // at most SR nodes per helper: their weights stay in registers, nothing is evaluated twice
+#pragma unroll
+            for (int i = 0; i < SR; i++) {
+              double a = -INFINITY, g = 0.0;
+              if (z0 + i < z1) node_w(z0 + i, a, g);
+              wr[i] = a;
+              gr[i] = g;
+              m = fmax(m, a);
+            }
+#pragma unroll
+            for (int i = 0; i < SR; i++) {
+              wr[i] = (z0 + i < z1) ? exp_nonpos(wr[i] - m, L.tab) * gr[i] : 0.0;
+              tot += wr[i];
+            }
+          } else
 #pragma unroll
           for (int c = 0; c < NCH; c++) {
             double cur = 0;
@@ -1198,20 +1218,26 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         NBP_CTICK(56 + (leaf ? 2 : 0) + (XP ? 1 : 0));  // pass 1: node weights of this helper's range (56 sweep, 57 on the point; 58 / 59 leaf level)
         // combine over the HL helper lanes of the sample (adjacent lanes of this wave): common max,
         // shares rescaled to it, inclusive prefix sum -> the one helper whose interval holds u * total
-        double Mx = m;
-#pragma unroll
-        for (int o = 1; o < HL; o <<= 1) Mx = fmax(Mx, __shfl_xor(Mx, o, HL));
+        const double Mx = group_max<HL>(m);
         const double share = (tot > 0) ? tot * exp_nonpos(m - Mx, L.tab) : 0.0;
-        double incl = share;
-#pragma unroll
-        for (int o = 1; o < HL; o <<= 1) {
-          const double v = __shfl_up(incl, o, HL);
-          if (h >= o) incl += v;
-        }
-        const double total = __shfl(incl, HL - 1, HL), target = ua * total, before = incl - share;
+        double total;
+        const double incl = group_inclusive_scan<HL>(share, h, &total);
+        const double target = ua * total, before = incl - share;
         int choice = -1;
         NBP_CTICK(45);  // shuffle combine
-        if (live && share > 0 && target >= before && target < incl) {
+        if (shortr) {
+          if (live && share > 0 && target >= before && target < incl) {
+            const double f = exp_nonpos(m - Mx, L.tab);
+            double c = before;
+            choice = z1 - 1;
+            bool hit = false;
+#pragma unroll
+            for (int i = 0; i < SR; i++) {
+              c += wr[i] * f;
+              if (!hit && z0 + i < z1 && target < c) { choice = z0 + i; hit = true; }
+            }
+          }
+        } else if (live && share > 0 && target >= before && target < incl) {
           // pass 2 inside this helper's own range: find the chunk that holds `target`, rescan only it
           double cacc = before;
           int za = z0, zb = z1;
@@ -1237,8 +1263,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             }
           }
         }
-#pragma unroll
-        for (int o = 1; o < HL; o <<= 1) choice = max(choice, __shfl_xor(choice, o, HL));
+        choice = group_max<HL>(choice);
         if (choice < 0) choice = cnt - 1;  // rounding left u * total beyond the last share
         if (h == 0 && live) ind[j * SPB + sl] = choice;
         NBP_CTICK(60 + (leaf ? 2 : 0) + (XP ? 1 : 0));  // pass 2: rescan of the chosen chunk + broadcast of the choice
