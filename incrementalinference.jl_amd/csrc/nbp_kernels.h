@@ -1119,7 +1119,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         // latency geometries (many helpers per sample): a level with at most SR nodes per helper -- every level of a
         // 200-particle tree at 32 helpers -- keeps the weights in registers: no chunks, no rescan, one exponential per node
         constexpr int SR = (HL >= 8) ? 8 : 1;
-        const bool shortr = (HL >= 8) && (cnt + HL - 1) / HL <= SR;
+        const int nzmax = (cnt + HL - 1) / HL;
+        const bool shortr = (HL >= 8) && nzmax <= SR;
         double wr[SR], gr[SR];
         NBP_CTICK(40);
         if (live) {
@@ -1158,8 +1159,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + (it < 0 ? 7 : it)) * NBP_MAXF + j), ua, ub);
           NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
           if (shortr) {  // at most SR nodes per helper: their weights stay in registers, nothing is evaluated twice
+            // (nzmax = the longest range of the level, wave-uniform: the coarse levels of a 32-helper geometry have one node
+            //  per helper or none, and the unrolled slots beyond that are branched over, not predicated through)
+#pragma unroll
+            for (int i = 0; i < SR; i++) { wr[i] = 0.0; gr[i] = 0.0; }
 #pragma unroll
             for (int i = 0; i < SR; i++) {
+              if (i >= nzmax) break;
               double a = -INFINITY, g = 0.0;
               if (z0 + i < z1) node_w(z0 + i, a, g);
               wr[i] = a;
@@ -1168,6 +1174,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             }
 #pragma unroll
             for (int i = 0; i < SR; i++) {
+              if (i >= nzmax) break;
               wr[i] = (z0 + i < z1) ? exp_nonpos(wr[i] - m, L.tab) * gr[i] : 0.0;
               tot += wr[i];
             }
@@ -1233,6 +1240,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             bool hit = false;
 #pragma unroll
             for (int i = 0; i < SR; i++) {
+              if (i >= nzmax) break;
               c += wr[i] * f;
               if (!hit && z0 + i < z1 && target < c) { choice = z0 + i; hit = true; }
             }
