@@ -1245,6 +1245,55 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               if (!hit && z0 + i < z1 && target < c) { choice = z0 + i; hit = true; }
             }
           }
+        } else if constexpr (HL <= 4) {
+          // pass 2, throughput geometries: the helper whose share holds the target locates the chunk; ALL helpers of the
+          // sample then rescan it together -- a row of HL nodes at a time, prefix over the row through DPP -- instead of
+          // idling while the one lane walks it (the rescan was a fifth of a chip-filling launch)
+          const bool own = live && share > 0 && target >= before && target < incl;
+          int pk = -1;
+          double cb = -INFINITY;
+          if (own) {
+            double cacc = before;
+            int za = z0, zb = z1;
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+              const double shc = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
+              const int ca = z0 + c * csz, cb_ = min(z1, ca + csz);
+              if (!found && ca < cb_) {
+                za = ca; zb = cb_;  // the last non-empty chunk is the fallback
+                if (target < cacc + shc) found = true;
+                else cacc += shc;
+              }
+            }
+            choice = zb - 1;
+            if (found) { pk = (za << 10) | (zb - za); cb = cacc; }
+          }
+          pk = group_max<HL>(pk);
+          cb = group_max<HL>(cb);
+          if (pk >= 0) {
+            const int za = pk >> 10, len = pk & 1023, rows = (len + HL - 1) / HL;
+            constexpr int NOHIT = 1 << 20;
+            int hitz = NOHIT;
+            double base = cb;
+            for (int r = 0; r < rows; r++) {
+              const int z = za + r * HL + h;
+              const bool valid = z < za + len;
+              double w = 0.0;
+              if (valid) {
+                double a, g;
+                node_w(z, a, g);
+                w = exp_nonpos(a - Mx, L.tab) * g;
+              }
+              double rowtot;
+              const double inc = group_inclusive_scan<HL>(w, h, &rowtot);
+              if (valid && target < base + inc) hitz = min(hitz, z);
+              if (group_max<HL>(hitz < NOHIT ? 1 : 0)) break;
+              base += rowtot;
+            }
+            const int best = -group_max<HL>(-hitz);  // the first node, in node order, whose cumulative weight passes the target
+            choice = best < NOHIT ? best : za + len - 1;
+          }
         } else if (live && share > 0 && target >= before && target < incl) {
           // pass 2 inside this helper's own range: find the chunk that holds `target`, rescan only it
           double cacc = before;
