@@ -1074,7 +1074,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         // Pass 2 (the helper whose share holds u * total): locate the chunk, re-evaluate just that chunk.
         auto draw = [&](auto xp_c) {
         constexpr bool XP = decltype(xp_c)::value;  // sampleIndices!: the label given the POINT x (nothing added to a node's variance)
-        constexpr int NCH = 4;
+#ifndef NBP_X_NCH
+#define NBP_X_NCH 2  // (four chunks cost sixteen more registers: 51 spilled at four waves per SIMD, 142 MB of scratch traffic per chip-filling launch; with the helpers rescanning a chunk together the longer chunk costs nothing)
+#endif
+        constexpr int NCH = NBP_X_NCH;
         double mn[D], vn[D], ua = 0, ub = 0, m = -INFINITY, tot = 0;
         double cs[NCH], ms[NCH];
         const double *mj = lm + j * D * NS + lb, *vj = lv + j * D * NS + lb, *rj = lr + j * D * NS + lb, *gj = lgw + j * NS + lb;
@@ -1328,7 +1331,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         // (the throughput geometries instantiate the draw on the point separately: g_z and the precisions from the staging,
         //  no rsqrt per node; in the latency kernels -- five manifolds x partial x big in one kernel -- the second copy costs
         //  300 spilled registers and goes through the general form)
-        if (HL <= 4 && it < 0) draw(std::true_type{});
+#ifndef NBP_X_XP_HL
+#define NBP_X_XP_HL 4
+#endif
+        if (HL <= NBP_X_XP_HL && it < 0) draw(std::true_type{});
         else draw(std::false_type{});
       }
     }

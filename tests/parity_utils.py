@@ -96,9 +96,9 @@ def both(oracle_factory, hip_factory, N, n_slots, side_ints, setup, run, read):
 
 
 def record_parity(line):
-    """append one line to gpurun_out/r03_whole_solve_parity.txt (the -m gpu suite's whole-solve figures: shares of
+    """append one line to gpurun_out/r04_whole_solve_parity.txt (the -m gpu suite's whole-solve figures: shares of
     particle-identical variables, KL medians, mode shares; copied to profiles/ after a GPU run)"""
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r03_whole_solve_parity.txt"), "a") as f:
+    with open(os.path.join(d, "r04_whole_solve_parity.txt"), "a") as f:
         f.write(line.rstrip("\n") + "\n")

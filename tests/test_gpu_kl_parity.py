@@ -9,7 +9,7 @@ from parity_utils import abi, iif, record_parity
 
 # Floors on the share of variables whose particles agree with the oracle's particle by particle (1e-6) in ONE solve with
 # identical random streams -- below them something other than a rare last-bit branch flip separates the two sides.
-# Observed on MI355X (profiles/r03_whole_solve_parity.txt) minus a margin; a variable that diverged is then held to the
+# Observed on MI355X (profiles/r04_whole_solve_parity.txt) minus a margin; a variable that diverged is then held to the
 # two-sample criterion of tests/kl_parity.py.
 # The configurations with THREE-dimensional Nelder-Mead searches (SE(2), Euclid(3)) are the exception: those searches stop
 # at a spread of 1e-8 of the OBJECTIVE, which leaves the root to ~1e-4, and device and host part ways inside that within a

@@ -37,5 +37,5 @@ def test_random_graph_solve_matches_oracle(oracle_backend, hip_backend, seed):
     print(line)
     record_parity(line)
     # (no floor here: eight of the twelve graphs come out particle-identical, the ones with three-dimensional searches or
-    #  inconsistent multihypo loops part ways early -- profiles/r03_whole_solve_parity.txt -- and are held to the
+    #  inconsistent multihypo loops part ways early -- profiles/r04_whole_solve_parity.txt -- and are held to the
     #  two-sample criterion above)

@@ -2,8 +2,8 @@
 # The round's evidence in one GPU call: plain bench line, kernel trace of the same command (+ timed-region summary,
 # per-kernel stats, the launches of one solve and of graph initialisation in order), PMC passes (HBM traffic) for the
 # default launch form and for the fused update kernel, the other configs, micro-benchmarks and SQ counters.
-# Output under gpurun_out/$TAG; copy what is to be judged into profiles/.   Usage (on the GPU box): tools/collect_profiles.sh r03
-TAG=${1:-r03}
+# Output under gpurun_out/$TAG; copy what is to be judged into profiles/.   Usage (on the GPU box): tools/collect_profiles.sh r04
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
@@ -22,7 +22,13 @@ cd $R
 tools/pmc_quick.sh $TAG/pmc_default NBP_X=1 > $O/pmc_traffic.txt 2>&1
 tools/pmc_quick.sh $TAG/pmc_fused NBP_FUSED_MIN=256 > $O/pmc_traffic_fused.txt 2>&1
 cd /tmp
-for c in 3 4 5; do python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; done
+for c in 3 4 5; do
+  python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err
+  rocprofv3 --kernel-trace --stats -d $O/trace_c$c -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-profile-pass > /dev/null 2> $O/trace_c$c.err
+  python $R/tools/summarize_trace.py $O/trace_c$c 3 > $O/bench_config${c}_timed_region_summary.txt
+  python $R/tools/kernel_stats.py $O/trace_c$c > $O/bench_config${c}_kernel_stats.csv
+  rm -rf $O/trace_c$c
+done
 python $R/tools/lcv_bench.py > $O/lcv_microbench.txt 2>/dev/null
 # SQ counters of the chip-filling bandwidth fit (two passes of 8 counters)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU -d $O/sq/p1 -- python $R/tools/lcv_bench.py 200 2048 > /dev/null 2>&1
@@ -39,8 +45,11 @@ done
 # time, and how busy the lanes of the per-particle searches are
 if [ -f $R/tools/libnbp_dbg.so ]; then
   NBP_NO_SPECULATIVE_FITS=1 python $R/tools/lcv_phase_timing.py > $O/lcv_phase_timing.txt 2>/dev/null
+  python $R/tools/product_phase_timing.py > $O/product_phase_timing.txt 2>/dev/null
   python $R/tools/exp/nm_lane_util.py > $O/search_lane_utilisation.txt 2>/dev/null
   for a in "488 2" "975 2" "4000 2"; do python $R/tools/exp/fused_phase.py $a 2>/dev/null; done > $O/fused_phase_timing.txt
 fi
-rm -rf $O/trace/*/*.db.tmp $O/sq $O/sq_prop $O/sq_prod
+# several ranks sharing the one GPU (gloo, host-staged exchange): every leg of tests/test_gpu_bench.py three times, the posterior sha of every rank
+(cd $R && tools/exp/loop_multirank.sh 3 > /dev/null 2>&1; cp gpurun_out/mr_loop/summary.txt $O/multirank_shared_gpu.txt)
+rm -rf $O/trace $O/sq $O/sq_prop $O/sq_prod
 du -sh $O
