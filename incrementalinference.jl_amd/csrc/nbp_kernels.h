@@ -349,8 +349,10 @@ __device__ __forceinline__ void proposal_body(const nbp_proposal_desc *d, double
   // manikde!(M, pts) (ApproxConv.jl:36-42): the bandwidth fit of this proposal runs in the prep launch
   // of its update (nbp_prep_kernel), or in nbp_bandwidth_kernel for the immediate-mode entry points;
   // this kernel keeps one lane per particle so that the Nelder-Mead simplex stays in registers.
+  // (only the rows the manifold has: nothing reads a row beyond them -- fits, KD builds, products and belief reads go by
+  //  the manifold; a third of a Euclid(2) proposal's write traffic)
   if (live)
-    for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
+    for (int k = 0; k < D; k++) out[k * N + n] = X[k * N + n];
   // infoPerCoord of the proposal: ones(D), zeroed outside the factor's `.partial` (EvalFactor.jl:383-391, :534-540)
   if (n < 3) out[3 * N + 3 + n] = (n < D && (!d->partial_mask || ((d->partial_mask >> n) & 1))) ? 1.0 : 0.0;
   if (n == 0) out[3 * N + 6] = 0.0;  // a proposal always holds N points

@@ -2,6 +2,7 @@
 # HBM traffic of the config-2 solve in three PMC passes (FETCH_SIZE, WRITE_SIZE, L2 hit / miss; no tracing).
 # Usage (on the GPU box): tools/pmc_quick.sh <tag> [ENV=VALUE ...]     -> gpurun_out/<tag>/pmc_traffic.json
 TAG=$1; shift
+[ -n "$TAG" ] || { echo "usage: tools/pmc_quick.sh <tag> [ENV=VALUE ...]"; exit 2; }
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
