@@ -256,7 +256,10 @@ nbp_status nbp_clique_upsolve_joint(nbp_ctx *ctx, const nbp_solver_params *param
  * one transfer of beliefs each way and one program whose k-th launches serve the k-th round of every clique.  Up and down
  * requests may be mixed.  Each request is what the single calls take (diff_out: NULL, or clique->n_diff entries as in
  * nbp_clique_upsolve_joint); `status` is written on success.  The random streams are keyed by (seed, pass, clique_id, step,
- * factor), so every belief comes out as the single calls deliver it, bit for bit.  The context needs the sum of
+ * factor), so every belief comes out as the single calls deliver it: bit for bit where the launches of batch and single
+ * call pick the same geometry (the cliques of a chain or a small tree), and to summation-order rounding (1e-9 on the
+ * particles) otherwise -- helper lanes per sample, helper rows of a fit and the speculative search are chosen by the
+ * number of updates in a launch, and a batch has more of them.  The context needs the sum of
  * nbp_clique_slots over the requests.  This is the entry for a host that keeps the control flow of the state machines but
  * gathers the cliques that are ready (the per-clique seam is bound by the latency of each clique's own
  * launches; batched, the cliques of a level share them). */

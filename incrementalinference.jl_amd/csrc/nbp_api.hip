@@ -611,6 +611,9 @@ static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int
 static nbp_status ensure_ws(nbp_ctx *c, int nprod, int kdF) {
   const size_t need = (size_t)nprod * (size_t)kdF * nbp_kd_ws_doubles(c->N);
   if (need <= c->ws_doubles) return NBP_OK;
+  // inside a two-stream round c->ws is an INTERIOR pointer of the workspace (the second half's share): it must never be
+  // freed or re-allocated here -- the round is sized at finalize, a shortfall now is a planning error, not a reason to grow
+  if (c->geom_n) return fail(NBP_ERR_RANGE, "KD workspace too small inside a two-stream round (sized at nbp_program_finalize)");
   HIPCHK(hipStreamSynchronize(c->stream));
   if (c->ws) HIPCHK(hipFree(c->ws));
   c->ws = nullptr;

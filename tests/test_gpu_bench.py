@@ -72,6 +72,32 @@ def test_bench_ranks_sharing_one_gpu(config, size, scaling, world):
         assert d["config"]["variables_per_gpu"] == 300 and d["posterior_max_mean_err"] < 1.5
 
 
+def _shas(out):
+    """{rank: posterior sha} from the `[bench rank N] ... sha=...` lines"""
+    import re
+    return {int(m.group(1)): m.group(2) for m in re.finditer(r"\[bench rank (\d+)\] posterior_max_mean_err=.*?sha=([0-9a-f]+)", out.stderr)}
+
+
+def test_ranks_in_lock_step_are_deterministic_and_equal_to_the_sequential_fits():
+    """Two ranks driving ONE device in lock step: the posteriors of a rank are the same run after run, with the speculative
+    bandwidth fits and without them (round 3's red gate: the rendezvous areas of the speculative fits were blanked with
+    hipMemsetAsync, which was not ordered with the fit kernel under a second process -- stale values of the previous launch
+    were consumed and every run differed)"""
+    def run(port, extra_env):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "2", "--nvars", "300",
+                              "--dist-backend", "gloo", "--no-cpu-baseline", "--no-profile-pass"],
+                             cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, _why(out)
+        sh = _shas(out)
+        assert set(sh) == {0, 1}, out.stderr[-2000:]
+        return sh
+    a, b, c = run(29571, {}), run(29572, {}), run(29573, {"NBP_NO_SPECULATIVE_FITS": "1"})
+    assert a == b, (a, b)
+    assert a == c, (a, c)
+
+
 def test_bench_two_ranks_if_two_gpus():
     """cliques sharded over 2 GPUs with RCCL point-to-point separator exchange; skipped on 1-GPU boxes
     (the world-2 logic itself is covered on CPU by tests/test_dist_gloo.py)"""
