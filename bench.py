@@ -67,7 +67,7 @@ def kernel_sources_sha():
     h = hashlib.sha1()
     csrc = os.path.join(ROOT, "incrementalinference.jl_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip")):
+        if f.endswith(".h") or (f.startswith("nbp_k_") and f.endswith(".hip")):  # device code; nbp_api.hip is host code
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
