@@ -1121,11 +1121,14 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
         };
         // chunk size of this helper's range: a multiple of 4, the pass-1 loop takes the nodes four at a time
         const int zr = z1 - z0, csz = (((zr + NCH - 1) / NCH) + 3) & ~3;
-        // latency geometries (many helpers per sample): a level with at most SR nodes per helper -- every level of a
-        // 200-particle tree at 32 helpers -- keeps the weights in registers: no chunks, no rescan, one exponential per node
-        constexpr int SR = (HL >= 8) ? 8 : 1;
+        // a level with at most SR nodes per helper -- every level of a 200-particle tree at 32 helpers, the three or four
+        // coarsest levels at 2 or 4 -- keeps the weights in registers: no chunks, no rescan, one exponential per node
+#ifndef NBP_X_SR_THR
+#define NBP_X_SR_THR 0  // register slots of the short-range draw in the throughput geometries (0 = chunks on every level; 4: measured 1 % on config 2 for 8 spilled registers and an occupancy step on Euclid(3): off)
+#endif
+        constexpr int SR = (HL >= 8) ? 8 : (NBP_X_SR_THR > 0 ? NBP_X_SR_THR : 1);
         const int nzmax = (cnt + HL - 1) / HL;
-        const bool shortr = (HL >= 8) && nzmax <= SR;
+        const bool shortr = (HL >= 8 || NBP_X_SR_THR > 0) && nzmax <= SR;
         double wr[SR], gr[SR];
         NBP_CTICK(40);
         if (live) {
