@@ -954,10 +954,16 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   // ---- multiscale Gibbs (Ihler, Sudderth, Freeman, Willsky, NIPS 2003, sec. 4; the gibbs1 loop of KernelDensityEstimate.jl):
   //      per level  samplePoint! (x from the labels of the level above) -> levelDown! (the candidates of every density
   //      are ALL nodes of this level) -> sampleIndices! (every label given x, independently) -> Niter sweeps of sampleIndex
-  for (int l = 0; l <= T.L + 1; l++) {
-    if (l > 0 && live) {  // samplePoint!
+  // Passes: KernelDensityEstimate's Nlevels = floor(log2(maxNp) + 1) -- the depth of the tree, except that a particle count
+  // that is a power of two gets one pass more than its tree has levels: the leaf level twice (a leaf is its own child)
+  int npass = 1;
+  for (int n2_ = N; n2_ > 1; n2_ >>= 1) npass++;
+  if (npass < T.L) npass = T.L;
+  for (int ps = 0; ps <= npass + 1; ps++) {
+    const int l = ps < T.L ? ps : T.L;  // the tree level of this pass
+    if (ps > 0 && live) {  // samplePoint!
       double n0, n1, n2 = 0, n3 = 0;
-      const uint32_t purpose = (l <= T.L) ? PURP_PLEVEL : PURP_PFINAL, k0 = (l <= T.L) ? (uint32_t)(2 * l) : 0u;
+      const uint32_t purpose = (ps <= npass) ? PURP_PLEVEL : PURP_PFINAL, k0 = (ps <= npass) ? (uint32_t)(2 * ps) : 0u;
       const double2 na = normal_pair_call(d->seed, (uint32_t)s, purpose, k0);
       n0 = na.x;
       n1 = na.y;
@@ -972,10 +978,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
       }
     }
     NBP_CTICK(47);  // samplePoint!: the normals
-    if (l > T.L) break;
+    if (ps > npass) break;
     const int cnt = T.cnt[l], off = T.off[l];
     const int lb = all ? off : 0;  // where this level's nodes start in a row of the statistics
-    if (!all || l == 0) {
+    if ((!all || ps == 0) && ps <= T.L) {  // (a repeated leaf pass finds its statistics in place)
     __syncthreads();
     NBP_CTICK(40);  // staging (first level) / Gibbs draws of the previous level
     // node statistics: of this level, or (resident levels) of every level at once -- node g of the tree at row position
@@ -1064,7 +1070,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     // wave-uniform branch in front of every node weight (two taken branches per node in the pass-1 loop)
     auto sweep = [&](auto leaf_c) {
     constexpr bool leaf = decltype(leaf_c)::value;
-    for (int it = -1; l > 0 && it < d->niter; it++) {  // it = -1: sampleIndices! (every label given the point x of the level above)
+    for (int it = -1; ps > 0 && it < d->niter; it++) {  // it = -1: sampleIndices! (every label given the point x of the level above)
       for (int j = 0; j < F; j++) {  // sampleIndex(j): sequential Gibbs sweep
         // Draw l_j ~ p(l_j | others) by inverse CDF over the nodes of this level.
         //   weight_z = w_z * N(mean_z; mn, var_z + vn)  =  exp(a_z) * g_z,
@@ -1164,7 +1170,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
             for (int k = 0; k < D; k++) linv[k] = (PARTIAL && !use[k]) ? 0.0 : 1.0 / (h2[j * 3 + k] + vn[k]);
           }
-          uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + (it < 0 ? 7 : it)) * NBP_MAXF + j), ua, ub);
+          uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + (it < 0 ? 7 : it)) * NBP_MAXF + j), ua, ub);
           NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
           if (shortr) {  // at most SR nodes per helper: their weights stay in registers, nothing is evaluated twice
             // (nzmax = the longest range of the level, wave-uniform: the coarse levels of a 32-helper geometry have one node

@@ -1264,25 +1264,31 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   for (int s = 0; s < N; s++) {
     int ind[NBP_MAXF];
     for (int j = 0; j < F; j++) ind[j] = 0; /* levelInit! / initIndices!: root */
-    for (int l = 1; l <= T.L; l++) {
+    /* passes: KernelDensityEstimate's Nlevels = floor(log2(maxNp) + 1) = the depth of the tree, except that a power of two
+       gets one pass more than its tree has levels -- the leaf level twice (levelDown! leaves a leaf as its own child) */
+    int npass = 1;
+    for (int n2 = N; n2 > 1; n2 >>= 1) npass++;
+    if (npass < T.L) npass = T.L;
+    for (int ps = 1; ps <= npass; ps++) {
+      const int l = ps < T.L ? ps : T.L, lp = (ps - 1) < T.L ? ps - 1 : T.L; /* tree level of this pass / of the labels it starts from */
       /* One level of the multiscale sampler as published (Ihler, Sudderth, Freeman, Willsky, "Efficient multiscale
          sampling from products of Gaussian mixtures", NIPS 2003, sec. 4; KernelDensityEstimate.jl's gibbs1 loop follows
          it: samplePoint!, levelDown!, sampleIndices!, then Niter sweeps of sampleIndex):
            samplePoint!:    x ~ the product of the Gaussians selected on the level above,
            levelDown!:      the candidates of every density become ALL nodes of this level,
            sampleIndices!:  every density draws its label given x, independently:  p(z) ~ w_z N(x; mean_z, var_z). */
-      const int cp = T.cnt[l - 1], cnt = T.cnt[l];
+      const int cp = T.cnt[lp], cnt = T.cnt[l];
       double xp[3];
       int xinf[3];
       {
         double nn[4] = {0, 0, 0, 0};
-        orc_normal_pair(d->seed, s, PURP_PLEVEL, (uint32_t)(2 * l), &nn[0], &nn[1]);
-        if (D > 2) orc_normal_pair(d->seed, s, PURP_PLEVEL, (uint32_t)(2 * l + 1), &nn[2], &nn[3]);
+        orc_normal_pair(d->seed, s, PURP_PLEVEL, (uint32_t)(2 * ps), &nn[0], &nn[1]);
+        if (D > 2) orc_normal_pair(d->seed, s, PURP_PLEVEL, (uint32_t)(2 * ps + 1), &nn[2], &nn[3]);
         for (int k = 0; k < D; k++) {
           double prec = 0, acc = 0, ss = 0, sc = 0;
           for (int q = 0; q < F; q++) {
             if (!((pm[q] >> k) & 1)) continue;
-            double mq = nmean[q][l - 1][k * cp + ind[q]], rq = nprec[q][l - 1][k * cp + ind[q]];
+            double mq = nmean[q][lp][k * cp + ind[q]], rq = nprec[q][lp][k * cp + ind[q]];
             prec += rq;
             if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
             else acc += mq * rq;
@@ -1296,7 +1302,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
       }
       for (int j = 0; j < F; j++) {
         double ua, ub;
-        orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + 7) * NBP_MAXF + j), &ua, &ub);
+        orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + 7) * NBP_MAXF + j), &ua, &ub);
         double ev[NBP_MAXN]; double m = -INFINITY;
         for (int z = 0; z < cnt; z++) {
           double e = 0;
@@ -1333,7 +1339,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             mn[k] = is_circ(M, k) ? atan2(ss, sc) : acc * vn[k]; /* getMu: Euclid / getCircMu */
           }
           double ua, ub;
-          orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((l * 8 + it) * NBP_MAXF + j), &ua, &ub);
+          orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + it) * NBP_MAXF + j), &ua, &ub);
           /* rand(Categorical(p)) by inverse CDF (max-stabilised weights) */
           double u = ua; int choice = -1;
           {
