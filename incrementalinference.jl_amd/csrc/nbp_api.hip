@@ -533,7 +533,7 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
     const nbp_product_desc &p = d[i];
     if (!manifold_ok(p.manifold)) return fail(NBP_ERR_ARG, "product: unknown manifold");
     if (p.nfactors < 1 || p.nfactors > NBP_MAXF) return fail(NBP_ERR_RANGE, "product: nfactors");
-    if (p.niter < 1 || p.niter > 8) return fail(NBP_ERR_RANGE, "product: niter");
+    if (p.niter < 1 || p.niter > 7) return fail(NBP_ERR_RANGE, "product: niter (1 .. 7: the eighth stream of a level belongs to the draw on the point)");
     if (p.out_slot < 0 || p.out_slot >= c->n_slots) return fail(NBP_ERR_RANGE, "product: out_slot");
     for (int k = 0; k < p.nfactors; k++)
       if (p.in_slot[k] < 0 || p.in_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "product: in_slot");
