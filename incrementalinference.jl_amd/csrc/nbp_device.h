@@ -208,6 +208,23 @@ __device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) {
 __device__ __forceinline__ void nbp_exp_tab_init(double *tab) {
   for (int q = threadIdx.x; q < NBP_LCVTAB; q += blockDim.x) tab[q] = __longlong_as_double((long long)NBP_LCV_TAB[q]);
 }
+// the bandwidth fit's own table: 2^NBP_LCV_TLOG entries.  8: the table of exp_nonpos and a quartic remainder polynomial;
+// 11 (experiment): 16 KB of LDS buy one Horner step per kernel pair -- the remainder is within ln2/4096 and a cubic reaches
+// 3.4e-17.  Measured (profiles/r04_lcv_pair_loop_experiments.txt): the same bandwidths bit for bit and the same 0.78 ps per
+// pair -- the pair loop is not bound by the number of its vector instructions
+#ifndef NBP_LCV_TLOG
+#define NBP_LCV_TLOG 8
+#endif
+#define NBP_FITTAB (1 << NBP_LCV_TLOG)
+__device__ __forceinline__ void nbp_fit_tab_init(double *tab) {
+#if NBP_LCV_TLOG == 11
+  for (int q = threadIdx.x; q < NBP_FITTAB; q += blockDim.x) tab[q] = __longlong_as_double((long long)NBP_LCV_TAB2K[q]);
+#elif NBP_LCV_TLOG == 8
+  for (int q = threadIdx.x; q < NBP_FITTAB; q += blockDim.x) tab[q] = __longlong_as_double((long long)NBP_LCV_TAB[q]);
+#else
+#error "NBP_LCV_TLOG: 8 or 11"
+#endif
+}
 __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
   // clamp instead of branching: exp(-700) = 1e-304 is as good as 0 for every sum it enters
   x = fmax(x, -700.0);
@@ -1102,15 +1119,21 @@ __device__ __forceinline__ double sgpr_double(double v) {
 __device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c, double h) {  // c = 1/(2 h^2): 1/c = 2 h^2 without a division
   lcv_exp_k K;
   const double rc = 2.0 * h * h;
-  K.A = sgpr_double(-c * 369.3299304675746);       // 256/ln2
+  K.A = sgpr_double(-c * (369.3299304675746 * (NBP_FITTAB / 256)));       // 2^TLOG/ln2 (256/ln2 times a power of two)
   K.negM = -6755399441055744.0;
-  K.B = sgpr_double(0.0027076061740622863 * rc);   // ln2/256
+  K.B = sgpr_double((0.0027076061740622863 / (NBP_FITTAB / 256)) * rc);   // ln2/2^TLOG
   K.qmax = sgpr_double(700.0 * rc);                 // exp(-700) = 1e-304 is as good as 0 for every sum it enters
   const double m = -c;
   K.a1 = sgpr_double(m);
   K.a2 = sgpr_double(m * m * 0.5);
+  // the leading coefficient stays in a VGPR pair (one scalar operand per VOP3)
+#if NBP_LCV_TLOG >= 11
+  K.a3 = m * m * m * 1.66666666666666666667e-01;
+  K.a4 = 0.0;
+#else
   K.a3 = sgpr_double(m * m * m * 1.66666666666666666667e-01);
-  K.a4 = m * m * m * m * 4.16666666666666666667e-02;  // the leading coefficient stays in a VGPR pair (one scalar operand per VOP3)
+  K.a4 = m * m * m * m * 4.16666666666666666667e-02;
+#endif
   return K;
 }
 #define NBP_FMA_VVS(dst, a, b, cst) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "s"(cst))
@@ -1118,22 +1141,31 @@ __device__ __forceinline__ lcv_exp_k lcv_exp_consts(double c, double h) {  // c 
 // the table entry of n with 2^(n >> 8) already on it: entry k = n & 255 holds the bits of 2^(k/256) with k << 12 taken off
 // the high word (tools/gen_lcv_table.py), so adding n << 12 = (e << 20) + (k << 12) leaves e on the exponent field
 __device__ __forceinline__ double lcv_tab_scaled(const double *tab, int n) {
-  const double w = tab[n & (NBP_LCVTAB - 1)];
+  const double w = tab[n & (NBP_FITTAB - 1)];
   int hi;
-  asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(w)));
+  asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(w)), "n"(20 - NBP_LCV_TLOG));
   return __hiloint2double(hi, __double2loint(w));
 }
+// the remainder polynomial 1 + a1 r + ... (cubic or quartic, see NBP_LCV_TLOG) without its last step
+#if NBP_LCV_TLOG >= 11
+#define NBP_LCV_HORNER(p, r, K) NBP_FMA_VVS(p, K.a3, r, K.a2); NBP_FMA_VVS(p, p, r, K.a1)
+#else
+#define NBP_LCV_HORNER(p, r, K) NBP_FMA_VVS(p, K.a4, r, K.a3); NBP_FMA_VVS(p, p, r, K.a2); NBP_FMA_VVS(p, p, r, K.a1)
+#endif
+__device__ __forceinline__ double lcv_clamp(double q, const lcv_exp_k &K) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(q), "s"(K.qmax));  // fmin() canonicalises the scalar operand into a VGPR pair first
+  return r;
+}
 __device__ __forceinline__ double lcv_exp(double q, const lcv_exp_k &K, const double *tab) {
-  q = fmin(q, K.qmax);
+  q = lcv_clamp(q, K);
   double t, r, p;
   const double M = 6755399441055744.0;
   NBP_FMA_VSV(t, q, K.A, M);
   const int n = __double2loint(t);
   const double tf = t + K.negM;
   NBP_FMA_VSV(r, tf, K.B, q);
-  NBP_FMA_VVS(p, K.a4, r, K.a3);
-  NBP_FMA_VVS(p, p, r, K.a2);
-  NBP_FMA_VVS(p, p, r, K.a1);
+  NBP_LCV_HORNER(p, r, K);
   p = fma(p, r, 1.0);
   return lcv_tab_scaled(tab, n) * p;
 }
@@ -1142,24 +1174,137 @@ __device__ __forceinline__ double lcv_exp(double q, const lcv_exp_k &K, const do
 // otherwise runs one Horner chain after the other when registers are tight)
 __device__ __forceinline__ void lcv_exp4(double &q0, double &q1, double &q2, double &q3, const lcv_exp_k &K, const double *tab) {
   const double M = 6755399441055744.0;
-  q0 = fmin(q0, K.qmax); q1 = fmin(q1, K.qmax); q2 = fmin(q2, K.qmax); q3 = fmin(q3, K.qmax);
+  q0 = lcv_clamp(q0, K); q1 = lcv_clamp(q1, K); q2 = lcv_clamp(q2, K); q3 = lcv_clamp(q3, K);
   double t0, t1, t2, t3;
   NBP_FMA_VSV(t0, q0, K.A, M); NBP_FMA_VSV(t1, q1, K.A, M); NBP_FMA_VSV(t2, q2, K.A, M); NBP_FMA_VSV(t3, q3, K.A, M);
+#if NBP_LCV_KO & 2
+  const double w0 = __hiloint2double(__double2loint(t0) << 9, 1), w1 = __hiloint2double(__double2loint(t1) << 9, 1);
+  const double w2 = __hiloint2double(__double2loint(t2) << 9, 1), w3 = __hiloint2double(__double2loint(t3) << 9, 1);
+#else
   const double w0 = lcv_tab_scaled(tab, __double2loint(t0)), w1 = lcv_tab_scaled(tab, __double2loint(t1));
   const double w2 = lcv_tab_scaled(tab, __double2loint(t2)), w3 = lcv_tab_scaled(tab, __double2loint(t3));
+#endif
   t0 += K.negM; t1 += K.negM; t2 += K.negM; t3 += K.negM;
   double r0, r1, r2, r3, p0, p1, p2, p3;
   NBP_FMA_VSV(r0, t0, K.B, q0); NBP_FMA_VSV(r1, t1, K.B, q1); NBP_FMA_VSV(r2, t2, K.B, q2); NBP_FMA_VSV(r3, t3, K.B, q3);
+#if NBP_LCV_TLOG >= 11
+  NBP_FMA_VVS(p0, K.a3, r0, K.a2); NBP_FMA_VVS(p1, K.a3, r1, K.a2); NBP_FMA_VVS(p2, K.a3, r2, K.a2); NBP_FMA_VVS(p3, K.a3, r3, K.a2);
+#else
   NBP_FMA_VVS(p0, K.a4, r0, K.a3); NBP_FMA_VVS(p1, K.a4, r1, K.a3); NBP_FMA_VVS(p2, K.a4, r2, K.a3); NBP_FMA_VVS(p3, K.a4, r3, K.a3);
   NBP_FMA_VVS(p0, p0, r0, K.a2); NBP_FMA_VVS(p1, p1, r1, K.a2); NBP_FMA_VVS(p2, p2, r2, K.a2); NBP_FMA_VVS(p3, p3, r3, K.a2);
+#endif
   NBP_FMA_VVS(p0, p0, r0, K.a1); NBP_FMA_VVS(p1, p1, r1, K.a1); NBP_FMA_VVS(p2, p2, r2, K.a1); NBP_FMA_VVS(p3, p3, r3, K.a1);
   p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0); p2 = fma(p2, r2, 1.0); p3 = fma(p3, r3, 1.0);
   q0 = w0 * p0; q1 = w1 * p1; q2 = w2 * p2; q3 = w3 * p3;
 }
 
+// EXPERIMENT, off (NBP_LCV_PIPE = 1 to build it): the pair loop as a two-stage software pipeline.  Stage A of a group of four
+// partners -- difference, square, clamp, t = q A + M, the read of the table entry -- is issued one group AHEAD of stage B
+// (remainder, polynomial, scaling by the table entry, the sums), so that the table entry a group needs was requested a whole
+// group of arithmetic earlier and no wave sits at an s_waitcnt for it (written straight through, the compiler puts the wait
+// directly behind the four reads).  Two register sets, the loop body written twice: no copies at the back edge.  The same
+// operations on the same values in the same order as the straight form -- bit-identical sums.  Measured: 4.29 ms against
+// 4.18 ms for 8192 chip-filling fits (128 VGPRs, 32 B of scratch, one idle stage A per call): the LDS LATENCY a wave sees is
+// not what the loop waits for.  The knock-out builds (NBP_LCV_KO, wrong sums) say what is: without the partner atomics
+// 0.61 ps per pair instead of 0.78, without the table reads 0.63, without either 0.54 = the vector instructions alone
+// (profiles/r04_lcv_pair_loop_experiments.txt).
+#ifndef NBP_LCV_KO
+#define NBP_LCV_KO 0
+#endif
+#ifndef NBP_LCV_PIPE
+#define NBP_LCV_PIPE 0
+#endif
+struct lcv_group {
+  double q0, q1, q2, q3, t0, t1, t2, t3, w0, w1, w2, w3;
+};
+template <bool CIRC>
+__device__ __forceinline__ void lcv_stage_a(lcv_group &G, double xi, double y0, double y1, double y2, double y3, const lcv_exp_k &K,
+                                            const double *tab) {
+  const double M = 6755399441055744.0;
+  const double d0 = xi - y0, d1 = xi - y1, d2 = xi - y2, d3 = xi - y3;
+  G.q0 = lcv_clamp(CIRC ? circ_sq(d0) : d0 * d0, K);
+  G.q1 = lcv_clamp(CIRC ? circ_sq(d1) : d1 * d1, K);
+  G.q2 = lcv_clamp(CIRC ? circ_sq(d2) : d2 * d2, K);
+  G.q3 = lcv_clamp(CIRC ? circ_sq(d3) : d3 * d3, K);
+  NBP_FMA_VSV(G.t0, G.q0, K.A, M); NBP_FMA_VSV(G.t1, G.q1, K.A, M); NBP_FMA_VSV(G.t2, G.q2, K.A, M); NBP_FMA_VSV(G.t3, G.q3, K.A, M);
+  G.w0 = tab[__double2loint(G.t0) & (NBP_FITTAB - 1)];
+  G.w1 = tab[__double2loint(G.t1) & (NBP_FITTAB - 1)];
+  G.w2 = tab[__double2loint(G.t2) & (NBP_FITTAB - 1)];
+  G.w3 = tab[__double2loint(G.t3) & (NBP_FITTAB - 1)];
+}
+// stage B: e = 2^(n/256) (1 + a1 r + ... + a4 r^4); the table entry enters last (a false dependence on the polynomial keeps
+// the scheduler from pulling its scaling -- and with it the wait for the read -- to the front)
+__device__ __forceinline__ double lcv_scale_late(double w, double t, double p) {
+  int hi;
+  asm("v_lshl_add_u32 %0, %1, %4, %2" : "=v"(hi) : "v"(__double2loint(t)), "v"(__double2hiint(w)), "v"(p), "n"(20 - NBP_LCV_TLOG));
+  return __hiloint2double(hi, __double2loint(w));
+}
+__device__ __forceinline__ void lcv_stage_b(const lcv_group &G, const lcv_exp_k &K, double &e0, double &e1, double &e2, double &e3) {
+  const double u0 = G.t0 + K.negM, u1 = G.t1 + K.negM, u2 = G.t2 + K.negM, u3 = G.t3 + K.negM;
+  double r0, r1, r2, r3, p0, p1, p2, p3;
+  NBP_FMA_VSV(r0, u0, K.B, G.q0); NBP_FMA_VSV(r1, u1, K.B, G.q1); NBP_FMA_VSV(r2, u2, K.B, G.q2); NBP_FMA_VSV(r3, u3, K.B, G.q3);
+  NBP_LCV_HORNER(p0, r0, K); NBP_LCV_HORNER(p1, r1, K); NBP_LCV_HORNER(p2, r2, K); NBP_LCV_HORNER(p3, r3, K);
+  p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0); p2 = fma(p2, r2, 1.0); p3 = fma(p3, r3, 1.0);
+  e0 = p0; e1 = p1; e2 = p2; e3 = p3;
+}
+#define NBP_LCV_FINISH(G, AP)                                                                                    \
+  {                                                                                                               \
+    const double f0 = lcv_scale_late(G.w0, G.t0, e0) * e0, f1 = lcv_scale_late(G.w1, G.t1, e1) * e1;              \
+    const double f2 = lcv_scale_late(G.w2, G.t2, e2) * e2, f3 = lcv_scale_late(G.w3, G.t3, e3) * e3;              \
+    s0 += f0; s1 += f1; s2 += f2; s3 += f3;                                                                       \
+    if (!(NBP_LCV_KO & 1)) { lds_add(AP, f0); lds_add(AP + 1, f1); lds_add(AP + 2, f2); lds_add(AP + 3, f3); }    \
+  }
+
 template <bool CIRC>
 __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta, int n4, int nt, bool extra, double xi, const lcv_exp_k &K,
                                                 double *accw, const double *tab) {
+#if NBP_LCV_PIPE
+  const double *xp = x + pi + ta;
+  nbp_lds_double *ap = (nbp_lds_double *)(accw + pi + ta);
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (n4 > 0) {
+    // x is followed by the row-sum partials in LDS: the reads run up to eleven entries past the last partner of the lane
+    // (two groups ahead), whose values go through a stage A nobody finishes
+    lcv_group GA, GB;
+    double e0, e1, e2, e3;
+    lcv_stage_a<CIRC>(GA, xi, xp[0], xp[1], xp[2], xp[3], K, tab);
+    double y0 = xp[4], y1 = xp[5], y2 = xp[6], y3 = xp[7];
+    // four additions of zero behind the first reads: the loop is then entered with the LDS queue it has at its back edge
+    // (table reads, coordinate reads, four atomics), and the wait for the coordinates at its top becomes lgkmcnt(4) -- the
+    // atomics of the group before stay in flight -- instead of the lgkmcnt(0) that merging the two entries gives
+    lds_add(ap, 0.0); lds_add(ap + 1, 0.0); lds_add(ap + 2, 0.0); lds_add(ap + 3, 0.0);
+    int k = 0;
+    for (; k + 2 <= n4; k += 2, xp += 8, ap += 8) {
+      lcv_stage_b(GA, K, e0, e1, e2, e3);
+      lcv_stage_a<CIRC>(GB, xi, y0, y1, y2, y3, K, tab);
+      y0 = xp[8]; y1 = xp[9]; y2 = xp[10]; y3 = xp[11];
+      NBP_LCV_FINISH(GA, ap)
+      lcv_stage_b(GB, K, e0, e1, e2, e3);
+      lcv_stage_a<CIRC>(GA, xi, y0, y1, y2, y3, K, tab);
+      y0 = xp[12]; y1 = xp[13]; y2 = xp[14]; y3 = xp[15];
+      NBP_LCV_FINISH(GB, ap + 4)
+    }
+    if (k < n4) {
+      lcv_stage_b(GA, K, e0, e1, e2, e3);
+      NBP_LCV_FINISH(GA, ap)
+      xp += 4;
+      ap += 4;
+    }
+  }
+  for (int k = 0; k < nt; k++) {
+    const double d0 = xi - xp[k];
+    const double e0 = lcv_exp(CIRC ? circ_sq(d0) : d0 * d0, K, tab);
+    s0 += e0;
+    lds_add(ap + k, e0);
+  }
+  if (extra) {
+    const double d0 = xi - xp[nt];
+    const double e0 = lcv_exp(CIRC ? circ_sq(d0) : d0 * d0, K, tab);
+    s1 += e0;
+    lds_add(ap + nt, e0);
+  }
+  return (s0 + s1) + (s2 + s3);
+#else
   // x and the accumulator row are stored twice over ([0,2N)): partner pi+t never wraps, so both
   // addresses are one base register plus an immediate that advances with t.
   // The partner accumulation is an LDS atomic without return (ds_add_f64): lane i's slot at step t+1
@@ -1175,7 +1320,13 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
   if (n4 > 0) { y0 = xp[0]; y1 = xp[1]; y2 = xp[2]; y3 = xp[3]; }
   for (int k = 0; k < n4; k++, xp += 4, ap += 4) {
     const double d0 = xi - y0, d1 = xi - y1, d2 = xi - y2, d3 = xi - y3;
-    if (k + 1 < n4) { y0 = xp[4]; y1 = xp[5]; y2 = xp[6]; y3 = xp[7]; }
+    // unconditionally (x is followed by the row-sum partials in LDS: the last group reads up to four entries past the
+    // lane's partners and drops them): behind a condition the four coordinates are copied at every back edge
+#if NBP_LCV_KO & 4  // knock-out experiments (wrong sums; tools/exp/lcv_ko.sh): 1 no partner atomics, 2 no table reads, 4 no coordinate reads
+    y0 += 1e-3; y1 += 1e-3; y2 += 1e-3; y3 += 1e-3;
+#else
+    y0 = xp[4]; y1 = xp[5]; y2 = xp[6]; y3 = xp[7];
+#endif
     double e0 = CIRC ? circ_sq(d0) : d0 * d0, e1 = CIRC ? circ_sq(d1) : d1 * d1;
     double e2 = CIRC ? circ_sq(d2) : d2 * d2, e3 = CIRC ? circ_sq(d3) : d3 * d3;
     lcv_exp4(e0, e1, e2, e3, K, tab);
@@ -1183,10 +1334,12 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
     s1 += e1;
     s2 += e2;
     s3 += e3;
+#if !(NBP_LCV_KO & 1)
     lds_add(ap, e0);
     lds_add(ap + 1, e1);
     lds_add(ap + 2, e2);
     lds_add(ap + 3, e3);
+#endif
   }
   for (int k = 0; k < nt; k++) {
     const double d0 = xi - xp[k];
@@ -1201,6 +1354,7 @@ __device__ __forceinline__ double loo_symmetric(const double *x, int pi, int ta,
     lds_add(ap + nt, e0);
   }
   return (s0 + s1) + (s2 + s3);
+#endif
 }
 
 // log() as a real call from the evaluation: inlined, the double constants of its polynomial are hoisted out of the search

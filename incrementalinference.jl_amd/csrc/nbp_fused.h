@@ -52,7 +52,7 @@ __host__ __device__ inline size_t nbp_update_lds_layout(int Fmax, int D, int N, 
   const size_t tr = o;
   // transient area: the largest of the four phases (all in doubles)
   const size_t prop = 3 * (size_t)N + NBP_RED + ((size_t)N + 1) / 2;
-  const size_t fit = 2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_LCVTAB;
+  const size_t fit = 2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_FITTAB;
   const size_t kd = nbp_update_kd_doubles(D, N, Npad, P) + ((size_t)N + 1) / 2 /* idx */;
   const size_t bulk = (size_t)Fmax * D * N;
   const size_t prodL = 3 * bulk + (circ ? 2 * (size_t)Fmax * N : 0) + (size_t)Fmax * N /* lg */ + 6 * (size_t)Fmax + N + ((size_t)Fmax * Npad * 2 + 1) / 2 /* ind | nxt */;

@@ -486,8 +486,9 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
   }
   const int N = slot_count(s, Ncap);  // manikde! of the points the belief holds (Ncap = slot capacity = stride)
   const int P = blockDim.x / Npad;
-  double *X = smem, *part = smem + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N, *tab = red + NBP_RED;
-  for (int q = n; q < NBP_LCVTAB; q += blockDim.x) tab[q] = __longlong_as_double((long long)NBP_LCV_TAB[q]);  // the table of lcv_exp
+  // the table of lcv_exp first: its address is then a constant of the kernel (one shift for the address of an entry)
+  double *tab = smem, *X = smem + NBP_FITTAB, *part = X + 2 * N, *red = part + P * Npad + (blockDim.x >> 6) * 2 * N;
+  nbp_fit_tab_init(tab);
   // circular coordinates are staged wrapped (the identity for stored beliefs): every pair difference of
   // the fit is then within (-2pi, 2pi), which is what circ_sqdist relies on
   if (n < N) {
@@ -512,7 +513,10 @@ __device__ __forceinline__ void lcv_slot_coordinate(double *s, int M, int k, int
 // ================================================================================================
 #define NBP_BANDWIDTH_ARGS const int32_t *slots, const int32_t *manifolds, double *arena, int N, int Npad, int64_t S, nbp_counters *ctr
 #if NBP_TU & NBP_TU_PREP
-__global__ void __launch_bounds__(1024)
+#ifndef NBP_W_PREP
+#define NBP_W_PREP 4
+#endif
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NBP_W_PREP)))
 nbp_bandwidth_kernel(NBP_BANDWIDTH_ARGS) {
   extern __shared__ double smem[];  // grid (jobs, 3)
   lcv_slot_coordinate<0>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
@@ -534,9 +538,9 @@ template __global__ void nbp_bandwidth_kernel_spec<3>(NBP_BANDWIDTH_ARGS, nbp_sp
 template <int DEPTH> __global__ void nbp_bandwidth_kernel_spec(NBP_BANDWIDTH_ARGS, nbp_spec_area *spec);
 #endif
 
-// X[2N] | part[P][Npad] | acc[NW][2N] | red | exp table     (NW = P*Npad/64 waves)
+// exp table | X[2N] | part[P][Npad] | acc[NW][2N] | red     (NW = P*Npad/64 waves)
 static inline size_t nbp_bandwidth_lds_bytes(int N, int Npad, int P) {
-  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_LCVTAB) * 8;
+  return (2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_FITTAB) * 8;
 }
 
 #if NBP_TU & NBP_TU_PROPOSAL
@@ -817,7 +821,7 @@ __device__ __forceinline__ void prep_body(const int32_t *bw_slots, const int32_t
 #define NBP_PREP_ARGS const int32_t *bw_slots, const int32_t *bw_manis, int nbw, const nbp_product_desc *descs, int nprod, int kdF, \
                       double *arena, double *ws, int N, int Npad, int64_t S, nbp_levels T, nbp_counters *ctr
 #if NBP_TU & NBP_TU_PREP
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NBP_W_PREP)))
 nbp_prep_kernel(NBP_PREP_ARGS) {
   extern __shared__ double smem[];
   prep_body<0>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, nullptr, smem);
