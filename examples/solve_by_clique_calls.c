@@ -318,9 +318,12 @@ int main(int argc, char **argv) {
   belief *graph0 = malloc(sizeof(belief) * nvars); /* the walk writes the roots' frontals back to the graph: keep the start */
   for (int v = 0; v < nvars; v++) { graph0[v] = belief_new(); belief_copy(&graph0[v], &graph[v]); }
   double t_first = 0;
-  for (int pass = 0; pass < 2 && !failed; pass++) { /* the second walk runs with every buffer of the library at its final size */
+  const int seam_timing = getenv("NBP_SEAM_TIMES") != NULL; /* a third walk with the library's phase clock on */
+  double t_timed = 0, ph[6] = {0};
+  for (int pass = 0; pass < 2 + seam_timing && !failed; pass++) { /* the second walk runs with every buffer of the library at its final size */
   for (int v = 0; v < nvars; v++) belief_copy(&graph[v], &graph0[v]);
   for (int c = 1; c <= ncl && pass; c++) { for (int i = 0; i < H.info[c].nfrontals + H.info[c].nseparators; i++) free(H.sub[c][i].pts); free(H.sub[c]); }
+  if (pass == 2) nbp_clique_seam_times(NULL, 2);
   const double tb = now_s();
   for (int d = maxdepth; d >= 0 && !failed && batched; d--) failed |= level_batched(&H, bctx, d, 0);
   for (int d = 1; d <= maxdepth && !failed && batched; d++) failed |= level_batched(&H, bctx, d, 1);
@@ -334,7 +337,7 @@ int main(int argc, char **argv) {
     for (int c = 1; c <= ncl; c++)
       if (H.depth[c] == d) failed |= down_clique(&H, &W[omp_get_thread_num()], c);
   }
-  if (!pass) t_first = now_s() - tb; else t_calls = now_s() - tb;
+  if (!pass) t_first = now_s() - tb; else if (pass == 1) t_calls = now_s() - tb; else { t_timed = now_s() - tb; nbp_clique_seam_times(ph, 1); }
   }
   if (failed) return 4;
   for (int t = 1; t < threads; t++) nbp_ctx_destroy(W[t].ctx);
@@ -355,6 +358,10 @@ int main(int argc, char **argv) {
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "
          "(the second walk; the first, while the library's buffers grow: %.1f ms)\n",
          t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls, t_first * 1e3);
+  if (seam_timing)
+    printf("  phases of a walk with the device waited for after the launches (%.1f ms, %.0f calls): planning %.2f ms, beliefs in %.2f, program assembly %.2f, "
+           "launches + device %.2f, beliefs out %.2f; the caller's own sub-graph assembly and bookkeeping %.2f\n", t_timed * 1e3, ph[5], ph[0] * 1e3, ph[1] * 1e3,
+           ph[2] * 1e3, ph[3] * 1e3, ph[4] * 1e3, (t_timed - ph[0] - ph[1] - ph[2] - ph[3] - ph[4]) * 1e3);
   nbp_ctx_destroy(ctx);
   nbp_tree_destroy(tree);
   nbp_graph_destroy(g);

@@ -274,6 +274,12 @@ typedef struct nbp_clique_request {
 } nbp_clique_request;
 nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *requests, int32_t n);
 
+/* diagnostics: host wall clock the clique calls of this process have spent, by phase (seconds): [0] planning the schedule,
+ * [1] beliefs host -> device, [2] program assembly + finalize, [3] launches (mode 2: + waiting for them), [4] (waiting +)
+ * beliefs device -> host, [5] number of calls.  mode 0: read; 1: read and reset; 2: read, reset, and from now on wait for
+ * the device after the launches so that [3] and [4] separate (not thread-safe: a measuring tool's switch). */
+nbp_status nbp_clique_seam_times(double *seconds_out6, int32_t mode);
+
 /* test access: the descriptors of stage s of the last compile (kind = NBP_STAGE_*; bytes copied <= cap) */
 int32_t nbp_tree_num_stages(const nbp_tree *t);
 nbp_status nbp_tree_stage(const nbp_tree *t, int32_t s, int32_t *kind, int32_t *n, void *descs_out, int64_t cap_bytes);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <unordered_map>
@@ -25,6 +26,28 @@ static nbp_status fail(nbp_status code, const std::string &msg) {
   return code;
 }
 // shared with nbp_host.cpp (same library): sets the message nbp_last_error() returns
+// host-side loops over many beliefs (a tree level's worth of them packed into / unpacked from the staging buffer, ~1 us
+// each): a few threads when there is enough work (profiles/r04_clique_seam_phases.txt)
+template <class F>
+static void host_parallel_for(int n, int grain, F &&f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  int nt = n / grain;
+  if (nt > 8) nt = 8;
+  if (hw && nt > (int)hw) nt = (int)hw;
+  if (nt <= 1) {
+    for (int i = 0; i < n; i++) f(i);
+    return;
+  }
+  auto part = [&](int t) {
+    const int a = (int)((int64_t)n * t / nt), b = (int)((int64_t)n * (t + 1) / nt);
+    for (int i = a; i < b; i++) f(i);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(part, t);
+  part(0);
+  for (std::thread &x : th) x.join();
+}
+
 extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { return fail(code, msg ? msg : ""); }
 #define HIPCHK(expr)                                                                               \
   do {                                                                                             \
@@ -408,8 +431,9 @@ nbp_status nbp_belief_write_batch(nbp_ctx *c, int32_t n, const int32_t *slots, c
   HIPCHK(hipStreamSynchronize(c->stream));  // the staging buffer is free again (and so is every slot about to be replaced)
   nbp_status rc = ensure_pin(c, (size_t)n * (size_t)c->S);
   if (rc) return rc;
-  for (int i = 0; i < n; i++)
+  host_parallel_for(n, 128, [&](int i) {
     pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, c->pin + (size_t)i * c->S);
+  });
   for (int i = 0; i < n;) {
     int j = i + 1;
     while (j < n && slots[j] == slots[j - 1] + 1) j++;
@@ -438,9 +462,10 @@ nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, co
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->pin, c->arena + c->S * slots[0], span * c->S * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < n; i++)
+    host_parallel_for(n, 128, [&](int i) {
       unpack_belief(c, manifolds[i], c->pin + (size_t)(slots[i] - slots[0]) * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr,
                     ipc ? ipc[i] : nullptr);
+    });
     return NBP_OK;
   }
   nbp_status rc = ensure_pin(c, (size_t)n * (size_t)c->S);
@@ -452,8 +477,9 @@ nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, co
     i = j;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < n; i++)
+  host_parallel_for(n, 128, [&](int i) {
     unpack_belief(c, manifolds[i], c->pin + (size_t)i * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
+  });
   return NBP_OK;
 }
 

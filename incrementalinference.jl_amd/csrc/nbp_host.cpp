@@ -7,12 +7,14 @@
 // orders, cliques, schedules and descriptor bytes, and tests/test_tree_known_answers.py pins the Python
 // side against the reference's own known answers.
 #include <algorithm>
+#include <chrono>
 #include <array>
 #include <deque>
 #include <cstring>
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nbp_host.h"
@@ -1720,6 +1722,11 @@ static int clique_zdim(int kind, int manifold) { return kind == NBP_F_LINREL ? m
 // One clique call, planned: the beliefs to move in, the rounds of (proposals, products), the differential stage, the
 // beliefs to move out -- with every slot number shifted by `off`, so that several cliques can share one context, one
 // transfer each way and one program whose stage pair r holds round r of every clique (nbp_clique_solve_batch).
+// host-side wall clock of the phases of the clique calls (diagnostics: nbp_clique_seam_times): 0 planning, 1 beliefs in,
+// 2 program assembly + finalize, 3 launches + waiting for them, 4 beliefs out, 5 calls
+static double g_seam_s[6] = {0, 0, 0, 0, 0, 0};
+static bool g_seam_sync = false;
+static inline double seam_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct clique_io { int32_t slot, mani; const nbp_tree_belief *src; nbp_tree_belief *dst; bool with_ipc; };
 struct clique_plan {
   int nslots = 0;  // slots this clique occupies: [0, base) beliefs that cross the boundary, [base, nslots) proposal scratch
@@ -1984,6 +1991,7 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
       offB += P.nslots - P.base;
     }
   }
+  const double t0 = seam_now();
   std::vector<int32_t> bs, bm, bn;
   std::vector<const double *> bp, bb, bi;
   for (const clique_plan &P : plans)
@@ -1993,6 +2001,7 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
     }
   nbp_status rc = nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
   if (rc) return rc;
+  const double t1 = seam_now();
   nbp_program *p = nullptr;
   rc = nbp_program_create(ctx, &p);
   if (rc) return rc;
@@ -2021,8 +2030,11 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
     if (rc) return rc;
   }
   rc = nbp_program_finalize(p);
+  const double t2 = seam_now();
   if (!rc) rc = nbp_program_run(p, 0, -1);
+  if (!rc && g_seam_sync) rc = nbp_synchronize(ctx);  // (timing mode: the wait is charged to the launches, not to the read)
   if (rc) return rc;
+  const double t3 = seam_now();
   std::vector<int32_t> os, om, on;
   std::vector<double *> op, ob, oi;
   std::vector<nbp_tree_belief *> dst;
@@ -2035,6 +2047,8 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
   rc = nbp_belief_read_batch(ctx, (int32_t)os.size(), os.data(), om.data(), op.data(), on.data(), ob.data(), oi.data());
   if (rc) return rc;
   for (size_t i = 0; i < dst.size(); i++) dst[i]->n_pts = on[i];
+  const double t4 = seam_now();
+  g_seam_s[1] += t1 - t0; g_seam_s[2] += t2 - t1; g_seam_s[3] += t3 - t2; g_seam_s[4] += t4 - t3;
   return NBP_OK;
 }
 
@@ -2049,7 +2063,9 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   if (!ctx) return hfail(NBP_ERR_ARG, "null argument");
   if (nbp_status rn = clique_particles_ok(ctx, sp)) return rn;
   std::vector<clique_plan> plans(1);
+  const double t0 = seam_now();
   nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, plans[0]);
+  g_seam_s[0] += seam_now() - t0; g_seam_s[5] += 1;
   if (!rc) rc = clique_plans_run(ctx, plans);
   if (rc) return rc;
   if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
@@ -2060,12 +2076,38 @@ nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t
   if (!ctx || (n > 0 && !req)) return hfail(NBP_ERR_ARG, "null argument");
   if (n <= 0) return NBP_OK;
   std::vector<clique_plan> plans((size_t)n);
+  const double t0 = seam_now();
   for (int i = 0; i < n; i++) {
     if (!req[i].params || !req[i].clique) return hfail(NBP_ERR_ARG, "clique batch: null params / clique");
     if (nbp_status rn = clique_particles_ok(ctx, req[i].params)) return rn;
-    nbp_status rc = clique_plan_build(req[i].params, req[i].clique, req[i].seed, req[i].beliefs, req[i].down != 0, req[i].diff_out, plans[(size_t)i]);
-    if (rc) return rc;
   }
+  {
+    // the plans of a level are independent of each other: a few threads when there are many (a chain's leaf level: ~500).
+    // The error text is thread-local, so a request that fails is planned once more on this thread to report it.
+    auto build = [&](int i) { return clique_plan_build(req[i].params, req[i].clique, req[i].seed, req[i].beliefs, req[i].down != 0, req[i].diff_out, plans[(size_t)i]); };
+    const unsigned hw = std::thread::hardware_concurrency();
+    int nt = n / 32;
+    if (nt > 8) nt = 8;
+    if (hw && nt > (int)hw) nt = (int)hw;
+    std::vector<nbp_status> rcs((size_t)n, NBP_OK);
+    auto part = [&](int t, int T) {
+      for (int i = (int)((int64_t)n * t / T); i < (int)((int64_t)n * (t + 1) / T); i++) rcs[(size_t)i] = build(i);
+    };
+    if (nt <= 1) part(0, 1);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; t++) th.emplace_back(part, t, nt);
+      part(0, nt);
+      for (std::thread &x : th) x.join();
+    }
+    for (int i = 0; i < n; i++)
+      if (rcs[(size_t)i]) {
+        plans[(size_t)i] = clique_plan();
+        const nbp_status rc = build(i);
+        return rc ? rc : rcs[(size_t)i];
+      }
+  }
+  g_seam_s[0] += seam_now() - t0; g_seam_s[5] += 1;
   nbp_status rc = clique_plans_run(ctx, plans);
   if (rc) return rc;
   for (int i = 0; i < n; i++) req[i].status = req[i].down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
@@ -2083,6 +2125,13 @@ nbp_status nbp_clique_upsolve_joint(nbp_ctx *ctx, const nbp_solver_params *sp, c
 nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
                                 nbp_tree_belief *bel, int32_t *status_out) {
   return clique_solve(ctx, sp, q, seed, bel, status_out, true);
+}
+
+nbp_status nbp_clique_seam_times(double *out, int32_t mode) {
+  if (out) for (int i = 0; i < 6; i++) out[i] = g_seam_s[i];
+  if (mode >= 1) for (int i = 0; i < 6; i++) g_seam_s[i] = 0;
+  if (mode >= 1) g_seam_sync = (mode == 2);
+  return NBP_OK;
 }
 
 int32_t nbp_tree_num_stages(const nbp_tree *t) { return t ? (int32_t)t->stages.size() : 0; }
