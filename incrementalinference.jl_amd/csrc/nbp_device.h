@@ -639,16 +639,11 @@ struct objective_t {
 // compare-exchange steps on compile-time indices, so every access is a register access (an index
 // permutation `ord[]` makes LLVM spill the simplex to scratch for the runtime-indexed reads).
 template <int DN>
-__device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1], int i) {
+__device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int i) {
   const bool sw = f[i] < f[i - 1];
   const double fa = f[i - 1], fb = f[i];
   f[i - 1] = sw ? fb : fa;
   f[i] = sw ? fa : fb;
-  if (DN > 2) {  // the vertex's place in Optim's simplex array travels with it (nm_centroid)
-    const int ia = id[i - 1], ib = id[i];
-    id[i - 1] = sw ? ib : ia;
-    id[i] = sw ? ia : ib;
-  }
 #pragma unroll
   for (int d = 0; d < DN; d++) {
     const double a = sx[i - 1][d], b = sx[i][d];
@@ -657,44 +652,16 @@ __device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[D
   }
 }
 template <int DN>
-__device__ __forceinline__ void nm_sort_all(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1]) {
+__device__ __forceinline__ void nm_sort_all(double (&sx)[DN + 1][DN], double (&f)[DN + 1]) {
 #pragma unroll
   for (int pass = 0; pass < DN; pass++)
 #pragma unroll
-    for (int i = DN; i >= 1 + pass; i--) nm_cswap<DN>(sx, f, id, i);
+    for (int i = DN; i >= 1 + pass; i--) nm_cswap<DN>(sx, f, i);
 }
 template <int DN>
-__device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1]) {
+__device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&f)[DN + 1]) {
 #pragma unroll
-  for (int i = DN; i >= 1; i--) nm_cswap<DN>(sx, f, id, i);
-}
-// Optim's centroid!(c, simplex, h): the vertices other than the worst summed IN THE ORDER THE SIMPLEX ARRAY HOLDS THEM
-// (a replaced vertex keeps the slot of the one it replaces), then rmul!(c, 1/n).  The simplex here is physically sorted
-// by value, so each vertex carries its slot (`id`).  Two vertices: a + b commutes, nothing to do.  Three: only WHICH
-// vertex is added last matters ((0 + p) + q is q + p) -- the one with the largest slot.  The rounding of this sum is
-// what the vertex coordinates of a 3-D search inherit: summed in sorted order the search parts from Optim's (and the
-// oracle's) in the last bit at the first iteration and by ~1e-8 at its end.
-template <int DN>
-__device__ __forceinline__ void nm_centroid(const double (&sx)[DN + 1][DN], const int (&id)[DN + 1], double (&xc)[DN]) {
-  if (DN == 3) {
-    const bool l0 = id[0] > id[1] && id[0] > id[2];
-    const bool l1 = !l0 && id[1] > id[2];
-#pragma unroll
-    for (int d = 0; d < DN; d++) {
-      const double L = l0 ? sx[0][d] : (l1 ? sx[1][d] : sx[2][d]);
-      const double U = l0 ? sx[1][d] : sx[0][d];
-      const double V = (l0 || l1) ? sx[2][d] : sx[1][d];
-      xc[d] = ((U + V) + L) * (1.0 / DN);
-    }
-  } else {
-#pragma unroll
-    for (int d = 0; d < DN; d++) {
-      double s = 0;
-#pragma unroll
-      for (int i = 0; i < DN; i++) s += sx[i][d];
-      xc[d] = s * (1.0 / DN);
-    }
-  }
+  for (int i = DN; i >= 1; i--) nm_cswap<DN>(sx, f, i);
 }
 
 // Optim's convergence test: nmobjective(f_simplex, n, m) = sqrt(var(y) * n / (n + 1)) <= g_tol, i.e. the population
@@ -718,14 +685,7 @@ template <class OBJ, int DN>
 __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   constexpr int M = DN + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / DN, gamma = 0.75 - 1.0 / (2.0 * DN), delta = 1.0 - 1.0 / DN;
-  // the vertex formulas below are Optim's, one rounding per operation: a contracted xc + coef * (xr - xc) differs from
-  // Julia's in the last bit whenever coef * (..) is inexact (beta = 5/3, gamma = 7/12, delta = 2/3 for three dimensions;
-  // 2, 1/2, 1/2 for two -- exact, which is why the 2-D searches never cared)
-#pragma clang fp contract(off)
   double sx[M][DN], f[M];
-  int id[M];
-#pragma unroll
-  for (int i = 0; i < M; i++) id[i] = i;
 #pragma unroll
   for (int i = 0; i < M; i++)
 #pragma unroll
@@ -734,7 +694,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   for (int j = 0; j < DN; j++) sx[j + 1][j] = (1.0 + 0.5) * sx[j + 1][j] + 0.025;
 #pragma unroll
   for (int i = 0; i < M; i++) f[i] = o(sx[i]);
-  nm_sort_all<DN>(sx, f, id);
+  nm_sort_all<DN>(sx, f);
   bool converged = nm_converged<DN>(f);
   int it = 0;
 #ifdef NBP_X_NMNOUNROLL
@@ -743,7 +703,13 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   while (!converged && it < 1000) {
     it++;
     double xc[DN], xr[DN], xcache[DN];
-    nm_centroid<DN>(sx, id, xc);
+#pragma unroll
+    for (int d = 0; d < DN; d++) {
+      double s = 0;
+#pragma unroll
+      for (int i = 0; i < DN; i++) s += sx[i][d];
+      xc[d] = s * (1.0 / DN);
+    }
     const double f_lowest = f[0], f_second = f[DN - 1], f_highest = f[DN];
 #pragma unroll
     for (int d = 0; d < DN; d++) xr[d] = xc[d] + alpha * (xc[d] - sx[DN][d]);
@@ -766,7 +732,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
 #pragma unroll
     for (int d = 0; d < DN; d++) sx[DN][d] = shrink ? sx[DN][d] : (take2 ? xcache[d] : xr[d]);
     f[DN] = shrink ? f[DN] : (take2 ? f2 : f_reflect);
-    nm_sift_last<DN>(sx, f, id);  // leaves a sorted simplex (the shrinking lanes') as it is
+    nm_sift_last<DN>(sx, f);  // leaves a sorted simplex (the shrinking lanes') as it is
     if (shrink) {
 #pragma unroll
       for (int q = 1; q < M; q++) {
@@ -774,13 +740,19 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
         for (int d = 0; d < DN; d++) sx[q][d] = sx[0][d] + delta * (sx[q][d] - sx[0][d]);
         f[q] = o(sx[q]);
       }
-      nm_sort_all<DN>(sx, f, id);
+      nm_sort_all<DN>(sx, f);
     }
     converged = nm_converged<DN>(f);
   }
   // after_while!: the better of the best vertex and the centroid of the DN best
   double xc[DN];
-  nm_centroid<DN>(sx, id, xc);
+#pragma unroll
+  for (int d = 0; d < DN; d++) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DN; i++) s += sx[i][d];
+    xc[d] = s * (1.0 / DN);
+  }
   const double fcen = o(xc);
   const bool usec = fcen < f[0];
 #pragma unroll
