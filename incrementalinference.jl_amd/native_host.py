@@ -117,6 +117,7 @@ def _lib():
         lib.nbp_clique_upsolve_joint.argtypes = [vp, C.POINTER(SolverParamsC), C.POINTER(CliqueDescC), C.c_uint64, C.POINTER(TreeBeliefC),
                                                  C.POINTER(TreeBeliefC), ip]
         lib.nbp_clique_solve_batch.argtypes = [vp, C.POINTER(CliqueRequestC), i32]
+        lib.nbp_clique_seam_times.argtypes = [C.POINTER(C.c_double), i32]
         for n in HOST_EXPORTS:
             getattr(lib, n).restype = i32
         _declared = True
@@ -533,3 +534,12 @@ class NativeTree:
             self.close()
         except Exception:
             pass
+
+
+def clique_seam_times(mode=0):
+    """nbp_clique_seam_times: host wall clock the clique calls of this process have spent, by phase (seconds) --
+    planning, beliefs in, program assembly, launches (+ device when mode 2 was set), beliefs out -- and the number of calls.
+    mode 1 resets, mode 2 resets and makes every call wait for the device after its launches."""
+    out = (C.c_double * 6)()
+    _check(_lib().nbp_clique_seam_times(out, mode))
+    return dict(zip(("planning_s", "beliefs_in_s", "assembly_s", "launches_s", "beliefs_out_s", "calls"), list(out)))

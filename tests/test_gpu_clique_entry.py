@@ -81,11 +81,18 @@ def test_level_batches_equal_single_clique_calls(hip_backend, name):
     iif.initAll(fa, backend=hip_backend, seed=0)
     tree = iif.buildTreeReset(fa, iif.nestedDissectionOrder(fa))
     be = hip_backend(fa.solverParams.N, 1024)
+    from iif_amd.native_host import clique_seam_times
     try:
+        clique_seam_times(1)
         one, st1 = solve_tree_by_clique_calls(fa, tree, be, 55)
+        t_one = clique_seam_times(2)  # from here on the calls wait for the device after their launches
         many, st2 = solve_tree_by_level_batches(fa, tree, be, 55)
+        t_many = clique_seam_times(1)
     finally:
         be.close()
+    # the seam's phase clock (nbp_clique_seam_times): one call per clique and direction against one per level and direction
+    assert t_one["calls"] == 2 * len(tree.cliques) - len(tree.roots) and 0 < t_many["calls"] < t_one["calls"]
+    assert all(t_many[k] > 0 for k in ("planning_s", "beliefs_in_s", "assembly_s", "launches_s", "beliefs_out_s"))
     assert st1 == st2 and set(one) == set(many) == set(fa.ls())
     for v in fa.ls():
         man = fa.getVariable(v).varType.manifold

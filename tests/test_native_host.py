@@ -70,6 +70,14 @@ def mark_initialised(fg):
         fg.getVariable(v).initialized = True
 
 
+def test_clique_seam_clock_reads_and_resets():
+    native_host.clique_seam_times(1)
+    t = native_host.clique_seam_times(0)
+    assert set(t) == {"planning_s", "beliefs_in_s", "assembly_s", "launches_s", "beliefs_out_s", "calls"}
+    assert all(v == 0.0 for v in t.values())
+    native_host.clique_seam_times(1)  # (mode 2 would make later clique calls of this process wait for the device)
+
+
 def test_header_symbols_are_exported():
     hdr = open(os.path.join(ROOT, "include", "nbp_host.h")).read()
     declared = set(re.findall(r"\b(nbp_(?:graph|tree|clique)_[a-z_0-9]+)\s*\(", hdr))
