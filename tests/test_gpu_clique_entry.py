@@ -91,7 +91,7 @@ def test_level_batches_equal_single_clique_calls(hip_backend, name):
     finally:
         be.close()
     # the seam's phase clock (nbp_clique_seam_times): one call per clique and direction against one per level and direction
-    assert t_one["calls"] == 2 * len(tree.cliques) - len(tree.roots) and 0 < t_many["calls"] < t_one["calls"]
+    assert t_one["calls"] == 2 * len(tree.cliques) - len(tree.roots) and 0 < t_many["calls"] <= t_one["calls"]
     assert all(t_many[k] > 0 for k in ("planning_s", "beliefs_in_s", "assembly_s", "launches_s", "beliefs_out_s"))
     assert st1 == st2 and set(one) == set(many) == set(fa.ls())
     for v in fa.ls():
