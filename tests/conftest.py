@@ -22,7 +22,7 @@ def pytest_configure(config):
 # the parity tests from running.  Files not listed keep their alphabetical place in the middle group.
 _GPU_ORDER = [
     "test_golden", "test_gpu_parity_ops", "test_gpu_analytic_known_answers", "test_gpu_tree_parity", "test_gpu_clique_entry",
-    "test_gpu_kl_parity", "test_gpu_configs", "test_gpu_fullsize_configs", "test_gpu_unequal_particle_counts",
+    "test_gpu_kl_parity", "test_gpu_stagewise_parity", "test_gpu_configs", "test_gpu_fullsize_configs", "test_gpu_unequal_particle_counts",
     "test_gpu_reference_bands", "test_gpu_random_graphs", "test_gpu_properties",
 ]
 _GPU_LAST = ["test_gpu_concurrent_contexts", "test_gpu_sharded_emulation", "test_gpu_native_host", "test_gpu_bench"]
