@@ -17,6 +17,8 @@ fit in twenty (observed: 0.05 % on SE(2), 1.7 % on the Euclid(3) mixtures) a gol
 are integers and the same on both sides, what is left is the rounding of the final draw); bandwidths 1e-7 / 1e-8 (observed
 <= 3e-9).  The worst of each kind goes into the parity
 record of the run (gpurun_out/r04_whole_solve_parity.txt)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -39,14 +41,26 @@ FULL = {"config2_full_size_1000_variables": lambda: iif.generateChainEuclid(1000
         "config5_800_variables": lambda: iif.generateMixtureChain(nvars=800, N=300, priorEvery=400)}
 
 
+# NBP_STAGEWISE_FULL=1: configs 3, 4 and 5 at BASELINE's own sizes as well (minutes of oracle time on 64 host threads each: run for
+# the record, profiles/r04_stagewise_parity_full_size.txt, not in the default suite)
+if os.environ.get("NBP_STAGEWISE_FULL"):
+    FULL.update({"config3_full_size_2000_poses": lambda: iif.generateCircularDoors(nposes=2000, N=200, sightEvery=25),
+                 "config4_full_size_50x100_lattice": lambda: iif.generateSE2Lattice(rows=50, cols=100, N=200, closeEvery=5),
+                 "config5_full_size_10000_variables": lambda: iif.generateMixtureChain(nvars=10000, N=300, priorEvery=500)})
+
+
 @pytest.mark.parametrize("name", list(CONFIGS) + list(FULL))
 def test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hip_backend, name):
     fg = (CONFIGS.get(name) or FULL[name])()
     order = iif.nestedDissectionOrder(fg)
-    iif.initAll(fg, backend=oracle_backend, seed=31)
+    # (where the two sides start from does not matter, only that it is the same state: the large graphs are initialised on the device)
+    iif.initAll(fg, backend=hip_backend if "full_size" in name else oracle_backend, seed=31)
     tree = iif.buildTreeReset(fg, order)
     tp = iif.TreeProgram(fg, tree, seed=31)
     N = fg.solverParams.N
+    if "full_size" in name and os.environ.get("NBP_STAGEWISE_FULL"):
+        from oracle.oracle_backend import OracleBackend
+        oracle_backend = lambda n, sl, side_ints=0: OracleBackend(n, sl, side_ints, threads=64)  # noqa: E731
     bes = [oracle_backend(N, tp.n_slots), hip_backend(N, tp.n_slots)]
     progs = []
     try:
