@@ -665,6 +665,12 @@ static nbp_status ensure_gstats(nbp_ctx *c, size_t need) {
 // latency of a single fit when the launch cannot fill the chip; P = 2 (512 lanes) lets four
 // workgroups share a CU so that the barrier/combine phases of one overlap the pair loop of the
 // others when there are many fits (throughput mode).
+// throughput-mode fits whose workgroup is 4k + 1 waves (N = 257 .. 320: config 5's N = 300) run the five-waves-per-SIMD
+// instances of the fit kernels: four such workgroups per CU, five waves on every SIMD, instead of three (nbp_kernels.h)
+static bool rows_of_4k_plus_1_waves(const nbp_ctx *c, int P) {
+  static const bool off = getenv("NBP_NO_W5_FITS") != nullptr;
+  return !off && P == 1 && ((c->Npad >> 6) & 3) == 1 && c->Npad > 64;
+}
 static int lcv_helpers(nbp_ctx *c, int nblocks) {
   static const int p2_min = getenv("NBP_LCV_P2_MIN") ? atoi(getenv("NBP_LCV_P2_MIN")) : 256;
   static const int p1_min = getenv("NBP_LCV_P1_MIN") ? atoi(getenv("NBP_LCV_P1_MIN")) : 4 * 256;
@@ -733,8 +739,8 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
     hipLaunchKernelGGL(nbp_prep_kernel_spec<2>, dim3(3 * nbw * KS + nkd), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
                        dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters, c->spec);
   else
-    hipLaunchKernelGGL(nbp_prep_kernel, dim3(3 * nbw + nkd), dim3(P * c->Npad), lds, c->stream, bw_slots, bw_manis, nbw,
-                       dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
+    hipLaunchKernelGGL(rows_of_4k_plus_1_waves(c, P) ? nbp_prep_kernel_w5 : nbp_prep_kernel, dim3(3 * nbw + nkd), dim3(P * c->Npad), lds, c->stream,
+                       bw_slots, bw_manis, nbw, dev, n, kdF, c->arena, c->ws, c->N, c->Npad, c->S, c->T, c->counters);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[1]);
 }
@@ -886,8 +892,17 @@ static nbp_status launch_bandwidth(nbp_ctx *c, const int32_t *dev_slots, const i
     hipLaunchKernelGGL(nbp_bandwidth_kernel_spec<2>, dim3(n, 3, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
                        dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters, c->spec);
   else
-    hipLaunchKernelGGL(nbp_bandwidth_kernel, dim3(n, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
+  {
+    auto *kern = rows_of_4k_plus_1_waves(c, P) ? nbp_bandwidth_kernel_w5 : nbp_bandwidth_kernel;
+    if (getenv("NBP_DEBUG_OCCUPANCY")) {  // what the runtime says a CU can hold of this launch
+      int nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, P * c->Npad, nbp_bandwidth_lds_bytes(c->N, c->Npad, P));
+      fprintf(stderr, "[nbp] nbp_bandwidth_kernel%s: %d lanes, %zu B of LDS per workgroup: %d workgroups = %d waves per CU\n",
+              kern == nbp_bandwidth_kernel_w5 ? "_w5" : "", P * c->Npad, nbp_bandwidth_lds_bytes(c->N, c->Npad, P), nb, nb * (P * c->Npad / 64));
+    }
+    hipLaunchKernelGGL(kern, dim3(n, 3), dim3(P * c->Npad), nbp_bandwidth_lds_bytes(c->N, c->Npad, P), c->stream,
                        dev_slots, dev_manis, c->arena, c->N, c->Npad, c->S, c->counters);
+  }
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[3]);
 }

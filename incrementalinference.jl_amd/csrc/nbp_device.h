@@ -1407,17 +1407,35 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     // has two contributors -- its owner and the last wave -- each with ONE atomic add into a slot that starts at zero:
     // a + b = b + a, so the sums do not depend on which comes first.
     const int nfull = lastbase >> 6, own_ws = (A2 <= 32) ? (len + (64 >> lg2) - 1) >> (6 - lg2) : len;
+    // Fold (throughput mode, a row of 4k full waves and one more: N = 257 .. 320, the N = 300 of BASELINE's config 5): a
+    // workgroup of five busy waves runs at two thirds of the rate of one of four -- two of its waves share a SIMD and the
+    // other three wait for them at every barrier of the evaluation (0.96 against 0.69 ps per pair at N = 300 / 256,
+    // profiles/r04_lcv_five_wave_rows.txt).  So the full waves take the last wave's points between them, a 1/nfull share
+    // of the steps each (second phase below), and the last wave sits the pair loop out: four busy waves, one per SIMD.
+    // A wave's share of a folded point's row sum goes into the wave's OWN accumulator row (the combine adds the rows in wave
+    // order), not into `part`, where four atomic adds would arrive in any order.
+#ifdef NBP_X_NOFOLD
+    const bool fold = false;
+#else
+    const bool fold = (P == 1) && nfull >= 4 && (nfull & 3) == 0;
+#endif
     int Lw = len;
-    if (A < 64 && nfull > 0) Lw = min(len, (own_ws + nfull * len + nfull) / (nfull + 1));
+    if (A < 64 && nfull > 0 && !fold) Lw = min(len, (own_ws + nfull * len + nfull) / (nfull + 1));
     const int hand = len - Lw;
     double *accw = acc + w * 2 * N;
+    // second phase of a wave (wave-uniform): nf2 groups of 64 points from base2 on, c2 steps from step ta2 on
+    int nf2 = 0, base2 = 0, ta2 = 0, c2 = 0;
     if (!lastwave) {
       const int n4 = __builtin_amdgcn_readfirstlane(Lw >> 2), nt = __builtin_amdgcn_readfirstlane(Lw & 3);
       const double xi = x[i];
       const double s = circ ? loo_symmetric<true>(x, i, t0, n4, nt, false, xi, K, accw, tab)
                             : loo_symmetric<false>(x, i, t0, n4, nt, false, xi, K, accw, tab);
       lds_add((nbp_lds_double *)(part + p * Npad + i), s);
-    } else {
+      if (fold) {  // this wave's share of the steps of the last wave's points (scalar: the wave index through readfirstlane)
+        const int ws = __builtin_amdgcn_readfirstlane(w), q = (len + nfull - 1) / nfull, wa = min(len, ws * q);
+        nf2 = 1; base2 = lastbase; ta2 = t0 + wa; c2 = min(len, wa + q) - wa;
+      }
+    } else if (!fold) {
       const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l >> lg2 : 0;
       const int lenmin = len >> lgH, rem = len - (lenmin << lgH);
       const int ta = t0 + hh * lenmin + min(hh, rem);
@@ -1428,14 +1446,22 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
                               : loo_symmetric<false>(x, pi, ta, n4, nt, hh < rem, xi, K, accw, tab);
         lds_add((nbp_lds_double *)(part + p * Npad + pi), s);
       }
-      if (hand > 0) {
-        const int h4 = __builtin_amdgcn_readfirstlane(hand >> 2), ht = __builtin_amdgcn_readfirstlane(hand & 3);
-        for (int f = 0; f < nfull; f++) {
-          const int pj = 64 * f + l;
+      if (hand > 0) { nf2 = nfull; base2 = 0; ta2 = t0 + Lw; c2 = hand; }  // the tail steps of every full wave's points
+    }
+    nf2 = __builtin_amdgcn_readfirstlane(nf2);
+    c2 = __builtin_amdgcn_readfirstlane(c2);
+    base2 = __builtin_amdgcn_readfirstlane(base2);
+    if (nf2 > 0 && c2 > 0) {
+      const int h4 = c2 >> 2, ht = c2 & 3;
+      const int sta = __builtin_amdgcn_readfirstlane(ta2);
+      double *rowdst = fold ? accw : part + p * Npad;
+      for (int f = 0; f < nf2; f++) {
+        const int pj = base2 + 64 * f + l;
+        if (pj < N) {
           const double xj = x[pj];
-          const double s = circ ? loo_symmetric<true>(x, pj, t0 + Lw, h4, ht, false, xj, K, accw, tab)
-                                : loo_symmetric<false>(x, pj, t0 + Lw, h4, ht, false, xj, K, accw, tab);
-          lds_add((nbp_lds_double *)(part + p * Npad + pj), s);
+          const double s = circ ? loo_symmetric<true>(x, pj, sta, h4, ht, false, xj, K, accw, tab)
+                                : loo_symmetric<false>(x, pj, sta, h4, ht, false, xj, K, accw, tab);
+          lds_add((nbp_lds_double *)(rowdst + pj), s);
         }
       }
     }

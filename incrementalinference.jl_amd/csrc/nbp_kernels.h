@@ -19,6 +19,7 @@
 #define NBP_TU_PRODUNI 32   // product kernels, throughput geometries, one manifold per instance
 #define NBP_TU_FUSED 64     // the fused variable-update kernels
 #define NBP_TU_PRODUNI4 128 // product kernels, one manifold per instance, four helper lanes (the two-lane ones: NBP_TU_PRODUNI)
+#define NBP_TU_PREPW5 256   // bandwidth fits + KD builds at five waves per SIMD (rows of 4k + 1 waves: N = 257 .. 320)
 #ifndef NBP_TU
 #define NBP_TU 0xFFFF
 #endif
@@ -524,6 +525,20 @@ nbp_bandwidth_kernel(NBP_BANDWIDTH_ARGS) {
 #else
 __global__ void nbp_bandwidth_kernel(NBP_BANDWIDTH_ARGS);
 #endif
+// The same kernel at FIVE waves per SIMD, for workgroups of 4k + 1 waves (N = 257 .. 320: BASELINE's config 5 runs N = 300).
+// At four waves per SIMD a CU holds three such workgroups (15 waves); at five it holds four, 5 waves on every SIMD: 0.90 ->
+// 0.78 ps per pair at N = 300, config 5's fits 189 -> 165 ms (profiles/r04_lcv_five_wave_rows.txt).  The cap costs this
+// instance 16 B of scratch per lane (96 VGPRs); rows of 4k waves gain nothing from it (N = 200 / 256: 1 %) and keep the
+// scratch-free kernel above.
+#if NBP_TU & NBP_TU_PREPW5
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+nbp_bandwidth_kernel_w5(NBP_BANDWIDTH_ARGS) {
+  extern __shared__ double smem[];  // grid (jobs, 3)
+  lcv_slot_coordinate<0>(arena + S * slots[blockIdx.x], manifolds[blockIdx.x], blockIdx.y, N, Npad, smem, ctr);
+}
+#else
+__global__ void nbp_bandwidth_kernel_w5(NBP_BANDWIDTH_ARGS);
+#endif
 #if NBP_TU & NBP_TU_PREPSPEC
 template <int DEPTH>
 __global__ void __launch_bounds__(1024)
@@ -828,6 +843,15 @@ nbp_prep_kernel(NBP_PREP_ARGS) {
 }
 #else
 __global__ void nbp_prep_kernel(NBP_PREP_ARGS);
+#endif
+#if NBP_TU & NBP_TU_PREPW5  // five waves per SIMD: see nbp_bandwidth_kernel_w5
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5)))
+nbp_prep_kernel_w5(NBP_PREP_ARGS) {
+  extern __shared__ double smem[];
+  prep_body<0>(bw_slots, bw_manis, nbw, descs, nprod, kdF, arena, ws, N, Npad, S, T, ctr, nullptr, smem);
+}
+#else
+__global__ void nbp_prep_kernel_w5(NBP_PREP_ARGS);
 #endif
 // latency mode: 2^DEPTH - 1 workgroups per fit (lcv_bandwidth_1d_spec)
 #if NBP_TU & NBP_TU_PREPSPEC
