@@ -759,6 +759,17 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
   int g = (waves + cap - 1) / cap;
   *wpb = (waves + g - 1) / g;
   *G = (waves + *wpb - 1) / *wpb;
+  // Throughput geometries: workgroups of EIGHT waves when the even split is not a multiple of four (N = 300 at two helper
+  // lanes: 10 waves of samples -> two workgroups of 8 instead of two of 5; N = 200: 7 -> 8).  A workgroup whose waves do not
+  // divide over the four SIMDs leaves one of them a wave short and makes its own waves wait for each other at the level
+  // barriers; the idle waves of the rounder workgroup have no samples and cost a few barriers.  Config 5: products 174.9 ->
+  // 164.2 ms per solve; config 2: unchanged (7.91 / 7.92 ms).  Workgroups of four (more of them per product, every one staging
+  // the node statistics again) measured worse: 215.7 ms.  NBP_PRODUCT_WPB8=0: the even split.
+  static const bool wpb8 = !(getenv("NBP_PRODUCT_WPB8") && atoi(getenv("NBP_PRODUCT_WPB8")) == 0);
+  if (wpb8 && *HL <= 4 && (*wpb & 3)) {
+    *wpb = 8;
+    *G = (waves + 7) / 8;
+  }
 }
 // LDS budget of a product workgroup: beyond it the node statistics live in global memory ("big")
 static const size_t NBP_PRODUCT_LDS_CAP = 150 * 1024;
