@@ -755,7 +755,10 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
   static const int hl32_max = getenv("NBP_PRODUCT_HL32_MAX") ? atoi(getenv("NBP_PRODUCT_HL32_MAX")) : 15;
   static const int hl4_min = getenv("NBP_PRODUCT_HL4_MIN") ? atoi(getenv("NBP_PRODUCT_HL4_MIN")) : 80;  // (48 until round 4: 66-product rounds of config 2 run 147 instead of 207 us with eight helpers)
   *HL = n >= hl2_min ? 2 : (n >= hl4_min ? 4 : (n >= 16 ? 8 : (n > hl32_max ? 16 : 32)));
-  const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL >= 8) ? 6 : 8;
+  // latency geometries: workgroups of FOUR waves (one per SIMD of their CU; six until round 4: config 3's products 25.9 -> 24.4 ms,
+  // config 2's 7.93 -> 7.77, config 4's 110.6 -> 107.8; two / three / five waves measured worse than four)
+  static const int lat_cap = getenv("NBP_PRODUCT_LAT_CAP") ? atoi(getenv("NBP_PRODUCT_LAT_CAP")) : 4;
+  const int SW = 64 / *HL, waves = (c->N + SW - 1) / SW, cap = (*HL >= 8) ? lat_cap : 8;
   int g = (waves + cap - 1) / cap;
   *wpb = (waves + g - 1) / g;
   *G = (waves + *wpb - 1) / *wpb;
