@@ -418,7 +418,10 @@ NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, NBP_W_
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
 // CircularCircular on the circle (config 3, incl. its multihypo sightings) and ManifoldFactor on SE(2) (config 4)
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_circ, NBP_F_CIRCULAR, NBP_CIRCULAR, 3)
-NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_se2, NBP_F_SE2, NBP_SE2, 2)
+#ifndef NBP_W_SE2
+#define NBP_W_SE2 2  // (3: 168 VGPRs and 80 B of scratch per lane; measured, profiles/r04_lcv_five_wave_rows.txt section 5)
+#endif
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_se2, NBP_F_SE2, NBP_SE2, NBP_W_SE2)
 
 // ================================================================================================
 // Deconvolution kernel: one workgroup = one approxDeconv(dfg, fct) (DeconvUtils.jl:32-160), one lane
