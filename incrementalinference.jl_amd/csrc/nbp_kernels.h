@@ -415,7 +415,14 @@ __global__ void nbp_proposal_kernel(NBP_PROPOSAL_ARGS);
 #define NBP_W_LIN2 3
 #endif
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin2, NBP_F_LINREL, NBP_EUCLID2, NBP_W_LIN2)
-NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, 3)
+// Euclid(3) instance at FIVE waves per SIMD (96 VGPRs, 44 B of scratch per lane; 120 VGPRs = four waves per SIMD without the cap):
+// BASELINE's config 5 runs N = 300, i.e. workgroups of five waves, of which a CU holds three at four waves per SIMD (15 waves, two
+// waves of every workgroup on one SIMD) and four at five.  975 proposals at N = 300: 1018 -> 747 us, 4000: 3630 -> 3010 us; a lone
+// proposal and N = 200 unchanged (168 / 499 us); config 5 415 -> 404 ms per solve (profiles/r04_lcv_five_wave_rows.txt, section 5)
+#ifndef NBP_W_LIN3
+#define NBP_W_LIN3 5
+#endif
+NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_lin3, NBP_F_LINREL, NBP_EUCLID3, NBP_W_LIN3)
 // CircularCircular on the circle (config 3, incl. its multihypo sightings) and ManifoldFactor on SE(2) (config 4)
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_circ, NBP_F_CIRCULAR, NBP_CIRCULAR, 3)
 #ifndef NBP_W_SE2
