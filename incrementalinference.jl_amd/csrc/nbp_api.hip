@@ -686,7 +686,7 @@ static int coords_of(const int32_t *manis, size_t n) {
   for (size_t i = 0; i < n; i++) cds += manifold_dim_h(manis[i]);
   return cds;
 }
-static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G);
+static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G, int mani = 0);
 // The product launch of a batch takes the node sums from the sorted coordinates itself (the _xs kernels: 4 KB instead of
 // 33 KB of KD workspace per density through HBM) when the batch runs a single-manifold throughput kernel and every
 // product has at most NBP_FUSED_MAXF densities; the prep launch in front then leaves the node sums out.
@@ -694,7 +694,7 @@ static bool products_use_xs(nbp_ctx *c, int n, int maxFD, int mani) {
   static const bool off = getenv("NBP_NO_XS_PRODUCTS") != nullptr;
   if (off || mani == 0 || n <= 0) return false;
   int HL, wpb, G;
-  product_geometry(c, n, &HL, &wpb, &G);
+  product_geometry(c, n, &HL, &wpb, &G, mani);
   const int F = maxFD / 4, D = maxFD % 4;
   if (HL > 4 || F > NBP_FUSED_MAXF) return false;
   return nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) + 8 + nbp_product_xs_doubles(F, D, c->N) * 8 <= 150 * 1024;
@@ -749,7 +749,8 @@ static nbp_status launch_prep(nbp_ctx *c, const int32_t *bw_slots, const int32_t
 // waves, grid.y = G workgroups per product.  Latency mode (the launch cannot fill the chip): HL = 32 (fewer than 16
 // products; NBP_PRODUCT_HL32_MAX) or 8 and several small workgroups per product; throughput mode: HL = 2 so that one
 // workgroup covers all samples and the node statistics of a product are computed once.
-static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
+// `mani`: the manifold of a single-manifold batch (0: mixed; < 0: size for the widest workgroup any kernel takes)
+static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G, int mani) {
   if (c->geom_n) n = c->geom_n;  // one half of a two-stream round: the geometry of the whole batch
   static const int hl2_min = getenv("NBP_PRODUCT_HL2_MIN") ? atoi(getenv("NBP_PRODUCT_HL2_MIN")) : 192;
   static const int hl32_max = getenv("NBP_PRODUCT_HL32_MAX") ? atoi(getenv("NBP_PRODUCT_HL32_MAX")) : 15;
@@ -772,6 +773,16 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G) {
   if (wpb8 && *HL <= 4 && (*wpb & 3)) {
     *wpb = 8;
     *G = (waves + 7) / 8;
+  }
+  // a product whose samples need more than eight waves: ONE workgroup of up to sixteen (a multiple of four) where the kernel takes
+  // it -- the Euclidean instances, NBP_PROD_WIDE in nbp_kernels.h -- instead of a full workgroup and a nearly empty one, each
+  // staging the node statistics (N = 300 at two helper lanes: ten waves of samples; config 5's products 162 -> 122 ms per solve)
+  static const int wpb_max = getenv("NBP_PRODUCT_WPB_MAX") ? atoi(getenv("NBP_PRODUCT_WPB_MAX")) : 16;
+  const bool wide = mani < 0 || NBP_PROD_WIDE(mani);
+  if (wide && wpb_max > 8 && *HL <= 4 && waves > 8) {
+    const int g2 = (waves + wpb_max - 1) / wpb_max;
+    *wpb = (((waves + g2 - 1) / g2) + 3) & ~3;
+    *G = (waves + *wpb - 1) / *wpb;
   }
 }
 // LDS budget of a product workgroup: beyond it the node statistics live in global memory ("big")
@@ -836,7 +847,7 @@ static int products_uniform_manifold(const nbp_product_desc *d, int n) {
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD, int mani = 0) {
   if (n <= 0) return NBP_OK;
   int HL, wpb, G;
-  product_geometry(c, n, &HL, &wpb, &G);
+  product_geometry(c, n, &HL, &wpb, &G, mani);
   // maxFD encodes the largest (F, D) of the batch as F*4 + D
   const int F = maxFD / 4, D = maxFD % 4;
   bool big = nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP;
@@ -879,7 +890,7 @@ static nbp_status presize_products(nbp_ctx *c, int n, int maxFD) {
   nbp_status rc = ensure_ws(c, n, maxFD / 4);
   if (rc) return rc;
   int HL, wpb, G;
-  product_geometry(c, n, &HL, &wpb, &G);
+  product_geometry(c, n, &HL, &wpb, &G, -1);  // (the widest workgroup a kernel may take: the larger label table decides about the scratch)
   const int F = maxFD / 4, D = maxFD % 4;
   if (nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) {
     if (HL != 8) product_geometry(c, 16, &HL, &wpb, &G);
@@ -1714,7 +1725,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     if (ps.fused || !qs.need_prep || qs.flush_before) continue;
     {  // products too large for the LDS share one node-statistics workspace: single stream
       int HL, wpb, G;
-      product_geometry(p->ctx, qs.n, &HL, &wpb, &G);
+      product_geometry(p->ctx, qs.n, &HL, &wpb, &G, qs.mani);
       if (nbp_product_lds_bytes(qs.maxfd / 4, qs.maxfd % 4, p->ctx->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) continue;
     }
     const nbp_product_desc *qd = (const nbp_product_desc *)(p->blob.data() + qs.offset);

@@ -891,6 +891,12 @@ struct product_lds {
 // RESIDENT LEVELS (bit 17 of a product kernel's F argument): the node statistics of EVERY level are staged once, at node
 // index = position, and the workgroup's waves then walk the levels without a barrier between them (2.3 N nodes per row
 // instead of N: taken where the LDS of two workgroups per CU allows it, launch_products)
+// Largest workgroup of a throughput product kernel: 16 waves for the Euclidean instances (<= 128 VGPRs: the bound costs them
+// nothing), 8 for the others (the SE(2) and generic kernels hold 186-221 VGPRs and would spill under a bound of 12 or 16 waves).
+// A product whose samples need more than eight waves (N = 300 at two helper lanes: ten) then runs as ONE workgroup, with one
+// staging of the node statistics, instead of a full one and a nearly empty one: config 5's products 162 -> 122 ms per solve.
+#define NBP_PROD_WIDE(MANI) ((MANI) == NBP_EUCLID1 || (MANI) == NBP_EUCLID2 || (MANI) == NBP_EUCLID3)
+#define NBP_PROD_LB(MANI) (NBP_PROD_WIDE(MANI) ? 1024 : 512)
 #define NBP_PROD_ALL_LEVELS 0x20000
 
 // `big` = the per-level node statistics (3 x F x D x N doubles) do not fit the LDS: they go to a scratch
@@ -1570,11 +1576,11 @@ __global__ void nbp_product_kernel_t2(NBP_PRODUCT_ARGS);
 #if NBP_TU & (NBP_TU_PRODUNI | NBP_TU_PRODUNI4)
 #define NBP_PRODUCT_UNIFORM_W(NAME, MANI, HL, NBP_UNIFORM_WAVES) NBP_PRODUCT_UNIFORM_W##HL(NAME, MANI, HL, NBP_UNIFORM_WAVES)
 #define NBP_PRODUCT_UNIFORM_DEF(NAME, MANI, HL, NBP_UNIFORM_WAVES)                                                                        \
-  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME(NBP_PRODUCT_ARGS) { \
+  __global__ void __launch_bounds__(NBP_PROD_LB(MANI)) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME(NBP_PRODUCT_ARGS) { \
     extern __shared__ double smem[];                                                                               \
     product_kernel_uniform<MANI, HL, false>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                    \
   }                                                                                                                \
-  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME##_xs(NBP_PRODUCT_ARGS) { \
+  __global__ void __launch_bounds__(NBP_PROD_LB(MANI)) __attribute__((amdgpu_waves_per_eu(NBP_UNIFORM_WAVES))) NAME##_xs(NBP_PRODUCT_ARGS) { \
     extern __shared__ double smem[];                                                                               \
     product_kernel_uniform<MANI, HL, true>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);                     \
   }
