@@ -779,7 +779,9 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G, int m
   // staging the node statistics (N = 300 at two helper lanes: ten waves of samples; config 5's products 162 -> 122 ms per solve)
   static const int wpb_max = getenv("NBP_PRODUCT_WPB_MAX") ? atoi(getenv("NBP_PRODUCT_WPB_MAX")) : 16;
   const bool wide = mani < 0 || NBP_PROD_WIDE(mani);
-  if (wide && wpb_max > 8 && *HL <= 4 && waves > 8) {
+  // (two helper lanes only, i.e. launches that fill the chip: a launch of 80-191 products at four helper lanes leaves CUs idle, and
+  //  there two workgroups per product on two CUs beat one on one -- config 2: 18.34 against 18.58 ms)
+  if (wide && wpb_max > 8 && *HL == 2 && waves > 8) {
     const int g2 = (waves + wpb_max - 1) / wpb_max;
     *wpb = (((waves + g2 - 1) / g2) + 3) & ~3;
     *G = (waves + *wpb - 1) / *wpb;
