@@ -774,6 +774,16 @@ static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G, int m
     *wpb = 8;
     *G = (waves + 7) / 8;
   }
+  // The circle: workgroups of FOUR waves in the throughput geometries too.  Its instances hold 162 VGPRs = three waves per SIMD =
+  // twelve wave slots per CU, of which one workgroup of eight leaves four empty and three workgroups of four none; the second
+  // staging per product is cheap in one dimension.  Config 3: products 24.4 -> 22.8 ms, 52.8 -> 51.3 ms per solve.  (SE(2), two
+  // waves per SIMD and a costly staging: 107 -> 126 ms -- it keeps eight.)  NBP_PRODUCT_THR_WPB overrides for every manifold.
+  static const int thr_wpb = getenv("NBP_PRODUCT_THR_WPB") ? atoi(getenv("NBP_PRODUCT_THR_WPB")) : 0;
+  const int tw = thr_wpb > 0 ? thr_wpb : (mani == NBP_CIRCULAR ? 4 : 0);
+  if (tw > 0 && *HL <= 4) {
+    *wpb = tw;
+    *G = (waves + tw - 1) / tw;
+  }
   // a product whose samples need more than eight waves: ONE workgroup of up to sixteen (a multiple of four) where the kernel takes
   // it -- the Euclidean instances, NBP_PROD_WIDE in nbp_kernels.h -- instead of a full workgroup and a nearly empty one, each
   // staging the node statistics (N = 300 at two helper lanes: ten waves of samples; config 5's products 162 -> 122 ms per solve)
