@@ -156,7 +156,7 @@ typedef struct nbp_proposal_desc {
 typedef struct nbp_product_desc {
   int32_t manifold;
   int32_t nfactors;            /* 1 = pass-through (AMP returns the single density)            */
-  int32_t niter;               /* Gibbs sweeps per tree level, 1 .. 7 (reference passes Niter=1) */
+  int32_t niter;               /* Gibbs sweeps per tree level, 1 .. 8 (reference passes Niter=1) */
   int32_t out_slot;            /* belief slot that receives points + bandwidth                 */
   int32_t in_slot[NBP_MAXF];   /* proposal slots                                               */
   int32_t labels_out;          /* >=0: offset in the int32 side buffer for labels[N][nfactors] */

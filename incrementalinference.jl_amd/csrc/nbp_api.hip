@@ -559,7 +559,7 @@ static nbp_status check_products(nbp_ctx *c, const nbp_product_desc *d, int n) {
     const nbp_product_desc &p = d[i];
     if (!manifold_ok(p.manifold)) return fail(NBP_ERR_ARG, "product: unknown manifold");
     if (p.nfactors < 1 || p.nfactors > NBP_MAXF) return fail(NBP_ERR_RANGE, "product: nfactors");
-    if (p.niter < 1 || p.niter > 7) return fail(NBP_ERR_RANGE, "product: niter (1 .. 7: the eighth stream of a level belongs to the draw on the point)");
+    if (p.niter < 1 || p.niter > 8) return fail(NBP_ERR_RANGE, "product: niter (1 .. 8)");
     if (p.out_slot < 0 || p.out_slot >= c->n_slots) return fail(NBP_ERR_RANGE, "product: out_slot");
     for (int k = 0; k < p.nfactors; k++)
       if (p.in_slot[k] < 0 || p.in_slot[k] >= c->n_slots) return fail(NBP_ERR_RANGE, "product: in_slot");
@@ -687,6 +687,9 @@ static int coords_of(const int32_t *manis, size_t n) {
   return cds;
 }
 static void product_geometry(nbp_ctx *c, int n, int *HL, int *wpb, int *G, int mani = 0);
+// the sin / cos rows of the node statistics are part of a product launch's LDS unless it runs a single-manifold throughput
+// kernel of a manifold without a circular coordinate (product_kernel_uniform lays its LDS out by the same rule)
+static inline bool product_lays_circ(int HL, int mani) { return HL >= 8 || !(mani == NBP_EUCLID1 || mani == NBP_EUCLID2 || mani == NBP_EUCLID3); }
 // The product launch of a batch takes the node sums from the sorted coordinates itself (the _xs kernels: 4 KB instead of
 // 33 KB of KD workspace per density through HBM) when the batch runs a single-manifold throughput kernel and every
 // product has at most NBP_FUSED_MAXF densities; the prep launch in front then leaves the node sums out.
@@ -697,7 +700,8 @@ static bool products_use_xs(nbp_ctx *c, int n, int maxFD, int mani) {
   product_geometry(c, n, &HL, &wpb, &G, mani);
   const int F = maxFD / 4, D = maxFD % 4;
   if (HL > 4 || F > NBP_FUSED_MAXF) return false;
-  return nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) + 8 + nbp_product_xs_doubles(F, D, c->N) * 8 <= 150 * 1024;
+  return nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false, (size_t)2 * 2 * wpb * 64, product_lays_circ(HL, mani)) + 8 +
+             nbp_product_xs_doubles(F, D, c->N) * 8 <= 150 * 1024;
 }
 // the rendezvous areas of the next launch of speculative fits, blanked on the library's stream (nbp_spec_blank_kernel)
 static void blank_spec_areas(nbp_ctx *c, int jobs) {
@@ -862,18 +866,37 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   product_geometry(c, n, &HL, &wpb, &G, mani);
   // maxFD encodes the largest (F, D) of the batch as F*4 + D
   const int F = maxFD / 4, D = maxFD % 4;
-  bool big = nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP;
+  // (the throughput geometries keep the chunk sums of their lanes in LDS: two chunks per lane at least)
+  bool big = nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false, HL <= 4 ? (size_t)2 * 2 * wpb * 64 : 0, product_lays_circ(HL, mani)) > NBP_PRODUCT_LDS_CAP;
   if (big && HL != 8) {  // many densities: small sample groups keep the label table in LDS
     product_geometry(c, 16, &HL, &wpb, &G);
   }
   const int TB = wpb * 64, SPB = TB / HL;
+  const bool circ = product_lays_circ(HL, mani);
   const bool xs = !big && products_use_xs(c, n, maxFD, mani);
-  size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
+  const size_t xsb = xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0;
+  // chunks per helper range of a throughput launch (pass 2 of a draw rescans ONE chunk): as many as the LDS takes while two
+  // workgroups still share a CU (80 KB each), else as many as one workgroup's budget takes
+  int nch = 0;
+  if (HL <= 4 && !big) {
+    static const int nch_env = getenv("NBP_PRODUCT_NCH") ? atoi(getenv("NBP_PRODUCT_NCH")) : 0;
+    static const size_t half = getenv("NBP_PRODUCT_NCH_KB") ? (size_t)atoi(getenv("NBP_PRODUCT_NCH_KB")) * 1024 : 80 * 1024;
+    auto lds_for = [&](int k) { return nbp_product_lds_bytes(F, D, c->N, SPB, false, (size_t)k * 2 * TB, circ) + xsb; };
+    nch = 2;
+    const int cand[2] = {8, 4};
+    for (int k : cand)
+      if (lds_for(k) <= half) { nch = k; break; }
+    if (nch == 2 && lds_for(2) > half)
+      for (int k : cand)
+        if (lds_for(k) <= NBP_PRODUCT_LDS_CAP) { nch = k; break; }
+    if (nch_env >= 1 && nch_env <= 15 && lds_for(nch_env) <= 160 * 1024) nch = nch_env;
+  }
+  size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big, (size_t)nch * 2 * TB, circ) + xsb;
   if (lds > 160 * 1024) return fail(NBP_ERR_RANGE, "product: too many densities for the LDS label table");
   // resident levels (NBP_PROD_ALL_LEVELS): the statistics of every tree level staged once, no barrier between the levels
   // of the Gibbs walk -- where two workgroups of the launch still fit a CU's 160 KB
   static const size_t all_cap = getenv("NBP_PRODUCT_ALL_LEVELS_KB") ? (size_t)atoi(getenv("NBP_PRODUCT_ALL_LEVELS_KB")) * 1024 : 76 * 1024;
-  int flagsF = F;
+  int flagsF = F | (nch << NBP_PROD_NCH_SHIFT);
   // (the latency geometries only: a lone product saves nine round trips to the KD workspace and eighteen barriers, 126 -> 116 us;
   //  a chip-filling launch gains nothing -- NBP_PRODUCT_ALL_LEVELS_HL = 2 switches it on there too)
   static const int all_hl = getenv("NBP_PRODUCT_ALL_LEVELS_HL") ? atoi(getenv("NBP_PRODUCT_ALL_LEVELS_HL")) : 8;

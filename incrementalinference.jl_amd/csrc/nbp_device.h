@@ -37,6 +37,7 @@
 #define PURP_OLDSEL 12    // sample(oldBel, nn): kernel pick / noise of the top-up of a belief with fewer than N points
 #define PURP_OLDNOISE 13
 #define PURP_PLEVEL 14    // samplePoint! between the levels of the product sampler (k = 2 l, 2 l + 1)
+#define PURP_PINDEX 15    // one block per (sample, pass, density), k = pass * NBP_MAXF + density: ua -> sampleIndices!, ub -> the first sweep's sampleIndex
 #define NBP_TAG 0x4E4250u
 
 #define NBP_MAXLEVELS 12
@@ -116,6 +117,14 @@ __device__ __attribute__((noinline)) double2 normal_pair_call(uint64_t seed, uin
   const double r = sqrt(-2.0 * log(ua));
   sincos_fast(NBP_TWO_PI * ub, &s, &c);
   return make_double2(r * c, r * s);
+}
+
+// a uniform pair as a leaf call (the latency-mode product kernels hold five manifolds' instances of the sampler at 252-256
+// registers: the block inlined at the top of every pass put 16 B per lane into scratch)
+__device__ __attribute__((noinline)) double2 uniform_pair_call(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k) {
+  double ua, ub;
+  uniform_pair(seed, n, purpose, k, ua, ub);
+  return make_double2(ua, ub);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,6 +260,15 @@ __device__ __forceinline__ double exp_nonpos(double x, const double *tab) {
   int hi;
   asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(hi) : "v"(n), "v"(__double2hiint(w)));  // 2^(n >> 8) onto the exponent field
   return __hiloint2double(hi, __double2loint(w)) * p;
+}
+
+// 1/sqrt(x) of a positive, finite, normal x (products of node variances): the device library's rsqrt -- v_rsq_f64 and one
+// coupled refinement step -- without its class test and the two selects behind it (three of ~50 vector instructions per
+// node weight of the product sampler's sweep); the same value bit for bit on such x
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(y0 * -x, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -55,7 +55,8 @@ __host__ __device__ inline size_t nbp_update_lds_layout(int Fmax, int D, int N, 
   const size_t fit = 2 * (size_t)N + (size_t)P * Npad + (size_t)(P * Npad / 64) * 2 * N + NBP_RED + NBP_FITTAB;
   const size_t kd = nbp_update_kd_doubles(D, N, Npad, P) + ((size_t)N + 1) / 2 /* idx */;
   const size_t bulk = (size_t)Fmax * D * N;
-  const size_t prodL = 3 * bulk + (circ ? 2 * (size_t)Fmax * N : 0) + (size_t)Fmax * N /* lg */ + 6 * (size_t)Fmax + N + ((size_t)Fmax * Npad * 2 + 1) / 2 /* ind | nxt */;
+  const size_t prodL = 3 * bulk + (circ ? 2 * (size_t)Fmax * N : 0) + (size_t)Fmax * N /* lg */ + 6 * (size_t)Fmax + N + 2 * (size_t)Fmax * Npad /* uu */ +
+                       ((size_t)Fmax * Npad * 2 + 1) / 2 /* ind | nxt */;
   size_t t = prop;
   if (fit > t) t = fit;
   if (kd > t) t = kd;
@@ -175,6 +176,8 @@ __device__ __forceinline__ void update_body(const nbp_update_desc *uds, const nb
     fio.L.h2 = b; b += (size_t)F * 3;
     fio.L.nw = b; b += N;
     fio.L.tab = FL.tab;
+    fio.L.uu = b; b += 2 * (size_t)F * Npad;  // (a workgroup of P x Npad lanes serves Npad samples)
+    fio.L.ck = nullptr;                        // chunk sums in registers
     fio.L.ind = (int *)b;
     fio.L.ns = N;
     fio.xs = FL.slot;
@@ -185,7 +188,7 @@ __device__ __forceinline__ void update_body(const nbp_update_desc *uds, const nb
     fio.bw = FL.bw;
     fio.out = FL.slot;
   }
-  product_body<M, false, P, false, true>(d, arena, nullptr, 0, nullptr, N, S, side, T, FL.tr, &fio);
+  product_body<M, false, P, false, 1>(d, arena, nullptr, 0, nullptr, N, S, side, T, FL.tr, &fio);
   __syncthreads();
   NBP_TICK(53);  // product
   // ---- setBelief! (SolveTree.jl:74): manikde! of the result (when anything reads it), one write of the new belief -----

@@ -885,6 +885,8 @@ template <int DEPTH> __global__ void nbp_prep_kernel_spec(NBP_PREP_ARGS, nbp_spe
 // product), 4 or 2 when it can (throughput: one workgroup per product computes the node statistics once).
 struct product_lds {
   double *lm, *lv, *lr, *ls, *lc, *lg, *cen, *h2, *nw, *tab;
+  double *uu;  // [F][SPB][2]: the uniforms of this pass's draws (one Philox block per sample and density: sampleIndices! | first sweep)
+  double *ck;  // [nch][2][TB]: chunk sums and running maxima of a lane's pass-1 range (throughput geometries; CK doubles)
   int *ind;
   int ns;  // nodes a (density, coordinate) row holds: N (one level at a time) or the node count of the whole tree
 };
@@ -898,12 +900,19 @@ struct product_lds {
 #define NBP_PROD_WIDE(MANI) ((MANI) == NBP_EUCLID1 || (MANI) == NBP_EUCLID2 || (MANI) == NBP_EUCLID3)
 #define NBP_PROD_LB(MANI) (NBP_PROD_WIDE(MANI) ? 1024 : 512)
 #define NBP_PROD_ALL_LEVELS 0x20000
+// bits 18 .. 21 of the same argument: chunks per helper range of the throughput geometries (their sums live in LDS; the host
+// takes as many as the LDS of the launch allows, launch_products)
+#define NBP_PROD_NCH_SHIFT 18
+#define NBP_PROD_NCH(kdF) ((((kdF) >> NBP_PROD_NCH_SHIFT) & 15) ? (((kdF) >> NBP_PROD_NCH_SHIFT) & 15) : 2)
 
 // `big` = the per-level node statistics (3 x F x D x N doubles) do not fit the LDS: they go to a scratch
 // area private to the workgroup in global memory and are served by L1/L2; LDS then holds only the small
 // per-product items.
 __host__ __device__ inline size_t nbp_product_gstats_doubles(int F, int D, int N) { return (3 * (size_t)F * D + 3 * (size_t)F) * N; }
-__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L, int NS = 0) {
+// CK: doubles of the chunk area (throughput geometries: nch x 2 x lanes of the workgroup; 0: chunk sums stay in registers);
+// circ: the launch may hold a product with a circular coordinate (false: the sin / cos rows are left out)
+__host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SPB, bool big, double *base, product_lds *L, int NS = 0,
+                                                     size_t CK = 0, bool circ = true) {
   size_t o = 0;
   auto dbl = [&](size_t n) { size_t r = o; o += n; return r; };
   if (NS <= 0) NS = N;
@@ -911,16 +920,18 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
   size_t lm = dbl(bulk), lv = dbl(bulk), lr = dbl(bulk);
   // circular coordinate (one per manifold at most): sin / cos of every node mean times its precision, so that the
   // conditional mean of a draw is two sums and one atan2 instead of a sincos per density
-  size_t ls = dbl(big ? 0 : (size_t)F * NS), lc = dbl(big ? 0 : (size_t)F * NS);
+  size_t ls = dbl((big || !circ) ? 0 : (size_t)F * NS), lc = dbl((big || !circ) ? 0 : (size_t)F * NS);
   // g_z = w_z / sqrt(prod_k var_zk): the weight of node z beside its exponential when the label is drawn on a POINT
   // (sampleIndices!: nothing is added to the node's own variance), once per node instead of once per draw
   size_t lg = dbl(big ? 0 : (size_t)F * NS);
   size_t cen = dbl((size_t)F * 3), h2 = dbl((size_t)F * 3);
   size_t nw = dbl((size_t)NS), tab = dbl(NBP_EXPTAB);
+  size_t uu = dbl((size_t)2 * F * SPB), ck = dbl(CK);
   size_t ints0 = o;
   if (L) {
     L->lm = base + lm; L->lv = base + lv; L->lr = base + lr; L->ls = base + ls; L->lc = base + lc; L->lg = base + lg; L->cen = base + cen; L->h2 = base + h2;
     L->nw = base + nw; L->tab = base + tab;
+    L->uu = base + uu; L->ck = base + ck;
     L->ind = (int *)(base + ints0);
     L->ns = NS;
   }
@@ -948,10 +959,14 @@ struct nbp_fused_io {
   const double *bw;                   // [F][3]
   double *out;                        // slot-shaped LDS area that receives the product's points
 };
-template <int MANI, bool PARTIAL, int HL, bool BIG, bool FUSED = false>
+// FUSED: 0 = densities from the KD workspaces; 1 = the fused update kernel (everything in LDS, `fio` made by the caller);
+//        2 = the _xs product kernels (sorted coordinates staged in LDS, `fio->L` laid out by product_lds_layout)
+// nch (throughput geometries, HL <= 4, not the update kernel): chunks per helper range, their sums kept in LDS (`L.ck`)
+template <int MANI, bool PARTIAL, int HL, bool BIG, int FUSED = 0>
 __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *arena, const double *ws, int kdF, double *gstats,
                                              int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem,
-                                             const nbp_fused_io *fio = nullptr, bool all_levels = false) {
+                                             const nbp_fused_io *fio = nullptr, bool all_levels = false, int nch = 2, bool lay_circ = true) {
+  constexpr bool CKL = (HL <= 4) && (FUSED != 1);  // chunk sums in LDS
   constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
   constexpr bool circ[3] = {MANI == NBP_CIRCULAR, false, MANI == NBP_SE2};
   const int F = d->nfactors, tid = threadIdx.x, TB = blockDim.x;
@@ -963,7 +978,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   product_lds L;
   const int TOT = T.off[T.L] + T.cnt[T.L];
   if constexpr (FUSED) L = fio->L;
-  else product_lds_layout(F, D, N, SPB, big, smem, &L, (all_levels && !big) ? TOT : N);
+  else product_lds_layout(F, D, N, SPB, big, smem, &L, (all_levels && !big) ? TOT : N, CKL ? (size_t)nch * 2 * TB : 0, lay_circ);
   const int NS = big ? N : L.ns;   // row length of the statistics
   const bool all = NS != N;        // every level resident
   double *cen = L.cen, *h2 = L.h2;
@@ -1089,6 +1104,24 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     __syncthreads();
     NBP_CTICK(41);  // node statistics
     }
+    // The uniforms of this pass: ONE Philox block per (sample, density) -- its first uniform for sampleIndices!, its second for
+    // the first sweep's sampleIndex.  The helper lanes of a sample take turns at the densities (lane h makes the blocks of
+    // j = h, h + HL, ...: with two densities and two helpers one block's worth of instructions per pass instead of four) and
+    // hand them over through LDS; the lanes of a sample are lanes of one wave, whose LDS operations stay in order.
+    // (the latency geometries -- 8 to 32 helpers per sample, a CU to themselves, five manifolds' instances in one kernel at
+    //  252 registers -- make the block where it is used, once for each of its two uniforms: the hand-over cost them scratch)
+    constexpr bool UUL = HL <= 4;
+    if (UUL && ps > 0 && live)
+      for (int j0 = 0; j0 < F; j0 += HL) {
+        const int j = j0 + h;
+        if (j < F) {
+          double u0, u1;
+          uniform_pair(d->seed, s, PURP_PINDEX, (uint32_t)(ps * NBP_MAXF + j), u0, u1);
+          L.uu[(j * SPB + sl) * 2] = u0;
+          L.uu[(j * SPB + sl) * 2 + 1] = u1;
+        }
+      }
+    NBP_CTICK(43);  // the uniforms of the pass
     // mean and precision of the product of the selected Gaussians (for the samplePoint! at the top of the next pass)
     auto point_moments = [&]() {
 #pragma unroll
@@ -1129,9 +1162,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #ifndef NBP_X_NCH
 #define NBP_X_NCH 2  // (four chunks cost sixteen more registers: 51 spilled at four waves per SIMD, 142 MB of scratch traffic per chip-filling launch; with the helpers rescanning a chunk together the longer chunk costs nothing)
 #endif
-        constexpr int NCH = NBP_X_NCH;
+        constexpr int NCH = NBP_X_NCH;  // chunks per helper range where their sums stay in registers
+        const int nchk = CKL ? nch : NCH;
         double mn[D], vn[D], ua = 0, ub = 0, m = -INFINITY, tot = 0;
-        double cs[NCH], ms[NCH];
+        double cs[CKL ? 1 : NCH], ms[CKL ? 1 : NCH];
+        double *ckc = L.ck + tid;  // chunk c of this lane: sum at ckc[2 c TB], running maximum at ckc[(2 c + 1) TB]
+        (void)cs; (void)ms; (void)ckc;
         const double *mj = lm + j * D * NS + lb, *vj = lv + j * D * NS + lb, *rj = lr + j * D * NS + lb, *gj = lgw + j * NS + lb;
         double linv[D];
         bool use[D];  // PARTIAL: coordinates informed by density j and by at least one other
@@ -1164,13 +1200,13 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             if constexpr (D == 1) { pv = v[0]; num = t[0]; }
             else if constexpr (D == 2) { pv = v[0] * v[1]; num = t[0] * v[1] + t[1] * v[0]; }
             else { const double v01 = v[0] * v[1]; pv = v01 * v[2]; num = t[0] * (v[1] * v[2]) + t[1] * (v[0] * v[2]) + t[2] * v01; }
-            const double r = rsqrt(pv);
+            const double r = rsqrt_pos(pv);
             a = -0.5 * num * (r * r);
             g = r * L.nw[lb + z];
           }
         };
         // chunk size of this helper's range: a multiple of 4, the pass-1 loop takes the nodes four at a time
-        const int zr = z1 - z0, csz = (((zr + NCH - 1) / NCH) + 3) & ~3;
+        const int zr = z1 - z0, csz = (((zr + nchk - 1) / nchk) + 3) & ~3;
         // a level with at most SR nodes per helper -- every level of a 200-particle tree at 32 helpers, the three or four
         // coarsest levels at 2 or 4 -- keeps the weights in registers: no chunks, no rescan, one exponential per node
 #ifndef NBP_X_SR_THR
@@ -1214,8 +1250,12 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
             for (int k = 0; k < D; k++) linv[k] = (PARTIAL && !use[k]) ? 0.0 : 1.0 / (h2[j * 3 + k] + vn[k]);
           }
-          uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + (it < 0 ? 7 : it)) * NBP_MAXF + j), ua, ub);
-          NBP_CTICK(43);  // conditional mean / variance of the other densities + the uniform
+          if (UUL && it <= 0) ua = L.uu[(j * SPB + sl) * 2 + (it < 0 ? 0 : 1)];
+          else {  // further sweeps: a block each
+            uniform_pair(d->seed, s, it <= 0 ? PURP_PINDEX : PURP_PGIBBS, (uint32_t)(it <= 0 ? ps * NBP_MAXF + j : (ps * 8 + it) * NBP_MAXF + j), ua, ub);
+            if (it == 0) ua = ub;
+          }
+          NBP_CTICK(44);  // conditional mean / variance of the other densities
           if (shortr) {  // at most SR nodes per helper: their weights stay in registers, nothing is evaluated twice
             // (nzmax = the longest range of the level, wave-uniform: the coarse levels of a 32-helper geometry have one node
             //  per helper or none, and the unrolled slots beyond that are branched over, not predicated through)
@@ -1236,11 +1276,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               wr[i] = (z0 + i < z1) ? exp_nonpos(wr[i] - m, L.tab) * gr[i] : 0.0;
               tot += wr[i];
             }
-          } else
-#pragma unroll
-          for (int c = 0; c < NCH; c++) {
-            double cur = 0;
-            const int za = z0 + c * csz, zb = min(z1, za + csz);
+          } else {
+          auto chunk = [&](int za, int zb, double &cur) {
             int z = za;
             // four nodes per step: four independent weight evaluations in flight (a lone wave on its SIMD is
             // bound by the dependent-chain latency of one) and one running-max update instead of four
@@ -1276,8 +1313,26 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               tot += w;
               cur += w;
             }
-            cs[c] = cur;
-            ms[c] = m;
+          };
+          if constexpr (CKL) {  // chunk c leaves the cumulative sum of the range up to its end and the running maximum there
+            for (int c = 0; c < nchk; c++) {
+              const int za = z0 + c * csz;
+              if (za >= z1) break;
+              double unused = 0;
+              chunk(za, min(z1, za + csz), unused);
+              ckc[(2 * c) * TB] = tot;
+              ckc[(2 * c + 1) * TB] = m;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+              double cur = 0;
+              const int za = z0 + c * csz;
+              chunk(za, min(z1, za + csz), cur);
+              cs[c] = cur;
+              ms[c] = m;
+            }
+          }
           }
         }
         NBP_CTICK(56 + (leaf ? 2 : 0) + (XP ? 1 : 0));  // pass 1: node weights of this helper's range (56 sweep, 57 on the point; 58 / 59 leaf level)
@@ -1314,14 +1369,26 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             double cacc = before;
             int za = z0, zb = z1;
             bool found = false;
+            if constexpr (CKL) {  // the cumulative sums the chunks left in LDS, each on the running maximum of its end
+              for (int c = 0; c < nchk; c++) {
+                const int ca = z0 + c * csz;
+                if (ca >= z1) break;
+                const double tc = ckc[(2 * c) * TB], mc = ckc[(2 * c + 1) * TB];
+                const double cum = (tc > 0) ? tc * exp_nonpos(mc - Mx, L.tab) : 0.0;
+                za = ca; zb = min(z1, ca + csz);  // the last non-empty chunk is the fallback
+                if (target < before + cum) { found = true; break; }
+                cacc = before + cum;
+              }
+            } else {
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-              const double shc = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
-              const int ca = z0 + c * csz, cb_ = min(z1, ca + csz);
-              if (!found && ca < cb_) {
-                za = ca; zb = cb_;  // the last non-empty chunk is the fallback
-                if (target < cacc + shc) found = true;
-                else cacc += shc;
+              for (int c = 0; c < NCH; c++) {
+                const double shc = (cs[c] > 0) ? cs[c] * exp_nonpos(ms[c] - Mx, L.tab) : 0.0;
+                const int ca = z0 + c * csz, cb_ = min(z1, ca + csz);
+                if (!found && ca < cb_) {
+                  za = ca; zb = cb_;  // the last non-empty chunk is the fallback
+                  if (target < cacc + shc) found = true;
+                  else cacc += shc;
+                }
               }
             }
             choice = zb - 1;
@@ -1446,13 +1513,14 @@ __device__ __forceinline__ void product_write_ipc(const nbp_product_desc *d, dou
 #define NBP_PRODUCT_BODY(M_, P_)                                                                              \
   do {                                                                                                        \
     if (HL >= 8 && gstats) product_body<M_, P_, HL, (HL >= 8)>(d, arena, ws, kdF, gstats, N, S, side, T, smem); \
-    else product_body<M_, P_, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem, nullptr, all_levels);  \
+    else product_body<M_, P_, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem, nullptr, all_levels, nch, true);  \
   } while (0)
 template <int HL>
 __device__ __forceinline__ void product_kernel_body(const nbp_product_desc *descs, double *arena, const double *ws, int kdF,
                                                     double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
   const bool all_levels = (kdF & NBP_PROD_ALL_LEVELS) != 0;
+  const int nch = NBP_PROD_NCH(kdF);
   kdF &= 0xFFFF;
   if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
   product_write_ipc(d, arena, N, S);
@@ -1489,6 +1557,8 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
                                                        double *gstats, int N, int64_t S, int32_t *side, const nbp_levels &T, double *smem) {
   const nbp_product_desc *d = descs + blockIdx.x;
   const bool all_levels = (kdF & NBP_PROD_ALL_LEVELS) != 0;
+  const int nch = NBP_PROD_NCH(kdF);
+  constexpr bool lay_circ = (MANI == NBP_CIRCULAR || MANI == NBP_SE2);  // (the host lays the LDS out the same way: launch_products)
   kdF &= 0xFFFF;
   if (d->nfactors == 1) { product_passthrough(d, arena, N, S, side); return; }
   product_write_ipc(d, arena, N, S);
@@ -1496,7 +1566,8 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
     constexpr int D = (MANI == NBP_SE2) ? 3 : (MANI == NBP_CIRCULAR ? 1 : MANI);
     const int F = d->nfactors, TB = blockDim.x, tid = threadIdx.x;
     nbp_fused_io fio;
-    const size_t own = (product_lds_layout(F, D, N, TB / HL, false, smem, &fio.L, all_levels ? T.off[T.L] + T.cnt[T.L] : N) + 7) / 8;
+    const size_t own = (product_lds_layout(F, D, N, TB / HL, false, smem, &fio.L, all_levels ? T.off[T.L] + T.cnt[T.L] : N,
+                                           HL <= 4 ? (size_t)nch * 2 * TB : 0, lay_circ) + 7) / 8;
     double *xs = smem + own, *cen = xs + (size_t)F * D * N, *bw = cen + 3 * F;
     const size_t wsd = nbp_kd_ws_doubles(N);
     const double *wsp = ws + (size_t)blockIdx.x * kdF * wsd;
@@ -1517,9 +1588,9 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
     fio.bw = bw;
     fio.out = arena + S * d->out_slot;
     __syncthreads();
-    product_body<MANI, false, HL, false, true>(d, arena, ws, kdF, gstats, N, S, side, T, smem, &fio);
+    product_body<MANI, false, HL, false, 2>(d, arena, ws, kdF, gstats, N, S, side, T, smem, &fio, false, nch, lay_circ);
   } else
-    product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem, nullptr, all_levels);  // HL = 4 / 2: never BIG (launch_products)
+    product_body<MANI, false, HL, false>(d, arena, ws, kdF, gstats, N, S, side, T, smem, nullptr, all_levels, nch, lay_circ);  // HL = 4 / 2: never BIG (launch_products)
 }
 
 // Entry points: the latency variants (HL = 32 for fewer than 16 products, 16 on request, HL = 8; few workgroups in flight) and the
@@ -1608,6 +1679,6 @@ NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_e3, NBP_EUCLID3, 4)
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_ci, NBP_CIRCULAR, 4)
 NBP_PRODUCT_UNIFORM(nbp_product_kernel_m4_se, NBP_SE2, 4)
 
-static inline size_t nbp_product_lds_bytes(int F, int D, int N, int SPB, bool big) {
-  return product_lds_layout(F, D, N, SPB, big, nullptr, nullptr);
+static inline size_t nbp_product_lds_bytes(int F, int D, int N, int SPB, bool big, size_t CK = 0, bool circ = true) {
+  return product_lds_layout(F, D, N, SPB, big, nullptr, nullptr, 0, CK, circ);
 }

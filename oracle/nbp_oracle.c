@@ -49,6 +49,7 @@
 #define PURP_PGIBBS 9
 #define PURP_PFINAL 10
 #define PURP_PLEVEL 14 /* samplePoint! between the levels of the product sampler */
+#define PURP_PINDEX 15 /* one block per (sample, pass, density): ua -> sampleIndices!, ub -> the first sweep's sampleIndex */
 #define PURP_ANYN 11
 #define PURP_OLDSEL 12
 #define PURP_OLDNOISE 13
@@ -1300,9 +1301,13 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
           xp[k] = is_circ(M, k) ? orc_wrap(v) : v;
         }
       }
+      /* One Philox block per (sample, pass, density) feeds both draws a density makes on a level with Niter = 1: its first
+         uniform the label given the point (sampleIndices!), its second the first sweep's sampleIndex; further sweeps
+         (it = 1 .. 7) have blocks of their own (PURP_PGIBBS). */
+      double ub_first[NBP_MAXF];
       for (int j = 0; j < F; j++) {
-        double ua, ub;
-        orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + 7) * NBP_MAXF + j), &ua, &ub);
+        double ua;
+        orc_uniform_pair(d->seed, s, PURP_PINDEX, (uint32_t)(ps * NBP_MAXF + j), &ua, &ub_first[j]);
         double ev[NBP_MAXN]; double m = -INFINITY;
         for (int z = 0; z < cnt; z++) {
           double e = 0;
@@ -1338,8 +1343,9 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             vn[k] = 1.0 / prec;
             mn[k] = is_circ(M, k) ? atan2(ss, sc) : acc * vn[k]; /* getMu: Euclid / getCircMu */
           }
-          double ua, ub;
-          orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + it) * NBP_MAXF + j), &ua, &ub);
+          double ua = ub_first[j], ub = 0;
+          (void)ub;
+          if (it > 0) orc_uniform_pair(d->seed, s, PURP_PGIBBS, (uint32_t)((ps * 8 + it) * NBP_MAXF + j), &ua, &ub);
           /* rand(Categorical(p)) by inverse CDF (max-stabilised weights) */
           double u = ua; int choice = -1;
           {
@@ -1362,7 +1368,6 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             if (choice < 0) choice = cnt - 1;
           }
           if (choice >= 0) ind[j] = choice;
-          (void)ub;
         }
       }
     }

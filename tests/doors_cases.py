@@ -35,7 +35,11 @@ def case_sighting_is_resolved_by_odometry(backend):
     assert 0.15 < by[mh] < 0.4, by            # ~1/4 of the particles per door hypothesis
     for f, v in by.items():
         if f != mh:
-            assert 0.55 < v < 0.95, by        # 1 - nullSurplusAdd of the sibling's particles, the rest spread
+            # 1 - nullSurplusAdd of the sibling's particles are solved; the rest keep x3's current value plus spreadNH x the
+            # belief's own spread of entropy (EvalFactor.jl:222-231) -- +-1.5 sigma of an initialised belief of sigma ~ 0.1-0.2,
+            # i.e. mostly still inside the 0.35 rad window: only the lower bound is informative (0.73 if they were
+            # scattered over the whole circle, less if the solved ones went astray)
+            assert 0.55 < v <= 1.0, by
     assert at(pts) > 0.9, at(pts)
     assert list(ipc) == [3.0]
     return by, at(pts)
