@@ -22,7 +22,15 @@ using StaticArrays
 using RecursiveArrayTools: ArrayPartition
 using Distributions
 using LinearAlgebra
+using Logging: ConsoleLogger
 
+# Dispatch contract of the overrides below.  None of them repeats a reference signature (a method with the signature of the
+# reference's would OVERWRITE it -- an error while an extension precompiles on Julia >= 1.10, and the `invoke` fall-backs
+# would then reach the override itself and recurse).  Every override is strictly MORE SPECIFIC in its graph argument: the
+# clique sub graph a state machine works on is an in-memory graph (`CliqStateMachineContainer.cliqSubFg::InMemG`,
+# entities/JunctionTreeTypes.jl:39; `LocalDFG` = `GraphsDFG`), whereas the reference's methods take `AbstractDFG`
+# (SolveTree.jl:164, CliqStateMachineUtils.jl:479, TreeMessageUtils.jl:279).  `invoke(f, Tuple{AbstractDFG, ...}, ...)`
+# therefore reaches the reference's method; a graph of another type never enters the shim.
 import IncrementalInference: upGibbsCliqueDensity, solveCliqDownFrontalProducts!, approxConvBelief, addLikelihoodsDifferentialCHILD!,
                              getSolverParams, getVariableType, getFactorType, getCliqueData, _getCCW,
                              TreeBelief, TreeClique, MsgPrior, setValKDE!
@@ -373,6 +381,13 @@ measok(fnc::Mixture) = all(z -> z isa NbpMeas, values(fnc.components)) && measok
 measok(::Union{PartialPriorPassThrough, MsgPrior}) = true
 measok(fnc, mechanicsonly::Bool = false) = mechanicsonly || (hasfield(typeof(fnc), :Z) && fnc.Z isa Union{NbpMeas, ManifoldKernelDensity})
 supported(fct::DFGFactor) = getFactorType(fct) isa Union{NbpUser, MsgPrior{<:ManifoldKernelDensity}} && measok(getFactorType(fct))
+# ... for a solve with N particles: the table of an AliasingScalarSampler lives in a belief slot of N rows, a longer one is
+# refused by nbp_clique_* (NBP_ERR_RANGE) -- such a factor's clique takes the generic path instead
+function supported(fct::DFGFactor, N::Int)
+  supported(fct) || return false
+  tb = tablesampler(getFactorType(fct))
+  return tb === nothing || length(tb.domain) <= N
+end
 
 # ---- beliefs at the boundary ------------------------------------------------------------------------------------------
 "host buffers of one TreeBelief; keeps them alive next to the C view"
@@ -510,7 +525,7 @@ TreeMessageUtils.jl:279-335 for a clique whose up solve ran on the device: the d
 nbp_clique_upsolve_joint in that call (same pairs, same order) and are handed over here; a clique that was solved by the
 generic path (unsupported factor) takes the generic method.
 """
-function addLikelihoodsDifferentialCHILD!(cliqSubFG::AbstractDFG, seps::Vector{Symbol}, tfg::AbstractDFG; solveKey::Symbol = :default)
+function addLikelihoodsDifferentialCHILD!(cliqSubFG::GraphsDFG, seps::Vector{Symbol}, tfg::AbstractDFG; solveKey::Symbol = :default)
   ret = lock(_DIFFS_LOCK) do
     pop!(_DIFFS, objectid(cliqSubFG), nothing)
   end
@@ -703,12 +718,12 @@ CliqStateMachineUtils.jl:375-385).  `dfg` is the clique sub graph with the child
 MsgPrior factors (addMsgFactors!, TreeMessageUtils.jl:542-578); like the reference it is updated in place
 (setBelief! of every variable the schedule touches) and the beliefs are returned as `Dict{Symbol,TreeBelief}`.
 """
-function upGibbsCliqueDensity(dfg::AbstractDFG, cliq::TreeClique, solveKey::Symbol, inmsgs, N::Int = getSolverParams(dfg).N,
-                              dbg::Bool = false, iters::Int = 3, logger = nothing)
+function upGibbsCliqueDensity(dfg::GraphsDFG, cliq::TreeClique, solveKey::Symbol, inmsgs, N::Int = getSolverParams(dfg).N,
+                              dbg::Bool = false, iters::Int = 3, logger = ConsoleLogger())
   cd = getCliqueData(cliq)
   labels = Symbol[cd.frontalIDs; cd.separatorIDs]
   factors = DFGFactor[getFactor(dfg, f) for f in lsf(dfg)]
-  all(supported, factors) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
+  all(f -> supported(f, N), factors) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
                                            dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)      # generic CPU path
   p = packclique(dfg, cliq, solveKey, N, labels, factors; senddiffs = true)
   runclique(:up, dfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64), iters)
@@ -730,7 +745,7 @@ end
 The clique down solve on the device (CliqStateMachineUtils.jl:479-571): `subfg` already holds the parent's separator
 values (updateSubFgFromDownMsgs!) and every factor of the frontals (addDownVariableFactors!, CliqueStateMachine.jl:823-835).
 """
-function solveCliqDownFrontalProducts!(subfg::AbstractDFG, cliq::TreeClique, opts::SolverParams, logger = nothing;
+function solveCliqDownFrontalProducts!(subfg::GraphsDFG, cliq::TreeClique, opts::SolverParams, logger = ConsoleLogger();
                                        solveKey::Symbol = :default, MCIters::Int = 3)
   cd = getCliqueData(cliq)
   inclq = Symbol[cd.frontalIDs; cd.separatorIDs]
@@ -739,7 +754,7 @@ function solveCliqDownFrontalProducts!(subfg::AbstractDFG, cliq::TreeClique, opt
     fc = getFactor(subfg, f)
     (getFactorType(fc) isa MsgPrior || fc in factors) || push!(factors, fc)
   end
-  MCIters == 3 && all(supported, factors) || return invoke(solveCliqDownFrontalProducts!, Tuple{AbstractDFG, TreeClique, SolverParams, Any},
+  MCIters == 3 && all(f -> supported(f, opts.N), factors) || return invoke(solveCliqDownFrontalProducts!, Tuple{AbstractDFG, TreeClique, SolverParams, Any},
                                                            subfg, cliq, opts, logger; solveKey, MCIters)
   others = Symbol[]
   for fc in factors, u in getVariableOrder(fc)

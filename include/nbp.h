@@ -53,7 +53,11 @@ enum nbp_dist {
                             CDF on one uniform.  The table lives in a slot: row 0 = the domain, row 1 = the CUMULATIVE
                             normalised weights, count = its length (<= N); written like a belief on NBP_EUCLID2
                             (nbp_belief_write; clique calls: factor_density[f]).  nbp_proposal_desc.var_slot[NBP_MAXV - 1]
-                            names the slot (factors with a table have at most NBP_MAXV - 1 variables); one table per factor */
+                            names the slot (factors with a table have at most NBP_MAXV - 1 variables); one table per factor.
+                            A slot has N rows: a table with MORE than N entries does not fit -- nbp_clique_* refuse it
+                            (NBP_ERR_RANGE) and the hosts (Python `table_belief(N)`, ext/IIFNbpExt.jl `supported(fct, N)`)
+                            refuse it before writing; nbp_belief_write itself cannot tell a table from a belief and keeps
+                            the first N rows of whatever it is given */
 };
 
 typedef int32_t nbp_status;

@@ -1660,6 +1660,11 @@ static nbp_status clique_check(const nbp_solver_params *sp, const nbp_clique_des
       if (s.nvars >= NBP_MAXV) return hfail(NBP_ERR_RANGE, "clique: a factor with a sampler table takes at most NBP_MAXV - 1 variables");
       if (!q->factor_density || !q->factor_density[f].pts || !q->factor_density[f].bw || q->factor_density[f].n_pts < 1)
         return hfail(NBP_ERR_ARG, "clique: an AliasingScalarSampler measurement needs its table (factor_density[f])");
+      // the table lives in a belief slot (N rows): a longer one would be cut to its first N entries and the tail's mass would
+      // land on entry N - 1 -- refused (the reference takes any length, entities/AliasScalarSampling.jl:13-55: such a clique
+      // goes down the caller's generic path, ext/IIFNbpExt.jl `supported`)
+      if (q->factor_density[f].n_pts > sp->N)
+        return hfail(NBP_ERR_RANGE, "clique: an AliasingScalarSampler table holds at most N entries (it lives in a belief slot)");
     }
     for (int i = 0; i < s.nvars; i++)
       if (s.vars[i] < 0 || s.vars[i] >= q->nvars) return hfail(NBP_ERR_RANGE, "clique: factor variable index");

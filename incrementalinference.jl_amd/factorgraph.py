@@ -82,8 +82,13 @@ class AliasingScalarSampler:
     def mean_sqrtcov(self):
         return np.zeros(1), np.zeros((1, 1))
 
-    def table_belief(self):
-        """the table as the device holds it: a belief on Euclid(2), row 0 the domain, row 1 the cumulative weights"""
+    def table_belief(self, N=None):
+        """the table as the device holds it: a belief on Euclid(2), row 0 the domain, row 1 the cumulative weights.
+        `N`: the particle count of the context that will hold it -- a slot takes at most N rows, and a longer table would be
+        cut to its first N entries (the tail's mass would land on entry N - 1): refused, here and by nbp_clique_*"""
+        if N is not None and self.domain.size > N:
+            raise ValueError(f"AliasingScalarSampler: a table of {self.domain.size} entries does not fit a device slot of N = {N} rows "
+                             "(libnbp holds the table in a belief slot; solve with N >= the table length)")
         cum = np.cumsum(self.weights)
         cum[-1] = 1.0
         return np.stack([self.domain, cum], axis=1), np.ones(2)
@@ -167,8 +172,8 @@ class _Factor:
             raise ValueError("one AliasingScalarSampler per factor")
         return tb[0] if tb else None
 
-    def density_belief(self):
-        return self.table.table_belief()
+    def density_belief(self, N=None):
+        return self.table.table_belief(N)
 
 
 class Prior(_Factor):
@@ -321,8 +326,9 @@ class PartialPriorPassThrough(_Factor):
     def components(self):
         return [(1.0, np.zeros(1), np.zeros((1, 1)))]
 
-    def density_belief(self):
-        """(points n x P in the variable's point layout, bw D): the partial coordinates filled, the others zero"""
+    def density_belief(self, N=None):
+        """(points n x P in the variable's point layout, bw D): the partial coordinates filled, the others zero
+        (`N`, the context's particle count, matters to sampler tables only: a density with more points is cut to N)"""
         D, n = self.varType.dim, self.points.shape[0]
         c, b = np.zeros((n, D)), np.zeros(D)
         for i, k in enumerate(self.partial):

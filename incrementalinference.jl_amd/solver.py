@@ -151,7 +151,7 @@ def _plan_densities(fg, labels, first_slot):
 def write_densities(fg, be, labels=None):
     for f in passthrough_factors(fg, labels):
         fnc = fg.getFactor(f).fnc
-        pts, bw = fnc.density_belief()
+        pts, bw = fnc.density_belief(be.N)
         be.belief_write(fnc.slot, fnc.varType.manifold if isinstance(fnc, PartialPriorPassThrough) else fnc.density_manifold, pts, bw)
 
 

@@ -68,7 +68,7 @@ def test_bad_variable_slot_and_factor_manifold_mismatch(hip_backend):
     be.close()
 
 
-@pytest.mark.parametrize("field,value", [("manifold", 9), ("nfactors", 0), ("nfactors", 129), ("niter", 0), ("niter", 8), ("out_slot", 99),
+@pytest.mark.parametrize("field,value", [("manifold", 9), ("nfactors", 0), ("nfactors", 129), ("niter", 0), ("niter", 9), ("out_slot", 99),
                                           ("labels_out", 5)])
 def test_bad_product_descriptors(hip_backend, field, value):
     N = 64
