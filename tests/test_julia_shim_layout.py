@@ -212,3 +212,48 @@ def test_shim_forwards_iters_and_reports_only_touched_labels():
     assert re.search(r"runclique\(:up,.*iters\)", up), "upGibbsCliqueDensity must forward its `iters` (SolveTree.jl:171,216-227)"
     assert "for l in touched" in up and "directFrtlMsgIDs" in up and "directPriorMsgIDs" in up
     assert "p.beliefs[i].n_pts" in src  # the count written back by libnbp, not N
+
+
+# The reference methods the shim specialises, by the types of their positional arguments (the data of a dispatch check, with
+# the file:line of each definition; an untyped argument is Any).  A shim method with exactly these types would OVERWRITE the
+# reference's method (an error while an extension precompiles on Julia >= 1.10) and its `invoke` fall-back would reach itself.
+REFERENCE_SIGNATURES = {
+    "upGibbsCliqueDensity": ["AbstractDFG", "TreeClique", "Symbol", "Any", "Int", "Bool", "Int", "Any"],   # services/SolveTree.jl:164-173
+    "solveCliqDownFrontalProducts!": ["AbstractDFG", "TreeClique", "SolverParams", "Any"],                 # CliqStateMachineUtils.jl:479-486
+    "addLikelihoodsDifferentialCHILD!": ["AbstractDFG", "Vector{Symbol}", "AbstractDFG"],                  # services/TreeMessageUtils.jl:279-286
+    "approxConvBelief": ["AbstractDFG", "DFGFactor", "Symbol", "AbstractVector"],                                    # services/ApproxConv.jl:4-10
+}
+NARROWER = {("GraphsDFG", "AbstractDFG")}  # LocalDFG = GraphsDFG <: AbstractDFG (DistributedFactorGraphs)
+
+
+def _positional_types(sig):
+    out = []
+    for a in _split_top(sig.split(";")[0]):
+        a = a.split("=")[0].strip()
+        out.append(a.split("::", 1)[1].strip() if "::" in a else "Any")
+    return out
+
+
+def test_shim_overrides_are_more_specific_than_the_reference_methods():
+    src = open(SHIM).read()
+    for name, ref in REFERENCE_SIGNATURES.items():
+        heads = re.findall(r"^function " + re.escape(name) + r"\((.*?)\)\n", src, flags=re.S | re.M)
+        assert heads, name
+        for head in heads:
+            mine = _positional_types(head)
+            assert len(mine) >= len(ref) - 1, (name, mine)
+            narrower = False
+            for m, r in zip(mine, ref):
+                if m == r:
+                    continue
+                assert (m, r) in NARROWER or m.startswith(r + "{"), (name, "argument type neither equal nor narrower", m, r)
+                narrower = True
+            assert narrower, f"{name}: the shim method has the reference's own signature -- it would overwrite it"
+        # the fall-back reaches the reference's method by its own signature
+        for m in re.finditer(r"invoke\(" + re.escape(name) + r",\s*Tuple\{", src):
+            k, depth = m.end(), 1
+            while depth:  # the matching brace of Tuple{
+                depth += {"{": 1, "}": -1}.get(src[k], 0)
+                k += 1
+            types = _split_top(src[m.end():k - 1])
+            assert types == ref[:len(types)] and types[0] == "AbstractDFG", (name, types)
