@@ -12,8 +12,9 @@ Tolerances (relative to max(1, |coordinate|)): points 1e-8 (observed <= 2e-10) -
 there the slope of the search's stopping point in its start is heavy-tailed, so among tens of thousands of searches a few
 end 1e-7 .. 1e-6 apart (and a comparison decided by the last bit leaves two searches ~1e-5 apart, inside the ball the
 search stops in); held there: a ladder of shares (LADDER / LADDER_SHARE below: at most 0.3 % of the particles beyond
-1e-7 ... 0.01 % beyond 1e-4), none beyond 1e-3, and at most one bandwidth
-fit in ten (observed: 0.05 % on SE(2), 1.7 % on the Euclid(3) mixtures at 800 variables, 5.3 % at 10 000) a golden-section step (<= 5 %) away -- a comparison of the fit decided by that 1e-7; products of several densities 1e-11 (observed <= 2e-13 on identical inputs: their labels
+1e-7 ... 0.03 % beyond 1e-5), none beyond 1e-4 (round 5; observed: none beyond 1e-5), and at most 3 % of the bandwidth
+fits (observed: 0.03 % on SE(2) at its full size, 1.1 % / 2.4 % on the Euclid(3) mixtures at 800 / 2500 variables; 5.3 % at 10 000,
+which is why that size stays outside the default suite: profiles/r05_nm_optim_order_e3.txt) a golden-section step (<= 5 %) away -- a comparison of the fit decided by that 1e-7; products of several densities 1e-11 (observed <= 2e-13 on identical inputs: their labels
 are integers and the same on both sides, what is left is the rounding of the final draw); bandwidths 1e-7 / 1e-8 (observed
 <= 3e-9).  The worst of each kind goes into the parity
 record of the run (gpurun_out/r04_whole_solve_parity.txt)."""
@@ -30,7 +31,8 @@ pytestmark = pytest.mark.gpu
 THREE_D = {"config4_se2_lattice", "config5_mixture_chain"}
 # outputs of 3-D searches: the share of particles allowed beyond each level of difference (observed on MI355X, times ~3)
 LADDER = (1e-7, 1e-6, 1e-5, 1e-4)
-LADDER_SHARE = (3e-3, 1e-3, 3e-4, 1e-4)
+LADDER_SHARE = (3e-3, 1e-3, 3e-4, 0.0)  # round 5: NO particle beyond 1e-4 (observed: none beyond 1e-5 in 26 M particles of the default suite)
+FIT_STEP_SHARE = 0.03  # fits that may end a golden-section step apart (observed <= 2.4 %: 611 of 25 868 at 2500 mixture variables; 0.03 % on SE(2))
 # BASELINE's config 2 at its own size as well (1000 variables, the graph the metric is quoted on: ~12 000 ops, every launch
 # geometry of the chip-filling levels), the oracle on eight host threads
 FULL = {"config2_full_size_1000_variables": lambda: iif.generateChainEuclid(1000, vardims=2, priorEvery=100, N=200),
@@ -41,12 +43,15 @@ FULL = {"config2_full_size_1000_variables": lambda: iif.generateChainEuclid(1000
         "config5_800_variables": lambda: iif.generateMixtureChain(nvars=800, N=300, priorEvery=400)}
 
 
-# NBP_STAGEWISE_FULL=1: configs 3, 4 and 5 at BASELINE's own sizes as well (minutes of oracle time on 64 host threads each: run for
-# the record, profiles/r04_stagewise_parity_full_size.txt, not in the default suite)
+# Round 5: configs 3 and 4 at BASELINE's OWN sizes and config 5 at a quarter of its 10 000 variables are part of the default
+# suite (20 + 100 + 55 s with the oracle on 64 host threads) -- every configuration is oracle-compared at size on the
+# driver's box, not only exercised there.  NBP_STAGEWISE_FULL=1 adds config 5 at all its 10 000 variables (3.5 minutes:
+# run for the record, profiles/r05_stagewise_parity_full_size.txt).
+FULL.update({"config3_full_size_2000_poses": lambda: iif.generateCircularDoors(nposes=2000, N=200, sightEvery=25),
+             "config4_full_size_50x100_lattice": lambda: iif.generateSE2Lattice(rows=50, cols=100, N=200, closeEvery=5),
+             "config5_full_size_quarter_2500_variables": lambda: iif.generateMixtureChain(nvars=2500, N=300, priorEvery=500)})
 if os.environ.get("NBP_STAGEWISE_FULL"):
-    FULL.update({"config3_full_size_2000_poses": lambda: iif.generateCircularDoors(nposes=2000, N=200, sightEvery=25),
-                 "config4_full_size_50x100_lattice": lambda: iif.generateSE2Lattice(rows=50, cols=100, N=200, closeEvery=5),
-                 "config5_full_size_10000_variables": lambda: iif.generateMixtureChain(nvars=10000, N=300, priorEvery=500)})
+    FULL.update({"config5_full_size_10000_variables": lambda: iif.generateMixtureChain(nvars=10000, N=300, priorEvery=500)})
 
 
 @pytest.mark.parametrize("name", list(CONFIGS) + list(FULL))
@@ -58,9 +63,10 @@ def test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hi
     tree = iif.buildTreeReset(fg, order)
     tp = iif.TreeProgram(fg, tree, seed=31)
     N = fg.solverParams.N
-    if "full_size" in name and os.environ.get("NBP_STAGEWISE_FULL"):
+    if "full_size" in name and not name.startswith("config2"):
         from oracle.oracle_backend import OracleBackend
-        oracle_backend = lambda n, sl, side_ints=0: OracleBackend(n, sl, side_ints, threads=64)  # noqa: E731
+        nthreads = max(8, min(64, os.cpu_count() or 8))
+        oracle_backend = lambda n, sl, side_ints=0: OracleBackend(n, sl, side_ints, threads=nthreads)  # noqa: E731
     bes = [oracle_backend(N, tp.n_slots), hip_backend(N, tp.n_slots)]
     progs = []
     try:
@@ -74,6 +80,9 @@ def test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hi
         worst = {"proposals": 0.0, "products": 0.0, "bandwidth": 0.0}
         n_ops = {"proposals": 0, "products": 0}
         three_d = tol_search > 1e-8
+        # (the opt-in 10 000-variable run, for the record: one of 31 M particles at 1.6e-4 and 5.3 % of the fits a step apart in round 4)
+        record_only = "10000" in name
+        hard, fit_share = (1e-3, 0.08) if record_only else (1e-4, FIT_STEP_SHARE)
         n_particles = n_fits = n_fit_steps = 0
         n_beyond = np.zeros(len(LADDER), dtype=np.int64)
         for s, (kind, descs) in enumerate(tp.stages):
@@ -99,7 +108,7 @@ def test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hi
                 else:  # outputs of 3-D searches: a statistical bound over the whole program, a hard one on the ball of the search
                     # (bandwidth: a golden-section comparison of the fit decided by 1e-7 of difference in the points moves the
                     #  bandwidth by a bracket step, 0.1-3 % -- counted, at most one fit in ten)
-                    assert e <= 1e-3 and eb <= 5e-2, f"{name}: stage {s} ({what}) op {i}: points / bandwidth differ by {e:.3e} / {eb:.3e}"
+                    assert e <= hard and eb <= 5e-2, f"{name}: stage {s} ({what}) op {i}: points / bandwidth differ by {e:.3e} / {eb:.3e}"
                     if what == "proposals":
                         n_particles += per_particle.size
                         n_beyond += np.array([(per_particle > t).sum() for t in LADDER])
@@ -112,8 +121,8 @@ def test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hi
                 bes[1].slot_write(d.out_slot, d.manifold, po, bo)  # the device continues from the oracle's state
         if three_d:
             for t, nb, cap in zip(LADDER, n_beyond, LADDER_SHARE):
-                assert nb <= max(1, int(cap * n_particles)), (name, t, int(nb), n_particles)
-            assert n_fit_steps <= max(1, n_fits // 10), (name, n_fit_steps, n_fits)
+                assert nb <= (max(1, int(cap * n_particles)) if (cap > 0 or record_only) else 0), (name, t, int(nb), n_particles)
+            assert n_fit_steps <= max(1, int(fit_share * n_fits)), (name, n_fit_steps, n_fits)
         line = (f"{name}: every stage of the tree program on the oracle's state ({len(tp.stages)} stages, {n_ops['proposals']} proposals, "
                 f"{n_ops['products']} products of several densities): worst proposal {worst['proposals']:.1e}, worst product {worst['products']:.1e}, "
                 f"worst bandwidth {worst['bandwidth']:.1e} (relative)"
