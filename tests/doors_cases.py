@@ -54,3 +54,61 @@ def case_short_chains_keep_the_true_mode(backend):
         out[nposes] = (min(s), float(np.median(s)))
         assert min(s) > 0.8, (nposes, min(s))
     return out
+
+
+def mechanisms(backend, nposes, variants, solves=1, seed=1):
+    """Config 3's graph solved `solves` times in a row under each (nullSurplusAdd, Niter) of `variants`; per variant and solve:
+    the share of particles at the true pose, pose by pose.  What DESIGN.md 5 argues -- the true mode is lost to the reference's
+    nullSurplusAdd = 0.3 (ApproxConv.jl:255-265) and to its under-mixed Niter = 1 product (GraphProductOperations.jl:53-60),
+    not to a defect of the restatement -- as a measurement (review r04, item 3)."""
+    out = {}
+    for nsa, niter in variants:
+        fg = iif.generateCircularDoors(nposes=nposes, N=200, sightEvery=25)
+        fg.solverParams.nullSurplusAdd = nsa
+        fg.solverParams.productNiter = niter
+        order = iif.nestedDissectionOrder(fg)
+        rows = []
+        for k in range(solves):
+            fg.solverParams.graphinit = (k == 0)  # a further solve continues from the posteriors of the last
+            iif.solveTree(fg, eliminationOrder=order, backend=backend, seed=seed + k)
+            rows.append(np.array([share(fg, i) for i in range(nposes)]))
+        out[(nsa, niter)] = rows
+    return out
+
+
+def case_true_mode_survives_without_null_surplus_and_with_a_mixed_product(backend, nposes=400):
+    """BASELINE.md 5's multimodal criterion (>= 0.6 x nominal at the true pose on >= 90 % of the poses) IS met by the restated
+    algorithm once the two reference parameters that lose the mode are taken out: nullSurplusAdd = 0 and Niter = 6 (the
+    sampler's stationary distribution is the exact product, tests/analytic_cases.py).  With the reference's own values
+    (0.3, 1) the same graph, same seed, keeps the true mode on a minority of the poses."""
+    r = mechanisms(backend, nposes, [(0.3, 1), (0.0, 6)])
+    ref, fixed = r[(0.3, 1)][0], r[(0.0, 6)][0]
+    assert (fixed >= 0.6).mean() >= 0.9 and np.median(fixed) >= 0.9, ((fixed >= 0.6).mean(), np.median(fixed), fixed.min())
+    assert (ref >= 0.6).mean() < (fixed >= 0.6).mean() - 0.2, ((ref >= 0.6).mean(), (fixed >= 0.6).mean())
+    return {"reference (0.3, 1)": (float((ref >= 0.6).mean()), float(np.median(ref))),
+            "nullSurplusAdd 0, Niter 6": (float((fixed >= 0.6).mean()), float(np.median(fixed)), float(fixed.min()))}
+
+
+def case_full_size_mechanisms(backend, nposes=2000):
+    """the same at BASELINE's 2000 poses, three solves in a row (device only: seconds there, a quarter of an hour on the oracle).
+    Measured on MI355X (profiles/r05_config3_mechanisms.txt): (0, 6) median 0.99 / min 0.81 after ONE solve; (0, 1) keeps the true
+    mode for the first ~800 poses; (0.3, 6) recovers it with further solves (0.38 -> 0.77 -> 0.83 of the poses above 0.8); the
+    reference's (0.3, 1) rises 0.06 -> 0.13 -> 0.23 and has its first 200 poses at >= 0.6 on 0.66 -> 0.75 -> 0.81."""
+    r = mechanisms(backend, nposes, [(0.3, 1), (0.0, 1), (0.3, 6), (0.0, 6)], solves=3)
+    above = lambda s: float((s > 0.8).mean())
+    # (i) + (ii): both parameters out -> BASELINE 5's criterion holds everywhere after one solve, and stays
+    for s in r[(0.0, 6)]:
+        assert (s >= 0.6).mean() >= 0.9 and np.median(s) >= 0.9, ((s >= 0.6).mean(), np.median(s))
+    # (i) alone: the true mode survives several hundred poses further than with the surplus
+    s01, sref = r[(0.0, 1)][0], r[(0.3, 1)][0]
+    assert np.median(s01[:600]) >= 0.9 and np.median(s01) > np.median(sref) + 0.3, (np.median(s01[:600]), np.median(s01), np.median(sref))
+    # (ii) alone: a mixed product lets further solves repair what the surplus leaks
+    a = [above(s) for s in r[(0.3, 6)]]
+    assert a[0] < a[1] < a[2] and a[2] >= 0.7, a
+    # (iii) the reference's own parameters: the share of poses above 0.8 rises with every solve; the stretch the x0 prior reaches
+    b = [above(s) for s in r[(0.3, 1)]]
+    assert b[0] < b[1] < b[2] and b[2] >= 0.15, b
+    first = [float((s[:200] >= 0.6).mean()) for s in r[(0.3, 1)]]
+    assert first[2] >= 0.7 and np.median(r[(0.3, 1)][2][:200]) >= 0.9, first
+    return {f"nullSurplusAdd {k[0]}, Niter {k[1]}": [(round(float(np.median(s)), 3), round(float(s.min()), 3), round(above(s), 3), round(float((s[:200] >= 0.6).mean()), 3))
+                                                    for s in v] for k, v in r.items()}
