@@ -505,3 +505,126 @@ def case_partial_relative_over_two_coordinates(backend, N=128):
             assert np.array_equal(got[:, free], x0[:, free])
             assert list(ipc) == [float((mask >> k) & 1) for k in range(3)]  # ones on `.partial`, EvalFactor.jl:383-391
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# a13, pinned by ENUMERATION: the labels a product draws, against the exact weights of every label tuple
+# ----------------------------------------------------------------------------------------------------------
+def exact_label_weights(dens, bws):
+    """The exact product of F kernel density estimates with diagonal Gaussian kernels is a mixture with one component per
+    label tuple (i_1 .. i_F); its weight is the integral of prod_j N(x; a_j[i_j], h_j^2) -- per coordinate
+    exp(-0.5 (sum_j r_j m_j^2 - (sum_j r_j m_j)^2 / sum_j r_j)), r_j = 1 / h_j^2, times a constant the tuples share.
+    Returns the normalised weights as an array of shape (N,) * F."""
+    F, (N, D) = len(dens), dens[0].shape
+    logw = np.zeros((N,) * F)
+    for k in range(D):
+        r = np.array([1.0 / h[k] ** 2 for h in bws])
+        s2, s1 = np.zeros((N,) * F), np.zeros((N,) * F)
+        for j in range(F):
+            shape = [1] * F
+            shape[j] = N
+            m = dens[j][:, k].reshape(shape)
+            s2 = s2 + r[j] * m * m
+            s1 = s1 + r[j] * m
+        logw += -0.5 * (s2 - s1 * s1 / r.sum())
+    w = np.exp(logw - logw.max())
+    return w / w.sum()
+
+
+def case_product_labels_match_enumeration(backend, N=8, nprod=4000):
+    """Small mixtures, every label tuple enumerated.  The samples of a product are independent draws (one chain and one
+    random stream per sample), so the counts of the label tuples over nprod x N samples are multinomial and Pearson's
+    statistic is chi-square distributed IF the sampler draws from the exact product: the bound is the 1 - 1e-6 quantile of
+    that distribution -- a tolerance that comes from Monte-Carlo error alone, not from what was observed.  Held for the
+    converged sampler (Niter = 8 sweeps per level, the ABI's maximum); the reference's Niter = 1 is REPORTED beside it:
+    its excess over the same bound is the under-mixing the reference accepts (GraphProductOperations.jl:53-60), measured
+    rather than folded into a tolerance.  Also per sample moments: mean and variance of the output against the exact
+    mixture's, within 5 standard errors."""
+    from scipy.stats import chi2
+    rng = np.random.default_rng(77)
+    report = []
+    for man, F, shape in ((abi.EUCLID1, 2, "overlapping"), (abi.EUCLID1, 3, "overlapping"), (abi.EUCLID2, 2, "overlapping"), (abi.EUCLID1, 2, "doors")):
+        D = abi.MANIFOLD_DIM[man]
+        if shape == "overlapping":
+            dens = [rng.normal(0.3 * j, 1.0, size=(N, D)) for j in range(F)]
+            bws = [np.full(D, 0.6 + 0.1 * j) for j in range(F)]
+        else:
+            # the scenario of config 3's sightings, in small (N = 16): an odometry-propagated belief with an eighth of its
+            # particles one door spacing off, times a sighting with four equally likely doors -- the case in which rounds 1-3's
+            # label hand-down tripled the minority mode (profiles/r04_sampler_variants.txt)
+            N = 16
+            dens = [np.concatenate([rng.normal(0.0, 0.1, 14), rng.normal(1.6, 0.1, 2)])[:, None],
+                    np.concatenate([rng.normal(c, 0.1, 4) for c in (-1.6, 0.0, 1.6, 3.2)])[:, None]]
+            dens = [d[rng.permutation(N)] for d in dens]
+            bws = [np.full(1, 0.15), np.full(1, 0.12)]
+        w = exact_label_weights(dens, bws)
+        # exact moments of the mixture (per coordinate): component mean = precision-weighted mean of the selected kernels
+        rr = np.array([[1.0 / h[k] ** 2 for h in bws] for k in range(D)])  # D x F
+        for niter in (8, 1):
+            be = backend(N, F + nprod, N * F * nprod)
+            try:
+                for j in range(F):
+                    be.slot_write(j, man, to_points(man, dens[j]), bws[j])
+                descs = [iif.solver.product_desc(man, list(range(F)), F + i, 5000 + i, niter, i * N * F) for i in range(nprod)]
+                be.run_products(descs)
+                lab = np.concatenate([be.side_read(i * N * F, N * F).reshape(N, F) for i in range(nprod)])
+                pts = np.concatenate([to_coords(man, be.slot_read(F + i, man)[0]) for i in range(0, nprod, 8)])
+            finally:
+                be.close()
+            n = lab.shape[0]
+            counts = np.zeros((N,) * F)
+            np.add.at(counts, tuple(lab[:, j] for j in range(F)), 1)
+            e = (w * n).ravel()
+            c = counts.ravel()
+            big = e >= 5.0
+            ee, cc = np.append(e[big], e[~big].sum()), np.append(c[big], c[~big].sum())
+            if ee[-1] < 5.0:  # the pooled small cells join the smallest big one
+                ee[-2] += ee[-1]; cc[-2] += cc[-1]; ee, cc = ee[:-1], cc[:-1]
+            stat, dof = float(((cc - ee) ** 2 / ee).sum()), len(ee) - 1
+            bound = float(chi2.ppf(1 - 1e-6, dof))
+            # moments
+            zs = []
+            for k in range(D):
+                s1 = sum(rr[k, j] * dens[j][:, k].reshape([N if q == j else 1 for q in range(F)]) for j in range(F))
+                mean_c = s1 / rr[k].sum()
+                mu = float((w * mean_c).sum())
+                var = float((w * ((mean_c - mu) ** 2 + 1.0 / rr[k].sum())).sum())
+                x = pts[:, k]
+                se_m = np.sqrt(var / len(x))
+                m4 = float((w * (3 * (1.0 / rr[k].sum()) ** 2 + 6 * (1.0 / rr[k].sum()) * (mean_c - mu) ** 2 + (mean_c - mu) ** 4)).sum())
+                se_v = np.sqrt(max(m4 - var * var, 1e-300) / len(x))
+                zs.append((float((x.mean() - mu) / se_m), float((((x - mu) ** 2).mean() - var) / se_v)))
+            extra = ()
+            if shape == "doors":  # mass of the minority mode (the off-by-one-door particles): exact against drawn
+                minority = dens[0][:, 0] > 0.8
+                extra = (round(float(w[minority, :].sum()), 4), round(float(minority[lab[:, 0]].mean()), 4))
+            report.append((man, F, shape, niter, n, dof, round(stat, 1), round(bound, 1), [(round(a, 2), round(b, 2)) for a, b in zs]) + extra)
+            if niter == 8 and shape == "overlapping":
+                assert stat < bound, (man, F, "label tuples of the converged sampler against the enumerated product", stat, bound, dof)
+                for zm, zv in zs:
+                    assert abs(zm) < 5 and abs(zv) < 5, (man, F, zs)
+            if shape == "doors":
+                # Separated modes: the sweeps cannot carry a sample from one mode to another (both labels would have to change
+                # at once), so the MASS of a mode is whatever the coarse levels -- moment-matched Gaussians -- gave it: the
+                # published algorithm's approximation, not Monte-Carlo error (exact 0.139; 0.064 with eight sweeps per level,
+                # 0.096 with the reference's one: more sweeps equilibrate to the COARSE level's distribution).  Held: within
+                # 0.1 of exact and not amplified (rounds 1-3's hand-down: 0.33).  WITHIN the majority mode the sampler is
+                # exact again: the label tuples there against the enumerated conditional weights, chi-square as above.
+                exact_min, got_min = extra
+                assert abs(got_min - exact_min) < 0.1 and got_min < exact_min + 4 * np.sqrt(exact_min / n), (niter, exact_min, got_min)
+                inmode = (~minority)[:, None] & (np.abs(dens[1][:, 0]) < 0.8)[None, :]
+                sel = inmode[lab[:, 0], lab[:, 1]]
+                wc = np.where(inmode, w, 0.0)
+                wc /= wc.sum()
+                cnt = np.zeros_like(w)
+                np.add.at(cnt, (lab[sel, 0], lab[sel, 1]), 1)
+                e2, c2 = (wc * sel.sum())[inmode], cnt[inmode]
+                big2 = e2 >= 5.0
+                e3, c3 = np.append(e2[big2], e2[~big2].sum()), np.append(c2[big2], c2[~big2].sum())
+                if e3[-1] < 5.0:
+                    e3, c3 = e3[:-1], c3[:-1]
+                stat2, dof2 = float(((c3 - e3) ** 2 / e3).sum()), len(e3) - 1
+                report[-1] = report[-1] + (("within the majority mode", int(sel.sum()), dof2, round(stat2, 1), round(float(chi2.ppf(1 - 1e-6, dof2)), 1)),)
+                if niter == 8:
+                    assert stat2 < chi2.ppf(1 - 1e-6, dof2), ("label tuples within the majority mode", stat2, dof2)
+    return report

@@ -34,3 +34,7 @@ def test_euclid_distance_ring(oracle_backend):
 
 def test_partial_relative_over_two_coordinates(oracle_backend):
     ac.case_partial_relative_over_two_coordinates(oracle_backend)
+
+
+def test_product_labels_match_enumeration(oracle_backend):
+    print(ac.case_product_labels_match_enumeration(oracle_backend))

@@ -37,3 +37,7 @@ def test_euclid_distance_ring(hip_backend):
 
 def test_partial_relative_over_two_coordinates(hip_backend):
     ac.case_partial_relative_over_two_coordinates(hip_backend)
+
+
+def test_product_labels_match_enumeration(hip_backend):
+    print(ac.case_product_labels_match_enumeration(hip_backend))
