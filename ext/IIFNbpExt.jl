@@ -138,7 +138,7 @@ struct NbpTreeBelief
   bw::Ptr{Float64}
   ipc::Ptr{Float64}
   n_pts::Int32
-  reserved_::Int32
+  handle::Int32       # 0: host buffers; h > 0: resident slot h of the context (nbp_ctx_reserve_resident)
 end
 
 # nbp_clique_desc (include/nbp_host.h)

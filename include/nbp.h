@@ -203,6 +203,12 @@ void *nbp_arena_ptr(nbp_ctx *ctx);
 void *nbp_stream_ptr(nbp_ctx *ctx); /* hipStream_t the library launches on */
 int32_t nbp_ctx_particles(const nbp_ctx *ctx); /* N the context was created for (0: null) */
 int32_t nbp_ctx_slots(const nbp_ctx *ctx);     /* belief slots of its arena (0: null) */
+/* Resident slots: the LAST n slots of the arena are set aside for beliefs that STAY on the device between clique calls --
+ * the deep-copied sub graph of a clique between its up and its down solve, the up message a parent reads from its child
+ * (a LikelihoodMessage that never visits the host: nbp_tree_belief.handle, nbp_host.h).  Handle h (1 .. n) names slot
+ * nbp_ctx_slots - h; the clique calls plan their own slots below the resident ones. */
+nbp_status nbp_ctx_reserve_resident(nbp_ctx *ctx, int32_t n);
+int32_t nbp_ctx_resident(const nbp_ctx *ctx);
 
 /* ---- belief I/O: setValKDE!/getVal at the boundary (FactorGraph.jl:250-297) --------------- */
 nbp_status nbp_slot_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP,
@@ -236,6 +242,17 @@ nbp_status nbp_belief_write_batch(nbp_ctx *ctx, int32_t n, const int32_t *slots,
                                   const int32_t *n_pts, const double *const *bw, const double *const *ipc);
 nbp_status nbp_belief_read_batch(nbp_ctx *ctx, int32_t n, const int32_t *slots, const int32_t *manifolds, double *const *pts,
                                  int32_t *n_pts, double *const *bw, double *const *ipc);
+/* The same transfers without a host synchronisation (the asynchronous clique seam, nbp_clique_submit_batch): staged in
+ * pinned buffers of a pool of the context, queued on the library stream behind whatever runs there.  _write_batch_async
+ * returns once the copies are queued (the caller's buffers are free again: they were packed).  _read_batch_begin queues the
+ * copies out and returns a token; _read_batch_end waits for them (an event, not the whole stream), unpacks into the caller's
+ * buffers (entries with pts[i] == NULL are skipped) and consumes the token. */
+typedef struct nbp_read_token nbp_read_token;
+nbp_status nbp_belief_write_batch_async(nbp_ctx *ctx, int32_t n, const int32_t *slots, const int32_t *manifolds, const double *const *pts,
+                                        const int32_t *n_pts, const double *const *bw, const double *const *ipc);
+nbp_status nbp_belief_read_batch_begin(nbp_ctx *ctx, int32_t n, const int32_t *slots, nbp_read_token **out);
+nbp_status nbp_belief_read_batch_end(nbp_read_token *token, const int32_t *manifolds, double *const *pts, int32_t *n_pts,
+                                     double *const *bw, double *const *ipc);
 /* sample(oldBel, N - Npts) in place: beliefs with fewer than N points are topped up to N with draws from their own KDE
  * (random kernel + bw * randn); the points they hold stay.  Multinomial resampling of a belief to the solver's N. */
 nbp_status nbp_run_resample(nbp_ctx *ctx, const int32_t *slots, const int32_t *manifolds, int32_t n, uint64_t seed);
@@ -276,6 +293,8 @@ nbp_status nbp_manifold_product(nbp_ctx *ctx, int32_t manifold, int32_t nfactors
  * NULL / -1) the sampled one.  Relative factors without multihypo only (reference #467/#927). */
 nbp_status nbp_run_deconv(nbp_ctx *ctx, const nbp_proposal_desc *descs, const int32_t *meas_slots, int32_t n);
 nbp_status nbp_run_copies(nbp_ctx *ctx, const nbp_copy_desc *descs, int32_t n);
+/* the same queued on the library stream without waiting (points_only != 0: the points and the count, not the bandwidth) */
+nbp_status nbp_run_copies_async(nbp_ctx *ctx, const nbp_copy_desc *descs, int32_t n, int32_t points_only);
 
 /* ---- clique seam: a whole up/down schedule resident on the device --------------------------
  * Replaces upGibbsCliqueDensity (SolveTree.jl:164-239) and solveCliqDownFrontalProducts!
@@ -316,7 +335,10 @@ nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *de
  * unset = never: the fused form trades time for traffic) and its factors are of a class the kernel is built
  * for; same particles and bandwidths as the three-launch form up to the rounding of sums taken in another order.
  * nbp_program_run refuses a stage range that ends between the two stages of a fused pair. */
-enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2, NBP_OPT_FUSED_UPDATES = 3 };
+enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2, NBP_OPT_FUSED_UPDATES = 3,
+                          NBP_OPT_ASYNC_UPLOAD = 4 /* (default 0) nbp_program_finalize sends the descriptors stream-ordered from a
+                                                      pinned buffer and does not wait: for short-lived programs queued behind
+                                                      running ones (the asynchronous clique seam, nbp_host.h) */ };
 nbp_status nbp_program_set_option(nbp_program *prog, int32_t option, int32_t value);
 nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
 nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);
@@ -328,6 +350,8 @@ nbp_status nbp_program_num_fused(nbp_program *prog, int32_t *out);
  * smallest product batch that is split; same particles and bandwidths as the single-stream order, bit for bit) */
 nbp_status nbp_program_num_two_stream(nbp_program *prog, int32_t *out);
 nbp_status nbp_program_destroy(nbp_program *prog);
+/* destroy without waiting: the program is dropped once everything queued on the library stream so far has run */
+nbp_status nbp_program_retire(nbp_program *prog);
 
 /* ---- separator exchange between ranks (one process per GPU) -------------------------------------------------------
  * The reference moves a LikelihoodMessage through a Channel per tree edge (JunctionTreeUtils.jl:943-956,

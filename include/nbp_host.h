@@ -184,7 +184,11 @@ typedef struct nbp_tree_belief {
   double *bw;       /* D                                                                          */
   double *ipc;      /* D: infoPerCoord (in: may be NULL = zeros; out: written when not NULL)      */
   int32_t n_pts;    /* in: particles held (<= N; fewer than N needs bw); out: particles written             */
-  int32_t reserved_;
+  int32_t handle;   /* 0: the belief lives in the host buffers above.  h > 0: it lives in resident slot h of the context
+                       (nbp_ctx_reserve_resident) -- read from there where a call takes it (pts / bw / ipc are then not
+                       read and may be NULL), and kept there where a call delivers it; a delivered belief is ALSO copied
+                       to the host buffers when pts is not NULL.  What the reference moves through the Channels of a tree
+                       edge as values (CliqueStateMachine.jl:590-593, 900-903) moves as a handle.            */
 } nbp_tree_belief;
 
 /* CliqStatus (entities/BeliefTypes.jl:8), the status a LikelihoodMessage carries */
@@ -273,6 +277,25 @@ typedef struct nbp_clique_request {
   int32_t status;            /* out: NBP_CLIQ_UPSOLVED / NBP_CLIQ_DOWNSOLVED */
 } nbp_clique_request;
 nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *requests, int32_t n);
+
+/* The same call in two halves, so that a host overlaps ITS work with the device's (review r04: "give the clique seam
+ * overlap").  nbp_clique_submit_batch plans the cliques, queues the beliefs (host ones: one packed copy; resident ones:
+ * device copies), the program and the copies out on the library stream and RETURNS WITHOUT WAITING; the requests, their
+ * descriptors and the host buffers beliefs are delivered INTO must stay alive until nbp_clique_wait(ticket), which waits
+ * for this batch only (an event behind its last copy), unpacks the delivered beliefs and writes the statuses.  Batches
+ * run in submission order.  With resident beliefs (nbp_tree_belief.handle) a parent's batch can be submitted before its
+ * children's has run -- the messages are slots the stream orders, not host values -- so a host can queue a whole pass and
+ * wait once: the next level's planning and sub-graph assembly run under the current level's kernels, and no belief
+ * crosses PCIe between levels.  nbp_clique_solve_batch = submit + wait.  The counterpart of the reference's clique tasks
+ * blocking on the Channels of their tree edges (CliqStateMachineUtils.jl:375-385, CliqueStateMachine.jl:590-593). */
+typedef struct nbp_clique_ticket nbp_clique_ticket;
+nbp_status nbp_clique_submit_batch(nbp_ctx *ctx, nbp_clique_request *requests, int32_t n, nbp_clique_ticket **ticket_out);
+nbp_status nbp_clique_wait(nbp_clique_ticket *ticket); /* consumes the ticket, whatever the status */
+/* resident beliefs from the host side: written (one packed copy, queued), read back (waits), copied among themselves on
+ * the device (queued; points_only: the down message -- the parent's VALUES of a separator, TreeMessageUtils.jl:66-84) */
+nbp_status nbp_resident_write(nbp_ctx *ctx, int32_t n, const int32_t *handles, const int32_t *manifolds, const nbp_tree_belief *beliefs);
+nbp_status nbp_resident_read(nbp_ctx *ctx, int32_t n, const int32_t *handles, const int32_t *manifolds, nbp_tree_belief *beliefs);
+nbp_status nbp_resident_copy(nbp_ctx *ctx, int32_t n, const int32_t *src_handles, const int32_t *dst_handles, int32_t points_only);
 
 /* diagnostics: host wall clock the clique calls of this process have spent, by phase (seconds): [0] planning the schedule,
  * [1] beliefs host -> device, [2] program assembly + finalize, [3] launches (mode 2: + waiting for them), [4] (waiting +)

@@ -95,6 +95,14 @@ struct nbp_ctx {
   // device blobs of destroyed programs, kept for the next short-lived one (a clique call compiles, runs and drops a
   // program: hipMalloc / hipFree per call would synchronise the whole device each time)
   std::vector<std::pair<char *, size_t>> blob_cache;
+  // ---- the asynchronous clique seam (nbp_clique_submit_batch / nbp_clique_wait, nbp_host.h) ----
+  // pinned staging buffers of transfers that are queued WITHOUT waiting for the stream: a buffer is free again once the
+  // event recorded behind its copy has completed (never waited for: a busy pool grows by a buffer)
+  struct pin_buf { char *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false, held = false; };
+  std::vector<pin_buf *> pin_pool;
+  // programs handed to nbp_program_retire: destroyed once the event recorded behind their last launch has completed
+  std::vector<std::pair<nbp_program *, hipEvent_t>> retired;
+  int resident = 0;  // the LAST `resident` slots of the arena are resident slots (nbp_ctx_reserve_resident): handle h = slot n_slots - h
   // fused variable updates (nbp_fused.h) for the stages that fill the chip: NBP_NO_FUSED_UPDATE=1 turns them off,
   // NBP_FUSED_MIN = smallest stage (updates) that runs fused
   // Off unless NBP_FUSED_MIN is set: measured on config 2 and on the 10 000-variable chain the fused form moves a ninth of
@@ -281,6 +289,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
 
 static void program_detach(nbp_program *p);
 static void ctx_detach_comms(nbp_ctx *c);
+static void reap_retired(nbp_ctx *c);
 
 nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (!c) return NBP_OK;
@@ -300,6 +309,14 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (c->pin) hipHostFree(c->pin);
   for (auto &b : c->blob_cache) hipFree(b.first);
   c->blob_cache.clear();
+  for (auto &r : c->retired) hipEventDestroy(r.second);  // (the programs themselves were detached with the live ones above)
+  c->retired.clear();
+  for (nbp_ctx::pin_buf *b : c->pin_pool) {
+    if (b->p) hipHostFree(b->p);
+    if (b->ev) hipEventDestroy(b->ev);
+    delete b;
+  }
+  c->pin_pool.clear();
   if (c->ws) hipFree(c->ws);
   if (c->gstats) hipFree(c->gstats);
   if (c->spec) hipFree(c->spec);
@@ -313,12 +330,52 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
 nbp_status nbp_synchronize(nbp_ctx *c) {
   if (!c) return fail(NBP_ERR_ARG, "ctx is null");
   HIPCHK(hipStreamSynchronize(c->stream));
+  reap_retired(c);
   return NBP_OK;
 }
 void *nbp_arena_ptr(nbp_ctx *c) { return c ? c->arena : nullptr; }
 void *nbp_stream_ptr(nbp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int32_t nbp_ctx_particles(const nbp_ctx *c) { return c ? c->N : 0; }
 int32_t nbp_ctx_slots(const nbp_ctx *c) { return c ? c->n_slots : 0; }
+int32_t nbp_ctx_resident(const nbp_ctx *c) { return c ? c->resident : 0; }
+nbp_status nbp_ctx_reserve_resident(nbp_ctx *c, int32_t n) {
+  if (!c) return fail(NBP_ERR_ARG, "ctx is null");
+  if (n < 0 || n > c->n_slots) return fail(NBP_ERR_RANGE, "resident slots: more than the context holds");
+  c->resident = n;
+  return NBP_OK;
+}
+
+// a pinned buffer nobody holds and no queued copy still reads (or a new one)
+static nbp_ctx::pin_buf *pin_acquire(nbp_ctx *c, size_t bytes) {
+  nbp_ctx::pin_buf *best = nullptr;
+  for (nbp_ctx::pin_buf *b : c->pin_pool) {
+    if (b->held) continue;
+    if (b->pending) {
+      if (hipEventQuery(b->ev) != hipSuccess) continue;
+      b->pending = false;
+    }
+    if (b->bytes >= bytes && (!best || b->bytes < best->bytes)) best = b;
+  }
+  if (!best) {
+    best = new nbp_ctx::pin_buf();
+    const size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
+    if (hipHostMalloc((void **)&best->p, cap, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&best->ev, hipEventDisableTiming) != hipSuccess) {
+      if (best->p) hipHostFree(best->p);
+      delete best;
+      return nullptr;
+    }
+    best->bytes = cap;
+    c->pin_pool.push_back(best);
+  }
+  best->held = true;
+  return best;
+}
+// free once everything queued on the library stream so far has run (the copies out of / into the buffer among it)
+static void pin_release_behind_stream(nbp_ctx *c, nbp_ctx::pin_buf *b) {
+  b->pending = hipEventRecord(b->ev, c->stream) == hipSuccess;
+  b->held = false;
+}
 
 // ---- belief I/O --------------------------------------------------------------------------------
 nbp_status nbp_slot_write(nbp_ctx *c, int32_t slot, int32_t manifold, const double *pts, const double *bw) {
@@ -481,6 +538,102 @@ nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, co
     unpack_belief(c, manifolds[i], c->pin + (size_t)i * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
   });
   return NBP_OK;
+}
+
+// The same transfers WITHOUT a host synchronisation (the asynchronous clique seam): staged in a buffer of the context's pool.
+nbp_status nbp_belief_write_batch_async(nbp_ctx *c, int32_t n, const int32_t *slots, const int32_t *manifolds, const double *const *pts,
+                                        const int32_t *n_pts, const double *const *bw, const double *const *ipc) {
+  if (!c || (n > 0 && (!slots || !manifolds || !pts))) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; i++) {
+    nbp_status rc = belief_args(c, slots[i], manifolds[i], pts[i]);
+    if (rc) return rc;
+    const int np = n_pts ? n_pts[i] : c->N;
+    if (np < 1) return fail(NBP_ERR_RANGE, "belief: n_pts < 1");
+    if (np < c->N && !(bw && bw[i])) return fail(NBP_ERR_ARG, "belief: a belief with fewer than N points needs its bandwidth (it is a density, not a point set)");
+  }
+  nbp_ctx::pin_buf *b = pin_acquire(c, (size_t)n * (size_t)c->S * 8);
+  if (!b) return fail(NBP_ERR_HIP, "pinned staging buffer");
+  double *pin = (double *)b->p;
+  host_parallel_for(n, 128, [&](int i) {
+    pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, pin + (size_t)i * c->S);
+  });
+  for (int i = 0; i < n;) {
+    int j = i + 1;
+    while (j < n && slots[j] == slots[j - 1] + 1) j++;
+    if (hipMemcpyAsync(c->arena + c->S * slots[i], pin + (size_t)i * c->S, (size_t)(j - i) * c->S * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      pin_release_behind_stream(c, b);
+      return fail(NBP_ERR_HIP, "hipMemcpyAsync (beliefs in)");
+    }
+    i = j;
+  }
+  pin_release_behind_stream(c, b);
+  return NBP_OK;
+}
+struct nbp_read_token {
+  nbp_ctx *ctx;
+  nbp_ctx::pin_buf *buf;
+  hipEvent_t done;
+  std::vector<int32_t> slots;
+};
+nbp_status nbp_belief_read_batch_begin(nbp_ctx *c, int32_t n, const int32_t *slots, nbp_read_token **out) {
+  if (!c || !out || (n > 0 && !slots)) return fail(NBP_ERR_ARG, "null argument");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; i++)
+    if (slots[i] < 0 || slots[i] >= c->n_slots) return fail(NBP_ERR_RANGE, "slot out of range");
+  nbp_read_token *t = new nbp_read_token();
+  t->ctx = c;
+  t->buf = nullptr;
+  t->done = nullptr;
+  t->slots.assign(slots, slots + (n > 0 ? n : 0));
+  if (hipEventCreateWithFlags(&t->done, hipEventDisableTiming) != hipSuccess) { delete t; return fail(NBP_ERR_HIP, "hipEventCreate"); }
+  if (n > 0) {
+    t->buf = pin_acquire(c, (size_t)n * (size_t)c->S * 8);
+    if (!t->buf) { hipEventDestroy(t->done); delete t; return fail(NBP_ERR_HIP, "pinned staging buffer"); }
+    double *pin = (double *)t->buf->p;
+    for (int i = 0; i < n;) {
+      int j = i + 1;
+      while (j < n && slots[j] == slots[j - 1] + 1) j++;
+      if (hipMemcpyAsync(pin + (size_t)i * c->S, c->arena + c->S * slots[i], (size_t)(j - i) * c->S * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+        pin_release_behind_stream(c, t->buf);
+        hipEventDestroy(t->done);
+        delete t;
+        return fail(NBP_ERR_HIP, "hipMemcpyAsync (beliefs out)");
+      }
+      i = j;
+    }
+  }
+  if (hipEventRecord(t->done, c->stream) != hipSuccess) {
+    if (t->buf) pin_release_behind_stream(c, t->buf);
+    hipEventDestroy(t->done);
+    delete t;
+    return fail(NBP_ERR_HIP, "hipEventRecord");
+  }
+  *out = t;
+  return NBP_OK;
+}
+// waits for the copies of `begin` (and everything queued before them), unpacks; the token is gone afterwards, whatever the status
+nbp_status nbp_belief_read_batch_end(nbp_read_token *t, const int32_t *manifolds, double *const *pts, int32_t *n_pts, double *const *bw,
+                                     double *const *ipc) {
+  if (!t) return fail(NBP_ERR_ARG, "null argument");
+  nbp_ctx *c = t->ctx;
+  const int n = (int)t->slots.size();
+  const hipError_t e = hipEventSynchronize(t->done);
+  nbp_status rc = NBP_OK;
+  if (e != hipSuccess) rc = fail(NBP_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+  else if (n > 0 && (!manifolds || !pts)) rc = fail(NBP_ERR_ARG, "null argument");
+  else if (n > 0) {
+    const double *pin = (const double *)t->buf->p;
+    host_parallel_for(n, 128, [&](int i) {
+      if (pts[i]) unpack_belief(c, manifolds[i], pin + (size_t)i * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
+    });
+  }
+  if (t->buf) { t->buf->held = false; t->buf->pending = false; }
+  hipEventDestroy(t->done);
+  delete t;
+  return rc;
 }
 
 nbp_status nbp_side_write(nbp_ctx *c, int32_t offset, const int32_t *src, int32_t n) {
@@ -1213,6 +1366,23 @@ nbp_status nbp_run_copies(nbp_ctx *c, const nbp_copy_desc *descs, int32_t n) {
   return NBP_OK;
 }
 
+// slot copies queued on the library stream, nothing waited for (resident beliefs of the asynchronous clique seam:
+// nbp_resident_copy).  The descriptors are read by the kernel from a pinned buffer of the context's pool (device-visible
+// host memory: a few bytes per workgroup), freed behind the launch.  points_only: NBP_STAGE_COPY_POINTS semantics.
+nbp_status nbp_run_copies_async(nbp_ctx *c, const nbp_copy_desc *descs, int32_t n, int32_t points_only) {
+  if (!c || (!descs && n > 0)) return fail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  nbp_status rc = check_copies(c, descs, n);
+  if (rc) return rc;
+  nbp_ctx::pin_buf *b = pin_acquire(c, sizeof(nbp_copy_desc) * (size_t)n);
+  if (!b) return fail(NBP_ERR_HIP, "pinned staging buffer");
+  memcpy(b->p, descs, sizeof(nbp_copy_desc) * (size_t)n);
+  rc = points_only ? launch_copy_points(c, (const nbp_copy_desc *)b->p, n) : launch_copies(c, (const nbp_copy_desc *)b->p, n);
+  pin_release_behind_stream(c, b);
+  return rc;
+}
+
 nbp_status nbp_run_bandwidth(nbp_ctx *c, const int32_t *slots, const int32_t *manifolds, int32_t n) {
   if (!c || ((!slots || !manifolds) && n > 0)) return fail(NBP_ERR_ARG, "null argument");
   if (n <= 0) return NBP_OK;
@@ -1288,6 +1458,7 @@ struct nbp_program {
   bool lazy_bw = false;  // NBP_OPT_LAZY_BANDWIDTH
   bool use_graph = true; // NBP_OPT_GRAPH_REPLAY
   bool use_fused = true; // NBP_OPT_FUSED_UPDATES
+  bool async_upload = false;  // NBP_OPT_ASYNC_UPLOAD: the descriptor blob travels stream-ordered from a pinned buffer, nothing waits
   int n_user_stages = 0;
   // captured launch sequences of nbp_program_run(first, last): key = first * 2^32 + last
   struct captured { hipGraphExec_t exec; uint64_t ws_gen; };  // ws_gen: the context's workspace generation at capture time
@@ -1357,6 +1528,7 @@ nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value)
   if (option == NBP_OPT_LAZY_BANDWIDTH) { p->lazy_bw = value != 0 && getenv("NBP_NO_LAZY_BANDWIDTH") == nullptr; return NBP_OK; }
   if (option == NBP_OPT_GRAPH_REPLAY) { p->use_graph = value != 0; return NBP_OK; }
   if (option == NBP_OPT_FUSED_UPDATES) { p->use_fused = value != 0; return NBP_OK; }
+  if (option == NBP_OPT_ASYNC_UPLOAD) { p->async_upload = value != 0; return NBP_OK; }
   return fail(NBP_ERR_ARG, "unknown program option");
 }
 
@@ -1833,7 +2005,22 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     p->dev_bytes = bytes < 65536 ? 65536 : bytes;
     HIPCHK(hipMalloc(&p->dev, p->dev_bytes));
   }
-  if (p->blob.size()) HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+  if (p->blob.size()) {
+    if (p->async_upload) {
+      // stream-ordered: behind whatever still reads a blob taken over from a retired program, in front of this program's launches
+      nbp_ctx::pin_buf *b = pin_acquire(p->ctx, p->blob.size());
+      if (!b) return fail(NBP_ERR_HIP, "pinned staging buffer");
+      memcpy(b->p, p->blob.data(), p->blob.size());
+      const hipError_t e = hipMemcpyAsync(p->dev, b->p, p->blob.size(), hipMemcpyHostToDevice, p->ctx->stream);
+      pin_release_behind_stream(p->ctx, b);
+      if (e != hipSuccess) return fail(NBP_ERR_HIP, std::string("hipMemcpyAsync (descriptors): ") + hipGetErrorString(e));
+    } else {
+      // (a blob from the cache may come from a RETIRED program whose launches are still queued: the library stream does not
+      //  wait for the legacy stream this copy runs on)
+      if (!p->ctx->retired.empty()) HIPCHK(hipStreamSynchronize(p->ctx->stream));
+      HIPCHK(hipMemcpy(p->dev, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+    }
+  }
   p->finalized = true;
   return NBP_OK;
 }
@@ -1999,11 +2186,45 @@ nbp_status nbp_program_num_two_stream(nbp_program *p, int32_t *out) {
   return NBP_OK;
 }
 
+// the programs handed to nbp_program_retire whose last launch has run
+static void program_free(nbp_program *p, bool sync);
+static void reap_retired(nbp_ctx *c) {
+  for (size_t i = 0; i < c->retired.size();) {
+    if (hipEventQuery(c->retired[i].second) == hipSuccess) {
+      hipEventDestroy(c->retired[i].second);
+      nbp_program *p = c->retired[i].first;
+      c->retired.erase(c->retired.begin() + (long)i);
+      program_free(p, false);
+    } else
+      i++;
+  }
+}
+// Destroy a program without waiting for it: it is dropped once everything queued on the library stream up to now has run
+// (checked at the next retire / nbp_clique_submit_batch / nbp_synchronize; nbp_ctx_destroy takes what is left).  Its device
+// blob goes to the next short-lived program only then.
+nbp_status nbp_program_retire(nbp_program *p) {
+  if (!p) return NBP_OK;
+  if (!p->ctx) { delete p; return NBP_OK; }
+  nbp_ctx *c = p->ctx;
+  hipSetDevice(c->device);
+  reap_retired(c);
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, c->stream) != hipSuccess) {
+    if (ev) hipEventDestroy(ev);
+    return nbp_program_destroy(p);  // (waits instead)
+  }
+  c->retired.emplace_back(p, ev);
+  return NBP_OK;
+}
 nbp_status nbp_program_destroy(nbp_program *p) {
   if (!p) return NBP_OK;
+  program_free(p, true);
+  return NBP_OK;
+}
+static void program_free(nbp_program *p, bool sync) {
   if (p->ctx) {  // (a program whose context is gone was detached by nbp_ctx_destroy: nothing left on the device)
     hipSetDevice(p->ctx->device);
-    hipStreamSynchronize(p->ctx->stream);
+    if (sync) hipStreamSynchronize(p->ctx->stream);
     if (p->dev) {
       // small blobs are kept for the next program of this context (hipFree synchronises the whole device)
       auto &bc = p->ctx->blob_cache;
@@ -2016,7 +2237,6 @@ nbp_status nbp_program_destroy(nbp_program *p) {
       if (v[i] == p) { v.erase(v.begin() + i); break; }
   }
   delete p;
-  return NBP_OK;
 }
 
 // ---- separator exchange between ranks: RCCL point-to-point over xGMI, from C -----------------------------------------

@@ -1840,12 +1840,12 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
   {
     auto put = [&](int slot, int mani, const nbp_tree_belief &m, bool with_ipc) { P.in.push_back({slot, mani, &m, nullptr, with_ipc}); };
     for (int v = 0; v < q->nvars; v++) {
-      if (!bel[v].pts) return hfail(NBP_ERR_ARG, "clique: null belief");
+      if (!bel[v].pts && bel[v].handle <= 0) return hfail(NBP_ERR_ARG, "clique: null belief");
       put(v, q->manifold[v], bel[v], true);
     }
     for (int i = 0; i < (down ? 0 : q->nmsgs); i++) {
       const nbp_tree_belief &m = q->msg_belief[i];
-      if (!m.pts || !m.bw) return hfail(NBP_ERR_ARG, "clique: a message needs points and bandwidth");
+      if ((!m.pts || !m.bw) && m.handle <= 0) return hfail(NBP_ERR_ARG, "clique: a message needs points and bandwidth");
       put(msg0 + i, q->manifold[q->msg_var[i]], m, true);
     }
     for (int f = 0; f < q->nfactors; f++)
@@ -1971,14 +1971,29 @@ static nbp_status clique_plan_build(const nbp_solver_params *sp, const nbp_cliqu
 }
 
 // the plans of one or several cliques on one context: one transfer in, one program (stage pair r = round r of every
-// clique; the differential stages of all of them behind the last round), one transfer out
-static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans) {
+// clique; the differential stages of all of them behind the last round), one transfer out.  Queued, not waited for:
+// clique_plans_finish waits for the copies out (an event behind them) and unpacks.  Beliefs with a handle are resident:
+// taken from / delivered to their resident slot by device copies in front of / behind the rounds (a copy stage each).
+struct nbp_clique_ticket {
+  nbp_ctx *ctx = nullptr;
+  nbp_read_token *tok = nullptr;
+  std::vector<int32_t> om;
+  std::vector<double *> op, ob, oi;
+  std::vector<nbp_tree_belief *> dst;
+  std::vector<nbp_clique_request *> reqs;  // statuses to write (batch entry)
+  int32_t *status_out = nullptr;           // (single-clique entries)
+  bool down = false;
+  double t_launched = 0;
+};
+static inline int resident_slot(nbp_ctx *ctx, int handle) { return nbp_ctx_slots(ctx) - handle; }
+static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &plans, nbp_clique_ticket *T, bool async) {
+  const int nres = nbp_ctx_resident(ctx), cap = nbp_ctx_slots(ctx) - nres;
   {
     int need = 0;
     for (const clique_plan &P : plans) need += P.nslots;
-    if (need > nbp_ctx_slots(ctx))
-      return hfail(NBP_ERR_RANGE, ("clique: the context has " + std::to_string(nbp_ctx_slots(ctx)) + " belief slots, the call needs " + std::to_string(need) +
-                                   " (nbp_clique_slots gives the bound per clique)").c_str());
+    if (need > cap)
+      return hfail(NBP_ERR_RANGE, ("clique: the context has " + std::to_string(cap) + " belief slots" + (nres ? " below its resident ones" : "") + ", the call needs " +
+                                   std::to_string(need) + " (nbp_clique_slots gives the bound per clique)").c_str());
   }
   {
     int offA = 0, offB = 0;
@@ -1999,20 +2014,33 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
   const double t0 = seam_now();
   std::vector<int32_t> bs, bm, bn;
   std::vector<const double *> bp, bb, bi;
+  std::vector<nbp_copy_desc> cin, cout;  // resident -> the call's slot, the call's slot -> resident
   for (const clique_plan &P : plans)
     for (const clique_io &e : P.in) {
+      if (e.src->handle > 0) {
+        if (e.src->handle > nres) return hfail(NBP_ERR_RANGE, "clique: belief handle beyond the context's resident slots (nbp_ctx_reserve_resident)");
+        cin.push_back({resident_slot(ctx, e.src->handle), e.slot});
+        continue;
+      }
       bs.push_back(e.slot); bm.push_back(e.mani); bn.push_back(e.src->n_pts); bp.push_back(e.src->pts); bb.push_back(e.src->bw);
       bi.push_back(e.with_ipc ? e.src->ipc : nullptr);
     }
-  nbp_status rc = nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
+  nbp_status rc = async ? nbp_belief_write_batch_async(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data())
+                        : nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
   if (rc) return rc;
   const double t1 = seam_now();
   nbp_program *p = nullptr;
   rc = nbp_program_create(ctx, &p);
   if (rc) return rc;
-  struct prog_guard { nbp_program *p; ~prog_guard() { nbp_program_destroy(p); } } guard{p};
+  // (the program is short-lived: retired behind its last launch when the call does not wait, destroyed otherwise)
+  struct prog_guard { nbp_program *p; bool async; ~prog_guard() { if (async) nbp_program_retire(p); else nbp_program_destroy(p); } } guard{p, async};
   rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
+  if (!rc && async) rc = nbp_program_set_option(p, NBP_OPT_ASYNC_UPLOAD, 1);
   if (rc) return rc;
+  if (!cin.empty()) {
+    rc = nbp_program_add_stage(p, NBP_STAGE_COPIES, cin.data(), (int)cin.size());
+    if (rc) return rc;
+  }
   size_t nr = 0;
   for (const clique_plan &P : plans) nr = std::max(nr, P.rounds.size());
   std::vector<nbp_proposal_desc> props;
@@ -2034,27 +2062,56 @@ static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans
     rc = nbp_program_add_stage(p, NBP_STAGE_DECONV, props.data(), (int)props.size());
     if (rc) return rc;
   }
+  // beliefs out: to their resident slots (a copy stage: it carries the fitted bandwidth along), to the host (below)
+  std::vector<int32_t> os;
+  for (const clique_plan &P : plans)
+    for (const clique_io &e : P.out) {
+      if (e.dst->handle > 0) {
+        if (e.dst->handle > nres) return hfail(NBP_ERR_RANGE, "clique: belief handle beyond the context's resident slots (nbp_ctx_reserve_resident)");
+        cout.push_back({e.slot, resident_slot(ctx, e.dst->handle)});
+      }
+      if (e.dst->pts || e.dst->handle <= 0) {
+        if (!e.dst->pts) return hfail(NBP_ERR_ARG, "clique: a delivered belief needs host buffers or a handle");
+        os.push_back(e.slot); T->om.push_back(e.mani); T->op.push_back(e.dst->pts); T->ob.push_back(e.dst->bw); T->oi.push_back(e.with_ipc ? e.dst->ipc : nullptr);
+        T->dst.push_back(e.dst);
+      }
+    }
+  if (!cout.empty()) {
+    rc = nbp_program_add_stage(p, NBP_STAGE_COPIES, cout.data(), (int)cout.size());
+    if (rc) return rc;
+  }
   rc = nbp_program_finalize(p);
   const double t2 = seam_now();
   if (!rc) rc = nbp_program_run(p, 0, -1);
   if (!rc && g_seam_sync) rc = nbp_synchronize(ctx);  // (timing mode: the wait is charged to the launches, not to the read)
   if (rc) return rc;
   const double t3 = seam_now();
-  std::vector<int32_t> os, om, on;
-  std::vector<double *> op, ob, oi;
-  std::vector<nbp_tree_belief *> dst;
-  for (const clique_plan &P : plans)
-    for (const clique_io &e : P.out) {
-      os.push_back(e.slot); om.push_back(e.mani); op.push_back(e.dst->pts); ob.push_back(e.dst->bw); oi.push_back(e.with_ipc ? e.dst->ipc : nullptr);
-      dst.push_back(e.dst);
-    }
-  on.resize(os.size());
-  rc = nbp_belief_read_batch(ctx, (int32_t)os.size(), os.data(), om.data(), op.data(), on.data(), ob.data(), oi.data());
+  T->ctx = ctx;
+  rc = nbp_belief_read_batch_begin(ctx, (int32_t)os.size(), os.data(), &T->tok);
   if (rc) return rc;
-  for (size_t i = 0; i < dst.size(); i++) dst[i]->n_pts = on[i];
-  const double t4 = seam_now();
-  g_seam_s[1] += t1 - t0; g_seam_s[2] += t2 - t1; g_seam_s[3] += t3 - t2; g_seam_s[4] += t4 - t3;
+  T->t_launched = t3;
+  g_seam_s[1] += t1 - t0; g_seam_s[2] += t2 - t1; g_seam_s[3] += t3 - t2;
   return NBP_OK;
+}
+// waits for the batch of `T` (its copies out; a batch without host deliveries: the event behind its last launch), unpacks
+static nbp_status clique_plans_finish(nbp_clique_ticket *T) {
+  const double t3 = seam_now();
+  std::vector<int32_t> on(T->dst.size());
+  nbp_status rc = nbp_belief_read_batch_end(T->tok, T->om.data(), T->op.data(), on.data(), T->ob.data(), T->oi.data());
+  T->tok = nullptr;
+  if (rc) return rc;
+  for (size_t i = 0; i < T->dst.size(); i++) T->dst[i]->n_pts = on[i];
+  g_seam_s[4] += seam_now() - t3;
+  return NBP_OK;
+}
+static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans) {
+  nbp_clique_ticket T;
+  nbp_status rc = clique_plans_submit(ctx, plans, &T, false);
+  if (rc) {
+    if (T.tok) nbp_belief_read_batch_end(T.tok, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return rc;
+  }
+  return clique_plans_finish(&T);
 }
 
 static nbp_status clique_particles_ok(nbp_ctx *ctx, const nbp_solver_params *sp) {
@@ -2077,10 +2134,7 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   return NBP_OK;
 }
 
-nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t n) {
-  if (!ctx || (n > 0 && !req)) return hfail(NBP_ERR_ARG, "null argument");
-  if (n <= 0) return NBP_OK;
-  std::vector<clique_plan> plans((size_t)n);
+static nbp_status clique_batch_plans(nbp_ctx *ctx, nbp_clique_request *req, int32_t n, std::vector<clique_plan> &plans) {
   const double t0 = seam_now();
   for (int i = 0; i < n; i++) {
     if (!req[i].params || !req[i].clique) return hfail(NBP_ERR_ARG, "clique batch: null params / clique");
@@ -2113,10 +2167,88 @@ nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t
       }
   }
   g_seam_s[0] += seam_now() - t0; g_seam_s[5] += 1;
-  nbp_status rc = clique_plans_run(ctx, plans);
+  return NBP_OK;
+}
+
+nbp_status nbp_clique_solve_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t n) {
+  if (!ctx || (n > 0 && !req)) return hfail(NBP_ERR_ARG, "null argument");
+  if (n <= 0) return NBP_OK;
+  std::vector<clique_plan> plans((size_t)n);
+  nbp_status rc = clique_batch_plans(ctx, req, n, plans);
+  if (!rc) rc = clique_plans_run(ctx, plans);
   if (rc) return rc;
   for (int i = 0; i < n; i++) req[i].status = req[i].down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
   return NBP_OK;
+}
+
+nbp_status nbp_clique_submit_batch(nbp_ctx *ctx, nbp_clique_request *req, int32_t n, nbp_clique_ticket **out) {
+  if (!ctx || !out || (n > 0 && !req)) return hfail(NBP_ERR_ARG, "null argument");
+  *out = nullptr;
+  nbp_clique_ticket *T = new nbp_clique_ticket();
+  T->ctx = ctx;
+  if (n > 0) {
+    std::vector<clique_plan> plans((size_t)n);
+    nbp_status rc = clique_batch_plans(ctx, req, n, plans);
+    if (!rc) rc = clique_plans_submit(ctx, plans, T, true);
+    if (rc) {
+      if (T->tok) nbp_belief_read_batch_end(T->tok, nullptr, nullptr, nullptr, nullptr, nullptr);
+      delete T;
+      return rc;
+    }
+    for (int i = 0; i < n; i++) T->reqs.push_back(&req[i]);
+  }
+  *out = T;
+  return NBP_OK;
+}
+nbp_status nbp_clique_wait(nbp_clique_ticket *T) {
+  if (!T) return hfail(NBP_ERR_ARG, "null argument");
+  nbp_status rc = NBP_OK;
+  if (T->tok) rc = clique_plans_finish(T);
+  if (!rc)
+    for (nbp_clique_request *r : T->reqs) r->status = r->down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
+  delete T;
+  return rc;
+}
+
+// ---- resident beliefs from the host side ------------------------------------------------------------------------------
+static nbp_status resident_slots(nbp_ctx *ctx, int32_t n, const int32_t *h, std::vector<int32_t> &slots) {
+  if (!ctx || (n > 0 && !h)) return hfail(NBP_ERR_ARG, "null argument");
+  const int nres = nbp_ctx_resident(ctx);
+  slots.resize((size_t)(n > 0 ? n : 0));
+  for (int i = 0; i < n; i++) {
+    if (h[i] < 1 || h[i] > nres) return hfail(NBP_ERR_RANGE, "resident belief: handle outside 1 .. nbp_ctx_resident");
+    slots[(size_t)i] = resident_slot(ctx, h[i]);
+  }
+  return NBP_OK;
+}
+nbp_status nbp_resident_write(nbp_ctx *ctx, int32_t n, const int32_t *handles, const int32_t *manifolds, const nbp_tree_belief *b) {
+  std::vector<int32_t> slots, np;
+  nbp_status rc = resident_slots(ctx, n, handles, slots);
+  if (rc || n <= 0) return rc;
+  if (!manifolds || !b) return hfail(NBP_ERR_ARG, "null argument");
+  std::vector<const double *> p, w, c;
+  for (int i = 0; i < n; i++) { p.push_back(b[i].pts); w.push_back(b[i].bw); c.push_back(b[i].ipc); np.push_back(b[i].n_pts); }
+  return nbp_belief_write_batch_async(ctx, n, slots.data(), manifolds, p.data(), np.data(), w.data(), c.data());
+}
+nbp_status nbp_resident_read(nbp_ctx *ctx, int32_t n, const int32_t *handles, const int32_t *manifolds, nbp_tree_belief *b) {
+  std::vector<int32_t> slots, np((size_t)(n > 0 ? n : 0));
+  nbp_status rc = resident_slots(ctx, n, handles, slots);
+  if (rc || n <= 0) return rc;
+  if (!manifolds || !b) return hfail(NBP_ERR_ARG, "null argument");
+  std::vector<double *> p, w, c;
+  for (int i = 0; i < n; i++) { p.push_back(b[i].pts); w.push_back(b[i].bw); c.push_back(b[i].ipc); }
+  rc = nbp_belief_read_batch(ctx, n, slots.data(), manifolds, p.data(), np.data(), w.data(), c.data());
+  if (!rc) for (int i = 0; i < n; i++) b[i].n_pts = np[(size_t)i];
+  return rc;
+}
+nbp_status nbp_resident_copy(nbp_ctx *ctx, int32_t n, const int32_t *src, const int32_t *dst, int32_t points_only) {
+  std::vector<int32_t> a, b;
+  nbp_status rc = resident_slots(ctx, n, src, a);
+  if (!rc) rc = resident_slots(ctx, n, dst, b);
+  if (rc || n <= 0) return rc;
+  std::vector<nbp_copy_desc> cd((size_t)n);
+  for (int i = 0; i < n; i++) cd[(size_t)i] = {a[(size_t)i], b[(size_t)i]};
+  return nbp_run_copies_async(ctx, cd.data(), n, points_only);
 }
 
 nbp_status nbp_clique_upsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,

@@ -40,7 +40,7 @@ XCHG_FN = C.CFUNCTYPE(i32, C.c_void_p, C.POINTER(Xfer), i32, C.POINTER(Xfer), i3
 
 class TreeBeliefC(C.Structure):
     """nbp_tree_belief: TreeBelief (val, bw, infoPerCoord) in host buffers"""
-    _fields_ = [("pts", C.POINTER(f64)), ("bw", C.POINTER(f64)), ("ipc", C.POINTER(f64)), ("n_pts", i32), ("reserved_", i32)]
+    _fields_ = [("pts", C.POINTER(f64)), ("bw", C.POINTER(f64)), ("ipc", C.POINTER(f64)), ("n_pts", i32), ("handle", i32)]
 
 
 class CliqueDescC(C.Structure):
