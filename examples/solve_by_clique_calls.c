@@ -8,7 +8,8 @@
  *
  *   gcc -O2 -fopenmp -Iinclude examples/solve_by_clique_calls.c -o /tmp/clique_calls \
  *       -Lincrementalinference.jl_amd/csrc -lnbp -Wl,-rpath,$PWD/incrementalinference.jl_amd/csrc -lm
- *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5] [concurrent callers=1; 0 = one batched call per tree level]
+ *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5] [concurrent callers=1; 0 = one batched call per tree level;
+ *                                                          -1 = the same, queued: resident beliefs, submit per level, wait once]
  *
  * With several concurrent callers the cliques of one tree level are solved side by side, one context per caller -- the
  * C equivalent of the reference's one-task-per-clique state machines.  Same posteriors: nothing depends on which context
@@ -67,7 +68,14 @@ typedef struct {
   belief *graph, *post;  /* the graph's beliefs (read-only during the passes, but for the roots' frontals) and the posteriors */
   const nbp_solver_params *sp;
   uint64_t seed;
+  /* callers = -1: the beliefs stay on the device between the calls (nbp_ctx_reserve_resident): handle of every graph
+   * belief and of every belief of every clique's sub graph; the copies a level needs in front of / behind its batch */
+  int resident;
+  int32_t *graph_h, **sub_h;
+  int32_t *cp_src, *cp_dst, ncp;     /* whole beliefs: the deep copy of a sub graph, a root's result back to the graph */
+  int32_t *pp_src, *pp_dst, npp;     /* points only: the down message */
 } host;
+static nbp_tree_belief resident_view(int32_t h) { nbp_tree_belief v = {NULL, NULL, NULL, N, h}; return v; }
 typedef struct { /* one concurrent caller: its context and its scratch; `q` = the clique call it has prepared */
   nbp_ctx *ctx;
   nbp_clique_desc q;
@@ -81,8 +89,12 @@ static int up_prepare(host *H, worker *w, int c) {
   const int nf = info[c].nfrontals, ns = info[c].nseparators, nv = nf + ns;
   int32_t *vars = w->vars, counts[4];
   memcpy(vars, H->fr[c], sizeof(int32_t) * nf); memcpy(vars + nf, H->se[c], sizeof(int32_t) * ns);
+  if (H->resident) { /* the deep copy happens on the device, queued in front of this level's batch */
+    for (int i = 0; i < nv; i++) { H->cp_src[H->ncp] = H->graph_h[vars[i]]; H->cp_dst[H->ncp++] = H->sub_h[c][i]; w->bel[i] = resident_view(H->sub_h[c][i]); }
+  } else {
   H->sub[c] = malloc(sizeof(belief) * nv);
   for (int i = 0; i < nv; i++) { H->sub[c][i] = belief_new(); belief_copy(&H->sub[c][i], &H->graph[vars[i]]); w->bel[i] = view(&H->sub[c][i]); } /* deep copy */
+  }
   nbp_clique_desc q;
   memset(&q, 0, sizeof(q));
   q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = w->mani;
@@ -98,7 +110,11 @@ static int up_prepare(host *H, worker *w, int c) {
   int nm = 0; /* the children's upward messages: their separator beliefs */
   for (int j = 0; j < info[c].nchildren; j++) {
     const int cc = H->ch[c][j];
-    for (int i = 0; i < info[cc].nseparators; i++) { w->msgv[nm] = find(vars, nv, H->se[cc][i]); w->msgb[nm++] = view(&H->sub[cc][info[cc].nfrontals + i]); }
+    for (int i = 0; i < info[cc].nseparators; i++) {
+      w->msgv[nm] = find(vars, nv, H->se[cc][i]);
+      w->msgb[nm++] = H->resident ? resident_view(H->sub_h[cc][info[cc].nfrontals + i]) /* the message is a handle: it never visits the host */
+                                  : view(&H->sub[cc][info[cc].nfrontals + i]);
+    }
   }
   q.nmsgs = nm; q.msg_var = w->msgv; q.msg_belief = w->msgb;
   w->q = q;
@@ -107,7 +123,10 @@ static int up_prepare(host *H, worker *w, int c) {
 static void up_finish(host *H, int c) {
   const int nf = H->info[c].nfrontals;
   if (H->info[c].parent == 0) /* root: the up-solved frontals are the posterior and go back to the graph */
-    for (int i = 0; i < nf; i++) { belief_copy(&H->post[H->fr[c][i]], &H->sub[c][i]); belief_copy(&H->graph[H->fr[c][i]], &H->sub[c][i]); }
+    for (int i = 0; i < nf; i++) {
+      if (H->resident) { H->cp_src[H->ncp] = H->sub_h[c][i]; H->cp_dst[H->ncp++] = H->graph_h[H->fr[c][i]]; continue; }
+      belief_copy(&H->post[H->fr[c][i]], &H->sub[c][i]); belief_copy(&H->graph[H->fr[c][i]], &H->sub[c][i]);
+    }
 }
 static int up_clique(host *H, worker *w, int c) {
   int32_t status = 0;
@@ -127,7 +146,8 @@ static int down_prepare(host *H, worker *w, int c) {
   for (int i = 0; i < ns; i++) { /* the down message: the parent's values of the separators */
     int pi = find(H->fr[p], info[p].nfrontals, H->se[c][i]);
     pi = pi >= 0 ? pi : info[p].nfrontals + find(H->se[p], info[p].nseparators, H->se[c][i]);
-    memcpy(H->sub[c][nf + i].pts, H->sub[p][pi].pts, sizeof(double) * N * D);
+    if (H->resident) { H->pp_src[H->npp] = H->sub_h[p][pi]; H->pp_dst[H->npp++] = H->sub_h[c][nf + i]; }
+    else memcpy(H->sub[c][nf + i].pts, H->sub[p][pi].pts, sizeof(double) * N * D);
   }
   int ncf = 0; /* every factor of the frontals, in graph order; their other variables come from the graph */
   for (int f = 0; f < H->nfac; f++) {
@@ -139,7 +159,8 @@ static int down_prepare(host *H, worker *w, int c) {
     ncf++;
   }
   for (int i = 0; i < ncf; i++) for (int k = 0; k < w->cf[i].nvars; k++) w->cf[i].vars[k] = find(vars, nv, w->cf[i].vars[k]);
-  for (int i = 0; i < nv; i++) w->bel[i] = i < nf + ns ? view(&H->sub[c][i]) : view(&H->graph[vars[i]]);
+  for (int i = 0; i < nv; i++)
+    w->bel[i] = H->resident ? resident_view(i < nf + ns ? H->sub_h[c][i] : H->graph_h[vars[i]]) : (i < nf + ns ? view(&H->sub[c][i]) : view(&H->graph[vars[i]]));
   nbp_clique_desc q;
   memset(&q, 0, sizeof(q));
   q.clique_id = c; q.nvars = nv; q.nfrontals = nf; q.nseparators = ns; q.manifold = w->mani; q.nfactors = ncf; q.factors = w->cf;
@@ -147,6 +168,7 @@ static int down_prepare(host *H, worker *w, int c) {
   return 0;
 }
 static void down_finish(host *H, int c) {
+  if (H->resident) return; /* the posteriors are read back once, at the end of the walk */
   for (int i = 0; i < H->info[c].nfrontals; i++) belief_copy(&H->post[H->fr[c][i]], &H->sub[c][i]);
 }
 static int down_clique(host *H, worker *w, int c) {
@@ -209,11 +231,60 @@ static int level_batched(host *H, nbp_ctx *ctx, int d, int down) {
   return 0;
 }
 
+/* callers = -1: the same level, QUEUED (nbp_clique_submit_batch): the device copies this level needs in front of its batch,
+ * the batch, the copies behind it -- and on to the next level while the device works; everything a queued batch points to
+ * stays alive until its ticket has been waited for */
+typedef struct { worker *W; nbp_clique_request *R; int n; nbp_clique_ticket *t; } queued_level;
+static int level_queued(host *H, nbp_ctx *ctx, int d, int down, queued_level *Q) {
+  int n = 0;
+  for (int c = 1; c <= H->ncl; c++) n += H->depth[c] == d;
+  worker *W = calloc((size_t)n, sizeof(*W));
+  nbp_clique_request *R = calloc((size_t)n, sizeof(*R));
+  int k = 0;
+  H->ncp = H->npp = 0;
+  for (int c = 1; c <= H->ncl; c++) {
+    if (H->depth[c] != d) continue;
+    int ncf = H->info[c].npotentials;
+    if (down) {
+      ncf = 0;
+      for (int f = 0; f < H->nfac; f++) {
+        int hit = 0;
+        for (int i = 0; i < H->fac[f].nvars; i++) hit |= find(H->fr[c], H->info[c].nfrontals, H->fac[f].vars[i]) >= 0;
+        ncf += hit;
+      }
+    }
+    int nmsg = 0;
+    for (int j = 0; j < H->info[c].nchildren; j++) nmsg += H->info[H->ch[c][j]].nseparators;
+    W[k] = worker_new(H->info[c].nfrontals + H->info[c].nseparators + 2 * ncf + nmsg + 1, ncf);
+    if (down ? down_prepare(H, &W[k], c) : up_prepare(H, &W[k], c)) return 1;
+    R[k].params = H->sp; R[k].clique = &W[k].q; R[k].seed = H->seed; R[k].beliefs = W[k].bel; R[k].down = down;
+    k++;
+  }
+  CHK(nbp_resident_copy(ctx, H->ncp, H->cp_src, H->cp_dst, 0)); /* up: the deep copies of this level's sub graphs */
+  CHK(nbp_resident_copy(ctx, H->npp, H->pp_src, H->pp_dst, 1)); /* down: the parents' values of this level's separators */
+  Q->W = W; Q->R = R; Q->n = n; Q->t = NULL;
+  CHK(nbp_clique_submit_batch(ctx, R, n, &Q->t));
+  H->ncp = 0;
+  for (int c = 1; c <= H->ncl && !down; c++) if (H->depth[c] == d) up_finish(H, c);
+  CHK(nbp_resident_copy(ctx, H->ncp, H->cp_src, H->cp_dst, 0)); /* a root's result goes back to the graph */
+  return 0;
+}
+static int level_wait(queued_level *Q, int down) {
+  CHK(nbp_clique_wait(Q->t));
+  for (int i = 0; i < Q->n; i++) {
+    if (Q->R[i].status != (down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED)) return 1;
+    worker_free(&Q->W[i]);
+  }
+  free(Q->W); free(Q->R);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int nvars = argc > 1 ? atoi(argv[1]) : 12;
   N = argc > 2 ? atoi(argv[2]) : 128;
   const int every = argc > 3 ? atoi(argv[3]) : 5;
-  const int batched = argc > 4 && atoi(argv[4]) == 0; /* callers = 0: the cliques of a level in one batched call */
+  const int queued = argc > 4 && atoi(argv[4]) < 0;     /* callers = -1: batched per level, resident beliefs, submit / wait */
+  const int batched = argc > 4 && atoi(argv[4]) <= 0;   /* callers = 0: the cliques of a level in one batched call */
   const int threads = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : 1;
   const uint64_t seed = 2024;
   nbp_solver_params sp;
@@ -311,7 +382,22 @@ int main(int argc, char **argv) {
       for (int c = 1; c <= ncl; c++) cnt += H.depth[c] == d;
       if (cnt > widest) widest = cnt;
     }
-    CHK(nbp_ctx_create(0, N, widest * 40 + 64, NULL, 0, 0, &bctx)); /* generous: nbp_clique_slots(desc) is the exact need of a clique */
+    int nres = 0; /* callers = -1: a resident slot for every graph belief and every belief of every sub graph */
+    if (queued) {
+      H.resident = 1;
+      H.graph_h = malloc(sizeof(int32_t) * nvars);
+      H.sub_h = calloc((size_t)ncl + 1, sizeof(*H.sub_h));
+      for (int v = 0; v < nvars; v++) H.graph_h[v] = ++nres;
+      for (int c = 1; c <= ncl; c++) {
+        const int nv = H.info[c].nfrontals + H.info[c].nseparators;
+        H.sub_h[c] = malloc(sizeof(int32_t) * nv);
+        for (int i = 0; i < nv; i++) H.sub_h[c][i] = ++nres;
+      }
+      H.cp_src = malloc(sizeof(int32_t) * (nres + nvars)); H.cp_dst = malloc(sizeof(int32_t) * (nres + nvars));
+      H.pp_src = malloc(sizeof(int32_t) * nres); H.pp_dst = malloc(sizeof(int32_t) * nres);
+    }
+    CHK(nbp_ctx_create(0, N, widest * 40 + 64 + nres, NULL, 0, 0, &bctx)); /* generous: nbp_clique_slots(desc) is the exact need of a clique */
+    CHK(nbp_ctx_reserve_resident(bctx, nres));
   }
   int failed = 0;
   double t_calls = 0;
@@ -319,14 +405,31 @@ int main(int argc, char **argv) {
   for (int v = 0; v < nvars; v++) { graph0[v] = belief_new(); belief_copy(&graph0[v], &graph[v]); }
   double t_first = 0;
   const int seam_timing = getenv("NBP_SEAM_TIMES") != NULL; /* a third walk with the library's phase clock on */
-  double t_timed = 0, ph[6] = {0};
+  double t_timed = 0, ph[6] = {0}, t_queued = 0;
   for (int pass = 0; pass < 2 + seam_timing && !failed; pass++) { /* the second walk runs with every buffer of the library at its final size */
   for (int v = 0; v < nvars; v++) belief_copy(&graph[v], &graph0[v]);
-  for (int c = 1; c <= ncl && pass; c++) { for (int i = 0; i < H.info[c].nfrontals + H.info[c].nseparators; i++) free(H.sub[c][i].pts); free(H.sub[c]); }
+  for (int c = 1; c <= ncl && pass && !queued; c++) { for (int i = 0; i < H.info[c].nfrontals + H.info[c].nseparators; i++) free(H.sub[c][i].pts); free(H.sub[c]); }
   if (pass == 2) nbp_clique_seam_times(NULL, 2);
   const double tb = now_s();
-  for (int d = maxdepth; d >= 0 && !failed && batched; d--) failed |= level_batched(&H, bctx, d, 0);
-  for (int d = 1; d <= maxdepth && !failed && batched; d++) failed |= level_batched(&H, bctx, d, 1);
+  if (queued) {
+    /* the graph goes to the device once, every level of both passes is queued behind it, ONE wait, the posteriors come back once */
+    nbp_tree_belief *gb = malloc(sizeof(*gb) * nvars);
+    int32_t *gm = malloc(sizeof(int32_t) * nvars), *ph_ = malloc(sizeof(int32_t) * nvars);
+    for (int v = 0; v < nvars; v++) { gb[v] = view(&graph[v]); gm[v] = NBP_EUCLID2; }
+    CHK(nbp_resident_write(bctx, nvars, H.graph_h, gm, gb));
+    queued_level *Q = calloc(2 * ((size_t)maxdepth + 1), sizeof(*Q));
+    int nq = 0;
+    for (int d = maxdepth; d >= 0 && !failed; d--) failed |= level_queued(&H, bctx, d, 0, &Q[nq++]);
+    for (int d = 1; d <= maxdepth && !failed; d++) failed |= level_queued(&H, bctx, d, 1, &Q[nq++]);
+    t_queued = now_s() - tb; /* everything is queued: from here on the host only waits */
+    for (int i = 0; i < nq && !failed; i++) failed |= level_wait(&Q[i], i > maxdepth);
+    for (int c = 1; c <= ncl; c++) for (int i = 0; i < H.info[c].nfrontals; i++) ph_[H.fr[c][i]] = H.sub_h[c][i]; /* a variable's posterior: its frontal clique's copy */
+    for (int v = 0; v < nvars; v++) gb[v] = view(&post[v]);
+    if (!failed) CHK(nbp_resident_read(bctx, nvars, ph_, gm, gb));
+    free(Q); free(gb); free(gm); free(ph_);
+  }
+  for (int d = maxdepth; d >= 0 && !failed && batched && !queued; d--) failed |= level_batched(&H, bctx, d, 0);
+  for (int d = 1; d <= maxdepth && !failed && batched && !queued; d++) failed |= level_batched(&H, bctx, d, 1);
   for (int d = maxdepth; d >= 0 && !failed && !batched; d--) { /* up pass: children before parents, the cliques of a level side by side */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(| : failed)
     for (int c = 1; c <= ncl; c++)
@@ -352,12 +455,15 @@ int main(int argc, char **argv) {
   }
   printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program; "
          "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %s%d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
-         post[0].ipc[0], post[0].ipc[1], worst, batched ? "one batched call per tree level, " : "", threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
+         post[0].ipc[0], post[0].ipc[1], worst, queued ? "one QUEUED batch per tree level (resident beliefs, submit / wait), " : (batched ? "one batched call per tree level, " : ""), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "
          "(the second walk; the first, while the library's buffers grow: %.1f ms)\n",
          t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls, t_first * 1e3);
+  if (queued)
+    printf("  queued walk: all %d batches submitted after %.1f ms of host work (planning, assembly, enqueueing), the rest of the %.1f ms is waiting for the device\n",
+           2 * maxdepth + 1, t_queued * 1e3, t_calls * 1e3);
   if (seam_timing)
     printf("  phases of a walk with the device waited for after the launches (%.1f ms, %.0f calls): planning %.2f ms, beliefs in %.2f, program assembly %.2f, "
            "launches + device %.2f, beliefs out %.2f; the caller's own sub-graph assembly and bookkeeping %.2f\n", t_timed * 1e3, ph[5], ph[0] * 1e3, ph[1] * 1e3,

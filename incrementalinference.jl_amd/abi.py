@@ -95,6 +95,8 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libnbp.so")
 EXPORTS = [
     "nbp_arena_bytes", "nbp_slot_stride_doubles", "nbp_ctx_create", "nbp_ctx_destroy",
     "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr", "nbp_ctx_particles", "nbp_ctx_slots",
+    "nbp_ctx_reserve_resident", "nbp_ctx_resident", "nbp_belief_write_batch_async", "nbp_belief_read_batch_begin", "nbp_belief_read_batch_end",
+    "nbp_run_copies_async", "nbp_program_retire",
     "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_belief_write_batch", "nbp_belief_read_batch", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
     "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",

@@ -2228,7 +2228,8 @@ static void program_free(nbp_program *p, bool sync) {
     if (p->dev) {
       // small blobs are kept for the next program of this context (hipFree synchronises the whole device)
       auto &bc = p->ctx->blob_cache;
-      if (p->dev_bytes <= (16u << 20) && bc.size() < 8) bc.emplace_back(p->dev, p->dev_bytes);
+      // (a queued walk retires one program per tree level and direction before the first of them has run: room for all of them)
+      if (p->dev_bytes <= (16u << 20) && bc.size() < 64) bc.emplace_back(p->dev, p->dev_bytes);
       else hipFree(p->dev);
     }
     for (auto &kv : p->graphs) hipGraphExecDestroy(kv.second.exec);

@@ -62,6 +62,7 @@ HOST_EXPORTS = ["nbp_graph_create", "nbp_graph_destroy", "nbp_graph_add_variable
                 "nbp_graph_init_num_stages", "nbp_graph_init_stage", "nbp_graph_init_compile", "nbp_tree_build", "nbp_tree_destroy", "nbp_tree_num_cliques",
                 "nbp_tree_clique", "nbp_tree_clique_idlists", "nbp_tree_max_schedule", "nbp_tree_plan_slots", "nbp_tree_main_slots", "nbp_tree_compile", "nbp_tree_schedule",
                 "nbp_tree_get_stats", "nbp_tree_num_stages", "nbp_tree_stage", "nbp_clique_slots", "nbp_clique_upsolve", "nbp_clique_upsolve_joint", "nbp_clique_downsolve", "nbp_clique_solve_batch", "nbp_clique_seam_times",
+                "nbp_clique_submit_batch", "nbp_clique_wait", "nbp_resident_write", "nbp_resident_read", "nbp_resident_copy",
                 "nbp_tree_partition", "nbp_tree_set_owner", "nbp_tree_num_segments", "nbp_tree_segment",
                 "nbp_tree_run_sharded", "nbp_tree_run_sharded_cb",
                 "nbp_graph_num_densities", "nbp_graph_density_factors", "nbp_graph_init_density_slot0", "nbp_tree_density_slot0"]

@@ -84,6 +84,11 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
     out = subprocess.run([exe, "60", "100", "10", "0"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "60 of 60 posteriors byte-identical" in out.stdout and "one batched call per tree level" in out.stdout, out.stdout
+    # the same, queued: every belief resident on the device (handles), a batch per tree level submitted without waiting
+    # (nbp_clique_submit_batch), one wait at the end of both passes -- the same bytes again
+    out = subprocess.run([exe, "60", "100", "10", "-1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "60 of 60 posteriors byte-identical" in out.stdout and "QUEUED" in out.stdout, out.stdout
 
 
 def test_native_graph_init_equals_python_init_all(hip_backend):

@@ -80,7 +80,7 @@ def test_clique_seam_clock_reads_and_resets():
 
 def test_header_symbols_are_exported():
     hdr = open(os.path.join(ROOT, "include", "nbp_host.h")).read()
-    declared = set(re.findall(r"\b(nbp_(?:graph|tree|clique)_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(nbp_(?:graph|tree|clique|resident)_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(native_host.HOST_EXPORTS), declared ^ set(native_host.HOST_EXPORTS)
     lib = iif.abi.load_library()
     for n in declared:

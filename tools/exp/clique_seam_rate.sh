@@ -7,3 +7,4 @@ export LD_LIBRARY_PATH=$R/incrementalinference.jl_amd/csrc:/opt/rocm/lib:$LD_LIB
 echo "examples/solve_by_clique_calls.c 1000 200 100 <callers> on one MI355X (config-2 shape: 1000-variable Euclid(2) chain, N = 200)"
 for c in 1 4 16; do GPU_MAX_HW_QUEUES=$c /tmp/sbcc 1000 200 100 $c 2>&1 | grep -v amdgpu.ids; done
 /tmp/sbcc 1000 200 100 0 2>&1 | grep -v amdgpu.ids
+/tmp/sbcc 1000 200 100 -1 2>&1 | grep -v amdgpu.ids
