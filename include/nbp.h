@@ -210,7 +210,12 @@ int32_t nbp_ctx_slots(const nbp_ctx *ctx);     /* belief slots of its arena (0: 
 nbp_status nbp_ctx_reserve_resident(nbp_ctx *ctx, int32_t n);
 int32_t nbp_ctx_resident(const nbp_ctx *ctx);
 
-/* ---- belief I/O: setValKDE!/getVal at the boundary (FactorGraph.jl:250-297) --------------- */
+/* ---- belief I/O: setValKDE!/getVal at the boundary (FactorGraph.jl:250-297) ---------------
+ * A slot is read and written BY MANIFOLD: the rows of the manifold's D coordinates (and bw / infoPerCoord entries 0 .. D-1)
+ * are the belief; rows beyond D are unspecified -- a write from the host zeroes them, a kernel that produces a belief
+ * leaves them as they were (a third of a Euclid(2) proposal's write traffic), and nothing in the library reads them (fits,
+ * KD builds, products, proposals and the reads below all go by the manifold; whole-slot copies carry them along unread).
+ * Read a slot with the manifold of the belief that was put there. */
 nbp_status nbp_slot_write(nbp_ctx *ctx, int32_t slot, int32_t manifold, const double *pts_NxP,
                           const double *bw_D /* nullable */);
 nbp_status nbp_slot_read(nbp_ctx *ctx, int32_t slot, int32_t manifold, double *pts_NxP,

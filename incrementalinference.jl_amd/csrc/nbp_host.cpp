@@ -7,6 +7,7 @@
 // orders, cliques, schedules and descriptor bytes, and tests/test_tree_known_answers.py pins the Python
 // side against the reference's own known answers.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <array>
 #include <deque>
@@ -1729,8 +1730,14 @@ static int clique_zdim(int kind, int manifold) { return kind == NBP_F_LINREL ? m
 // transfer each way and one program whose stage pair r holds round r of every clique (nbp_clique_solve_batch).
 // host-side wall clock of the phases of the clique calls (diagnostics: nbp_clique_seam_times): 0 planning, 1 beliefs in,
 // 2 program assembly + finalize, 3 launches + waiting for them, 4 beliefs out, 5 calls
-static double g_seam_s[6] = {0, 0, 0, 0, 0, 0};
-static bool g_seam_sync = false;
+// (atomics: the reference runs cliques as concurrent tasks, and clique calls on different contexts may come from different
+//  host threads at once -- plain globals updated by all of them were a data race)
+static std::atomic<double> g_seam_s[6];
+static std::atomic<bool> g_seam_sync{false};
+static inline void seam_add(int i, double v) {
+  double cur = g_seam_s[i].load(std::memory_order_relaxed);
+  while (!g_seam_s[i].compare_exchange_weak(cur, cur + v, std::memory_order_relaxed)) {}
+}
 static inline double seam_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct clique_io { int32_t slot, mani; const nbp_tree_belief *src; nbp_tree_belief *dst; bool with_ipc; };
 struct clique_plan {
@@ -2090,7 +2097,7 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
   rc = nbp_belief_read_batch_begin(ctx, (int32_t)os.size(), os.data(), &T->tok);
   if (rc) return rc;
   T->t_launched = t3;
-  g_seam_s[1] += t1 - t0; g_seam_s[2] += t2 - t1; g_seam_s[3] += t3 - t2;
+  seam_add(1, t1 - t0); seam_add(2, t2 - t1); seam_add(3, t3 - t2);
   return NBP_OK;
 }
 // waits for the batch of `T` (its copies out; a batch without host deliveries: the event behind its last launch), unpacks
@@ -2101,7 +2108,7 @@ static nbp_status clique_plans_finish(nbp_clique_ticket *T) {
   T->tok = nullptr;
   if (rc) return rc;
   for (size_t i = 0; i < T->dst.size(); i++) T->dst[i]->n_pts = on[i];
-  g_seam_s[4] += seam_now() - t3;
+  seam_add(4, seam_now() - t3);
   return NBP_OK;
 }
 static nbp_status clique_plans_run(nbp_ctx *ctx, std::vector<clique_plan> &plans) {
@@ -2127,7 +2134,7 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   std::vector<clique_plan> plans(1);
   const double t0 = seam_now();
   nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, plans[0]);
-  g_seam_s[0] += seam_now() - t0; g_seam_s[5] += 1;
+  seam_add(0, seam_now() - t0); seam_add(5, 1);
   if (!rc) rc = clique_plans_run(ctx, plans);
   if (rc) return rc;
   if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
@@ -2166,7 +2173,7 @@ static nbp_status clique_batch_plans(nbp_ctx *ctx, nbp_clique_request *req, int3
         return rc ? rc : rcs[(size_t)i];
       }
   }
-  g_seam_s[0] += seam_now() - t0; g_seam_s[5] += 1;
+  seam_add(0, seam_now() - t0); seam_add(5, 1);
   return NBP_OK;
 }
 
@@ -2265,9 +2272,9 @@ nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *sp, const
 }
 
 nbp_status nbp_clique_seam_times(double *out, int32_t mode) {
-  if (out) for (int i = 0; i < 6; i++) out[i] = g_seam_s[i];
-  if (mode >= 1) for (int i = 0; i < 6; i++) g_seam_s[i] = 0;
-  if (mode >= 1) g_seam_sync = (mode == 2);
+  if (out) for (int i = 0; i < 6; i++) out[i] = g_seam_s[i].load(std::memory_order_relaxed);
+  if (mode >= 1) for (int i = 0; i < 6; i++) g_seam_s[i].store(0.0, std::memory_order_relaxed);
+  if (mode >= 1) g_seam_sync.store(mode == 2);
   return NBP_OK;
 }
 
