@@ -618,6 +618,11 @@ end
 # ONE nbp_clique_solve_batch: one transfer of beliefs each way and shared launches (DESIGN.md 6: 926 ms -> 41 ms per solve
 # of the config-2 graph when whole levels arrive together).  The state machines stay as they are: each waits for its own
 # result.  Same posteriors either way (the random streams are keyed by clique, not by batch).
+# Round 5: the batch goes through nbp_clique_submit_batch / nbp_clique_wait (nbp_host.h) -- the call returns once everything
+# is queued, so the dispatcher overlaps its own planning of the next batch with the device's work on this one.  Resident
+# beliefs (NbpTreeBelief.handle: a message that stays on the device between the child's call and the parent's) are offered
+# by the C ABI and exercised by examples/solve_by_clique_calls.c (47 -> 32 ms per solve of the config-2 graph); using them
+# from the state machines means a TreeBelief whose `val` is fetched on first read, which this shim does not attempt.
 const BATCH_CLIQUES = Ref(false)
 struct PendingClique
   N::Int
@@ -644,10 +649,31 @@ function dispatchcliques()
       try
         reqs = NbpCliqueRequest[NbpCliqueRequest(Base.unsafe_convert(Ptr{NbpSolverParams}, b.sp), Base.unsafe_convert(Ptr{NbpCliqueDesc}, b.q),
                                                  b.seed, pointer(b.p.beliefs), ptr_or_null(b.p.diff.out), b.down ? 1 : 0, 0) for b in group]
-        GC.@preserve group reqs withctx(N, sum(b.need for b in group)) do ctx
-          chk(ccall((:nbp_clique_solve_batch, libnbp), Int32, (Ptr{Cvoid}, Ptr{NbpCliqueRequest}, Int32), ctx.ptr, reqs, length(reqs)))
+        # submit, then wait: the batch is queued on the library stream (nbp_clique_submit_batch returns without waiting for
+        # the device), so with more than one Julia thread the wait runs elsewhere and this dispatcher is free to gather, plan
+        # and queue whatever became ready in the meantime behind it -- batches run in submission order.  The context stays
+        # borrowed, and `group` / `reqs` stay referenced by the closure (Julia's collector does not move objects), until
+        # nbp_clique_wait has unpacked the results.
+        ctx = acquire(N, sum(b.need for b in group))
+        ticket = Ref{Ptr{Cvoid}}(C_NULL)
+        try
+          GC.@preserve group reqs chk(ccall((:nbp_clique_submit_batch, libnbp), Int32, (Ptr{Cvoid}, Ptr{NbpCliqueRequest}, Int32, Ref{Ptr{Cvoid}}),
+                                            ctx.ptr, reqs, length(reqs), ticket))
+        catch
+          release!(ctx)
+          rethrow()
         end
-        foreach((b, r) -> put!(b.done, r.status), group, reqs)
+        finish = () -> begin
+          try
+            GC.@preserve group reqs chk(ccall((:nbp_clique_wait, libnbp), Int32, (Ptr{Cvoid},), ticket[]))
+            foreach((b, r) -> put!(b.done, r.status), group, reqs)
+          catch err
+            foreach(b -> put!(b.done, err), group)     # (a hard error of the device: every clique of the batch sees it)
+          finally
+            release!(ctx)
+          end
+        end
+        Threads.nthreads() > 1 ? errormonitor(Threads.@spawn finish()) : finish()
       catch
         # one request of the batch is at fault (unsupported input, slot overflow): the others must not fail with it -- each
         # request again on its own, so that only the offending clique task sees the error (monitorCSMs takes it from there).

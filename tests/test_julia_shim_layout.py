@@ -164,7 +164,7 @@ def _ok(ctype, jtype):
         return jtype in ("Ptr{Ptr{%s}}" % _jl_scalar(base), "Ptr{Ptr{Cvoid}}", "Ref{Ptr{Cvoid}}")
     if ctype.endswith("*"):
         base = ctype[:-1]
-        if base in ("void", "nbp_ctx", "nbp_program", "nbp_comm", "nbp_graph", "nbp_tree"):  # opaque handles
+        if base in ("void", "nbp_ctx", "nbp_program", "nbp_comm", "nbp_graph", "nbp_tree", "nbp_clique_ticket", "nbp_read_token"):  # opaque handles
             return jtype in ("Ptr{Cvoid}",)
         if base == "char":
             return jtype in ("Cstring", "Ptr{UInt8}", "Ptr{Cchar}")
