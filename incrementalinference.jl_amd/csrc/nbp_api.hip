@@ -110,6 +110,9 @@ struct nbp_ctx {
   // three-launch form spreads over the chip).
   bool fused_on = true;
   int fused_min = 1 << 30;
+  // smallest launch of simple Euclidean proposals that runs one WAVE per proposal (launch_proposals); -1: the default of the
+  // class (NBP_PROPOSAL_WAVE_MIN overrides it for every class)
+  int prop_wave_min = -1;
   int fused_p1_min = 2048;  // rounds with at least this many updates run one lane per particle (NBP_FUSED_P1_MIN); smaller
                             // ones two helper rows per update, so that they fill the chip with twice the lanes each
   // two-stream rounds (NBP_PIPELINE_MIN = smallest product batch; see plan_pipeline): the second stream, the fork / join
@@ -252,6 +255,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   c->spec_depth3 = !(getenv("NBP_SPEC_DEPTH3") && atoi(getenv("NBP_SPEC_DEPTH3")) == 0);
   c->fused_on = getenv("NBP_NO_FUSED_UPDATE") == nullptr;
   if (getenv("NBP_FUSED_MIN")) c->fused_min = atoi(getenv("NBP_FUSED_MIN"));
+  if (getenv("NBP_PROPOSAL_WAVE_MIN")) c->prop_wave_min = atoi(getenv("NBP_PROPOSAL_WAVE_MIN"));
   if (getenv("NBP_PIPELINE_MIN")) c->pipe_min = atoi(getenv("NBP_PIPELINE_MIN"));
   HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->pipe_ev[i], hipEventDisableTiming));
@@ -756,6 +760,7 @@ static nbp_status toc(nbp_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>>
 // 0, or the class of a batch whose relative factors are all full (non-partial) factors of one kind on one manifold, with
 // everything else in it (priors, message priors, pass-through densities) on that manifold as well:
 // 1 LinearRelative / Euclid(2), 3 LinearRelative / Euclid(3)
+#define NBP_CLS_SIMPLE 256
 static int proposals_uniform_class(const nbp_proposal_desc *d, int n) {
   if (n <= 0) return 0;
   const int M = d[0].manifold;
@@ -763,23 +768,38 @@ static int proposals_uniform_class(const nbp_proposal_desc *d, int n) {
   const int cls = M == NBP_EUCLID2 ? 1 : (M == NBP_EUCLID3 ? 3 : (M == NBP_CIRCULAR ? 4 : (M == NBP_SE2 ? 5 : 0)));
   const int want = M == NBP_CIRCULAR ? NBP_F_CIRCULAR : (M == NBP_SE2 ? NBP_F_SE2 : NBP_F_LINREL);
   if (!cls) return 0;
-  bool any = false;
+  // "simple" (bit 8, NBP_CLS_SIMPLE): every particle of every proposal on the factor's one hypothesis -- no multihypo, no
+  // nullhypo, no injected hypothesis indices, binary relatives: what the one-wave-per-proposal kernels are written for
+  bool simple = true;
   for (int i = 0; i < n; i++) {
     if (d[i].manifold != M) return 0;
     const int k = d[i].factor_kind;
     if (d[i].partial_mask) return 0;  // partial priors and partial relatives run the generic kernel
+    if (d[i].has_multihypo || d[i].nullhypo != 0.0 || d[i].mhidx_in >= 0) simple = false;
     if (k == NBP_F_PRIOR || k == NBP_F_MSGPRIOR || k == NBP_F_PASSTHROUGH) continue;
     if (k != want) return 0;
-    any = true;
+    if (d[i].nvars != 2) simple = false;
   }
-  (void)any;  // a batch of priors / message priors alone runs its manifold's instance as well
-  return cls;
+  // (a batch of priors / message priors alone runs its manifold's instance as well)
+  return cls | (simple ? NBP_CLS_SIMPLE : 0);
 }
 static nbp_status launch_proposals(nbp_ctx *c, const nbp_proposal_desc *dev, int n, int cls = 0) {
   if (n <= 0) return NBP_OK;
   nbp_status rc = tic(c, c->ev[0]);
   if (rc) return rc;
   (void)hipGetLastError();  // clear stale, unrelated errors
+  const bool simple = (cls & NBP_CLS_SIMPLE) != 0;
+  cls &= NBP_CLS_SIMPLE - 1;
+  // chip-filling launches of simple Euclidean batches: one wave per proposal, no workgroup barrier (nbp_kernels.h,
+  // proposal_wave_body); rows of up to five waves (N <= 320)
+  const int wave_min = c->prop_wave_min >= 0 ? c->prop_wave_min : (cls == 1 ? 900 : (c->N > 256 ? 1500 : (1 << 30)));
+  if (simple && n >= wave_min && (cls == 1 || cls == 3) && c->N <= (cls == 1 ? 256 : 320)) {
+    auto *wk = cls == 1 ? nbp_proposal_wave_kernel_lin2 : (c->N <= 256 ? nbp_proposal_wave_kernel_lin3 : nbp_proposal_wave_kernel_lin3n5);
+    hipLaunchKernelGGL(wk, dim3((n + NBP_PW_WAVES - 1) / NBP_PW_WAVES), dim3(64 * NBP_PW_WAVES), nbp_proposal_wave_lds_bytes(c->N, cls == 1 ? 2 : 3),
+                       c->stream, dev, n, c->arena, c->N, c->S, c->side, c->counters);
+    HIPCHK(hipGetLastError());
+    return toc(c, c->ev[0]);
+  }
   auto *kern = cls == 1 ? nbp_proposal_kernel_lin2 : (cls == 3 ? nbp_proposal_kernel_lin3 : (cls == 4 ? nbp_proposal_kernel_circ :
                (cls == 5 ? nbp_proposal_kernel_se2 : nbp_proposal_kernel)));
   hipLaunchKernelGGL(kern, dim3(n), dim3(c->Npad), nbp_proposal_lds_bytes(c->N), c->stream, dev, c->arena, c->N, c->Npad, c->S, c->side,
@@ -1035,13 +1055,18 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
     static const int nch_env = getenv("NBP_PRODUCT_NCH") ? atoi(getenv("NBP_PRODUCT_NCH")) : 0;
     static const size_t half = getenv("NBP_PRODUCT_NCH_KB") ? (size_t)atoi(getenv("NBP_PRODUCT_NCH_KB")) * 1024 : 80 * 1024;
     auto lds_for = [&](int k) { return nbp_product_lds_bytes(F, D, c->N, SPB, false, (size_t)k * 2 * TB, circ) + xsb; };
-    nch = 2;
-    const int cand[2] = {8, 4};
+    // (8 and 4 cost the same, 2 is ~5 % slower, 1 -- a range is its own chunk, pass 2 rescans all of it -- slower again; but ONE
+    //  workgroup per CU costs a launch of 257 .. 512 workgroups a second generation: a mixed launch of two- and three-density
+    //  products, sized by the three, took 736 us where two resident workgroups take ~600: profiles/r05_product_chunks_by_launch_size.txt)
+    nch = 0;
+    const int cand[4] = {8, 4, 2, 1};
     for (int k : cand)
       if (lds_for(k) <= half) { nch = k; break; }
-    if (nch == 2 && lds_for(2) > half)
+    if (!nch) {
+      nch = 2;
       for (int k : cand)
         if (lds_for(k) <= NBP_PRODUCT_LDS_CAP) { nch = k; break; }
+    }
     if (nch_env >= 1 && nch_env <= 15 && lds_for(nch_env) <= 160 * 1024) nch = nch_env;
   }
   size_t lds = nbp_product_lds_bytes(F, D, c->N, SPB, big, (size_t)nch * 2 * TB, circ) + xsb;
@@ -1443,6 +1468,11 @@ struct nbp_stage {
   int upd_F = 0, upd_cls = 0;
   std::vector<nbp_update_desc> upd;
   size_t upd_off = 0;
+  // a range of nbp_program_run that ends or starts BETWEEN the two stages of a fused pair runs them in the three-launch
+  // form (run_range): the fused_second stage keeps, as its entry fits, the proposals of the pair that carry a bandwidth
+  // (ent_s / ent_m) and, here, the outputs the fused launch fits itself
+  std::vector<int32_t> split_in_s, split_in_m, split_out_s, split_out_m;
+  size_t split_out_off = 0;
   // two-stream round (plan_pipeline): descriptors [0, pipe_split) are the first half; on the PRODUCTS stage pipe_ent splits
   // the entry fits the same way.  `pipe` on the PROPOSALS stage = the pair runs that way.
   bool pipe = false;
@@ -1631,7 +1661,7 @@ static bool fused_plan(const nbp_program *p, int s, std::vector<nbp_update_desc>
   if (!c->fused_on || !p->use_fused || s + 1 >= p->n_user_stages || c->Npad > 256) return false;
   const nbp_stage &A = p->stages[s], &B = p->stages[s + 1];
   if (A.kind != NBP_STAGE_PROPOSALS || B.kind != NBP_STAGE_PRODUCTS || B.n < c->fused_min || A.n < B.n) return false;
-  if (A.mani != 1) return false;  // proposals_uniform_class: 1 = LinearRelative on Euclid(2)
+  if ((A.mani & (NBP_CLS_SIMPLE - 1)) != 1) return false;  // proposals_uniform_class: 1 = LinearRelative on Euclid(2)
   const int M = NBP_EUCLID2;
   const nbp_proposal_desc *pd = (const nbp_proposal_desc *)(p->blob.data() + A.offset);
   const nbp_product_desc *qd = (const nbp_product_desc *)(p->blob.data() + B.offset);
@@ -1712,7 +1742,7 @@ static bool fused_plan(const nbp_program *p, int s, std::vector<nbp_update_desc>
     }
   }
   for (auto &w : watch) upd[w.second.first].flags |= 2 << w.second.second;
-  cls = A.mani;
+  cls = A.mani & (NBP_CLS_SIMPLE - 1);
   return true;
 }
 
@@ -1838,6 +1868,14 @@ nbp_status nbp_program_finalize(nbp_program *p) {
           }
           if (fit) upd[i].flags |= NBP_UPD_FIT_OUT;
         }
+        nx.split_out_s.clear(); nx.split_out_m.clear();
+        std::vector<int32_t> in_s, in_m;
+        for (int i = 0; i < st.n; i++)
+          if (!pd[i].skip_bandwidth && pd[i].factor_kind != NBP_F_PASSTHROUGH) { in_s.push_back(pd[i].out_slot); in_m.push_back(pd[i].manifold); }
+        for (int i = 0; i < nx.n; i++)
+          if (upd[i].flags & NBP_UPD_FIT_OUT) { nx.split_out_s.push_back(qd[i].out_slot); nx.split_out_m.push_back(qd[i].manifold); }
+        nx.split_in_s = in_s;
+        nx.split_in_m = in_m;
         st.fused = true;
         st.upd = std::move(upd);
         st.upd_F = Fm;
@@ -1849,7 +1887,9 @@ nbp_status nbp_program_finalize(nbp_program *p) {
       }
     }
     if (st.kind == NBP_STAGE_PRODUCTS && st.fused_second) {  // ran inside the launch of the stage in front
-      st.ent_s.clear(); st.ent_m.clear();
+      // (its entry list: the fits of a range that splits the pair -- never read when the pair runs as one launch)
+      st.ent_s = st.split_in_s;
+      st.ent_m = st.split_in_m;
       st.need_prep = false;
       // an output slot whose old points still had a fit queued cannot be: the launch in front flushed everything
       continue;
@@ -1957,6 +1997,16 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     st.ent_off = off;
   }
   for (nbp_stage &st : p->stages)
+    if (st.fused_second) {
+      size_t off = (p->blob.size() + 63) & ~(size_t)63;
+      p->blob.resize(off + (st.split_out_s.size() + st.split_out_m.size()) * 4 + 4);
+      if (!st.split_out_s.empty()) {
+        memcpy(p->blob.data() + off, st.split_out_s.data(), st.split_out_s.size() * 4);
+        memcpy(p->blob.data() + off + st.split_out_s.size() * 4, st.split_out_m.data(), st.split_out_m.size() * 4);
+      }
+      st.split_out_off = off;
+    }
+  for (nbp_stage &st : p->stages)
     if (st.fused) {
       size_t off = (p->blob.size() + 63) & ~(size_t)63;
       p->blob.resize(off + st.upd.size() * sizeof(nbp_update_desc));
@@ -2034,7 +2084,11 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
     nbp_status rc = NBP_OK;
     if (st.flush_before) rc = launch_bandwidth(c, ent_s(st), ent_s(st) + nent, nent, coords_of(st.ent_m.data(), st.ent_m.size()));
     if (rc) return rc;
-    if (st.kind == NBP_STAGE_PROPOSALS && st.fused) {
+    if (st.kind == NBP_STAGE_PROPOSALS && st.fused && s + 1 >= last) {
+      // the range ends between the two stages of a fused pair: the proposals alone, to their arena slots; their fits are the
+      // entry list of the stage behind, which the end of the range runs (below)
+      rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
+    } else if (st.kind == NBP_STAGE_PROPOSALS && st.fused) {
       const nbp_stage &nx = p->stages[s + 1];
       rc = launch_update(c, st, (const nbp_update_desc *)(p->dev + st.upd_off), (const nbp_proposal_desc *)(p->dev + st.offset),
                          (const nbp_product_desc *)(p->dev + nx.offset), nx.n);
@@ -2082,8 +2136,16 @@ static nbp_status run_range(nbp_program *p, int first, int last) {
       rc = launch_proposals(c, (const nbp_proposal_desc *)(p->dev + st.offset), st.n, st.mani);
     } else if (st.kind == NBP_STAGE_PRODUCTS) {
       const nbp_product_desc *dd = (const nbp_product_desc *)(p->dev + st.offset);
-      if (st.need_prep) rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd, coords_of(st.ent_m.data(), st.ent_m.size()), st.mani);
+      // (fused_second: only a range that starts between the two stages of a fused pair gets here -- three-launch form, the
+      //  proposals' fits beside the KD builds, the outputs the fused launch would have fitted behind the products)
+      if (st.need_prep || st.fused_second)
+        rc = launch_prep(c, ent_s(st), ent_s(st) + nent, nent, dd, st.n, st.maxfd, coords_of(st.ent_m.data(), st.ent_m.size()), st.mani);
       if (!rc) rc = launch_products(c, dd, st.n, st.maxfd, st.mani);
+      if (!rc && st.fused_second && !st.split_out_s.empty()) {
+        const int32_t *os = (const int32_t *)(p->dev + st.split_out_off);
+        const int no = (int)st.split_out_s.size();
+        rc = launch_bandwidth(c, os, os + no, no, coords_of(st.split_out_m.data(), st.split_out_m.size()));
+      }
     } else if (st.kind == NBP_STAGE_DECONV) {
       rc = launch_deconv(c, (const nbp_proposal_desc *)(p->dev + st.offset), nullptr, st.n);
     } else if (st.kind == NBP_STAGE_COPY_POINTS) {
@@ -2107,9 +2169,8 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   const int nuser = p->n_user_stages;
   if (last < 0 || last > nuser) last = nuser;
   if (first < 0) first = 0;
-  if (first < last && (p->stages[first].fused_second || p->stages[last - 1].fused))
-    return fail(NBP_ERR_ARG, "program_run: the range splits a fused variable update (a PROPOSALS stage and the PRODUCTS stage behind it); "
-                             "cut the range around the pair or set NBP_OPT_FUSED_UPDATES to 0");
+  // (a range that splits a fused variable update -- a PROPOSALS stage and the PRODUCTS stage behind it -- runs that pair in
+  //  the three-launch form: run_range)
   // Replay: the launch sequence of a range is captured into a hipGraph the second time it runs and launched as one
   // graph from then on (the descriptors live in device memory, so nbp_program_reseed still takes effect).  Per-kernel
   // event timing (nbp_timing_enable) and programs of a handful of launches take the plain path.

@@ -20,6 +20,7 @@
 #define NBP_TU_FUSED 64     // the fused variable-update kernels
 #define NBP_TU_PRODUNI4 128 // product kernels, one manifold per instance, four helper lanes (the two-lane ones: NBP_TU_PRODUNI)
 #define NBP_TU_PREPW5 256   // bandwidth fits + KD builds at five waves per SIMD (rows of 4k + 1 waves: N = 257 .. 320)
+#define NBP_TU_PROPWAVE 512 // proposal kernels, one wave per proposal (chip-filling launches of simple Euclidean batches)
 #ifndef NBP_TU
 #define NBP_TU 0xFFFF
 #endif
@@ -429,6 +430,232 @@ NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_circ, NBP_F_CIRCULAR, NBP_CIRCULAR, 3)
 #define NBP_W_SE2 2  // (3: 168 VGPRs and 80 B of scratch per lane; measured, profiles/r04_lcv_five_wave_rows.txt section 5)
 #endif
 NBP_PROPOSAL_UNIFORM(nbp_proposal_kernel_se2, NBP_F_SE2, NBP_SE2, NBP_W_SE2)
+
+// ================================================================================================
+// One WAVE per proposal: the geometry of chip-filling launches of "simple" Euclidean batches (thousands of LinearRelative
+// proposals of one tree level of a long chain, no multihypo, no nullhypo, full factors; priors, message priors and
+// pass-through densities ride along).  A workgroup of the kernels above takes, per inflation cycle, as long as the slowest
+// search of its slowest wave, and its other waves wait at the barrier behind the spread statistics (SQ_WAIT_ANY = 0.5 of the
+// wave-cycles, an instruction issuing in 0.6-0.7 of the SIMD-time: profiles/r04_proposal_wave_occupancy.txt).  Here lane l of
+// the one wave owns the particles l, l + 64, l + 128, ... and runs their searches one after the other; the spread statistics
+// are wave reductions over the chunks of 64 in the order block_sum() adds the wave partials (same sums, bit for bit); there is
+// no barrier, so a wave is always ready to issue, and with >= ~4000 proposals in a launch every SIMD holds four or five.
+// LDS: the scratch copy X[D][N] of the target belief only (each lane reads and writes the entries of its own particles:
+// storage that can be indexed by the chunk loop, no exchange between lanes).  The measurements of a lane's NC particles stay
+// in registers and are rotated by one place per chunk, so that the chunk loop is not unrolled (one copy of the search).
+// Particle for particle the same operations as proposal_body<NBP_F_LINREL, FIXM>.
+// ================================================================================================
+template <int NC>
+__device__ __forceinline__ double wave_chunks_sum(const double (&v)[NC]) {
+  double t = wave_sum(v[0]);
+#pragma unroll
+  for (int p = 1; p < NC; p++) t += wave_sum(v[p]);
+  return t;
+}
+
+template <int FIXM, int NC>
+__device__ __forceinline__ void proposal_wave_body(const nbp_proposal_desc *d, double *out, double *arena, int N, int64_t S, int32_t *side,
+                                                   nbp_counters *ctr, double *X) {
+  constexpr int M = FIXM, D = FIXM;  // Euclid(D)
+  const int lane = threadIdx.x & 63, kind = d->factor_kind;
+  unsigned int n_solves = 0, n_nonconv = 0, n_nan = 0, n_evals = 0;
+  {
+    const double *src = arena + S * d->var_slot[(kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR || kind == NBP_F_PASSTHROUGH) ? 0 : d->sfidx];
+    const int ct = slot_count(src, N);
+#pragma unroll
+    for (int p = 0; p < NC; p++) {
+      const int n = lane + 64 * p;
+      if (n < N)
+        for (int k = 0; k < D; k++) X[k * N + n] = (n < ct) ? src[k * N + n] : 0.0;
+    }
+  }
+  if (d->mhidx_out >= 0) {
+#pragma unroll
+    for (int p = 0; p < NC; p++)
+      if (lane + 64 * p < N) side[d->mhidx_out + lane + 64 * p] = 1;  // every particle on the factor's one hypothesis
+  }
+  if (kind == NBP_F_PASSTHROUGH) {  // (proposal_body, same branch)
+    const double *den = arena + S * d->var_slot[1];
+    const int cd = slot_count(den, N), pm = d->partial_mask ? d->partial_mask : 7;
+#pragma unroll 1
+    for (int p = 0; p < NC; p++) {
+      const int n = lane + 64 * p;
+      if (n >= N) continue;
+      int idx = n;
+      if (!d->keep_count && cd < N) {
+        double ua, ub;
+        uniform_pair(d->seed, n, PURP_KDESEL, 0, ua, ub);
+        idx = (int)(ua * cd);
+        if (idx >= cd) idx = cd - 1;
+      }
+      double nz0 = 0, nz1 = 0, nz2 = 0, nz3 = 0;
+      if (d->keep_count == 2 && cd < N && n >= cd) {
+        double ua, ub;
+        uniform_pair(d->seed, n, PURP_OLDSEL, 0, ua, ub);
+        idx = (int)(ua * cd);
+        if (idx >= cd) idx = cd - 1;
+        normal_pair(d->seed, n, PURP_OLDNOISE, 0, nz0, nz1);
+        if (D > 2) normal_pair(d->seed, n, PURP_OLDNOISE, 1, nz2, nz3);
+      }
+      if (idx < cd)
+        for (int k = 0; k < D; k++)
+          if ((pm >> k) & 1) {
+            const double nzk = k == 0 ? nz0 : (k == 1 ? nz1 : nz2);
+            X[k * N + n] = den[k * N + idx] + den[3 * N + k] * nzk;
+          }
+      for (int k = 0; k < 3; k++) out[k * N + n] = (k < D) ? X[k * N + n] : 0.0;
+    }
+    if (lane < 3) {
+      const bool in = lane < D && ((pm >> lane) & 1);
+      out[3 * N + lane] = in ? den[3 * N + lane] : 0.0;
+      out[3 * N + 3 + lane] = in ? 1.0 : 0.0;
+    }
+    if (lane == 0) out[3 * N + 6] = (d->keep_count == 1 && cd < N) ? (double)cd : 0.0;
+    return;
+  }
+  if (kind == NBP_F_PRIOR || kind == NBP_F_MSGPRIOR) {
+    // evalPotentialSpecific(prior) with every particle on the hypothesis (no nullhypo in this class: the spread is not needed)
+#pragma unroll 1
+    for (int p = 0; p < NC; p++) {
+      const int n = lane + 64 * p;
+      if (n >= N) continue;
+      double x[3] = {0, 0, 0};
+      if (kind == NBP_F_PRIOR) {
+        sample_measurement(d, n, D, x, arena, S, N);
+      } else {
+        const double *msg = arena + S * d->var_slot[1];
+        const int cm = slot_count(msg, N);
+        const uint64_t mseed = d->meas_seed ? d->meas_seed : d->seed;
+        double ua, ub, n0, n1, n2 = 0, n3 = 0;
+        uniform_pair(mseed, n, PURP_KDESEL, 0, ua, ub);
+        int i = (int)(ua * cm);
+        if (i >= cm) i = cm - 1;
+        normal_pair(mseed, n, PURP_KDENOISE, 0, n0, n1);
+        if (D > 2) normal_pair(mseed, n, PURP_KDENOISE, 1, n2, n3);
+        x[0] = msg[i] + msg[3 * N] * n0;
+        if (D > 1) x[1] = msg[N + i] + msg[3 * N + 1] * n1;
+        if (D > 2) x[2] = msg[2 * N + i] + msg[3 * N + 2] * n2;
+      }
+      for (int k = 0; k < D; k++) X[k * N + n] = x[k];
+    }
+  } else {
+    // evalPotentialSpecific(relative): LinearRelative between two variables, one hypothesis group holding every particle
+    // (build_recipe without multihypo: act = {1, 2}, both certain)
+    const int sf1 = d->sfidx + 1, solve_b = (sf1 == 2), vother = solve_b ? 1 : 2;
+    const double *O = arena + S * d->var_slot[vother - 1];
+    const int co = slot_count(O, N);
+    double z[NC][D];
+#pragma unroll
+    for (int p = 0; p < NC; p++) {
+      double zz[3] = {0, 0, 0};
+      if (lane + 64 * p < N) sample_measurement(d, lane + 64 * p, D, zz, arena, S, N);  // sampleFactor!, once per approxConv
+#pragma unroll
+      for (int k = 0; k < D; k++) z[p][k] = zz[k];
+    }
+    const double rN = (double)N;
+    for (int c = 0; c < d->inflate_cycles; c++) {
+      // calcStdBasicSpread of the scratch copy (std_basic_spread / block_sum, chunk by chunk)
+      double acc[NC];
+#pragma unroll
+      for (int p = 0; p < NC; p++) acc[p] = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        double v[NC];
+#pragma unroll
+        for (int p = 0; p < NC; p++) v[p] = (lane + 64 * p < N) ? X[k * N + lane + 64 * p] : 0.0;
+        const double mu = wave_chunks_sum<NC>(v) / rN;
+#pragma unroll
+        for (int p = 0; p < NC; p++)
+          if (lane + 64 * p < N) {
+            const double dl = v[p] - mu;
+            acc[p] += dl * dl;
+          }
+      }
+      const double sg = sqrt(wave_chunks_sum<NC>(acc) / (double)(N - 1));
+      const double spread = d->inflation * ((1e-10 < sg) ? sg : 1.0);
+#pragma unroll 1
+      for (int p = 0; p < NC; p++) {
+        const int n = lane + 64 * p;
+        if (n < N) {
+          const int io = anyn_index(n, co, d->seed, vother);  // _getindex_anyn
+          double oth[3] = {O[io], 0, 0};
+          if (D > 1) oth[1] = O[N + io];
+          if (D > 2) oth[2] = O[2 * N + io];
+          double x[3] = {X[n], 0, 0};
+          if (D > 1) x[1] = X[N + n];
+          if (D > 2) x[2] = X[2 * N + n];
+          double zz[3] = {z[0][0], 0, 0};
+          if (D > 1) zz[1] = z[0][1];
+          if (D > 2) zz[2] = z[0][D - 1];
+          add_entropy(M, D, x, n, spread, d->seed, (1 * 8 + c) * 2, 0);
+          solve_particle_t<NBP_F_LINREL, D>(M, zz, oth, solve_b, x, n_solves, n_nonconv, n_nan, n_evals);
+          X[n] = x[0];
+          if (D > 1) X[N + n] = x[1];
+          if (D > 2) X[2 * N + n] = x[2];
+        }
+        // the next chunk's measurement moves to the front (NC rotations bring every one back to its place)
+        double z0[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) z0[k] = z[0][k];
+#pragma unroll
+        for (int q = 0; q + 1 < NC; q++)
+#pragma unroll
+          for (int k = 0; k < D; k++) z[q][k] = z[q + 1][k];
+#pragma unroll
+        for (int k = 0; k < D; k++) z[NC - 1][k] = z0[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NC; p++) {
+    const int n = lane + 64 * p;
+    if (n < N)
+      for (int k = 0; k < D; k++) out[k * N + n] = X[k * N + n];
+  }
+  if (lane < 3) out[3 * N + 3 + lane] = (lane < D) ? 1.0 : 0.0;  // infoPerCoord (no partial factors in this class)
+  if (lane == 0) out[3 * N + 6] = 0.0;
+  {
+    unsigned int v[4] = {n_solves, n_nonconv, n_nan, n_evals};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      unsigned int t = v[q];
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      v[q] = t;
+    }
+    if (lane == 0 && (v[0] | v[3])) {
+      atomicAdd(&ctr->solves, (unsigned long long)v[0]);
+      atomicAdd(&ctr->nonconverged, (unsigned long long)v[1]);
+      atomicAdd(&ctr->nan_results, (unsigned long long)v[2]);
+      atomicAdd(&ctr->residual_evals, (unsigned long long)v[3]);
+    }
+  }
+}
+
+#define NBP_PROPOSAL_WAVE_ARGS const nbp_proposal_desc *descs, int n, double *arena, int N, int64_t S, int32_t *side, nbp_counters *ctr
+#if NBP_TU & NBP_TU_PROPWAVE
+// workgroups of NBP_PW_WAVES independent waves (no barrier between them), one proposal each
+#define NBP_PROPOSAL_WAVE(NAME, M_, NC_, WAVES)                                                                            \
+  __global__ void __launch_bounds__(64 * NBP_PW_WAVES) __attribute__((amdgpu_waves_per_eu(WAVES)))                         \
+  NAME(NBP_PROPOSAL_WAVE_ARGS) {                                                                                           \
+    extern __shared__ double smem[];                                                                                       \
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = blockIdx.x * NBP_PW_WAVES + w;                                                     \
+    if (i >= n) return;                                                                                                    \
+    proposal_wave_body<M_, NC_>(descs + i, arena + S * descs[i].out_slot, arena, N, S, side, ctr, smem + (size_t)w * M_ * N); \
+  }
+#else
+#define NBP_PROPOSAL_WAVE(NAME, M_, NC_, WAVES) __global__ void NAME(NBP_PROPOSAL_WAVE_ARGS);
+#endif
+#define NBP_PW_WAVES 4
+#ifndef NBP_WW_LIN2
+#define NBP_WW_LIN2 5  // 94 VGPRs
+#endif
+#ifndef NBP_WW_LIN3
+#define NBP_WW_LIN3 3  // 133 / 140 VGPRs
+#endif
+NBP_PROPOSAL_WAVE(nbp_proposal_wave_kernel_lin2, NBP_EUCLID2, 4, NBP_WW_LIN2)
+NBP_PROPOSAL_WAVE(nbp_proposal_wave_kernel_lin3, NBP_EUCLID3, 4, NBP_WW_LIN3)
+NBP_PROPOSAL_WAVE(nbp_proposal_wave_kernel_lin3n5, NBP_EUCLID3, 5, NBP_WW_LIN3)
+static inline size_t nbp_proposal_wave_lds_bytes(int N, int D) { return (size_t)NBP_PW_WAVES * D * N * 8; }
 
 // ================================================================================================
 // Deconvolution kernel: one workgroup = one approxDeconv(dfg, fct) (DeconvUtils.jl:32-160), one lane
@@ -935,7 +1162,8 @@ __host__ __device__ inline size_t product_lds_layout(int F, int D, int N, int SP
     L->ind = (int *)(base + ints0);
     L->ns = NS;
   }
-  return ints0 * 8 + (size_t)F * SPB * 4 * 2;  // ind[F][SPB] | nxt[F][SPB]
+  return ints0 * 8 + (size_t)F * SPB * 4;  // ind[F][SPB]  (a second row, the labels of the next level, went with the round-4 sampler:
+                                          //  3 KB at three densities -- what kept two chunks per range and two workgroups per CU apart)
 }
 
 // PARTIAL: some input density is partial (AMP.marginal(propBel, pardims), ApproxConv.jl:287-291): a

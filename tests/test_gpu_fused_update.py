@@ -146,20 +146,37 @@ def test_later_readers_of_a_proposal_slot_see_it(hip_backend, fused_min):
         assert np.abs(p).max() > 0
 
 
-def test_a_range_that_splits_a_fused_pair_is_refused(hip_backend, fused_min):
+def test_a_range_that_splits_a_fused_pair_runs_it_in_three_launches(hip_backend, fused_min):
+    """nbp_program_run(first, last) with a range that ends or starts between the two stages of a fused pair (legal when the
+    program was finalized; round 4 refused it with NBP_ERR_ARG): the pair runs in the three-launch form -- the proposals
+    to their arena slots with their fits at the end of the range, then KD builds, products and the fits of the results.
+    The same particles and bandwidths as a program with fused updates off, run in the same two halves."""
     fused_min(64)
-    props, prods, stride = _round(200, 2)
-    be = hip_backend(N, 4 + stride * 200, 0)
-    prog = be.program([(abi.STAGE_PROPOSALS, props), (abi.STAGE_PRODUCTS, prods)])
-    assert prog.num_fused() == 1
-    with pytest.raises(RuntimeError, match="splits a fused"):
+    nops, F = 200, 2
+    props, prods, stride = _round(nops, F)
+    rng = np.random.default_rng(5)
+    pts = [rand_points(rng, MAN, N, c, 0.4) for c in (0.0, 2.0, 1.0)]
+    res = []
+    for fused in (True, False):
+        be = hip_backend(N, 4 + stride * nops, 0)
+        for s, p_ in enumerate(pts):
+            be.slot_write(s, MAN, p_)
+        prog = be.program([(abi.STAGE_PROPOSALS, props), (abi.STAGE_PRODUCTS, prods)], fused_updates=fused)
+        assert prog.num_fused() == (1 if fused else 0)
         prog.run(0, 1)
-    with pytest.raises(RuntimeError, match="splits a fused"):
+        be.synchronize()
+        mid = [be.belief_read(4 + stride * i + j, MAN) for i in (0, 77, nops - 1) for j in range(F)]  # the proposals, fitted
         prog.run(1, 2)
-    prog.run(0, 2)
-    be.synchronize()
-    prog.close()
-    be.close()
+        be.synchronize()
+        out = [be.belief_read(4 + stride * i + F, MAN) for i in (0, 77, nops - 1)]
+        prog.close()
+        be.close()
+        res.append((mid, out))
+    for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert_points_close(MAN, a[0], b[0], rtol=1e-12, what="split fused pair vs three-launch program")
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-9)  # bandwidths
+        np.testing.assert_allclose(a[2], b[2])             # infoPerCoord
+        assert np.all(a[1] > 0)
 
 
 def test_whole_solve_with_fused_rounds(hip_backend, fused_min):

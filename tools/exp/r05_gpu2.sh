@@ -1,16 +1,30 @@
-# round 5: Optim's arithmetic in the Euclid(3) searches -- what it buys in the stage-wise comparison and what it costs
+# wave-per-proposal geometry against the workgroup geometry; product launches by size and chunks per range
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-for lib in "" tools/libnbp_nm0.so; do
-  echo "=== library: ${lib:-default (NBP_NM_OPTIM_E3=1)}"
-  NBP_LIB_OVERRIDE=$lib timeout 1500 python -m pytest tests/test_gpu_stagewise_parity.py -m gpu -x -q -s -k "config5 or config3_full or config4_full" --durations=8 2>&1 | grep -E "every stage|passed|failed|Error|assert|s call" | cut -c1-600
-  for c in 5 3; do
-  NBP_LIB_OVERRIDE=$lib python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-10k > gpurun_out/nm_$c.json 2> gpurun_out/nm_$c.err
-  python - <<PY
-import json
-d=json.load(open("gpurun_out/nm_$c.json"))
-k=d["roofline"]["kernel_ms_per_step"]
-print("config $c: %.2f ms/step  proposal %.2f prep %.2f product %.2f  graph_init %.3f s" % (d["ms_per_step"],k["nbp_proposal_kernel"],k["nbp_prep_kernel"],k["nbp_product_kernel"],d["host_setup"]["graph_init_s"]))
-PY
+O=gpurun_out/r05b; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_wave_proposal_kernels.py tests/test_gpu_uniform_proposal_kernels.py -m gpu -x -q -s 2>&1 | tail -15 > $O/pytest.txt
+cat $O/pytest.txt
+{
+for spec in "lin2 200" "lin3 200" "lin3 300"; do set -- $spec
+  for B in 975 2000 4000 9750; do
+    NBP_PROPOSAL_WAVE_MIN=100000000 python tools/exp/prop_batch.py $B $2 $1 | sed 's/^/workgroup /'
+    NBP_PROPOSAL_WAVE_MIN=1 python tools/exp/prop_batch.py $B $2 $1 | sed 's/^/wave      /'
   done
 done
+} > $O/prop_wave.txt 2>&1
+cat $O/prop_wave.txt
+{
+for n in 245 332 488 738 975; do
+  python tools/exp/prod_batch.py $n 2 | sed 's/^/nch default  /'
+  for k in 2 4 8; do NBP_PRODUCT_NCH=$k python tools/exp/prod_batch.py $n 2 | sed "s/^/nch $k        /"; done
+done
+for n in 372 488; do
+  python tools/exp/prod_batch.py $n 3 | sed 's/^/nch default  /'
+  for k in 2 4 8; do NBP_PRODUCT_NCH=$k python tools/exp/prod_batch.py $n 3 | sed "s/^/nch $k        /"; done
+done
+} > $O/prod_nch.txt 2>&1
+cat $O/prod_nch.txt
+for w in 100000000 3000 1500; do
+  NBP_PROPOSAL_WAVE_MIN=$w python bench.py --config 2p --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wave_min $w', j['ms_per_step'], j['roofline']['kernel_ms_per_step'], j['posterior_max_mean_err'])"
+done > $O/bench10k.txt 2>&1
+cat $O/bench10k.txt
