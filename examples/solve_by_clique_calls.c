@@ -445,17 +445,21 @@ int main(int argc, char **argv) {
   if (failed) return 4;
   for (int t = 1; t < threads; t++) nbp_ctx_destroy(W[t].ctx);
   /* ---- compare -------------------------------------------------------------------------------------------------- */
+  /* (the walk's launches and the program's differ in size and so, from some size on, in geometry -- helper lanes per sample, rows of
+   *  a fit, one wave per proposal: summation-order rounding, nbp_host.h -- and a Gibbs chain turns one flipped label into other
+   *  draws of the same posterior: what is not the same bytes is reported as the distance between the posterior means) */
   int same = 0;
-  double worst = 0;
+  double worst = 0, worst_dm = 0;
   for (int v = 0; v < nvars; v++) {
     same += memcmp(post[v].pts, whole[v].pts, sizeof(double) * N * D) == 0 && memcmp(post[v].bw, whole[v].bw, sizeof(post[v].bw)) == 0;
-    double mx = 0;
-    for (int n = 0; n < N; n++) mx += post[v].pts[2 * n];
+    double mx = 0, mw = 0;
+    for (int n = 0; n < N; n++) { mx += post[v].pts[2 * n]; mw += whole[v].pts[2 * n]; }
     if (fabs(mx / N - v) > worst) worst = fabs(mx / N - v);
+    if (fabs(mx - mw) / N > worst_dm) worst_dm = fabs(mx - mw) / N;
   }
-  printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program; "
+  printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program (means of the others within %.3f); "
          "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %s%d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
-         post[0].ipc[0], post[0].ipc[1], worst, queued ? "one QUEUED batch per tree level (resident beliefs, submit / wait), " : (batched ? "one batched call per tree level, " : ""), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
+         worst_dm, post[0].ipc[0], post[0].ipc[1], worst, queued ? "one QUEUED batch per tree level (resident beliefs, submit / wait), " : (batched ? "one batched call per tree level, " : ""), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "

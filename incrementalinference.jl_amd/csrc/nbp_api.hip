@@ -266,6 +266,9 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_x16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_y32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_l8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_x16_w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_y32_w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_l8_w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_m4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)nbp_product_kernel_t2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   for (const void *k : {(const void *)nbp_product_kernel_t2_e1, (const void *)nbp_product_kernel_t2_e2, (const void *)nbp_product_kernel_t2_e3,
@@ -979,10 +982,11 @@ static const size_t NBP_PRODUCT_LDS_CAP = 150 * 1024;
 typedef void (*nbp_product_fn)(const nbp_product_desc *, double *, const double *, int, double *, int, int64_t, int32_t *, nbp_levels);
 // the kernel of a product launch: HL helper lanes per sample; `mani` != 0: every multi-density product of the batch lives
 // on that manifold and has only full inputs (the throughput variants then run the single-instantiation kernels)
-static nbp_product_fn product_kernel_for(int HL, int mani, bool xs = false) {
-  if (HL == 32) return nbp_product_kernel_y32;
-  if (HL == 16) return nbp_product_kernel_x16;
-  if (HL == 8) return nbp_product_kernel_l8;
+// `w1`: the launch has at most one workgroup (of at most four waves) per CU -- the latency instances that own their SIMDs
+static nbp_product_fn product_kernel_for(int HL, int mani, bool xs = false, bool w1 = false) {
+  if (HL == 32) return w1 ? nbp_product_kernel_y32_w1 : nbp_product_kernel_y32;
+  if (HL == 16) return w1 ? nbp_product_kernel_x16_w1 : nbp_product_kernel_x16;
+  if (HL == 8) return w1 ? nbp_product_kernel_l8_w1 : nbp_product_kernel_l8;
   if (xs) {
     switch (mani * 8 + HL) {
     case NBP_EUCLID1 * 8 + 4: return nbp_product_kernel_m4_e1_xs;
@@ -1093,7 +1097,9 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   rc = tic(c, c->ev[2]);
   if (rc) return rc;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(product_kernel_for(HL, mani, xs), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, flagsF, gs, c->N, c->S, c->side, c->T);
+  static const int w1_max = getenv("NBP_PRODUCT_W1_MAX") ? atoi(getenv("NBP_PRODUCT_W1_MAX")) : 256;  // workgroups (= CUs of the chip)
+  const bool w1 = HL >= 8 && TB <= 256 && (long)n * G <= w1_max && !c->geom_n;
+  hipLaunchKernelGGL(product_kernel_for(HL, mani, xs, w1), dim3(n, G), dim3(TB), lds, c->stream, dev, c->arena, c->ws, flagsF, gs, c->N, c->S, c->side, c->T);
   HIPCHK(hipGetLastError());
   return toc(c, c->ev[2]);
 }

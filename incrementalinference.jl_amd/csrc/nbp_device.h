@@ -627,12 +627,17 @@ struct objective_t {
       // z - (x - other) when x is the second variable, z - (other - x) = z + (x - other) when it is the first: the same
       // values as normsq() either way (a negation is exact), without a wave-uniform branch on solve_b in front of every
       // evaluation -- a lone wave (the slowest search of a workgroup) pays a taken branch with its instruction fetch
+      // (the squares summed with one rounding per operation: the oracle's sum, and the same sum in every kernel the search is
+      //  inlined into -- a contraction the compiler chooses per instance made the one-wave-per-proposal kernels differ from the
+      //  workgroup kernels in one coordinate of a few hundred at 3e-12)
       const double sg = solve_b ? -1.0 : 1.0;
       double acc = 0;
 #pragma unroll
       for (int d = 0; d < DN; d++) {
+#pragma clang fp contract(off)
         const double r = fma(sg, x[d] - other[d], z[d]);
-        acc += r * r;
+        const double rr = r * r;
+        acc = acc + rr;
       }
       return acc;
     }
@@ -736,7 +741,10 @@ __device__ __forceinline__ bool nm_converged(const double (&f)[DN + 1]) {
   a *= rm;
   double v = 0;
 #pragma unroll
-  for (int i = 0; i <= DN; i++) v += (f[i] - a) * (f[i] - a);
+  for (int i = 0; i <= DN; i++) {  // (the multiply-add spelled out: the same in every instance)
+    const double df = f[i] - a;
+    v = fma(df, df, v);
+  }
   return v <= 1e-16 * (DN + 1);
 }
 
@@ -750,7 +758,7 @@ __device__ __forceinline__ double nm_lin(double a, double c, double b) {
     const double p = c * b;
     return a + p;
   } else
-    return a + c * b;
+    return fma(c, b, a);  // (spelled out: the same in every instance; exact in two dimensions, where c is a power of two)
 }
 
 template <class OBJ, int DN, bool OPT = false>

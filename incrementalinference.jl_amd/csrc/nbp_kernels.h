@@ -103,7 +103,16 @@ __device__ __forceinline__ void add_entropy(int manifold, int D, double *x, int 
   if (mask == 0) mask = 7;
   // (selects, not conditional stores: the compiler merges those into stores through a selected address, and the caller's
   //  point then lives in scratch)
-  const double v0 = x[0] + spread * (u0 - 0.5), v1 = x[1] + spread * (u1 - 0.5), v2 = x[2] + spread * (u2 - 0.5);
+  // (one rounding per operation, as the oracle and Julia evaluate it -- and the same in every kernel this is inlined into:
+  //  left to the compiler, a multiply-add is contracted in one instance of the proposal kernels and not in another)
+  double v0, v1, v2;
+  {
+#pragma clang fp contract(off)
+    const double p0 = spread * (u0 - 0.5), p1 = spread * (u1 - 0.5), p2 = spread * (u2 - 0.5);
+    v0 = x[0] + p0;
+    v1 = x[1] + p1;
+    v2 = x[2] + p2;
+  }
   x[0] = (mask & 1) ? (is_circ(manifold, 0) ? wrap_pi(v0) : v0) : x[0];
   x[1] = (D > 1 && (mask & 2)) ? v1 : x[1];
   x[2] = (D > 2 && (mask & 4)) ? (is_circ(manifold, 2) ? wrap_pi(v2) : v2) : x[2];
@@ -1338,7 +1347,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     // hand them over through LDS; the lanes of a sample are lanes of one wave, whose LDS operations stay in order.
     // (the latency geometries -- 8 to 32 helpers per sample, a CU to themselves, five manifolds' instances in one kernel at
     //  252 registers -- make the block where it is used, once for each of its two uniforms: the hand-over cost them scratch)
-    constexpr bool UUL = HL <= 4;
+#ifndef NBP_X_UUL_LAT
+#define NBP_X_UUL_LAT 1
+#endif
+    constexpr bool UUL = HL <= 4 || NBP_X_UUL_LAT;
     if (UUL && ps > 0 && live)
       for (int j0 = 0; j0 < F; j0 += HL) {
         const int j = j0 + h;
@@ -1825,26 +1837,29 @@ __device__ __forceinline__ void product_kernel_uniform(const nbp_product_desc *d
 // throughput variants (one workgroup per product, per-manifold instances); none of them uses scratch
 // (profiles/r03_kernel_resources.txt).
 #define NBP_PRODUCT_ARGS const nbp_product_desc *descs, double *arena, const double *ws, int kdF, double *gstats, int N, int64_t S, int32_t *side, nbp_levels T
+// Latency geometries (8 / 16 / 32 helper lanes per sample, workgroups of at most four waves).  Each in two instances: the
+// plain one (launch bound 512: two waves per SIMD, 256 registers, 16 B of scratch per lane since the uniforms of a pass are made
+// once per sample and handed over through LDS) and `_w1` for launches with at most one workgroup per CU (launch bound 256: one
+// wave per SIMD may hold 512 registers, the compiler parks four values in accumulation registers: no scratch).  A lone product of
+// 2 / 5 / 8 densities: 82.8 / 196.8 / 325.3 -> 78.4 / 178.6 / 289.4 us; 66 products (462 workgroups, the plain instance) 168.9 ->
+// 162.4 us -- at one wave per SIMD they take 234 us (profiles/r05_latency_product_uniforms.txt)
 #if NBP_TU & NBP_TU_PRODLAT
-__global__ void __launch_bounds__(512) nbp_product_kernel_x16(NBP_PRODUCT_ARGS) {
-  extern __shared__ double smem[];
-  product_kernel_body<16>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
-}
-__global__ void __launch_bounds__(512) nbp_product_kernel_l8(NBP_PRODUCT_ARGS) {
-  extern __shared__ double smem[];
-  product_kernel_body<8>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
-}
+#define NBP_PRODUCT_LATENCY(NAME, HL_, BOUNDS)                                                \
+  __global__ void __launch_bounds__(BOUNDS) NAME(NBP_PRODUCT_ARGS) {                          \
+    extern __shared__ double smem[];                                                          \
+    product_kernel_body<HL_>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);             \
+  }
+#else
+#define NBP_PRODUCT_LATENCY(NAME, HL_, BOUNDS) __global__ void NAME(NBP_PRODUCT_ARGS);
+#endif
+NBP_PRODUCT_LATENCY(nbp_product_kernel_x16, 16, 512)
+NBP_PRODUCT_LATENCY(nbp_product_kernel_l8, 8, 512)
 // fewer than 16 products alone on the chip: 32 helper lanes per sample halve the node range of every lane once more
 // (a lone F = 2 product: 87 -> 77 us; 64 lanes per sample gain nothing more and cost twelve F = 3 products 209 instead of 109 us)
-__global__ void __launch_bounds__(512) nbp_product_kernel_y32(NBP_PRODUCT_ARGS) {
-  extern __shared__ double smem[];
-  product_kernel_body<32>(descs, arena, ws, kdF, gstats, N, S, side, T, smem);
-}
-#else
-__global__ void nbp_product_kernel_y32(NBP_PRODUCT_ARGS);
-__global__ void nbp_product_kernel_x16(NBP_PRODUCT_ARGS);
-__global__ void nbp_product_kernel_l8(NBP_PRODUCT_ARGS);
-#endif
+NBP_PRODUCT_LATENCY(nbp_product_kernel_y32, 32, 512)
+NBP_PRODUCT_LATENCY(nbp_product_kernel_x16_w1, 16, 256)
+NBP_PRODUCT_LATENCY(nbp_product_kernel_l8_w1, 8, 256)
+NBP_PRODUCT_LATENCY(nbp_product_kernel_y32_w1, 32, 256)
 #if NBP_TU & NBP_TU_PRODTHR
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) nbp_product_kernel_m4(NBP_PRODUCT_ARGS) {
   extern __shared__ double smem[];

@@ -18,7 +18,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "incrementalinference.jl_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
 HEADERS = [os.path.join(CSRC, h) for h in ("nbp_kernels.h", "nbp_device.h", "nbp_lcv_table.h", "nbp_fused.h")] + \
           [os.path.join(ROOT, "include", h) for h in ("nbp.h", "nbp_host.h")]
 
