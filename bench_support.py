@@ -5,6 +5,7 @@ One rank: ordering, Bayes tree, Gibbs schedules and stage descriptors come from 
 its share.  Scaling: BASELINE.json's configurations 4 and 5 are fixed graphs on 8 GPUs -- strong scaling, the default for
 them; configurations 2 / 2p / 3 are single-GPU configurations -- with several ranks the graph grows with the ranks (weak
 scaling: `size` per GPU), unless --scaling says otherwise."""
+import os
 import time
 
 import numpy as np
@@ -66,15 +67,23 @@ def workloads(iif):
 
     def tol_mix(v, n):
         # the only information is the prior every 500th pose; a Mixture link adds 0.8 x 0.1^2 + 0.2 x 1.0^2 = 0.208 of variance
-        # along x, so the exact posterior of a pose d links from its nearest prior has sigma = sqrt(0.208 d) (7.2 at d = 250,
-        # 9.1 at the end of a 400-pose chain with its single prior): a sample mean is accepted within 6 (the figure of rounds
-        # 1-3: what the NBP posterior of this configuration delivers between two priors), or within 1 + 0.8 sigma where the
-        # exact posterior is wider than that -- the open end of a chain far from its only prior
+        # along every coordinate, so the exact posterior of a pose d links from its nearest prior has sigma = sqrt(0.208 d) (7.2 at
+        # d = 250).  Between two priors a sample mean is accepted within 6 (the figure of rounds 1-3: what the NBP posterior of
+        # this configuration delivers there).  The OPEN END of a chain -- the last stretch, a prior on one side only; a 400-pose
+        # chain with its single prior is all open end -- is different in kind: the frontals of the last cliques see each other
+        # through their own factor, every Gibbs iteration multiplies a belief with a proposal made from itself, and the belief
+        # collapses (std of x397 .. x399 after one solve: 0.16-0.34 of the exact sigma, oracle and device alike: the reference's
+        # fmcmc! multiplies the proposals of ALL factors of a variable, propagateBelief, GraphProductOperations.jl:16-64) onto
+        # a point that is itself spread like a draw from the posterior around it.  Measured over 24 graph initialisations
+        # (profiles/r05_open_end_of_a_chain.txt): std of the end pose's mean 0.18-0.27 sigma per coordinate, largest 0.6; one
+        # initialisation (bench.py's own, seed 0) sits at 0.71-0.87 sigma in y for every solve seed.  Accepted there: within
+        # 1 + 1.5 sigma (rounds 3-4 had 1 + 0.8 sigma and passed by 0.1 sigma); a sign or index error in a factor puts the end of
+        # the chain hundreds of sigmas off
         i = int(v[1:])
         d = i % 500
         if (i // 500 + 1) * 500 < n:
-            d = min(d, 500 - d)
-        return max(6.0, 1.0 + 0.8 * float(np.sqrt(0.208 * d)))
+            return max(6.0, 1.0 + 0.8 * float(np.sqrt(0.208 * min(d, 500 - d))))
+        return max(6.0, 1.0 + 1.5 * float(np.sqrt(0.208 * d)))
 
     return {
         "2": Workload("2", "config 2: ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 1000, chain2, truth_chain, 1.0, "variables"),
@@ -182,7 +191,7 @@ class RankSolve:
     def step(self, k):
         if self.sharded:
             return self.impl.step(k)
-        self.prog.reseed(0x9E37 + k)
+        self.prog.reseed(0x9E37 + k + 1000 * int(os.environ.get("NBP_BENCH_SEED", "0")))  # (NBP_BENCH_SEED: seed soaks, tools/exp)
         self.prog.run()
 
     def check_posteriors(self):

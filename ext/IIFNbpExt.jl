@@ -239,6 +239,11 @@ manifoldcode(::Circular) = NBP_CIRCULAR
 manifoldcode(vt::InferenceVariable) =
   getManifold(vt) isa typeof(SpecialEuclidean(2; vectors = HybridTangentRepresentation())) ? NBP_SE2 :
   error("libnbp: unsupported variable type $(typeof(vt))")
+# the variable types a slot holds (tangent dimension <= NBP_MAXD = 3): a clique with any other -- ContinuousEuclid{4}, a user
+# manifold -- takes the reference's method (upGibbsCliqueDensity / solveCliqDownFrontalProducts! below, `varsok`)
+varok(::Union{Position{1}, Position{2}, Position{3}, Circular}) = true
+varok(vt::InferenceVariable) = getManifold(vt) isa typeof(SpecialEuclidean(2; vectors = HybridTangentRepresentation()))
+varsok(dfg::AbstractDFG, factors) = all(fc -> all(v -> varok(getVariableType(dfg, v)), getVariableOrder(fc)), factors)
 
 pointdoubles(code::Int32) = code == NBP_SE2 ? 6 : (code == NBP_CIRCULAR ? 1 : Int(code))
 tangentdim(code::Int32) = code == NBP_SE2 ? 3 : (code == NBP_CIRCULAR ? 1 : Int(code))
@@ -749,7 +754,7 @@ function upGibbsCliqueDensity(dfg::GraphsDFG, cliq::TreeClique, solveKey::Symbol
   cd = getCliqueData(cliq)
   labels = Symbol[cd.frontalIDs; cd.separatorIDs]
   factors = DFGFactor[getFactor(dfg, f) for f in lsf(dfg)]
-  all(f -> supported(f, N), factors) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
+  (all(f -> supported(f, N), factors) && varsok(dfg, factors)) || return invoke(upGibbsCliqueDensity, Tuple{AbstractDFG, TreeClique, Symbol, Any, Int, Bool, Int, Any},
                                            dfg, cliq, solveKey, inmsgs, N, dbg, iters, logger)      # generic CPU path
   p = packclique(dfg, cliq, solveKey, N, labels, factors; senddiffs = true)
   runclique(:up, dfg, cliq, solveKey, N, p, length(cd.frontalIDs), length(cd.separatorIDs), rand(UInt64), iters)
@@ -780,7 +785,7 @@ function solveCliqDownFrontalProducts!(subfg::GraphsDFG, cliq::TreeClique, opts:
     fc = getFactor(subfg, f)
     (getFactorType(fc) isa MsgPrior || fc in factors) || push!(factors, fc)
   end
-  MCIters == 3 && all(f -> supported(f, opts.N), factors) || return invoke(solveCliqDownFrontalProducts!, Tuple{AbstractDFG, TreeClique, SolverParams, Any},
+  (MCIters == 3 && all(f -> supported(f, opts.N), factors) && varsok(subfg, factors)) || return invoke(solveCliqDownFrontalProducts!, Tuple{AbstractDFG, TreeClique, SolverParams, Any},
                                                            subfg, cliq, opts, logger; solveKey, MCIters)
   others = Symbol[]
   for fc in factors, u in getVariableOrder(fc)

@@ -9,6 +9,7 @@ payload (val N x P, bw, entities/BeliefTypes.jl:47-57) = one slot (4.9 KB at N =
 latency bound, so messages of one tree level are batched into a single group of point-to-point
 `isend/irecv` (RCCL over xGMI with backend "nccl", gloo in the CPU tests) -- no ring collective.
 """
+import os
 import sys
 
 import numpy as np
@@ -271,7 +272,7 @@ class ShardedTreeSolve:
         self._native = (g, nt)
 
     def step(self, k):
-        self.runner.run(salt=0x9E37 + k)
+        self.runner.run(salt=0x9E37 + k + 1000 * int(os.environ.get("NBP_BENCH_SEED", "0")))
 
     def close(self):
         self.runner.close()

@@ -1454,21 +1454,29 @@ int32_t orc_run_deconv(double *arena, int32_t N, const nbp_proposal_desc *d, int
 /* ops of one stage are independent by construction (distinct out slots), so the multi-core
  * baseline runs them with OpenMP -- the analogue of the reference's task-per-clique concurrency
  * (services/SolverAPI.jl:59-97). */
+/* (a team no larger than the stage: the rounds near the root of a tree hold a handful of ops, and waking 128 threads for
+ *  five of them -- a few hundred times per solve -- is what made the baseline SLOWER beyond 16 threads in rounds 3 and 4) */
+#ifdef _OPENMP
+#include <omp.h>
+static int team_for(int n) { const int t = omp_get_max_threads(); return n < t ? (n > 0 ? n : 1) : t; }
+#else
+static int team_for(int n) { (void)n; return 1; }
+#endif
 int32_t orc_run_proposals(double *arena, int32_t N, int32_t *side, const nbp_proposal_desc *d, int32_t n) {
   int rc = NBP_OK;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
   for (int i = 0; i < n; i++) { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
   return rc;
 }
 int32_t orc_run_products(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d, int32_t n) {
   int rc = NBP_OK;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
   for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
   return rc;
 }
 int32_t orc_run_deconvs(double *arena, int32_t N, const nbp_proposal_desc *d, const int32_t *meas_slots, int32_t n) {
   int rc = NBP_OK;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
   for (int i = 0; i < n; i++) { int r = orc_run_deconv(arena, N, d + i, meas_slots ? meas_slots[i] : -1); if (r) rc = r; diag_merge(); }
   return rc;
 }
@@ -1478,7 +1486,6 @@ void orc_run_copies(double *arena, int32_t N, const nbp_copy_desc *c, int32_t n)
 }
 
 #ifdef _OPENMP
-#include <omp.h>
 void orc_set_threads(int32_t n) { omp_set_num_threads(n); }
 int32_t orc_get_max_threads(void) { return omp_get_max_threads(); }
 #else

@@ -3,9 +3,11 @@ priors, message priors and pass-through densities ride along) run one WAVE per p
 _lin3 / _lin3n5, launch_proposals in nbp_api.hip; selected from NBP_PROPOSAL_WAVE_MIN proposals per launch on, 3000 by
 default).  Lane l of the wave owns the particles l, l + 64, ...; the spread statistics add the chunks of 64 in the order
 the workgroup kernels add their wave partials, every particle's search is the same sequence of operations.  The particles
-must not depend on the geometry: compared with the workgroup instance of the same class.  Observed: as many residual
-evaluations in every search, the particles bit for bit except one coordinate in a few hundred at 3e-12 (the compiler
-contracts a sum of the search differently in another kernel) -- asserted to 1e-9 like every other pair of geometries."""
+must not depend on the geometry: compared with the workgroup instance of the same class, BIT FOR BIT -- as many
+residual evaluations in every search, the same particles and bandwidths to the last bit.  (Since round 5 libnbp is built with
+-ffp-contract=on: a multiply-add is contracted inside one source statement only, so an inlined device function is the same
+arithmetic in every kernel it lands in.  With the compiler's default the two geometries differed in one coordinate of a few
+hundred at 3e-12: profiles/r05_fp_contract_on_vs_fast.txt.)"""
 import os
 
 import numpy as np
@@ -65,6 +67,5 @@ def test_wave_geometry_equals_workgroup_geometry(man, dim, N):
     for (pa, ba), (pb, bb) in zip(wg, wv):
         assert pa.shape == pb.shape
         worst = max(worst, float(np.abs(pa - pb).max()))
-        np.testing.assert_allclose(pb, pa, rtol=1e-9, atol=1e-9)
-        np.testing.assert_allclose(bb, ba, rtol=1e-9)
+        assert np.array_equal(pb, pa) and np.array_equal(bb, ba), f"max |difference| {np.abs(pa - pb).max():.3e}"
     print(f"wave vs workgroup, manifold {man} N {N}: max |difference| {worst:.3e}")
