@@ -101,6 +101,7 @@ struct NbpDiag
   nan_results::Int64
   residual_evals::Int64
   lcv_evals::Int64
+  lcv_evals_f32::Int64
 end
 
 # nbp_solver_params (include/nbp_host.h): the SolverParams fields the path reads (entities/SolverParams.jl:12-75)

@@ -183,7 +183,11 @@ typedef struct nbp_diag {
   int64_t nonconverged;  /* NumericalCalculations.jl:128-131                   */
   int64_t nan_results;   /* NumericalCalculations.jl:348-351                   */
   int64_t residual_evals;
-  int64_t lcv_evals;     /* leave-one-out likelihood evaluations (each = N(N-1)/2 kernel pairs) */
+  int64_t lcv_evals;     /* leave-one-out likelihood evaluations in double precision (each = N(N-1)/2 kernel pairs) */
+  int64_t lcv_evals_f32; /* bracketing evaluations of the bandwidth searches in single precision (each = N(N-1) ordered
+                            pairs): they decide comparisons whose two sides are further apart than their error bounds;
+                            the bandwidth selected is that of the all-double search, bit for bit (NBP_FIT_F64=1 in the
+                            environment of nbp_ctx_create: every evaluation in double precision)                        */
 } nbp_diag;
 
 typedef struct nbp_ctx nbp_ctx;

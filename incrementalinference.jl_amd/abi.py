@@ -81,6 +81,7 @@ class Diag(C.Structure):
         ("nan_results", C.c_int64),
         ("residual_evals", C.c_int64),
         ("lcv_evals", C.c_int64),
+        ("lcv_evals_f32", C.c_int64),
     ]
 
 

@@ -249,6 +249,11 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
   HIPCHK(hipMemset(c->side, 0, (size_t)c->side_ints * 4));
   HIPCHK(hipMalloc(&c->counters, sizeof(nbp_counters)));
   HIPCHK(hipMemset(c->counters, 0, sizeof(nbp_counters)));
+  {  // NBP_FIT_F64=1: the bandwidth searches evaluate in double precision only (no single-precision bracketing, neg_loo_ll_f32)
+    const char *e = getenv("NBP_FIT_F64");
+    const unsigned long long fl = (e && *e && *e != '0') ? 1ull : 0ull;
+    HIPCHK(hipMemcpy(&c->counters->flags, &fl, sizeof(fl), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&c->spec, sizeof(nbp_spec_area) * 3 * NBP_SPEC_MAXJOBS));
   c->spec_on = getenv("NBP_NO_SPECULATIVE_FITS") == nullptr;
@@ -2487,7 +2492,8 @@ nbp_status nbp_diag_read(nbp_ctx *c, nbp_diag *out, int32_t reset) {
   out->nan_results = (int64_t)h.nan_results;
   out->residual_evals = (int64_t)h.residual_evals;
   out->lcv_evals = (int64_t)h.lcv_evals;
-  if (reset) HIPCHK(hipMemset(c->counters, 0, sizeof(h)));
+  out->lcv_evals_f32 = (int64_t)h.lcv_evals_f32;
+  if (reset) HIPCHK(hipMemset(c->counters, 0, offsetof(nbp_counters, flags)));  // (the flags are the context's, not counters)
   return NBP_OK;
 }
 

@@ -58,6 +58,8 @@ struct nbp_levels {
 
 struct nbp_counters {
   unsigned long long solves, nonconverged, nan_results, residual_evals, lcv_evals;
+  unsigned long long lcv_evals_f32;  // single-precision bracketing evaluations of the bandwidth searches (neg_loo_ll_f32)
+  unsigned long long flags;          // set by the host at context creation, never reset: bit 0 = every evaluation in double precision
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1610,6 +1612,168 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
   return -tsum / (double)N;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same likelihood in SINGLE precision, for the evaluations of the search that only BRACKET the minimum.  A golden-section
+// search uses a likelihood value for one thing: the comparison f2 < f1.  While the two values are far apart -- the first nine
+// or ten of the sixteen evaluations of a typical fit -- the comparison can be decided on values that carry an error bound far
+// below their distance; the search below (lcv_bandwidth_1d) takes a single-precision value only when |f1 - f2| exceeds the
+// sum of the two bounds, re-evaluates in double precision what it cannot decide, and from then on evaluates in double
+// precision only.  Every comparison has the outcome the all-double search has, so the selected bandwidth is bit-identical.
+//   exp(-d^2 / (2 h^2)) = 2^(-(d c)^2), c = sqrt(log2(e) / 2) / h: the points are centred, scaled by c and rounded to single
+// precision ONCE per evaluation (LDS), a pair then costs v_sub, v_mul, v_exp_f32, v_add -- no table, no polynomial, no
+// partner atomic: every lane sums over ALL partners of its own point (ordered pairs; the transcendental unit does the work
+// the twelve double-precision operations of lcv_exp4 do), the partners arriving four at a time as broadcast ds_read_b128.
+// The term of a point with itself is masked out (only in the sixteen groups of four that hold the points of the lane's own
+// wave; the other groups run without the select).
+// Error of the returned value against the double-precision one (u = 2^-24, X = the largest scaled coordinate, q = the
+// exponent -log2 of a term): |df| <= max_i |d log s_i| <= the largest relative error of a term that matters plus that of the sum.
+//   scaled points rounded to single precision: |dx| <= u X; the difference: |dd| <= 2 u X + u |d|;
+//   q = d^2 rounded: |dq| <= 4 u sqrt(q) X + 3 u q; v_exp_f32: 1 ulp = 2 u  => a term: ln2 (4 u sqrt(q) X + 3 u q) + 2 u
+//   terms that matter: s_i >= 2^-40 (below: invalid) and N <= 2^8 per 2^-24 of weight => q <= 72: u (23.5 X + 152)
+//   the sums: <= N / 4 + 2 additions of positive terms per lane, u each; v_log_f32: 1 ulp of |log2| <= 46: 64 u; slack 34 u
+//   => bound E = u (24 X + 314 + N / 4)   (lcv_f32_bound; the differences measured are ~1e-3 of it: rounding errors do not
+//      line up over N^2 terms)
+// Returns NaN when some point's sum is below 2^-40 (an isolated point: its nearest neighbour decides the sum and the bound
+// above does not cover it) -- the caller then evaluates in double precision.
+// LDS: the scaled points live in the first row of the partner accumulators (all zero between evaluations, restored here).
+// ------------------------------------------------------------------------------------------------
+#ifndef NBP_LCV_F32
+#define NBP_LCV_F32 1
+#endif
+template <bool CIRC>
+__device__ __forceinline__ void loo_f32_quad(const float4 y, float xi, float T, float &e0, float &e1, float &e2, float &e3) {
+  float d0 = xi - y.x, d1 = xi - y.y, d2 = xi - y.z, d3 = xi - y.w;
+  if (CIRC) {  // geodesic distance on the circle, scaled: min(|d|, ||d| - 2 pi c|)
+    d0 = fminf(fabsf(d0), fabsf(fabsf(d0) - T));
+    d1 = fminf(fabsf(d1), fabsf(fabsf(d1) - T));
+    d2 = fminf(fabsf(d2), fabsf(fabsf(d2) - T));
+    d3 = fminf(fabsf(d3), fabsf(fabsf(d3) - T));
+  }
+  e0 = __builtin_amdgcn_exp2f(-d0 * d0);
+  e1 = __builtin_amdgcn_exp2f(-d1 * d1);
+  e2 = __builtin_amdgcn_exp2f(-d2 * d2);
+  e3 = __builtin_amdgcn_exp2f(-d3 * d3);
+}
+template <bool CIRC, bool MASK>
+__device__ __forceinline__ void loo_f32_groups(const float4 *x4, int ga, int gb, float xi, int i, float T, float &s0, float &s1, float &s2,
+                                               float &s3) {
+#pragma unroll 2
+  for (int g = ga; g < gb; g++) {
+    float e0, e1, e2, e3;
+    loo_f32_quad<CIRC>(x4[g], xi, T, e0, e1, e2, e3);
+    if (MASK) {
+      const int j = 4 * g;
+      e0 = (j == i) ? 0.f : e0;
+      e1 = (j + 1 == i) ? 0.f : e1;
+      e2 = (j + 2 == i) ? 0.f : e2;
+      e3 = (j + 3 == i) ? 0.f : e3;
+    }
+    s0 += e0;
+    s1 += e1;
+    s2 += e2;
+    s3 += e3;
+  }
+}
+// a last wave of at most 32 points, re-dealt as A2 points x HH = 64 / A2 sub-helpers (A2 = the point count rounded up to a
+// power of two): sub-helper hh of a point takes the hh-th part of the row's groups -- the wave leaves its SIMD after 1 / HH of
+// the steps (N = 200: 8 points x 8 sub-helpers; the workgroup's four waves cost 3.1 wave-loops instead of 4) -- and the
+// parts are added up by a butterfly over the lanes of the point.  `pad` = the index of a group of padding partners.
+template <bool CIRC>
+__device__ __forceinline__ float loo_f32_redealt(const float4 *x4, int ga, int gb, int pad, float xi, int pi, int hh, int lgH, float T) {
+  const int len = gb - ga, a = ga + ((hh * len) >> lgH), b = ga + (((hh + 1) * len) >> lgH);
+  const int steps = __builtin_amdgcn_readfirstlane((len + (1 << lgH) - 1) >> lgH);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int t = 0; t < steps; t++) {
+    const int g = (a + t < b) ? a + t : pad;
+    float e0, e1, e2, e3;
+    loo_f32_quad<CIRC>(x4[g], xi, T, e0, e1, e2, e3);
+    const int j = 4 * g;
+    s0 += (j == pi) ? 0.f : e0;
+    s1 += (j + 1 == pi) ? 0.f : e1;
+    s2 += (j + 2 == pi) ? 0.f : e2;
+    s3 += (j + 3 == pi) ? 0.f : e3;
+  }
+  float sf = (s0 + s1) + (s2 + s3);
+  for (int o = 64 >> lgH; o < 64; o <<= 1) sf += __shfl_xor(sf, o, 64);
+  return sf;
+}
+// |f_single - f_double| <= this (see above; u = 2^-24): u (24 X + 250 + N / 4) for the sums + 64 u for log2 in single precision
+__device__ __forceinline__ double lcv_f32_bound(double xmax, double h, int N) {
+  return 5.9604644775390625e-8 * (24.0 * (xmax * (0.84932180028801907 / h)) + 314.0 + 0.25 * (double)N);
+}
+__device__ __forceinline__ double neg_loo_ll_f32(const double *x, int N, int Npad, bool circ, double h, double lognorm0, double cen,
+                                                 double *part, double *red) {
+  const int tid = threadIdx.x;
+  const int P = ((int)blockDim.x == Npad) ? 1 : (int)blockDim.x / Npad;
+  const int p = (P == 1) ? 0 : tid / Npad, i = (P == 1) ? tid : tid - p * Npad;
+  const double inv_h = 1.0 / h, scl = inv_h * 0.84932180028801907;  // sqrt(log2(e) / 2) / h
+  double *acc = part + P * Npad;
+  float *xf = (float *)(acc + (((uintptr_t)acc >> 3) & 1));  // 16-byte aligned (an offset, not a cast: the pointer stays an LDS pointer)
+  const int G4 = (N + 3) >> 2;
+  // (the padding of the last group and one group of nothing but padding: partners at a distance whose weight underflows to zero)
+  for (int j = tid; j < 4 * G4 + 4; j += blockDim.x) xf[j] = (j < N) ? (float)((x[j] - cen) * scl) : 3.0e18f;
+  __syncthreads();
+  const float T = (float)(NBP_TWO_PI * scl);
+  // row p of the workgroup takes the p-th share of the groups; the groups that hold the points of this lane's own wave are
+  // the ones that need the self term masked (all bounds wave-uniform: scalar loops)
+  const int ga = __builtin_amdgcn_readfirstlane((p * G4) / P), gb = __builtin_amdgcn_readfirstlane(((p + 1) * G4) / P);
+  const int lastbase = (N - 1) & ~63, A = N - lastbase;
+  int lg2 = 0;
+  while ((1 << lg2) < A) lg2++;
+  const bool redeal = __builtin_amdgcn_readfirstlane((int)(i >= lastbase && lg2 <= 5)) != 0;
+  const float4 *x4 = (const float4 *)xf;
+  float sf;
+  if (redeal) {
+    const int l = tid & 63, pi = lastbase + (l & ((1 << lg2) - 1)), hh = l >> lg2;
+    const float xi = (pi < N) ? xf[pi] : 0.f;
+    sf = circ ? loo_f32_redealt<true>(x4, ga, gb, G4, xi, pi, hh, 6 - lg2, T) : loo_f32_redealt<false>(x4, ga, gb, G4, xi, pi, hh, 6 - lg2, T);
+  } else {
+    const float xi = (i < N) ? xf[i] : 0.f;
+    const int o0 = __builtin_amdgcn_readfirstlane((i & ~63) >> 2);
+    const int m0 = max(ga, min(gb, o0)), m1 = max(ga, min(gb, o0 + 16));
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (circ) {
+      loo_f32_groups<true, false>(x4, ga, m0, xi, i, T, s0, s1, s2, s3);
+      loo_f32_groups<true, true>(x4, m0, m1, xi, i, T, s0, s1, s2, s3);
+      loo_f32_groups<true, false>(x4, m1, gb, xi, i, T, s0, s1, s2, s3);
+    } else {
+      loo_f32_groups<false, false>(x4, ga, m0, xi, i, T, s0, s1, s2, s3);
+      loo_f32_groups<false, true>(x4, m0, m1, xi, i, T, s0, s1, s2, s3);
+      loo_f32_groups<false, false>(x4, m1, gb, xi, i, T, s0, s1, s2, s3);
+    }
+    sf = (s0 + s1) + (s2 + s3);
+  }
+  if (P > 1 && i < N) part[p * Npad + i] = (double)sf;  // (`part` is all zero between evaluations)
+  __syncthreads();
+  for (int j = tid; j < 2 * G4 + 4; j += blockDim.x) acc[j] = 0.0;  // the accumulator row as the double-precision evaluation expects it
+  // f = -(ln2 / N) sum_i log2(s_i) + log(h) + lognorm0: the logarithm of a point's sum in single precision (v_log_f32),
+  // log(h) in double precision by ONE wave (the last of row 0: the re-dealt one when there is one)
+  double term = 0;
+  if (p == 0 && i < N) {
+    float s = sf;
+    if (P > 1) {
+      double sd = 0;
+      for (int q = 0; q < P; q++) {
+        sd += part[q * Npad + i];
+        part[q * Npad + i] = 0.0;
+      }
+      s = (float)sd;
+    }
+    // 2^-40: below it the sum of an isolated point; NaN marks the evaluation invalid (and swallows a NaN / Inf coordinate)
+    term = (s >= 9.094947017729282e-13f) ? (double)__builtin_amdgcn_logf(s) : __builtin_nan("");
+  }
+  term = wave_sum(term);
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < Npad) red[threadIdx.x >> 6] = term;
+  if (__builtin_amdgcn_readfirstlane((int)(p == 0 && (i >> 6) == (lastbase >> 6)))) {
+    const double lh = lcv_log(h);
+    if ((tid & 63) == 0) red[32] = lh;
+  }
+  __syncthreads();
+  double tsum = red[0];
+  for (int q = 1; q < (Npad >> 6); q++) tsum += red[q];
+  return fma(-0.69314718055994531 / (double)N, tsum, red[32] + lognorm0);
+}
+
 __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int Npad, bool circ, double *part, double *red,
                                                    const double *tab, nbp_counters *ctr) {
   const int i = threadIdx.x;
@@ -1641,26 +1805,48 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   double x0 = ax, x3 = cx, x1, x2;
   if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = fma(C, cx - bx, bx); }
   else { x2 = bx; x1 = fma(-C, bx - ax, bx); }
-  // one call site for the evaluation (its six pair loops are inlined once per kernel, not once per call): the two
-  // initial values, then one new point per iteration
-  double f1 = 0.0, f2 = 0.0, pt = x1;
-  unsigned int nev = 2;
-  int stage = 0;
+  // one call site for each evaluation (the six pair loops of the double-precision one are inlined once per kernel, not once
+  // per call): the two initial values, then one new point per iteration.
+  // Bracketing in single precision (neg_loo_ll_f32): e1 / e2 = the error bounds of f1 / f2 (0: a double-precision value).  A
+  // comparison the bounds do not decide re-evaluates its single-precision sides in double precision -- `todo` 3 / 4 -- and ends
+  // the single-precision phase; every decision is then the all-double search's, and so is every position and the result.
+  const double cen = circ ? 0.0 : 0.5 * (lo + hi), xmax = circ ? NBP_TWO_PI : 0.5 * (hi - lo);
+  bool m32 = NBP_LCV_F32 && !(ctr && (ctr->flags & 1));
+  double f1 = 0.0, f2 = 0.0, e1 = 0.0, e2 = 0.0, pt = x1;
+  unsigned int nev = 0, nev32 = 0;
+  int todo = 0;  // 0 / 1: the initial values at x1 / x2; 2: the new point of an iteration; 3 / 4: f1 / f2 again, in double precision
   bool c = false;
   while (true) {
-    const double v = neg_loo_ll(x, N, Npad, circ, pt * scs, ln0, part, red, tab);
-    if (stage == 0) { f1 = v; stage = 1; pt = x2; continue; }
-    if (stage == 1) { f2 = v; stage = 2; }
-    else if (c) f2 = v;
-    else f1 = v;
+    double v, ev = 0.0;
+    if (m32 && todo <= 2) {
+      v = neg_loo_ll_f32(x, N, Npad, circ, pt * scs, ln0, cen, part, red);
+      nev32++;
+      if (!(fabs(v) < INFINITY)) { m32 = false; continue; }  // invalid (an isolated point, NaN): the same point in double precision
+      ev = lcv_f32_bound(xmax, pt * scs, N);
+    } else {
+      v = neg_loo_ll(x, N, Npad, circ, pt * scs, ln0, part, red, tab);
+      nev++;
+    }
+    if (todo == 0) { f1 = v; e1 = ev; todo = 1; pt = x2; continue; }
+    if (todo == 1 || (todo == 2 && c) || todo == 4) { f2 = v; e2 = ev; }
+    else { f1 = v; e1 = ev; }
+    if ((e1 > 0 || e2 > 0) && !(fabs(f1 - f2) > e1 + e2)) {  // undecided: the single-precision sides again
+      m32 = false;
+      if (e1 > 0) { todo = 3; pt = x1; }
+      else { todo = 4; pt = x2; }
+      continue;
+    }
     if (!(fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2)))) break;
-    nev++;
     c = f2 < f1;
     // positions by explicit fma (see golden_step)
-    if (c) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; pt = x2; }
-    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; pt = x1; }
+    if (c) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; e1 = e2; pt = x2; }
+    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; e2 = e1; pt = x1; }
+    todo = 2;
   }
-  if (ctr && threadIdx.x == 0) atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
+  if (ctr && threadIdx.x == 0) {
+    atomicAdd(&ctr->lcv_evals, (unsigned long long)nev);
+    if (nev32) atomicAdd(&ctr->lcv_evals_f32, (unsigned long long)nev32);
+  }
   return (f1 < f2 ? x1 : x2) * scs;
 }
 

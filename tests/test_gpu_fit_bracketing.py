@@ -1,0 +1,110 @@
+"""-m gpu: the bracketing evaluations of the bandwidth searches in single precision (neg_loo_ll_f32, nbp_device.h).  A
+golden-section search uses a likelihood value only in the comparison f2 < f1; the search takes a single-precision value
+where the two sides are further apart than the sum of their error bounds and re-evaluates in double precision what it
+cannot decide -- so the selected bandwidth is the all-double search's (NBP_FIT_F64=1), bit for bit, on every manifold, for
+clouds with separated modes, isolated points, offsets far from the origin, duplicates, and for beliefs that hold fewer
+points than the slot."""
+import os
+
+import numpy as np
+import pytest
+
+from parity_utils import abi, iif
+
+pytestmark = pytest.mark.gpu
+
+
+def clouds(rng, manifold, N, kind):
+    D = abi.MANIFOLD_DIM[manifold]
+    eucl = manifold not in (abi.CIRCULAR, abi.SE2)
+    if kind == "gauss":
+        c = rng.normal(size=(N, D)) * rng.uniform(0.05, 3.0)
+    elif kind == "modes":
+        c = rng.normal(size=(N, D)) * 0.05 + np.array([-2.5, -0.7, 0.3, 2.1])[np.arange(N) % 4][:, None]
+    elif kind == "outliers":
+        c = rng.normal(size=(N, D)) * 0.5 + (40.0 if eucl else 0.0)
+        c[0] += 30.0 if eucl else 2.0
+        c[1] -= 55.0 if eucl else 1.5
+    elif kind == "offset":
+        c = rng.normal(size=(N, D)) * 0.01
+        c[:2] += 1000.0 if eucl else 3.0
+    elif kind == "duplicates":
+        c = np.repeat(rng.normal(size=(max(N // 4, 2), D)), 4, axis=0)[:N]
+        c = np.concatenate([c, rng.normal(size=(N - c.shape[0], D))]) if c.shape[0] < N else c
+    else:  # "heavy": Cauchy tails
+        c = rng.standard_cauchy(size=(N, D)) * (1.0 if eucl else 0.2)
+    if manifold == abi.SE2:
+        th = c[:, 2]
+        return np.stack([c[:, 0], c[:, 1], np.cos(th), np.sin(th), -np.sin(th), np.cos(th)], axis=1)
+    if manifold == abi.CIRCULAR:
+        return (c + np.pi) % (2 * np.pi) - np.pi
+    return c
+
+
+def fit(N, manifold, beliefs, f64, copies=1):
+    old = {k: os.environ.get(k) for k in ("NBP_FIT_F64", "NBP_NO_SPECULATIVE_FITS")}
+    os.environ["NBP_FIT_F64"] = "1" if f64 else "0"
+    os.environ["NBP_NO_SPECULATIVE_FITS"] = "1"  # the sequential search is the one that brackets
+    try:
+        n = len(beliefs) * copies
+        be = iif.HipBackend(N, n, 0)
+        try:
+            for s, b in enumerate(beliefs):
+                if len(b) == N:
+                    be.slot_write(s, manifold, b)
+                else:  # a belief that holds fewer points than the slot (the fit is of the points it holds)
+                    be.belief_write(s, manifold, b)
+            if copies > 1:
+                be.run_copies([abi.CopyDesc(s % len(beliefs), s) for s in range(len(beliefs), n)])
+            be.diag(reset=True)
+            be.run_bandwidth(list(range(n)), [manifold] * n)
+            bw = np.array([be.slot_read(s, manifold)[1] for s in range(len(beliefs))])
+            d = be.diag()
+        finally:
+            be.close()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    return bw, d
+
+
+KINDS = ["gauss", "modes", "outliers", "offset", "duplicates", "heavy"]
+
+
+@pytest.mark.parametrize("manifold", [abi.EUCLID1, abi.EUCLID2, abi.EUCLID3, abi.CIRCULAR, abi.SE2])
+@pytest.mark.parametrize("N", [200, 300, 64, 37, 256, 257])
+def test_bracketed_search_selects_the_all_double_bandwidth(manifold, N):
+    rng = np.random.default_rng(1000 * manifold + N)
+    beliefs = [clouds(rng, manifold, N, k) for k in KINDS for _ in range(3)]
+    a, da = fit(N, manifold, beliefs, True)
+    b, db = fit(N, manifold, beliefs, False)
+    assert np.all(a > 0) and np.all(np.isfinite(a))
+    np.testing.assert_array_equal(b, a)
+    assert da["lcv_evals_f32"] == 0 and db["lcv_evals_f32"] > 0
+    assert db["lcv_evals"] < da["lcv_evals"]  # fewer double-precision evaluations than the all-double search makes
+
+
+def test_beliefs_with_fewer_points_than_the_slot():
+    N, man = 200, abi.EUCLID2
+    rng = np.random.default_rng(3)
+    beliefs = [rng.normal(size=(n, 2)) * 0.7 for n in (200, 150, 65, 64, 33, 9, 3)]
+    a, _ = fit(N, man, beliefs, True)
+    b, db = fit(N, man, beliefs, False)
+    np.testing.assert_array_equal(b, a)
+    assert db["lcv_evals_f32"] > 0
+
+
+def test_chip_filling_launch_and_the_share_of_single_precision_evaluations():
+    """2048 fits of 200-point Euclid(2) beliefs (a tree level of the 10 000-variable chain): identical bandwidths, and the
+    share of the evaluations the bracketing takes over -- the reason it exists -- stays where it was measured (~0.6)"""
+    N, man = 200, abi.EUCLID2
+    rng = np.random.default_rng(11)
+    beliefs = [rng.normal(size=(N, 2)) * rng.uniform(0.1, 2.0) + rng.normal(size=2) * 10 for _ in range(64)]
+    a, da = fit(N, man, beliefs, True, copies=32)
+    b, db = fit(N, man, beliefs, False, copies=32)
+    np.testing.assert_array_equal(b, a)
+    share = db["lcv_evals_f32"] / (db["lcv_evals_f32"] + db["lcv_evals"])
+    assert share > 0.5, share
+    assert db["lcv_evals"] < 0.55 * da["lcv_evals"], (db["lcv_evals"], da["lcv_evals"])

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def fit(N, manifold, nfits, env):
-    old = {k: os.environ.get(k) for k in ("NBP_NO_SPECULATIVE_FITS", "NBP_SPEC_DEPTH3")}
+    old = {k: os.environ.get(k) for k in ("NBP_NO_SPECULATIVE_FITS", "NBP_SPEC_DEPTH3", "NBP_FIT_F64")}
     for k in old:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -38,7 +38,11 @@ def fit(N, manifold, nfits, env):
 @pytest.mark.parametrize("manifold", [abi.EUCLID1, abi.EUCLID2, abi.EUCLID3, abi.CIRCULAR, abi.SE2])
 @pytest.mark.parametrize("N,nfits", [(100, 1), (200, 3), (256, 8), (37, 2)])
 def test_speculative_search_is_bit_identical(manifold, N, nfits):
-    seq, ev0 = fit(N, manifold, nfits, {"NBP_NO_SPECULATIVE_FITS": "1"})
+    # (the sequential search in double precision throughout: with its bracketing evaluations in single precision it counts
+    #  fewer double-precision evaluations -- tests/test_gpu_fit_bracketing.py -- for the same bandwidths)
+    seq, ev0 = fit(N, manifold, nfits, {"NBP_NO_SPECULATIVE_FITS": "1", "NBP_FIT_F64": "1"})
+    brk, _ = fit(N, manifold, nfits, {"NBP_NO_SPECULATIVE_FITS": "1"})
+    np.testing.assert_array_equal(brk, seq)
     k3, ev3 = fit(N, manifold, nfits, {"NBP_SPEC_DEPTH3": "0"})
     k7, ev7 = fit(N, manifold, nfits, {})
     assert np.all(seq > 0)
