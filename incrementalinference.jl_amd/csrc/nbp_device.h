@@ -1478,6 +1478,11 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
     int A2 = 1, lg2 = 0;  // powers of two: every division by A2 or HH below is a shift
     while (A2 < A) { A2 <<= 1; lg2++; }
     const bool lastwave = i >= lastbase;            // wave-uniform
+    // a wave BEHIND the last one: a belief that holds fewer points than the slot (N = its count, Npad = the slot's row) leaves
+    // whole waves of the row without a point.  They take no part in the pair loop -- dealt the roles of the last wave, as they
+    // were through round 4, they added its pairs a second time (the fitted bandwidth of such a belief was off by up to 15 %;
+    // found by tests/test_gpu_fit_bracketing.py against the single-precision evaluation, pinned on the oracle there)
+    const bool behind = i >= lastbase + 64;         // wave-uniform
     const bool redeal = lastwave && A2 <= 32;
     const int lgH = redeal ? 6 - lg2 : 0, HH = 1 << lgH;
     const int len = t1 - t0;
@@ -1515,7 +1520,7 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
         const int ws = __builtin_amdgcn_readfirstlane(w), q = (len + nfull - 1) / nfull, wa = min(len, ws * q);
         nf2 = 1; base2 = lastbase; ta2 = t0 + wa; c2 = min(len, wa + q) - wa;
       }
-    } else if (!fold) {
+    } else if (!fold && !behind) {
       const int pi = redeal ? lastbase + (l & (A2 - 1)) : i, hh = redeal ? l >> lg2 : 0;
       const int lenmin = len >> lgH, rem = len - (lenmin << lgH);
       const int ta = t0 + hh * lenmin + min(hh, rem);
@@ -1640,27 +1645,35 @@ __device__ __forceinline__ double neg_loo_ll(const double *x, int N, int Npad, b
 #ifndef NBP_LCV_F32
 #define NBP_LCV_F32 1
 #endif
+// CIRC: the angles live on the circle as 32-bit integers (x 2^32 / 2 pi): the difference of two of them, taken modulo 2^32, IS the
+// geodesic difference -- no wrap, no min -- and it is exact; what single precision rounds is the difference, not the angle
+// (the scaled angle 2 pi c can be hundreds of kernel widths for a belief with narrow modes: rounded to single precision first,
+// it would carry that many times the error)
 template <bool CIRC>
-__device__ __forceinline__ void loo_f32_quad(const float4 y, float xi, float T, float &e0, float &e1, float &e2, float &e3) {
-  float d0 = xi - y.x, d1 = xi - y.y, d2 = xi - y.z, d3 = xi - y.w;
-  if (CIRC) {  // geodesic distance on the circle, scaled: min(|d|, ||d| - 2 pi c|)
-    d0 = fminf(fabsf(d0), fabsf(fabsf(d0) - T));
-    d1 = fminf(fabsf(d1), fabsf(fabsf(d1) - T));
-    d2 = fminf(fabsf(d2), fabsf(fabsf(d2) - T));
-    d3 = fminf(fabsf(d3), fabsf(fabsf(d3) - T));
+__device__ __forceinline__ void loo_f32_quad(const float4 y, float xi, float K, float &e0, float &e1, float &e2, float &e3) {
+  float d0, d1, d2, d3;
+  if (CIRC) {
+    const unsigned int xq = __float_as_uint(xi);  // (unsigned: the wrap-around is the point)
+    d0 = (float)(int)(xq - __float_as_uint(y.x)) * K;
+    d1 = (float)(int)(xq - __float_as_uint(y.y)) * K;
+    d2 = (float)(int)(xq - __float_as_uint(y.z)) * K;
+    d3 = (float)(int)(xq - __float_as_uint(y.w)) * K;
+  } else {
+    d0 = xi - y.x; d1 = xi - y.y; d2 = xi - y.z; d3 = xi - y.w;
   }
   e0 = __builtin_amdgcn_exp2f(-d0 * d0);
   e1 = __builtin_amdgcn_exp2f(-d1 * d1);
   e2 = __builtin_amdgcn_exp2f(-d2 * d2);
   e3 = __builtin_amdgcn_exp2f(-d3 * d3);
 }
+// groups [ga, gb) of four partners, all of them points (the group that holds the padding is the caller's: loo_f32_tail)
 template <bool CIRC, bool MASK>
-__device__ __forceinline__ void loo_f32_groups(const float4 *x4, int ga, int gb, float xi, int i, float T, float &s0, float &s1, float &s2,
+__device__ __forceinline__ void loo_f32_groups(const float4 *x4, int ga, int gb, float xi, int i, float K, float &s0, float &s1, float &s2,
                                                float &s3) {
 #pragma unroll 2
   for (int g = ga; g < gb; g++) {
     float e0, e1, e2, e3;
-    loo_f32_quad<CIRC>(x4[g], xi, T, e0, e1, e2, e3);
+    loo_f32_quad<CIRC>(x4[g], xi, K, e0, e1, e2, e3);
     if (MASK) {
       const int j = 4 * g;
       e0 = (j == i) ? 0.f : e0;
@@ -1674,30 +1687,38 @@ __device__ __forceinline__ void loo_f32_groups(const float4 *x4, int ga, int gb,
     s3 += e3;
   }
 }
+// one group with the point itself and the entries beyond the N-th masked out
+template <bool CIRC>
+__device__ __forceinline__ void loo_f32_tail(const float4 *x4, int g, bool on, float xi, int i, int N, float K, float &s0, float &s1, float &s2,
+                                             float &s3) {
+  float e0, e1, e2, e3;
+  loo_f32_quad<CIRC>(x4[g], xi, K, e0, e1, e2, e3);
+  const int j = 4 * g;
+  s0 += (!on || j == i || j >= N) ? 0.f : e0;
+  s1 += (!on || j + 1 == i || j + 1 >= N) ? 0.f : e1;
+  s2 += (!on || j + 2 == i || j + 2 >= N) ? 0.f : e2;
+  s3 += (!on || j + 3 == i || j + 3 >= N) ? 0.f : e3;
+}
 // a last wave of at most 32 points, re-dealt as A2 points x HH = 64 / A2 sub-helpers (A2 = the point count rounded up to a
 // power of two): sub-helper hh of a point takes the hh-th part of the row's groups -- the wave leaves its SIMD after 1 / HH of
 // the steps (N = 200: 8 points x 8 sub-helpers; the workgroup's four waves cost 3.1 wave-loops instead of 4) -- and the
-// parts are added up by a butterfly over the lanes of the point.  `pad` = the index of a group of padding partners.
+// parts are added up by a butterfly over the lanes of the point.
 template <bool CIRC>
-__device__ __forceinline__ float loo_f32_redealt(const float4 *x4, int ga, int gb, int pad, float xi, int pi, int hh, int lgH, float T) {
+__device__ __forceinline__ float loo_f32_redealt(const float4 *x4, int ga, int gb, float xi, int pi, int N, int hh, int lgH, float K) {
   const int len = gb - ga, a = ga + ((hh * len) >> lgH), b = ga + (((hh + 1) * len) >> lgH);
   const int steps = __builtin_amdgcn_readfirstlane((len + (1 << lgH) - 1) >> lgH);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int t = 0; t < steps; t++) {
-    const int g = (a + t < b) ? a + t : pad;
-    float e0, e1, e2, e3;
-    loo_f32_quad<CIRC>(x4[g], xi, T, e0, e1, e2, e3);
-    const int j = 4 * g;
-    s0 += (j == pi) ? 0.f : e0;
-    s1 += (j + 1 == pi) ? 0.f : e1;
-    s2 += (j + 2 == pi) ? 0.f : e2;
-    s3 += (j + 3 == pi) ? 0.f : e3;
+    const bool on = a + t < b;
+    loo_f32_tail<CIRC>(x4, on ? a + t : ga, on, xi, pi, N, K, s0, s1, s2, s3);
   }
   float sf = (s0 + s1) + (s2 + s3);
   for (int o = 64 >> lgH; o < 64; o <<= 1) sf += __shfl_xor(sf, o, 64);
   return sf;
 }
 // |f_single - f_double| <= this (see above; u = 2^-24): u (24 X + 250 + N / 4) for the sums + 64 u for log2 in single precision
+// (circular coordinates: the differences of the integer angles are exact and their conversion rounds like the subtraction it
+// replaces; what is left of the representation term is the grid itself, 2 pi / 2^32 per angle: xmax = 0.0125 stands for it)
 __device__ __forceinline__ double lcv_f32_bound(double xmax, double h, int N) {
   return 5.9604644775390625e-8 * (24.0 * (xmax * (0.84932180028801907 / h)) + 314.0 + 0.25 * (double)N);
 }
@@ -1710,10 +1731,14 @@ __device__ __forceinline__ double neg_loo_ll_f32(const double *x, int N, int Npa
   double *acc = part + P * Npad;
   float *xf = (float *)(acc + (((uintptr_t)acc >> 3) & 1));  // 16-byte aligned (an offset, not a cast: the pointer stays an LDS pointer)
   const int G4 = (N + 3) >> 2;
-  // (the padding of the last group and one group of nothing but padding: partners at a distance whose weight underflows to zero)
-  for (int j = tid; j < 4 * G4 + 4; j += blockDim.x) xf[j] = (j < N) ? (float)((x[j] - cen) * scl) : 3.0e18f;
+  // (circular: the angle as a 32-bit integer, 2^32 to the turn -- the conversion through 64 bits wraps pi itself to -2^31)
+  for (int j = tid; j < 4 * G4; j += blockDim.x) {
+    if (circ) ((int *)xf)[j] = (j < N) ? (int)(long long)rint(x[j] * 683565275.57643159) : 0;
+    else xf[j] = (j < N) ? (float)((x[j] - cen) * scl) : 0.f;
+  }
   __syncthreads();
-  const float T = (float)(NBP_TWO_PI * scl);
+  const float K = (float)(scl * 1.4629180792671596e-9);  // circular: scaled radians per integer step (2 pi c / 2^32)
+  const int full = N >> 2;                                // groups of four points; group `full` (if N % 4) holds the padding
   // row p of the workgroup takes the p-th share of the groups; the groups that hold the points of this lane's own wave are
   // the ones that need the self term masked (all bounds wave-uniform: scalar loops)
   const int ga = __builtin_amdgcn_readfirstlane((p * G4) / P), gb = __builtin_amdgcn_readfirstlane(((p + 1) * G4) / P);
@@ -1721,31 +1746,35 @@ __device__ __forceinline__ double neg_loo_ll_f32(const double *x, int N, int Npa
   int lg2 = 0;
   while ((1 << lg2) < A) lg2++;
   const bool redeal = __builtin_amdgcn_readfirstlane((int)(i >= lastbase && lg2 <= 5)) != 0;
+  const bool behind = __builtin_amdgcn_readfirstlane((int)(i >= lastbase + 64)) != 0;  // a wave without a point (a belief of fewer points than the slot)
   const float4 *x4 = (const float4 *)xf;
-  float sf;
-  if (redeal) {
+  float sf = 0.f;
+  if (behind) {
+  } else if (redeal) {
     const int l = tid & 63, pi = lastbase + (l & ((1 << lg2) - 1)), hh = l >> lg2;
     const float xi = (pi < N) ? xf[pi] : 0.f;
-    sf = circ ? loo_f32_redealt<true>(x4, ga, gb, G4, xi, pi, hh, 6 - lg2, T) : loo_f32_redealt<false>(x4, ga, gb, G4, xi, pi, hh, 6 - lg2, T);
+    sf = circ ? loo_f32_redealt<true>(x4, ga, gb, xi, pi, N, hh, 6 - lg2, K) : loo_f32_redealt<false>(x4, ga, gb, xi, pi, N, hh, 6 - lg2, K);
   } else {
     const float xi = (i < N) ? xf[i] : 0.f;
-    const int o0 = __builtin_amdgcn_readfirstlane((i & ~63) >> 2);
-    const int m0 = max(ga, min(gb, o0)), m1 = max(ga, min(gb, o0 + 16));
+    const int o0 = __builtin_amdgcn_readfirstlane((i & ~63) >> 2), gf = min(gb, full);
+    const int m0 = max(ga, min(gf, o0)), m1 = max(ga, min(gf, o0 + 16));
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (circ) {
-      loo_f32_groups<true, false>(x4, ga, m0, xi, i, T, s0, s1, s2, s3);
-      loo_f32_groups<true, true>(x4, m0, m1, xi, i, T, s0, s1, s2, s3);
-      loo_f32_groups<true, false>(x4, m1, gb, xi, i, T, s0, s1, s2, s3);
+      loo_f32_groups<true, false>(x4, ga, m0, xi, i, K, s0, s1, s2, s3);
+      loo_f32_groups<true, true>(x4, m0, m1, xi, i, K, s0, s1, s2, s3);
+      loo_f32_groups<true, false>(x4, m1, gf, xi, i, K, s0, s1, s2, s3);
+      if (gb > full) loo_f32_tail<true>(x4, full, true, xi, i, N, K, s0, s1, s2, s3);
     } else {
-      loo_f32_groups<false, false>(x4, ga, m0, xi, i, T, s0, s1, s2, s3);
-      loo_f32_groups<false, true>(x4, m0, m1, xi, i, T, s0, s1, s2, s3);
-      loo_f32_groups<false, false>(x4, m1, gb, xi, i, T, s0, s1, s2, s3);
+      loo_f32_groups<false, false>(x4, ga, m0, xi, i, K, s0, s1, s2, s3);
+      loo_f32_groups<false, true>(x4, m0, m1, xi, i, K, s0, s1, s2, s3);
+      loo_f32_groups<false, false>(x4, m1, gf, xi, i, K, s0, s1, s2, s3);
+      if (gb > full) loo_f32_tail<false>(x4, full, true, xi, i, N, K, s0, s1, s2, s3);
     }
     sf = (s0 + s1) + (s2 + s3);
   }
   if (P > 1 && i < N) part[p * Npad + i] = (double)sf;  // (`part` is all zero between evaluations)
   __syncthreads();
-  for (int j = tid; j < 2 * G4 + 4; j += blockDim.x) acc[j] = 0.0;  // the accumulator row as the double-precision evaluation expects it
+  for (int j = tid; j < 2 * G4 + 2; j += blockDim.x) acc[j] = 0.0;  // the accumulator row as the double-precision evaluation expects it
   // f = -(ln2 / N) sum_i log2(s_i) + log(h) + lognorm0: the logarithm of a point's sum in single precision (v_log_f32),
   // log(h) in double precision by ONE wave (the last of row 0: the re-dealt one when there is one)
   double term = 0;
@@ -1810,7 +1839,7 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   // Bracketing in single precision (neg_loo_ll_f32): e1 / e2 = the error bounds of f1 / f2 (0: a double-precision value).  A
   // comparison the bounds do not decide re-evaluates its single-precision sides in double precision -- `todo` 3 / 4 -- and ends
   // the single-precision phase; every decision is then the all-double search's, and so is every position and the result.
-  const double cen = circ ? 0.0 : 0.5 * (lo + hi), xmax = circ ? NBP_TWO_PI : 0.5 * (hi - lo);
+  const double cen = circ ? 0.0 : 0.5 * (lo + hi), xmax = circ ? 0.0125 : 0.5 * (hi - lo);  // (circular: the integer grid's half step on both angles, as a coordinate of that size)
   bool m32 = NBP_LCV_F32 && !(ctr && (ctr->flags & 1));
   double f1 = 0.0, f2 = 0.0, e1 = 0.0, e2 = 0.0, pt = x1;
   unsigned int nev = 0, nev32 = 0;
