@@ -3,7 +3,7 @@
 # per-kernel stats, the launches of one solve and of graph initialisation in order), PMC passes (HBM traffic) for the
 # default launch form and for the fused update kernel, the other configs, micro-benchmarks and SQ counters.
 # Output under gpurun_out/$TAG; copy what is to be judged into profiles/.   Usage (on the GPU box): tools/collect_profiles.sh r04
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
@@ -31,8 +31,8 @@ for c in 3 4 5; do
 done
 python $R/tools/lcv_bench.py > $O/lcv_microbench.txt 2>/dev/null
 # SQ counters of the chip-filling bandwidth fit (two passes of 8 counters)
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU -d $O/sq/p1 -- python $R/tools/lcv_bench.py 200 2048 > /dev/null 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INST_CYCLES_SALU -d $O/sq/p2 -- python $R/tools/lcv_bench.py 200 2048 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU -d $O/sq/p1 -- python $R/tools/lcv_bench.py 200 2048 shipped > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INST_CYCLES_SALU -d $O/sq/p2 -- python $R/tools/lcv_bench.py 200 2048 shipped > /dev/null 2>&1
 python $R/tools/pmc_sq.py $O/sq nbp_bandwidth > $O/lcv_sq_counters.txt 2>&1
 # SQ counters of a chip-filling batch of proposals / of products (975 of each: one tree level of config 2)
 for k in prop prod; do
@@ -44,7 +44,7 @@ done
 # debug build (tools/libnbp_dbg.so, -DNBP_PHASE_TIMING): where one evaluation of a fit and one fused workgroup spend their
 # time, and how busy the lanes of the per-particle searches are
 if [ -f $R/tools/libnbp_dbg.so ]; then
-  NBP_NO_SPECULATIVE_FITS=1 python $R/tools/lcv_phase_timing.py > $O/lcv_phase_timing.txt 2>/dev/null
+  NBP_NO_SPECULATIVE_FITS=1 NBP_FIT_F64=1 python $R/tools/lcv_phase_timing.py > $O/lcv_phase_timing.txt 2>/dev/null
   python $R/tools/product_phase_timing.py > $O/product_phase_timing.txt 2>/dev/null
   python $R/tools/exp/nm_lane_util.py > $O/search_lane_utilisation.txt 2>/dev/null
   for a in "488 2" "975 2" "4000 2"; do python $R/tools/exp/fused_phase.py $a 2>/dev/null; done > $O/fused_phase_timing.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy_profiles.sh TAG: what tools/collect_profiles.sh TAG left under gpurun_out/TAG -> profiles/TAG_* (the tracked, judged copies)
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.." || exit 1
 for f in gpurun_out/$TAG/*.json gpurun_out/$TAG/*.csv gpurun_out/$TAG/*.txt; do
   b=$(basename $f)
