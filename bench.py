@@ -247,11 +247,14 @@ def _main(real_stdout):
         bytes_per_launch = alg_rank / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM traffic cannot be counted from inside this process (PMC passes need rocprofv3 around it): the figures of the
-        # committed PMC run of this very command (tools/pmc_quick.sh -> profiles/r03_pmc_traffic.json) are quoted, for the
+        # committed PMC run of this very command (tools/pmc_quick.sh -> profiles/rNN_pmc_traffic.json) are quoted, for the
         # configuration they were taken on only
         traffic, traffic_src, traffic_step, traffic_ratio = None, None, None, None
         fused_on = os.environ.get("NBP_FUSED_MIN") is not None and os.environ.get("NBP_NO_FUSED_UPDATE") is None
-        pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_fused.json" if fused_on else "r04_pmc_traffic.json")
+        # (the newest round's file; it is quoted only while it was taken on the kernel sources of this build, below)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic_fused.json" if fused_on else "r[0-9][0-9]_pmc_traffic.json")))
+        pmc = cands[-1] if cands else os.path.join(ROOT, "profiles", "none")
         traffic_stale = None
         if world == 1 and a.config == "2" and size == 1000 and N == 200 and os.path.exists(pmc):
             try:
