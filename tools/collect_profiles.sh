@@ -52,7 +52,7 @@ done
     [ -x $R/tools/exp/$t ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -Wno-unused-value -w $R/tools/exp/$t.hip -o $R/tools/exp/$t 2>/dev/null
   done
   echo; echo "== tools/exp/lcv_f32_values.hip: single-precision evaluations against the host's, P = 1, 2, 4 rows, nine point counts, two coordinate kinds, five bandwidths"
-  $R/tools/exp/lcv_f32_values | awk '{ n++; if ($0 ~ /ok $/) ok++; d = $(NF-4); if (d < 0) d = -d; if (d + 0 > m) m = d + 0 } END { printf "%d evaluations, %d inside the bound, largest |f32 - f64| %.2e\n", n, ok, m }'
+  $R/tools/exp/lcv_f32_values | awk '{ n++; if ($0 ~ /ok $/) ok++; for (k = 1; k < NF; k++) if ($k == "diff") { d = $(k + 1) + 0; if (d < 0) d = -d; if (d > m) m = d } } END { printf "%d evaluations, %d inside the bound, largest |f32 - f64| %.2e\n", n, ok, m }'
   $R/tools/exp/lcv_f32_values | grep "P=1 circ=0" | grep "h= 0.30"
   echo; echo "== tools/exp/lcv_f32_proto.hip: the pair loop alone, 8192 fits x 16 evaluations"
   $R/tools/exp/lcv_f32_proto 8192 16
