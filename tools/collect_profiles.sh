@@ -43,26 +43,7 @@ done
 { python $R/tools/exp/prod_batch.py 975 2; python $R/tools/exp/prod_batch.py 1 2; python $R/tools/pmc_sq.py $O/sq_prod nbp_product; } > $O/product_sq_counters.txt 2>/dev/null
 # single-precision bracketing of the bandwidth searches: bit-equal bandwidths and timings with / without (NBP_FIT_F64=1), every
 # evaluation against the host's and the bound, what a pair costs in the candidate loop forms, small launches, the configs either way
-{
-  echo "== tools/exp/lcv_f32_check.py: all-double (NBP_FIT_F64=1) against the shipped search, per launch of fits (evals are per KDE: the sum over its coordinates)"
-  python $R/tools/exp/lcv_f32_check.py 2>/dev/null | grep -v "fits=    1 "
-  echo; echo "== tools/exp/lone_fit_latency.py: small launches (default = speculative search where every workgroup is resident)"
-  python $R/tools/exp/lone_fit_latency.py 2>/dev/null
-  for t in lcv_f32_values lcv_f32_proto; do
-    [ -x $R/tools/exp/$t ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -Wno-unused-value -w $R/tools/exp/$t.hip -o $R/tools/exp/$t 2>/dev/null
-  done
-  echo; echo "== tools/exp/lcv_f32_values.hip: single-precision evaluations against the host's, P = 1, 2, 4 rows, nine point counts, two coordinate kinds, five bandwidths"
-  $R/tools/exp/lcv_f32_values | awk '{ n++; if ($0 ~ /ok $/) ok++; for (k = 1; k < NF; k++) if ($k == "diff") { d = $(k + 1) + 0; if (d < 0) d = -d; if (d > m) m = d } } END { printf "%d evaluations, %d inside the bound, largest |f32 - f64| %.2e\n", n, ok, m }'
-  $R/tools/exp/lcv_f32_values | grep "P=1 circ=0" | grep "h= 0.30"
-  echo; echo "== tools/exp/lcv_f32_proto.hip: the pair loop alone, 8192 fits x 16 evaluations"
-  $R/tools/exp/lcv_f32_proto 8192 16
-  echo; echo "== the configurations, ms per solve as shipped | with NBP_FIT_F64=1 (same process order, same box)"
-  for c in 2 3 4 5; do
-    a=$(python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-10k --no-profile-pass 2>/dev/null | python -c "import json,sys; print('%.2f' % json.load(sys.stdin)['ms_per_step'])")
-    b=$(NBP_FIT_F64=1 python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-10k --no-profile-pass 2>/dev/null | python -c "import json,sys; print('%.2f' % json.load(sys.stdin)['ms_per_step'])")
-    echo "config $c: $a | $b"
-  done
-} > $O/fit_bracketing.txt 2>&1
+bash $R/tools/exp/fit_bracketing_record.sh > $O/fit_bracketing.txt 2>&1
 # debug build (tools/libnbp_dbg.so, -DNBP_PHASE_TIMING): where one evaluation of a fit and one fused workgroup spend their
 # time, and how busy the lanes of the per-particle searches are
 if [ -f $R/tools/libnbp_dbg.so ]; then
