@@ -130,3 +130,48 @@ def test_chip_filling_launch_and_the_share_of_single_precision_evaluations():
     share = db["lcv_evals_f32"] / (db["lcv_evals_f32"] + db["lcv_evals"])
     assert share > 0.5, share
     assert db["lcv_evals"] < 0.55 * da["lcv_evals"], (db["lcv_evals"], da["lcv_evals"])
+
+
+def extreme_cloud(rng, man, n):
+    """scales from 1e-6 to 1e6, offsets to 1e6, duplicates, heavy tails, lattices, a few points three decades out"""
+    D = abi.MANIFOLD_DIM[man]
+    eucl = man not in (abi.CIRCULAR, abi.SE2)
+    kind = rng.integers(0, 7)
+    scale = 10.0 ** rng.uniform(-6, 6) if eucl else 10.0 ** rng.uniform(-4, 0.5)
+    off = rng.normal(size=D) * 10.0 ** rng.uniform(-2, 6) if eucl else rng.normal(size=D)
+    if kind == 0:
+        c = rng.normal(size=(n, D))
+    elif kind == 1:
+        c = rng.standard_cauchy(size=(n, D))
+    elif kind == 2:
+        c = rng.normal(size=(n, D)) * 0.02 + rng.integers(0, 5, size=(n, 1)) * 1.0
+    elif kind == 3:
+        c = np.repeat(rng.normal(size=((n + 2) // 3, D)), 3, axis=0)[:n] + rng.normal(size=(n, D)) * 1e-9
+    elif kind == 4:
+        c = rng.uniform(-1, 1, size=(n, D))
+    elif kind == 5:
+        c = np.round(rng.normal(size=(n, D)) * 4) / 4 + rng.normal(size=(n, D)) * 1e-3
+    else:
+        c = rng.normal(size=(n, D))
+        c[: max(1, n // 50)] *= 1e3
+    c = c * scale + off
+    if man == abi.SE2:
+        th = c[:, 2]
+        return np.stack([c[:, 0], c[:, 1], np.cos(th), np.sin(th), -np.sin(th), np.cos(th)], axis=1)
+    if man == abi.CIRCULAR:
+        return (c + np.pi) % (2 * np.pi) - np.pi
+    return c
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_soak_of_extreme_clouds(seed):
+    """(tools/exp/fit_soak.py is the long form: 13 492 bandwidths in profiles/r05_fit_bracketing.txt)"""
+    rng = np.random.default_rng(4000 + seed)
+    N = int(rng.choice([200, 300, 64, 100, 256, 257, 37, 320, 128, 500]))
+    man = [abi.EUCLID1, abi.EUCLID2, abi.EUCLID3, abi.CIRCULAR, abi.SE2][seed % 5]
+    nb = int(rng.choice([3, 12, 70]))
+    beliefs = [extreme_cloud(rng, man, N if rng.random() < 0.6 else int(rng.integers(2, N + 1))) for _ in range(nb)]
+    a, _ = fit(N, man, beliefs, True)
+    b, _ = fit(N, man, beliefs, False)
+    assert np.all(np.isfinite(a)) and np.all(a > 0)
+    np.testing.assert_array_equal(b, a)
