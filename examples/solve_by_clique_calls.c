@@ -9,7 +9,8 @@
  *   gcc -O2 -fopenmp -Iinclude examples/solve_by_clique_calls.c -o /tmp/clique_calls \
  *       -Lincrementalinference.jl_amd/csrc -lnbp -Wl,-rpath,$PWD/incrementalinference.jl_amd/csrc -lm
  *   /tmp/clique_calls [nvars=12] [N=128] [prior every=5] [concurrent callers=1; 0 = one batched call per tree level;
- *                                                          -1 = the same, queued: resident beliefs, submit per level, wait once]
+ *                                                          -1 = the same, queued: resident beliefs, submit per level, wait once;
+ *                                                          -2 = queued, the requests of every level kept across walks]
  *
  * With several concurrent callers the cliques of one tree level are solved side by side, one context per caller -- the
  * C equivalent of the reference's one-task-per-clique state machines.  Same posteriors: nothing depends on which context
@@ -249,41 +250,58 @@ static int level_batched(host *H, nbp_ctx *ctx, int d, int down) {
 /* callers = -1: the same level, QUEUED (nbp_clique_submit_batch): the device copies this level needs in front of its batch,
  * the batch, the copies behind it -- and on to the next level while the device works; everything a queued batch points to
  * stays alive until its ticket has been waited for */
-typedef struct { worker *W; nbp_clique_request *R; int n; nbp_clique_ticket *t; } queued_level;
-static int level_queued(host *H, nbp_ctx *ctx, int d, int down, queued_level *Q) {
-  int n = 0;
-  for (int c = 1; c <= H->ncl; c++) n += H->depth[c] == d;
-  worker *W = calloc((size_t)n, sizeof(*W));
-  nbp_clique_request *R = calloc((size_t)n, sizeof(*R));
-  int k = 0;
-  H->ncp = H->npp = 0;
-  for (int c = 1; c <= H->ncl; c++) {
-    if (H->depth[c] != d) continue;
-    int ncf = H->info[c].npotentials;
-    if (down) { int32_t ff[MAXCF]; ncf = frontal_factors(H, c, ff); if (ncf < 0) return 1; }
-    int nmsg = 0;
-    for (int j = 0; j < H->info[c].nchildren; j++) nmsg += H->info[H->ch[c][j]].nseparators;
-    W[k] = worker_new(H->info[c].nfrontals + H->info[c].nseparators + 2 * ncf + nmsg + 1, ncf);
-    if (down ? down_prepare(H, &W[k], c) : up_prepare(H, &W[k], c)) return 1;
-    R[k].params = H->sp; R[k].clique = &W[k].q; R[k].seed = H->seed; R[k].beliefs = W[k].bel; R[k].down = down;
-    k++;
+typedef struct {
+  worker *W; nbp_clique_request *R; int n; nbp_clique_ticket *t;
+  /* callers = -2: the requests of a level and its copy lists are KEPT across walks (the tree has not changed: the descriptors,
+   * the id lists, the handles are the same) -- what a CliqueStateMachine that solves the same tree again does not rebuild */
+  int built, ncp0, npp0, ncp1;
+  int32_t *cp0_src, *cp0_dst, *pp0_src, *pp0_dst, *cp1_src, *cp1_dst;
+} queued_level;
+static int32_t *dup32(const int32_t *a, int n) { int32_t *r = malloc(sizeof(int32_t) * (n > 0 ? n : 1)); memcpy(r, a, sizeof(int32_t) * n); return r; }
+static int level_queued(host *H, nbp_ctx *ctx, int d, int down, queued_level *Q, int keep) {
+  if (!(keep && Q->built)) {
+    int n = 0;
+    for (int c = 1; c <= H->ncl; c++) n += H->depth[c] == d;
+    worker *W = calloc((size_t)n, sizeof(*W));
+    nbp_clique_request *R = calloc((size_t)n, sizeof(*R));
+    int k = 0;
+    H->ncp = H->npp = 0;
+    for (int c = 1; c <= H->ncl; c++) {
+      if (H->depth[c] != d) continue;
+      int ncf = H->info[c].npotentials;
+      if (down) { int32_t ff[MAXCF]; ncf = frontal_factors(H, c, ff); if (ncf < 0) return 1; }
+      int nmsg = 0;
+      for (int j = 0; j < H->info[c].nchildren; j++) nmsg += H->info[H->ch[c][j]].nseparators;
+      W[k] = worker_new(H->info[c].nfrontals + H->info[c].nseparators + 2 * ncf + nmsg + 1, ncf);
+      if (down ? down_prepare(H, &W[k], c) : up_prepare(H, &W[k], c)) return 1;
+      R[k].params = H->sp; R[k].clique = &W[k].q; R[k].seed = H->seed; R[k].beliefs = W[k].bel; R[k].down = down;
+      k++;
+    }
+    Q->W = W; Q->R = R; Q->n = n;
+    Q->ncp0 = H->ncp; Q->cp0_src = dup32(H->cp_src, H->ncp); Q->cp0_dst = dup32(H->cp_dst, H->ncp);
+    Q->npp0 = H->npp; Q->pp0_src = dup32(H->pp_src, H->npp); Q->pp0_dst = dup32(H->pp_dst, H->npp);
+    H->ncp = 0;
+    for (int c = 1; c <= H->ncl && !down; c++) if (H->depth[c] == d) up_finish(H, c);
+    Q->ncp1 = H->ncp; Q->cp1_src = dup32(H->cp_src, H->ncp); Q->cp1_dst = dup32(H->cp_dst, H->ncp);
+    Q->built = 1;
   }
-  CHK(nbp_resident_copy(ctx, H->ncp, H->cp_src, H->cp_dst, 0)); /* up: the deep copies of this level's sub graphs */
-  CHK(nbp_resident_copy(ctx, H->npp, H->pp_src, H->pp_dst, 1)); /* down: the parents' values of this level's separators */
-  Q->W = W; Q->R = R; Q->n = n; Q->t = NULL;
-  CHK(nbp_clique_submit_batch(ctx, R, n, &Q->t));
-  H->ncp = 0;
-  for (int c = 1; c <= H->ncl && !down; c++) if (H->depth[c] == d) up_finish(H, c);
-  CHK(nbp_resident_copy(ctx, H->ncp, H->cp_src, H->cp_dst, 0)); /* a root's result goes back to the graph */
+  Q->t = NULL;
+  CHK(nbp_resident_copy(ctx, Q->ncp0, Q->cp0_src, Q->cp0_dst, 0)); /* up: the deep copies of this level's sub graphs */
+  CHK(nbp_resident_copy(ctx, Q->npp0, Q->pp0_src, Q->pp0_dst, 1)); /* down: the parents' values of this level's separators */
+  CHK(nbp_clique_submit_batch(ctx, Q->R, Q->n, &Q->t));
+  CHK(nbp_resident_copy(ctx, Q->ncp1, Q->cp1_src, Q->cp1_dst, 0)); /* a root's result goes back to the graph */
   return 0;
 }
-static int level_wait(queued_level *Q, int down) {
+static void level_free(queued_level *Q) {
+  for (int i = 0; i < Q->n; i++) worker_free(&Q->W[i]);
+  free(Q->W); free(Q->R); free(Q->cp0_src); free(Q->cp0_dst); free(Q->pp0_src); free(Q->pp0_dst); free(Q->cp1_src); free(Q->cp1_dst);
+  memset(Q, 0, sizeof(*Q));
+}
+static int level_wait(queued_level *Q, int down, int keep) {
   CHK(nbp_clique_wait(Q->t));
-  for (int i = 0; i < Q->n; i++) {
+  for (int i = 0; i < Q->n; i++)
     if (Q->R[i].status != (down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED)) return 1;
-    worker_free(&Q->W[i]);
-  }
-  free(Q->W); free(Q->R);
+  if (!keep) level_free(Q);
   return 0;
 }
 
@@ -292,6 +310,7 @@ int main(int argc, char **argv) {
   N = argc > 2 ? atoi(argv[2]) : 128;
   const int every = argc > 3 ? atoi(argv[3]) : 5;
   const int queued = argc > 4 && atoi(argv[4]) < 0;     /* callers = -1: batched per level, resident beliefs, submit / wait */
+  const int keep = argc > 4 && atoi(argv[4]) == -2;     /* callers = -2: the same, the requests of every level kept across walks */
   const int batched = argc > 4 && atoi(argv[4]) <= 0;   /* callers = 0: the cliques of a level in one batched call */
   const int threads = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : 1;
   const uint64_t seed = 2024;
@@ -432,16 +451,17 @@ int main(int argc, char **argv) {
     int32_t *gm = malloc(sizeof(int32_t) * nvars), *ph_ = malloc(sizeof(int32_t) * nvars);
     for (int v = 0; v < nvars; v++) { gb[v] = view(&graph[v]); gm[v] = NBP_EUCLID2; }
     CHK(nbp_resident_write(bctx, nvars, H.graph_h, gm, gb));
-    queued_level *Q = calloc(2 * ((size_t)maxdepth + 1), sizeof(*Q));
+    static queued_level *Q = NULL;
+    if (!Q) Q = calloc(2 * ((size_t)maxdepth + 1), sizeof(*Q));
     int nq = 0;
-    for (int d = maxdepth; d >= 0 && !failed; d--) failed |= level_queued(&H, bctx, d, 0, &Q[nq++]);
-    for (int d = 1; d <= maxdepth && !failed; d++) failed |= level_queued(&H, bctx, d, 1, &Q[nq++]);
+    for (int d = maxdepth; d >= 0 && !failed; d--) failed |= level_queued(&H, bctx, d, 0, &Q[nq++], keep);
+    for (int d = 1; d <= maxdepth && !failed; d++) failed |= level_queued(&H, bctx, d, 1, &Q[nq++], keep);
     t_queued = now_s() - tb; /* everything is queued: from here on the host only waits */
-    for (int i = 0; i < nq && !failed; i++) failed |= level_wait(&Q[i], i > maxdepth);
+    for (int i = 0; i < nq && !failed; i++) failed |= level_wait(&Q[i], i > maxdepth, keep);
     for (int c = 1; c <= ncl; c++) for (int i = 0; i < H.info[c].nfrontals; i++) ph_[H.fr[c][i]] = H.sub_h[c][i]; /* a variable's posterior: its frontal clique's copy */
     for (int v = 0; v < nvars; v++) gb[v] = view(&post[v]);
     if (!failed) CHK(nbp_resident_read(bctx, nvars, ph_, gm, gb));
-    free(Q); free(gb); free(gm); free(ph_);
+    free(gb); free(gm); free(ph_);
   }
   for (int d = maxdepth; d >= 0 && !failed && batched && !queued; d--) failed |= level_batched(&H, bctx, d, 0);
   for (int d = 1; d <= maxdepth && !failed && batched && !queued; d++) failed |= level_batched(&H, bctx, d, 1);
@@ -474,7 +494,7 @@ int main(int argc, char **argv) {
   }
   printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program (means of the others within %.3f); "
          "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %s%d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
-         worst_dm, post[0].ipc[0], post[0].ipc[1], worst, queued ? "one QUEUED batch per tree level (resident beliefs, submit / wait), " : (batched ? "one batched call per tree level, " : ""), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
+         worst_dm, post[0].ipc[0], post[0].ipc[1], worst, queued ? (keep ? "one QUEUED batch per tree level (resident beliefs, submit / wait), the requests KEPT across walks, " : "one QUEUED batch per tree level (resident beliefs, submit / wait), ") : (batched ? "one batched call per tree level, " : ""), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "

@@ -89,6 +89,10 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
     out = subprocess.run([exe, "60", "100", "10", "-1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "60 of 60 posteriors byte-identical" in out.stdout and "QUEUED" in out.stdout, out.stdout
+    # ... and with the requests of every level KEPT across walks (the second walk re-submits what the first one built)
+    out = subprocess.run([exe, "60", "100", "10", "-2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "60 of 60 posteriors byte-identical" in out.stdout and "KEPT across walks" in out.stdout, out.stdout
 
 
 def test_native_graph_init_equals_python_init_all(hip_backend):

@@ -8,3 +8,4 @@ echo "examples/solve_by_clique_calls.c 1000 200 100 <callers> on one MI355X (con
 for c in 1 4 16; do GPU_MAX_HW_QUEUES=$c /tmp/sbcc 1000 200 100 $c 2>&1 | grep -v amdgpu.ids; done
 /tmp/sbcc 1000 200 100 0 2>&1 | grep -v amdgpu.ids
 /tmp/sbcc 1000 200 100 -1 2>&1 | grep -v amdgpu.ids
+/tmp/sbcc 1000 200 100 -2 2>&1 | grep -v amdgpu.ids
