@@ -6,3 +6,6 @@ export LD_LIBRARY_PATH=$R/incrementalinference.jl_amd/csrc:/opt/rocm/lib:$LD_LIB
 export NBP_SEAM_TIMES=1
 /tmp/sbcc 1000 200 100 0 2>&1 | grep -v amdgpu.ids
 /tmp/sbcc 1000 200 100 1 2>&1 | grep -v amdgpu.ids
+# the queued walks (resident beliefs; -2: the requests of every level kept across walks), second walk + the phase clock of a third
+/tmp/sbcc 1000 200 100 -1 2>&1 | grep -v amdgpu.ids
+/tmp/sbcc 1000 200 100 -2 2>&1 | grep -v amdgpu.ids
