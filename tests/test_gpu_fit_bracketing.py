@@ -175,3 +175,25 @@ def test_soak_of_extreme_clouds(seed):
     b, _ = fit(N, man, beliefs, False)
     assert np.all(np.isfinite(a)) and np.all(a > 0)
     np.testing.assert_array_equal(b, a)
+
+
+@pytest.mark.parametrize("config,nvars", [("2", None), ("3", 400), ("5", 600)])
+def test_whole_solve_posteriors_do_not_depend_on_the_bracketing(config, nvars):
+    """bench.py's posterior sha (every particle of every posterior of a full up + down solve) with the bracketed fits and with
+    every evaluation in double precision: the bandwidths are bit-identical, so is everything computed from them
+    (tools/exp/bracketing_whole_solve_sha.sh: the five BASELINE configurations at full size)"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = []
+    for f64 in ("0", "1"):
+        env = dict(os.environ, NBP_BENCH_SHA="1", NBP_FIT_F64=f64)
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-10k",
+               "--no-profile-pass"] + (["--nvars", str(nvars)] if nvars else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        m = re.search(r"sha=([0-9a-f]+)", out.stderr)
+        assert m, out.stderr[-2000:]
+        shas.append(m.group(1))
+    assert shas[0] == shas[1], shas

@@ -23,3 +23,5 @@ R=${GRAFT_REPO_ROOT:-$PWD}
     b=$(NBP_FIT_F64=1 python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-10k --no-profile-pass 2>/dev/null | python -c "import json,sys; print('%.2f' % json.load(sys.stdin)['ms_per_step'])")
     echo "config $c: $a | $b"
   done
+  echo; echo "== tools/exp/bracketing_whole_solve_sha.sh: every posterior of a full solve, bracketed fits against all-double"
+  bash $R/tools/exp/bracketing_whole_solve_sha.sh 2>/dev/null
