@@ -1089,7 +1089,10 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   static const int all_hl = getenv("NBP_PRODUCT_ALL_LEVELS_HL") ? atoi(getenv("NBP_PRODUCT_ALL_LEVELS_HL")) : 8;
   if (!big && HL >= all_hl) {
     const int TOT = c->T.off[c->T.L] + c->T.cnt[c->T.L];
-    const size_t lds_all = product_lds_layout(F, D, c->N, SPB, false, nullptr, nullptr, TOT) + (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
+    // (with the chunk sums of the throughput geometries, which the kernel lays out behind the statistics: without them the
+    //  experiment NBP_PRODUCT_ALL_LEVELS_HL <= 4 ran config 3's products past their LDS -- non-finite posteriors)
+    const size_t lds_all = product_lds_layout(F, D, c->N, SPB, false, nullptr, nullptr, TOT, HL <= 4 ? (size_t)nch * 2 * TB : 0, circ) +
+                           (xs ? 8 + nbp_product_xs_doubles(F, D, c->N) * 8 : 0);
     if (lds_all <= all_cap) { lds = lds_all; flagsF |= NBP_PROD_ALL_LEVELS; }
   }
   nbp_status rc = NBP_OK;
