@@ -1098,7 +1098,7 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
   nbp_status rc = NBP_OK;
   double *gs = nullptr;
   if (big) {
-    rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, D, c->N));
+    rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, 3, c->N));  // (the kernel's stride: largest F of the launch, D = 3)
     if (rc) return rc;
     gs = c->gstats;
   }
@@ -1121,7 +1121,7 @@ static nbp_status presize_products(nbp_ctx *c, int n, int maxFD) {
   const int F = maxFD / 4, D = maxFD % 4;
   if (nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) {
     if (HL != 8) product_geometry(c, 16, &HL, &wpb, &G);
-    rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, D, c->N));
+    rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, 3, c->N));
   }
   return rc;
 }

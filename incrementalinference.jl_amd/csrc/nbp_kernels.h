@@ -1223,7 +1223,11 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   double *out = FUSED ? fio->out : arena + S * d->out_slot;
   const double *wsp = FUSED ? nullptr : ws + (size_t)blockIdx.x * kdF * nbp_kd_ws_doubles(N);
   // node statistics: LDS, or (big) this workgroup's private scratch in global memory
-  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * nbp_product_gstats_doubles(F, D, N) : nullptr;
+  // (the stride is the LAUNCH's -- its largest density count, three coordinates: what launch_products sized the area by.  By the
+  //  product's own count, as it was through round 5, the workgroups of a launch that mixes density counts wrote over each
+  //  other's statistics: products of 3-D manifolds at N >= ~260 with four densities beside smaller ones came out wrong or
+  //  non-finite -- found by the whole-solve differential check, tools/exp/se2_mixed_products.py)
+  double *gs = big ? gstats + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * nbp_product_gstats_doubles(kdF & 0xFFFF, 3, N) : nullptr;
   double *lm = big ? gs : L.lm, *lv = big ? gs + (size_t)F * D * N : L.lv, *lr = big ? gs + 2 * (size_t)F * D * N : L.lr;
   double *lsn = big ? gs + 3 * (size_t)F * D * N : L.ls, *lcs = big ? gs + (3 * (size_t)F * D + F) * N : L.lc;
   double *lgw = big ? gs + (3 * (size_t)F * D + 2 * (size_t)F) * N : L.lg;
