@@ -20,6 +20,9 @@
 #include <stdint.h>
 
 #include "../../include/nbp.h"
+// log / sin / cos / atan2 / wrap of the values that travel from op to op: ONE definition for the kernels and the CPU checker
+// (the header says why; this library is compiled with -ffp-contract=off, one rounding per written operation, for the same reason)
+#include "../../include/nbp_math.h"
 
 #define NBP_PI 3.14159265358979323846
 #define NBP_TWO_PI 6.28318530717958647692
@@ -93,32 +96,21 @@ __device__ __forceinline__ void uniform_pair(uint64_t seed, uint32_t n, uint32_t
 }
 
 __device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs);
+// two standard normals: Box-Muller on the shared log and sincos (include/nbp_math.h) -- the CPU checker's normals bit for bit
 __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k,
                                             double &na, double &nb) {
   double ua, ub;
   uniform_pair(seed, n, purpose, k, ua, ub);
-  double r = sqrt(-2.0 * log(ua));
-  double th = NBP_TWO_PI * ub;
-  double s, c;
-#ifdef NBP_X_FASTSINCOS
-  sincos_fast(th, &s, &c);
-#else
-  sincos(th, &s, &c);
-#endif
-  na = r * c;
-  nb = r * s;
+  nbpm_box_muller(ua, ub, &na, &nb);
 }
 
 // the same as a leaf call (the product sampler draws a point per tree level: inlined, the constants of log and sincos are
 // hoisted out of the level loop and kept live through the Gibbs sweeps -- 40-50 registers spilled at four waves per SIMD)
-// (sincos_fast: the angle is within [0, 2 pi); libm's sincos carries its large-argument reduction along -- a product draws
-//  a point per tree level and sample, the normals were a fifth of its time)
 __device__ __attribute__((noinline)) double2 normal_pair_call(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k) {
-  double ua, ub, s, c;
+  double ua, ub, na, nb;
   uniform_pair(seed, n, purpose, k, ua, ub);
-  const double r = sqrt(-2.0 * log(ua));
-  sincos_fast(NBP_TWO_PI * ub, &s, &c);
-  return make_double2(r * c, r * s);
+  nbpm_box_muller(ua, ub, &na, &nb);
+  return make_double2(na, nb);
 }
 
 // a uniform pair as a leaf call (the latency-mode product kernels hold five manifolds' instances of the sampler at 252-256
@@ -163,49 +155,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: w
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// mod(a + pi, 2pi) - pi.  Sums and differences of wrapped angles stay within a few pi, where fmod is one
-// exact subtraction (Sterbenz), so that range is done with selects -- same roundings as the fmod form,
-// no divergent slow path inside the dependent chains that call this.  Anything larger (or NaN) takes fmod.
-__device__ __forceinline__ double wrap_pi(double a) {
-  const double t = a + NBP_PI;
-  double r = (t >= NBP_TWO_PI) ? t - NBP_TWO_PI : t;
-  r = (t < 0.0) ? t + NBP_TWO_PI : r;
-  double res = (a >= -NBP_PI && a < NBP_PI) ? a : r - NBP_PI;
-  if (!(fabs(a) < 2.9 * NBP_PI)) {
-    double q = fmod(t, NBP_TWO_PI);
-    if (q < 0) q += NBP_TWO_PI;
-    res = q - NBP_PI;
-  }
-  return res;
-}
+// Manifolds.sym_rem -> [-pi, pi): nbpm_wrap_pi (include/nbp_math.h: selects within a few pi, fmod beyond)
+__device__ __forceinline__ double wrap_pi(double a) { return nbpm_wrap_pi(a); }
 
-// sin and cos of an angle of moderate size (|a| < ~1e5; here: sums of a few wrapped angles).  The device library's
-// sincos carries the Payne-Hanek reduction for huge arguments and costs several hundred cycles of a lone wave; the
-// per-particle searches on SE(2) call it at every evaluation of a reverse residual.  Cody-Waite reduction by pi/2 in two
-// parts + the fdlibm kernels (|r| <= pi/4): < 1 ulp, ~35 FP64 operations, no branches.
-__device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) {
-  const double t = fma(a, 6.36619772367581382433e-01, 6755399441055744.0);  // a * 2/pi + 1.5 * 2^52
-  const int k = __double2loint(t);
-  const double kf = t - 6755399441055744.0;
-  double r = fma(kf, -1.57079632673412561417e+00, a);   // pio2_1 (33 bits: k * pio2_1 is exact)
-  r = fma(kf, -6.07710050650619224932e-11, r);          // pio2_1t
-  const double z = r * r;
-  // __kernel_sin
-  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                         -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
-  const double s = fma(r * z, ps, r);
-  // __kernel_cos (the qx form keeps < 1 ulp up to pi/4)
-  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                                          2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-  const double ar = fabs(r);
-  const double qx = (ar > 0.78125) ? 0.28125 : __hiloint2double(__double2hiint(ar) - 0x00200000, 0);
-  const double qq = (ar < 0.3) ? 0.0 : qx;
-  const double c = (1.0 - qq) - ((0.5 * z - qq) - z * pc);
-  const bool swap = k & 1;
-  const double ss = swap ? c : s, cc = swap ? s : c;
-  *sn = (k & 2) ? -ss : ss;
-  *cs = ((k + 1) & 2) ? -cc : cc;
-}
+// sin and cos of an angle of moderate size (|a| < ~1e5; here: sums of a few wrapped angles): nbpm_sincos (include/nbp_math.h) --
+// Cody-Waite reduction by pi/2 in two parts + the fdlibm kernels, ~35 FP64 operations, no branches, no Payne-Hanek path.  The
+// per-particle searches on SE(2) call it at every evaluation of a reverse residual; the CPU checker calls the same function.
+__device__ __forceinline__ void sincos_fast(double a, double *sn, double *cs) { nbpm_sincos(a, sn, cs); }
 
 // exp(x) for x <= ~0 in the O(N^2) kernel sums (arguments are -d^2/(2h^2) or weights relative to
 // their max).  Table-driven: x = (32k + j) ln2/32 + r, |r| <= ln2/64, exp(x) = 2^k * 2^(j/32) * p(r)
@@ -554,7 +510,7 @@ __device__ __forceinline__ double mean_default_coord(const double *x, int N, int
     double s = 0, c = 0;
     if (threadIdx.x < N) sincos_fast(x[threadIdx.x], &s, &c);
     double ss = block_sum(s, red), sc = block_sum(c, red);
-    return atan2(ss, sc);
+    return nbpm_atan2(ss, sc);
   }
   double v = (threadIdx.x < N) ? x[threadIdx.x] : 0.0;
   return block_sum(v, red) / (double)N;
@@ -663,17 +619,19 @@ struct objective_t {
 // The simplex is kept PHYSICALLY sorted by f (vertex 0 = best, vertex DN = worst) with
 // compare-exchange steps on compile-time indices, so every access is a register access (an index
 // permutation `ord[]` makes LLVM spill the simplex to scratch for the runtime-indexed reads).
-// OPT (Optim's own arithmetic, bit for bit): every vertex carries its slot of Optim's simplex array (nm_centroid) and the
-// vertex formulas round once per operation (nm_lin).  Instantiated for the three-dimensional Euclidean searches
-// (NBP_NM_OPTIM_E3); the other searches keep the contracted formulas and the sorted-order centroid -- in two dimensions
-// both are the same search bit for bit, on SE(2) the selects cost 15 % of the proposal time (profiles/r04_nelder_mead_arithmetic.txt)
+// The arithmetic is Optim's, operation for operation (round 6): every vertex formula rounds once per operation (nm_lin; the
+// library is compiled without contraction) and, in three dimensions, every vertex carries its slot of Optim's simplex array so
+// that the centroid is summed in the order Optim's centroid! sums it (nm_centroid).  In two dimensions the coefficients are
+// 2, 1/2, 1/2 and the centroid is a + b: any order and any contraction is the same search bit for bit.  The CPU checker runs
+// the same search from the same start and ends on the same bits (tests/test_gpu_stagewise_parity.py); what it costs is in
+// profiles/r06_nm_optim_order.txt.
 template <int DN, bool OPT>
 __device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1], int i) {
   const bool sw = f[i] < f[i - 1];
   const double fa = f[i - 1], fb = f[i];
   f[i - 1] = sw ? fb : fa;
   f[i] = sw ? fa : fb;
-  if (OPT && DN > 2) {  // the vertex's place in Optim's simplex array travels with it (nm_centroid)
+  if (DN > 2) {  // the vertex's place in Optim's simplex array travels with it (nm_centroid)
     const int ia = id[i - 1], ib = id[i];
     id[i - 1] = sw ? ib : ia;
     id[i] = sw ? ia : ib;
@@ -705,7 +663,7 @@ __device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&
 // oracle's) in the last bit at the first iteration and by ~1e-8 at its end.
 template <int DN, bool OPT>
 __device__ __forceinline__ void nm_centroid(const double (&sx)[DN + 1][DN], const int (&id)[DN + 1], double (&xc)[DN]) {
-  if (OPT && DN == 3) {
+  if (DN == 3) {
     const bool l0 = id[0] > id[1] && id[0] > id[2];
     const bool l1 = !l0 && id[1] > id[2];
 #pragma unroll
@@ -750,17 +708,14 @@ __device__ __forceinline__ bool nm_converged(const double (&f)[DN + 1]) {
   return v <= 1e-16 * (DN + 1);
 }
 
-// a + c * b.  OPT: one rounding per operation, as Julia evaluates Optim's vertex formulas -- a contracted multiply-add differs
-// in the last bit whenever c * b is inexact (beta = 5/3, gamma = 7/12, delta = 2/3 in three dimensions; 2, 1/2, 1/2 in two:
-// exact, which is why the 2-D searches never cared)
+// a + c * b, one rounding per operation, as Julia evaluates Optim's vertex formulas -- a contracted multiply-add differs in the
+// last bit whenever c * b is inexact (beta = 5/3, gamma = 7/12, delta = 2/3 in three dimensions, and 1.5 x + 0.025 of the initial
+// simplex in any; 2, 1/2, 1/2 in two: exact)
 template <bool OPT>
 __device__ __forceinline__ double nm_lin(double a, double c, double b) {
-  if constexpr (OPT) {
-#pragma clang fp contract(off)
-    const double p = c * b;
-    return a + p;
-  } else
-    return fma(c, b, a);  // (spelled out: the same in every instance; exact in two dimensions, where c is a power of two)
+  NBPM_EXACT
+  const double p = c * b;
+  return a + p;
 }
 
 template <class OBJ, int DN, bool OPT = false>
@@ -986,13 +941,6 @@ __device__ __forceinline__ bool bfgs_nd(OBJ &o, double (&x)[DN]) {
 }
 
 // _solveCCWNumeric! for one particle (NumericalCalculations.jl:413-452, :90-133)
-#ifndef NBP_NM_OPTIM_E3
-// Optim's arithmetic bit for bit in the LinearRelative searches on Euclid(3) (config 5): nelder_mead<.., OPT>.  OFF: measured
-// in round 5 on the stage-wise comparison (profiles/r05_nm_optim_order_e3.txt) -- at 2500 mixture variables 4305 instead of 4608
-// of 7.76 M particles beyond 1e-7, 611 instead of 599 of 25 868 fits a golden-section step apart, i.e. nothing, for 72 -> 93 ms
-// of proposals per config-5 solve: what parts the two sides is what goes INTO a search, not the search's arithmetic
-#define NBP_NM_OPTIM_E3 0
-#endif
 #ifdef NBP_SOLVE_NOINLINE
 #define NBP_SOLVE_ATTR __attribute__((noinline))
 #else
@@ -1017,7 +965,7 @@ __device__ NBP_SOLVE_ATTR void solve_particle_t(int manifold, const double *z, c
   bool conv;
   if constexpr (DN == 1) conv = bfgs_1d(o, xc);
   else if constexpr (PARTIAL_BFGS) conv = bfgs_nd<objective_t<KIND, DN>, DN>(o, xc);
-  else conv = nelder_mead<objective_t<KIND, DN>, DN, (NBP_NM_OPTIM_E3 != 0 && DN == 3 && KIND == NBP_F_LINREL)>(o, xc);
+  else conv = nelder_mead<objective_t<KIND, DN>, DN>(o, xc);
   n_solves++;
   n_evals += o.evals;
   if (!conv) n_nonconv++;
@@ -1832,8 +1780,8 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
   const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   const double scs = sgpr_double(sc), ln0 = sgpr_double(lognorm0);
   double x0 = ax, x3 = cx, x1, x2;
-  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = fma(C, cx - bx, bx); }
-  else { x2 = bx; x1 = fma(-C, bx - ax, bx); }
+  if (fabs(cx - bx) > fabs(bx - ax)) { x1 = bx; x2 = bx + C * (cx - bx); }
+  else { x2 = bx; x1 = bx - C * (bx - ax); }
   // one call site for each evaluation (the six pair loops of the double-precision one are inlined once per kernel, not once
   // per call): the two initial values, then one new point per iteration.
   // Bracketing in single precision (neg_loo_ll_f32): e1 / e2 = the error bounds of f1 / f2 (0: a double-precision value).  A
@@ -1867,9 +1815,9 @@ __device__ __forceinline__ double lcv_bandwidth_1d(const double *x, int N, int N
     }
     if (!(fabs(x3 - x0) > tol * (fabs(x1) + fabs(x2)))) break;
     c = f2 < f1;
-    // positions by explicit fma (see golden_step)
-    if (c) { x0 = x1; x1 = x2; x2 = fma(R, x1, C * x3); f1 = f2; e1 = e2; pt = x2; }
-    else { x3 = x2; x2 = x1; x1 = fma(R, x2, C * x0); f2 = f1; e2 = e1; pt = x1; }
+    // positions with one rounding per operation, as Julia evaluates KernelDensityEstimate's golden section (see golden_step)
+    if (c) { x0 = x1; x1 = x2; x2 = R * x1 + C * x3; f1 = f2; e1 = e2; pt = x2; }
+    else { x3 = x2; x2 = x1; x1 = R * x2 + C * x0; f2 = f1; e2 = e1; pt = x1; }
     todo = 2;
   }
   if (ctr && threadIdx.x == 0) {
@@ -1902,12 +1850,12 @@ struct golden_state {
 // the positional update of one iteration given the outcome c = (f2 < f1); returns the point the iteration evaluates
 // (its value belongs in f2 when c, in f1 otherwise)
 __device__ __forceinline__ double golden_step(golden_state &g, bool c, double R, double C) {
-  // one explicit fma per position (hipcc contracts a * b + c wherever it likes, and differently in different
-  // functions): the sequential search and this one then walk through bit-identical positions
-  // Both outcomes as selects (the values of `if (c) {x0 = x1; x1 = x2; x2 = fma(R, x1, C x3); f1 = f2} else {x3 = x2; x2 = x1;
-  // x1 = fma(R, x2, C x0); f2 = f1}`): with branches the compiler merges the conditional stores into "store to field f1 or
+  // one rounding per operation (the library is compiled without contraction): the sequential search, this one and the CPU
+  // checker's walk through bit-identical positions
+  // Both outcomes as selects (the values of `if (c) {x0 = x1; x1 = x2; x2 = R x1 + C x3; f1 = f2} else {x3 = x2; x2 = x1;
+  // x1 = R x2 + C x0; f2 = f1}`): with branches the compiler merges the conditional stores into "store to field f1 or
   // f2" and the whole state goes to scratch (48 B per lane in the speculative kernels)
-  const double up = fma(R, g.x2, C * g.x3), dn = fma(R, g.x1, C * g.x0);
+  const double up = R * g.x2 + C * g.x3, dn = R * g.x1 + C * g.x0;
   const double x0 = c ? g.x1 : g.x0, x1 = c ? g.x2 : dn, x2 = c ? up : g.x1, x3 = c ? g.x3 : g.x2;
   const double f1 = c ? g.f2 : g.f1, f2 = c ? g.f2 : g.f1;
   g.x0 = x0; g.x1 = x1; g.x2 = x2; g.x3 = x3; g.f1 = f1; g.f2 = f2;
@@ -1952,8 +1900,8 @@ __device__ __forceinline__ double lcv_bandwidth_1d_spec(const double *x, int N, 
   const double lognorm0 = 0.5 * log(NBP_TWO_PI) + log((double)(N - 1));
   golden_state g;
   g.x0 = ax; g.x3 = cx;
-  if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = fma(C, cx - bx, bx); }
-  else { g.x2 = bx; g.x1 = fma(-C, bx - ax, bx); }
+  if (fabs(cx - bx) > fabs(bx - ax)) { g.x1 = bx; g.x2 = bx + C * (cx - bx); }
+  else { g.x2 = bx; g.x1 = bx - C * (bx - ax); }
   // uniform state in SGPRs across the evaluations (see lcv_bandwidth_1d)
   const double scs = sgpr_double(sc), ln0 = sgpr_double(lognorm0);
   g.f1 = g.f2 = 0.0;

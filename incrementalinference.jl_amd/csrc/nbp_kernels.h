@@ -78,7 +78,7 @@ __device__ __forceinline__ void sample_measurement(const nbp_proposal_desc *d, i
         while (i < K - 1 && !(ua < tb[N + i])) i++;
         z0 = tb[i];
       } else
-        z0 = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
+        z0 = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * nbpm_log(ua));
     } else {
       double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
       normal_pair(mseed, n, PURP_MEAS, 0, n0, n1);
@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             acc += lm[(q * D + k) * NS + lb + iq] * rq;
         }
         xpr[k] = prec;
-        xmu[k] = (PARTIAL && !(prec > 0)) ? 0.0 : (circ[k] ? atan2(ss, sc) : acc / prec);
+        xmu[k] = (PARTIAL && !(prec > 0)) ? 0.0 : (circ[k] ? nbpm_atan2(ss, sc) : acc / prec);
       }
     };
     const int z0 = (h * cnt) / HL, z1 = ((h + 1) * cnt) / HL;  // this helper's node range (the root, l = 0: nothing to draw)
@@ -1488,7 +1488,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
               if (!use[k]) prec = 1.0;
             }
             vn[k] = 1.0 / prec;
-            mn[k] = circ[k] ? atan2(ss, sc) : acc * vn[k];
+            mn[k] = circ[k] ? nbpm_atan2(ss, sc) : acc * vn[k];
           }
           if (leaf) {
 #pragma unroll

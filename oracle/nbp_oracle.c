@@ -32,6 +32,8 @@
  */
 #define _GNU_SOURCE
 #include "../include/nbp.h"
+#include "../include/nbp_math.h" /* log / sincos / atan2 / wrap of the values that travel from op to op: one definition for
+                                    the checker and the product (the header says why) */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -119,10 +121,7 @@ void orc_uniform_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k, d
 void orc_normal_pair(uint64_t seed, uint32_t n, uint32_t purpose, uint32_t k, double *na, double *nb) {
   double ua, ub;
   orc_uniform_pair(seed, n, purpose, k, &ua, &ub);
-  double r = sqrt(-2.0 * log(ua));
-  double th = TWO_PI * ub;
-  *na = r * cos(th);
-  *nb = r * sin(th);
+  nbpm_box_muller(ua, ub, na, nb); /* sqrt(-2 log ua) (cos, sin)(2 pi ub), include/nbp_math.h */
 }
 
 /* particle count of a belief: a slot holds up to N points, slot[3N + 6] = the count (0 = N) */
@@ -158,12 +157,7 @@ static int mani_P(int m) { return m == NBP_SE2 ? 6 : mani_dim(m); }
 static int is_circ(int m, int d) { return (m == NBP_CIRCULAR && d == 0) || (m == NBP_SE2 && d == 2); }
 
 /* Manifolds.sym_rem: wrap to [-pi, pi) */
-double orc_wrap(double a) {
-  if (a >= -PI && a < PI) return a; /* exact identity on the principal interval */
-  double r = fmod(a + PI, TWO_PI);
-  if (r < 0) r += TWO_PI;
-  return r - PI;
-}
+double orc_wrap(double a) { return nbpm_wrap_pi(a); }
 
 int32_t orc_manifold_dim(int32_t m) { return mani_dim(m); }
 int32_t orc_manifold_P(int32_t m) { return mani_P(m); }
@@ -222,38 +216,149 @@ void orc_slot_read(const double *arena, int32_t N, int32_t slot, int32_t manifol
   if (bw) for (int d = 0; d < D; d++) bw[d] = s[3 * N + d];
 }
 
-/* mean(M, pts, GeodesicInterpolation()) : running geodesic interpolation, Manifolds.jl.
- * services/VariableStatistics.jl:30 */
-static void mean_geodesic_n(int manifold, const double *x, int N, int cnt, double *mu);
-static void mean_geodesic(int manifold, const double *x, int N, double *mu) { mean_geodesic_n(manifold, x, N, N, mu); }
-/* N = stride of the coordinate arrays, cnt = points held */
+/* ------------------------------------------------------------------------------------------ */
+/* Sums in the order the kernels take them.                                                   */
+/* A belief's spread statistics (calcStdBasicSpread, the means of calcVariableDistanceExpectedFractional) go INTO every   */
+/* per-particle search: an ulp of difference there comes out of a 3-D Nelder-Mead search at 1e-9.  A sum of  */
+/* N doubles has no canonical value -- Manifolds.jl's running mean, a pairwise tree and a serial loop all differ in the    */
+/* last bit -- so ONE order is fixed for both sides, the one the device's reductions have: the 64 values of a chunk by the  */
+/* butterfly of a wave (pairs 32 apart, then 16, ... 1), chunks added one after the other (block_sum / wave_chunks_sum in   */
+/* csrc/nbp_device.h); prefix sums in the order of the wave scan (wave_inclusive_scan).  The reference's own definition,     */
+/* the running geodesic mean, stays below as orc_mean_geodesic_walk and tests/test_spread_statistics.py holds the two to     */
+/* 1e-13 of each other.                                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+static double chunked_tree_sum(const double *v, int n) {
+  double tot = 0.0;
+  for (int base = 0; base < n; base += 64) {
+    double t[64];
+    for (int i = 0; i < 64; i++) t[i] = (base + i < n) ? v[base + i] : 0.0; /* idle lanes hold zeros */
+    for (int o = 32; o > 0; o >>= 1)
+      for (int i = 0; i < o; i++) t[i] = t[i] + t[i + o];
+    tot = (base == 0) ? t[0] : tot + t[0];
+  }
+  return tot;
+}
+/* inclusive prefix sums over 64 lanes in the association wave_inclusive_scan() produces them in: three row shifts of the
+ * input, shifts by 4 and 8 of the partial sums inside each row of 16, then the row totals broadcast to the rows behind */
+static void wave_scan64(const double *x, double *s) {
+  double a[64];
+  for (int i = 0; i < 64; i++) {
+    const int r = i & 15;
+    double v = x[i] + (r >= 1 ? x[i - 1] : 0.0);
+    v = v + (r >= 2 ? x[i - 2] : 0.0);
+    v = v + (r >= 3 ? x[i - 3] : 0.0);
+    a[i] = v;
+  }
+  for (int i = 0; i < 64; i++) s[i] = a[i] + ((i & 15) >= 4 ? a[i - 4] : 0.0);
+  for (int i = 0; i < 64; i++) a[i] = s[i] + ((i & 15) >= 8 ? s[i - 8] : 0.0);
+  for (int i = 0; i < 64; i++) s[i] = a[i] + (((i >> 4) & 1) ? a[(i & ~15) - 1] : 0.0); /* row_bcast:15 into rows 1 and 3 */
+  for (int i = 0; i < 64; i++) a[i] = s[i] + ((i >> 5) ? s[31] : 0.0);                   /* row_bcast:31 into rows 2 and 3 */
+  for (int i = 0; i < 64; i++) s[i] = a[i];
+}
+
+/* The reference's definition: mean(M, pts, GeodesicInterpolation()), the running geodesic interpolation of Manifolds.jl
+ * (services/VariableStatistics.jl:30), point by point. */
+double orc_mean_geodesic_walk(const double *x, int cnt, int circ) {
+  double m = x[0];
+  for (int i = 1; i < cnt; i++) {
+    double dl = x[i] - m;
+    if (circ) dl = orc_wrap(dl);
+    m = fma(dl, 1.0 / (double)(i + 1), m);
+    if (circ) m = orc_wrap(m);
+  }
+  return m;
+}
+
+/* The same mean of a circular coordinate, the way the kernels reach it (mean_geodesic_coord, csrc/nbp_device.h):
+ *  (1) every point within an arc shorter than ~pi of the first: no step of the walk wraps, the recurrence is the arithmetic
+ *      mean of the offsets from the first point;
+ *  (2) otherwise the walk's lifts X_i = x_i + 2 pi k_i (k_i puts X_i within pi of the mean of the points before it) are
+ *      iterated to their fixed point with prefix sums -- the head of 64 alone first, then every chunk -- and the mean is the
+ *      sum of the lifted points over the count;
+ *  (3) lifts that have not settled within the kernels' sweep budget: the walk itself. */
+static double mean_geodesic_circ(const double *x, int cnt) {
+  const double x0 = x[0];
+  double *d = (double *)malloc(sizeof(double) * (cnt + 64) * 3), *k = d + cnt + 64, *X = k + cnt + 64;
+  double hi = -INFINITY, lo = -INFINITY, res;
+  for (int i = 0; i < cnt; i++) {
+    d[i] = orc_wrap(x[i] - x0);
+    hi = fmax(hi, d[i]);
+    lo = fmax(lo, -d[i]);
+  }
+  if (hi + lo < 3.0) {
+    const double mo = chunked_tree_sum(d, cnt) / (double)cnt;
+    res = orc_wrap(x0 + mo);
+    free(d);
+    return res;
+  }
+  const int nch = (cnt + 63) / 64;
+  const double r2pi = 1.0 / TWO_PI;
+  for (int i = 0; i < nch * 64; i++) k[i] = 0.0;
+  /* head: the first 64 points alone, up to 24 sweeps */
+  for (int sweep = 0; sweep < 24; sweep++) {
+    double Xh[64], inc[64];
+    int moved = 0;
+    for (int i = 0; i < 64; i++) Xh[i] = (i < cnt) ? fma(TWO_PI, k[i], x[i]) : 0.0;
+    wave_scan64(Xh, inc);
+    for (int i = 1; i < 64 && i < cnt; i++) {
+      const double before = inc[i] - Xh[i];
+      const double kn = k[i] + rint((before / (double)i - Xh[i]) * r2pi);
+      if (kn != k[i]) moved = 1;
+      k[i] = kn;
+    }
+    if (!moved) break;
+  }
+  /* every chunk: up to 32 sweeps; a sweep after which nothing moved holds the sums of the fixed point */
+  int fixed = 0, any_prev = 1;
+  double tot = 0.0;
+  for (int sweep = 0; sweep < 32; sweep++) {
+    double wt[16], inc[16 * 64];
+    for (int i = 0; i < nch * 64; i++) X[i] = (i < cnt) ? fma(TWO_PI, k[i], x[i]) : 0.0;
+    for (int w = 0; w < nch; w++) { wave_scan64(X + 64 * w, inc + 64 * w); wt[w] = inc[64 * w + 63]; }
+    tot = 0.0;
+    for (int w = 0; w < nch; w++) tot += wt[w];
+    if (sweep > 0 && !any_prev) { fixed = 1; break; }
+    int any = 0;
+    double off = 0.0;
+    for (int w = 0; w < nch; w++) {
+      for (int l = 0; l < 64; l++) {
+        const int i = 64 * w + l;
+        if (i < 1 || i >= cnt) continue;
+        const double before = off + inc[i] - X[i];
+        const double kn = k[i] + rint((before / (double)i - X[i]) * r2pi);
+        if (kn != k[i]) any = 1;
+        k[i] = kn;
+      }
+      off += wt[w];
+    }
+    any_prev = any;
+  }
+  res = fixed ? orc_wrap(tot / (double)cnt) : orc_mean_geodesic_walk(x, cnt, 1);
+  free(d);
+  return res;
+}
+
+/* mean(M, pts, GeodesicInterpolation()), services/VariableStatistics.jl:30.  N = stride of the coordinate arrays,
+ * cnt = points held.  Euclidean coordinates: the arithmetic mean (what the running mean is, up to rounding). */
 static void mean_geodesic_n(int manifold, const double *x, int N, int cnt, double *mu) {
   int D = mani_dim(manifold);
-  for (int d = 0; d < D; d++) {
-    double m = x[d * N];
-    for (int i = 1; i < cnt; i++) {
-      double dl = x[d * N + i] - m;
-      if (is_circ(manifold, d)) dl = orc_wrap(dl);
-      m = m + dl * (1.0 / (double)(i + 1)); /* weight as a reciprocal, like the kernel's recurrence */
-      if (is_circ(manifold, d)) m = orc_wrap(m);
-    }
-    mu[d] = m;
-  }
+  for (int d = 0; d < D; d++)
+    mu[d] = is_circ(manifold, d) ? mean_geodesic_circ(x + d * N, cnt) : chunked_tree_sum(x + d * N, cnt) / (double)cnt;
 }
+static void mean_geodesic(int manifold, const double *x, int N, double *mu) { mean_geodesic_n(manifold, x, N, N, mu); }
 
 /* default mean(M, pts): arithmetic on Euclidean coordinates, extrinsic on the circle */
 static void mean_default_n(int manifold, const double *x, int N, int cnt, double *mu) {
   int D = mani_dim(manifold);
   for (int d = 0; d < D; d++) {
     if (is_circ(manifold, d)) {
-      double sc = 0, ss = 0;
-      for (int i = 0; i < cnt; i++) { sc += cos(x[d * N + i]); ss += sin(x[d * N + i]); }
-      mu[d] = atan2(ss, sc);
-    } else {
-      double s = 0;
-      for (int i = 0; i < cnt; i++) s += x[d * N + i];
-      mu[d] = s / cnt;
-    }
+      double *sn = (double *)malloc(sizeof(double) * 2 * cnt), *cs = sn + cnt;
+      for (int i = 0; i < cnt; i++) nbpm_sincos(x[d * N + i], &sn[i], &cs[i]);
+      const double ss = chunked_tree_sum(sn, cnt), sc = chunked_tree_sum(cs, cnt);
+      mu[d] = nbpm_atan2(ss, sc);
+      free(sn);
+    } else
+      mu[d] = chunked_tree_sum(x + d * N, cnt) / (double)cnt;
   }
 }
 static void mean_default(int manifold, const double *x, int N, double *mu) { mean_default_n(manifold, x, N, N, mu); }
@@ -264,19 +369,26 @@ double orc_std_basic_spread(int manifold, const double *x, int N) {
   double mu[3];
   int D = mani_dim(manifold);
   mean_geodesic(manifold, x, N, mu);
-  double acc = 0;
+  double *acc = (double *)malloc(sizeof(double) * N);
   for (int i = 0; i < N; i++) {
+    double a = 0;
     for (int d = 0; d < D; d++) {
       double dl = x[d * N + i] - mu[d];
       if (is_circ(manifold, d)) {
         dl = orc_wrap(dl);
-        acc += (manifold == NBP_SE2 ? 2.0 : 1.0) * dl * dl;
+        a += (manifold == NBP_SE2 ? 2.0 : 1.0) * dl * dl;
       } else
-        acc += dl * dl;
+        a += dl * dl;
     }
+    acc[i] = a;
   }
-  double sg = sqrt(acc / (double)(N - 1));
+  double sg = sqrt(chunked_tree_sum(acc, N) / (double)(N - 1));
+  free(acc);
   return (1e-10 < sg) ? sg : 1.0;
+}
+/* exposed for tests/test_spread_statistics.py */
+double orc_mean_geodesic_device_order(const double *x, int32_t cnt, int32_t circ) {
+  return circ ? mean_geodesic_circ(x, cnt) : chunked_tree_sum(x, cnt) / (double)cnt;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -306,7 +418,8 @@ int32_t orc_residual(int32_t kind, int32_t manifold, const double *z, const doub
     return 1;
   }
   case NBP_F_SE2: { /* Factors/GenericFunctions.jl:39-44 */
-    double c = cos(a[2]), s = sin(a[2]);
+    double c, s;
+    nbpm_sincos(a[2], &s, &c);
     double qx = a[0] + c * z[0] - s * z[1]; /* compose(p, exp(e, X)) */
     double qy = a[1] + s * z[0] + c * z[1];
     double qt = a[2] + z[2];
@@ -851,7 +964,7 @@ static void sample_measurement(const nbp_proposal_desc *d, int n, int zdim, doub
     double ua, ub;
     orc_uniform_pair(mseed, n, PURP_MEAS, 0, &ua, &ub);
     if (cp[12] == (double)NBP_DIST_TABLE) z[0] = table_draw(arena + orc_slot_stride(N) * d->var_slot[NBP_MAXV - 1], N, ua);
-    else z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * log(ua));
+    else z[0] = cp[12] == (double)NBP_DIST_UNIFORM ? fma(cp[4], ua, cp[1]) : cp[4] * sqrt(-2.0 * nbpm_log(ua));
     z[1] = z[2] = 0;
     return;
   }
@@ -1229,9 +1342,8 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     kd_build(x, N, D, pm[j], idx[j], 0, N);
     xs[j] = (double *)malloc(sizeof(double) * 3 * N);
     for (int k = 0; k < D; k++) {
-      double c = 0;
-      for (int i = 0; i < N; i++) c += x[k * N + i];
-      c /= N;
+      /* the centre of the density: the sum in the order the KD build's workgroup reduces it (chunked_tree_sum above) */
+      double c = chunked_tree_sum(x + k * N, N) / (double)N;
       ctr[j][k] = c;
       h2[j][k] = x[3 * N + k] * x[3 * N + k];
       for (int i = 0; i < N; i++) xs[j][k * N + i] = x[k * N + idx[j][i]] - c;
@@ -1291,12 +1403,12 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
             if (!((pm[q] >> k) & 1)) continue;
             double mq = nmean[q][lp][k * cp + ind[q]], rq = nprec[q][lp][k * cp + ind[q]];
             prec += rq;
-            if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
+            if (is_circ(M, k)) { double sq, cq; nbpm_sincos(mq, &sq, &cq); ss += sq * rq; sc += cq * rq; }
             else acc += mq * rq;
           }
           xinf[k] = prec > 0;
           if (!xinf[k]) { xp[k] = 0.0; continue; } /* no density informs this coordinate: it enters no weight */
-          double mu = is_circ(M, k) ? atan2(ss, sc) : acc / prec;
+          double mu = is_circ(M, k) ? nbpm_atan2(ss, sc) : acc / prec;
           double v = mu + sqrt(1.0 / prec) * nn[k];
           xp[k] = is_circ(M, k) ? orc_wrap(v) : v;
         }
@@ -1336,12 +1448,12 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
               if (q == j || !((pm[q] >> k) & 1)) continue;
               double mq = nmean[q][l][k * cnt + ind[q]], rq = nprec[q][l][k * cnt + ind[q]];
               prec += rq;
-              if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
+              if (is_circ(M, k)) { double sq, cq; nbpm_sincos(mq, &sq, &cq); ss += sq * rq; sc += cq * rq; }
               else acc += mq * rq;
             }
             use[k] = ((pm[j] >> k) & 1) && prec > 0;
             vn[k] = 1.0 / prec;
-            mn[k] = is_circ(M, k) ? atan2(ss, sc) : acc * vn[k]; /* getMu: Euclid / getCircMu */
+            mn[k] = is_circ(M, k) ? nbpm_atan2(ss, sc) : acc * vn[k]; /* getMu: Euclid / getCircMu */
           }
           double ua = ub_first[j], ub = 0;
           (void)ub;
@@ -1382,11 +1494,11 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
         if (!((pm[q] >> k) & 1)) continue;
         double mq = nmean[q][T.L][k * cnt + ind[q]], rq = nprec[q][T.L][k * cnt + ind[q]];
         prec += rq;
-        if (is_circ(M, k)) { ss += sin(mq) * rq; sc += cos(mq) * rq; }
+        if (is_circ(M, k)) { double sq, cq; nbpm_sincos(mq, &sq, &cq); ss += sq * rq; sc += cq * rq; }
         else acc += mq * rq;
       }
       if (!(prec > 0)) { res[k * N + s] = old ? old[k * N + s] : 0.0; continue; } /* uninformed coordinate */
-      double mu = is_circ(M, k) ? atan2(ss, sc) : acc / prec;
+      double mu = is_circ(M, k) ? nbpm_atan2(ss, sc) : acc / prec;
       double v = mu + sqrt(1.0 / prec) * nn[k];
       res[k * N + s] = is_circ(M, k) ? orc_wrap(v) : v;
     }

@@ -18,7 +18,10 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "incrementalinference.jl_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=on"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", os.environ.get("NBP_FP_CONTRACT", "-ffp-contract=off")]
+# -ffp-contract=off: ONE ROUNDING PER WRITTEN OPERATION in every kernel -- the arithmetic of the CPU checker (gcc -ffp-contract=off)
+# and of Julia; the multiply-adds that are wanted are explicit fma() calls (round 6: DESIGN.md section 5; +1..2 % per solve,
+# profiles/r06_contract_off_cost.txt)
 HEADERS = [os.path.join(CSRC, h) for h in ("nbp_kernels.h", "nbp_device.h", "nbp_lcv_table.h", "nbp_fused.h")] + \
           [os.path.join(ROOT, "include", h) for h in ("nbp.h", "nbp_host.h")]
 
