@@ -378,6 +378,9 @@ typedef struct nbp_xfer { int32_t peer; int32_t slot; } nbp_xfer;
 nbp_status nbp_comm_unique_id(void *id_out /* NBP_COMM_ID_BYTES */);
 nbp_status nbp_comm_create(nbp_ctx *ctx, int32_t world, int32_t rank, const void *id, nbp_comm **out);
 nbp_status nbp_comm_destroy(nbp_comm *comm);
+/* what RCCL itself says about the communicator: ncclCommCount / ncclCommUserRank (bench.py prints them: a scaling run shows
+ * how many ranks the library's own communicator had, not how many the launcher was asked for) */
+nbp_status nbp_comm_info(nbp_comm *comm, int32_t *nranks_out, int32_t *rank_out);
 nbp_status nbp_exchange(nbp_ctx *ctx, nbp_comm *comm, const nbp_xfer *sends, int32_t n_sends, const nbp_xfer *recvs, int32_t n_recvs);
 
 /* per-kernel timing with HIP events on the library stream (bench.py roofline leg) */
@@ -388,6 +391,12 @@ nbp_status nbp_timing_read(nbp_ctx *ctx, double *ms, int64_t *launches);
 /* the same with n <= 5 entries: 4 = the fused update kernel (NBP_OPT_FUSED_UPDATES); all five are reset by either call */
 nbp_status nbp_timing_read_n(nbp_ctx *ctx, double *ms, int64_t *launches, int32_t n);
 nbp_status nbp_diag_read(nbp_ctx *ctx, nbp_diag *out, int32_t reset);
+
+/* Self-test of the elementary functions the kernels and the CPU checker share (include/nbp_math.h), evaluated ON THE DEVICE:
+ * fn 0: out0 = log(a); 1: (out0, out1) = (sin, cos)(a); 2: out0 = atan2(a, b); 3: out0 = wrap to [-pi, pi) of a;
+ * 4: (out0, out1) = the Box-Muller pair of the uniforms (a, b).  Host buffers of n doubles (b, out1 may be null where unused).
+ * tests/test_gpu_device_math.py compares with the same header compiled by gcc: equal to the last bit. */
+nbp_status nbp_math_eval(nbp_ctx *ctx, int32_t fn, const double *a, const double *b, double *out0, double *out1, int64_t n);
 
 #ifdef __cplusplus
 }

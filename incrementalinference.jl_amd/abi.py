@@ -103,7 +103,7 @@ EXPORTS = [
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
     "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_num_fused", "nbp_program_num_two_stream", "nbp_program_destroy",
     "nbp_timing_enable", "nbp_timing_read", "nbp_timing_read_n", "nbp_diag_read",
-    "nbp_comm_unique_id", "nbp_comm_create", "nbp_comm_destroy", "nbp_exchange",
+    "nbp_comm_unique_id", "nbp_comm_create", "nbp_comm_destroy", "nbp_comm_info", "nbp_exchange", "nbp_math_eval",
 ]
 
 _lib = None
@@ -176,6 +176,8 @@ def load_library(path=None):
     lib.nbp_comm_unique_id.argtypes = [vp]
     lib.nbp_comm_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
     lib.nbp_comm_destroy.argtypes = [vp]
+    lib.nbp_comm_info.argtypes = [vp, ip, ip]
+    lib.nbp_math_eval.argtypes = [vp, i32, dp, dp, dp, dp, i64]
     lib.nbp_exchange.argtypes = [vp, vp, C.POINTER(Xfer), i32, C.POINTER(Xfer), i32]
     lib.nbp_timing_enable.argtypes = [vp, i32]
     lib.nbp_timing_read.argtypes = [vp, dp, C.POINTER(i64)]

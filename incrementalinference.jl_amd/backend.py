@@ -222,6 +222,22 @@ class HipBackend:
         self._comm = h
         return h
 
+    def comm_info(self):
+        """(nranks, rank) as RCCL reports them for the library's communicator"""
+        n, r = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.nbp_comm_info(self._comm, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def math_eval(self, fn, a, b=None):
+        """the shared elementary functions (include/nbp_math.h) evaluated on the device: (out0, out1)"""
+        dp = C.POINTER(C.c_double)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        o0, o1 = np.empty_like(a), np.empty_like(a)
+        self._check(self.lib.nbp_math_eval(self._ctx, fn, a.ctypes.data_as(dp), b.ctypes.data_as(dp) if b is not None else C.cast(None, dp),
+                                           o0.ctypes.data_as(dp), o1.ctypes.data_as(dp), a.size))
+        return o0, o1
+
     def comm_destroy(self):
         if getattr(self, "_comm", None):
             self.lib.nbp_comm_destroy(self._comm)

@@ -2326,6 +2326,8 @@ struct rccl_api {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -2348,6 +2350,8 @@ static nbp_status rccl_load() {
   NBP_RCCL_SYM(GetUniqueId);
   NBP_RCCL_SYM(CommInitRank);
   NBP_RCCL_SYM(CommDestroy);
+  NBP_RCCL_SYM(CommCount);
+  NBP_RCCL_SYM(CommUserRank);
   NBP_RCCL_SYM(GroupStart);
   NBP_RCCL_SYM(GroupEnd);
   NBP_RCCL_SYM(Recv);
@@ -2420,6 +2424,53 @@ nbp_status nbp_comm_destroy(nbp_comm *m) {
   comm_shutdown(m);  // nothing left to do when the context went first
   delete m;
   return NBP_OK;
+}
+
+nbp_status nbp_comm_info(nbp_comm *m, int32_t *nranks_out, int32_t *rank_out) {
+  if (!m || !nranks_out || !rank_out) return fail(NBP_ERR_ARG, "null argument");
+  if (!m->ctx || !m->comm) return fail(NBP_ERR_ARG, "comm_info: the communicator's context was destroyed");
+  int n = 0, r = 0;
+  RCCLCHK(g_rccl.CommCount(m->comm, &n));
+  RCCLCHK(g_rccl.CommUserRank(m->comm, &r));
+  *nranks_out = n;
+  *rank_out = r;
+  return NBP_OK;
+}
+
+// ---- self-test of the shared elementary functions (include/nbp_math.h) on the device -----------------------------------
+__global__ void nbp_math_eval_kernel(int fn, const double *a, const double *b, double *o0, double *o1, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r0 = 0.0, r1 = 0.0;
+  switch (fn) {
+  case 0: r0 = nbpm_log(a[i]); break;
+  case 1: nbpm_sincos(a[i], &r0, &r1); break;
+  case 2: r0 = nbpm_atan2(a[i], b[i]); break;
+  case 3: r0 = nbpm_wrap_pi(a[i]); break;
+  default: nbpm_box_muller(a[i], b[i], &r0, &r1); break;
+  }
+  o0[i] = r0;
+  if (o1) o1[i] = r1;
+}
+nbp_status nbp_math_eval(nbp_ctx *c, int32_t fn, const double *a, const double *b, double *out0, double *out1, int64_t n) {
+  if (!c || !a || !out0) return fail(NBP_ERR_ARG, "null argument");
+  if (fn < 0 || fn > 4) return fail(NBP_ERR_RANGE, "math_eval: fn");
+  if ((fn == 2 || fn == 4) && !b) return fail(NBP_ERR_ARG, "math_eval: this function takes two arguments");
+  if (n <= 0) return NBP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  double *d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(double) * 4 * (size_t)n));
+  nbp_status rc = NBP_OK;
+  do {
+    if (hipMemcpyAsync(d, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(NBP_ERR_HIP, "math_eval: copy in"); break; }
+    if (b && hipMemcpyAsync(d + n, b, sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(NBP_ERR_HIP, "math_eval: copy in"); break; }
+    hipLaunchKernelGGL(nbp_math_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)fn, d, b ? d + n : nullptr, d + 2 * n, d + 3 * n, (long long)n);
+    if (hipMemcpyAsync(out0, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(NBP_ERR_HIP, "math_eval: copy out"); break; }
+    if (out1 && hipMemcpyAsync(out1, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(NBP_ERR_HIP, "math_eval: copy out"); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(NBP_ERR_HIP, "math_eval: synchronize");
+  } while (0);
+  hipFree(d);
+  return rc;
 }
 
 nbp_status nbp_exchange(nbp_ctx *c, nbp_comm *m, const nbp_xfer *sends, int32_t ns, const nbp_xfer *recvs, int32_t nr) {

@@ -84,6 +84,23 @@ void orc_diag_read(orc_diag *out, int reset) {
 
 int64_t orc_slot_stride(int32_t N) { return 3 * (int64_t)N + 8; }
 
+/* the shared elementary functions (include/nbp_math.h) as gcc compiles them: the CPU side of tests/test_gpu_device_math.py
+ * (same numbering as nbp_math_eval, include/nbp.h) */
+void orc_math_eval(int32_t fn, const double *a, const double *b, double *o0, double *o1, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    double r0 = 0.0, r1 = 0.0;
+    switch (fn) {
+    case 0: r0 = nbpm_log(a[i]); break;
+    case 1: nbpm_sincos(a[i], &r0, &r1); break;
+    case 2: r0 = nbpm_atan2(a[i], b[i]); break;
+    case 3: r0 = nbpm_wrap_pi(a[i]); break;
+    default: nbpm_box_muller(a[i], b[i], &r0, &r1); break;
+    }
+    o0[i] = r0;
+    if (o1) o1[i] = r1;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Philox4x32-10 (Salmon et al., SC'11) -- counter-based so that CPU and GPU draw identical     */
 /* streams irrespective of the execution order.                                                */

@@ -49,6 +49,7 @@ CONFIGS = {
     "config5_2500": lambda: iif.generateMixtureChain(nvars=2500, N=300, priorEvery=500),
     "config4_50x100": lambda: iif.generateSE2Lattice(rows=50, cols=100, N=200, closeEvery=5),
     "config5_10000": lambda: iif.generateMixtureChain(nvars=10000, N=300, priorEvery=500),
+    "config3_2000": lambda: iif.generateCircularDoors(nposes=2000, N=200, sightEvery=25),
 }
 DEFAULT = ["config1_scalar_chain", "config2_euclid2_chain", "config3_circular_doors", "config4_se2_lattice", "config5_mixture_chain",
            "config2_1000", "config3_1000", "config4_16x40", "config5_800"]
