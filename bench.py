@@ -107,11 +107,13 @@ def cpu_baseline(iif, nvars, N, thread_counts):
     fg = iif.generateChainEuclid(nvars, vardims=2, priorEvery=100, N=N)
     order = iif.nestedDissectionOrder(fg)
     tree = iif.buildTreeReset(fg, order)
-    iif.initAll(fg, backend=lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=max(thread_counts)), seed=0)
+    iif.initAll(fg, backend=lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=max(thread_counts), nested=True), seed=0)
     tp = iif.TreeProgram(fg, tree, seed=1)
     out = []
     for threads in thread_counts:
-        be = OracleBackend(N, tp.n_slots, 0, threads=threads)
+        # two OpenMP levels: the ops of a stage, and inside an op its particles / samples / likelihood rows on the threads the
+        # stage leaves idle (the stages near the root hold a handful of ops) -- the serial results bit for bit
+        be = OracleBackend(N, tp.n_slots, 0, threads=threads, nested=threads > 1)
         for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
@@ -135,7 +137,39 @@ def timed_steps(rs, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
+def launch_ranks_if_asked():
+    """`python bench.py --gpus N` from a bare environment (no launcher: WORLD_SIZE unset) starts its own N ranks: the process
+    re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on the loopback, one rank per
+    GPU; rank 0 prints the one JSON line to the inherited stdout.  Under a launcher (the driver's torchrun line) nothing
+    happens here: RANK / WORLD_SIZE are taken from the environment as before.  Through round 5 `--gpus` was parsed and never
+    read -- the first scaling run invoked this way would have executed one rank and printed n_gpus: 1."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    gpus = 1
+    argv = sys.argv[1:]
+    for i, tok in enumerate(argv):
+        if tok == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif tok.startswith("--gpus="):
+            gpus = int(tok.split("=", 1)[1])
+    if gpus <= 1:
+        return
+    import socket
+    with socket.socket() as so:  # a free port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
+    launch_ranks_if_asked()
     # stdout carries ONE JSON line: whatever libraries print there (RCCL's version banner, for one) goes to stderr
     # (fd 1 stays redirected until the process ends: RCCL prints its banner from a destructor, after main returns)
     real_stdout = os.dup(1)
@@ -158,6 +192,8 @@ def _main(real_stdout):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and rank == 0:  # (a launcher's world size wins; said once, on stderr)
+        print(f"[bench] --gpus {a.gpus} but the launcher started {world} rank(s): running {world}", file=sys.stderr, flush=True)
     import torch
     import iif_amd_loader
     iif = iif_amd_loader.load()
@@ -237,6 +273,10 @@ def _main(real_stdout):
                    "two_stream_round_min": int(os.environ["NBP_PIPELINE_MIN"]) if os.environ.get("NBP_PIPELINE_MIN") else None,
                    "parallelism": (f"cliques sharded over {world} GPU(s), separator exchange: "
                                    f"{getattr(getattr(rs, 'impl', None), 'transport', 'none')}") if world > 1 else "single GPU"},
+        # how the separator slots travelled between the ranks, and how many ranks RCCL itself counts in the library's communicator
+        # (ncclCommCount through nbp_comm_info; null where no RCCL communicator exists: one rank, or the gloo test transport)
+        "exchange_transport": getattr(getattr(rs, "impl", None), "transport", "none") if world > 1 else "none",
+        "rccl_ranks": getattr(getattr(rs, "impl", None), "rccl_ranks", None),
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": rs.posterior_max_mean_err,
         "posterior_mode_share_min_median": rs.posterior_mode_share,
         "posterior_alias_share_min_median": getattr(rs, "posterior_alias_share", None), "host_setup": rs.host_setup,
@@ -328,13 +368,18 @@ def _main(real_stdout):
         # the port is compiled for THIS host before it is timed (-O3 -march=native; the stock test library is -O2 generic);
         # -ffp-contract=off stays, so its results are the oracle's
         from oracle import oracle_backend as _ob
+        # threads pinned and spread over the cores (read by the OpenMP runtime when the port's library is loaded)
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "threads")
+        os.environ.setdefault("OMP_WAIT_POLICY", "active")
         flags = _ob.use_native_build(f"/tmp/liboracle_native_{os.getpid()}.so") or "-O2 (stock test library: the native build failed)"
-        sweep = cpu_baseline(iif, a.cpu_sample_vars, 200, sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128)}))
+        sweep = cpu_baseline(iif, a.cpu_sample_vars, 200, sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, 256)}))
         v, secs, m, threads = max(sweep)
         out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port", "build": flags,
                                "thread_sweep": {str(t): round(val, 1) for val, _, _, t in sweep},
                                "sample": f"the config-2 chain with {a.cpu_sample_vars} variables, N=200, one full up+down solve "
-                                         f"({m} messages) in {secs:.1f} s, OpenMP over stage ops, best of the thread sweep on a "
+                                         f"({m} messages) in {secs:.1f} s, two OpenMP levels (the ops of a stage; particles, product samples and "
+                                         f"likelihood rows inside an op), threads pinned, best of the thread sweep on a "
                                          f"{ncpu}-thread host, every bandwidth fit made (the port has no dead-fit elimination); "
                                          f"the restatement baseline, not the Julia package (no Julia on the box)"}
         # also the single-thread rate of the same restatement (smaller sample: it is slow)

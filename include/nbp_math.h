@@ -18,9 +18,10 @@
  * product sampler and inside the leave-one-out likelihood of the bandwidth fit -- those values decide comparisons and
  * label draws (integers), they never travel as coordinates.
  *
- * Accuracy (tests/test_nbp_math.py against the host libm on 10^6 arguments each): nbpm_log, nbpm_sincos < 1 ulp,
- * nbpm_atan2 < 1.5 ulp.  Domain: nbpm_log positive normal finite arguments; nbpm_sincos |a| < 1e5 (sums of a few
- * wrapped angles; the reduction is Cody-Waite in two parts, no Payne-Hanek); nbpm_atan2 finite arguments.
+ * Accuracy (tests/test_nbp_math.py against the host libm on 10^6 arguments each): nbpm_log within 1 ulp, nbpm_atan2 within
+ * 1.5 ulp, nbpm_sincos within 1 ulp + |a| * 1e-26 (the reduction carries pi/2 to 86 bits: next to a zero of the function
+ * the error is absolute, not relative).  Domain: nbpm_log positive normal finite arguments; nbpm_sincos |a| < 1e5 (sums of a
+ * few wrapped angles; Cody-Waite in two parts, no Payne-Hanek); nbpm_atan2 finite arguments.
  *
  * The polynomial coefficients and the reduction schemes are the classical ones of Sun's fdlibm (e_log.c, k_sin.c,
  * k_cos.c, s_atan.c: minimax coefficients published with the library), evaluated here in fma-Horner form.

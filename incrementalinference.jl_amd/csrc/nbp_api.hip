@@ -300,6 +300,7 @@ nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *aren
 }
 
 static void program_detach(nbp_program *p);
+static void program_delete(nbp_program *p);  // detach + delete (defined behind the type)
 static void ctx_detach_comms(nbp_ctx *c);
 static void reap_retired(nbp_ctx *c);
 
@@ -321,7 +322,12 @@ nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (c->pin) hipHostFree(c->pin);
   for (auto &b : c->blob_cache) hipFree(b.first);
   c->blob_cache.clear();
-  for (auto &r : c->retired) hipEventDestroy(r.second);  // (the programs themselves were detached with the live ones above)
+  // the programs handed to nbp_program_retire that are still pending: the caller gave up ownership there, so they end here
+  // (the stream was synchronised above: everything they queued has run; detached like the live ones, then deleted)
+  for (auto &r : c->retired) {
+    hipEventDestroy(r.second);
+    program_delete(r.first);
+  }
   c->retired.clear();
   for (nbp_ctx::pin_buf *b : c->pin_pool) {
     if (b->p) hipHostFree(b->p);
@@ -1042,14 +1048,27 @@ static int products_uniform_manifold(const nbp_product_desc *d, int n) {
   }
   return mani > 0 ? mani : 0;
 }
+// ONE answer to "do the node statistics of this product launch fit the LDS" -- asked by the launch itself, by the presizing of
+// its scratch area and by the two-stream guard of nbp_program_finalize, with the same terms: the launch's geometry, the chunk
+// sums the throughput geometries keep in LDS (two chunks per lane at least) and the sin / cos rows of a circular coordinate.
+// (Through round 5 the guard and the presizing left the chunk sums out: a round of Euclid(3) products at N = 300 with five
+//  densities passed the guard, was pipelined, and its halves -- laid out by the geometry of the whole batch, whose kernels
+//  have no scratch path -- ran past the LDS the launch had allocated.)
+static bool product_is_big(nbp_ctx *c, int n, int maxFD, int mani) {
+  int HL, wpb, G;
+  product_geometry(c, n, &HL, &wpb, &G, mani);
+  const int F = maxFD / 4, D = maxFD % 4;  // maxFD encodes the largest (F, D) of the batch as F*4 + D
+  return nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false, HL <= 4 ? (size_t)2 * 2 * wpb * 64 : 0, product_lays_circ(HL, mani)) > NBP_PRODUCT_LDS_CAP;
+}
 static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n, int maxFD, int mani = 0) {
   if (n <= 0) return NBP_OK;
   int HL, wpb, G;
   product_geometry(c, n, &HL, &wpb, &G, mani);
-  // maxFD encodes the largest (F, D) of the batch as F*4 + D
   const int F = maxFD / 4, D = maxFD % 4;
-  // (the throughput geometries keep the chunk sums of their lanes in LDS: two chunks per lane at least)
-  bool big = nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false, HL <= 4 ? (size_t)2 * 2 * wpb * 64 : 0, product_lays_circ(HL, mani)) > NBP_PRODUCT_LDS_CAP;
+  bool big = product_is_big(c, n, maxFD, mani);
+  // (the halves of a two-stream round take the geometry of the whole batch, whose throughput kernels have no scratch path, and
+  //  share one scratch area: nbp_program_finalize pipelines no round whose products are big -- refused here should it ever)
+  if (big && c->geom_n) return fail(NBP_ERR_RANGE, "product: node statistics beyond the LDS inside a two-stream round");
   if (big && HL != 8) {  // many densities: small sample groups keep the label table in LDS
     product_geometry(c, 16, &HL, &wpb, &G);
   }
@@ -1113,14 +1132,16 @@ static nbp_status launch_products(nbp_ctx *c, const nbp_product_desc *dev, int n
 }
 
 // the allocations launch_prep / launch_products would make on demand for a batch of n products
-static nbp_status presize_products(nbp_ctx *c, int n, int maxFD) {
+static nbp_status presize_products(nbp_ctx *c, int n, int maxFD, int mani = 0) {
   nbp_status rc = ensure_ws(c, n, maxFD / 4);
   if (rc) return rc;
-  int HL, wpb, G;
-  product_geometry(c, n, &HL, &wpb, &G, -1);  // (the widest workgroup a kernel may take: the larger label table decides about the scratch)
-  const int F = maxFD / 4, D = maxFD % 4;
-  if (nbp_product_lds_bytes(F, D, c->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) {
+  // the launch's own decision (product_is_big), or the widest workgroup any kernel may take (mani = -1: its larger label table
+  // decides about the scratch) -- whichever asks for the scratch area gets it allocated here, outside the replayed region
+  if (product_is_big(c, n, maxFD, mani) || product_is_big(c, n, maxFD, -1)) {
+    int HL, wpb, G;
+    product_geometry(c, n, &HL, &wpb, &G, mani);
     if (HL != 8) product_geometry(c, 16, &HL, &wpb, &G);
+    const int F = maxFD / 4;
     rc = ensure_gstats(c, (size_t)n * G * nbp_product_gstats_doubles(F, 3, c->N));
   }
   return rc;
@@ -1527,6 +1548,10 @@ static void program_detach(nbp_program *p) {
   if (p->dev) hipFree(p->dev);
   p->dev = nullptr;
   p->ctx = nullptr;
+}
+static void program_delete(nbp_program *p) {
+  program_detach(p);
+  delete p;
 }
 #define PROG_ALIVE(p) do { if (!(p)->ctx) return fail(NBP_ERR_ARG, "the program's context was destroyed"); } while (0)
 
@@ -1984,11 +2009,8 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     nbp_stage &ps = p->stages[s0], &qs = p->stages[s0 + 1];
     if (ps.kind != NBP_STAGE_PROPOSALS || qs.kind != NBP_STAGE_PRODUCTS || ps.pipe_split < 0 || qs.pipe_split < 0) continue;
     if (ps.fused || !qs.need_prep || qs.flush_before) continue;
-    {  // products too large for the LDS share one node-statistics workspace: single stream
-      int HL, wpb, G;
-      product_geometry(p->ctx, qs.n, &HL, &wpb, &G, qs.mani);
-      if (nbp_product_lds_bytes(qs.maxfd / 4, qs.maxfd % 4, p->ctx->N, wpb * 64 / HL, false) > NBP_PRODUCT_LDS_CAP) continue;
-    }
+    // products too large for the LDS share one node-statistics workspace: single stream (the launch's own decision)
+    if (product_is_big(p->ctx, qs.n, qs.maxfd, qs.mani)) continue;
     const nbp_product_desc *qd = (const nbp_product_desc *)(p->blob.data() + qs.offset);
     std::unordered_map<int32_t, int> second;  // slots the second half's products read
     for (int i = qs.pipe_split; i < qs.n; i++)
@@ -2050,7 +2072,7 @@ nbp_status nbp_program_finalize(nbp_program *p) {
   nbp_status rc = NBP_OK;
   for (const nbp_stage &st : p->stages)
     if (st.kind == NBP_STAGE_PRODUCTS && st.n > 0 && !st.fused_second) {
-      rc = presize_products(p->ctx, st.n, st.maxfd);
+      rc = presize_products(p->ctx, st.n, st.maxfd, st.mani);
       if (rc) return rc;
     }
   size_t bytes = p->blob.size() ? p->blob.size() : 64;

@@ -247,10 +247,12 @@ class ShardedTreeSolve:
         self.main = nt.main
         t4 = time.perf_counter()
         self.transport, group = ("none", None)
+        self.rccl_ranks = None
         if self.dist is not None and self.world > 1:
             log = lambda m: print(m, file=sys.stderr, flush=True)
             if self.dist.get_backend() == "nccl" and native_comm(self.be, self.dist, dev, log):
                 self.transport = "rccl-native"
+                self.rccl_ranks = self.be.comm_info()[0]  # ncclCommCount of the library's own communicator
             else:
                 self.transport, group = choose_transport(self.dist, dev, log=log)
         self.runner = ShardedRunner(self.tp, self.be, self.dist, lambda s: self.arena[s * stride:(s + 1) * stride],

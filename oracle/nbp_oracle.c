@@ -61,6 +61,13 @@ typedef struct {
   int64_t solves, nonconverged, nan_results, residual_evals, lcv_evals;
 } orc_diag;
 
+/* Two levels of OpenMP (the CPU baseline of bench.py): the ops of a stage are independent (outer team, orc_run_proposals /
+ * orc_run_products), and inside an op so are the particles of a proposal, the samples of a product and the rows of a
+ * leave-one-out likelihood -- a stage near the root of a tree holds a handful of ops, and without the inner level a 256-thread
+ * host ran them on a handful of cores (round 5: the baseline peaked at 16 threads).  g_inner = threads each op of the running
+ * stage may use (max threads / outer team; 1: serial, the test suite's setting).  Every inner loop is over independent items and
+ * every sum is still taken serially in the same order: the results are the serial ones bit for bit, whatever the thread counts. */
+static int g_inner = 1;
 static orc_diag g_diag;               /* merged totals */
 static __thread orc_diag t_diag;      /* per-thread counters, merged at the end of every op */
 
@@ -886,6 +893,8 @@ static double neg_loo_ll(const double *x, int N, int circ, double h) {
   double inv2h2 = 1.0 / (2.0 * h * h), acc = 0;
   double lognorm = log(h) + 0.5 * log(TWO_PI) + log((double)(N - 1));
   t_diag.lcv_evals++;
+  double term[NBP_MAXN];
+#pragma omp parallel for schedule(static) num_threads(g_inner) if (g_inner > 1)
   for (int i = 0; i < N; i++) {
     double s = 0;
     for (int j = 0; j < N; j++) {
@@ -895,8 +904,9 @@ static double neg_loo_ll(const double *x, int N, int circ, double h) {
       s += exp(-d * d * inv2h2);
     }
     if (s < 1e-300) s = 1e-300;
-    acc += log(s) - lognorm;
+    term[i] = log(s) - lognorm;
   }
+  for (int i = 0; i < N; i++) acc += term[i]; /* the rows added in order: the serial sum */
   return -acc / N;
 }
 
@@ -1185,6 +1195,11 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
           double spread = var_distance_expected_fractional(d, &R, arena, N, X, d->inflation);
           for (int n = 0; n < N; n++)
             if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8 + c) * 2, d->partial_mask);
+          /* (the searches of the particles are independent: the inner OpenMP level of the CPU baseline; every inner thread
+             hands its counters in before the team ends) */
+#pragma omp parallel num_threads(g_inner) if (g_inner > 1)
+          {
+#pragma omp for schedule(dynamic, 4)
           for (int n = 0; n < N; n++) { /* approxConvOnElements!, :14-27 */
             if (mhidx[n] != hyp) continue;
             double x[3], oth[3];
@@ -1215,6 +1230,8 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
             else
               solve_particle(d->factor_kind, d->manifold, Z + 3 * n, oth, solve_b, x);
             for (int k = 0; k < D; k++) X[k * N + n] = x[k];
+          }
+          if (g_inner > 1) diag_merge();
           }
         }
       } else { /* other-hypothesis (:208-220) and nullhypo (:222-231): entropy only */
@@ -1391,6 +1408,8 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
     }
   }
   double *res = (double *)malloc(sizeof(double) * 3 * N);
+  /* (the output samples are independent -- every draw is keyed by the sample index: the inner OpenMP level of the CPU baseline) */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_inner) if (g_inner > 1)
   for (int s = 0; s < N; s++) {
     int ind[NBP_MAXF];
     for (int j = 0; j < F; j++) ind[j] = 0; /* levelInit! / initIndices!: root */
@@ -1591,16 +1610,31 @@ static int team_for(int n) { const int t = omp_get_max_threads(); return n < t ?
 #else
 static int team_for(int n) { (void)n; return 1; }
 #endif
+/* threads each op of a stage of n ops may use inside (g_inner): what the outer team leaves of the host, when the caller asked
+ * for two levels (orc_set_nested) */
+static int g_nested = 0;
+static void set_inner_for(int n) {
+#ifdef _OPENMP
+  const int t = omp_get_max_threads(), team = team_for(n);
+  g_inner = (g_nested && team > 0 && t / team > 1) ? t / team : 1;
+#else
+  (void)n;
+#endif
+}
 int32_t orc_run_proposals(double *arena, int32_t N, int32_t *side, const nbp_proposal_desc *d, int32_t n) {
   int rc = NBP_OK;
+  set_inner_for(n);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
   for (int i = 0; i < n; i++) { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
+  g_inner = 1;
   return rc;
 }
 int32_t orc_run_products(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d, int32_t n) {
   int rc = NBP_OK;
+  set_inner_for(n);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
   for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
+  g_inner = 1;
   return rc;
 }
 int32_t orc_run_deconvs(double *arena, int32_t N, const nbp_proposal_desc *d, const int32_t *meas_slots, int32_t n) {
@@ -1610,14 +1644,18 @@ int32_t orc_run_deconvs(double *arena, int32_t N, const nbp_proposal_desc *d, co
   return rc;
 }
 void orc_set_threads(int32_t n);
+void orc_set_nested(int32_t on);
 void orc_run_copies(double *arena, int32_t N, const nbp_copy_desc *c, int32_t n) {
   for (int i = 0; i < n; i++) orc_run_copy(arena, N, c + i);
 }
 
 #ifdef _OPENMP
+/* two levels of OpenMP (the CPU baseline): on = 1 lets an op use the threads its stage's outer team leaves idle */
+void orc_set_nested(int32_t on) { g_nested = on; omp_set_max_active_levels(on ? 2 : 1); }
 void orc_set_threads(int32_t n) { omp_set_num_threads(n); }
 int32_t orc_get_max_threads(void) { return omp_get_max_threads(); }
 #else
+void orc_set_nested(int32_t on) { (void)on; }
 void orc_set_threads(int32_t n) { (void)n; }
 int32_t orc_get_max_threads(void) { return 1; }
 #endif

@@ -76,7 +76,15 @@ def lib():
         L.orc_uniform_pair.restype = None
         L.orc_normal_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp, dp]
         L.orc_normal_pair.restype = None
+        L.orc_math_eval.argtypes = [i32, dp, dp, dp, dp, C.c_int64]
+        L.orc_math_eval.restype = None
+        L.orc_mean_geodesic_device_order.argtypes = [dp, i32, i32]
+        L.orc_mean_geodesic_device_order.restype = C.c_double
+        L.orc_mean_geodesic_walk.argtypes = [dp, i32, i32]
+        L.orc_mean_geodesic_walk.restype = C.c_double
         L.orc_set_threads.argtypes = [i32]
+        L.orc_set_nested.argtypes = [i32]
+        L.orc_set_nested.restype = None
         L.orc_set_threads.restype = None
         L.orc_get_max_threads.restype = i32
         L.orc_diag_read.argtypes = [C.POINTER(C.c_int64 * 5), i32]
@@ -89,11 +97,24 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def math_eval(fn, a, b=None):
+    """the shared elementary functions (include/nbp_math.h) as gcc compiles them -- same numbering as nbp_math_eval:
+    0 log, 1 sincos, 2 atan2(a, b), 3 wrap to [-pi, pi), 4 Box-Muller of the uniforms (a, b).  -> (out0, out1)"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.zeros_like(a) if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    o0, o1 = np.empty_like(a), np.empty_like(a)
+    lib().orc_math_eval(fn, _dp(a), _dp(b), _dp(o0), _dp(o1), a.size)
+    return o0, o1
+
+
 class OracleBackend:
     name = "oracle"
 
-    def __init__(self, N, n_slots, side_ints=0, threads=1, **_):
+    def __init__(self, N, n_slots, side_ints=0, threads=1, nested=False, **_):
+        """threads: OpenMP team over the independent ops of a stage; nested: a second level inside an op (particles, product
+        samples, likelihood rows) on the threads the stage's team leaves idle -- same results bit for bit either way"""
         self.lib = lib()
+        self.nested = bool(nested)
         self.N, self.n_slots = int(N), int(n_slots)
         self.arena = np.zeros(self.n_slots * abi.slot_stride(self.N))
         self.side = np.zeros(max(int(side_ints), 1), dtype=np.int32)
@@ -152,6 +173,7 @@ class OracleBackend:
 
     def run_proposals(self, descs):
         self.lib.orc_set_threads(self.threads)
+        self.lib.orc_set_nested(1 if self.nested else 0)
         arr, n = self._arr(descs, abi.ProposalDesc)
         rc = self.lib.orc_run_proposals(_dp(self.arena), self.N, self._sidep(), arr, n)
         if rc:
@@ -159,6 +181,7 @@ class OracleBackend:
 
     def run_products(self, descs):
         self.lib.orc_set_threads(self.threads)
+        self.lib.orc_set_nested(1 if self.nested else 0)
         arr, n = self._arr(descs, abi.ProductDesc)
         rc = self.lib.orc_run_products(_dp(self.arena), self.N, self._sidep(), arr, n)
         if rc:
@@ -166,6 +189,7 @@ class OracleBackend:
 
     def run_deconv(self, descs, meas_slots=None):
         self.lib.orc_set_threads(self.threads)
+        self.lib.orc_set_nested(1 if self.nested else 0)
         arr, n = self._arr(descs, abi.ProposalDesc)
         ms = np.ascontiguousarray(meas_slots if meas_slots is not None else [-1] * n, dtype=np.int32)
         rc = self.lib.orc_run_deconvs(_dp(self.arena), self.N, arr, ms.ctypes.data_as(C.POINTER(C.c_int32)), n)

@@ -72,6 +72,30 @@ def test_bench_ranks_sharing_one_gpu(config, size, scaling, world):
         assert d["config"]["variables_per_gpu"] == 300 and d["posterior_max_mean_err"] < 1.5
 
 
+def test_bench_launches_its_own_ranks_from_a_bare_environment():
+    """`python bench.py --gpus 2` with NO launcher around it (no RANK / WORLD_SIZE in the environment): bench.py re-executes
+    itself under torch.distributed.run with two ranks and rank 0 prints the one JSON line.  Through round 5 `--gpus` was parsed
+    and never read: invoked this way a scaling run executed one rank and printed n_gpus: 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--nvars", "300",
+                          "--dist-backend", "gloo", "--no-cpu-baseline", "--no-10k"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, _why(out)
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = _check(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["exchange_transport"] == "staged" and d["rccl_ranks"] is None  # gloo ranks sharing one GPU: no RCCL communicator
+    # and the one-rank line is what it was: no launcher, n_gpus 1, no exchange
+    out1 = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--nvars", "200", "--no-cpu-baseline", "--no-10k"],
+                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out1.returncode == 0, _why(out1)
+    d1 = _check(out1.stdout.strip().splitlines()[-1])
+    assert d1["n_gpus"] == 1 and d1["exchange_transport"] == "none" and d1["rccl_ranks"] is None
+
+
 def _shas(out):
     """{rank: posterior sha} from the `[bench rank N] ... sha=...` lines"""
     import re

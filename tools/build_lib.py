@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # and of Julia; the multiply-adds that are wanted are explicit fma() calls (round 6: DESIGN.md section 5; +1..2 % per solve,
 # profiles/r06_contract_off_cost.txt)
 HEADERS = [os.path.join(CSRC, h) for h in ("nbp_kernels.h", "nbp_device.h", "nbp_lcv_table.h", "nbp_fused.h")] + \
-          [os.path.join(ROOT, "include", h) for h in ("nbp.h", "nbp_host.h")]
+          [os.path.join(ROOT, "include", h) for h in ("nbp.h", "nbp_host.h", "nbp_math.h")]
 
 
 def sources():
@@ -70,7 +70,7 @@ def main():
     def hdr_m(src):
         hs = [h for h in HEADERS if os.path.exists(h)]
         if src.endswith("nbp_host.cpp"):
-            hs = [h for h in hs if os.path.basename(h) in ("nbp.h", "nbp_host.h")]
+            hs = [h for h in hs if os.path.basename(h) in ("nbp.h", "nbp_host.h")]  # (no device code: nbp_math.h is not included)
         elif os.path.basename(src).startswith("nbp_k_"):
             hs = [h for h in hs if os.path.basename(h) != "nbp_host.h"]
         return max(os.path.getmtime(h) for h in hs)
