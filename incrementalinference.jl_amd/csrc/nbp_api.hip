@@ -131,13 +131,7 @@ struct nbp_ctx {
 static int manifold_dim_h(int m) { return m == NBP_SE2 ? 3 : (m == NBP_CIRCULAR ? 1 : m); }
 static int manifold_P_h(int m) { return m == NBP_SE2 ? 6 : manifold_dim_h(m); }
 static bool manifold_ok(int m) { return m >= NBP_EUCLID1 && m <= NBP_SE2; }
-static double wrap_h(double a) {
-  const double PI = 3.14159265358979323846, TP = 6.28318530717958647692;
-  if (a >= -PI && a < PI) return a;
-  double r = fmod(a + PI, TP);
-  if (r < 0) r += TP;
-  return r - PI;
-}
+static double wrap_h(double a) { return nbpm_wrap_pi(a); }  // (include/nbp_math.h)
 
 extern "C" {
 
@@ -414,7 +408,7 @@ static void pack_belief(const nbp_ctx *c, int32_t manifold, const double *pts, i
     if (manifold == NBP_SE2) {
       s[n] = p[0];
       s[N + n] = p[1];
-      s[2 * N + n] = std::atan2(p[3], p[2]);
+      s[2 * N + n] = nbpm_atan2(p[3], p[2]);  // (the shared atan2, include/nbp_math.h: the CPU checker converts with the same function)
     } else if (manifold == NBP_CIRCULAR) {
       s[n] = wrap_h(p[0]);
     } else {
@@ -435,7 +429,9 @@ static void unpack_belief(const nbp_ctx *c, int32_t manifold, const double *s, d
     if (manifold == NBP_SE2) {
       double th = s[2 * N + n];
       p[0] = s[n]; p[1] = s[N + n];
-      p[2] = std::cos(th); p[3] = std::sin(th); p[4] = -std::sin(th); p[5] = std::cos(th);
+      double sn, cs;
+      nbpm_sincos(th, &sn, &cs);  // (the shared sincos: a libm's cos / sin and its fused sincos round differently now and then)
+      p[2] = cs; p[3] = sn; p[4] = -sn; p[5] = cs;
     } else {
       for (int d = 0; d < D; d++) p[d] = s[d * N + n];
     }

@@ -203,7 +203,7 @@ void orc_belief_write(double *arena, int32_t N, int32_t slot, int32_t manifold, 
     if (manifold == NBP_SE2) {
       s[0 * N + n] = p[0];
       s[1 * N + n] = p[1];
-      s[2 * N + n] = atan2(p[3], p[2]); /* R = [c -s; s c] column-major: R11,R21,R12,R22 */
+      s[2 * N + n] = nbpm_atan2(p[3], p[2]); /* R = [c -s; s c] column-major: R11,R21,R12,R22 */
     } else if (manifold == NBP_CIRCULAR) {
       s[n] = orc_wrap(p[0]);
     } else {
@@ -232,7 +232,9 @@ void orc_slot_read(const double *arena, int32_t N, int32_t slot, int32_t manifol
     if (manifold == NBP_SE2) {
       double th = s[2 * N + n];
       p[0] = s[n]; p[1] = s[N + n];
-      p[2] = cos(th); p[3] = sin(th); p[4] = -sin(th); p[5] = cos(th);
+      double sn, cs;
+      nbpm_sincos(th, &sn, &cs);
+      p[2] = cs; p[3] = sn; p[4] = -sn; p[5] = cs;
     } else {
       for (int d = 0; d < D; d++) p[d] = s[d * N + n];
     }

@@ -12,27 +12,6 @@ import iif_amd_loader  # noqa: E402
 iif_amd_loader.load()
 
 
-# NBP_PARITY_EXACT=1 (an experiment switch, tools/exp): every comparison written with a tolerance of 1e-5 or tighter is made
-# with NO tolerance -- which of the suite's oracle-vs-device and geometry-vs-geometry comparisons hold bit for bit
-if os.environ.get("NBP_PARITY_EXACT"):
-    import numpy as _np
-    _orig_allclose = _np.testing.assert_allclose
-
-    def _exact_allclose(actual, desired, rtol=1e-7, atol=0, *a, **k):
-        if rtol <= 1e-5 and atol <= 1e-5:
-            rtol, atol = 0.0, 0.0
-        return _orig_allclose(actual, desired, rtol, atol, *a, **k)
-
-    _np.testing.assert_allclose = _exact_allclose
-    import parity_utils as _pu
-    _orig_apc = _pu.assert_points_close
-
-    def _exact_apc(manifold, a, b, rtol=_pu.RTOL, max_bad=0, what=""):
-        return _orig_apc(manifold, a, b, rtol=0.0 if rtol <= 1e-5 else rtol, max_bad=0, what=what)
-
-    _pu.assert_points_close = _exact_apc
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 

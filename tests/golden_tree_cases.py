@@ -21,12 +21,13 @@ def _config1():
 
 
 TREE_CASES = {
-    # name -> (builder, share of the variables that must be particle-identical on the device, note)
+    # name -> (builder, share of the variables that must be BIT-identical on the device: all of them, on every configuration
+    #          (through round 5 the two configurations with 3-D searches were held to 0.0 and a mean offset))
     "tree_config1_chain6": (_config1, 1.0),
     "tree_config2_euclid2_chain24": (lambda: iif.generateChainEuclid(24, vardims=2, priorEvery=8, N=200), 1.0),
     "tree_config3_circular_doors24": (lambda: iif.generateCircularDoors(nposes=20, N=200, sightEvery=5), 1.0),
-    "tree_config4_se2_lattice8": (lambda: iif.generateSE2Lattice(rows=2, cols=4, N=128, closeEvery=2), 0.0),
-    "tree_config5_mixture_chain10": (lambda: iif.generateMixtureChain(nvars=10, N=300, priorEvery=5), 0.0),
+    "tree_config4_se2_lattice8": (lambda: iif.generateSE2Lattice(rows=2, cols=4, N=128, closeEvery=2), 1.0),
+    "tree_config5_mixture_chain10": (lambda: iif.generateMixtureChain(nvars=10, N=300, priorEvery=5), 1.0),
 }
 
 
@@ -75,7 +76,10 @@ def compare(fg, got, ref, prefix, rtol):
         a, b = ref[f"{prefix}_pts_{v}"], got[f"{prefix}_pts_{v}"]
         d = np.abs(coord_diff(man, a, b))
         scale = np.maximum(1.0, np.abs(coords(man, a)))
-        ok = not (d > rtol * scale).any() and np.allclose(got[f"{prefix}_bw_{v}"], ref[f"{prefix}_bw_{v}"], rtol=max(rtol, 1e-9))
+        if rtol == 0:
+            ok = np.array_equal(a, b) and np.array_equal(got[f"{prefix}_bw_{v}"], ref[f"{prefix}_bw_{v}"])
+        else:
+            ok = not (d > rtol * scale).any() and np.allclose(got[f"{prefix}_bw_{v}"], ref[f"{prefix}_bw_{v}"], rtol=max(rtol, 1e-9))
         (same if ok else other).append(v)
         if not ok:
             ca = coords(man, a)

@@ -1,6 +1,6 @@
 """Shared helpers for the oracle-vs-HIP parity tests: build the same slots and descriptors on both
-backends, run, compare.  Tolerances: identical RNG streams -> per-particle results
-within 1e-9 relative; integer outputs (mhidx, labels) identical."""
+backends, run, compare.  Identical RNG streams -> identical results, floating point included (round 6): RTOL = 0; BASELINE.md 5
+asked for 1e-9 relative per particle."""
 import os
 
 import numpy as np
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 iif = iif_amd_loader.load()
 abi = iif.abi
 
-RTOL = 1e-9
+RTOL = 0.0
 
 
 def rand_points(rng, manifold, N, center=0.0, spread=1.0):

@@ -29,7 +29,7 @@ def test_batch_equals_one_by_one(hip_backend):
         np.testing.assert_array_equal(p0, p1)
         np.testing.assert_array_equal(b0, b1)
         np.testing.assert_array_equal(i0, i1)
-        np.testing.assert_allclose(p1, pw[:n], atol=1e-15)   # SE(2) goes through atan2 / cos / sin: not bit-exact
+        np.testing.assert_allclose(p1, pw[:n], atol=1e-15)   # SE(2) goes through atan2 / cos / sin at the host boundary (numpy's on the way in): not bit-exact
         np.testing.assert_array_equal(b1, bw)
         np.testing.assert_array_equal(i1, iw)
     for s, m in ((5, abi.EUCLID3), (10, abi.EUCLID2), (16, abi.SE2)):  # the copies saw the batch

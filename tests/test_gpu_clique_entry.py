@@ -60,8 +60,10 @@ def test_clique_calls_equal_whole_tree_program(hip_backend, name):
     nbit = 0
     for v in fa.ls():
         man = fa.getVariable(v).varType.manifold
-        assert_points_close(man, fa.getVal(v), post[v].pts, rtol=1e-9, what=f"{name}:{v}")
-        np.testing.assert_allclose(post[v].bw, fa.getVariable(v).bw, rtol=1e-9)
+        # (between clique calls a belief travels in its HOST form -- rotation matrices on SE(2), whose heading comes back from
+        #  atan2(sin, cos) an ulp off now and then -- so this comparison keeps a tolerance; everywhere else it holds bit for bit)
+        assert_points_close(man, fa.getVal(v), post[v].pts, rtol=1e-9 if man == abi.SE2 else 0, what=f"{name}:{v}")
+        np.testing.assert_allclose(post[v].bw, fa.getVariable(v).bw, rtol=1e-9 if man == abi.SE2 else 0)
         nbit += int(np.array_equal(fa.getVal(v), post[v].pts))
         # infoPerCoord: the number of densities of the variable's last update, on every coordinate (ApproxConv.jl:277,298-303)
         D = abi.MANIFOLD_DIM[man]
@@ -96,8 +98,8 @@ def test_level_batches_equal_single_clique_calls(hip_backend, name):
     assert st1 == st2 and set(one) == set(many) == set(fa.ls())
     for v in fa.ls():
         man = fa.getVariable(v).varType.manifold
-        assert_points_close(man, one[v].pts, many[v].pts, rtol=1e-9, what=f"{name}:{v}")
-        np.testing.assert_allclose(one[v].bw, many[v].bw, rtol=1e-9)
+        assert_points_close(man, one[v].pts, many[v].pts, rtol=0, what=f"{name}:{v}")
+        np.testing.assert_allclose(one[v].bw, many[v].bw, rtol=0)
         np.testing.assert_array_equal(one[v].ipc, many[v].ipc)
         if name != "se2_lattice":
             np.testing.assert_array_equal(one[v].pts, many[v].pts)
@@ -135,7 +137,7 @@ def test_joint_messages_through_the_clique_entry(hip_backend, name):
     assert ndiff > 0 or name == "kaess"  # differentials did travel (the Kaess graph's tree sends common priors only)
     for v in fa.ls():
         np.testing.assert_array_equal(fa.getVal(v), post[v].pts, err_msg=f"{name}:{v}")
-        np.testing.assert_allclose(post[v].bw, fa.getVariable(v).bw, rtol=1e-12)
+        np.testing.assert_allclose(post[v].bw, fa.getVariable(v).bw, rtol=0)
 
 
 def test_clique_entry_rejects_bad_input(hip_backend):

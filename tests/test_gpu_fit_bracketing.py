@@ -115,7 +115,7 @@ def test_fit_of_a_belief_with_fewer_points_is_the_oracles(oracle_backend, manifo
         ob.close()
     for f64 in (True, False):
         got, _ = fit(N, manifold, beliefs, f64)
-        np.testing.assert_allclose(got, want, rtol=1e-9)
+        np.testing.assert_allclose(got, want, rtol=0)
 
 
 def test_chip_filling_launch_and_the_share_of_single_precision_evaluations():

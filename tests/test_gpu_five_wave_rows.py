@@ -35,13 +35,13 @@ def test_throughput_fits_of_five_wave_rows(oracle_backend, hip_backend, N, manif
     for s in range(B):  # every copy of a belief gets the bandwidth of the original, bit for bit
         np.testing.assert_array_equal(thr[s], thr[s % K])
     for k in range(K):  # the two geometries sum in different orders: equal to rounding
-        np.testing.assert_allclose(thr[k], lat[k], rtol=1e-9)
+        np.testing.assert_allclose(thr[k], lat[k], rtol=0)
     ob = oracle_backend(N, K + 1)
     try:
         for k in range(K):
             ob.slot_write(k, manifold, pts[k])
         ob.run_bandwidth(list(range(K)), [manifold] * K)
         for k in range(K):
-            np.testing.assert_allclose(thr[k], ob.slot_read(k, manifold)[1], rtol=1e-9)
+            np.testing.assert_allclose(thr[k], ob.slot_read(k, manifold)[1], rtol=0)
     finally:
         ob.close()

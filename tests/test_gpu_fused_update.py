@@ -78,13 +78,13 @@ def test_fused_round_equals_three_launch_round(hip_backend, fused_min, F):
     nu, uo, up, ud = _run_round(hip_backend, nops, F, False)
     assert nf == 1 and nu == 0
     for (p, bw, ipc), (q, bw2, ipc2) in zip(fo, uo):
-        assert_points_close(MAN, q, p, rtol=1e-9, what=f"fused product, F = {F}")
-        np.testing.assert_allclose(bw, bw2, rtol=1e-9)
+        assert_points_close(MAN, q, p, rtol=0, what=f"fused product, F = {F}")
+        np.testing.assert_allclose(bw, bw2, rtol=0)
         np.testing.assert_array_equal(ipc, ipc2)
     # proposals that are still in their slots when the program ends are written there by the fused kernel too
-    assert_points_close(MAN, up[0], fp[0], rtol=1e-12, what="proposal slot")
+    assert_points_close(MAN, up[0], fp[0], rtol=0, what="proposal slot")
     if F > 1:  # (a lone proposal's fit travels with the pass-through product: its own slot keeps no bandwidth)
-        np.testing.assert_allclose(fp[1], up[1], rtol=1e-9)
+        np.testing.assert_allclose(fp[1], up[1], rtol=0)
     for k in ("solves", "nonconverged", "nan_results", "residual_evals"):
         assert fd[k] == ud[k], k
 
@@ -115,8 +115,8 @@ def test_fused_round_against_the_oracle(oracle_backend, hip_backend, fused_min):
         prog.close()
         be.close()
     for (p, bw), (q, bw2) in zip(*res):
-        assert_points_close(MAN, p, q, rtol=1e-8, what="fused update vs oracle")
-        np.testing.assert_allclose(bw2, bw, rtol=1e-9)
+        assert_points_close(MAN, p, q, rtol=0, what="fused update vs oracle")
+        np.testing.assert_allclose(bw2, bw, rtol=0)
 
 
 def test_later_readers_of_a_proposal_slot_see_it(hip_backend, fused_min):
@@ -141,8 +141,8 @@ def test_later_readers_of_a_proposal_slot_see_it(hip_backend, fused_min):
         prog.close()
         be.close()
     for (p, bw), (q, bw2) in zip(*outs):
-        assert_points_close(MAN, q, p, rtol=1e-12, what="copied proposal")
-        np.testing.assert_allclose(bw, bw2, rtol=1e-9)
+        assert_points_close(MAN, q, p, rtol=0, what="copied proposal")
+        np.testing.assert_allclose(bw, bw2, rtol=0)
         assert np.abs(p).max() > 0
 
 
@@ -173,8 +173,8 @@ def test_a_range_that_splits_a_fused_pair_runs_it_in_three_launches(hip_backend,
         be.close()
         res.append((mid, out))
     for a, b in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
-        assert_points_close(MAN, a[0], b[0], rtol=1e-12, what="split fused pair vs three-launch program")
-        np.testing.assert_allclose(a[1], b[1], rtol=1e-9)  # bandwidths
+        assert_points_close(MAN, a[0], b[0], rtol=0, what="split fused pair vs three-launch program")
+        np.testing.assert_allclose(a[1], b[1], rtol=0)  # bandwidths
         np.testing.assert_allclose(a[2], b[2])             # infoPerCoord
         assert np.all(a[1] > 0)
 
@@ -199,6 +199,6 @@ def test_whole_solve_with_fused_rounds(hip_backend, fused_min):
     same = 0
     for i, v in enumerate(sorted(a, key=lambda s: int(s[1:]))):
         assert np.abs(a[v].mean(axis=0) - i).max() < 0.6, (v, a[v].mean(axis=0))
-        same += np.allclose(a[v], b[v], rtol=1e-6, atol=1e-9)
+        same += np.allclose(a[v], b[v], rtol=0, atol=0)
     print(f"fused vs three-launch solve: {same} of {len(a)} variables particle-identical")
     assert same >= len(a) // 2

@@ -1,27 +1,18 @@
-"""-m gpu: the BASELINE.md 5 symmetric-KL figure, GPU solve against oracle solve, on every BASELINE configuration at
-reduced size and on the exact Gaussian chain.  See tests/kl_parity.py for the criterion."""
+"""-m gpu: whole solves, GPU against oracle, on every BASELINE configuration at reduced size -- BIT FOR BIT -- and the
+BASELINE.md 5 symmetric-KL figure against the exact posterior of the Gaussian chain.
+
+Through round 5 this file held the configurations with three-dimensional Nelder-Mead searches (SE(2), Euclid(3)) to a KL
+criterion: 7 % / 4 % of their variables came out particle-identical, the rest were compared with a second oracle solve as a
+yardstick (median KL capped at 0.08 where BASELINE.md 5 says 0.05).  The cause was measured in round 4 and removed in round
+6 ("One arithmetic for the values that travel"): with identical random streams the two sides now
+deliver the same particles and the same bandwidths to the last bit on all five configurations -- graph initialisation, up
+pass and down pass -- so the share floor is 1.0 everywhere, the comparison is np.array_equal, and the KL cap, the
+seed-to-seed yardstick and the ladder of tests/test_gpu_stagewise_parity.py are gone rather than tuned."""
 import numpy as np
 import pytest
 
 import kl_tools
-from kl_parity import compare_solves
 from parity_utils import abi, iif, record_parity
-
-# Floors on the share of variables whose particles agree with the oracle's particle by particle (1e-6) in ONE solve with
-# identical random streams -- below them something other than a rare last-bit branch flip separates the two sides.
-# Observed on MI355X (profiles/r04_whole_solve_parity.txt) minus a margin; a variable that diverged is then held to the
-# two-sample criterion of tests/kl_parity.py.
-# The configurations with THREE-dimensional Nelder-Mead searches (SE(2), Euclid(3)) are the exception, for a measured reason
-# (profiles/r04_nelder_mead_arithmetic.txt, tools/exp/first_divergence.py): a search stops ~1e-4 from the root, and where in
-# that ball is a piecewise-affine function of its start with a heavy-tailed slope -- the ulp-level differences that go into
-# a search (tree reductions against the host's running mean, two libm's) come out of a proposal stage at 1e-9 and grow by
-# ~100 per stage until a product label flips.  (The 2-D searches are bit-robust: their adaptive coefficients are 2, 1/2,
-# 1/2 and their centroid is a + b.)  There the figure that is held is the symmetric KL itself: about BASELINE.md 5's 0.05
-# nats in the median, and no more than 1.5 x what two oracle solves with different seeds read: once the two sides have
-# parted they are independent draws of one algorithm.
-SHARE_FLOOR = {"config1_scalar_chain": 0.9, "config2_euclid2_chain": 0.9, "config3_circular_doors": 0.9,
-               "config4_se2_lattice": 0.0, "config5_mixture_chain": 0.0}
-KL_MEDIAN_CAP = {"config4_se2_lattice": 0.08, "config5_mixture_chain": 0.08}
 
 pytestmark = pytest.mark.gpu
 
@@ -46,25 +37,19 @@ CONFIGS = {
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
-def test_symmetric_kl_gpu_vs_oracle(oracle_backend, hip_backend, name):
+def test_whole_solve_is_the_oracles_bit_for_bit(oracle_backend, hip_backend, name):
     build = CONFIGS[name]
-    fo, fg_, fo2 = build(), build(), build()
+    fo, fg_ = build(), build()
     order = iif.nestedDissectionOrder(fo)
-    iif.solveTree(fo, eliminationOrder=order, backend=oracle_backend, seed=31)
+    iif.solveTree(fo, eliminationOrder=order, backend=oracle_backend, seed=31)   # graph initialisation + up + down
     iif.solveTree(fg_, eliminationOrder=order, backend=hip_backend, seed=31)
-    iif.solveTree(fo2, eliminationOrder=order, backend=oracle_backend, seed=32)
-    share, kl = compare_solves(fo, fg_, fo2)
-    # the yardstick beside it: the same figures for the second oracle solve (another seed) against the first
-    ref = [kl_tools.symmetric_kl(abi, fo.getVariable(v).varType.manifold, fo.getVal(v), fo2.getVal(v)) for v in fo.ls()]
-    line = (f"{name}: {share:.0%} of {len(fo.ls())} variables particle-identical (1e-6) to the oracle solve; symKL of the rest: "
-            f"median {np.median([k for k in kl.values() if k > 0] or [0.0]):.3f} max {max(kl.values()):.3f} nats; "
-            f"oracle vs oracle (another seed): median {np.median(ref):.3f} max {max(ref):.3f}")
+    differ = [v for v in fo.ls() if not (np.array_equal(fo.getVal(v), fg_.getVal(v)) and
+                                         np.array_equal(np.asarray(fo.getVariable(v).bw), np.asarray(fg_.getVariable(v).bw)))]
+    line = (f"{name}: {len(fo.ls()) - len(differ)} of {len(fo.ls())} variables BIT-identical to the oracle solve "
+            f"(particles and bandwidths; graph initialisation + up + down, identical streams)")
     print(line)
     record_parity(line)
-    assert share >= SHARE_FLOOR[name], (name, share)
-    if name in KL_MEDIAN_CAP:
-        rest = [k for k in kl.values() if k > 0]
-        assert np.median(rest) <= KL_MEDIAN_CAP[name] and np.median(rest) <= 1.5 * np.median(ref), (np.median(rest), np.median(ref))
+    assert not differ, (name, differ, {v: float(np.abs(fo.getVal(v) - fg_.getVal(v)).max()) for v in differ[:5]})
 
 
 @pytest.mark.parametrize("seed", [3, 17])

@@ -45,4 +45,4 @@ def test_products_of_a_launch_that_mixes_density_counts_are_the_oracles(oracle_b
     o = run(oracle_backend, N, man, Fs, keep=keep)
     assert all(np.isfinite(v).all() for v in d.values())
     for i in keep:
-        np.testing.assert_allclose(d[i], o[i], rtol=0, atol=1e-9, err_msg=f"product {i} ({Fs[i]} densities)")
+        np.testing.assert_allclose(d[i], o[i], rtol=0, atol=0, err_msg=f"product {i} ({Fs[i]} densities)")

@@ -1,5 +1,7 @@
 """-m gpu: the HIP kernels against the CPU oracle on identical seeded inputs, through the C ABI.
-Floating point: <= 1e-9 relative per particle; integers (mhidx, product labels) identical."""
+Floating point AND integers identical to the last bit (round 6: the values that travel are computed by one arithmetic on both
+sides); the tolerances that remain are against closed forms or across the host boundary's own
+conversions, and say so."""
 import numpy as np
 import pytest
 
@@ -23,7 +25,7 @@ def test_bandwidth_lcv(oracle_backend, hip_backend, manifold, N):
     o, h = both(oracle_backend, hip_backend, N, 2, 0, setup, lambda be: be.run_bandwidth([0], [manifold]),
                 lambda be: be.slot_read(0, manifold))
     assert_points_close(manifold, o[0], h[0], what="slot roundtrip")
-    np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
+    np.testing.assert_allclose(h[1], o[1], rtol=0)
     assert (o[1] > 0).all()
 
 
@@ -46,7 +48,7 @@ def test_prior_proposal(oracle_backend, hip_backend, manifold, kind, nullhypo):
                 lambda be: (be.slot_read(1, manifold), be.side_read(0, N)))
     np.testing.assert_array_equal(o[1], h[1])
     assert_points_close(manifold, o[0][0], h[0][0], what="prior proposal")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
     if nullhypo > 0:
         assert 0 < (o[1] == 0).sum() < N
 
@@ -81,9 +83,9 @@ def test_relative_conv(oracle_backend, hip_backend, kind, manifold, mean, sig, s
     # EuclidDistance has a ring of solutions: Nelder-Mead walks to it from the inflated start, a
     # rare branch flip may move a particle along the ring by more than the tolerance
     max_bad = 2 if kind == abi.F_EUCLIDDIST else 0
-    assert_points_close(manifold, o[0][0], h[0][0], rtol=1e-7 if kind == abi.F_EUCLIDDIST else 1e-9, max_bad=max_bad,
+    assert_points_close(manifold, o[0][0], h[0][0], rtol=0 if kind == abi.F_EUCLIDDIST else 1e-9, max_bad=max_bad,
                         what="relative conv")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-6 if kind == abi.F_EUCLIDDIST else 1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0 if kind == abi.F_EUCLIDDIST else 1e-9)
     # mutation contract: the stored belief of the target is untouched (testMultiHypo3Door.jl:74-90)
     assert_points_close(manifold, h[1][0], b if sfidx == 1 else a, what="target belief untouched")
     assert h[2]["solves"] == 3 * N == o[2]["solves"]
@@ -107,7 +109,7 @@ def test_mixture_and_nullhypo_conv(oracle_backend, hip_backend):
                 lambda be: (be.slot_read(2, manifold), be.side_read(0, N)))
     np.testing.assert_array_equal(o[1], h[1])
     assert_points_close(manifold, o[0][0], h[0][0], what="mixture conv")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
 
 
 @pytest.mark.parametrize("sfidx", [0, 1, 3])
@@ -135,7 +137,7 @@ def test_multihypo_conv_injected_mhidx(oracle_backend, hip_backend, sfidx):
     np.testing.assert_array_equal(h[1], mhidx)
     np.testing.assert_array_equal(o[1], mhidx)
     assert_points_close(manifold, o[0][0], h[0][0], what="multihypo conv")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
 
 
 def test_multihypo_sampled_mhidx_identical(oracle_backend, hip_backend):
@@ -170,7 +172,7 @@ def test_msgprior_proposal(oracle_backend, hip_backend):
     o, h = both(oracle_backend, hip_backend, N, 3, 0, setup, lambda be: be.run_proposals([d]),
                 lambda be: be.slot_read(2, manifold))
     assert_points_close(manifold, o[0], h[0], what="MsgPrior proposal")
-    np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
+    np.testing.assert_allclose(h[1], o[1], rtol=0)
 
 
 @pytest.mark.parametrize("manifold", MANIS)
@@ -194,7 +196,7 @@ def test_manifold_product(oracle_backend, hip_backend, manifold, F):
     assert same.sum() >= N - 1, f"{N - same.sum()} samples picked different labels"
     assert_points_close(manifold, o[0][0][same], h[0][0][same], what="product samples")
     if same.all():
-        np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+        np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
 
 
 def test_product_passthrough_single_density(oracle_backend, hip_backend):
@@ -244,14 +246,14 @@ def test_partial_prior_proposal(oracle_backend, hip_backend, manifold, mask, nul
                 lambda be: (be.slot_read(1, manifold), be.side_read(0, N)))
     np.testing.assert_array_equal(o[1], h[1])
     assert_points_close(manifold, o[0][0], h[0][0], what="partial prior proposal")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
     # coordinates outside the mask keep the target's current values, exactly
     from parity_utils import coords
     D = abi.MANIFOLD_DIM[manifold]
     c0, c1 = coords(manifold, cur), coords(manifold, h[0][0])
     for k in range(D):
         if not (mask >> k) & 1:
-            np.testing.assert_allclose(c1[:, k], c0[:, k], atol=1e-12)
+            np.testing.assert_allclose(c1[:, k], c0[:, k], atol=1e-12)  # (through the host form: a heading round-trips via atan2(sin, cos))
         else:
             assert np.abs(c1[:, k] - c0[:, k]).max() > 1e-3
 
@@ -275,7 +277,7 @@ def test_partial_relative_conv(oracle_backend, hip_backend, manifold, mask, sfid
     o, h = both(oracle_backend, hip_backend, N, 3, 0, setup, lambda be: be.run_proposals([d]),
                 lambda be: be.slot_read(2, manifold))
     assert_points_close(manifold, o[0], h[0], what="partial relative conv")
-    np.testing.assert_allclose(h[1], o[1], rtol=1e-9)
+    np.testing.assert_allclose(h[1], o[1], rtol=0)
     ks = [k for k in range(3) if (mask >> k) & 1]
     tgt, oth = (b, a) if sfidx == 1 else (a, b)
     sign = 1.0 if sfidx == 1 else -1.0
@@ -317,7 +319,7 @@ def test_partial_product(oracle_backend, hip_backend, manifold, masks, N):
                 lambda be: (be.slot_read(out, manifold), be.side_read(0, N * F)))
     np.testing.assert_array_equal(o[1], h[1])
     assert_points_close(manifold, o[0][0], h[0][0], what="partial product")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
     from parity_utils import coords
     D = abi.MANIFOLD_DIM[manifold]
     cov = 0
@@ -364,8 +366,8 @@ def test_deconv(oracle_backend, hip_backend, kind, manifold, mean, sig):
         return be.slot_read(2, zman)[0], be.slot_read(3, zman)[0], be.diag(reset=True)
 
     o, h = both(oracle_backend, hip_backend, N, 4, 0, setup, lambda be: be.run_deconv([d], [3]), read)
-    np.testing.assert_allclose(h[1], o[1], rtol=1e-12, atol=1e-14)  # sampled measurements: same stream
-    np.testing.assert_allclose(h[0], o[0], rtol=1e-9, atol=1e-9)    # predicted measurements
+    np.testing.assert_allclose(h[1], o[1], rtol=0, atol=0)  # sampled measurements: same stream
+    np.testing.assert_allclose(h[0], o[0], rtol=0, atol=0)    # predicted measurements
     assert h[2]["solves"] == N
     # the prediction zeroes the residual: check against the closed forms
     from parity_utils import coords
@@ -481,10 +483,10 @@ def test_differential_factor_program(oracle_backend, hip_backend, kind, manifold
         return [be.slot_read(s, manifold) for s in (2, 3, 4, 5)]
 
     o, h = both(oracle_backend, hip_backend, N, 6, 0, setup, run, read)
-    assert_points_close(manifold, h[0][0], o[0][0], rtol=1e-8, what="predicted measurements")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-6)  # the KDE's bandwidth
+    assert_points_close(manifold, h[0][0], o[0][0], rtol=0, what="predicted measurements")
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)  # the KDE's bandwidth
     for k in (1, 2):  # both convolution directions through the KDE-measurement factor
-        assert_points_close(manifold, h[k][0], o[k][0], rtol=1e-6, max_bad=2, what=f"proposal {k}")
+        assert_points_close(manifold, h[k][0], o[k][0], rtol=0, max_bad=0, what=f"proposal {k}")
     # the forward convolution lands on b's belief
     assert np.abs(coord_diff(manifold, h[1][0], b).mean(axis=0)).max() < 0.2
     assert np.isfinite(h[3][0]).all()
@@ -525,4 +527,4 @@ def test_stored_measurements_gpu(oracle_backend, hip_backend):
     o, h = both(oracle_backend, hip_backend, N, 4, 0, setup, lambda be: be.run_proposals([d1, d2]),
                 lambda be: [be.slot_read(s, man)[0] for s in (2, 3)])
     for k in range(2):
-        assert_points_close(man, h[k], o[k], rtol=1e-8, max_bad=1, what=f"proposal {k}")
+        assert_points_close(man, h[k], o[k], rtol=0, max_bad=0, what=f"proposal {k}")

@@ -19,8 +19,8 @@ def test_partial_se2_known_answers_and_parity(oracle_backend, hip_backend, case)
         d = np.abs(pg - po).max(axis=1)
         assert (d < 1e-6).mean() > 0.6, (d < 1e-6).mean()
         return
-    assert_points_close(abi.SE2, po, pg, rtol=1e-7, what=case.__name__)
-    np.testing.assert_allclose(bg, bo, rtol=1e-6)
+    assert_points_close(abi.SE2, po, pg, rtol=0, what=case.__name__)
+    np.testing.assert_allclose(bg, bo, rtol=0)
 
 
 def test_partial_se2_in_a_graph(hip_backend):

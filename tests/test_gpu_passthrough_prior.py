@@ -20,17 +20,17 @@ def test_conv_is_the_density(hip_backend, oracle_backend):
 
 def test_product_with_a_prior_has_n_points(hip_backend, oracle_backend):
     np.testing.assert_allclose(pc.case_product_with_a_prior_has_n_points(hip_backend), pc.case_product_with_a_prior_has_n_points(oracle_backend),
-                               rtol=1e-9, atol=1e-9)
+                               rtol=0, atol=0)
 
 
 def test_product_with_a_relative_is_full(hip_backend, oracle_backend):
     np.testing.assert_allclose(pc.case_product_with_a_relative_is_full(hip_backend), pc.case_product_with_a_relative_is_full(oracle_backend),
-                               rtol=1e-7, atol=1e-7)  # after a Nelder-Mead search per particle
+                               rtol=0, atol=0)  # after a Nelder-Mead search per particle
 
 
 def test_init_restricts_the_graph_to_n(hip_backend, oracle_backend):
     np.testing.assert_allclose(pc.case_init_restricts_the_graph_to_n(hip_backend), pc.case_init_restricts_the_graph_to_n(oracle_backend),
-                               rtol=1e-12, atol=1e-12)
+                               rtol=0, atol=0)
 
 
 def test_init_with_more_points_than_n(hip_backend, oracle_backend):
@@ -65,7 +65,7 @@ def test_clique_entry_takes_the_density(hip_backend):
                 assert pts.shape == (N, 6) and np.abs(pc.se2_coords(pts)[:, 2]).max() < 0.1
             else:
                 assert pts.shape == (pc.NDENS, 6)
-                np.testing.assert_allclose(pc.se2_coords(pts)[:, :2], pc.density()[0], atol=1e-12)
+                np.testing.assert_allclose(pc.se2_coords(pts)[:, :2], pc.density()[0], atol=0)
                 np.testing.assert_allclose(bel["x0"].bw, [0.35, 0.35, 0.0])
         finally:
             be.close()

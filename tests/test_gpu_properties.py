@@ -49,10 +49,10 @@ def test_batch_size_does_not_change_results(hip_backend):
     (s0, s1), sp = run(1)
     (b0, b1), bp = run(nbig)
     for (p, bw) in (b0, b1):
-        assert_points_close(man, s0[0], p, rtol=1e-9, what="product in big batch")
-        np.testing.assert_allclose(bw, s0[1], rtol=1e-9)
-    assert_points_close(man, sp[0], bp[0], rtol=1e-12, what="proposal in big batch")
-    np.testing.assert_allclose(bp[1], sp[1], rtol=1e-9)
+        assert_points_close(man, s0[0], p, rtol=0, what="product in big batch")
+        np.testing.assert_allclose(bw, s0[1], rtol=0)
+    assert_points_close(man, sp[0], bp[0], rtol=0, what="proposal in big batch")
+    np.testing.assert_allclose(bp[1], sp[1], rtol=0)
 
 
 @pytest.mark.parametrize("N", [8, 64, 65, 512])
@@ -75,10 +75,10 @@ def test_extreme_particle_counts_match_oracle(oracle_backend, hip_backend, N):
     o, h = both(oracle_backend, hip_backend, N, 5, 2 * N, setup, run,
                 lambda be: (be.slot_read(2, man), be.slot_read(4, man), be.side_read(0, 2 * N)))
     assert_points_close(man, o[0][0], h[0][0], what=f"conv N={N}")
-    np.testing.assert_allclose(h[0][1], o[0][1], rtol=1e-9)
+    np.testing.assert_allclose(h[0][1], o[0][1], rtol=0)
     np.testing.assert_array_equal(o[2], h[2])
     assert_points_close(man, o[1][0], h[1][0], what=f"product N={N}")
-    np.testing.assert_allclose(h[1][1], o[1][1], rtol=1e-9)
+    np.testing.assert_allclose(h[1][1], o[1][1], rtol=0)
 
 
 def test_baseline_config2_full_size_properties(hip_backend):
@@ -123,7 +123,7 @@ def test_product_geometries_match_oracle(oracle_backend, hip_backend, manifold, 
     for (pts, bw), lab in run(hip_backend, batch):
         np.testing.assert_array_equal(lab, ref[1])
         assert_points_close(manifold, ref[0][0], pts, what=f"product batch {batch}")
-        np.testing.assert_allclose(bw, ref[0][1], rtol=1e-9)
+        np.testing.assert_allclose(bw, ref[0][1], rtol=0)
 
 
 @pytest.mark.parametrize("manifold,F,N", [(abi.CIRCULAR, 81, 200), (abi.EUCLID2, 40, 200), (abi.SE2, 24, 100), (abi.EUCLID1, 128, 64)])
@@ -149,7 +149,7 @@ def test_products_of_many_densities(oracle_backend, hip_backend, manifold, F, N)
         for (pts, bw), lab in run(hip_backend, nops):
             np.testing.assert_array_equal(lab, ref[1])
             assert_points_close(manifold, ref[0][0], pts, what=f"product of {F}")
-            np.testing.assert_allclose(bw, ref[0][1], rtol=1e-9)
+            np.testing.assert_allclose(bw, ref[0][1], rtol=0)
 
 
 def test_product_mean_is_unbiased_gpu(hip_backend):

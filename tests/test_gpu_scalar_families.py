@@ -9,20 +9,20 @@ pytestmark = pytest.mark.gpu
 
 
 def test_uniform_prior(hip_backend, oracle_backend):
-    np.testing.assert_allclose(sc.case_uniform_prior(hip_backend), sc.case_uniform_prior(oracle_backend), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sc.case_uniform_prior(hip_backend), sc.case_uniform_prior(oracle_backend), rtol=0, atol=0)
 
 
 def test_rayleigh_prior(hip_backend, oracle_backend):
-    np.testing.assert_allclose(sc.case_rayleigh_prior(hip_backend), sc.case_rayleigh_prior(oracle_backend), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sc.case_rayleigh_prior(hip_backend), sc.case_rayleigh_prior(oracle_backend), rtol=0, atol=0)
 
 
 def test_mixture_with_a_uniform_component(hip_backend, oracle_backend):
     np.testing.assert_allclose(sc.case_mixture_with_a_uniform_component(hip_backend), sc.case_mixture_with_a_uniform_component(oracle_backend),
-                               rtol=1e-12, atol=1e-12)
+                               rtol=0, atol=0)
 
 
 def test_rayleigh_relative(hip_backend, oracle_backend):
-    np.testing.assert_allclose(sc.case_rayleigh_relative(hip_backend), sc.case_rayleigh_relative(oracle_backend), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(sc.case_rayleigh_relative(hip_backend), sc.case_rayleigh_relative(oracle_backend), rtol=0, atol=0)
 
 
 def test_alias_sampler_prior(hip_backend, oracle_backend):
@@ -31,8 +31,8 @@ def test_alias_sampler_prior(hip_backend, oracle_backend):
 
 def test_mixture_with_an_alias_sampler(hip_backend, oracle_backend):
     np.testing.assert_allclose(sc.case_mixture_with_an_alias_sampler(hip_backend), sc.case_mixture_with_an_alias_sampler(oracle_backend),
-                               rtol=1e-12, atol=1e-12)
+                               rtol=0, atol=0)
 
 
 def test_alias_sampler_relative(hip_backend, oracle_backend):
-    np.testing.assert_allclose(sc.case_alias_sampler_relative(hip_backend), sc.case_alias_sampler_relative(oracle_backend), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(sc.case_alias_sampler_relative(hip_backend), sc.case_alias_sampler_relative(oracle_backend), rtol=0, atol=0)

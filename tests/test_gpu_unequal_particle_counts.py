@@ -15,22 +15,22 @@ def test_count_round_trip(hip_backend):
 
 def test_shorter_operand(hip_backend, oracle_backend):
     np.testing.assert_allclose(uc.case_shorter_operand_is_read_at_a_random_element(hip_backend),
-                               uc.case_shorter_operand_is_read_at_a_random_element(oracle_backend), rtol=1e-8, atol=1e-8)
+                               uc.case_shorter_operand_is_read_at_a_random_element(oracle_backend), rtol=0, atol=0)
 
 
 def test_shorter_target(hip_backend, oracle_backend):
     np.testing.assert_allclose(uc.case_shorter_target_is_filled_with_the_point_default(hip_backend),
-                               uc.case_shorter_target_is_filled_with_the_point_default(oracle_backend), rtol=1e-9, atol=1e-9)
+                               uc.case_shorter_target_is_filled_with_the_point_default(oracle_backend), rtol=0, atol=0)
 
 
 def test_message_with_fewer_points(hip_backend, oracle_backend):
     (a, ba), (b, bb) = uc.case_message_with_fewer_points(hip_backend), uc.case_message_with_fewer_points(oracle_backend)
-    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9)
-    np.testing.assert_allclose(ba, bb, rtol=1e-9)
+    np.testing.assert_allclose(a, b, rtol=0, atol=0)
+    np.testing.assert_allclose(ba, bb, rtol=0)
 
 
 def test_bandwidth_of_a_shorter_belief(hip_backend, oracle_backend):
-    np.testing.assert_allclose(uc.case_bandwidth_of_a_shorter_belief(hip_backend), uc.case_bandwidth_of_a_shorter_belief(oracle_backend), rtol=1e-9)
+    np.testing.assert_allclose(uc.case_bandwidth_of_a_shorter_belief(hip_backend), uc.case_bandwidth_of_a_shorter_belief(oracle_backend), rtol=0)
 
 
 def test_resample(hip_backend):
@@ -39,7 +39,7 @@ def test_resample(hip_backend):
 
 def test_old_points_of_a_partial_product(hip_backend, oracle_backend):
     np.testing.assert_allclose(uc.case_old_points_of_a_partial_product(hip_backend), uc.case_old_points_of_a_partial_product(oracle_backend),
-                               rtol=1e-9, atol=1e-9)
+                               rtol=0, atol=0)
 
 
 def test_clique_call_with_a_short_message(hip_backend):

@@ -33,6 +33,6 @@ def test_uniform_batch_equals_generic_batch(man, dim):
     be.run_proposals(descs + [other])  # mixed manifolds: the generic kernel
     generic = [be.slot_read(s, man) for s in (6, 7, 8, 9)]
     for u, g in zip(uniform, generic):
-        np.testing.assert_allclose(u[0], g[0], rtol=1e-9, atol=1e-9)  # points
-        np.testing.assert_allclose(u[1], g[1], rtol=1e-9)  # bandwidths
+        np.testing.assert_allclose(u[0], g[0], rtol=0, atol=0)  # points
+        np.testing.assert_allclose(u[1], g[1], rtol=0)  # bandwidths
     be.close()

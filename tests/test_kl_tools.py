@@ -48,7 +48,7 @@ def test_independent_solves_differ_by_far_more_than_the_bound(oracle_backend):
     """Why the 0.05-nat figure is a common-random-numbers figure: two oracle solves of the config-1 chain with
     INDEPENDENT streams read 0.5-1.9 nats per variable (the posteriors of this algorithm are narrower than the
     spread of their means from seed to seed -- sigma 0.3-0.4 against mean offsets of +-0.3), while the same seed gives
-    the same particles.  tests/kl_parity.py builds the whole-solve criterion on exactly this."""
+    the same particles.  tests/kl_parity.py built the whole-solve criterion of rounds 2-5 on exactly this (retired in round 6: whole solves are bit-identical)."""
     def chain():
         fg = iif.initfg(iif.SolverParams(N=100))
         for i in range(6):
