@@ -278,6 +278,7 @@ def _main(real_stdout):
         "exchange_transport": getattr(getattr(rs, "impl", None), "transport", "none") if world > 1 else "none",
         "rccl_ranks": getattr(getattr(rs, "impl", None), "rccl_ranks", None),
         "solve_wall_s": dt / a.steps, "posterior_max_mean_err": rs.posterior_max_mean_err,
+        "posterior_baseline5_band_share": getattr(rs, "posterior_baseline5_band_share", None),
         "posterior_mode_share_min_median": rs.posterior_mode_share,
         "posterior_alias_share_min_median": getattr(rs, "posterior_alias_share", None), "host_setup": rs.host_setup,
     }

@@ -32,8 +32,31 @@ def door_alias_share(angles, i, sight_every=25, halfwidth=0.5):
 
 
 class Workload:
-    def __init__(self, key, name, N, size, build, truth, tol, unit_name):
+    def __init__(self, key, name, N, size, build, truth, tol, unit_name, band=None):
         self.key, self.name, self.N, self.size, self.build, self.truth, self.tol, self.unit_name = key, name, N, size, build, truth, tol, unit_name
+        self.band = band  # band(label, size_total, N) -> BASELINE.md 5's own per-pose band 3 sigma_post / sqrt(N) + 0.1 scale (reported, not gating)
+
+
+_CHAIN_SIGMA = {}
+
+
+def chain_exact_sigma(n, prior_every=100, sigma=0.1):
+    """exact posterior standard deviation (per coordinate) of every pose of the config-2 chain: priors of `sigma` at every
+    `prior_every`-th pose, odometry of `sigma` between neighbours -- a linear-Gaussian chain: information from the left and from
+    the right by two recursions"""
+    key = (n, prior_every, sigma)
+    if key not in _CHAIN_SIGMA:
+        q, ip = sigma * sigma, 1.0 / (sigma * sigma)
+        has = np.array([i % prior_every == 0 for i in range(n)])
+        left, right = np.zeros(n), np.zeros(n)   # information about pose i from poses < i / > i (their priors, through the odometry)
+        for i in range(1, n):
+            li = left[i - 1] + (ip if has[i - 1] else 0.0)
+            left[i] = 1.0 / (1.0 / li + q) if li > 0 else 0.0
+        for i in range(n - 2, -1, -1):
+            ri = right[i + 1] + (ip if has[i + 1] else 0.0)
+            right[i] = 1.0 / (1.0 / ri + q) if ri > 0 else 0.0
+        _CHAIN_SIGMA[key] = 1.0 / np.sqrt(left + right + np.where(has, ip, 0.0))
+    return _CHAIN_SIGMA[key]
 
 
 def workloads(iif):
@@ -55,6 +78,20 @@ def workloads(iif):
 
     def truth_chain(v, n):
         return np.array([float(v[1:])] * 2) if v.startswith("x") else None
+
+    def band_chain(v, n, N):
+        # BASELINE.md 5, Gaussian-posterior configurations: |mean - truth| <= 3 sigma_post / sqrt(N) + 0.1 scale (scale = the factors' sigma)
+        return 3.0 * float(chain_exact_sigma(n)[int(v[1:])]) / np.sqrt(N) + 0.1 * 0.1
+
+    def tol_chain(v, n):
+        # What is ACCEPTED (Amendments, "Config 2, mean band"): the band above assumes the posterior mean is estimated from
+        # N independent draws of the exact posterior; the reference's algorithm delivers a belief that is narrower than the exact
+        # posterior around a centre that itself moves from solve to solve (the down solve multiplies pre-solve
+        # beliefs in; measured on 64 poses x 20 seeds, oracle and device bit for bit: centre offsets up to 0.7 sigma_post) -- so
+        # the gate is 0.1 + sigma_post of the pose (0.2 next to a prior, 0.6 midway between two), and the share of the sampled poses
+        # inside BASELINE's own band is reported beside it (`posterior_baseline5_band_share`).  A sign or index error in a factor
+        # puts a pose whole units off.
+        return 0.1 + float(chain_exact_sigma(n)[int(v[1:])])
 
     def truth_lattice(v, rows):
         k = int(v[1:])
@@ -86,8 +123,8 @@ def workloads(iif):
         return max(6.0, 1.0 + 1.5 * float(np.sqrt(0.208 * d)))
 
     return {
-        "2": Workload("2", "config 2: ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 1000, chain2, truth_chain, 1.0, "variables"),
-        "2p": Workload("2p", "config 2' (north-star target): ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 10000, chain2, truth_chain, 1.0, "variables"),
+        "2": Workload("2", "config 2: ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 1000, chain2, truth_chain, tol_chain, "variables", band=band_chain),
+        "2p": Workload("2p", "config 2' (north-star target): ContinuousEuclid(2) {size}-variable odometry chain + priors every 100", 200, 10000, chain2, truth_chain, tol_chain, "variables", band=band_chain),
         "3": Workload("3", "config 3: Circular {size}-pose chain, 4 door landmarks, multihypo sightings every 25 poses", 200, 2000, doors, None, None, "poses"),
         "4": Workload("4", "config 4: SE(2) {size}x100 boustrophedon lattice with loop closures every 5th column", 200, 50, lattice, truth_lattice, 2.0, "rows"),
         "5": Workload("5", "config 5: ContinuousEuclid(3) {size}-variable chain of Mixture(LinearRelative, [0.8, 0.2]) factors, priors every 500", 300, 10000, mixture, truth_mix, tol_mix, "variables"),
@@ -201,6 +238,7 @@ class RankSolve:
         poses = [v for v in self.mine if v.startswith("x")]
         sample = poses[:: max(1, len(poses) // 64)]
         worst, shares, alias, bad = 0.0, [], [], None
+        in_band = []
         for v in sample:
             man = fg.getVariable(v).varType.manifold
             pts, bw = self.be.slot_read(self.main[v], man)
@@ -211,6 +249,8 @@ class RankSolve:
                 err = float(np.abs(pts[:, :len(t)].mean(axis=0) - t).max())
                 worst = max(worst, err)
                 tol = wl.tol(v, self.size_total) if callable(wl.tol) else wl.tol
+                if wl.band is not None:
+                    in_band.append(err <= wl.band(v, self.size_total, self.N))
                 if not err < tol and bad is None:
                     bad = (v, f"mean off by {err}", tol)
             else:
@@ -221,6 +261,8 @@ class RankSolve:
                 if i < 25 and shares[-1] < 0.6 and bad is None:
                     bad = (v, shares[-1], "share of the particles at the true pose >= 0.6")
         self.posterior_max_mean_err = worst if wl.truth is not None else None
+        # share of the sampled poses whose mean is inside BASELINE.md 5's own band (reported; the gate is wl.tol, see there)
+        self.posterior_baseline5_band_share = float(np.mean(in_band)) if in_band else None
         self.posterior_mode_share = (float(np.min(shares)), float(np.median(shares))) if shares else None
         self.posterior_alias_share = (float(np.min(alias)), float(np.median(alias))) if alias else None
         if alias and not (np.min(alias) >= 0.6 and np.median(alias) >= 0.9) and bad is None:
