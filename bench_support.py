@@ -85,13 +85,15 @@ def workloads(iif):
 
     def tol_chain(v, n):
         # What is ACCEPTED (Amendments, "Config 2, mean band"): the band above assumes the posterior mean is estimated from
-        # N independent draws of the exact posterior; the reference's algorithm delivers a belief that is narrower than the exact
-        # posterior around a centre that itself moves from solve to solve (the down solve multiplies pre-solve
-        # beliefs in; measured on 64 poses x 20 seeds, oracle and device bit for bit: centre offsets up to 0.7 sigma_post) -- so
-        # the gate is 0.1 + sigma_post of the pose (0.2 next to a prior, 0.6 midway between two), and the share of the sampled poses
-        # inside BASELINE's own band is reported beside it (`posterior_baseline5_band_share`).  A sign or index error in a factor
-        # puts a pose whole units off.
-        return 0.1 + float(chain_exact_sigma(n)[int(v[1:])])
+        # N independent draws of the exact posterior; the reference's algorithm delivers a belief around a centre that itself moves
+        # from solve to solve (the down solve multiplies pre-solve beliefs in).  Measured on all 1000 poses x 20
+        # solve seeds (profiles/r06_config2_mean_wander.txt; oracle and device are the same bits): |mean - truth| / sigma_post median
+        # 0.20, 95 % 0.60, 99.9 % 1.54, max 2.0; 60 % of the (seed, pose) pairs inside BASELINE's own band; sample std within
+        # [0.5, 2] sigma_post for 92 %.  The gate is 0.1 + 2 sigma_post of the pose (0.3 next to a prior, 1.1 midway between two
+        # priors, 2.1 at the open end of the chain) -- the flat 1.0 of rounds 1-5 was looser next to the priors and tighter at the
+        # open end -- and the share of the sampled poses inside BASELINE's own band is reported beside it
+        # (`posterior_baseline5_band_share`).  A sign or index error in a factor puts a pose whole units off.
+        return 0.1 + 2.0 * float(chain_exact_sigma(n)[int(v[1:])])
 
     def truth_lattice(v, rows):
         k = int(v[1:])

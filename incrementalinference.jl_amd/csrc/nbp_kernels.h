@@ -1259,6 +1259,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
   int npass = 1;
   for (int n2_ = N; n2_ > 1; n2_ >>= 1) npass++;
   if (npass < T.L) npass = T.L;
+  int Lc = 0;  // the coarse levels 0 .. Lc share one staging (below): as many as one row of the statistics holds
+  while (Lc + 1 <= T.L && T.off[Lc + 1] + T.cnt[Lc + 1] <= N) Lc++;
   for (int ps = 0; ps <= npass + 1; ps++) {
     const int l = ps < T.L ? ps : T.L;  // the tree level of this pass
     if (ps > 0 && live) {  // samplePoint!
@@ -1280,13 +1282,23 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
     NBP_CTICK(47);  // samplePoint!: the normals
     if (ps > npass) break;
     const int cnt = T.cnt[l], off = T.off[l];
-    const int lb = all ? off : 0;  // where this level's nodes start in a row of the statistics
-    if ((!all || ps == 0) && ps <= T.L) {  // (a repeated leaf pass finds its statistics in place)
+    // THE COARSE LEVELS TOGETHER (round 6): the levels 0 .. Lc whose nodes fit one row of N statistics between them (N = 200:
+    // 1 + 2 + ... + 64 = 127 nodes, levels 0 .. 6 of 8) are staged in ONE go in front of the first pass, at row position = node
+    // index, and the waves then walk them without a barrier between the levels; only the fine levels (128 and 200 nodes) are
+    // staged one by one.  A level's staging is two loops, three barriers and a dependent chain of table reads whatever its node
+    // count -- six of nine of them per product were spent on levels whose draws take a few hundred cycles.  Same statistics,
+    // same draws: only where a level's nodes sit in the row changes (`lb`).
+#ifndef NBP_X_COARSE_BLOCK
+#define NBP_X_COARSE_BLOCK 1
+#endif
+    const bool inblock = !all && NBP_X_COARSE_BLOCK && l <= Lc;
+    const int lb = (all || inblock) ? off : 0;  // where this level's nodes start in a row of the statistics
+    if ((all ? ps == 0 : (ps == 0 || !inblock)) && ps <= T.L) {  // (a repeated leaf pass finds its statistics in place)
     __syncthreads();
     NBP_CTICK(40);  // staging (first level) / Gibbs draws of the previous level
-    // node statistics: of this level, or (resident levels) of every level at once -- node g of the tree at row position
-    // g - g0 + (all ? 0 : 0): a level's nodes are contiguous in the tree's node arrays
-    const int g0 = all ? 0 : off, gn = all ? TOT : cnt;
+    // node statistics: of this level, of the coarse levels together, or (resident levels) of every level at once -- node g
+    // of the tree at row position g - g0: a level's nodes are contiguous in the tree's node arrays
+    const int g0 = (all || inblock) ? 0 : off, gn = all ? TOT : (inblock ? T.off[Lc] + T.cnt[Lc] : cnt);
     for (int item = tid; item < F * D * gn; item += TB) {
       const int z = item % gn, jk = item / gn, g = g0 + z;
       const int lo = T.node_lo[g], hi = T.node_hi[g];
