@@ -286,6 +286,7 @@ static int level_queued(host *H, nbp_ctx *ctx, int d, int down, queued_level *Q,
     Q->built = 1;
   }
   Q->t = NULL;
+  for (int i = 0; i < Q->n; i++) Q->R[i].seed = H->seed; /* (kept requests: this walk's seed) */
   CHK(nbp_resident_copy(ctx, Q->ncp0, Q->cp0_src, Q->cp0_dst, 0)); /* up: the deep copies of this level's sub graphs */
   CHK(nbp_resident_copy(ctx, Q->npp0, Q->pp0_src, Q->pp0_dst, 1)); /* down: the parents' values of this level's separators */
   CHK(nbp_clique_submit_batch(ctx, Q->R, Q->n, &Q->t));
@@ -439,11 +440,20 @@ int main(int argc, char **argv) {
   for (int v = 0; v < nvars; v++) { graph0[v] = belief_new(); belief_copy(&graph0[v], &graph[v]); }
   double t_first = 0;
   const int seam_timing = getenv("NBP_SEAM_TIMES") != NULL; /* a third walk with the library's phase clock on */
-  double t_timed = 0, ph[6] = {0}, t_queued = 0;
-  for (int pass = 0; pass < 2 + seam_timing && !failed; pass++) { /* the second walk runs with every buffer of the library at its final size */
+  double t_timed = 0, ph[6] = {0}, t_queued = 0, t_queued_calls = 0, t_walk[16] = {0};
+  /* walks: the second runs with every buffer of the library at its final size; a queued walk of an unchanged tree is, from its
+   * second submission on, a cached program per level with new seeds (the library's plan cache), and from the third a hipGraph
+   * launch per level -- so the queued modes walk four times and report the last (NBP_WALKS overrides) */
+  int nwalks = getenv("NBP_WALKS") ? atoi(getenv("NBP_WALKS")) : (queued ? 4 : 2);
+  if (nwalks < 2) nwalks = 2;
+  if (nwalks > 15) nwalks = 15;
+  for (int pass = 0; pass < nwalks + seam_timing && !failed; pass++) {
   for (int v = 0; v < nvars; v++) belief_copy(&graph[v], &graph0[v]);
+  /* NBP_WALK_SEEDS=1: every walk but the last two with a seed of its own (a cached level program is re-seeded, nbp_program_set_seeds);
+   * the last walks use the whole-tree program's seed again, and their posteriors must be its bytes */
+  H.seed = seed + ((getenv("NBP_WALK_SEEDS") && pass + 1 < nwalks) ? 1000u * (unsigned)(pass + 1) : 0u);
   for (int c = 1; c <= ncl && pass && !queued; c++) { for (int i = 0; i < H.info[c].nfrontals + H.info[c].nseparators; i++) free(H.sub[c][i].pts); free(H.sub[c]); }
-  if (pass == 2) nbp_clique_seam_times(NULL, 2);
+  if (pass == nwalks) nbp_clique_seam_times(NULL, 2);
   const double tb = now_s();
   if (queued) {
     /* the graph goes to the device once, every level of both passes is queued behind it, ONE wait, the posteriors come back once */
@@ -475,7 +485,8 @@ int main(int argc, char **argv) {
     for (int c = 1; c <= ncl; c++)
       if (H.depth[c] == d) failed |= down_clique(&H, &W[omp_get_thread_num()], c);
   }
-  if (!pass) t_first = now_s() - tb; else if (pass == 1) t_calls = now_s() - tb; else { t_timed = now_s() - tb; nbp_clique_seam_times(ph, 1); }
+  t_walk[pass] = now_s() - tb;
+  if (!pass) t_first = now_s() - tb; else if (pass < nwalks) { t_calls = now_s() - tb; t_queued_calls = t_queued; } else { t_timed = now_s() - tb; nbp_clique_seam_times(ph, 1); }
   }
   if (failed) return 4;
   for (int t = 1; t < threads; t++) nbp_ctx_destroy(W[t].ctx);
@@ -498,11 +509,16 @@ int main(int argc, char **argv) {
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "
-         "(the second walk; the first, while the library's buffers grow: %.1f ms)\n",
-         t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls, t_first * 1e3);
+         "(walk %d of %d; the first, while the library's buffers grow: %.1f ms)\n",
+         t_resident * 1e3, t_replay * 1e3, msgs / t_replay, t_io * 1e3, msgs / (t_replay + t_io), t_calls * 1e3, msgs / t_calls, nwalks, nwalks, t_first * 1e3);
+  if (nwalks > 2) {
+    printf("  walks in order:");
+    for (int i = 0; i < nwalks; i++) printf(" %.1f", t_walk[i] * 1e3);
+    printf(" ms\n");
+  }
   if (queued)
     printf("  queued walk: all %d batches submitted after %.1f ms of host work (planning, assembly, enqueueing), the rest of the %.1f ms is waiting for the device\n",
-           2 * maxdepth + 1, t_queued * 1e3, t_calls * 1e3);
+           2 * maxdepth + 1, t_queued_calls * 1e3, t_calls * 1e3);
   if (seam_timing)
     printf("  phases of a walk with the device waited for after the launches (%.1f ms, %.0f calls): planning %.2f ms, beliefs in %.2f, program assembly %.2f, "
            "launches + device %.2f, beliefs out %.2f; the caller's own sub-graph assembly and bookkeeping %.2f\n", t_timed * 1e3, ph[5], ph[0] * 1e3, ph[1] * 1e3,

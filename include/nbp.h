@@ -201,6 +201,10 @@ int64_t nbp_slot_stride_doubles(int32_t N);
 nbp_status nbp_ctx_create(int32_t device, int32_t N, int32_t n_slots, void *arena,
                           int64_t arena_bytes, int32_t side_ints, nbp_ctx **out);
 nbp_status nbp_ctx_destroy(nbp_ctx *ctx);
+/* One object of the layer above rides with the context (the native host's plan cache): `destroy(obj)` is called at the top of
+ * nbp_ctx_destroy, while the context and its programs are still whole, or when another object takes its place. */
+nbp_status nbp_ctx_attach(nbp_ctx *ctx, void *obj, void (*destroy)(void *obj));
+void *nbp_ctx_attached(const nbp_ctx *ctx);
 const char *nbp_last_error(void);
 nbp_status nbp_synchronize(nbp_ctx *ctx);
 void *nbp_arena_ptr(nbp_ctx *ctx);
@@ -352,6 +356,12 @@ nbp_status nbp_program_set_option(nbp_program *prog, int32_t option, int32_t val
 nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
 nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);
 nbp_status nbp_program_reseed(nbp_program *prog, uint64_t salt); /* xor-mix all op seeds on device */
+/* New seeds for every op of a finalized program, in stage order: per proposal / deconvolution descriptor its seed and, where the
+ * descriptor named a stored measurement when the program was finalized (meas_seed != 0), that one behind it; per product
+ * descriptor its seed.  n = nbp_program_num_seeds.  Stream-ordered.  (The native host's plan cache: a batch of clique requests
+ * whose structure has not changed is the same program with other seeds -- include/nbp_host.h.) */
+nbp_status nbp_program_num_seeds(nbp_program *prog, int32_t *out);
+nbp_status nbp_program_set_seeds(nbp_program *prog, const uint64_t *seeds, int32_t n);
 nbp_status nbp_program_num_stages(nbp_program *prog, int32_t *out);
 /* rounds of a finalized program that run as one launch of the fused update kernel (NBP_OPT_FUSED_UPDATES) */
 nbp_status nbp_program_num_fused(nbp_program *prog, int32_t *out);

@@ -101,7 +101,7 @@ EXPORTS = [
     "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_belief_write_batch", "nbp_belief_read_batch", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
     "nbp_run_proposals", "nbp_run_bandwidth", "nbp_run_products", "nbp_run_copies", "nbp_run_deconv", "nbp_kde_bandwidth", "nbp_conv", "nbp_manifold_product",
     "nbp_program_create", "nbp_program_add_stage", "nbp_program_set_option", "nbp_program_finalize", "nbp_program_run",
-    "nbp_program_reseed", "nbp_program_num_stages", "nbp_program_num_fused", "nbp_program_num_two_stream", "nbp_program_destroy",
+    "nbp_program_reseed", "nbp_program_num_seeds", "nbp_program_set_seeds", "nbp_ctx_attach", "nbp_ctx_attached", "nbp_program_num_stages", "nbp_program_num_fused", "nbp_program_num_two_stream", "nbp_program_destroy",
     "nbp_timing_enable", "nbp_timing_read", "nbp_timing_read_n", "nbp_diag_read",
     "nbp_comm_unique_id", "nbp_comm_create", "nbp_comm_destroy", "nbp_comm_info", "nbp_exchange", "nbp_math_eval",
 ]

@@ -67,6 +67,8 @@ struct nbp_comm;
 struct nbp_ctx {
   std::vector<nbp_program *> programs;  // live programs: detached (device blob freed, ctx = null) by nbp_ctx_destroy
   std::vector<nbp_comm *> comms;        // live communicators: shut down (and detached) by nbp_ctx_destroy
+  void *attached = nullptr;             // an object of the layer above (nbp_ctx_attach: the native host's plan cache) ...
+  void (*attached_destroy)(void *) = nullptr;  // ... destroyed at the top of nbp_ctx_destroy, while the context is whole
   uint64_t ws_gen = 0;  // bumped whenever a workspace a captured launch sequence holds by value (ws, gstats) is re-allocated
   int device = 0, N = 0, n_slots = 0, side_ints = 0, threads = 0, Npad = 0, P = 1;
   int64_t S = 0;
@@ -298,10 +300,21 @@ static void program_delete(nbp_program *p);  // detach + delete (defined behind 
 static void ctx_detach_comms(nbp_ctx *c);
 static void reap_retired(nbp_ctx *c);
 
+nbp_status nbp_ctx_attach(nbp_ctx *c, void *obj, void (*destroy)(void *)) {
+  if (!c) return fail(NBP_ERR_ARG, "ctx is null");
+  if (c->attached && c->attached_destroy && c->attached != obj) c->attached_destroy(c->attached);
+  c->attached = obj;
+  c->attached_destroy = destroy;
+  return NBP_OK;
+}
+void *nbp_ctx_attached(const nbp_ctx *c) { return c ? c->attached : nullptr; }
+
 nbp_status nbp_ctx_destroy(nbp_ctx *c) {
   if (!c) return NBP_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->attached && c->attached_destroy) c->attached_destroy(c->attached);  // (may destroy programs of this context: first)
+  c->attached = nullptr;
   for (nbp_program *p : c->programs) program_detach(p);  // a program outliving its context must not touch it
   c->programs.clear();
   ctx_detach_comms(c);  // likewise a communicator: shut down now, its handle stays valid for nbp_comm_destroy
@@ -1526,6 +1539,7 @@ struct nbp_program {
   std::unordered_map<uint64_t, captured> graphs;
   std::unordered_map<uint64_t, int> runs;
   size_t seed_off = 0;  // table of the blob offsets of every descriptor's seed field (one reseed launch)
+  size_t seed_val_off = 0;  // n_seeds values behind the table: where nbp_program_set_seeds puts the new seeds before it scatters them
   int n_seeds = 0;
 };
 
@@ -2061,7 +2075,8 @@ nbp_status nbp_program_finalize(nbp_program *p) {
     }
     p->seed_off = (p->blob.size() + 63) & ~(size_t)63;
     p->n_seeds = (int)so.size();
-    p->blob.resize(p->seed_off + so.size() * 8);
+    p->seed_val_off = p->seed_off + so.size() * 8;
+    p->blob.resize(p->seed_val_off + so.size() * 8);
     if (!so.empty()) memcpy(p->blob.data() + p->seed_off, so.data(), so.size() * 8);
   }
   // size the workspaces now: nothing may allocate once a launch sequence is being captured
@@ -2253,6 +2268,42 @@ nbp_status nbp_program_reseed(nbp_program *p, uint64_t salt) {
   if (p->n_seeds > 0)
     hipLaunchKernelGGL(nbp_reseed_kernel, dim3((p->n_seeds + 255) / 256), dim3(256), 0, c->stream, p->dev,
                        (const int64_t *)(p->dev + p->seed_off), p->n_seeds, salt);
+  HIPCHK(hipGetLastError());
+  return NBP_OK;
+}
+
+// New seeds for every op of a finalized program (the native host's plan cache: a batch of clique requests whose structure has not
+// changed is the same program with other seeds).  `seeds` in stage order: per proposal / deconvolution descriptor its seed and,
+// where the descriptor names a stored measurement (meas_seed != 0 when the program was finalized), that one behind it; per
+// product descriptor its seed -- the order of the program's own seed table.  Stream-ordered: behind what the program has
+// queued so far, in front of its next run.
+__global__ void nbp_setseed_kernel(char *blob, const int64_t *seed_off, const uint64_t *vals, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) *(uint64_t *)(blob + seed_off[i]) = vals[i];
+}
+nbp_status nbp_program_num_seeds(nbp_program *p, int32_t *out) {
+  if (!p || !out) return fail(NBP_ERR_ARG, "null argument");
+  if (!p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+  *out = p->n_seeds;
+  return NBP_OK;
+}
+nbp_status nbp_program_set_seeds(nbp_program *p, const uint64_t *seeds, int32_t n) {
+  if (!p || !p->finalized) return fail(NBP_ERR_ARG, "program not finalized");
+  PROG_ALIVE(p);
+  if (n != p->n_seeds || (n > 0 && !seeds)) return fail(NBP_ERR_ARG, "set_seeds: the count is not the program's (nbp_program_num_seeds)");
+  if (n == 0) return NBP_OK;
+  nbp_ctx *c = p->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  // (from a pinned buffer of the context's pool: a copy from pageable memory would make the caller wait for the stream)
+  nbp_ctx::pin_buf *b = pin_acquire(c, (size_t)n * 8);
+  if (!b) return fail(NBP_ERR_HIP, "pinned staging buffer");
+  memcpy(b->p, seeds, (size_t)n * 8);
+  const hipError_t e = hipMemcpyAsync(p->dev + p->seed_val_off, b->p, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+  pin_release_behind_stream(c, b);
+  if (e != hipSuccess) return fail(NBP_ERR_HIP, std::string("hipMemcpyAsync (seeds): ") + hipGetErrorString(e));
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(nbp_setseed_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, p->dev, (const int64_t *)(p->dev + p->seed_off),
+                     (const uint64_t *)(p->dev + p->seed_val_off), n);
   HIPCHK(hipGetLastError());
   return NBP_OK;
 }

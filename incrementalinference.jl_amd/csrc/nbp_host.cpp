@@ -11,10 +11,15 @@
 #include <chrono>
 #include <array>
 #include <deque>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1992,6 +1997,66 @@ struct nbp_clique_ticket {
   bool down = false;
   double t_launched = 0;
 };
+// The plan cache of a context (see clique_plans_submit): finalized programs keyed by their own descriptors with the seed fields
+// blanked.  It rides with the context (nbp_ctx_attach) and is destroyed, its programs with it, at the top of nbp_ctx_destroy.
+struct plan_cache {
+  struct entry { uint64_t hash; std::vector<char> sig; nbp_program *prog; uint64_t used; };
+  std::vector<entry> e;
+  size_t cap = 64;
+  uint64_t tick = 0, hits = 0, misses = 0;
+  std::mutex mu;  // (clique calls on one context may come from several host threads)
+  static uint64_t hash_of(const std::vector<char> &v) {
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over 8-byte words (the tail byte-wise)
+    const size_t nw = v.size() / 8;
+    const uint64_t *w = (const uint64_t *)v.data();
+    for (size_t i = 0; i < nw; i++) { h ^= w[i]; h *= 1099511628211ull; }
+    for (size_t i = nw * 8; i < v.size(); i++) { h ^= (unsigned char)v[i]; h *= 1099511628211ull; }
+    return h;
+  }
+  nbp_program *find(const std::vector<char> &sig) {
+    std::lock_guard<std::mutex> lk(mu);
+    const uint64_t h = hash_of(sig);
+    for (entry &x : e)
+      if (x.hash == h && x.sig.size() == sig.size() && memcmp(x.sig.data(), sig.data(), sig.size()) == 0) {
+        x.used = ++tick;
+        hits++;
+        return x.prog;
+      }
+    misses++;
+    return nullptr;
+  }
+  bool insert(std::vector<char> &&sig, nbp_program *p) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (cap == 0) return false;
+    if (e.size() >= cap) {  // the least recently used one out: dropped once what it has queued has run
+      size_t lru = 0;
+      for (size_t i = 1; i < e.size(); i++) if (e[i].used < e[lru].used) lru = i;
+      nbp_program_retire(e[lru].prog);
+      e.erase(e.begin() + (long)lru);
+    }
+    const uint64_t h = hash_of(sig);
+    e.push_back({h, std::move(sig), p, ++tick});
+    return true;
+  }
+  ~plan_cache() {
+    if (getenv("NBP_PLAN_CACHE_STATS")) fprintf(stderr, "[libnbp] plan cache: %llu hits, %llu misses, %zu programs kept\n", (unsigned long long)hits, (unsigned long long)misses, e.size());
+    for (entry &x : e) nbp_program_destroy(x.prog);
+  }
+};
+static void plan_cache_destroy(void *o) { delete (plan_cache *)o; }
+static plan_cache *plan_cache_of(nbp_ctx *ctx) {
+  static const int on = getenv("NBP_PLAN_CACHE") ? atoi(getenv("NBP_PLAN_CACHE")) : 1;
+  if (!on) return nullptr;
+  static std::mutex make_mu;
+  std::lock_guard<std::mutex> lk(make_mu);
+  plan_cache *pc = (plan_cache *)nbp_ctx_attached(ctx);
+  if (!pc) {
+    pc = new plan_cache();
+    if (getenv("NBP_PLAN_CACHE_ENTRIES")) pc->cap = (size_t)std::max(0, atoi(getenv("NBP_PLAN_CACHE_ENTRIES")));
+    if (nbp_ctx_attach(ctx, pc, plan_cache_destroy)) { delete pc; return nullptr; }
+  }
+  return pc;
+}
 static inline int resident_slot(nbp_ctx *ctx, int handle) { return nbp_ctx_slots(ctx) - handle; }
 static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &plans, nbp_clique_ticket *T, bool async) {
   const int nres = nbp_ctx_resident(ctx), cap = nbp_ctx_slots(ctx) - nres;
@@ -2036,18 +2101,13 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
                         : nbp_belief_write_batch(ctx, (int32_t)bs.size(), bs.data(), bm.data(), bp.data(), bn.data(), bb.data(), bi.data());
   if (rc) return rc;
   const double t1 = seam_now();
-  nbp_program *p = nullptr;
-  rc = nbp_program_create(ctx, &p);
-  if (rc) return rc;
-  // (the program is short-lived: retired behind its last launch when the call does not wait, destroyed otherwise)
-  struct prog_guard { nbp_program *p; bool async; ~prog_guard() { if (async) nbp_program_retire(p); else nbp_program_destroy(p); } } guard{p, async};
-  rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
-  if (!rc && async) rc = nbp_program_set_option(p, NBP_OPT_ASYNC_UPLOAD, 1);
-  if (rc) return rc;
-  if (!cin.empty()) {
-    rc = nbp_program_add_stage(p, NBP_STAGE_COPIES, cin.data(), (int)cin.size());
-    if (rc) return rc;
-  }
+  // ---- the stages of the batch's program, in order: [copies in] (proposals, products) x rounds [deconv] [copies out] ----------
+  struct stage_buf { int32_t kind; int32_t n; std::vector<char> bytes; };
+  std::vector<stage_buf> stg;
+  auto add = [&](int32_t kind, const void *d, size_t n, size_t esz) {
+    stg.push_back({kind, (int32_t)n, std::vector<char>((const char *)d, (const char *)d + n * esz)});
+  };
+  if (!cin.empty()) add(NBP_STAGE_COPIES, cin.data(), cin.size(), sizeof(nbp_copy_desc));
   size_t nr = 0;
   for (const clique_plan &P : plans) nr = std::max(nr, P.rounds.size());
   std::vector<nbp_proposal_desc> props;
@@ -2059,16 +2119,12 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
         props.insert(props.end(), P.rounds[r].first.begin(), P.rounds[r].first.end());
         prods.insert(prods.end(), P.rounds[r].second.begin(), P.rounds[r].second.end());
       }
-    rc = nbp_program_add_stage(p, NBP_STAGE_PROPOSALS, props.data(), (int)props.size());
-    if (!rc) rc = nbp_program_add_stage(p, NBP_STAGE_PRODUCTS, prods.data(), (int)prods.size());
-    if (rc) return rc;
+    add(NBP_STAGE_PROPOSALS, props.data(), props.size(), sizeof(nbp_proposal_desc));
+    add(NBP_STAGE_PRODUCTS, prods.data(), prods.size(), sizeof(nbp_product_desc));
   }
   props.clear();
   for (const clique_plan &P : plans) props.insert(props.end(), P.deconv.begin(), P.deconv.end());
-  if (!props.empty()) {
-    rc = nbp_program_add_stage(p, NBP_STAGE_DECONV, props.data(), (int)props.size());
-    if (rc) return rc;
-  }
+  if (!props.empty()) add(NBP_STAGE_DECONV, props.data(), props.size(), sizeof(nbp_proposal_desc));
   // beliefs out: to their resident slots (a copy stage: it carries the fitted bandwidth along), to the host (below)
   std::vector<int32_t> os;
   for (const clique_plan &P : plans)
@@ -2083,11 +2139,64 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
         T->dst.push_back(e.dst);
       }
     }
-  if (!cout.empty()) {
-    rc = nbp_program_add_stage(p, NBP_STAGE_COPIES, cout.data(), (int)cout.size());
-    if (rc) return rc;
+  if (!cout.empty()) add(NBP_STAGE_COPIES, cout.data(), cout.size(), sizeof(nbp_copy_desc));
+  // ---- PLAN CACHE (round 6): a batch whose program is, descriptor for descriptor, one this context has built before -- the
+  // requests of a tree level that has not changed since the last walk -- runs that program again with the new seeds
+  // (nbp_program_set_seeds) instead of assembling, finalizing and enqueueing ~60 launches: from its third run on the program
+  // is one hipGraph launch.  The key is the PROGRAM, not the request: the fresh plan is built either way (2-3 ms of a walk,
+  // on the planning pool) and compared byte for byte with its seed fields blanked, so nothing the planner looks at can be
+  // missed by the key.  NBP_PLAN_CACHE=0 switches it off, NBP_PLAN_CACHE_ENTRIES (default 64) sizes it (least recently used out).
+  std::vector<uint64_t> seeds;     // the seeds of the fresh plan in the order of the program's seed table
+  std::vector<char> sig;           // the stages with their seed fields blanked
+  plan_cache *PC = plan_cache_of(ctx);
+  if (PC) {
+    size_t tot = 0;
+    for (const stage_buf &b : stg) tot += 8 + b.bytes.size();
+    sig.reserve(tot);
+    for (stage_buf &b : stg) {
+      const int32_t hdr[2] = {b.kind, b.n};
+      sig.insert(sig.end(), (const char *)hdr, (const char *)hdr + 8);
+      const size_t at = sig.size();
+      sig.insert(sig.end(), b.bytes.begin(), b.bytes.end());
+      if (b.kind == NBP_STAGE_PROPOSALS || b.kind == NBP_STAGE_DECONV)
+        for (int i = 0; i < b.n; i++) {
+          nbp_proposal_desc *d = (nbp_proposal_desc *)(sig.data() + at) + i;
+          seeds.push_back(d->seed);
+          d->seed = 0;
+          if (d->meas_seed) { seeds.push_back(d->meas_seed); d->meas_seed = 1; }  // (that it names a stored measurement is structure)
+        }
+      else if (b.kind == NBP_STAGE_PRODUCTS)
+        for (int i = 0; i < b.n; i++) {
+          nbp_product_desc *d = (nbp_product_desc *)(sig.data() + at) + i;
+          seeds.push_back(d->seed);
+          d->seed = 0;
+        }
+    }
   }
-  rc = nbp_program_finalize(p);
+  nbp_program *p = PC ? PC->find(sig) : nullptr;
+  const bool hit = p != nullptr;
+  // (a program of its own is short-lived: retired behind its last launch when the call does not wait, destroyed otherwise; a
+  //  cached one belongs to the cache)
+  struct prog_guard { nbp_program *p; bool async, owned; ~prog_guard() { if (!owned || !p) return; if (async) nbp_program_retire(p); else nbp_program_destroy(p); } } guard{nullptr, async, false};
+  if (hit) {
+    int32_t ns = 0;
+    rc = nbp_program_num_seeds(p, &ns);
+    if (!rc && ns != (int32_t)seeds.size()) rc = hfail(NBP_ERR_ARG, "plan cache: the cached program's seed count is not the plan's");
+    if (!rc) rc = nbp_program_set_seeds(p, seeds.data(), ns);
+    if (rc) return rc;
+  } else {
+    rc = nbp_program_create(ctx, &p);
+    if (rc) return rc;
+    guard.p = p;
+    guard.owned = true;
+    rc = nbp_program_set_option(p, NBP_OPT_LAZY_BANDWIDTH, 1);
+    if (!rc && async) rc = nbp_program_set_option(p, NBP_OPT_ASYNC_UPLOAD, 1);
+    for (const stage_buf &b : stg)
+      if (!rc) rc = nbp_program_add_stage(p, b.kind, b.bytes.data(), b.n);
+    if (!rc) rc = nbp_program_finalize(p);
+    if (rc) return rc;
+    if (PC && PC->insert(std::move(sig), p)) guard.owned = false;  // the cache keeps it
+  }
   const double t2 = seam_now();
   if (!rc) rc = nbp_program_run(p, 0, -1);
   if (!rc && g_seam_sync) rc = nbp_synchronize(ctx);  // (timing mode: the wait is charged to the launches, not to the read)
@@ -2141,6 +2250,68 @@ static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const 
   return NBP_OK;
 }
 
+// A small persistent pool for the planning of a batch (round 6; through round 5 every call with >= 64 requests spawned and
+// joined up to seven std::threads: ~40 thread creations per walk of a 1000-variable tree).  Workers are started on first use and
+// sleep on a condition variable between batches; a batch is a function of (part, parts) run once per part, part 0 on the calling
+// thread.  One batch at a time (callers from several host threads queue up on the mutex: planning is short).
+namespace {
+struct plan_pool {
+  std::mutex run_mu;                 // one batch at a time
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> workers;
+  std::function<void(int, int)> job;
+  int parts = 0, next = 0, pending = 0;
+  uint64_t gen = 0;
+  bool stop = false;
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      int part, T;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return stop || (gen != seen && next < parts); });
+        if (stop) return;
+        part = next++;
+        T = parts;
+        if (next >= parts) seen = gen;
+      }
+      job(part, T);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void run(int T, const std::function<void(int, int)> &f) {
+    if (T <= 1) { f(0, 1); return; }
+    std::lock_guard<std::mutex> batch(run_mu);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while ((int)workers.size() < T - 1) workers.emplace_back([this] { worker(); });
+      job = f;
+      parts = T;
+      next = 1;          // part 0 runs here
+      pending = T - 1;
+      gen++;
+    }
+    cv_work.notify_all();
+    f(0, T);
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~plan_pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (std::thread &t : workers) t.join();
+  }
+};
+plan_pool g_plan_pool;
+}  // namespace
+
 static nbp_status clique_batch_plans(nbp_ctx *ctx, nbp_clique_request *req, int32_t n, std::vector<clique_plan> &plans) {
   const double t0 = seam_now();
   for (int i = 0; i < n; i++) {
@@ -2159,13 +2330,7 @@ static nbp_status clique_batch_plans(nbp_ctx *ctx, nbp_clique_request *req, int3
     auto part = [&](int t, int T) {
       for (int i = (int)((int64_t)n * t / T); i < (int)((int64_t)n * (t + 1) / T); i++) rcs[(size_t)i] = build(i);
     };
-    if (nt <= 1) part(0, 1);
-    else {
-      std::vector<std::thread> th;
-      for (int t = 1; t < nt; t++) th.emplace_back(part, t, nt);
-      part(0, nt);
-      for (std::thread &x : th) x.join();
-    }
+    g_plan_pool.run(nt < 1 ? 1 : nt, part);  // (a persistent pool: no thread is created per call)
     for (int i = 0; i < n; i++)
       if (rcs[(size_t)i]) {
         plans[(size_t)i] = clique_plan();

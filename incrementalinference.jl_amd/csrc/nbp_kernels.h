@@ -1454,8 +1454,10 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
           } else {
             double pv, num;
             if constexpr (D == 1) { pv = v[0]; num = t[0]; }
-            else if constexpr (D == 2) { pv = v[0] * v[1]; num = t[0] * v[1] + t[1] * v[0]; }
-            else { const double v01 = v[0] * v[1]; pv = v01 * v[2]; num = t[0] * (v[1] * v[2]) + t[1] * (v[0] * v[2]) + t[2] * v01; }
+            // (weights decide label draws, they never travel as coordinates: their multiply-adds are spelled out as fma -- the
+            //  library is compiled without contraction for the sake of the values that do travel)
+            else if constexpr (D == 2) { pv = v[0] * v[1]; num = fma(t[0], v[1], t[1] * v[0]); }
+            else { const double v01 = v[0] * v[1]; pv = v01 * v[2]; num = fma(t[0], v[1] * v[2], fma(t[1], v[0] * v[2], t[2] * v01)); }
             const double r = rsqrt_pos(pv);
             a = -0.5 * num * (r * r);
             g = r * L.nw[lb + z];
@@ -1551,8 +1553,8 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
                 cur *= f;
                 m = am;
               }
-              const double w = (exp_nonpos(a0 - m, L.tab) * g0 + exp_nonpos(a1 - m, L.tab) * g1) +
-                               (exp_nonpos(a2 - m, L.tab) * g2 + exp_nonpos(a3 - m, L.tab) * g3);
+              const double w = fma(exp_nonpos(a0 - m, L.tab), g0, exp_nonpos(a1 - m, L.tab) * g1) +
+                               fma(exp_nonpos(a2 - m, L.tab), g2, exp_nonpos(a3 - m, L.tab) * g3);
               tot += w;
               cur += w;
             }
@@ -1610,7 +1612,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
 #pragma unroll
             for (int i = 0; i < SR; i++) {
               if (i >= nzmax) break;
-              c += wr[i] * f;
+              c = fma(wr[i], f, c);
               if (!hit && z0 + i < z1 && target < c) { choice = z0 + i; hit = true; }
             }
           }
@@ -1696,7 +1698,7 @@ __device__ __forceinline__ void product_body(const nbp_product_desc *d, double *
             for (int z = za; z < zb; z++) {
               double a, g;
               node_w(z, a, g);
-              c += exp_nonpos(a - Mx, L.tab) * g;
+              c = fma(exp_nonpos(a - Mx, L.tab), g, c);
               if (target < c) { choice = z; break; }
             }
           }

@@ -61,12 +61,13 @@ typedef struct {
   int64_t solves, nonconverged, nan_results, residual_evals, lcv_evals;
 } orc_diag;
 
-/* Two levels of OpenMP (the CPU baseline of bench.py): the ops of a stage are independent (outer team, orc_run_proposals /
- * orc_run_products), and inside an op so are the particles of a proposal, the samples of a product and the rows of a
- * leave-one-out likelihood -- a stage near the root of a tree holds a handful of ops, and without the inner level a 256-thread
- * host ran them on a handful of cores (round 5: the baseline peaked at 16 threads).  g_inner = threads each op of the running
- * stage may use (max threads / outer team; 1: serial, the test suite's setting).  Every inner loop is over independent items and
- * every sum is still taken serially in the same order: the results are the serial ones bit for bit, whatever the thread counts. */
+/* Two levels of parallelism in ONE OpenMP team (the CPU baseline of bench.py): the ops of a stage are tasks, and inside an op
+ * the particles of a proposal, the samples of a product and the rows of a leave-one-out likelihood are taskloops -- a stage
+ * near the root of a tree holds a handful of ops, and the threads that got none of them pick up pieces of the ones that run
+ * (round 5: ops only, the baseline peaked at 16 threads -- the critical path of the tree; nested parallel regions, tried first
+ * in round 6, were slower still: libgomp builds a new team for every inner region).  g_inner > 1: the inner level is on (off in
+ * the test suite).  Every inner loop is over independent items and every sum is still taken serially in the same order: the
+ * results are the serial ones bit for bit, whatever the thread count. */
 static int g_inner = 1;
 static orc_diag g_diag;               /* merged totals */
 static __thread orc_diag t_diag;      /* per-thread counters, merged at the end of every op */
@@ -896,7 +897,7 @@ static double neg_loo_ll(const double *x, int N, int circ, double h) {
   double lognorm = log(h) + 0.5 * log(TWO_PI) + log((double)(N - 1));
   t_diag.lcv_evals++;
   double term[NBP_MAXN];
-#pragma omp parallel for schedule(static) num_threads(g_inner) if (g_inner > 1)
+#pragma omp taskloop grainsize(16) default(shared) if (g_inner > 1)
   for (int i = 0; i < N; i++) {
     double s = 0;
     for (int j = 0; j < N; j++) {
@@ -1199,9 +1200,8 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
             if (mhidx[n] == hyp) add_entropy(d->manifold, X, N, n, spread, d->seed, (g * 8 + c) * 2, d->partial_mask);
           /* (the searches of the particles are independent: the inner OpenMP level of the CPU baseline; every inner thread
              hands its counters in before the team ends) */
-#pragma omp parallel num_threads(g_inner) if (g_inner > 1)
           {
-#pragma omp for schedule(dynamic, 4)
+#pragma omp taskloop grainsize(8) default(shared) if (g_inner > 1)
           for (int n = 0; n < N; n++) { /* approxConvOnElements!, :14-27 */
             if (mhidx[n] != hyp) continue;
             double x[3], oth[3];
@@ -1233,7 +1233,6 @@ int32_t orc_run_proposal(double *arena, int32_t N, int32_t *side, const nbp_prop
               solve_particle(d->factor_kind, d->manifold, Z + 3 * n, oth, solve_b, x);
             for (int k = 0; k < D; k++) X[k * N + n] = x[k];
           }
-          if (g_inner > 1) diag_merge();
           }
         }
       } else { /* other-hypothesis (:208-220) and nullhypo (:222-231): entropy only */
@@ -1411,7 +1410,7 @@ int32_t orc_run_product(double *arena, int32_t N, int32_t *side, const nbp_produ
   }
   double *res = (double *)malloc(sizeof(double) * 3 * N);
   /* (the output samples are independent -- every draw is keyed by the sample index: the inner OpenMP level of the CPU baseline) */
-#pragma omp parallel for schedule(dynamic, 4) num_threads(g_inner) if (g_inner > 1)
+#pragma omp taskloop grainsize(8) default(shared) if (g_inner > 1)
   for (int s = 0; s < N; s++) {
     int ind[NBP_MAXF];
     for (int j = 0; j < F; j++) ind[j] = 0; /* levelInit! / initIndices!: root */
@@ -1612,30 +1611,37 @@ static int team_for(int n) { const int t = omp_get_max_threads(); return n < t ?
 #else
 static int team_for(int n) { (void)n; return 1; }
 #endif
-/* threads each op of a stage of n ops may use inside (g_inner): what the outer team leaves of the host, when the caller asked
- * for two levels (orc_set_nested) */
+/* the ops of a stage as tasks of one team; with the inner level on (orc_set_nested) the whole team is present whatever the
+ * number of ops, and its idle threads take the taskloops inside the ops that run.  The counters of the searches are per
+ * thread: every thread of the team hands its own in before the team ends. */
 static int g_nested = 0;
-static void set_inner_for(int n) {
-#ifdef _OPENMP
-  const int t = omp_get_max_threads(), team = team_for(n);
-  g_inner = (g_nested && team > 0 && t / team > 1) ? t / team : 1;
-#else
-  (void)n;
-#endif
-}
 int32_t orc_run_proposals(double *arena, int32_t N, int32_t *side, const nbp_proposal_desc *d, int32_t n) {
   int rc = NBP_OK;
-  set_inner_for(n);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
-  for (int i = 0; i < n; i++) { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
+  g_inner = g_nested ? 2 : 1;
+#pragma omp parallel num_threads(g_nested ? team_for(1 << 30) : team_for(n))
+  {
+#pragma omp single
+    for (int i = 0; i < n; i++) {
+#pragma omp task firstprivate(i) shared(rc)
+      { int r = orc_run_proposal(arena, N, side, d + i); if (r) rc = r; }
+    }
+    diag_merge();
+  }
   g_inner = 1;
   return rc;
 }
 int32_t orc_run_products(double *arena, int32_t N, int32_t *side, const nbp_product_desc *d, int32_t n) {
   int rc = NBP_OK;
-  set_inner_for(n);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(team_for(n))
-  for (int i = 0; i < n; i++) { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; diag_merge(); }
+  g_inner = g_nested ? 2 : 1;
+#pragma omp parallel num_threads(g_nested ? team_for(1 << 30) : team_for(n))
+  {
+#pragma omp single
+    for (int i = 0; i < n; i++) {
+#pragma omp task firstprivate(i) shared(rc)
+      { int r = orc_run_product(arena, N, side, d + i); if (r) rc = r; }
+    }
+    diag_merge();
+  }
   g_inner = 1;
   return rc;
 }
@@ -1652,8 +1658,8 @@ void orc_run_copies(double *arena, int32_t N, const nbp_copy_desc *c, int32_t n)
 }
 
 #ifdef _OPENMP
-/* two levels of OpenMP (the CPU baseline): on = 1 lets an op use the threads its stage's outer team leaves idle */
-void orc_set_nested(int32_t on) { g_nested = on; omp_set_max_active_levels(on ? 2 : 1); }
+/* the inner level of parallelism (the CPU baseline): on = 1 lets the idle threads of a stage's team work inside its ops */
+void orc_set_nested(int32_t on) { g_nested = on; }
 void orc_set_threads(int32_t n) { omp_set_num_threads(n); }
 int32_t orc_get_max_threads(void) { return omp_get_max_threads(); }
 #else

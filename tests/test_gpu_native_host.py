@@ -93,6 +93,20 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
     out = subprocess.run([exe, "60", "100", "10", "-2"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "60 of 60 posteriors byte-identical" in out.stdout and "KEPT across walks" in out.stdout, out.stdout
+    # The library's PLAN CACHE (round 6): a level whose program has not changed is the cached program with new seeds, and from
+    # its third run a hipGraph launch.  Six walks with a seed of their own each (NBP_WALK_SEEDS) and the whole-tree program's
+    # seed again on the last two: the cached programs, re-seeded five times, must deliver its bytes -- with the cache, without
+    # it, and with room for two programs only (every level evicted and rebuilt all the time).
+    for env_extra in ({"NBP_PLAN_CACHE_STATS": "1"}, {"NBP_PLAN_CACHE": "0"}, {"NBP_PLAN_CACHE_ENTRIES": "2", "NBP_PLAN_CACHE_STATS": "1"}):
+        for mode in ("-1", "-2"):
+            env = dict(os.environ, NBP_WALKS="6", NBP_WALK_SEEDS="1", **env_extra)
+            out = subprocess.run([exe, "200", "100", "20", mode], capture_output=True, text=True, timeout=600, env=env)
+            assert out.returncode == 0, out.stdout + out.stderr
+            assert "200 of 200 posteriors byte-identical" in out.stdout, (env_extra, mode, out.stdout)
+            if env_extra.get("NBP_PLAN_CACHE_STATS") and "NBP_PLAN_CACHE_ENTRIES" not in env_extra:
+                import re
+                m = re.search(r"plan cache: (\d+) hits, (\d+) misses", out.stderr)
+                assert m and int(m.group(1)) >= 4 * int(m.group(2)) > 0, out.stderr[-500:]  # five of six walks are hits on every level
 
 
 def test_native_graph_init_equals_python_init_all(hip_backend):
