@@ -107,13 +107,16 @@ def cpu_baseline(iif, nvars, N, thread_counts):
     fg = iif.generateChainEuclid(nvars, vardims=2, priorEvery=100, N=N)
     order = iif.nestedDissectionOrder(fg)
     tree = iif.buildTreeReset(fg, order)
-    iif.initAll(fg, backend=lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=max(thread_counts), nested=True), seed=0)
+    iif.initAll(fg, backend=lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=min(32, max(thread_counts))), seed=0)
     tp = iif.TreeProgram(fg, tree, seed=1)
     out = []
     for threads in thread_counts:
-        # two OpenMP levels: the ops of a stage, and inside an op its particles / samples / likelihood rows on the threads the
-        # stage leaves idle (the stages near the root hold a handful of ops) -- the serial results bit for bit
-        be = OracleBackend(N, tp.n_slots, 0, threads=threads, nested=threads > 1)
+        # OpenMP over the independent ops of a stage.  (An inner level -- particles, product samples and likelihood rows of an op as
+        # taskloops of the same team, `nested=True`: the serial results bit for bit -- was built and measured in round 6 and is NOT
+        # used: on the 256-thread host libgomp's task queue costs more than the idle threads bring from 32 threads on,
+        # profiles/r06_cpu_baseline_scaling.txt.  What caps the port at 16-32 threads is the tree: its last levels hold one to six
+        # cliques, and a clique's Gibbs steps depend on each other.)
+        be = OracleBackend(N, tp.n_slots, 0, threads=threads, nested=False)
         for v in fg.ls():
             var = fg.getVariable(v)
             be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
@@ -374,13 +377,15 @@ def _main(real_stdout):
         os.environ.setdefault("OMP_PLACES", "threads")
         os.environ.setdefault("OMP_WAIT_POLICY", "active")
         flags = _ob.use_native_build(f"/tmp/liboracle_native_{os.getpid()}.so") or "-O2 (stock test library: the native build failed)"
-        sweep = cpu_baseline(iif, a.cpu_sample_vars, 200, sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, 256)}))
+        sweep = cpu_baseline(iif, a.cpu_sample_vars, 200, sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128)}))
         v, secs, m, threads = max(sweep)
         out["cpu_baseline"] = {"value": v, "unit": "messages/s", "cores": threads, "kind": "port", "build": flags,
                                "thread_sweep": {str(t): round(val, 1) for val, _, _, t in sweep},
                                "sample": f"the config-2 chain with {a.cpu_sample_vars} variables, N=200, one full up+down solve "
-                                         f"({m} messages) in {secs:.1f} s, two OpenMP levels (the ops of a stage; particles, product samples and "
-                                         f"likelihood rows inside an op), threads pinned, best of the thread sweep on a "
+                                         f"({m} messages) in {secs:.1f} s, OpenMP over the ops of a stage, threads pinned and spread over the "
+                                         f"cores; the port stops scaling at 16-32 threads because the last levels of the tree hold one to six cliques "
+                                         f"whose Gibbs steps depend on each other (an inner level of parallelism was measured and is slower on this host: "
+                                         f"profiles/r06_cpu_baseline_scaling.txt); best of the thread sweep on a "
                                          f"{ncpu}-thread host, every bandwidth fit made (the port has no dead-fit elimination); "
                                          f"the restatement baseline, not the Julia package (no Julia on the box)"}
         # also the single-thread rate of the same restatement (smaller sample: it is slow)

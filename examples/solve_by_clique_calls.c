@@ -523,6 +523,7 @@ int main(int argc, char **argv) {
     printf("  phases of a walk with the device waited for after the launches (%.1f ms, %.0f calls): planning %.2f ms, beliefs in %.2f, program assembly %.2f, "
            "launches + device %.2f, beliefs out %.2f; the caller's own sub-graph assembly and bookkeeping %.2f\n", t_timed * 1e3, ph[5], ph[0] * 1e3, ph[1] * 1e3,
            ph[2] * 1e3, ph[3] * 1e3, ph[4] * 1e3, (t_timed - ph[0] - ph[1] - ph[2] - ph[3] - ph[4]) * 1e3);
+  if (bctx) nbp_ctx_destroy(bctx);
   nbp_ctx_destroy(ctx);
   nbp_tree_destroy(tree);
   nbp_graph_destroy(g);

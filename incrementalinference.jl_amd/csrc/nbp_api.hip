@@ -53,7 +53,7 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
   do {                                                                                             \
     hipError_t e_ = (expr);                                                                        \
     if (e_ != hipSuccess)                                                                          \
-      return fail(NBP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+      return fail(NBP_ERR_HIP, std::string(#expr) + " (nbp_api.hip:" + std::to_string(__LINE__) + "): " + hipGetErrorString(e_)); \
   } while (0)
 
 // Speculative fits (lcv_bandwidth_1d_spec): used when every workgroup of the launch is resident at once -- the launch,
@@ -2236,7 +2236,10 @@ nbp_status nbp_program_run(nbp_program *p, int32_t first, int32_t last) {
   if (it == p->graphs.end()) {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
-    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    // (relaxed: nothing between begin and end is a call the capture could not take, and under the thread-local mode another
+    //  host thread synchronising ITS context's stream meanwhile was refused with "operation not permitted when stream is
+    //  capturing" -- seen in round 6 when concurrent callers' clique programs began to be replayed, tools/exp/plan_cache_repro.sh)
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
     nbp_status rc = run_range(p, first, last);
     hipError_t e = hipStreamEndCapture(c->stream, &g);
     if (rc) { if (g) hipGraphDestroy(g); return rc; }
