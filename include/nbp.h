@@ -347,7 +347,9 @@ nbp_status nbp_program_add_stage(nbp_program *prog, int32_t kind, const void *de
  * the new belief touching HBM -- when the round has at least NBP_FUSED_MIN updates (environment, read at nbp_ctx_create;
  * unset = never: the fused form trades time for traffic) and its factors are of a class the kernel is built
  * for; same particles and bandwidths as the three-launch form up to the rounding of sums taken in another order.
- * nbp_program_run refuses a stage range that ends between the two stages of a fused pair. */
+ * A stage range of nbp_program_run that ends between the two stages of a fused pair runs the pair in the three-launch form
+ * (the proposals to their arena slots, their fits at the end of the range); a range that starts at the second stage of such a pair
+ * fits every proposal of the pair again before the products (redundant after the previous range's end-of-range fits, never wrong). */
 enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2, NBP_OPT_FUSED_UPDATES = 3,
                           NBP_OPT_ASYNC_UPLOAD = 4 /* (default 0) nbp_program_finalize sends the descriptors stream-ordered from a
                                                       pinned buffer and does not wait: for short-lived programs queued behind

@@ -60,8 +60,12 @@ extern "C" nbp_status nbp_internal_fail(nbp_status code, const char *msg) { retu
 // with 3 or 7 workgroups per fitted coordinate, stays below NBP_SPEC_MAXBLOCKS (the chip has 256 CUs and a fit's
 // workgroup has a CU to itself: 1024 lanes, ~63 KB of LDS).  Counted are the workgroups that stay: those of a
 // coordinate the manifold does not have leave at once (`coords` = sum of the manifold dimensions of the jobs).
+#ifndef NBP_SPEC_MAXJOBS
 #define NBP_SPEC_MAXJOBS 40
+#endif
+#ifndef NBP_SPEC_MAXBLOCKS
 #define NBP_SPEC_MAXBLOCKS 224
+#endif
 struct nbp_program;
 struct nbp_comm;
 struct nbp_ctx {
