@@ -55,6 +55,6 @@ fi
 # several ranks sharing the one GPU (gloo, host-staged exchange): every leg of tests/test_gpu_bench.py three times, the posterior sha of every rank
 (cd $R && tools/exp/loop_multirank.sh 3 > /dev/null 2>&1; cp gpurun_out/mr_loop/summary.txt $O/multirank_shared_gpu.txt)
 # the clique seam from plain C: one call per clique (1 / 4 / 16 callers), a batched call per tree level, queued batches
-(cd $R && bash tools/exp/clique_seam_rate.sh > $O/clique_seam_rate.txt 2>&1; bash tools/exp/clique_seam_phases.sh > $O/clique_seam_phases.txt 2>&1)
+(cd $R && NBP_PLAN_CACHE_STATS=1 bash tools/exp/clique_seam_rate.sh > $O/clique_seam_rate.txt 2>&1; bash tools/exp/clique_seam_phases.sh > $O/clique_seam_phases.txt 2>&1; NBP_PLAN_CACHE=0 bash tools/exp/clique_seam_rate.sh > $O/clique_seam_rate_no_plan_cache.txt 2>&1)
 rm -rf $O/trace $O/sq $O/sq_prop $O/sq_prod
 du -sh $O
