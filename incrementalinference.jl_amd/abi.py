@@ -171,6 +171,8 @@ def load_library(path=None):
     lib.nbp_program_finalize.argtypes = [vp]
     lib.nbp_program_run.argtypes = [vp, i32, i32]
     lib.nbp_program_reseed.argtypes = [vp, C.c_uint64]
+    lib.nbp_program_num_seeds.argtypes = [vp, ip]
+    lib.nbp_program_set_seeds.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     lib.nbp_program_num_stages.argtypes = [vp, ip]
     lib.nbp_program_destroy.argtypes = [vp]
     lib.nbp_comm_unique_id.argtypes = [vp]

@@ -318,6 +318,31 @@ class HipProgram:
     def reseed(self, salt):
         self.backend._check(self.backend.lib.nbp_program_reseed(self._p, C.c_uint64(salt)))
 
+    def num_seeds(self):
+        n = C.c_int32(0)
+        self.backend._check(self.backend.lib.nbp_program_num_seeds(self._p, C.byref(n)))
+        return n.value
+
+    def set_seeds(self, seeds):
+        """new seeds for every op, in stage order: per proposal / deconv descriptor its seed and (where the descriptor named a
+        stored measurement at finalize) its meas_seed behind it; per product descriptor its seed (nbp_program_set_seeds)"""
+        arr = (C.c_uint64 * len(seeds))(*[int(x) for x in seeds])
+        self.backend._check(self.backend.lib.nbp_program_set_seeds(self._p, arr, len(seeds)))
+
+    @staticmethod
+    def seeds_of(stages):
+        """the seed list set_seeds() takes, read off a list of (kind, descriptors) stages"""
+        out = []
+        for kind, descs in stages:
+            if kind in (abi.STAGE_PROPOSALS, abi.STAGE_DECONV):
+                for d in descs:
+                    out.append(d.seed)
+                    if d.meas_seed:
+                        out.append(d.meas_seed)
+            elif kind == abi.STAGE_PRODUCTS:
+                out.extend(d.seed for d in descs)
+        return out
+
     def close(self):
         if self._p:
             self.backend.lib.nbp_program_destroy(self._p)

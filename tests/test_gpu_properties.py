@@ -173,3 +173,51 @@ def test_product_mean_is_unbiased_gpu(hip_backend):
     be.close()
     for m in (m2, m3):
         assert abs(m.mean()) < 0.05 * sig, (m.mean(), m.std() / np.sqrt(B))
+
+
+@pytest.mark.parametrize("build", ["euclid2", "doors", "se2"])
+def test_program_with_new_seeds_is_the_program_compiled_with_them(hip_backend, build):
+    """nbp_program_set_seeds (what the native host's plan cache re-seeds a cached level program with): a tree program compiled
+    with seed A and handed the seeds of the SAME tree compiled with seed B delivers, from the same initial beliefs, the posteriors
+    of the program compiled with B -- bit for bit (graph replay included: the second run of a range is captured, the third replayed)"""
+    from parity_utils import iif
+    make = {"euclid2": lambda: iif.generateChainEuclid(30, vardims=2, priorEvery=10, N=100),
+            "doors": lambda: iif.generateCircularDoors(nposes=20, N=100, sightEvery=5),
+            "se2": lambda: iif.generateSE2Lattice(rows=2, cols=4, N=100, closeEvery=2)}[build]
+    fg = make()
+    iif.initAll(fg, backend=hip_backend, seed=3)
+    tree = iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
+    tpa, tpb = iif.TreeProgram(fg, tree, seed=11), iif.TreeProgram(fg, tree, seed=12)
+    from iif_amd.backend import HipProgram
+    sa, sb = HipProgram.seeds_of(tpa.stages), HipProgram.seeds_of(tpb.stages)
+    assert len(sa) == len(sb) and sa != sb
+
+    def solve(tp, seeds_then=None, runs=1):
+        be = hip_backend(fg.solverParams.N, tp.n_slots)
+        try:
+            prog = be.program(tp.stages, lazy_bandwidth=True)
+            assert prog.num_seeds() == len(sa)
+            out = None
+            for r in range(runs):
+                for v in fg.ls():
+                    var = fg.getVariable(v)
+                    be.belief_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+                iif.solver.write_densities(fg, be)
+                if seeds_then is not None and r == runs - 1:
+                    prog.set_seeds(seeds_then)
+                prog.run()
+                be.synchronize()
+                out = {v: be.slot_read(tp.main[v], fg.getVariable(v).varType.manifold) for v in fg.ls()}
+            prog.close()
+            return out
+        finally:
+            be.close()
+
+    want = solve(tpb)
+    for runs in (1, 3):  # (3: the re-seeded run is a hipGraph replay)
+        got = solve(tpa, seeds_then=sb, runs=runs)
+        for v in fg.ls():
+            assert np.array_equal(got[v][0], want[v][0]) and np.array_equal(got[v][1], want[v][1]), (build, runs, v)
+    back = solve(tpa, seeds_then=sa, runs=2)
+    ref = solve(tpa)
+    assert all(np.array_equal(back[v][0], ref[v][0]) for v in fg.ls())
