@@ -668,14 +668,26 @@ __device__ __forceinline__ void nm_centroid(const double (&sx)[DN + 1][DN], cons
     const bool l1 = !l0 && id[1] > id[2];
 #pragma unroll
     for (int d = 0; d < DN; d++) {
-      // (opaque copies: a select between elements of the simplex is rewritten by the compiler into an element read
-      //  through a selected index, and a simplex that is indexed at run time lives in scratch)
-      double a = sx[0][d], b = sx[1][d], c = sx[2][d];
-      asm("" : "+v"(a), "+v"(b), "+v"(c));
-      const double L = l0 ? a : (l1 ? b : c);
-      const double U = l0 ? b : a;
-      const double V = (l0 || l1) ? c : b;
-      xc[d] = ((U + V) + L) * (1.0 / DN);
+      NBPM_EXACT
+      if constexpr (OPT) {
+        // SUMS: the three sums "x added last" are all taken and the one Optim's order gives is selected -- six additions and two
+        // selects per coordinate instead of four selects between elements of the simplex with their opaque register copies (below):
+        // the same value bit for bit, ~6 instructions fewer per coordinate.  Config 5's proposals 87.0 -> 82.2 ms; the SE(2) search,
+        // whose objective holds more registers, got slower with it (136.4 -> 140 ms) and keeps the selects
+        // (profiles/r06_nm_centroid_forms.txt)
+        const double a = sx[0][d], b = sx[1][d], c = sx[2][d];
+        const double ra = (b + c) + a, rb = (a + c) + b, rc = (a + b) + c;
+        xc[d] = (l0 ? ra : (l1 ? rb : rc)) * (1.0 / DN);
+      } else {
+        // (opaque copies: a select between elements of the simplex is rewritten by the compiler into an element read
+        //  through a selected index, and a simplex that is indexed at run time lives in scratch)
+        double a = sx[0][d], b = sx[1][d], c = sx[2][d];
+        asm("" : "+v"(a), "+v"(b), "+v"(c));
+        const double L = l0 ? a : (l1 ? b : c);
+        const double U = l0 ? b : a;
+        const double V = (l0 || l1) ? c : b;
+        xc[d] = ((U + V) + L) * (1.0 / DN);
+      }
     }
   } else {
 #pragma unroll
@@ -718,7 +730,8 @@ __device__ __forceinline__ double nm_lin(double a, double c, double b) {
   return a + p;
 }
 
-template <class OBJ, int DN, bool OPT = false>
+// OPT: the form of the 3-D centroid (nm_centroid): sums taken and selected (true) or elements selected and summed (false)
+template <class OBJ, int DN, bool OPT = true>
 __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   constexpr int M = DN + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / DN, gamma = 0.75 - 1.0 / (2.0 * DN), delta = 1.0 - 1.0 / DN;
@@ -965,7 +978,7 @@ __device__ NBP_SOLVE_ATTR void solve_particle_t(int manifold, const double *z, c
   bool conv;
   if constexpr (DN == 1) conv = bfgs_1d(o, xc);
   else if constexpr (PARTIAL_BFGS) conv = bfgs_nd<objective_t<KIND, DN>, DN>(o, xc);
-  else conv = nelder_mead<objective_t<KIND, DN>, DN>(o, xc);
+  else conv = nelder_mead<objective_t<KIND, DN>, DN, KIND != NBP_F_SE2>(o, xc);
   n_solves++;
   n_evals += o.evals;
   if (!conv) n_nonconv++;
@@ -1043,7 +1056,7 @@ __device__ __forceinline__ void deconv_particle_t(const double *a, const double 
   for (int k = 0; k < ZD; k++) zc[k] = z[k];
   bool conv;
   if constexpr (ZD == 1) conv = bfgs_1d(o, zc);
-  else conv = nelder_mead(o, zc);
+  else conv = nelder_mead<deconv_objective_t<KIND, DN, ZD>, ZD, KIND != NBP_F_SE2>(o, zc);
   n_solves++;
   n_evals += o.evals;
   if (!conv) n_nonconv++;
