@@ -12,6 +12,7 @@
 #include <unordered_map>
 
 #include <dlfcn.h>
+#include <algorithm>
 #include <rccl/rccl.h>  // types and prototypes only: the entry points are resolved with dlsym (see rccl_api)
 
 #ifndef NBP_TU
@@ -504,6 +505,20 @@ static nbp_status ensure_pin(nbp_ctx *c, size_t doubles) {
   c->pin_doubles = cap;
   return NBP_OK;
 }
+// The beliefs of a batch are staged IN SLOT ORDER, so that every run of consecutive slots is one copy whatever order the caller
+// names them in: resident handles count down from the end of the arena (handle h = slot n_slots - h), and a graph of a thousand
+// beliefs written or read through its handles was a thousand copies of 4.9 KB (round 6: 1813 `copyBuffer` launches per queued walk
+// of the clique seam, ~3 ms of device time and twice that in launch gaps; tools/exp/seam_walk_trace.sh).  ord[k] = the request
+// staged at position k (stable: a slot named twice keeps the caller's order).
+static std::vector<int> slot_order(int n, const int32_t *slots) {
+  std::vector<int> ord((size_t)(n > 0 ? n : 0));
+  for (int i = 0; i < n; i++) ord[(size_t)i] = i;
+  bool asc = true;
+  for (int i = 1; i < n && asc; i++) asc = slots[i] >= slots[i - 1];
+  if (!asc) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return slots[a] < slots[b]; });
+  return ord;
+}
+
 nbp_status nbp_belief_write_batch(nbp_ctx *c, int32_t n, const int32_t *slots, const int32_t *manifolds, const double *const *pts,
                                   const int32_t *n_pts, const double *const *bw, const double *const *ipc) {
   if (!c || (n > 0 && (!slots || !manifolds || !pts))) return fail(NBP_ERR_ARG, "null argument");
@@ -519,13 +534,15 @@ nbp_status nbp_belief_write_batch(nbp_ctx *c, int32_t n, const int32_t *slots, c
   HIPCHK(hipStreamSynchronize(c->stream));  // the staging buffer is free again (and so is every slot about to be replaced)
   nbp_status rc = ensure_pin(c, (size_t)n * (size_t)c->S);
   if (rc) return rc;
-  host_parallel_for(n, 128, [&](int i) {
-    pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, c->pin + (size_t)i * c->S);
+  const std::vector<int> ord = slot_order(n, slots);
+  host_parallel_for(n, 128, [&](int k) {
+    const int i = ord[(size_t)k];
+    pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, c->pin + (size_t)k * c->S);
   });
   for (int i = 0; i < n;) {
     int j = i + 1;
-    while (j < n && slots[j] == slots[j - 1] + 1) j++;
-    HIPCHK(hipMemcpyAsync(c->arena + c->S * slots[i], c->pin + (size_t)i * c->S, (size_t)(j - i) * c->S * 8, hipMemcpyHostToDevice, c->stream));
+    while (j < n && slots[ord[(size_t)j]] == slots[ord[(size_t)j - 1]] + 1) j++;
+    HIPCHK(hipMemcpyAsync(c->arena + c->S * slots[ord[(size_t)i]], c->pin + (size_t)i * c->S, (size_t)(j - i) * c->S * 8, hipMemcpyHostToDevice, c->stream));
     i = j;
   }
   return NBP_OK;  // stream-ordered: whatever is launched next sees the beliefs; the next use of the staging buffer waits for the copies
@@ -542,16 +559,18 @@ nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, co
   HIPCHK(hipStreamSynchronize(c->stream));
   // ascending slots with small gaps (the updated variables of many cliques): reading the gaps along costs less than a copy
   // per run -- one copy of the whole span while it stays under four times the bytes asked for
-  bool ascending = true;
-  for (int i = 1; i < n; i++) ascending &= slots[i] > slots[i - 1];
-  const size_t span = ascending ? (size_t)(slots[n - 1] - slots[0] + 1) : 0;
-  if (ascending && span > (size_t)n && span <= 4 * (size_t)n) {
+  const std::vector<int> ord = slot_order(n, slots);  // (in slot order: see slot_order)
+  const int32_t s_lo = slots[ord[0]], s_hi = slots[ord[(size_t)n - 1]];
+  bool strictly = true;
+  for (int k = 1; k < n; k++) strictly &= slots[ord[(size_t)k]] > slots[ord[(size_t)k - 1]];
+  const size_t span = strictly ? (size_t)(s_hi - s_lo + 1) : 0;
+  if (strictly && span > (size_t)n && span <= 4 * (size_t)n) {
     nbp_status rc = ensure_pin(c, span * (size_t)c->S);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->pin, c->arena + c->S * slots[0], span * c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->pin, c->arena + c->S * s_lo, span * c->S * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     host_parallel_for(n, 128, [&](int i) {
-      unpack_belief(c, manifolds[i], c->pin + (size_t)(slots[i] - slots[0]) * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr,
+      unpack_belief(c, manifolds[i], c->pin + (size_t)(slots[i] - s_lo) * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr,
                     ipc ? ipc[i] : nullptr);
     });
     return NBP_OK;
@@ -560,13 +579,14 @@ nbp_status nbp_belief_read_batch(nbp_ctx *c, int32_t n, const int32_t *slots, co
   if (rc) return rc;
   for (int i = 0; i < n;) {
     int j = i + 1;
-    while (j < n && slots[j] == slots[j - 1] + 1) j++;
-    HIPCHK(hipMemcpyAsync(c->pin + (size_t)i * c->S, c->arena + c->S * slots[i], (size_t)(j - i) * c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    while (j < n && slots[ord[(size_t)j]] == slots[ord[(size_t)j - 1]] + 1) j++;
+    HIPCHK(hipMemcpyAsync(c->pin + (size_t)i * c->S, c->arena + c->S * slots[ord[(size_t)i]], (size_t)(j - i) * c->S * 8, hipMemcpyDeviceToHost, c->stream));
     i = j;
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  host_parallel_for(n, 128, [&](int i) {
-    unpack_belief(c, manifolds[i], c->pin + (size_t)i * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
+  host_parallel_for(n, 128, [&](int k) {
+    const int i = ord[(size_t)k];
+    unpack_belief(c, manifolds[i], c->pin + (size_t)k * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
   });
   return NBP_OK;
 }
@@ -587,13 +607,15 @@ nbp_status nbp_belief_write_batch_async(nbp_ctx *c, int32_t n, const int32_t *sl
   nbp_ctx::pin_buf *b = pin_acquire(c, (size_t)n * (size_t)c->S * 8);
   if (!b) return fail(NBP_ERR_HIP, "pinned staging buffer");
   double *pin = (double *)b->p;
-  host_parallel_for(n, 128, [&](int i) {
-    pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, pin + (size_t)i * c->S);
+  const std::vector<int> ord = slot_order(n, slots);
+  host_parallel_for(n, 128, [&](int k) {
+    const int i = ord[(size_t)k];
+    pack_belief(c, manifolds[i], pts[i], n_pts ? n_pts[i] : c->N, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr, pin + (size_t)k * c->S);
   });
   for (int i = 0; i < n;) {
     int j = i + 1;
-    while (j < n && slots[j] == slots[j - 1] + 1) j++;
-    if (hipMemcpyAsync(c->arena + c->S * slots[i], pin + (size_t)i * c->S, (size_t)(j - i) * c->S * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+    while (j < n && slots[ord[(size_t)j]] == slots[ord[(size_t)j - 1]] + 1) j++;
+    if (hipMemcpyAsync(c->arena + c->S * slots[ord[(size_t)i]], pin + (size_t)i * c->S, (size_t)(j - i) * c->S * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
       pin_release_behind_stream(c, b);
       return fail(NBP_ERR_HIP, "hipMemcpyAsync (beliefs in)");
     }
@@ -607,6 +629,7 @@ struct nbp_read_token {
   nbp_ctx::pin_buf *buf;
   hipEvent_t done;
   std::vector<int32_t> slots;
+  std::vector<int> ord;  // staging position -> request (slot order: slot_order)
 };
 nbp_status nbp_belief_read_batch_begin(nbp_ctx *c, int32_t n, const int32_t *slots, nbp_read_token **out) {
   if (!c || !out || (n > 0 && !slots)) return fail(NBP_ERR_ARG, "null argument");
@@ -624,10 +647,12 @@ nbp_status nbp_belief_read_batch_begin(nbp_ctx *c, int32_t n, const int32_t *slo
     t->buf = pin_acquire(c, (size_t)n * (size_t)c->S * 8);
     if (!t->buf) { hipEventDestroy(t->done); delete t; return fail(NBP_ERR_HIP, "pinned staging buffer"); }
     double *pin = (double *)t->buf->p;
+    t->ord = slot_order(n, slots);
+    const std::vector<int> &ord = t->ord;
     for (int i = 0; i < n;) {
       int j = i + 1;
-      while (j < n && slots[j] == slots[j - 1] + 1) j++;
-      if (hipMemcpyAsync(pin + (size_t)i * c->S, c->arena + c->S * slots[i], (size_t)(j - i) * c->S * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+      while (j < n && slots[ord[(size_t)j]] == slots[ord[(size_t)j - 1]] + 1) j++;
+      if (hipMemcpyAsync(pin + (size_t)i * c->S, c->arena + c->S * slots[ord[(size_t)i]], (size_t)(j - i) * c->S * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
         pin_release_behind_stream(c, t->buf);
         hipEventDestroy(t->done);
         delete t;
@@ -657,8 +682,9 @@ nbp_status nbp_belief_read_batch_end(nbp_read_token *t, const int32_t *manifolds
   else if (n > 0 && (!manifolds || !pts)) rc = fail(NBP_ERR_ARG, "null argument");
   else if (n > 0) {
     const double *pin = (const double *)t->buf->p;
-    host_parallel_for(n, 128, [&](int i) {
-      if (pts[i]) unpack_belief(c, manifolds[i], pin + (size_t)i * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
+    host_parallel_for(n, 128, [&](int k) {
+      const int i = t->ord[(size_t)k];
+      if (pts[i]) unpack_belief(c, manifolds[i], pin + (size_t)k * c->S, pts[i], n_pts ? &n_pts[i] : nullptr, bw ? bw[i] : nullptr, ipc ? ipc[i] : nullptr);
     });
   }
   if (t->buf) { t->buf->held = false; t->buf->pending = false; }
