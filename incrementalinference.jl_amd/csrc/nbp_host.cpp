@@ -2193,7 +2193,8 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
     if (!rc && async) rc = nbp_program_set_option(p, NBP_OPT_ASYNC_UPLOAD, 1);
     // (the program of a single clique or of a handful is a few launches: replayed as it is, no hipGraph -- a capture per
     //  clique program costs more than it saves, and sixteen callers' contexts would be capturing side by side)
-    if (!rc && plans.size() < 8) rc = nbp_program_set_option(p, NBP_OPT_GRAPH_REPLAY, 0);
+    static const size_t graph_min = getenv("NBP_PLAN_CACHE_GRAPH_MIN") ? (size_t)atoi(getenv("NBP_PLAN_CACHE_GRAPH_MIN")) : 8;
+    if (!rc && plans.size() < graph_min) rc = nbp_program_set_option(p, NBP_OPT_GRAPH_REPLAY, 0);
     for (const stage_buf &b : stg)
       if (!rc) rc = nbp_program_add_stage(p, b.kind, b.bytes.data(), b.n);
     if (!rc) rc = nbp_program_finalize(p);
