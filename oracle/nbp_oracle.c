@@ -943,7 +943,17 @@ double orc_lcv_bandwidth_1d(const double *x, int32_t N, int32_t circ) {
 static void fit_bandwidth(double *slot, int N, int manifold) {
   int D = mani_dim(manifold);
   const int cnt = slot_count(slot, N); /* manikde! of the points the belief holds */
-  for (int d = 0; d < D; d++) slot[3 * N + d] = orc_lcv_bandwidth_1d(slot + d * N, cnt, is_circ(manifold, d));
+  for (int d = 0; d < D; d++) {
+    /* a circular coordinate is fitted on its representative in [-pi, pi): the identity for a stored belief, not for the
+     * predicted measurements of a deconvolution (orc_run_deconv leaves b - a as the search found it), whose neighbour
+     * distances would otherwise round differently from those of the wrapped angles */
+    if (is_circ(manifold, d)) {
+      double w[NBP_MAXN];
+      for (int i = 0; i < cnt; i++) w[i] = orc_wrap(slot[d * N + i]);
+      slot[3 * N + d] = orc_lcv_bandwidth_1d(w, cnt, 1);
+    } else
+      slot[3 * N + d] = orc_lcv_bandwidth_1d(slot + d * N, cnt, 0);
+  }
   for (int d = D; d < 3; d++) slot[3 * N + d] = 0.0;
 }
 

@@ -528,3 +528,35 @@ def test_stored_measurements_gpu(oracle_backend, hip_backend):
                 lambda be: [be.slot_read(s, man)[0] for s in (2, 3)])
     for k in range(2):
         assert_points_close(man, h[k], o[k], rtol=0, max_bad=0, what=f"proposal {k}")
+
+
+# ---- manikde! of predicted measurements: a circular coordinate is fitted on its wrapped representative --------------------
+@pytest.mark.parametrize("manifold", [abi.CIRCULAR, abi.SE2])
+@pytest.mark.parametrize("N", [200, 300])
+def test_fit_of_angles_a_deconvolution_leaves_unwrapped(oracle_backend, hip_backend, manifold, N):
+    """approxDeconv stores b - a as the search found it: outside [-pi, pi) for one point in ten on a circle.  The fit of such
+    a slot is the fit of the wrapped angles (the kernels stage them wrapped), bit for bit the oracle's -- and the fit of the
+    same points written wrapped.  (Found by the stage-wise harness with useMsgLikelihoods: profiles/r06_stagewise_other_solver_parameters.txt)"""
+    rng = np.random.default_rng(90 + manifold + N)
+    D = abi.MANIFOLD_DIM[manifold]
+    rows = np.zeros((N, 3))
+    rows[:, :D] = rng.normal(size=(N, D)) * 2.0
+    rows[:, D - 1] = rng.uniform(-2 * np.pi, 2 * np.pi, size=N)  # the circular coordinate, as raw as a search leaves it
+    wrapped = rows.copy()
+    wrapped[:, D - 1] = (rows[:, D - 1] + np.pi) % (2 * np.pi) - np.pi
+
+    def setup(be):
+        be.slot_write(0, abi.EUCLID3, rows)
+        be.slot_write(1, abi.EUCLID3, wrapped)
+
+    def read(be):
+        return be.slot_read(0, abi.EUCLID3), be.slot_read(1, abi.EUCLID3)
+
+    o, h = both(oracle_backend, hip_backend, N, 2, 0, setup, lambda be: be.run_bandwidth([0, 1], [manifold, manifold]), read)
+    for s in (0, 1):
+        assert np.array_equal(o[s][0], h[s][0]) and np.array_equal(np.asarray(o[s][1]), np.asarray(h[s][1]))
+    assert np.array_equal(h[0][0], rows)  # the fit does not touch the points
+    bw_raw, bw_wrapped = np.asarray(h[0][1]), np.asarray(h[1][1])
+    assert np.all(bw_raw[:D] > 0)
+    # the same KDE: the two fits can only differ through the rounding of the host-side wrap above (an ulp on a few angles)
+    np.testing.assert_allclose(bw_raw, bw_wrapped, rtol=0.05)

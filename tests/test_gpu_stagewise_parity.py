@@ -76,7 +76,10 @@ def test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hi
             what = "products" if kind == abi.STAGE_PRODUCTS else "proposals"
             for i, d in enumerate(descs):
                 # the stored coordinates themselves: an SE(2) slot read as its three rows (x, y, theta)
-                rm = abi.EUCLID3 if d.manifold == abi.SE2 else d.manifold
+                # (and the predicted measurements of a deconvolution stage as rows too: b - a on the circle is stored as the search
+                #  found it, outside [-pi, pi) for one point in ten, and a read / write through the circular manifold would hand
+                #  the device the WRAPPED angles -- 2 pi away from the oracle's in the starts of the next level's searches)
+                rm = abi.EUCLID3 if d.manifold == abi.SE2 or kind == abi.STAGE_DECONV else d.manifold
                 (po, bo), (ph, bh) = bes[0].slot_read(d.out_slot, rm), bes[1].slot_read(d.out_slot, rm)
                 bo, bh = np.asarray(bo, dtype=float), np.asarray(bh, dtype=float)
                 if not (np.array_equal(po, ph) and np.array_equal(bo, bh)):

@@ -11,6 +11,12 @@ builder-run scripts then (tools/exp/stagewise_any_n.py, tools/exp/many_density_p
 (1) every BASELINE shape (reduced graphs), EVERY STAGE of its tree program on the oracle's state, at N = 64, 150, 257, 300, 500:
     one wave, a ragged third wave, 4k + 1 waves (the five-waves-per-SIMD instances), BASELINE's other count, eight waves.
 (2) products of 8 / 32 / 128 densities in ONE launch beside two- and three-density ones, five manifolds, N = 100 / 200 / 300.
+(3) every BASELINE shape with the SOLVER PARAMETERS its configurations leave at their defaults set otherwise: joint messages
+    (useMsgLikelihoods -> deconvolution stages and message-likelihood factors), the number of product iterations and Gibbs
+    sweeps, the inflation cycles and their spread, limitfixeddown, no null-hypothesis surplus.  The first run of this sweep
+    (tools/exp/stagewise_other_params.sh, profiles/r06_stagewise_other_solver_parameters.txt) found the two places where
+    checker and harness did not treat an UNWRAPPED angle the way the kernels do: the fit of a deconvolution's output, and the
+    hand-back of one through the circular manifold.
 What is asserted is np.array_equal on stored coordinates and bandwidths (tests/test_gpu_stagewise_parity.py says why that holds)."""
 import numpy as np
 import pytest
@@ -55,3 +61,26 @@ def test_products_of_many_densities_beside_small_ones(hip_backend, man, N):
     for i in keep:
         assert np.array_equal(d[i], o[i]), (f"product {i} of the launch ({Fs[i]} densities, manifold {man}, N = {N}): "
                                            f"{int((d[i] != o[i]).any(axis=1).sum())} of {N} samples differ, by up to {np.abs(d[i] - o[i]).max():.2e}")
+
+
+SETTINGS = [{"useMsgLikelihoods": True}, {"productNiter": 2}, {"productNiter": 8}, {"inflateCycles": 1}, {"inflateCycles": 5},
+            {"gibbsIters": 1}, {"gibbsIters": 5}, {"limitfixeddown": True}, {"spreadNH": 1.0, "inflation": 2.0}, {"nullSurplusAdd": 0.0}]
+
+
+@pytest.mark.parametrize("setting", SETTINGS, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_every_stage_with_solver_parameters_baseline_leaves_at_their_defaults(oracle_backend, hip_backend, shape, setting):
+    name = f"{shape}_full_size_probe_" + "_".join(setting)
+
+    def make():
+        fg = SHAPES[shape](200)
+        for k, v in setting.items():
+            assert hasattr(fg.solverParams, k), k
+            setattr(fg.solverParams, k, v)
+        return fg
+
+    stagewise.FULL[name] = make
+    try:
+        stagewise.test_every_stage_of_the_tree_program_on_the_oracles_state(oracle_backend, hip_backend, name)
+    finally:
+        del stagewise.FULL[name]
