@@ -403,11 +403,19 @@ int main(int argc, char **argv) {
   for (int c = 1; c <= ncl; c++) { int d = 0; for (int p = H.info[c].parent; p; p = H.info[p].parent) d++; H.depth[c] = d; if (d > maxdepth) maxdepth = d; }
   /* one context per concurrent caller: the cliques of a tree level are independent of each other (the reference runs them
    * as concurrent tasks, CliqueStateMachine.jl), and contexts share nothing */
+  /* NBP_SHARED_CTX=1: every caller on the SAME context -- the library merges the single-clique calls that arrive while a batch
+   * is on the device into the next batch (nbp_host.cpp, "single-clique calls ... merged"): the callers keep the reference's shape,
+   * one task and one call per clique, and the device sees a launch per round of a dozen cliques instead of a dozen launches */
+  const int shared = getenv("NBP_SHARED_CTX") && atoi(getenv("NBP_SHARED_CTX")) && !batched;
+  /* (NBP_SHARED_SLOTS=n: the shared context is one of its own with n belief slots -- room for a few cliques only, so that a
+   *  merged batch has to be cut to what the context holds) */
+  nbp_ctx *sctx = ctx;
+  if (shared && getenv("NBP_SHARED_SLOTS")) CHK(nbp_ctx_create(0, N, atoi(getenv("NBP_SHARED_SLOTS")), NULL, 0, 0, &sctx));
   worker *W = calloc((size_t)threads, sizeof(*W));
   for (int t = 0; t < threads; t++) {
     W[t] = worker_new(nvars, nfac);
-    W[t].ctx = t == 0 ? ctx : NULL;
-    if (t > 0) CHK(nbp_ctx_create(0, N, 256, NULL, 0, 0, &W[t].ctx));
+    W[t].ctx = shared ? sctx : (t == 0 ? ctx : NULL);
+    if (!W[t].ctx) CHK(nbp_ctx_create(0, N, 256, NULL, 0, 0, &W[t].ctx));
   }
   nbp_ctx *bctx = NULL; /* batched mode: a context with room for the widest level */
   if (batched) {
@@ -489,7 +497,8 @@ int main(int argc, char **argv) {
   if (!pass) t_first = now_s() - tb; else if (pass < nwalks) { t_calls = now_s() - tb; t_queued_calls = t_queued; } else { t_timed = now_s() - tb; nbp_clique_seam_times(ph, 1); }
   }
   if (failed) return 4;
-  for (int t = 1; t < threads; t++) nbp_ctx_destroy(W[t].ctx);
+  for (int t = 1; t < threads && !shared; t++) nbp_ctx_destroy(W[t].ctx);
+  if (sctx != ctx) nbp_ctx_destroy(sctx);
   /* ---- compare -------------------------------------------------------------------------------------------------- */
   /* (the walk's launches and the program's differ in size and so, from some size on, in geometry -- helper lanes per sample, rows of
    *  a fit, one wave per proposal: summation-order rounding, nbp_host.h -- and a Gibbs chain turns one flipped label into other
@@ -505,7 +514,7 @@ int main(int argc, char **argv) {
   }
   printf("solve_by_clique_calls: %d variables, %d cliques: %d of %d posteriors byte-identical to the whole-tree program (means of the others within %.3f); "
          "infoPerCoord of x0 = (%.0f, %.0f); worst posterior mean error %.3f; %s%d concurrent caller(s), GPU_MAX_HW_QUEUES=%s\n", nvars, ncl, same, nvars,
-         worst_dm, post[0].ipc[0], post[0].ipc[1], worst, queued ? (keep ? "one QUEUED batch per tree level (resident beliefs, submit / wait), the requests KEPT across walks, " : "one QUEUED batch per tree level (resident beliefs, submit / wait), ") : (batched ? "one batched call per tree level, " : ""), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
+         worst_dm, post[0].ipc[0], post[0].ipc[1], worst, queued ? (keep ? "one QUEUED batch per tree level (resident beliefs, submit / wait), the requests KEPT across walks, " : "one QUEUED batch per tree level (resident beliefs, submit / wait), ") : (batched ? "one batched call per tree level, " : (shared ? "callers on ONE context (their calls merged by the library), " : "")), threads, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset: 4)");
   const int msgs = 2 * (ncl - 1);
   printf("  resident whole-tree program: first run %.1f ms, replayed %.1f ms = %.0f clique messages/s (+ %.1f ms to write and read every belief "
          "of the graph over PCIe, one batched call each way: %.0f messages/s);  one C call per clique, beliefs from and to host memory: %.1f ms = %.0f clique messages/s "

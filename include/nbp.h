@@ -211,6 +211,7 @@ void *nbp_arena_ptr(nbp_ctx *ctx);
 void *nbp_stream_ptr(nbp_ctx *ctx); /* hipStream_t the library launches on */
 int32_t nbp_ctx_particles(const nbp_ctx *ctx); /* N the context was created for (0: null) */
 int32_t nbp_ctx_slots(const nbp_ctx *ctx);     /* belief slots of its arena (0: null) */
+int32_t nbp_ctx_device(const nbp_ctx *ctx);    /* the HIP device it was created on (-1: null) */
 /* Resident slots: the LAST n slots of the arena are set aside for beliefs that STAY on the device between clique calls --
  * the deep-copied sub graph of a clique between its up and its down solve, the up message a parent reads from its child
  * (a LikelihoodMessage that never visits the host: nbp_tree_belief.handle, nbp_host.h).  Handle h (1 .. n) names slot

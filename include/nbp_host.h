@@ -246,6 +246,15 @@ int32_t nbp_clique_slots(const nbp_clique_desc *cliq);
 /* beliefs_inout[nvars]: in = the beliefs of the clique sub graph (the deep copy the CSM made); out = the belief of
  * every variable the schedule updated (the others are left as they were).  status_out (nullable) = NBP_CLIQ_UPSOLVED /
  * NBP_CLIQ_DOWNSOLVED.  Hard errors return < 0 (the shim raises, the CSM monitor propagates ERROR_STATUS). */
+/* CONCURRENT CALLERS.  These three calls may be made from several host threads on ONE context -- the reference's shape, a
+ * task per clique (CliqueStateMachine.jl; SolverAPI.jl:59-97).  Calls that arrive while a batch is on the device are merged
+ * into the next batch (the path of nbp_clique_solve_batch below): the first caller that finds a free lane leads, gives the
+ * callers the last batch released a moment to come back (NBP_COMBINE_GATHER_US, 150), takes what has queued up, runs it and
+ * wakes its callers.  Lanes (NBP_COMBINE_LANES, 2) are the context itself and contexts of the library's own on the same
+ * device, so that two batches are on the device side by side; a request whose beliefs are resident handles runs on the
+ * caller's context only.  Every caller gets its own status and message; the bytes of a result do not depend on what it was
+ * batched with.  1000-variable chain, 16 callers: 171 ms a walk with a context per caller, 116 ms merged
+ * (profiles/r06_clique_seam_rate.txt).  A lone caller's call is a batch of one, as it always was. */
 nbp_status nbp_clique_upsolve(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,
                               nbp_tree_belief *beliefs_inout, int32_t *status_out);
 nbp_status nbp_clique_downsolve(nbp_ctx *ctx, const nbp_solver_params *params, const nbp_clique_desc *cliq, uint64_t seed,

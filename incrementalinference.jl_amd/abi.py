@@ -95,7 +95,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libnbp.so")
 # every symbol include/nbp.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "nbp_arena_bytes", "nbp_slot_stride_doubles", "nbp_ctx_create", "nbp_ctx_destroy",
-    "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr", "nbp_ctx_particles", "nbp_ctx_slots",
+    "nbp_last_error", "nbp_synchronize", "nbp_arena_ptr", "nbp_stream_ptr", "nbp_ctx_particles", "nbp_ctx_slots", "nbp_ctx_device",
     "nbp_ctx_reserve_resident", "nbp_ctx_resident", "nbp_belief_write_batch_async", "nbp_belief_read_batch_begin", "nbp_belief_read_batch_end",
     "nbp_run_copies_async", "nbp_program_retire",
     "nbp_slot_write", "nbp_slot_read", "nbp_belief_write", "nbp_belief_read", "nbp_belief_write_batch", "nbp_belief_read_batch", "nbp_run_resample", "nbp_side_write", "nbp_side_read",
@@ -147,6 +147,7 @@ def load_library(path=None):
     lib.nbp_stream_ptr.argtypes = [vp]
     lib.nbp_ctx_particles.argtypes = [vp]
     lib.nbp_ctx_slots.argtypes = [vp]
+    lib.nbp_ctx_device.argtypes = [vp]
     lib.nbp_slot_write.argtypes = [vp, i32, i32, dp, dp]
     lib.nbp_slot_read.argtypes = [vp, i32, i32, dp, dp]
     lib.nbp_belief_write.argtypes = [vp, i32, i32, dp, i32, dp, dp]

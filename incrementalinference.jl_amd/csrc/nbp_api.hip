@@ -367,6 +367,7 @@ void *nbp_arena_ptr(nbp_ctx *c) { return c ? c->arena : nullptr; }
 void *nbp_stream_ptr(nbp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int32_t nbp_ctx_particles(const nbp_ctx *c) { return c ? c->N : 0; }
 int32_t nbp_ctx_slots(const nbp_ctx *c) { return c ? c->n_slots : 0; }
+int32_t nbp_ctx_device(const nbp_ctx *c) { return c ? c->device : -1; }
 int32_t nbp_ctx_resident(const nbp_ctx *c) { return c ? c->resident : 0; }
 nbp_status nbp_ctx_reserve_resident(nbp_ctx *c, int32_t n) {
   if (!c) return fail(NBP_ERR_ARG, "ctx is null");
@@ -1631,6 +1632,9 @@ nbp_status nbp_program_add_stage(nbp_program *p, int32_t kind, const void *descs
 
 nbp_status nbp_program_set_option(nbp_program *p, int32_t option, int32_t value) {
   if (!p) return fail(NBP_ERR_ARG, "null argument");
+  // (graph replay is a property of the runs, not of the compiled stages: it may be switched after nbp_program_finalize --
+  //  graphs already captured stay with the program and are used again when it is switched back on)
+  if (option == NBP_OPT_GRAPH_REPLAY && p->finalized) { p->use_graph = value != 0; return NBP_OK; }
   if (p->finalized) return fail(NBP_ERR_ARG, "program already finalized");
   // NBP_NO_LAZY_BANDWIDTH=1 (environment): every fit the reference makes is made, whatever the program asks for -- the
   // measurement of what the option saves (bench.py "ms_per_step_every_fit")

@@ -2043,21 +2043,63 @@ struct plan_cache {
     for (entry &x : e) nbp_program_destroy(x.prog);
   }
 };
-static void plan_cache_destroy(void *o) { delete (plan_cache *)o; }
-static plan_cache *plan_cache_of(nbp_ctx *ctx) {
-  static const int on = getenv("NBP_PLAN_CACHE") ? atoi(getenv("NBP_PLAN_CACHE")) : 1;
-  if (!on) return nullptr;
+// What rides with a context on the host side (nbp_ctx_attach; destroyed at the top of nbp_ctx_destroy): its plan cache and the
+// queue in which single-clique calls from several host threads are merged (clique_solve below).
+struct combine_req {
+  nbp_clique_request r;
+  int32_t *status_out = nullptr;
+  nbp_status rc = NBP_OK;
+  std::string err;
+  bool taken = false, done = false;  // taken: in a batch that is running
+};
+struct combiner {
+  std::mutex mu;
+  std::condition_variable cv, cv_lead;  // cv: "a batch is done / a lane is free"; cv_lead: "another request has queued up" (for a gathering leader only)
+  std::deque<combine_req *> q;
+  // lanes: lane 0 is the caller's context, the others are contexts of the library's own (same device, N, slots), created when
+  // a second leader first needs one; one batch per lane at a time, batches of different lanes side by side on the device
+  std::vector<nbp_ctx *> lane;
+  std::vector<char> busy;
+  int nbusy = 0;
+  bool gathering = false;
+  size_t inflight = 0;  // requests in the batches now running
+  size_t expect = 1;    // callers seen when the last batch ended (running + queued)
+  uint64_t batches = 0, merged = 0, widest = 0, lanes_used = 1;
+};
+struct ctx_host_state {
+  plan_cache *pc = nullptr;
+  combiner cb;
+  ~ctx_host_state() {
+    if (getenv("NBP_PLAN_CACHE_STATS") && cb.widest > 1)
+      fprintf(stderr, "[libnbp] single-clique calls merged: %llu calls in %llu batches (widest %llu) on %llu lane(s)\n", (unsigned long long)cb.merged,
+              (unsigned long long)cb.batches, (unsigned long long)cb.widest, (unsigned long long)cb.lanes_used);
+    for (size_t i = 1; i < cb.lane.size(); i++)
+      if (cb.lane[i]) nbp_ctx_destroy(cb.lane[i]);
+    delete pc;
+  }
+};
+static void ctx_host_state_destroy(void *o) { delete (ctx_host_state *)o; }
+static ctx_host_state *host_state_of(nbp_ctx *ctx) {
   static std::mutex make_mu;
   std::lock_guard<std::mutex> lk(make_mu);
-  plan_cache *pc = (plan_cache *)nbp_ctx_attached(ctx);
-  if (!pc) {
-    pc = new plan_cache();
-    if (getenv("NBP_PLAN_CACHE_ENTRIES")) pc->cap = (size_t)std::max(0, atoi(getenv("NBP_PLAN_CACHE_ENTRIES")));
-    if (nbp_ctx_attach(ctx, pc, plan_cache_destroy)) { delete pc; return nullptr; }
+  ctx_host_state *hs = (ctx_host_state *)nbp_ctx_attached(ctx);
+  if (!hs) {
+    hs = new ctx_host_state();
+    static const int on = getenv("NBP_PLAN_CACHE") ? atoi(getenv("NBP_PLAN_CACHE")) : 1;
+    if (on) {
+      hs->pc = new plan_cache();
+      if (getenv("NBP_PLAN_CACHE_ENTRIES")) hs->pc->cap = (size_t)std::max(0, atoi(getenv("NBP_PLAN_CACHE_ENTRIES")));
+    }
+    if (nbp_ctx_attach(ctx, hs, ctx_host_state_destroy)) { delete hs; return nullptr; }
   }
-  return pc;
+  return hs;
+}
+static plan_cache *plan_cache_of(nbp_ctx *ctx) {
+  ctx_host_state *hs = host_state_of(ctx);
+  return hs ? hs->pc : nullptr;
 }
 static inline int resident_slot(nbp_ctx *ctx, int handle) { return nbp_ctx_slots(ctx) - handle; }
+static thread_local bool t_merged_calls = false;  // this thread is running a batch merged from concurrent single-clique calls (clique_solve)
 static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &plans, nbp_clique_ticket *T, bool async) {
   const int nres = nbp_ctx_resident(ctx), cap = nbp_ctx_slots(ctx) - nres;
   {
@@ -2183,6 +2225,7 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
     rc = nbp_program_num_seeds(p, &ns);
     if (!rc && ns != (int32_t)seeds.size()) rc = hfail(NBP_ERR_ARG, "plan cache: the cached program's seed count is not the plan's");
     if (!rc) rc = nbp_program_set_seeds(p, seeds.data(), ns);
+    if (!rc && t_merged_calls) rc = nbp_program_set_option(p, NBP_OPT_GRAPH_REPLAY, 0);
     if (rc) return rc;
   } else {
     rc = nbp_program_create(ctx, &p);
@@ -2194,7 +2237,10 @@ static nbp_status clique_plans_submit(nbp_ctx *ctx, std::vector<clique_plan> &pl
     // (the program of a single clique or of a handful is a few launches: replayed as it is, no hipGraph -- a capture per
     //  clique program costs more than it saves, and sixteen callers' contexts would be capturing side by side)
     static const size_t graph_min = getenv("NBP_PLAN_CACHE_GRAPH_MIN") ? (size_t)atoi(getenv("NBP_PLAN_CACHE_GRAPH_MIN")) : 8;
-    if (!rc && plans.size() < graph_min) rc = nbp_program_set_option(p, NBP_OPT_GRAPH_REPLAY, 0);
+    // (nor the batches merged from concurrent callers: their composition changes from round to round, and a capture on one lane
+    //  while another lane's leader synchronises its stream is refused by the runtime -- "operation not permitted when stream is
+    //  capturing", one walk in a few, whatever the capture mode)
+    if (!rc && (plans.size() < graph_min || t_merged_calls)) rc = nbp_program_set_option(p, NBP_OPT_GRAPH_REPLAY, 0);
     for (const stage_buf &b : stg)
       if (!rc) rc = nbp_program_add_stage(p, b.kind, b.bytes.data(), b.n);
     if (!rc) rc = nbp_program_finalize(p);
@@ -2240,20 +2286,6 @@ static nbp_status clique_particles_ok(nbp_ctx *ctx, const nbp_solver_params *sp)
                                std::to_string(nbp_ctx_particles(ctx))).c_str());
   return NBP_OK;
 }
-static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
-                               nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
-  if (!ctx) return hfail(NBP_ERR_ARG, "null argument");
-  if (nbp_status rn = clique_particles_ok(ctx, sp)) return rn;
-  std::vector<clique_plan> plans(1);
-  const double t0 = seam_now();
-  nbp_status rc = clique_plan_build(sp, q, seed, bel, down, diff_out, plans[0]);
-  seam_add(0, seam_now() - t0); seam_add(5, 1);
-  if (!rc) rc = clique_plans_run(ctx, plans);
-  if (rc) return rc;
-  if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
-  return NBP_OK;
-}
-
 // A small persistent pool for the planning of a batch (round 6; through round 5 every call with >= 64 requests spawned and
 // joined up to seven std::threads: ~40 thread creations per walk of a 1000-variable tree).  Workers are started on first use and
 // sleep on a condition variable between batches; a batch is a function of (part, parts) run once per part, part 0 on the calling
@@ -2343,6 +2375,133 @@ static nbp_status clique_batch_plans(nbp_ctx *ctx, nbp_clique_request *req, int3
       }
   }
   seam_add(0, seam_now() - t0); seam_add(5, 1);
+  return NBP_OK;
+}
+
+// ---- single-clique calls from several host threads on ONE context: merged ------------------------------------------------
+// The reference runs the cliques of a tree level as concurrent tasks, each calling its own solve (CliqueStateMachine.jl,
+// SolverAPI.jl:59-97).  Through round 5 a host that kept that shape needed one context per task, and 16 such callers walked
+// the 1000-variable chain in 171-198 ms -- three times the lone caller's time per call: every call pays its own transfers,
+// its own five or six latency-bound launches and its own wait, and sixteen streams of those do not share the device the way
+// one launch serving sixteen cliques does.  Here calls that arrive while a batch is on the device are MERGED: the first caller
+// to find nobody leading leads -- it takes what has queued up (its own request among it), runs it as one batch
+// (nbp_clique_solve_batch's path), marks those requests done and wakes their callers; a caller that wakes with its request
+// still queued leads the next round.  Nothing in a clique's result depends on what it was batched with (streams keyed by
+// (seed, pass, clique, step, factor); nbp_host.h says where a batch's bytes can differ from a single call's: nowhere on a
+// chain).  A lone caller's call is a batch of one behind an uncontended mutex, as before; and concurrent single-clique calls
+// on one context, which used to trample each other's slots, are now simply correct.
+static void combine_run(nbp_ctx *ctx, std::vector<combine_req *> &batch, std::vector<combine_req *> &back) {
+  const int n = (int)batch.size();
+  std::vector<nbp_clique_request> req((size_t)n);
+  for (int i = 0; i < n; i++) req[(size_t)i] = batch[(size_t)i]->r;
+  std::vector<clique_plan> plans((size_t)n);
+  nbp_status rc = clique_batch_plans(ctx, req.data(), n, plans);
+  int take = n;
+  if (!rc && n > 1) {  // as many as the context has slots for (at least one: a clique too large for it reports that itself)
+    const int cap = nbp_ctx_slots(ctx) - nbp_ctx_resident(ctx);
+    int need = 0;
+    take = 0;
+    while (take < n && (take == 0 || need + plans[(size_t)take].nslots <= cap)) need += plans[(size_t)take++].nslots;
+    if (take < n) {
+      back.assign(batch.begin() + take, batch.end());
+      batch.resize((size_t)take);
+      plans.resize((size_t)take);
+    }
+  }
+  t_merged_calls = true;
+  // (the synchronous path: the queued one -- pinned staging, the wait on the batch's own event -- measured 5-15 % slower here,
+  //  two lanes' worth of short batches gain nothing from a copy the stream makes)
+  if (!rc) rc = clique_plans_run(ctx, plans);
+  t_merged_calls = false;
+  if (rc && take > 1) {  // whose fault: each request on its own, so that every caller gets its own status and message
+    for (combine_req *b : batch) {
+      std::vector<clique_plan> one(1);
+      b->rc = clique_batch_plans(ctx, &b->r, 1, one);
+      if (!b->rc) b->rc = clique_plans_run(ctx, one);
+      if (b->rc) b->err = nbp_last_error();
+    }
+    return;
+  }
+  for (combine_req *b : batch) {
+    b->rc = rc;
+    if (rc) b->err = nbp_last_error();
+  }
+}
+static bool request_is_resident(const nbp_clique_request &r) {  // a belief named by handle lives in the caller's context
+  for (int i = 0; i < r.clique->nvars; i++) if (r.beliefs && r.beliefs[i].handle > 0) return true;
+  for (int i = 0; i < r.clique->n_diff; i++) if (r.diff_out && r.diff_out[i].handle > 0) return true;
+  return false;
+}
+static nbp_status clique_solve(nbp_ctx *ctx, const nbp_solver_params *sp, const nbp_clique_desc *q, uint64_t seed,
+                               nbp_tree_belief *bel, int32_t *status_out, bool down, nbp_tree_belief *diff_out = nullptr) {
+  if (!ctx || !sp || !q) return hfail(NBP_ERR_ARG, "null argument");
+  ctx_host_state *hs = host_state_of(ctx);
+  if (!hs) return hfail(NBP_ERR_ARG, "clique: the context carries a foreign attachment");
+  combiner &C = hs->cb;
+  static const int widest = getenv("NBP_COMBINE_MAX") ? std::max(1, atoi(getenv("NBP_COMBINE_MAX"))) : 256;
+  static const int nlanes = getenv("NBP_COMBINE_LANES") ? std::min(16, std::max(1, atoi(getenv("NBP_COMBINE_LANES")))) : 2;
+  // the callers a batch has just released need a moment to come back with their next clique (wake up, assemble the sub
+  // graph): a leader that saw more callers when the last batch ended than are queued now gives them that moment, once
+  static const int gather_us = getenv("NBP_COMBINE_GATHER_US") ? std::max(0, atoi(getenv("NBP_COMBINE_GATHER_US"))) : 150;
+  combine_req me;
+  me.r = nbp_clique_request{sp, q, seed, bel, diff_out, down ? 1 : 0, 0};
+  const bool home = request_is_resident(me.r);
+  std::unique_lock<std::mutex> lk(C.mu);
+  if (C.lane.empty()) { C.lane.assign((size_t)nlanes, nullptr); C.lane[0] = ctx; C.busy.assign((size_t)nlanes, 0); }
+  C.q.push_back(&me);
+  if (C.gathering) C.cv_lead.notify_one();
+  while (!me.done) {
+    // lead on a free lane (a request with resident beliefs: on the caller's own context only); one leader gathers at a time
+    int L = -1;
+    if (!C.gathering && !me.taken)
+      for (int i = 0; i < (home ? 1 : nlanes) && L < 0; i++) if (!C.busy[(size_t)i]) L = i;
+    if (L < 0) { C.cv.wait(lk); continue; }
+    if (!C.lane[(size_t)L]) {  // (created under the lock: once per lane and context)
+      nbp_ctx *lc = nullptr;
+      const int slots = std::min(nbp_ctx_slots(ctx) - nbp_ctx_resident(ctx), 8192);
+      if (nbp_ctx_create(nbp_ctx_device(ctx), nbp_ctx_particles(ctx), slots < 64 ? 64 : slots, nullptr, 0, 0, &lc)) {
+        C.busy[(size_t)L] = 2;  // no memory for another lane: it stays closed, the caller takes an open one
+        continue;
+      }
+      C.lane[(size_t)L] = lc;
+      if ((uint64_t)L + 1 > C.lanes_used) C.lanes_used = (uint64_t)L + 1;
+    }
+    C.busy[(size_t)L] = 1;
+    C.nbusy++;
+    // this lane's share of the callers around: with every lane busy in turn, a batch is one lane's worth of them
+    const size_t share = (C.expect + (size_t)nlanes - 1) / (size_t)nlanes;
+    if (gather_us && C.q.size() < share && C.expect > 1) {
+      C.gathering = true;
+      const size_t want = std::min(share, (size_t)widest);
+      C.cv_lead.wait_for(lk, std::chrono::microseconds(gather_us), [&] { return C.q.size() >= want; });
+      C.gathering = false;
+    }
+    std::vector<combine_req *> batch, back;
+    for (auto it = C.q.begin(); it != C.q.end() && (int)batch.size() < widest;) {
+      if (L > 0 && request_is_resident((*it)->r)) { ++it; continue; }
+      (*it)->taken = true;
+      batch.push_back(*it);
+      it = C.q.erase(it);
+    }
+    C.inflight += batch.size();
+    C.cv.notify_all();  // (the gathering is over: another caller may lead on another lane)
+    lk.unlock();
+    if (!batch.empty()) combine_run(C.lane[(size_t)L], batch, back);
+    lk.lock();
+    for (size_t i = back.size(); i > 0; i--) { back[i - 1]->taken = false; C.q.push_front(back[i - 1]); }  // (no room in the context this time: first in line next time)
+    C.inflight -= batch.size() + back.size();
+    for (combine_req *b : batch) b->done = true;
+    C.expect = batch.size() + C.inflight + C.q.size();
+    C.batches++;
+    C.merged += batch.size();
+    if (batch.size() > C.widest) C.widest = batch.size();
+    C.busy[(size_t)L] = 0;
+    C.nbusy--;
+    C.cv.notify_all();
+  }
+  lk.unlock();
+  if (me.rc) return hfail(me.rc, me.err.c_str());
+  if (status_out) *status_out = down ? NBP_CLIQ_DOWNSOLVED : NBP_CLIQ_UPSOLVED;
   return NBP_OK;
 }
 

@@ -80,6 +80,16 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
     out = subprocess.run([exe, "60", "100", "10", "4"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "60 of 60 posteriors byte-identical" in out.stdout and "4 concurrent caller(s)" in out.stdout, out.stdout
+    # the same callers -- 4, 16 and 48 of them -- on ONE context: the library merges the single-clique calls that arrive while a
+    # batch is on the device into the next one (one lane, two lanes side by side, four; with and without the moment a leader
+    # gives the others to come back; batches cut to five requests): one call and one result per clique, the same bytes
+    for callers, env_extra in (("4", {}), ("16", {}), ("48", {"NBP_COMBINE_LANES": "4"}), ("16", {"NBP_COMBINE_LANES": "1", "NBP_COMBINE_GATHER_US": "0"}),
+                               ("16", {"NBP_COMBINE_MAX": "5"}), ("16", {"NBP_SHARED_SLOTS": "24"})):  # (24 slots: a batch is cut to the two or three cliques that fit)
+        env = dict(os.environ, NBP_SHARED_CTX="1", NBP_PLAN_CACHE_STATS="1", **env_extra)
+        out = subprocess.run([exe, "200", "100", "20", callers], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "200 of 200 posteriors byte-identical" in out.stdout and "callers on ONE context" in out.stdout, (env_extra, out.stdout)
+        assert "single-clique calls merged" in out.stderr, out.stderr[-500:]  # (it did merge: the widest batch held several calls)
     # the cliques of a tree level in one nbp_clique_solve_batch call
     out = subprocess.run([exe, "60", "100", "10", "0"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
