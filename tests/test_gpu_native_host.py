@@ -89,7 +89,8 @@ def test_pure_c_clique_calls_equal_whole_tree_program(tmp_path):
         out = subprocess.run([exe, "200", "100", "20", callers], capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "200 of 200 posteriors byte-identical" in out.stdout and "callers on ONE context" in out.stdout, (env_extra, out.stdout)
-        assert "single-clique calls merged" in out.stderr, out.stderr[-500:]  # (it did merge: the widest batch held several calls)
+        if int(callers) >= 16:  # (it did merge: the widest batch held several calls -- with sixteen callers behind a 0.5 ms batch, always)
+            assert "single-clique calls merged" in out.stderr, out.stderr[-500:]
     # the cliques of a tree level in one nbp_clique_solve_batch call
     out = subprocess.run([exe, "60", "100", "10", "0"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
