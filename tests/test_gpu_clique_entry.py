@@ -191,3 +191,55 @@ def test_clique_batch_rejects_bad_input_and_takes_an_empty_batch(hip_backend):
         assert lib.nbp_clique_solve_batch(be._ctx, None, 0) == 0
     finally:
         be.close()
+
+
+def test_concurrent_single_clique_calls_on_one_context_are_merged_and_keep_their_own_errors(hip_backend):
+    """nbp_clique_upsolve from several host threads on ONE context (include/nbp_host.h, "CONCURRENT CALLERS"): the library merges the
+    calls into batches.  Eight Python threads (ctypes releases the GIL), five of them with good requests -- each must come out
+    with the bytes of the lone call -- and three with solver parameters for another particle count, whose batch mates must not
+    fail with them: every bad call raises ITS message, every good call succeeds."""
+    import threading
+    from iif_amd.native_host import Belief, clique_solve
+    N = 64
+    fg = iif.generateChainEuclid(4, vardims=2, priorEvery=2, N=N)
+    f = fg.getFactor(fg.ls("x0")[0])
+    rng = np.random.default_rng(5)
+    start = {v: (rng.normal(size=(N, 2)) + i, np.full(2, 0.5)) for i, v in enumerate(("x0", "x1"))}
+
+    def fresh():
+        return {v: Belief(abi.EUCLID2, p.copy(), b.copy()) for v, (p, b) in start.items()}
+
+    def call(be, sp, seed):
+        bel = fresh()
+        clique_solve(be, sp, 1, ["x0", "x1"], 1, 1, [abi.EUCLID2] * 2, [f], bel, seed, lists={"itervar": ["x0"]})
+        return bel["x0"].pts.copy(), np.asarray(bel["x0"].bw).copy()
+
+    be = hip_backend(N, 256)
+    try:
+        lone = {seed: call(be, fg.solverParams, seed) for seed in range(1, 6)}
+        other = iif.SolverParams(N=32)
+        problems, rounds = [], 25
+
+        def good(seed):
+            for _ in range(rounds):
+                p, b = call(be, fg.solverParams, seed)
+                if not (np.array_equal(p, lone[seed][0]) and np.array_equal(b, lone[seed][1])):
+                    problems.append(f"seed {seed}: a merged call's result is not the lone call's")
+
+        def bad():
+            for _ in range(rounds):
+                try:
+                    call(be, other, 9)
+                    problems.append("a call with parameters for N = 32 on a context for N = 64 was accepted")
+                except ValueError as e:
+                    if "created for N" not in str(e):
+                        problems.append(f"a bad call raised somebody else's message: {e}")
+
+        threads = [threading.Thread(target=good, args=(s,)) for s in range(1, 6)] + [threading.Thread(target=bad) for _ in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not problems, problems[:5]
+    finally:
+        be.close()
