@@ -625,13 +625,23 @@ struct objective_t {
 // 2, 1/2, 1/2 and the centroid is a + b: any order and any contraction is the same search bit for bit.  The CPU checker runs
 // the same search from the same start and ends on the same bits (tests/test_gpu_stagewise_parity.py); what it costs is in
 // profiles/r06_nm_optim_order.txt.
-template <int DN, bool OPT>
-__device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1], int i) {
-  const bool sw = f[i] < f[i - 1];
+// TB: ties broken by slot (true), or ties only NOTICED (false: `tied` is set when two values compared equal, and the caller
+// runs the search again with TB -- two dimensions, where nothing else needs the slots and carrying them through every
+// compare-exchange cost config 2's proposals 18 %: profiles/r06_nm_tie_order.txt)
+template <int DN, bool OPT, bool TB>
+__device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1], int i, bool &tied) {
+  // the order is Optim's sortperm!(i_order, f_simplex): by value, EQUAL VALUES BY THEIR SLOT in the simplex array (Base's Perm
+  // ordering breaks ties by index).  Ties do not happen between the values of a search that is converging; they do when a
+  // search stalls with an objective of ~1e8 (a pose 1e4 away from its start): the values sit on a lattice of 1.5e-8 there, two
+  // vertices tie, and which of them counts as the worst decides the rest of the search -- one particle of 29 136 fuzzed
+  // proposals ended 0.1 from the oracle's before the slots broke the ties (tools/exp/fuzz_proposals.py, seed 19).
+  bool sw = f[i] < f[i - 1];
+  if constexpr (TB) sw = sw || (f[i] == f[i - 1] && id[i] < id[i - 1]);
+  else tied = tied || (f[i] == f[i - 1]);
   const double fa = f[i - 1], fb = f[i];
   f[i - 1] = sw ? fb : fa;
   f[i] = sw ? fa : fb;
-  if (DN > 2) {  // the vertex's place in Optim's simplex array travels with it (nm_centroid)
+  if (DN > 2 || TB) {  // the vertex's place in Optim's simplex array travels with it (ties; nm_centroid in three dimensions)
     const int ia = id[i - 1], ib = id[i];
     id[i - 1] = sw ? ib : ia;
     id[i] = sw ? ia : ib;
@@ -643,17 +653,17 @@ __device__ __forceinline__ void nm_cswap(double (&sx)[DN + 1][DN], double (&f)[D
     sx[i][d] = sw ? a : b;
   }
 }
-template <int DN, bool OPT>
-__device__ __forceinline__ void nm_sort_all(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1]) {
+template <int DN, bool OPT, bool TB>
+__device__ __forceinline__ void nm_sort_all(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1], bool &tied) {
 #pragma unroll
   for (int pass = 0; pass < DN; pass++)
 #pragma unroll
-    for (int i = DN; i >= 1 + pass; i--) nm_cswap<DN, OPT>(sx, f, id, i);
+    for (int i = DN; i >= 1 + pass; i--) nm_cswap<DN, OPT, TB>(sx, f, id, i, tied);
 }
-template <int DN, bool OPT>
-__device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1]) {
+template <int DN, bool OPT, bool TB>
+__device__ __forceinline__ void nm_sift_last(double (&sx)[DN + 1][DN], double (&f)[DN + 1], int (&id)[DN + 1], bool &tied) {
 #pragma unroll
-  for (int i = DN; i >= 1; i--) nm_cswap<DN, OPT>(sx, f, id, i);
+  for (int i = DN; i >= 1; i--) nm_cswap<DN, OPT, TB>(sx, f, id, i, tied);
 }
 // Optim's centroid!(c, simplex, h): the vertices other than the worst summed IN THE ORDER THE SIMPLEX ARRAY HOLDS THEM
 // (a replaced vertex keeps the slot of the one it replaces), then rmul!(c, 1/n).  The simplex here is physically sorted
@@ -731,8 +741,8 @@ __device__ __forceinline__ double nm_lin(double a, double c, double b) {
 }
 
 // OPT: the form of the 3-D centroid (nm_centroid): sums taken and selected (true) or elements selected and summed (false)
-template <class OBJ, int DN, bool OPT = true>
-__device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
+template <class OBJ, int DN, bool OPT, bool TB>
+__device__ __forceinline__ bool nelder_mead_tb(OBJ &o, double (&x)[DN], bool &tied) {
   constexpr int M = DN + 1;
   const double alpha = 1.0, beta = 1.0 + 2.0 / DN, gamma = 0.75 - 1.0 / (2.0 * DN), delta = 1.0 - 1.0 / DN;
   double sx[M][DN], f[M];
@@ -747,7 +757,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
   for (int j = 0; j < DN; j++) sx[j + 1][j] = nm_lin<OPT>(0.025, 1.0 + 0.5, sx[j + 1][j]);
 #pragma unroll
   for (int i = 0; i < M; i++) f[i] = o(sx[i]);
-  nm_sort_all<DN, OPT>(sx, f, id);
+  nm_sort_all<DN, OPT, TB>(sx, f, id, tied);
   bool converged = nm_converged<DN>(f);
   int it = 0;
 #ifdef NBP_X_NMNOUNROLL
@@ -779,7 +789,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
 #pragma unroll
     for (int d = 0; d < DN; d++) sx[DN][d] = shrink ? sx[DN][d] : (take2 ? xcache[d] : xr[d]);
     f[DN] = shrink ? f[DN] : (take2 ? f2 : f_reflect);
-    nm_sift_last<DN, OPT>(sx, f, id);  // leaves a sorted simplex (the shrinking lanes') as it is
+    nm_sift_last<DN, OPT, TB>(sx, f, id, tied);  // leaves a sorted simplex (the shrinking lanes') as it is
     if (shrink) {
 #pragma unroll
       for (int q = 1; q < M; q++) {
@@ -787,7 +797,7 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
         for (int d = 0; d < DN; d++) sx[q][d] = nm_lin<OPT>(sx[0][d], delta, sx[q][d] - sx[0][d]);
         f[q] = o(sx[q]);
       }
-      nm_sort_all<DN, OPT>(sx, f, id);
+      nm_sort_all<DN, OPT, TB>(sx, f, id, tied);
     }
     converged = nm_converged<DN>(f);
   }
@@ -799,6 +809,34 @@ __device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
 #pragma unroll
   for (int d = 0; d < DN; d++) x[d] = usec ? xc[d] : sx[0][d];
   return converged;
+}
+
+// The search with Optim's order of equal values (nm_cswap).  Three dimensions: the slots travel anyway (nm_centroid) and break
+// the ties where they are compared.  Two dimensions: the search runs without the slots and only notices a tie; the one search
+// in tens of thousands that sees one starts again from its start with them (the evaluations counted are those of the search
+// that stands).
+template <class OBJ, int DN, bool OPT = true>
+__device__ __forceinline__ bool nelder_mead(OBJ &o, double (&x)[DN]) {
+  bool tied = false;
+#ifdef NBP_X_NOTIEBREAK
+  return nelder_mead_tb<OBJ, DN, OPT, false>(o, x, tied);
+#else
+  if constexpr (DN != 2) return nelder_mead_tb<OBJ, DN, OPT, true>(o, x, tied);
+  else {
+    double x0[DN];
+#pragma unroll
+    for (int d = 0; d < DN; d++) x0[d] = x[d];
+    const unsigned int e0 = o.evals;
+    bool conv = nelder_mead_tb<OBJ, DN, OPT, false>(o, x, tied);
+    if (tied) {
+#pragma unroll
+      for (int d = 0; d < DN; d++) x[d] = x0[d];
+      o.evals = e0;
+      conv = nelder_mead_tb<OBJ, DN, OPT, true>(o, x, tied);
+    }
+    return conv;
+  }
+#endif
 }
 
 // Optim.BFGS for a 1-D decision variable (islen1 branch), central finite differences,
