@@ -91,4 +91,5 @@ def main():
     print(f"fuzz_products: {total - nbad} of {total} product outputs bit-identical to the oracle ({nbad} differ)")
 
 
-main()
+if __name__ == "__main__":
+    main()

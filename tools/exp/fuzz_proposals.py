@@ -119,4 +119,5 @@ def main():
     print(f"fuzz_proposals: {total - nbad} of {total} proposal outputs bit-identical to the oracle ({nbad} differ)")
 
 
-main()
+if __name__ == "__main__":
+    main()
