@@ -27,6 +27,7 @@ def load(name):
 
 def test_the_launch_in_which_a_stalled_search_compared_equal_vertex_values():
     fz = load("fuzz_proposals")
+    fz.SHORT = False  # (the generator's stream of the run that found it: every belief with N points)
     n, bad = fz.run_launch(1000 * 19 + 400, 300, 400, fz.KINDS[4], True)  # seed 19's 400 plain SE(2) proposals: op 358
     assert n == 400 and not bad, bad[:3]
 
@@ -47,3 +48,12 @@ def test_random_product_launches_are_the_oracles(seed):
     for B, man in ((90, None), (1, None), (90, fz.MANS[seed % 5]), (400, fz.MANS[1 + seed % 4])):
         n, bad = fz.run_launch(900000 + 7000 * seed + B, N, B, man)
         assert n == B and not bad, (B, man, bad[:3])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_deconvolutions_are_the_oracles(seed):
+    fz = load("fuzz_proposals")
+    N = [64, 200, 257, 300][seed % 4]
+    for B in (1, 120):
+        n, bad = fz.run_deconv_launch(300000 + 10 * seed + B, N, B)
+        assert n == B and not bad, (B, bad[:3])

@@ -1,7 +1,7 @@
 """Differential fuzz of the proposal kernels against the oracle, BIT FOR BIT: launches of random proposal descriptors -- factor
 kinds x manifolds x the variable solved for x nullhypo x mixtures x multihypo (door sightings) x partial masks x inflation cycles
 and spread x measurement noise from 1e-3 to 3 x beliefs centred at 0 / 100 / -1e4 with spreads from 1e-3 to 3 (on the circle: all
-the way round, the lifted and the walked geodesic means) -- in MIXED launches (the generic kernel), in uniform ones of 1 / 40 /
+the way round, the lifted and the walked geodesic means), one input belief in seven with fewer points than the slot -- in MIXED launches (the generic kernel), in uniform ones of 1 / 40 /
 1200 proposals (the single-manifold workgroup kernels, the one-wave-per-proposal kernels), at N = 64 / 200 / 257 / 300; every
 output's points (raw rows), bandwidths and hypothesis indices compared with np.array_equal.
 usage (GPU box): fuzz_proposals.py [seeds=6] [first seed=0]"""
@@ -12,6 +12,7 @@ import numpy as np
 from parity_utils import abi, iif, rand_points, relative_factor_desc
 from oracle.oracle_backend import OracleBackend
 
+SHORT = os.environ.get("FUZZ_SHORT", "1") != "0"  # some input beliefs with fewer points than N (FUZZ_SHORT=0: none)
 KINDS = [("lin1", abi.F_LINREL, abi.EUCLID1), ("lin2", abi.F_LINREL, abi.EUCLID2), ("lin3", abi.F_LINREL, abi.EUCLID3),
          ("circ", abi.F_CIRCULAR, abi.CIRCULAR), ("se2", abi.F_SE2, abi.SE2), ("dist2", abi.F_EUCLIDDIST, abi.EUCLID2),
          ("dist3", abi.F_EUCLIDDIST, abi.EUCLID3), ("prior1", abi.F_PRIOR, abi.EUCLID1), ("prior2", abi.F_PRIOR, abi.EUCLID2),
@@ -23,7 +24,10 @@ def belief(rng, man, N):
     spread = float(rng.choice([1e-3, 0.05, 0.3, 3.0]))
     if man in (abi.CIRCULAR, abi.SE2):
         center = float(rng.uniform(-3, 3)) if man == abi.CIRCULAR else center
-    return rand_points(rng, man, N, center, spread)
+    pts = rand_points(rng, man, N, center, spread)
+    if SHORT and rng.random() < 0.15:  # a belief that holds fewer points than the slot (a density of its own count: its bandwidth rides along)
+        pts = pts[:int(rng.integers(max(8, N // 3), N))]
+    return pts
 
 
 def make_case(rng, name, kind, man, slots, out_slot, side_off, N, simple):
@@ -80,7 +84,10 @@ def run_launch(seed, N, B, which, simple):
         be = make()
         try:
             for sl, man, pts in writes:
-                be.slot_write(sl, man, pts)
+                if pts.shape[0] == N:
+                    be.slot_write(sl, man, pts)
+                else:
+                    be.belief_write(sl, man, pts, np.full(abi.MANIFOLD_DIM[man], 0.1))
             be.run_proposals(descs)
             res.append(([be.slot_read(o, abi.EUCLID3) for o, _, _, _ in outs], be.side_read(0, B * N)))
         finally:
@@ -95,6 +102,45 @@ def run_launch(seed, N, B, which, simple):
                        f"inflation {d.inflation}: {int((dp > 0).any(axis=1).sum())} of {N} particles differ (max {np.nanmax(dp):.3e}), bandwidths by "
                        f"{np.abs(np.asarray(po[j][1]) - np.asarray(ph[j][1])).max():.3e}, hypothesis indices {int((so[j * N:(j + 1) * N] != sh[j * N:(j + 1) * N]).sum())} differ"
                        f"{', NaN in the oracle' if not np.isfinite(po[j][0]).all() else ''}")
+    return len(outs), bad
+
+
+def run_deconv_launch(seed, N, B):
+    """approxDeconv of B random relative factors (plain: the closed set of DeconvUtils.jl) + manikde! of the predicted
+    measurements on the variable's manifold: predicted and sampled measurements (raw rows) and bandwidths, bit for bit"""
+    rng = np.random.default_rng(seed)
+    rel = [k for k in KINDS if k[1] != abi.F_PRIOR]
+    descs, writes, outs, s = [], [], [], 0
+    for j in range(B):
+        name, kind, man = rel[int(rng.integers(0, len(rel)))]
+        d, used = make_case(rng, name, kind, man, [s, s + 1, s + 2, s + 3], s + 4, -1, N, True)
+        d.mhidx_out = -1
+        for k in range(2):
+            writes.append((s + k, man, belief(rng, man, N)))
+        descs.append(d); outs.append((s + 4, s + 3, man, name, d))
+        s += 5
+    res = []
+    for make in (lambda: OracleBackend(N, s + 1, 0, threads=32), lambda: iif.HipBackend(N, s + 1, side_ints=0)):
+        be = make()
+        try:
+            for sl, man, pts in writes:
+                if pts.shape[0] == N:
+                    be.slot_write(sl, man, pts)
+                else:
+                    be.belief_write(sl, man, pts, np.full(abi.MANIFOLD_DIM[man], 0.1))
+            be.run_deconv(descs, [m for _, m, _, _, _ in outs])
+            be.run_bandwidth([o for o, _, _, _, _ in outs], [man for _, _, man, _, _ in outs])
+            res.append([(be.slot_read(o, abi.EUCLID3), be.slot_read(m, abi.EUCLID3)[0]) for o, m, _, _, _ in outs])
+        finally:
+            be.close()
+    bad = []
+    for j, (o, m, man, name, d) in enumerate(outs):
+        (po, bo), mo = res[0][j]
+        (ph, bh), mh = res[1][j]
+        if not (np.array_equal(po, ph) and np.array_equal(np.asarray(bo), np.asarray(bh)) and np.array_equal(mo, mh)):
+            dp = np.abs(po - ph)
+            bad.append(f"    deconv {j} {name} sfidx {d.sfidx}: {int((dp > 0).any(axis=1).sum())} of {N} predicted measurements differ (max {np.nanmax(dp):.3e}), "
+                       f"bandwidths by {np.abs(np.asarray(bo) - np.asarray(bh)).max():.3e}, sampled measurements {'differ' if not np.array_equal(mo, mh) else 'equal'}")
     return len(outs), bad
 
 
@@ -114,6 +160,12 @@ def main():
             n, bad = run_launch(1000 * seed + B, N, B, which, simple)
             total += n; nbad += len(bad)
             print(f"seed {seed} N={N}: {what}: {n - len(bad)} of {n} outputs bit-identical", flush=True)
+            for b in bad[:6]:
+                print(b, flush=True)
+        for B in (1, 120):
+            n, bad = run_deconv_launch(77000 + 10 * seed + B, N, B)
+            total += n; nbad += len(bad)
+            print(f"seed {seed} N={N}: approxDeconv of {B} random relative factors + the fit of the predicted measurements: {n - len(bad)} of {n} outputs bit-identical", flush=True)
             for b in bad[:6]:
                 print(b, flush=True)
     print(f"fuzz_proposals: {total - nbad} of {total} proposal outputs bit-identical to the oracle ({nbad} differ)")

@@ -1,3 +1,7 @@
+# the proposal the fuzz found (tools/exp/fuzz_proposals.py seed 19, op 358 of 400 plain SE(2) proposals, N = 300), alone, by number of inflation cycles
+# usage (GPU box): GPU=1 python tools/exp/repro/fuzz_se2_op358.py
+import os
+os.environ['FUZZ_SHORT'] = '0'  # the generator's stream of the run that found it
 import sys, os
 sys.argv=['x']
 src=open('/root/repo/tools/exp/fuzz_proposals.py').read().replace("\nmain()\n","\n")
