@@ -57,3 +57,14 @@ def test_random_deconvolutions_are_the_oracles(seed):
     for B in (1, 120):
         n, bad = fz.run_deconv_launch(300000 + 10 * seed + B, N, B)
         assert n == B and not bad, (B, bad[:3])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_whole_solves_of_random_graphs_on_every_manifold_are_the_oracles(seed):
+    """tools/exp/fuzz_graphs.py: all five manifolds (tests/test_gpu_random_graphs.py draws from three), odometry steps up to
+    1000 and priors at 1e4, joint messages on every third graph; 660 such solves in profiles/r06_fuzz_graphs.txt"""
+    fz = load("fuzz_graphs")
+    info, res, why = fz.solve_pair(seed)
+    assert res is not None, why
+    nv, differ, worst, finite = res
+    assert finite and not differ, (info, differ[:5], worst)

@@ -1,0 +1,109 @@
+"""Differential fuzz of WHOLE SOLVES (graph initialisation, up pass, down pass) against the oracle, bit for bit: random sparse
+graphs on all five manifolds -- a spanning tree of relative factors with loop closures, extra priors, multihypo sightings,
+mixtures, nullhypo, EuclidDistance ranges, partial priors, marginalized variables -- with measurement noise from 1e-2 to 1, odometry
+steps from 1 to 1000 (priors that put a graph at 1e4: the badly scaled inputs the op fuzz found the tie order with), N = 64 / 100,
+gibbsIters 1 .. 4, joint messages on every third graph.  The HIP backend under the native host's schedule, the oracle under the
+Python mirror's; every variable's points and bandwidths compared with np.array_equal.
+usage (GPU box): fuzz_graphs.py [seeds=40] [first seed=0]"""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+from parity_utils import abi, iif
+from oracle.oracle_backend import OracleBackend
+
+
+def random_graph(seed):
+    r = np.random.default_rng(seed)
+    kind = int(r.integers(0, 5))
+    step = float(r.choice([1.0, 1.0, 30.0, 1000.0]))
+    sig = float(r.choice([0.01, 0.1, 1.0]))
+    far = float(r.choice([0.0, 0.0, 100.0, 1e4]))
+    if kind == 0:
+        vt = iif.ContinuousScalar
+        rel = lambda: iif.LinearRelative(iif.Normal(step, sig))
+        pri = lambda: iif.Prior(iif.Normal(far, 10 * sig))
+    elif kind == 1:
+        vt = iif.ContinuousEuclid(2)
+        rel = lambda: iif.LinearRelative(iif.MvNormal([step, 0.1 * step], [sig, sig]))
+        pri = lambda: iif.Prior(iif.MvNormal([far, -far], [10 * sig, 10 * sig]))
+    elif kind == 2:
+        vt = iif.ContinuousEuclid(3)
+        rel = lambda: iif.LinearRelative(iif.MvNormal([step, 0.0, -0.5 * step], [sig, sig, sig]))
+        pri = lambda: iif.Prior(iif.MvNormal([far, 0.0, -far], [10 * sig, 10 * sig, 10 * sig]))
+    elif kind == 3:
+        vt = iif.Circular
+        rel = lambda: iif.CircularCircular(iif.Normal(0.3, min(sig, 0.3)))
+        pri = lambda: iif.PriorCircular(iif.Normal(float(r.uniform(-3, 3)), 0.2))
+    else:
+        vt = iif.SpecialEuclidean2
+        rel = lambda: iif.ManifoldFactor(iif.MvNormal([step, 0.1 * step, 0.2], [sig, sig, 0.1 * min(sig, 0.5)]))
+        pri = lambda: iif.ManifoldPrior(np.array([far, -far, 0.3]), iif.MvNormal(np.zeros(3), [10 * sig, 10 * sig, 0.05]))
+    n = int(r.integers(4, 36))
+    fg = iif.initfg(iif.SolverParams(N=int(r.choice([64, 100])), gibbsIters=int(r.integers(1, 5))))
+    fg.solverParams.useMsgLikelihoods = seed % 3 == 1
+    for i in range(n):
+        iif.addVariable(fg, f"v{i}", vt)
+    iif.addFactor(fg, ["v0"], pri())
+    for i in range(1, n):
+        j = int(r.integers(max(0, i - 6), i))
+        nh = 0.1 if r.random() < 0.15 else 0.0
+        if kind == 0 and r.random() < 0.15:
+            iif.addFactor(fg, [f"v{j}", f"v{i}"], iif.Mixture(iif.LinearRelative, (iif.Normal(step, sig), iif.Normal(2 * step, 5 * sig)), [0.7, 0.3]))
+        else:
+            iif.addFactor(fg, [f"v{j}", f"v{i}"], rel(), nullhypo=nh)
+    for _ in range(int(r.integers(0, n // 3 + 1))):
+        a, b, c = (int(x) for x in r.choice(n, size=3, replace=False))
+        u = r.random()
+        if u < 0.35:
+            iif.addFactor(fg, [f"v{a}", f"v{b}"], rel())
+        elif u < 0.5:
+            iif.addFactor(fg, [f"v{a}"], pri())
+        elif u < 0.6 and kind in (1, 2):
+            iif.addFactor(fg, [f"v{a}", f"v{b}"], iif.EuclidDistance(iif.Normal(abs(step) * abs(a - b) * 0.5 + 1.0, sig)))
+        elif u < 0.7 and kind in (1, 2):
+            iif.addFactor(fg, [f"v{a}"], iif.PartialPrior(vt, iif.Normal(far, 10 * sig), (int(r.integers(1, 3 if kind == 1 else 4)),)))
+        elif kind in (0, 1, 3):
+            iif.addFactor(fg, [f"v{a}", f"v{b}", f"v{c}"], rel(), multihypo=[1.0, 0.5, 0.5])
+    if r.random() < 0.3:
+        fg.getVariable(f"v{int(r.integers(0, n))}").ismargin = True
+    return fg, dict(kind=kind, n=n, step=step, sig=sig, far=far, N=fg.solverParams.N, joint=fg.solverParams.useMsgLikelihoods)
+
+
+def solve_pair(seed):
+    (fa, info), (fb, _) = random_graph(seed), random_graph(seed)
+    order = iif.nestedDissectionOrder(fa)
+    try:
+        iif.solveTree(fa, eliminationOrder=order, backend=lambda n, s, side_ints=0: OracleBackend(n, s, side_ints, threads=32), seed=seed)
+    except ValueError as e:
+        return info, None, f"not solved ({str(e)[:80]})"
+    iif.solveTree(fb, eliminationOrder=order, backend=lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints), seed=seed)
+    differ = [v for v in fa.ls() if not (np.array_equal(fa.getVal(v), fb.getVal(v)) and np.array_equal(np.asarray(fa.getVariable(v).bw), np.asarray(fb.getVariable(v).bw)))]
+    worst = max((float(np.abs(fa.getVal(v) - fb.getVal(v)).max()) for v in differ), default=0.0)
+    finite = all(np.isfinite(fb.getVal(v)).all() for v in fb.ls())
+    return info, (len(fa.ls()), differ, worst, finite), None
+
+
+def main():
+    nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ok = bad = skipped = 0
+    for seed in range(first, first + nseeds):
+        info, res, why = solve_pair(seed)
+        tag = f"graph {seed} (manifold kind {info['kind']}, {info['n']} variables, N {info['N']}, step {info['step']:g}, noise {info['sig']:g}, prior at {info['far']:g}{', joint messages' if info['joint'] else ''})"
+        if res is None:
+            skipped += 1
+            print(f"{tag}: {why}", flush=True)
+            continue
+        nv, differ, worst, finite = res
+        if differ:
+            bad += 1
+            print(f"{tag}: {len(differ)} of {nv} variables DIFFER from the oracle's (by up to {worst:.3e}){'' if finite else ', non-finite values on the device'}: {differ[:6]}", flush=True)
+        else:
+            ok += 1
+            print(f"{tag}: {nv} of {nv} variables bit-identical", flush=True)
+    print(f"fuzz_graphs: {ok} of {ok + bad} whole solves bit-identical to the oracle's ({bad} differ, {skipped} not solved)")
+
+
+if __name__ == "__main__":
+    main()
