@@ -4,7 +4,7 @@ mixtures, nullhypo, EuclidDistance ranges, partial priors, marginalized variable
 steps from 1 to 1000 (priors that put a graph at 1e4: the badly scaled inputs the op fuzz found the tie order with), N = 64 / 100,
 gibbsIters 1 .. 4, joint messages on every third graph.  The HIP backend under the native host's schedule, the oracle under the
 Python mirror's; every variable's points and bandwidths compared with np.array_equal.
-usage (GPU box): fuzz_graphs.py [seeds=40] [first seed=0]"""
+usage (GPU box): fuzz_graphs.py [seeds=40] [first seed=0] [seam]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -84,12 +84,90 @@ def solve_pair(seed):
     return info, (len(fa.ls()), differ, worst, finite), None
 
 
+def seam_pair(seed):
+    """the same random graph through the PER-CLIQUE entry points (tests/clique_csm.py: one nbp_clique_upsolve / _downsolve per
+    clique, joint messages through nbp_clique_upsolve_joint; and the cliques of a level in one nbp_clique_solve_batch) against the
+    whole-tree resident program, both on the device: the same bytes (an SE(2) belief crosses the host boundary between clique
+    calls as a rotation matrix: 1e-9 there)"""
+    from clique_csm import solve_tree_by_clique_calls, solve_tree_by_clique_calls_joint, solve_tree_by_level_batches
+    hip = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints)
+    (fa, info), (fb, _) = random_graph(seed), random_graph(seed)
+    for f in (fa, fb):
+        iif.initAll(f, backend=hip, seed=seed)
+        f.solverParams.graphinit = False
+    order = iif.nestedDissectionOrder(fa)
+    tree = iif.buildTreeReset(fa, order)
+    try:
+        iif.solveTree(fa, tree=iif.buildTreeReset(fa, order), backend=hip, seed=seed + 7)
+    except ValueError as e:
+        return info, None, f"not solved ({str(e)[:80]})"
+    be = hip(fb.solverParams.N, 2048)
+    try:
+        if info["joint"]:
+            post, _ = solve_tree_by_clique_calls_joint(fb, tree, be, seed + 7)
+            post2, _ = solve_tree_by_clique_calls_joint(fb, tree, be, seed + 7, batched=True)
+        else:
+            post, _ = solve_tree_by_clique_calls(fb, tree, be, seed + 7)
+            post2, _ = solve_tree_by_level_batches(fb, tree, be, seed + 7)
+    finally:
+        be.close()
+    differ, worst = [], 0.0
+    for v in fa.ls():
+        for q in (post, post2):
+            a, b = fa.getVal(v), q[v].pts
+            if info["kind"] != 4:  # the same bytes
+                d = np.abs(a - b).max() if a.shape == b.shape else np.inf
+                db = np.abs(np.asarray(fa.getVariable(v).bw) - np.asarray(q[v].bw)).max()
+                if d > 0 or db > 0:
+                    differ.append(v); worst = max(worst, float(d), float(db))
+            else:
+                # SE(2): between clique calls a belief is the reference's host form, (t, R) -- theta -> (cos, sin) -> atan2 is not
+                # a bitwise round trip, an ulp in a heading moves a 3-D search by 1e-4 and a Gibbs label with it: other draws of
+                # the same posterior.  Held as a distribution: the means of x, y within 0.75 of the spread
+                for k in range(2):
+                    sd = 0.5 * (a[:, k].std() + b[:, k].std()) + 1e-9
+                    d = abs(a[:, k].mean() - b[:, k].mean()) / sd
+                    if d > 0.75:
+                        differ.append(v); worst = max(worst, float(d))
+    return info, (len(fa.ls()), sorted(set(differ)), worst, True), None
+
+
+def perturb_pair(seed):
+    """SE(2) graphs only: the whole-tree program twice on the device, the second time with the heading of every particle of ONE
+    variable moved by one ulp before the solve -- how far apart two solves are that differ by what a belief's trip through its
+    host form (t, R) does to it.  The yardstick for the SE(2) lines of the clique-seam fuzz: same criterion."""
+    hip = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints)
+    (fa, info), (fb, _) = random_graph(seed), random_graph(seed)
+    if info["kind"] != 4:
+        return info, None, "not an SE(2) graph"
+    for f in (fa, fb):
+        iif.initAll(f, backend=hip, seed=seed)
+        f.solverParams.graphinit = False
+    v = fb.getVariable("v1")
+    th = np.arctan2(v.val[:, 3], v.val[:, 2])
+    th2 = np.nextafter(th, np.inf)
+    v.val[:, 2], v.val[:, 3], v.val[:, 4], v.val[:, 5] = np.cos(th2), np.sin(th2), -np.sin(th2), np.cos(th2)
+    order = iif.nestedDissectionOrder(fa)
+    for f in (fa, fb):
+        iif.solveTree(f, tree=iif.buildTreeReset(f, order), backend=hip, seed=seed + 7)
+    differ, worst = [], 0.0
+    for v in fa.ls():
+        a, b = fa.getVal(v), fb.getVal(v)
+        for k in range(2):
+            sd = 0.5 * (a[:, k].std() + b[:, k].std()) + 1e-9
+            d = abs(a[:, k].mean() - b[:, k].mean()) / sd
+            if d > 0.75:
+                differ.append(v); worst = max(worst, float(d))
+    return info, (len(fa.ls()), sorted(set(differ)), worst, True), None
+
+
 def main():
     nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    seam = len(sys.argv) > 3 and sys.argv[3] == "seam"  # third argument "seam": clique calls against the whole-tree program
     ok = bad = skipped = 0
     for seed in range(first, first + nseeds):
-        info, res, why = solve_pair(seed)
+        info, res, why = (perturb_pair if len(sys.argv) > 3 and sys.argv[3] == "perturb" else seam_pair if seam else solve_pair)(seed)
         tag = f"graph {seed} (manifold kind {info['kind']}, {info['n']} variables, N {info['N']}, step {info['step']:g}, noise {info['sig']:g}, prior at {info['far']:g}{', joint messages' if info['joint'] else ''})"
         if res is None:
             skipped += 1
@@ -98,11 +176,11 @@ def main():
         nv, differ, worst, finite = res
         if differ:
             bad += 1
-            print(f"{tag}: {len(differ)} of {nv} variables DIFFER from the oracle's (by up to {worst:.3e}){'' if finite else ', non-finite values on the device'}: {differ[:6]}", flush=True)
+            print(f"{tag}: {len(differ)} of {nv} variables DIFFER (by up to {worst:.3e}){'' if finite else ', non-finite values on the device'}: {differ[:6]}", flush=True)
         else:
             ok += 1
-            print(f"{tag}: {nv} of {nv} variables bit-identical", flush=True)
-    print(f"fuzz_graphs: {ok} of {ok + bad} whole solves bit-identical to the oracle's ({bad} differ, {skipped} not solved)")
+            print(f"{tag}: {nv} of {nv} variables " + ("agree (SE(2): as distributions)" if seam and info["kind"] == 4 else "bit-identical"), flush=True)
+    print(f"fuzz_graphs: {ok} of {ok + bad} " + ("walks by clique calls (single and batched) deliver the whole-tree program's posteriors" if seam else "whole solves bit-identical to the oracle's") + f" ({bad} differ, {skipped} not solved)")
 
 
 if __name__ == "__main__":
