@@ -4,7 +4,7 @@ mixtures, nullhypo, EuclidDistance ranges, partial priors, marginalized variable
 steps from 1 to 1000 (priors that put a graph at 1e4: the badly scaled inputs the op fuzz found the tie order with), N = 64 / 100,
 gibbsIters 1 .. 4, joint messages on every third graph.  The HIP backend under the native host's schedule, the oracle under the
 Python mirror's; every variable's points and bandwidths compared with np.array_equal.
-usage (GPU box): fuzz_graphs.py [seeds=40] [first seed=0] [seam]"""
+usage (GPU box): fuzz_graphs.py [seeds=40] [first seed=0] [seam | perturb | sharded]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -161,13 +161,99 @@ def perturb_pair(seed):
     return info, (len(fa.ls()), sorted(set(differ)), worst, True), None
 
 
+def sharded_pair(seed):
+    """the sharded solve of row (e): the cliques of the graph's tree partitioned over 2 .. 4 ranks (dist_solver.partition_cliques),
+    every rank's program compiled with its ghosts and exchange points, the ranks emulated on ONE GPU (a context each, separator
+    slots carried between the arenas at the exchange points as the RCCL exchange carries them) -- against the one-rank program:
+    every frontal variable on its owner, the same bytes"""
+    import collections
+    from iif_amd.dist_solver import partition_cliques
+    hip = lambda n, s, side_ints=0: iif.HipBackend(n, s, side_ints=side_ints)
+    fg, info = random_graph(seed)
+    iif.initAll(fg, backend=hip, seed=seed)
+    tree = iif.buildTreeReset(fg, iif.nestedDissectionOrder(fg))
+    world = 2 + seed % 3
+    if len(tree.cliques) < world:
+        return info, None, "fewer cliques than ranks"
+    N, RAW = fg.solverParams.N, abi.EUCLID3
+
+    def load(be, tp):
+        for v in fg.ls():
+            var = fg.getVariable(v)
+            be.slot_write(tp.main[v], var.varType.manifold, var.val, var.bw)
+        iif.solver.write_densities(fg, be)
+
+    try:
+        tp = iif.TreeProgram(fg, tree, seed=seed + 3)
+    except ValueError as e:
+        return info, None, f"not compiled ({str(e)[:80]})"
+    be = hip(N, tp.n_slots)
+    load(be, tp)
+    prog = be.program(tp.stages, lazy_bandwidth=True)
+    prog.run(); be.synchronize()
+    ref = {v: be.slot_read(tp.main[v], RAW) for v in fg.ls()}
+    prog.close(); be.close()
+    owner = partition_cliques(tree, world)
+    if len(set(owner.values())) < world:
+        return info, None, "the partition left a rank empty"
+    tps = [iif.TreeProgram(fg, tree, seed=seed + 3, owner=owner, rank=r) for r in range(world)]
+    bes = [hip(N, t.n_slots) for t in tps]
+    progs = []
+    try:
+        for b, t in zip(bes, tps):
+            load(b, t)
+            progs.append(b.program(t.stages, lazy_bandwidth=True))
+        mail = collections.defaultdict(collections.deque)
+        pos, sent = [0] * world, [False] * world
+        for _ in range(100000):
+            progress = False
+            for r, t in enumerate(tps):
+                if pos[r] >= len(t.segments):
+                    continue
+                seg = t.segments[pos[r]]
+                if seg[0] == "run":
+                    if seg[2] > seg[1]:
+                        progs[r].run(seg[1], seg[2])
+                    pos[r] += 1; progress = True
+                    continue
+                if not sent[r]:
+                    bes[r].synchronize()
+                    for peer, slot in seg[1]:
+                        mail[(r, peer)].append(bes[r].slot_read(slot, RAW))
+                    sent[r] = True; progress = True
+                need = collections.Counter(peer for peer, _ in seg[2])
+                if all(len(mail[(q, r)]) >= n for q, n in need.items()):
+                    for peer, slot in seg[2]:
+                        pts, bw = mail[(peer, r)].popleft()
+                        bes[r].slot_write(slot, RAW, pts, bw)
+                    pos[r] += 1; sent[r] = False; progress = True
+            if all(pos[r] >= len(t.segments) for r, t in enumerate(tps)):
+                break
+            if not progress:
+                return info, (len(fg.ls()), ["<the emulated ranks deadlocked>"], float("inf"), True), None
+        differ, worst = [], 0.0
+        for c, r in owner.items():
+            for v in tree.cliques[c].frontalIDs:
+                pts, bw = bes[r].slot_read(tps[r].main[v], RAW)
+                if not (np.array_equal(pts, ref[v][0]) and np.array_equal(np.asarray(bw), np.asarray(ref[v][1]))):
+                    differ.append(v); worst = max(worst, float(np.abs(pts - ref[v][0]).max()))
+        info = dict(info, world=world)
+        return info, (len(fg.ls()), differ, worst, True), None
+    finally:
+        for pr in progs:
+            pr.close()
+        for b in bes:
+            b.close()
+
+
 def main():
     nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     seam = len(sys.argv) > 3 and sys.argv[3] == "seam"  # third argument "seam": clique calls against the whole-tree program
     ok = bad = skipped = 0
     for seed in range(first, first + nseeds):
-        info, res, why = (perturb_pair if len(sys.argv) > 3 and sys.argv[3] == "perturb" else seam_pair if seam else solve_pair)(seed)
+        mode = sys.argv[3] if len(sys.argv) > 3 else ""
+        info, res, why = {"perturb": perturb_pair, "seam": seam_pair, "sharded": sharded_pair}.get(mode, solve_pair)(seed)
         tag = f"graph {seed} (manifold kind {info['kind']}, {info['n']} variables, N {info['N']}, step {info['step']:g}, noise {info['sig']:g}, prior at {info['far']:g}{', joint messages' if info['joint'] else ''})"
         if res is None:
             skipped += 1
