@@ -68,3 +68,14 @@ def test_whole_solves_of_random_graphs_on_every_manifold_are_the_oracles(seed):
     assert res is not None, why
     nv, differ, worst, finite = res
     assert finite and not differ, (info, differ[:5], worst)
+
+
+@pytest.mark.parametrize("seed", [0, 2, 3, 4, 5, 6, 7, 8])
+def test_random_graphs_sharded_over_emulated_ranks_are_the_one_rank_program(seed):
+    """row (e) on graphs nobody drew by hand: 2 .. 4 ranks emulated on one GPU (tools/exp/fuzz_graphs.py sharded_pair; the machinery
+    of tests/test_gpu_sharded_emulation.py on random graphs of every manifold, joint messages on a third of them)"""
+    fz = load("fuzz_graphs")
+    info, res, why = fz.sharded_pair(seed)
+    assert res is not None, why
+    nv, differ, worst, _ = res
+    assert not differ, (info, differ[:5], worst)

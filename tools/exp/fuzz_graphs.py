@@ -266,7 +266,10 @@ def main():
         else:
             ok += 1
             print(f"{tag}: {nv} of {nv} variables " + ("agree (SE(2): as distributions)" if seam and info["kind"] == 4 else "bit-identical"), flush=True)
-    print(f"fuzz_graphs: {ok} of {ok + bad} " + ("walks by clique calls (single and batched) deliver the whole-tree program's posteriors" if seam else "whole solves bit-identical to the oracle's") + f" ({bad} differ, {skipped} not solved)")
+    what = {"seam": "walks by clique calls (single and batched) deliver the whole-tree program's posteriors",
+            "perturb": "SE(2) solves within the criterion of their one-ulp twin",
+            "sharded": "solves sharded over 2 .. 4 emulated ranks deliver the one-rank program's bytes"}.get(sys.argv[3] if len(sys.argv) > 3 else "", "whole solves bit-identical to the oracle's")
+    print(f"fuzz_graphs: {ok} of {ok + bad} {what} ({bad} differ, {skipped} not solved)")
 
 
 if __name__ == "__main__":
