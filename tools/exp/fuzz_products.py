@@ -72,12 +72,15 @@ def run_launch(seed, N, B, man_fixed):
     return len(outs), bad
 
 
+NS = [int(x) for x in os.environ.get("FUZZ_NS", "64,200,257,300").split(",")]  # particle counts by seed (FUZZ_NS=37,129,333,512: others)
+
+
 def main():
     nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     total = nbad = 0
     for seed in range(first, first + nseeds):
-        N = [64, 200, 257, 300][seed % 4]
+        N = NS[seed % len(NS)]
         plans = [("mixed manifolds, 90 products", 90, None), ("mixed manifolds, 12 products", 12, None), ("a lone product", 1, None)]
         plans += [(f"manifold {m}, 90 products", 90, m) for m in MANS]
         plans.append((f"manifold {MANS[1 + seed % 2]}, 700 products", 700, MANS[1 + seed % 2]))

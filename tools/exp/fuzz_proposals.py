@@ -144,12 +144,15 @@ def run_deconv_launch(seed, N, B):
     return len(outs), bad
 
 
+NS = [int(x) for x in os.environ.get("FUZZ_NS", "64,200,257,300").split(",")]  # particle counts by seed (FUZZ_NS=37,129,333,512: others)
+
+
 def main():
     nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     total = nbad = 0
     for seed in range(first, first + nseeds):
-        N = [64, 200, 257, 300][seed % 4]
+        N = NS[seed % len(NS)]
         plans = [("mixed launch of 60 (every kind, every option)", 60, None, False)]
         for w in (KINDS[1], KINDS[2], KINDS[3], KINDS[4]):
             plans.append((f"uniform {w[0]}, 40, every option", 40, w, False))
