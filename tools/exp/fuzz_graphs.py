@@ -13,6 +13,9 @@ from parity_utils import abi, iif
 from oracle.oracle_backend import OracleBackend
 
 
+SIZES = tuple(int(x) for x in os.environ.get("FUZZ_GRAPH_SIZES", "4,36").split(","))  # variables per graph: from, to (FUZZ_GRAPH_SIZES=120,400: levels that fill launches)
+
+
 def random_graph(seed):
     r = np.random.default_rng(seed)
     kind = int(r.integers(0, 5))
@@ -39,7 +42,7 @@ def random_graph(seed):
         vt = iif.SpecialEuclidean2
         rel = lambda: iif.ManifoldFactor(iif.MvNormal([step, 0.1 * step, 0.2], [sig, sig, 0.1 * min(sig, 0.5)]))
         pri = lambda: iif.ManifoldPrior(np.array([far, -far, 0.3]), iif.MvNormal(np.zeros(3), [10 * sig, 10 * sig, 0.05]))
-    n = int(r.integers(4, 36))
+    n = int(r.integers(*SIZES))
     fg = iif.initfg(iif.SolverParams(N=int(r.choice([64, 100])), gibbsIters=int(r.integers(1, 5))))
     fg.solverParams.useMsgLikelihoods = seed % 3 == 1
     for i in range(n):
