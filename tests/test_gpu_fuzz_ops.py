@@ -79,3 +79,17 @@ def test_random_graphs_sharded_over_emulated_ranks_are_the_one_rank_program(seed
     assert res is not None, why
     nv, differ, worst, _ = res
     assert not differ, (info, differ[:5], worst)
+
+
+@pytest.mark.parametrize("seed", [1, 4, 5, 6, 10, 11])
+def test_random_graphs_walked_by_concurrent_single_clique_calls(seed):
+    """the per-clique entry points on random graphs (Euclid(1/2/3), circle; joint messages on seeds 1, 4, 10): one call per clique,
+    and the cliques of a level as CONCURRENT single calls from eight host threads on one context -- merged by the library --
+    against the whole-tree program: the same bytes (tools/exp/fuzz_graphs.py seam_pair, FUZZ_SEAM_THREADS)"""
+    fz = load("fuzz_graphs")
+    fz.THREADS = 8
+    info, res, why = fz.seam_pair(seed)
+    assert res is not None, why
+    assert info["kind"] != 4  # (SE(2) crosses the host boundary as (t, R): held as distributions in the builder's run, not here)
+    nv, differ, worst, _ = res
+    assert not differ, (info, differ[:5], worst)

@@ -13,6 +13,7 @@ from parity_utils import abi, iif
 from oracle.oracle_backend import OracleBackend
 
 
+THREADS = int(os.environ.get("FUZZ_SEAM_THREADS", "0"))  # seam mode: the batched leg as concurrent single calls from this many host threads
 SIZES = tuple(int(x) for x in os.environ.get("FUZZ_GRAPH_SIZES", "4,36").split(","))  # variables per graph: from, to (FUZZ_GRAPH_SIZES=120,400: levels that fill launches)
 
 
@@ -105,7 +106,19 @@ def seam_pair(seed):
     except ValueError as e:
         return info, None, f"not solved ({str(e)[:80]})"
     be = hip(fb.solverParams.N, 2048)
+    import clique_csm
+    real_batch = clique_csm.clique_solve_batch
     try:
+        if THREADS:
+            # the cliques of a level as CONCURRENT single calls on the one context, from a pool of host threads (ctypes releases
+            # the GIL): the library merges them (csrc/nbp_host.cpp clique_solve) -- in place of the batched call
+            from concurrent.futures import ThreadPoolExecutor
+            from iif_amd.native_host import clique_solve
+
+            def threaded(backend, calls):
+                with ThreadPoolExecutor(THREADS) as ex:
+                    return list(ex.map(lambda c: clique_solve(backend, *c[0], **c[1]), calls))
+            clique_csm.clique_solve_batch = threaded
         if info["joint"]:
             post, _ = solve_tree_by_clique_calls_joint(fb, tree, be, seed + 7)
             post2, _ = solve_tree_by_clique_calls_joint(fb, tree, be, seed + 7, batched=True)
@@ -113,6 +126,7 @@ def seam_pair(seed):
             post, _ = solve_tree_by_clique_calls(fb, tree, be, seed + 7)
             post2, _ = solve_tree_by_level_batches(fb, tree, be, seed + 7)
     finally:
+        clique_csm.clique_solve_batch = real_batch
         be.close()
     differ, worst = [], 0.0
     for v in fa.ls():
