@@ -1,4 +1,4 @@
-"""-m gpu: a differential fuzz of the op kernels against the oracle, bit for bit (tools/exp/fuzz_proposals.py, fuzz_products.py).
+"""-m gpu: a differential fuzz of the op kernels against the oracle, bit for bit (tests/fuzz_proposals.py, fuzz_products.py, fuzz_graphs.py; runners of the same names in tools/exp/).
 
 Random descriptors over everything a descriptor can say -- factor kinds x manifolds x the variable solved for x nullhypo x
 mixtures x door-sighting multihypo x partial masks x inflation cycles and spread x measurement noise 1e-3 .. 3 x beliefs at
@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", "exp", name + ".py"))
+    """a fresh copy of tests/<name>.py (the tests set its module-level switches)"""
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -61,7 +62,7 @@ def test_random_deconvolutions_are_the_oracles(seed):
 
 @pytest.mark.parametrize("seed", range(16))
 def test_whole_solves_of_random_graphs_on_every_manifold_are_the_oracles(seed):
-    """tools/exp/fuzz_graphs.py: all five manifolds (tests/test_gpu_random_graphs.py draws from three), odometry steps up to
+    """tests/fuzz_graphs.py: all five manifolds (tests/test_gpu_random_graphs.py draws from three), odometry steps up to
     1000 and priors at 1e4, joint messages on every third graph; 660 such solves in profiles/r06_fuzz_graphs.txt"""
     fz = load("fuzz_graphs")
     info, res, why = fz.solve_pair(seed)
@@ -72,7 +73,7 @@ def test_whole_solves_of_random_graphs_on_every_manifold_are_the_oracles(seed):
 
 @pytest.mark.parametrize("seed", [0, 2, 3, 4, 5, 6, 7, 8])
 def test_random_graphs_sharded_over_emulated_ranks_are_the_one_rank_program(seed):
-    """row (e) on graphs nobody drew by hand: 2 .. 4 ranks emulated on one GPU (tools/exp/fuzz_graphs.py sharded_pair; the machinery
+    """row (e) on graphs nobody drew by hand: 2 .. 4 ranks emulated on one GPU (tests/fuzz_graphs.py sharded_pair; the machinery
     of tests/test_gpu_sharded_emulation.py on random graphs of every manifold, joint messages on a third of them)"""
     fz = load("fuzz_graphs")
     info, res, why = fz.sharded_pair(seed)
@@ -85,7 +86,7 @@ def test_random_graphs_sharded_over_emulated_ranks_are_the_one_rank_program(seed
 def test_random_graphs_walked_by_concurrent_single_clique_calls(seed):
     """the per-clique entry points on random graphs (Euclid(1/2/3), circle; joint messages on seeds 1, 4, 10): one call per clique,
     and the cliques of a level as CONCURRENT single calls from eight host threads on one context -- merged by the library --
-    against the whole-tree program: the same bytes (tools/exp/fuzz_graphs.py seam_pair, FUZZ_SEAM_THREADS)"""
+    against the whole-tree program: the same bytes (tests/fuzz_graphs.py seam_pair, FUZZ_SEAM_THREADS)"""
     fz = load("fuzz_graphs")
     fz.THREADS = 8
     info, res, why = fz.seam_pair(seed)

@@ -4,8 +4,8 @@ import os
 os.environ['FUZZ_SHORT'] = '0'  # the generator's stream of the run that found it
 import sys, os
 sys.argv=['x']
-src=open('/root/repo/tools/exp/fuzz_proposals.py').read().replace("\nmain()\n","\n")
-g={'__file__':'/root/repo/tools/exp/fuzz_proposals.py','__name__':'fz'}
+src=open('/root/repo/tests/fuzz_proposals.py').read().replace("\nmain()\n","\n")
+g={'__file__':'/root/repo/tests/fuzz_proposals.py','__name__':'fz'}
 exec(compile(src,'fz','exec'),g)
 import numpy as np
 abi=g['abi']; iif=g['iif']; OracleBackend=g['OracleBackend']
