@@ -11,6 +11,7 @@ import numpy as np
 from parity_utils import abi, iif, rand_points
 from oracle.oracle_backend import OracleBackend
 
+DUP = os.environ.get("FUZZ_DUP", "0") != "0"  # FUZZ_DUP=1: four source beliefs in ten hold repeated points
 MANS = [abi.EUCLID1, abi.EUCLID2, abi.EUCLID3, abi.CIRCULAR, abi.SE2]
 
 
@@ -26,7 +27,11 @@ def run_launch(seed, N, B, man_fixed):
         for j in range(nsrc):
             spread = float(rng.choice([0.02, 0.3, 1.5]))
             c = (base + 0.2 * j) if man != abi.CIRCULAR else float(rng.uniform(-3, 3))
-            writes.append((s + j, man, rand_points(rng, man, N, c, spread)))
+            pts = rand_points(rng, man, N, c, spread)
+            if DUP and rng.random() < 0.4:  # a belief with REPEATED points (a multinomial resampling without noise): equal keys in the KD sort
+                k = int(rng.integers(1, max(2, N // 2)))
+                pts[rng.choice(N, size=k, replace=False)] = pts[rng.choice(N, size=k)]
+            writes.append((s + j, man, pts))
         s += nsrc
     n_src = s
     descs, outs, side = [], [], 0
