@@ -94,3 +94,15 @@ def test_random_graphs_walked_by_concurrent_single_clique_calls(seed):
     assert info["kind"] != 4  # (SE(2) crosses the host boundary as (t, R): held as distributions in the builder's run, not here)
     nv, differ, worst, _ = res
     assert not differ, (info, differ[:5], worst)
+
+
+@pytest.mark.parametrize("count", [64, 2, 17])
+@pytest.mark.parametrize("man", [1, 2, 3, 4, 5])
+def test_degenerate_beliefs_are_the_oracles_too(man, count):
+    """identical points, clusters 1e6 apart, an offset of 1e8, a spread of 1e-12, three distinct values, 2 or 17 points in a slot
+    of 64 -- through the fit, proposals from and onto the belief, a prior with nullhypo, products of two and three densities
+    (tests/fuzz_degenerate.py; 390 such cases in profiles/r06_fuzz_ops.txt): finite, and the oracle's bits"""
+    fd = load("fuzz_degenerate")
+    for name in ("identical", "two far clusters", "huge offset", "tiny spread", "three values"):
+        bad, finite = fd.run_case(man, 64, count, name, 7 * man + count)
+        assert finite and not bad, (name, bad[:2])
