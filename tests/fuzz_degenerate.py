@@ -1,7 +1,9 @@
 """Differential check of DEGENERATE beliefs, device against oracle, bit for bit (tests/degenerate_inputs.py asks each side only for
 finite results): identical points, two clusters 1e6 apart, an offset of 1e8, a spread of 1e-12, three distinct values, and beliefs
 that hold 2 / 3 / 5 / 17 / 63 / 65 points in a slot of N -- on every manifold, through the fit, a relative proposal from and to the
-belief, a prior proposal, and products of two and three densities.
+belief, a prior proposal, and products of two and three densities.  (FUZZ_NAN=1 adds a belief with one NaN particle: NOT part of the claim -- the bandwidth fit of
+data with a NaN in it is garbage on both sides, different garbage: each side terminates, and a NaN particle stays where it was,
+tests/degenerate_inputs.py.)
 usage (GPU box): python tools/exp/fuzz_degenerate.py   (test infrastructure: drives the oracle)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +12,7 @@ import numpy as np
 from parity_utils import abi, iif, rand_points, relative_factor_desc, product_desc
 from oracle.oracle_backend import OracleBackend
 
+NAN = os.environ.get("FUZZ_NAN", "0") != "0"  # FUZZ_NAN=1: also a belief with one NaN particle (compared NaN for NaN; finiteness not asked)
 REL = {abi.EUCLID1: (abi.F_LINREL, [1.0], [0.1]), abi.EUCLID2: (abi.F_LINREL, [1.0, -0.5], [0.1, 0.2]), abi.EUCLID3: (abi.F_LINREL, [1.0, 0.0, 0.3], [0.1, 0.1, 0.1]),
        abi.CIRCULAR: (abi.F_CIRCULAR, [0.4], [0.05]), abi.SE2: (abi.F_SE2, [1.0, 0.2, 0.3], [0.1, 0.1, 0.01])}
 
@@ -32,7 +35,8 @@ def shapes(rng, man, n):
            "huge offset": base * 0.1 + (1e8 if not circ else 3.0),
            "tiny spread": base * 1e-12 + 0.5,
            "three values": np.array([[0.1] * D, [0.7] * D, [-1.3] * D])[np.arange(n) % 3],
-           "plain": base}
+           "plain": base,
+           "one NaN particle": np.where((np.arange(n) == min(5, n - 1))[:, None], np.nan, base)}
     if man == abi.SE2:  # keep the offsets off the heading
         for k in ("two far clusters", "huge offset"):
             out[k][:, 2] = base[:, 2]
@@ -84,7 +88,7 @@ def main():
             for count in (N, 2, 3, 5, 17, 63, 65):
                 if count > N:
                     continue
-                for name in ("identical", "two far clusters", "huge offset", "tiny spread", "three values", "plain"):
+                for name in ("identical", "two far clusters", "huge offset", "tiny spread", "three values", "plain") + (("one NaN particle",) if NAN else ()):
                     bad, finite = run_case(man, N, count, name, 7 * man + count)
                     total += 1; nbad += bool(bad); nonfinite += not finite
                     if bad or not finite:
