@@ -355,6 +355,8 @@ enum nbp_program_option { NBP_OPT_LAZY_BANDWIDTH = 1, NBP_OPT_GRAPH_REPLAY = 2, 
                           NBP_OPT_ASYNC_UPLOAD = 4 /* (default 0) nbp_program_finalize sends the descriptors stream-ordered from a
                                                       pinned buffer and does not wait: for short-lived programs queued behind
                                                       running ones (the asynchronous clique seam, nbp_host.h) */ };
+/* options are set before nbp_program_finalize; NBP_OPT_GRAPH_REPLAY alone may also be switched afterwards (it is a property of the
+ * runs: graphs already captured stay with the program) */
 nbp_status nbp_program_set_option(nbp_program *prog, int32_t option, int32_t value);
 nbp_status nbp_program_finalize(nbp_program *prog);              /* uploads descriptors        */
 nbp_status nbp_program_run(nbp_program *prog, int32_t first_stage, int32_t last_stage /* excl, -1=all */);
