@@ -560,3 +560,37 @@ def test_fit_of_angles_a_deconvolution_leaves_unwrapped(oracle_backend, hip_back
     assert np.all(bw_raw[:D] > 0)
     # the same KDE: the two fits can only differ through the rounding of the host-side wrap above (an ulp on a few angles)
     np.testing.assert_allclose(bw_raw, bw_wrapped, rtol=0.05)
+
+
+# ---- Nelder-Mead with EQUAL vertex values: Optim's sortperm! orders them by their slot -------------------------------------
+@pytest.mark.parametrize("manifold", [abi.EUCLID2, abi.EUCLID3])
+@pytest.mark.parametrize("N", [200, 300])
+def test_searches_whose_vertices_tie(oracle_backend, hip_backend, manifold, N):
+    """A search whose objective is symmetric in its coordinates -- both beliefs on the diagonal, a noise-free measurement (1, .., 1),
+    no inflation -- starts with vertices 1 and 2 (and 3) at EXACTLY equal values, and meets more ties on its way.  Optim orders
+    equal values by their slot in the simplex array (sortperm!, Base's Perm ordering); so does the oracle; the kernels' physically
+    sorted simplex has to (nm_cswap, csrc/nbp_device.h): in three dimensions the slots travel with the vertices, in two the search
+    notices the tie and runs again with them -- this is the test that makes every 2-D search take that second run.  (Found, in its
+    one natural habitat -- a stalled SE(2) search with an objective of 1e8 -- by the fuzz: profiles/r06_fuzz_ops.txt.)"""
+    D = abi.MANIFOLD_DIM[manifold]
+    rng = np.random.default_rng(40 + D + N)
+    a = np.repeat(rng.normal(size=(N, 1)), D, axis=1)
+    b = np.repeat(rng.normal(size=(N, 1)) + 2.0, D, axis=1)
+    outs = []
+    for sfidx in (0, 1):
+        d = relative_factor_desc(abi.F_LINREL, manifold, 2, sfidx, [0, 1], 2, 500 + sfidx, [1.0] * D, [0.0] * D, inflation=0.0)
+        d.skip_bandwidth = 1
+
+        def setup(be):
+            be.slot_write(0, manifold, a)
+            be.slot_write(1, manifold, b)
+
+        o, h = both(oracle_backend, hip_backend, N, 3, 0, setup, lambda be: be.run_proposals([d]), lambda be: (be.slot_read(2, manifold)[0], be.diag(reset=True)))
+        assert np.array_equal(o[0], h[0]), f"sfidx {sfidx}: {int((o[0] != h[0]).any(axis=1).sum())} of {N} particles differ, by up to {np.abs(o[0] - h[0]).max():.2e}"
+        assert o[1]["residual_evals"] == h[1]["residual_evals"]  # (the evaluations counted are those of the search that stands)
+        outs.append(o[0])
+        # the searches do find the root (x_b = x_a + 1), within Nelder-Mead's own stopping distance
+        want = (a + 1.0) if sfidx == 1 else (b - 1.0)
+        assert np.abs(o[0] - want).max() < 2e-3
+    # ... and the ties DID decide something: a symmetric problem with its ties broken by slot does not stay on the diagonal
+    assert (outs[0][:, 0] != outs[0][:, 1]).any()
